@@ -1,0 +1,207 @@
+/* nsim.h -- C ABI of libnsim_hip.so, the MI355X (gfx950) implementation of the NeuS / StreetSurf
+ * volume-render hot path of PJLab-ADG/neuralsim.
+ *
+ * The reference has no C/FFI plugin interface: its extension mechanism is Python class substitution
+ * (``import_str(cfg.model_class)(**cfg.model_params)``, app/resources/asset_bank.py:129-138) and the
+ * native work sits behind the Python API of the (un-vendored) nr3d_lib.  Every entry point below
+ * therefore names the nr3d_lib Python symbol / reference call site whose native half it replaces; the
+ * binding a maintainer adds is the ctypes stub shown in INTEGRATION.md (neuralsim_amd/_lib.py).
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no C++/torch types; all pointers are DEVICE pointers unless marked host;
+ *   - never allocates, never synchronises; work is enqueued on ``stream`` (a hipStream_t);
+ *   - returns 0 on success, a positive code otherwise (1000 + hipError_t for launch failures,
+ *     1..99 for argument errors); nsim_strerror() explains argument errors;
+ *   - "packed" arrays: ``pack_infos`` is int64 [P,2] = (first index, count) per ray
+ *     (nr3d_lib.graphics.pack_ops.get_pack_infos_from_n; buffer_compose_renderer.py:991).
+ */
+#ifndef NSIM_H
+#define NSIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSIM_MAX_LEVELS 24
+#define NSIM_LOTD_DENSE 0
+#define NSIM_LOTD_HASH 1
+
+/* LoTD level table (host struct, passed by pointer, copied by value into the launch).
+ * nr3d_lib.models.grid_encodings.lotd ``lotd_cfg{lod_res, lod_n_feats, lod_types, hashmap_size}``
+ * (code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:96-101). n_feats is 2 for every level. */
+typedef struct NsimLotdMeta {
+  int32_t num_levels;
+  int32_t n_feats;                     /* must be 2 */
+  int32_t res[NSIM_MAX_LEVELS];        /* vertices per axis */
+  int32_t type[NSIM_MAX_LEVELS];       /* NSIM_LOTD_DENSE | NSIM_LOTD_HASH */
+  uint32_t size[NSIM_MAX_LEVELS];      /* entries (vertices or hash slots) */
+  int64_t offset[NSIM_MAX_LEVELS];     /* offset of the level in the flat param tensor, in scalars */
+} NsimLotdMeta;
+
+/* Occupancy-grid / AABB description (host struct). nr3d_lib.models.accelerations.OccGridAccel +
+ * nr3d_lib.models.spatial.AABBSpace (``accel_cfg{type: occ_grid, resolution: [64,64,64]}``,
+ * lotd_neus.dtu.230814.yaml:140-155). scale = res / (aabb_max - aabb_min). */
+typedef struct NsimOccMeta {
+  float aabb_min[3];
+  float aabb_max[3];
+  float scale[3];
+  int32_t res[3];
+} NsimOccMeta;
+
+const char* nsim_strerror(int code);
+int nsim_version(void);
+
+/* ---------------------------------------------------------------- pack ops (graphics.pack_ops) */
+/* get_pack_infos_from_n(n) ; total (device int64[1], may be NULL) receives sum(n). */
+int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, void* stream);
+/* packed_sum(x [S,C], pack_infos) -> out [P,C]   (single_volume_renderer.py:84-101) */
+int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream);
+/* out[s,c] = x[s,c] (op) per_pack[p, c or 0]; op 0 mul, 1 div, 2 add, 3 sub; x may be NULL (treated as 1 for
+ * mul => broadcast, the backward of packed_sum).  packed_div: single_volume_renderer.py:86 */
+int nsim_packed_binary(const float* x, int C, const float* per_pack, int Cp, const int64_t* pack_infos,
+                       int64_t P, int op, float* out, void* stream);
+/* packed_geq / packed_leq / packed_lt / packed_gt (op 0..3) -> uint8 mask (app/loss/lidar.py:102-110) */
+int nsim_packed_cmp(const float* x, const float* per_pack, const int64_t* pack_infos, int64_t P, int op,
+                    uint8_t* out, void* stream);
+/* packed_matmul(x [S,3], rot [P,3,3]) : out[s] = rot[p] @ x[s] (transpose != 0: rot[p]^T @ x[s], the backward)
+ * (app/renderers/utils.py:25) */
+int nsim_packed_matmul3(const float* x, const float* rot, const int64_t* pack_infos, int64_t P,
+                        int transpose, float* out, void* stream);
+/* packed_sort(x, pack_infos) -> (sorted, GLOBAL indices)  (buffer_compose_renderer.py:1043-1047) */
+int nsim_packed_sort(const float* x, const int64_t* pack_infos, int64_t P, float* sorted,
+                     int64_t* indices, void* stream);
+/* interleave_linstep(start [P], n [P], step): pack_infos = get_pack_infos_from_n(n)  (buffer_compose_renderer.py:1036) */
+int nsim_interleave_linstep(const int64_t* start, const int64_t* pack_infos, int64_t P, int64_t step,
+                            int64_t* out, void* stream);
+/* merge_two_packs_sorted (single_volume_renderer.py:341-344): packs of a / b live on rays slot_a / slot_b
+ * (index into the union ray list, ascending); pack_infos_out [U,2] given (from the summed counts).
+ * a-first on ties. */
+int nsim_merge_two_packs(const float* va, const int64_t* pia, const int64_t* slot_a, int64_t Pa,
+                         const float* vb, const int64_t* pib, const int64_t* slot_b, int64_t Pb,
+                         const int64_t* pack_infos_out, int64_t U, int64_t* pidx_a, int64_t* pidx_b,
+                         void* stream);
+
+/* --------------------------------------------------------------- graphics.nerf / compositing */
+/* packed_alpha_to_vw (single_volume_renderer.py:79-83): vw_i = alpha_i * prod_{j<i}(1-alpha_j+1e-10).
+ * trans (may be NULL) receives the transmittance T_i, saved for the backward. */
+int nsim_alpha_to_vw_fwd(const float* alpha, const int64_t* pack_infos, int64_t P, float* vw, float* trans,
+                         void* stream);
+int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw, const float* dvw,
+                         const int64_t* pack_infos, int64_t P, float* dalpha, void* stream);
+/* Fused SingleVolumeRenderer._volume_integration (single_volume_renderer.py:73-102): alpha -> vw -> mask,
+ * depth (optionally normalised), rgb, normals per ray.  rgb / nrm (and their outputs) may be NULL. */
+int nsim_composite_fwd(const float* alpha, const float* t, const float* rgb, const float* nrm,
+                       const int64_t* pack_infos, int64_t P, int normalized_depth, float* vw, float* trans,
+                       float* mask, float* depth, float* rgb_out, float* nrm_out, void* stream);
+int nsim_composite_bwd(const float* alpha, const float* trans, const float* vw, const float* t,
+                       const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
+                       int normalized_depth, const float* mask, const float* depth, const float* dmask,
+                       const float* ddepth, const float* drgb_out, const float* dnrm_out,
+                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, void* stream);
+/* NeuS sdf -> opacity (NeusRendererMixin): alpha_i for interval (i,i+1), 0 at the
+ * last sample of each pack.  inv_s = exp(ln_inv_s[0] * ln_inv_s_factor) unless forward_inv_s > 0. */
+int nsim_neus_alpha_fwd(const float* sdf, const int64_t* pack_infos, int64_t P, const float* ln_inv_s,
+                        float ln_inv_s_factor, float forward_inv_s, float* alpha, void* stream);
+int nsim_neus_alpha_bwd(const float* sdf, const float* dalpha, const int64_t* pack_infos, int64_t P,
+                        const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, float* dsdf,
+                        float* d_ln_inv_s, void* stream);
+
+/* ------------------------------------------------------------------------------ ray generation */
+/* Camera._get_selected_rays_from_ixy (app/resources/observers/cameras.py:281-310) */
+int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr /*[V,3,3]*/,
+                        const float* c2w /*[V,4,4]*/, const int64_t* WH /*[V,2]*/, int64_t N, int snap,
+                        float* rays_o, float* rays_d, void* stream);
+/* AABBSpace.ray_test (call site single_volume_renderer.py:235-238): far < 0 means "no far". */
+int nsim_aabb_ray_test(const float* rays_o, const float* rays_d, int64_t N, const NsimOccMeta* meta,
+                       float near, float far, float* near_out, float* far_out, uint8_t* hit, void* stream);
+
+/* ------------------------------------------------------------------------ occupancy + sampling */
+/* OccGridEma update (lotd_neus.dtu.230814.yaml:140-155): val = max(val*decay, 4 sig(s sdf)(1-sig)) */
+int nsim_occ_decay(float* val, int64_t nvox, float decay, void* stream);
+int nsim_occ_update(float* val, const float* pts, const float* sdf, int64_t n, const NsimOccMeta* meta,
+                    float inv_s, void* stream);
+int nsim_occ_pack_bits(const float* val, int64_t nvox, float thre, uint32_t* bits, void* stream);
+/* OccGridAccel.ray_march (march_cfg{step_size,max_steps}): lattice t_k = near + (k + jitter) * step */
+int nsim_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                     const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta,
+                     float step, int max_steps, int64_t* counts, void* stream);
+int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                    const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta,
+                    float step, int max_steps, const int64_t* pack_infos, float* t_out, void* stream);
+/* coarse_step_cfg{step_mode: linear}: t = near + (far-near) * ((i + u)/C); jitter_c NULL => u = 0.5 */
+int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C,
+                       float* out, void* stream);
+/* One NeuS up-sampling stage (num_fine[i], upsample_inv_s * factor[i], upsample_use_estimate_alpha).
+ * scratch: float [S]. t_new: [R, n_fine] ascending. */
+int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, void* stream);
+/* Sorted merge of packed (t_a, v_a) with batched (t_b, v_b) [R,nb]; packs must tile the arrays in order.
+ * v_a / v_b / v_out may be NULL. pack_infos_out [R,2] is written. */
+int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
+                      const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
+                      int64_t* pack_infos_out, void* stream);
+
+/* ------------------------------------------------------------------- LoTD encoding (standalone) */
+/* LoTDEncoding.forward / forward_dydx (inspect_rendering.py:468-474): x [S,3] in [-1,1], grid fp16.
+ * out f32 [S, L*2]; dydx (may be NULL) f32 [S, L*2, 3] = d out / d x. */
+int nsim_lotd_fwd(const float* x, const void* grid_f16, const NsimLotdMeta* meta, int64_t S, float* out,
+                  float* dydx, void* stream);
+/* LoTD backward: dgrid (f32 [n_params], accumulated with atomics) += d L/d out . d out/d grid
+ *   + (if dL_ddydx != NULL) d L / d dydx . d dydx / d grid  (the second-order path used by nablas). */
+int nsim_lotd_bwd(const float* x, const float* dL_dout, const float* dL_ddydx, const NsimLotdMeta* meta,
+                  int64_t S, float* dgrid, void* stream);
+
+/* ------------------------------------------------------- fused NeuS field (LoTD + MLPs, MFMA) */
+/* Network description (host struct).  LoTDNeuSModel = LoTDSDF + RadianceNet
+ * (app/models/single/neus.py:24-62; lotd_neus.dtu.230814.yaml:92-139). */
+typedef struct NsimFieldMeta {
+  NsimLotdMeta lotd;     /* must have 16 levels x 2 feats = 32 input features */
+  int32_t sdf_D;         /* hidden layers of the SDF decoder: 1 or 2 (width 64, softplus beta) */
+  int32_t precision;     /* 0: fp16 MFMA (v_mfma_f32_32x32x16_f16), 1: exact f32 MFMA (32x32x2 f32) */
+  float softplus_beta;   /* 100 */
+} NsimFieldMeta;
+
+/* size in bytes of the packed-fragment weight buffer for a given meta */
+int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta);
+/* Re-pack f32 master weights into MFMA A-fragment order (once per optimizer step).
+ * sdf_w: [W1 (64x32), (W2 (64x64)), Wout (1x64)] concatenated row-major; sdf_b likewise [64,(64),1];
+ * rad_w: [Wr1 (64x26), Wr2 (64x64), Wr3 (3x64)], rad_b [64,64,3]. */
+int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b,
+                            const float* rad_w, const float* rad_b, void* wpack, void* stream);
+/* No-grad SDF query (model.query_sdf / forward_sdf; inspect_rendering.py:120-128).
+ * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]]. */
+int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                   int64_t S, float* sdf, void* stream);
+/* With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
+ * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
+ * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902). */
+int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, void* stream);
+/* Backward of nsim_field_fwd given dL/dsdf [S], dL/dnablas [S,3], dL/drgb [S,3] (any may be NULL):
+ * accumulates (atomics) into dgrid f32 [n_params], dsdf_w, dsdf_b, drad_w, drad_b (same layouts as
+ * nsim_field_pack_weights) and, if non-NULL, dh_appear [R,4]. Includes the double-backward terms of
+ * nablas w.r.t. grid and decoder weights (app/loss/eikonal.py:216-251 needs them). */
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* sdf_w,
+                   const float* x, const float* rays_o, const float* rays_d, const float* t,
+                   const int64_t* ridx, const float* h_appear, int64_t S, const float* dsdf,
+                   const float* dnablas, const float* drgb, float* dgrid, float* dsdf_w, float* dsdf_b,
+                   float* drad_w, float* drad_b, float* dh_appear, void* stream);
+
+/* ------------------------------------------------------------------------------- optimizer */
+/* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;
+ * p16 (may be NULL) receives the fp16 copy used by the kernels; grad is scaled by grad_scale and zeroed. */
+int nsim_adam_step(float* p, void* p16, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float bias1, float bias2, float grad_scale, int zero_grad,
+                   void* stream);
+
+/* MFMA layout self-test (tests only): writes D = A(32x16 f16) * B(16x32 f16) with the wrappers used by the
+ * field kernels; a, b given in plain row-major. d is 32x32 f32 row-major. */
+int nsim_selftest_mfma(const float* a, const float* b, float* d, int use_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSIM_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libnsim_hip.so (include/nsim.h) -- the ONLY compute backend of this package.
+
+There is no CPU fallback: if the gfx950 library is missing or an op is given a non-CUDA tensor the call
+raises.  (The pure-PyTorch restatement under ``oracle/`` is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+NSIM_MAX_LEVELS = 24
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libnsim_hip.so"
+
+
+class LotdMeta(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("n_feats", C.c_int32), ("res", C.c_int32 * NSIM_MAX_LEVELS),
+                ("type", C.c_int32 * NSIM_MAX_LEVELS), ("size", C.c_uint32 * NSIM_MAX_LEVELS),
+                ("offset", C.c_int64 * NSIM_MAX_LEVELS)]
+
+
+class OccMeta(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("scale", C.c_float * 3),
+                ("res", C.c_int32 * 3)]
+
+
+class FieldMeta(C.Structure):
+    _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I = C.c_int
+_F = C.c_float
+
+# name -> argtypes (every function additionally takes the trailing ``void* stream`` unless listed in _NOSTREAM)
+SIGNATURES = {
+    "nsim_pack_infos_from_n": [_P, _I64, _P, _P],
+    "nsim_packed_sum": [_P, _I, _P, _I64, _P],
+    "nsim_packed_binary": [_P, _I, _P, _I, _P, _I64, _I, _P],
+    "nsim_packed_cmp": [_P, _P, _P, _I64, _I, _P],
+    "nsim_packed_matmul3": [_P, _P, _P, _I64, _I, _P],
+    "nsim_packed_sort": [_P, _P, _I64, _P, _P],
+    "nsim_interleave_linstep": [_P, _P, _I64, _I64, _P],
+    "nsim_merge_two_packs": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
+    "nsim_alpha_to_vw_fwd": [_P, _P, _I64, _P, _P],
+    "nsim_alpha_to_vw_bwd": [_P, _P, _P, _P, _P, _I64, _P],
+    "nsim_composite_fwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P],
+    "nsim_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_neus_alpha_fwd": [_P, _P, _I64, _P, _F, _F, _P],
+    "nsim_neus_alpha_bwd": [_P, _P, _P, _I64, _P, _F, _F, _P, _P],
+    "nsim_raygen_pinhole": [_P, _P, _P, _P, _P, _I64, _I, _P, _P],
+    "nsim_aabb_ray_test": [_P, _P, _I64, C.POINTER(OccMeta), _F, _F, _P, _P, _P],
+    "nsim_occ_decay": [_P, _I64, _F],
+    "nsim_occ_update": [_P, _P, _P, _I64, C.POINTER(OccMeta), _F],
+    "nsim_occ_pack_bits": [_P, _I64, _F, _P],
+    "nsim_march_count": [_P, _P, _P, _P, _P, _I64, _P, C.POINTER(OccMeta), _F, _I, _P],
+    "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
+    "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],
+    "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P],
+    "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
+    "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],
+    "nsim_lotd_bwd": [_P, _P, _P, C.POINTER(LotdMeta), _I64, _P],
+    "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
+    "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P,
+                       _P, _P],
+    "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
+    "nsim_selftest_mfma": [_P, _P, _P, _I],
+}
+NOSTREAM = {
+    "nsim_strerror": ([_I], C.c_char_p),
+    "nsim_version": ([], _I),
+    "nsim_field_wpack_bytes": ([C.POINTER(FieldMeta)], _I64),
+}
+
+
+def bind(cdll):
+    """Attach argtypes/restype for every symbol of include/nsim.h (raises AttributeError if one is missing)."""
+    for name, args in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.argtypes = list(args) + [_P]
+        fn.restype = _I
+    for name, (args, res) in NOSTREAM.items():
+        fn = getattr(cdll, name)
+        fn.argtypes = list(args)
+        fn.restype = res
+    return cdll
+
+
+_LIB = None
+
+
+def get_lib():
+    """The gfx950 library; raises loudly when it has not been built (``python -m neuralsim_amd.csrc.build``)."""
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"neuralsim_amd: {LIB_PATH} is missing. This package has no CPU fallback -- build the HIP "
+                f"extension with `python -m neuralsim_amd.csrc.build` (needs hipcc, --offload-arch=gfx950).")
+        _LIB = bind(C.CDLL(str(LIB_PATH)))
+    return _LIB
+
+
+def stream_handle() -> int:
+    """Current HIP stream of the current device (ops run on the caller's stream)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t: torch.Tensor, name: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"neuralsim_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    require_device(t, name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"neuralsim_amd: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"neuralsim_amd: {name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def call(name: str, *args):
+    """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code."""
+    lib = get_lib()
+    rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
+    if rc != 0:
+        msg = lib.nsim_strerror(rc)
+        raise RuntimeError(f"{name} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,955 @@
+// field.hip -- the fused NeuS field kernels for gfx950: LoTD gather -> SDF decoder MLP (+ analytic
+// normals) -> radiance MLP, forward and backward (including the second-order terms of the normals), with
+// every dense contraction on the matrix cores.
+//
+// Replaces the native half of nr3d_lib's LoTDNeuSModel.forward_sdf / forward_sdf_nablas / radiance query
+// and their autograd backward (call sites: app/renderers/single_volume_renderer.py:244-246,
+// code_single/tools/inspect_rendering.py:120-128; normals mechanism
+// docs/exps/exp_permuto_3d_modulated.py:63-76; network shapes
+// code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:92-139; second-order requirement
+// app/loss/eikonal.py:216-251).  The executable spec is oracle/field.py.
+//
+// MI355X design (not a translation of any CUDA kernel):
+//  * one 64-lane wave owns a tile of 32 points; lane (j = l&31, hi = l>>5) owns point j and HALF of the
+//    feature / hidden units -- exactly the C/D fragment of v_mfma_f32_32x32x*: register r of M-tile m on
+//    lane-half hi holds unit U(m,r,hi) = 32m + (r&3) + 8(r>>2) + 4hi;
+//  * every layer is computed TRANSPOSED (Out^T[units x points] = W . In^T): weights are the A operand,
+//    activations the B operand.  Because the K slots of A and B are indexed identically by (l>>5, e), a
+//    lane's own accumulator registers ARE its B fragment for the next layer -- the whole
+//    gather -> MLP -> dMLP/dh -> normals -> radiance chain runs in registers, no LDS round trips;
+//  * the lane-half that owns feature U(0,r,hi) also gathers it: each lane gathers 8 of the 16 levels of
+//    its point (64 corner loads of one half2 each) and keeps d feature / d x (48 VGPRs) for the normals;
+//  * weight gradients contract over points, so they (and only they) need a transpose: activations are
+//    staged [unit][point] in LDS (pitch 40 halfs => conflict-free ds_read_b128), multiplied on the MFMA
+//    and accumulated per workgroup in LDS f32 atomics, then flushed once per block with global atomics;
+//  * fp16 MFMA operands are re-scaled per tile by an exact power of two (dyn_scale) so that the tiny
+//    upstream gradients of a volume-render loss do not underflow -- no global loss scaler is required;
+//  * PREC=1 selects v_mfma_f32_32x32x2_f32 (exact f32 at the vector rate) for tight parity tests.
+#include "lotd_dev.h"
+
+// ----------------------------------------------------------------------------------------- layout
+enum { M_W1 = 0, M_W2, M_W2T, M_W1T, M_R1, M_R2, M_R3, M_R3T, M_R2T, M_R1T, M_COUNT };
+enum { V_B1 = 0, V_B2, V_WH, V_RB1, V_RB2, V_RB3, V_SCAL, V_COUNT };
+
+struct FieldLayout {
+  int64_t mat[M_COUNT];  // byte offsets
+  int64_t vec[V_COUNT];
+  int64_t total;
+  int elt;               // bytes per matrix element (2 | 4)
+};
+
+static const int kMatUo[M_COUNT] = {64, 64, 64, 32, 64, 64, 32, 64, 64, 32};
+static const int kMatUi[M_COUNT] = {32, 64, 64, 64, 32, 64, 64, 32, 64, 64};
+
+static inline FieldLayout field_layout(int precision) {
+  FieldLayout L;
+  L.elt = precision == 0 ? 2 : 4;
+  int64_t off = 0;
+  for (int m = 0; m < M_COUNT; ++m) {
+    L.mat[m] = off;
+    off += (int64_t)kMatUo[m] * kMatUi[m] * L.elt;
+  }
+  for (int v = 0; v < V_COUNT; ++v) {
+    L.vec[v] = off;
+    off += 64 * 4;
+  }
+  L.total = off;
+  return L;
+}
+
+// flat f32 master-weight layouts (shared with the gradient buffers)
+struct SrcOff {
+  int w1, w2, wh, b1, b2, bh;   // sdf_w / sdf_b
+  int r1, r2, r3, rb1, rb2, rb3;
+  int n_sdf_w, n_sdf_b, n_rad_w, n_rad_b;
+};
+__host__ __device__ inline SrcOff src_off(int D) {
+  SrcOff o;
+  o.w1 = 0;
+  o.w2 = 2048;
+  o.wh = (D == 2) ? 2048 + 4096 : 2048;
+  o.n_sdf_w = o.wh + 64;
+  o.b1 = 0;
+  o.b2 = 64;
+  o.bh = (D == 2) ? 128 : 64;
+  o.n_sdf_b = o.bh + 1;
+  o.r1 = 0;
+  o.r2 = 64 * 26;
+  o.r3 = 64 * 26 + 4096;
+  o.n_rad_w = o.r3 + 192;
+  o.rb1 = 0;
+  o.rb2 = 64;
+  o.rb3 = 128;
+  o.n_rad_b = 131;
+  return o;
+}
+
+__device__ __forceinline__ int unit_of(int m, int r, int hi) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------------------------ weight packing
+__device__ __forceinline__ float pack_src(int mat, int row, int col, int D, const float* sdf_w, const float* rad_w) {
+  const SrcOff o = src_off(D);
+  switch (mat) {
+    case M_W1: return sdf_w[o.w1 + row * 32 + col];
+    case M_W2: return D == 2 ? sdf_w[o.w2 + row * 64 + col] : 0.f;
+    case M_W2T: return D == 2 ? sdf_w[o.w2 + col * 64 + row] : 0.f;
+    case M_W1T: return sdf_w[o.w1 + col * 32 + row];
+    case M_R1: return col < 26 ? rad_w[o.r1 + row * 26 + col] : 0.f;
+    case M_R2: return rad_w[o.r2 + row * 64 + col];
+    case M_R3: return row < 3 ? rad_w[o.r3 + row * 64 + col] : 0.f;
+    case M_R3T: return col < 3 ? rad_w[o.r3 + col * 64 + row] : 0.f;
+    case M_R2T: return rad_w[o.r2 + col * 64 + row];
+    case M_R1T: return row < 26 ? rad_w[o.r1 + col * 26 + row] : 0.f;
+  }
+  return 0.f;
+}
+
+struct PackDims {
+  int uo[M_COUNT], ui[M_COUNT];
+};
+
+__global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims, int D, const float* __restrict__ sdf_w,
+                                                     const float* __restrict__ sdf_b, const float* __restrict__ rad_w,
+                                                     const float* __restrict__ rad_b, char* __restrict__ wpack) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // matrices: one thread per element
+  int64_t base = 0;
+  for (int m = 0; m < M_COUNT; ++m) {
+    const int Uo = dims.uo[m], Ui = dims.ui[m];
+    const int64_t cnt = (int64_t)Uo * Ui;
+    if (tid >= base && tid < base + cnt) {
+      const int64_t k = tid - base;
+      int row, col;
+      if (L.elt == 2) {
+        const int e = (int)(k & 7), lane = (int)((k >> 3) & 63);
+        const int fs = (int)(k >> 9);
+        const int nS = Ui / 16;
+        const int mo = fs / nS, s = fs % nS;
+        row = 32 * mo + (lane & 31);
+        col = 16 * s + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        ((f16*)(wpack + L.mat[m]))[k] = (f16)pack_src(m, row, col, D, sdf_w, rad_w);
+      } else {
+        const int lane = (int)(k & 63);
+        const int fr = (int)(k >> 6);
+        const int r = fr & 15, fm = fr >> 4;
+        const int nMi = Ui / 32;
+        const int mo = fm / nMi, mi = fm % nMi;
+        row = 32 * mo + (lane & 31);
+        col = unit_of(mi, r, lane >> 5);
+        ((float*)(wpack + L.mat[m]))[k] = pack_src(m, row, col, D, sdf_w, rad_w);
+      }
+      return;
+    }
+    base += cnt;
+  }
+  // vectors: per-lane order [hi][m*16 + r]
+  const int64_t vtid = tid - base;
+  if (vtid >= 0 && vtid < (int64_t)V_COUNT * 64) {
+    const int v = (int)(vtid >> 6), k = (int)(vtid & 63);
+    const int hi = k >> 5, m = (k >> 4) & 1, r = k & 15;
+    const int u = unit_of(m, r, hi);
+    const SrcOff o = src_off(D);
+    float val = 0.f;
+    switch (v) {
+      case V_B1: val = sdf_b[o.b1 + u]; break;
+      case V_B2: val = D == 2 ? sdf_b[o.b2 + u] : 0.f; break;
+      case V_WH: val = sdf_w[o.wh + u]; break;
+      case V_RB1: val = rad_b[o.rb1 + u]; break;
+      case V_RB2: val = rad_b[o.rb2 + u]; break;
+      case V_RB3: val = (u < 3) ? rad_b[o.rb3 + u] : 0.f; break;
+      case V_SCAL: val = (k == 0) ? sdf_b[o.bh] : 0.f; break;
+    }
+    ((float*)(wpack + L.vec[v]))[k] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------- MFMA helpers
+__device__ __forceinline__ void wave_sync_lds() {
+#ifdef NSIM_HOST_EMU
+  emu::wave_barrier();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// exact power-of-two scale bringing the wave-wide max |v| to ~16 (1 when PREC==1 or all-zero)
+template <int PREC, int N>
+__device__ __forceinline__ float dyn_scale(const float (&v)[N]) {
+  if constexpr (PREC == 1) {
+    return 1.0f;
+  } else {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) m = fmaxf(m, fabsf(v[i]));
+    m = wave_max(m);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
+    int ex;
+    frexpf(m, &ex);  // m = f * 2^ex, f in [0.5,1)
+    int k = 4 - ex;
+    k = k > 60 ? 60 : (k < -60 ? -60 : k);
+    return ldexpf(1.0f, k);
+  }
+}
+
+// acc[mo] += W[32mo.., :] . In^T   with In given in activation-register order (NI M-tiles of 16 regs),
+// multiplied by in_scale before the f16 conversion.  Caller multiplies the result by 1/in_scale.
+template <int PREC, int MO, int NI>
+__device__ __forceinline__ void contract(f32x16 (&acc)[MO], const char* wmat, const float (&in)[NI * 16],
+                                         float in_scale) {
+  const int lane = nsim_lane();
+  if constexpr (PREC == 0) {
+    const f16x8* A = reinterpret_cast<const f16x8*>(wmat);
+#pragma unroll
+    for (int s = 0; s < 2 * NI; ++s) {
+      f16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = (f16)(in[(s >> 1) * 16 + 8 * (s & 1) + e] * in_scale);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 * NI + s) * 64 + lane], b, acc[mo]);
+    }
+  } else {
+    const float* A = reinterpret_cast<const float*>(wmat);
+#pragma unroll
+    for (int mi = 0; mi < NI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float b = in[mi * 16 + r];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+          acc[mo] = mfma_32x32x2_f32(A[((mo * NI + mi) * 16 + r) * 64 + lane], b, acc[mo]);
+      }
+    }
+  }
+}
+
+// out[m*16+r] = (W . In^T)[unit(m,r,hi)][pt]
+template <int PREC, int MO, int NI>
+__device__ __forceinline__ void dense(float (&out)[MO * 16], const char* wmat, const float (&in)[NI * 16],
+                                      bool dynamic) {
+  f32x16 acc[MO];
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo) acc[mo] = zero16();
+  const float sc = dynamic ? dyn_scale<PREC, NI * 16>(in) : 1.0f;
+  contract<PREC, MO, NI>(acc, wmat, in, sc);
+  const float inv = 1.0f / sc;
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[mo * 16 + r] = acc[mo][r] * inv;
+}
+
+// ---- LDS staging [unit][point] for the weight-gradient contractions (contract over the tile's 32 points)
+template <int PREC>
+struct StageT {
+  typedef f16 T;
+  static constexpr int PITCH = 40;
+};
+template <>
+struct StageT<1> {
+  typedef float T;
+  static constexpr int PITCH = 33;
+};
+
+template <int PREC, int NM>
+__device__ __forceinline__ void stage(void* st, const float (&v)[NM * 16], float scale) {
+  typedef typename StageT<PREC>::T T;
+  T* p = reinterpret_cast<T*>(st);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[unit_of(m, r, hi) * StageT<PREC>::PITCH + j] = (T)(v[m * 16 + r] * scale);
+}
+
+// C[32mo + row][32no + col] = sum_pt A[32mo+row][pt] * B[32no+col][pt]
+template <int PREC>
+__device__ __forceinline__ f32x16 dw_tile(const void* stA, int mo, const void* stB, int no) {
+  typedef typename StageT<PREC>::T T;
+  constexpr int P = StageT<PREC>::PITCH;
+  const T* a = reinterpret_cast<const T*>(stA);
+  const T* b = reinterpret_cast<const T*>(stB);
+  const int lane = nsim_lane(), i = lane & 31, hi = lane >> 5;
+  f32x16 acc = zero16();
+  if constexpr (PREC == 0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f16x8 av = *reinterpret_cast<const f16x8*>(a + (32 * mo + i) * P + 16 * s + 8 * hi);
+      const f16x8 bv = *reinterpret_cast<const f16x8*>(b + (32 * no + i) * P + 16 * s + 8 * hi);
+      acc = mfma_32x32x16_f16(av, bv, acc);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float av = a[(32 * mo + i) * P + 2 * q + hi];
+      const float bv = b[(32 * no + i) * P + 2 * q + hi];
+      acc = mfma_32x32x2_f32(av, bv, acc);
+    }
+  }
+  return acc;
+}
+
+// accumulate a dW tile into the workgroup accumulator: dst[(32mo+row)*ld + 32no + col]
+__device__ __forceinline__ void dw_flush(float* dst, int ld, int rows, int cols, int mo, int no, const f32x16& acc,
+                                         float unscale) {
+  const int lane = nsim_lane(), col = 32 * no + (lane & 31), hi = lane >> 5;
+  if (col >= cols) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * mo + mfma_row(r, hi);
+    if (row < rows) atomicAdd(&dst[row * ld + col], acc[r] * unscale);
+  }
+}
+
+// dW[rows x cols] += A (NMA m-tiles) (x) B (NMB m-tiles) over the tile's points; db[rows] += rowsum(A)
+template <int PREC, int NMA, int NMB>
+__device__ __forceinline__ void dw_product(void* stA, void* stB, const float (&A)[NMA * 16], const float (&B)[NMB * 16],
+                                           float* dW, int ld, int rows, int cols, float* db) {
+  const float sa = dyn_scale<PREC, NMA * 16>(A), sb = dyn_scale<PREC, NMB * 16>(B);
+  wave_sync_lds();
+  stage<PREC, NMA>(stA, A, sa);
+  stage<PREC, NMB>(stB, B, sb);
+  wave_sync_lds();
+  const float un = 1.0f / (sa * sb);
+#pragma unroll
+  for (int mo = 0; mo < NMA; ++mo)
+#pragma unroll
+    for (int no = 0; no < NMB; ++no) {
+      const f32x16 acc = dw_tile<PREC>(stA, mo, stB, no);
+      dw_flush(dW, ld, rows, cols, mo, no, acc, un);
+    }
+  if (db) {
+    typedef typename StageT<PREC>::T T;
+    const T* a = reinterpret_cast<const T*>(stA);
+    const int lane = nsim_lane();
+    if (lane < NMA * 32 && lane < rows) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += (float)a[lane * StageT<PREC>::PITCH + j];
+      atomicAdd(&db[lane], s / sa);
+    }
+  }
+}
+
+// row sums of an activation (for vector-shaped gradients such as the SDF head weights)
+template <int PREC, int NM>
+__device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16], float* dst, int rows) {
+  const float sa = dyn_scale<PREC, NM * 16>(A);
+  wave_sync_lds();
+  stage<PREC, NM>(stA, A, sa);
+  wave_sync_lds();
+  typedef typename StageT<PREC>::T T;
+  const T* a = reinterpret_cast<const T*>(stA);
+  const int lane = nsim_lane();
+  if (lane < NM * 32 && lane < rows) {
+    float s = 0.f;
+    for (int j = 0; j < 32; ++j) s += (float)a[lane * StageT<PREC>::PITCH + j];
+    atomicAdd(&dst[lane], s / sa);
+  }
+}
+
+// ------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float softplus_b(float z, float beta) {
+  const float bz = z * beta;
+  return bz > 20.f ? z : log1pf(expf(bz)) / beta;
+}
+// sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return -expm1f(-beta * a); }
+
+__device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
+  const float x = d[0], y = d[1], z = d[2];
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// ------------------------------------------------------------------------------------------ kernel
+struct FieldArgs {
+  LotdDev lotd;
+  FieldLayout lay;
+  float beta;
+  const f16* grid;
+  const char* wpack;
+  const float *x, *rays_o, *rays_d, *t;
+  const int64_t* ridx;
+  const float* h_appear;
+  int64_t S;
+  float *sdf, *nablas, *rgb;
+  const float *dsdf, *dnablas, *drgb;
+  float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
+  int has_rgb;
+};
+
+// LDS accumulator layout (floats) for MODE 2
+struct AccOff {
+  int w1, w2, wh, b1, b2, bh, r1, r2, r3, rb1, rb2, rb3, total;
+};
+__host__ __device__ inline AccOff acc_off() {
+  AccOff a;
+  int o = 0;
+  a.w1 = o; o += 64 * 32;
+  a.w2 = o; o += 64 * 64;
+  a.wh = o; o += 64;
+  a.b1 = o; o += 64;
+  a.b2 = o; o += 64;
+  a.bh = o; o += 4;
+  a.r1 = o; o += 64 * 26;
+  a.r2 = o; o += 64 * 64;
+  a.r3 = o; o += 3 * 64;
+  a.rb1 = o; o += 64;
+  a.rb2 = o; o += 64;
+  a.rb3 = o; o += 4;
+  a.total = o;
+  return a;
+}
+
+template <int PREC>
+__host__ __device__ constexpr int stage_bytes_per_wave() {
+  return 2 * 64 * StageT<PREC>::PITCH * (int)sizeof(typename StageT<PREC>::T);
+}
+
+#define FIELD_WAVES 4
+
+template <int PREC, int SDF_D, int MODE>
+__global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
+  NSIM_DYN_SMEM(smem);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  const int wave = (int)(threadIdx.x >> 6);
+  const float beta = a.beta;
+  const char* W = a.wpack;
+  const FieldLayout& L = a.lay;
+
+  float* accum = nullptr;
+  char* stA = nullptr;
+  char* stB = nullptr;
+  const AccOff AO = acc_off();
+  if constexpr (MODE == 2) {
+    accum = reinterpret_cast<float*>(smem);
+    char* stbase = smem + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+    stA = stbase;
+    stB = stbase + stage_bytes_per_wave<PREC>() / 2;
+    for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+    __syncthreads();
+  }
+
+  // per-lane constant vectors (activation-register order)
+  float vb1[32], vwh[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    vb1[k] = reinterpret_cast<const float*>(W + L.vec[V_B1])[hi * 32 + k];
+    vwh[k] = reinterpret_cast<const float*>(W + L.vec[V_WH])[hi * 32 + k];
+  }
+  const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
+
+  const int64_t ntiles = (a.S + 31) / 32;
+  const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
+    const int64_t s = tile * 32 + j;
+    const bool valid = s < a.S;
+    // ---------------------------------------------------------------- point, view dir
+    float xx[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 1.f};
+    int64_t ray = 0;
+    if (valid) {
+      if (a.x) {
+        xx[0] = a.x[3 * s]; xx[1] = a.x[3 * s + 1]; xx[2] = a.x[3 * s + 2];
+        if (a.ridx) ray = a.ridx[s];
+      } else {
+        ray = a.ridx[s];
+        const float tt = a.t[s];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xx[c] = a.rays_o[3 * ray + c] + tt * a.rays_d[3 * ray + c];
+      }
+      if (MODE >= 1 && a.rays_d) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vd[c] = a.rays_d[3 * ray + c];
+      }
+    }
+    // ---------------------------------------------------------------- gather (8 of 16 levels per lane)
+    float h[16];
+    float J[16][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int l = 4 * q + 2 * hi + b;
+        const int R = a.lotd.res[l];
+        const LotdCell c = lotd_cell(xx, R);
+        float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+          float w, dw[3];
+          lotd_corner_w(c, corner, w, dw);
+          const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
+                                          c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
+          float g0, g1;
+          lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
+          f0 = f0 + w * g0;
+          f1 = f1 + w * g1;
+          if (MODE >= 1) {
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+              j0[c3] = j0[c3] + dw[c3] * g0;
+              j1[c3] = j1[c3] + dw[c3] * g1;
+            }
+          }
+        }
+        h[4 * q + 2 * b] = f0;
+        h[4 * q + 2 * b + 1] = f1;
+        if (MODE >= 1) {
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            J[4 * q + 2 * b][c3] = j0[c3] * c.dscale;
+            J[4 * q + 2 * b + 1][c3] = j1[c3] * c.dscale;
+          }
+        }
+      }
+    }
+    // ---------------------------------------------------------------- SDF decoder forward
+    float a1[32];
+    dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vb1[k], beta);
+    float a2[32];  // last hidden activation (== a1 when SDF_D == 1)
+    if constexpr (SDF_D == 2) {
+      dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        a2[k] = softplus_b(a2[k] + reinterpret_cast<const float*>(W + L.vec[V_B2])[hi * 32 + k], beta);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a2[k] = a1[k];
+    }
+    float sdf = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sdf = sdf + vwh[k] * a2[k];
+    sdf = sdf + wave_shfl_xor(sdf, 32);
+    sdf = sdf + b_out;
+    if constexpr (MODE == 0) {
+      if (valid && hi == 0) a.sdf[s] = sdf;
+      continue;
+    }
+    // ---------------------------------------------------------------- d sdf / d h  (the "g chain")
+    float e1[32];  // d sdf / d a1  (only SDF_D == 2)
+    float d1[32];  // d sdf / d z1
+    if constexpr (SDF_D == 2) {
+      float d2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vwh[k];
+      dense<PREC, 2, 2>(e1, W + L.mat[M_W2T], d2, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        e1[k] = vwh[k];
+        d1[k] = sig_from_softplus(a1[k], beta) * vwh[k];
+      }
+    }
+    float g[16];
+    dense<PREC, 1, 2>(g, W + L.mat[M_W1T], d1, false);
+    float nab[3];
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) {
+      float acc = 0.f;
+#pragma unroll
+      for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
+      nab[c3] = acc + wave_shfl_xor(acc, 32);
+    }
+    // ---------------------------------------------------------------- radiance forward
+    float rin[16], r1[32], r2[32], rgbv[3] = {0.f, 0.f, 0.f};
+    if (a.has_rgb) {
+      float sh[16];
+      sh4_eval(vd, sh);
+      float ha[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid && a.h_appear) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ha[c] = a.h_appear[4 * ray + c];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int slot = unit_of(0, r, hi);  // 0-2 x, 3-18 SH, 19-21 nablas, 22-25 appearance, pad
+        float v = 0.f;
+        if (slot < 3) v = xx[slot];
+        else if (slot < 19) v = sh[slot - 3];
+        else if (slot < 22) v = nab[slot - 19];
+        else if (slot < 26) v = ha[slot - 22];
+        rin[r] = v;
+      }
+      dense<PREC, 2, 1>(r1, W + L.mat[M_R1], rin, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        r1[k] = fmaxf(r1[k] + reinterpret_cast<const float*>(W + L.vec[V_RB1])[hi * 32 + k], 0.f);
+      dense<PREC, 2, 2>(r2, W + L.mat[M_R2], r1, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        r2[k] = fmaxf(r2[k] + reinterpret_cast<const float*>(W + L.vec[V_RB2])[hi * 32 + k], 0.f);
+      float o3[16];
+      dense<PREC, 1, 2>(o3, W + L.mat[M_R3], r2, false);
+      // rows 0..2 live on the hi==0 half in registers 0..2; broadcast to both halves
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = o3[c] + reinterpret_cast<const float*>(W + L.vec[V_RB3])[hi * 32 + c];
+        v = 1.0f / (1.0f + expf(-v));
+        v = wave_shfl(v, j);  // value held by lane j (hi == 0)
+        rgbv[c] = v;
+      }
+    }
+    if constexpr (MODE == 1) {
+      if (valid && hi == 0) {
+        a.sdf[s] = sdf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.nablas[3 * s + c] = nab[c];
+        if (a.has_rgb && a.rgb) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a.rgb[3 * s + c] = rgbv[c];
+        }
+      }
+      continue;
+    }
+    // ======================================================================================= backward
+    if constexpr (MODE == 2) {
+      const SrcOff so = src_off(SDF_D);
+      (void)so;
+      float gs = 0.f, gn[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f};
+      if (valid) {
+        if (a.dsdf) gs = a.dsdf[s];
+        if (a.dnablas) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gn[c] = a.dnablas[3 * s + c];
+        }
+        if (a.has_rgb && a.drgb) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gr[c] = a.drgb[3 * s + c];
+        }
+      }
+      // ------------------------------------------------------------ radiance backward
+      if (a.has_rgb) {
+        float dout[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dout[r] = 0.f;
+        if (hi == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
+        }
+        dw_product<PREC, 1, 2>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
+        float dr2[32];
+        dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
+        dw_product<PREC, 2, 2>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
+        float dr1[32];
+        dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
+        dw_product<PREC, 2, 1>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
+        float din[16];
+        dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
+        // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
+        float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
+        gn[0] += v0 + wave_shfl_xor(v0, 32);
+        gn[1] += v1 + wave_shfl_xor(v1, 32);
+        gn[2] += v2 + wave_shfl_xor(v2, 32);
+        // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
+        if (a.dh_appear && valid) {
+          if (hi == 1) {
+            if (din[10] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 0], din[10]);
+            if (din[11] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 1], din[11]);
+          } else {
+            if (din[12] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 2], din[12]);
+            if (din[13] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 3], din[13]);
+          }
+        }
+      }
+      // ------------------------------------------------------------ second-order path through the normals
+      float gh[16];  // dL / dg
+#pragma unroll
+      for (int f = 0; f < 16; ++f) gh[f] = J[f][0] * gn[0] + J[f][1] * gn[1] + J[f][2] * gn[2];
+      float dh1[32];  // dL / d d1  = W1 . gh
+      dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
+      dw_product<PREC, 2, 1>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
+      float dz1[32];
+      float whv[32];  // vector-shaped gradient of the SDF head weights
+      if constexpr (SDF_D == 2) {
+        float eh1[32];  // dL / d e1
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float s1 = sig_from_softplus(a1[k], beta);
+          dz1[k] = dh1[k] * e1[k] * (beta * s1 * (1.0f - s1));
+          eh1[k] = dh1[k] * s1;
+        }
+        float d2[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vwh[k];
+        dw_product<PREC, 2, 2>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
+        float dh2[32];  // dL / d d2 = W2 . eh1
+        dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
+        float dz2[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float s2 = sig_from_softplus(a2[k], beta);
+          whv[k] = dh2[k] * s2 + gs * a2[k];
+          dz2[k] = gs * vwh[k] * s2 + dh2[k] * vwh[k] * (beta * s2 * (1.0f - s2));
+        }
+        dw_product<PREC, 2, 2>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
+        float da1[32];
+        dense<PREC, 2, 2>(da1, W + L.mat[M_W2T], dz2, true);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dz1[k] = dz1[k] + da1[k] * sig_from_softplus(a1[k], beta);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float s1 = sig_from_softplus(a1[k], beta);
+          whv[k] = dh1[k] * s1 + gs * a1[k];
+          dz1[k] = gs * vwh[k] * s1 + dh1[k] * vwh[k] * (beta * s1 * (1.0f - s1));
+        }
+      }
+      rowsum_acc<PREC, 2>(stA, whv, accum + AO.wh, 64);
+      {
+        float v = (hi == 0) ? gs : 0.f;
+        v = wave_sum(v);
+        if (lane == 0 && v != 0.f) atomicAdd(&accum[AO.bh], v);
+      }
+      dw_product<PREC, 2, 1>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
+      float dh[16];
+      dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
+      // ------------------------------------------------------------ scatter to the grid
+      if (valid && a.dgrid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 4 * q + 2 * hi + b;
+            const int R = a.lotd.res[l];
+            const LotdCell c = lotd_cell(xx, R);
+            const int r0 = 4 * q + 2 * b;
+            const float q0[3] = {g[r0] * gn[0] * c.dscale, g[r0] * gn[1] * c.dscale, g[r0] * gn[2] * c.dscale};
+            const float q1[3] = {g[r0 + 1] * gn[0] * c.dscale, g[r0 + 1] * gn[1] * c.dscale,
+                                 g[r0 + 1] * gn[2] * c.dscale};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+              float w, dw[3];
+              lotd_corner_w(c, corner, w, dw);
+              const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
+                                              c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
+              const float v0 = w * dh[r0] + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
+              const float v1 = w * dh[r0 + 1] + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
+              float* dst = a.dgrid + a.lotd.offset[l] + 2 * (int64_t)idx;
+              if (v0 != 0.f) atomicAdd(dst, v0);
+              if (v1 != 0.f) atomicAdd(dst + 1, v1);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (MODE == 2) {
+    __syncthreads();
+    const SrcOff so = src_off(SDF_D);
+    for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
+      const float v = accum[i];
+      if (v == 0.f) continue;
+      float* dst = nullptr;
+      if (i < AO.w2) dst = a.dsdf_w + so.w1 + (i - AO.w1);
+      else if (i < AO.wh) dst = (SDF_D == 2) ? a.dsdf_w + so.w2 + (i - AO.w2) : nullptr;
+      else if (i < AO.b1) dst = a.dsdf_w + so.wh + (i - AO.wh);
+      else if (i < AO.b2) dst = a.dsdf_b + so.b1 + (i - AO.b1);
+      else if (i < AO.bh) dst = (SDF_D == 2) ? a.dsdf_b + so.b2 + (i - AO.b2) : nullptr;
+      else if (i < AO.r1) dst = (i == AO.bh) ? a.dsdf_b + so.bh : nullptr;
+      else if (i < AO.r2) dst = a.drad_w + so.r1 + (i - AO.r1);
+      else if (i < AO.r3) dst = a.drad_w + so.r2 + (i - AO.r2);
+      else if (i < AO.rb1) dst = a.drad_w + so.r3 + (i - AO.r3);
+      else if (i < AO.rb2) dst = a.drad_b + so.rb1 + (i - AO.rb1);
+      else if (i < AO.rb3) dst = a.drad_b + so.rb2 + (i - AO.rb2);
+      else dst = (i - AO.rb3 < 3) ? a.drad_b + so.rb3 + (i - AO.rb3) : nullptr;
+      if (dst) atomicAdd(dst, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- self test
+__global__ void __launch_bounds__(64) k_selftest_mfma(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ D, int use_f32) {
+  // D[32x32] = A[32x16] * B[16x32] (row-major), computed only through the documented operand contract:
+  // lane (i,hi) supplies row i of A / column i of B for the K slots (hi, e) <-> k = 8*hi + e.
+  const int lane = nsim_lane(), i = lane & 31, hi = lane >> 5;
+  f32x16 acc = zero16();
+  if (!use_f32) {
+    f16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = (f16)A[i * 16 + 8 * hi + e];
+      b[e] = (f16)B[(8 * hi + e) * 32 + i];
+    }
+    acc = mfma_32x32x16_f16(a, b, acc);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = 2 * q + hi;
+      acc = mfma_32x32x2_f32(A[i * 16 + k], B[k * 32 + i], acc);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) D[mfma_row(r, hi) * 32 + i] = acc[r];
+}
+
+// ================================================================================== C ABI
+static int field_meta_check(const NsimFieldMeta* m) {
+  if (!m) return 20;
+  const int rc = lotd_meta_check(&m->lotd);
+  if (rc) return rc;
+  if (m->lotd.num_levels != 16) return 21;
+  if (m->sdf_D != 1 && m->sdf_D != 2) return 22;
+  if (m->precision != 0 && m->precision != 1) return 23;
+  return 0;
+}
+
+static FieldArgs field_args(const NsimFieldMeta* meta) {
+  FieldArgs a = FieldArgs();
+  a.lotd = lotd_dev(&meta->lotd);
+  a.lay = field_layout(meta->precision);
+  a.beta = meta->softplus_beta;
+  return a;
+}
+
+static unsigned field_grid(int64_t S, int64_t max_blocks) {
+  const int64_t tiles = (S + 31) / 32;
+  int64_t b = (tiles + FIELD_WAVES - 1) / FIELD_WAVES;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+template <int MODE>
+static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t shmem, int64_t max_blocks,
+                        hipStream_t stream) {
+  const dim3 grid(field_grid(a.S, max_blocks)), block(64 * FIELD_WAVES);
+  const int key = meta->precision * 2 + (meta->sdf_D - 1);
+  switch (key) {
+    case 0: hipLaunchKernelGGL((k_field<0, 1, MODE>), grid, block, shmem, stream, a); break;
+    case 1: hipLaunchKernelGGL((k_field<0, 2, MODE>), grid, block, shmem, stream, a); break;
+    case 2: hipLaunchKernelGGL((k_field<1, 1, MODE>), grid, block, shmem, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_field<1, 2, MODE>), grid, block, shmem, stream, a); break;
+  }
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
+
+int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta) {
+  if (field_meta_check(meta)) return -1;
+  return field_layout(meta->precision).total;
+}
+
+int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b, const float* rad_w,
+                            const float* rad_b, void* wpack, void* stream) {
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  const FieldLayout L = field_layout(meta->precision);
+  PackDims dims;
+  int64_t total = 0;
+  for (int m = 0; m < M_COUNT; ++m) {
+    dims.uo[m] = kMatUo[m];
+    dims.ui[m] = kMatUi[m];
+    total += (int64_t)kMatUo[m] * kMatUi[m];
+  }
+  total += (int64_t)V_COUNT * 64;
+  hipLaunchKernelGGL(k_field_pack, dim3(nsim_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, L, dims,
+                     meta->sdf_D, sdf_w, sdf_b, rad_w, rad_b, (char*)wpack);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
+                   float* sdf, void* stream) {
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  FieldArgs a = field_args(meta);
+  a.grid = (const f16*)grid_f16;
+  a.wpack = (const char*)wpack;
+  a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.S = S;
+  a.sdf = sdf;
+  return field_launch<0>(meta, a, 0, 1 << 20, (hipStream_t)stream);
+}
+
+int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, void* stream) {
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (rgb && !(rays_d && ridx)) return 25;
+  FieldArgs a = field_args(meta);
+  a.grid = (const f16*)grid_f16;
+  a.wpack = (const char*)wpack;
+  a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.h_appear = h_appear;
+  a.S = S;
+  a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
+  a.has_rgb = rgb ? 1 : 0;
+  return field_launch<1>(meta, a, 0, 1 << 20, (hipStream_t)stream);
+}
+
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* sdf_w,
+                   const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                   const float* h_appear, int64_t S, const float* dsdf, const float* dnablas, const float* drgb,
+                   float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w, float* drad_b, float* dh_appear,
+                   void* stream) {
+  (void)sdf_w;
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (drgb && !(rays_d && ridx)) return 25;
+  if (!dsdf_w || !dsdf_b || !drad_w || !drad_b) return 26;
+  FieldArgs a = field_args(meta);
+  a.grid = (const f16*)grid_f16;
+  a.wpack = (const char*)wpack;
+  a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.h_appear = h_appear;
+  a.S = S;
+  a.dsdf = dsdf; a.dnablas = dnablas; a.drgb = drgb;
+  a.dgrid = dgrid; a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
+  a.dh_appear = dh_appear;
+  a.has_rgb = drgb ? 1 : 0;
+  const AccOff AO = acc_off();
+  const size_t stage = meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
+  const size_t shmem = ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage;
+  // one workgroup per CU, two rounds: every block flushes its LDS accumulator once
+  return field_launch<2>(meta, a, shmem, 512, (hipStream_t)stream);
+}
+
+int nsim_selftest_mfma(const float* a, const float* b, float* d, int use_f32, void* stream) {
+  hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d, use_f32);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

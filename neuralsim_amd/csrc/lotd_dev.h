@@ -1,0 +1,95 @@
+// lotd_dev.h -- device-side LoTD (multi-resolution Dense/Hash grid) addressing shared by lotd.hip and
+// field.hip.  Conventions are those of oracle/lotd.py (the executable spec standing in for the absent
+// nr3d_lib.models.grid_encodings.lotd; config: lotd_neus.dtu.230814.yaml:96-111):
+//   u = x/2 + 0.5 ; pos = u * (R-1) ; c0 = clamp(floor(pos), 0, R-2) ; w = pos - c0
+//   Dense index = cx + R*(cy + R*cz) ; Hash index = (cx ^ cy*2654435761 ^ cz*805459861) mod T (uint32)
+//   params: flat fp16, level l at [offset_l, offset_l + size_l*2), feature index fastest.
+#pragma once
+#include "nsim_common.h"
+
+struct LotdDev {
+  int num_levels;
+  int res[NSIM_MAX_LEVELS];
+  int type[NSIM_MAX_LEVELS];
+  uint32_t size[NSIM_MAX_LEVELS];
+  int64_t offset[NSIM_MAX_LEVELS];
+};
+
+static inline LotdDev lotd_dev(const NsimLotdMeta* m) {
+  LotdDev d;
+  d.num_levels = m->num_levels;
+  for (int l = 0; l < NSIM_MAX_LEVELS; ++l) {
+    d.res[l] = l < m->num_levels ? m->res[l] : 2;
+    d.type[l] = l < m->num_levels ? m->type[l] : 0;
+    d.size[l] = l < m->num_levels ? m->size[l] : 8;
+    d.offset[l] = l < m->num_levels ? m->offset[l] : 0;
+  }
+  return d;
+}
+
+static inline int lotd_meta_check(const NsimLotdMeta* m) {
+  if (!m) return 10;
+  if (m->n_feats != 2) return 11;
+  if (m->num_levels < 1 || m->num_levels > NSIM_MAX_LEVELS) return 12;
+  for (int l = 0; l < m->num_levels; ++l) {
+    if (m->res[l] < 2) return 13;
+    if (m->type[l] == NSIM_LOTD_DENSE) {
+      if ((uint64_t)m->res[l] * m->res[l] * m->res[l] != (uint64_t)m->size[l]) return 14;
+    } else if (m->type[l] != NSIM_LOTD_HASH) {
+      return 15;
+    }
+    if (m->offset[l] & 1) return 16;
+  }
+  return 0;
+}
+
+struct LotdCell {
+  int c0[3];
+  float w[3];
+  float dscale;  // d pos / d x = 0.5 * (R-1)
+};
+
+__device__ __forceinline__ LotdCell lotd_cell(const float x[3], int R) {
+  LotdCell c;
+  const float rm1 = (float)(R - 1);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float u = x[a] * 0.5f + 0.5f;
+    const float pos = u * rm1;
+    float f = floorf(pos);
+    f = fminf(fmaxf(f, 0.f), (float)(R - 2));
+    c.c0[a] = (int)f;
+    c.w[a] = pos - f;
+  }
+  c.dscale = 0.5f * rm1;
+  return c;
+}
+
+__device__ __forceinline__ uint32_t lotd_index(int cx, int cy, int cz, int R, int type, uint32_t T) {
+  if (type == NSIM_LOTD_DENSE) return (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  const uint32_t h = (uint32_t)cx ^ ((uint32_t)cy * 2654435761u) ^ ((uint32_t)cz * 805459861u);
+  return h % T;
+}
+
+// trilinear weight of corner (dx,dy,dz) and its derivative w.r.t. the three cell coordinates
+__device__ __forceinline__ void lotd_corner_w(const LotdCell& c, int corner, float& w, float dw[3]) {
+  const int dx = corner & 1, dy = (corner >> 1) & 1, dz = (corner >> 2) & 1;
+  const float wx = dx ? c.w[0] : 1.0f - c.w[0];
+  const float wy = dy ? c.w[1] : 1.0f - c.w[1];
+  const float wz = dz ? c.w[2] : 1.0f - c.w[2];
+  w = wx * wy * wz;
+  dw[0] = (dx ? 1.0f : -1.0f) * wy * wz;
+  dw[1] = (dy ? 1.0f : -1.0f) * wx * wz;
+  dw[2] = (dz ? 1.0f : -1.0f) * wx * wy;
+}
+
+__device__ __forceinline__ void lotd_load2(const f16* grid, int64_t off, uint32_t idx, float& f0, float& f1) {
+  const uint32_t raw = *reinterpret_cast<const uint32_t*>(grid + off + 2 * (int64_t)idx);
+  union {
+    uint32_t u;
+    f16 h[2];
+  } cv;
+  cv.u = raw;
+  f0 = (float)cv.h[0];
+  f1 = (float)cv.h[1];
+}

@@ -1,0 +1,33 @@
+// misc.hip -- version / error strings of the C ABI.
+#include "nsim_common.h"
+
+extern "C" {
+
+int nsim_version(void) { return 100; }
+
+const char* nsim_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case 2: return "negative size";
+    case 3: return "bad channel count / op code";
+    case 4: return "required output pointer is NULL";
+    case 5: return "missing occupancy/AABB meta or non-positive step";
+    case 10: return "LoTD meta is NULL";
+    case 11: return "LoTD n_feats must be 2";
+    case 12: return "LoTD num_levels out of range";
+    case 13: return "LoTD level resolution < 2";
+    case 14: return "LoTD dense level size != res^3";
+    case 15: return "LoTD unknown level type";
+    case 16: return "LoTD level offset must be even";
+    case 20: return "field meta is NULL";
+    case 21: return "fused field kernels need exactly 16 LoTD levels (32 features)";
+    case 22: return "sdf_D must be 1 or 2";
+    case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";
+    case 24: return "need either x or (rays_o, rays_d, t, ridx)";
+    case 25: return "radiance needs rays_d and ridx";
+    case 26: return "gradient output pointer is NULL";
+    default: return code >= 1000 ? "HIP launch error (code - 1000 = hipError_t)" : "unknown error";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// nsim_common.h -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// All kernels are written for 64-lane wavefronts.  Cross-lane primitives and the
+// MFMA instructions are reached only through the thin wrappers below, so that the
+// test-only host emulator (tests/emu/hip_emu.h, -DNSIM_HOST_EMU) can stand in for
+// the hardware when the kernel *logic* is checked on a CPU-only machine.  The
+// product build never defines NSIM_HOST_EMU.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#ifdef NSIM_HOST_EMU
+#include "hip_emu.h"
+#define NSIM_DYN_SMEM(name) char* name = emu::st().dyn_smem
+#else
+#include <hip/hip_runtime.h>
+#define NSIM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include "../../include/nsim.h"
+
+#define NSIM_WAVE 64
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ cross-lane
+__device__ __forceinline__ int nsim_lane() {
+#ifdef NSIM_HOST_EMU
+  return emu::lane_id();
+#else
+  return (int)(threadIdx.x & 63);
+#endif
+}
+
+template <class T>
+__device__ __forceinline__ T wave_shfl(T v, int src) {
+#ifdef NSIM_HOST_EMU
+  return emu::shfl(v, src);
+#else
+  return __shfl(v, src, 64);
+#endif
+}
+
+template <class T>
+__device__ __forceinline__ T wave_shfl_xor(T v, int mask) {
+  return wave_shfl(v, nsim_lane() ^ mask);
+}
+
+__device__ __forceinline__ unsigned long long wave_ballot(int pred) {
+#ifdef NSIM_HOST_EMU
+  return emu::ballot(pred);
+#else
+  return __ballot(pred);
+#endif
+}
+
+// inclusive scans across the 64 lanes (Hillis-Steele over shuffles)
+template <class T>
+__device__ __forceinline__ T wave_incl_sum(T v) {
+  const int lane = nsim_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T u = wave_shfl(v, lane - o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_incl_prod(T v) {
+  const int lane = nsim_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T u = wave_shfl(v, lane - o);
+    if (lane >= o) v *= u;
+  }
+  return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += wave_shfl_xor(v, o);
+  return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = wave_shfl_xor(v, o);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------ MFMA
+// v_mfma_f32_32x32x16_f16: A lane l -> row (l&31), B lane l -> col (l&31),
+// 8 K-slots per lane indexed by (l>>5, e); C/D: col = l&31,
+// row = (r&3) + 8*(r>>2) + 4*(l>>5).  (CDNA4 guide, "Fragment layout".)
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+#ifdef NSIM_HOST_EMU
+  f16 aa[8], bb[8];
+  float cc[16], dd[16];
+  for (int e = 0; e < 8; ++e) { aa[e] = a[e]; bb[e] = b[e]; }
+  for (int r = 0; r < 16; ++r) cc[r] = c[r];
+  emu::mfma32<f16, 8>(aa, bb, cc, dd);
+  f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = dd[r];
+  return d;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA, one K-slot per lane (k = l>>5).
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+#ifdef NSIM_HOST_EMU
+  float cc[16], dd[16];
+  for (int r = 0; r < 16; ++r) cc[r] = c[r];
+  emu::mfma32<float, 1>(&a, &b, cc, dd);
+  f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = dd[r];
+  return d;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+// row of accumulator register r for lane-half hi within a 32-row MFMA tile
+__device__ __forceinline__ constexpr int mfma_row(int r, int hi) {
+  return (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+
+// ------------------------------------------------------------------- launching
+#define NSIM_CHECK_LAUNCH()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return 1000 + (int)e__;   \
+  } while (0)
+
+static inline unsigned nsim_blocks(int64_t n, int per_block, int64_t cap = 1 << 20) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}

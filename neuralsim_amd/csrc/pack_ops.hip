@@ -1,0 +1,599 @@
+// pack_ops.hip -- segmented ("packed") tensor ops and the fused volume-integration kernels for gfx950.
+//
+// Replaces the native half of nr3d_lib.graphics.pack_ops / nr3d_lib.graphics.nerf as the reference calls
+// them (app/renderers/single_volume_renderer.py:73-102, app/renderers/buffer_compose_renderer.py:644-723,
+// app/loss/lidar.py:102-110).  Design: ONE 64-lane wavefront owns one pack (ray); lanes stride over the
+// pack's samples (coalesced 256-B rows), segmented scans are wave-level shuffle scans with a scalar carry
+// between 64-sample chunks.  Everything here is HBM-bound: 4-44 B per sample in, 4-28 B out.
+#include "nsim_common.h"
+
+#define PACK_WAVES_PER_BLOCK 4
+#define PACK_BLOCK (64 * PACK_WAVES_PER_BLOCK)
+
+__device__ __forceinline__ int64_t pack_wave_id() {
+  return (int64_t)blockIdx.x * PACK_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+}
+static inline dim3 pack_grid(int64_t P) { return dim3(nsim_blocks(P, PACK_WAVES_PER_BLOCK)); }
+
+// ------------------------------------------------------------------------------ pack_infos_from_n
+__global__ void __launch_bounds__(256) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
+                                                             int64_t* __restrict__ pi,
+                                                             int64_t* __restrict__ total) {
+  __shared__ int64_t sums[256];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (P + 255) / 256;
+  const int64_t b = tid * chunk, e = (b + chunk < P) ? b + chunk : P;
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += n[i];
+  sums[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int i = 0; i < 256; ++i) {
+      int64_t v = sums[i];
+      sums[i] = run;
+      run += v;
+    }
+    if (total) total[0] = run;
+  }
+  __syncthreads();
+  int64_t run = sums[tid];
+  for (int64_t i = b; i < e; ++i) {
+    int64_t v = n[i];
+    pi[2 * i] = run;
+    pi[2 * i + 1] = v;
+    run += v;
+  }
+}
+
+// ------------------------------------------------------------------------------------ packed_sum
+__global__ void __launch_bounds__(PACK_BLOCK) k_packed_sum(const float* __restrict__ x, int C,
+                                                             const int64_t* __restrict__ pi, int64_t P,
+                                                             float* __restrict__ out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int64_t i = lane; i < n; i += 64) acc += x[(st + i) * C + c];
+    acc = wave_sum(acc);
+    if (lane == 0) out[p * C + c] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_packed_binary(const float* __restrict__ x, int C,
+                                                                const float* __restrict__ pp, int Cp,
+                                                                const int64_t* __restrict__ pi, int64_t P,
+                                                                int op, float* __restrict__ out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  const int64_t tot = n * C;
+  for (int64_t j = lane; j < tot; j += 64) {
+    const int c = (int)(j % C);
+    const float b = pp[p * Cp + (Cp == 1 ? 0 : c)];
+    const float a = x ? x[st * C + j] : 1.0f;
+    float r;
+    if (op == 0) r = a * b;
+    else if (op == 1) r = a / b;
+    else if (op == 2) r = a + b;
+    else r = a - b;
+    out[st * C + j] = r;
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_packed_cmp(const float* __restrict__ x,
+                                                             const float* __restrict__ pp,
+                                                             const int64_t* __restrict__ pi, int64_t P, int op,
+                                                             uint8_t* __restrict__ out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  const float b = pp[p];
+  for (int64_t i = lane; i < n; i += 64) {
+    const float a = x[st + i];
+    bool r = (op == 0) ? (a >= b) : (op == 1) ? (a <= b) : (op == 2) ? (a < b) : (a > b);
+    out[st + i] = r ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_packed_matmul3(const float* __restrict__ x,
+                                                                 const float* __restrict__ rot,
+                                                                 const int64_t* __restrict__ pi, int64_t P,
+                                                                 int transpose, float* __restrict__ out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  float r[9];
+  for (int k = 0; k < 9; ++k) r[k] = rot[p * 9 + k];
+  for (int64_t i = lane; i < n; i += 64) {
+    const float a = x[(st + i) * 3 + 0], b = x[(st + i) * 3 + 1], c = x[(st + i) * 3 + 2];
+    float o0, o1, o2;
+    if (!transpose) {  // (rot * x[None,:]).sum(-1): broadcast-multiply-sum, no reduced-precision matmul
+      o0 = r[0] * a + r[1] * b + r[2] * c;
+      o1 = r[3] * a + r[4] * b + r[5] * c;
+      o2 = r[6] * a + r[7] * b + r[8] * c;
+    } else {
+      o0 = r[0] * a + r[3] * b + r[6] * c;
+      o1 = r[1] * a + r[4] * b + r[7] * c;
+      o2 = r[2] * a + r[5] * b + r[8] * c;
+    }
+    out[(st + i) * 3 + 0] = o0;
+    out[(st + i) * 3 + 1] = o1;
+    out[(st + i) * 3 + 2] = o2;
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_interleave_linstep(const int64_t* __restrict__ start,
+                                                                     const int64_t* __restrict__ pi,
+                                                                     int64_t P, int64_t step,
+                                                                     int64_t* __restrict__ out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1], s0 = start[p];
+  for (int64_t i = lane; i < n; i += 64) out[st + i] = s0 + i * step;
+}
+
+// ------------------------------------------------------------------------------------ packed_sort
+// Stable rank sort inside one pack: rank(i) = #{j : x_j < x_i  or (x_j == x_i and j < i)}.
+// O(n^2 / 64) per wave -- packs on this path hold O(10..500) samples (buffer_compose_renderer.py:687).
+__global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restrict__ x,
+                                                              const int64_t* __restrict__ pi, int64_t P,
+                                                              float* __restrict__ sorted,
+                                                              int64_t* __restrict__ indices) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  for (int64_t i = lane; i < n; i += 64) {
+    const float xi = x[st + i];
+    int64_t rank = 0;
+    for (int64_t j = 0; j < n; ++j) {
+      const float xj = x[st + j];
+      rank += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+    }
+    sorted[st + rank] = xi;
+    indices[st + rank] = st + i;
+  }
+}
+
+// lower_bound / upper_bound on a sorted global array segment
+__device__ __forceinline__ int64_t seg_lower_bound(const float* a, int64_t n, float v) {  // #elements < v
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int64_t seg_upper_bound(const float* a, int64_t n, float v) {  // #elements <= v
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// merge_two_packs_sorted: one wave per pack of a and per pack of b (two launches share this kernel).
+// For a pack of `self` on union slot u, every element's position in the merged pack is its own index plus
+// the number of `other` elements that precede it (strictly smaller; ties: a first).
+__global__ void __launch_bounds__(PACK_BLOCK) k_merge_two_packs(
+    const float* __restrict__ vs, const int64_t* __restrict__ pis, const int64_t* __restrict__ slot_s,
+    int64_t Ps, const float* __restrict__ vo, const int64_t* __restrict__ pio,
+    const int64_t* __restrict__ slot_o, int64_t Po, const int64_t* __restrict__ pi_out, int self_is_a,
+    int64_t* __restrict__ pidx_s) {
+  const int64_t p = pack_wave_id();
+  if (p >= Ps) return;
+  const int lane = nsim_lane();
+  const int64_t st = pis[2 * p], n = pis[2 * p + 1], u = slot_s[p];
+  // find the other side's pack on the same union slot (slot_o ascending & unique)
+  int64_t lo = 0, hi = Po;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (slot_o[mid] < u) lo = mid + 1; else hi = mid;
+  }
+  const bool has_other = (lo < Po) && (slot_o[lo] == u);
+  const int64_t ost = has_other ? pio[2 * lo] : 0, on = has_other ? pio[2 * lo + 1] : 0;
+  const int64_t out_st = pi_out[2 * u];
+  for (int64_t i = lane; i < n; i += 64) {
+    const float v = vs[st + i];
+    const int64_t before = self_is_a ? seg_lower_bound(vo + ost, on, v) : seg_upper_bound(vo + ost, on, v);
+    pidx_s[st + i] = out_st + i + before;
+  }
+}
+
+// ------------------------------------------------------------------------------- alpha -> vw
+// chunked exclusive product scan of f = 1 - alpha + eps with a scalar carry
+__device__ __forceinline__ void vw_chunk(float a, bool valid, float eps, float& carry, float& T) {
+  const int lane = nsim_lane();
+  const float f = valid ? (1.0f - a + eps) : 1.0f;
+  const float incl = wave_incl_prod(f);
+  float excl = wave_shfl(incl, lane - 1);
+  if (lane == 0) excl = 1.0f;
+  T = carry * excl;
+  carry = carry * wave_shfl(incl, 63);
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_alpha_to_vw_fwd(const float* __restrict__ alpha,
+                                                                  const int64_t* __restrict__ pi, int64_t P,
+                                                                  float* __restrict__ vw,
+                                                                  float* __restrict__ trans) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  float carry = 1.0f;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < n;
+    const float a = valid ? alpha[st + i] : 0.f;
+    float T;
+    vw_chunk(a, valid, 1e-10f, carry, T);
+    if (valid) {
+      vw[st + i] = a * T;
+      if (trans) trans[st + i] = T;
+    }
+  }
+}
+
+// d alpha_i = dvw_i * T_i - (sum_{k>i} dvw_k vw_k) / (1 - alpha_i + eps), chunks walked back to front
+__global__ void __launch_bounds__(PACK_BLOCK) k_alpha_to_vw_bwd(
+    const float* __restrict__ alpha, const float* __restrict__ trans, const float* __restrict__ vw,
+    const float* __restrict__ dvw, const int64_t* __restrict__ pi, int64_t P, float* __restrict__ dalpha) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  float carry = 0.f;  // sum of g over all later chunks
+  const int64_t nchunks = (n + 63) / 64;
+  for (int64_t c = nchunks - 1; c >= 0; --c) {
+    const int64_t i = c * 64 + lane;
+    const bool valid = i < n;
+    const float g = valid ? dvw[st + i] * vw[st + i] : 0.f;
+    const float incl = wave_incl_sum(g);
+    const float tot = wave_shfl(incl, 63);
+    const float suffix = carry + (tot - incl);
+    if (valid) {
+      const float a = alpha[st + i];
+      dalpha[st + i] = dvw[st + i] * trans[st + i] - suffix / (1.0f - a + 1e-10f);
+    }
+    carry += tot;
+  }
+}
+
+// ------------------------------------------------------------------------- fused compositing
+__global__ void __launch_bounds__(PACK_BLOCK) k_composite_fwd(
+    const float* __restrict__ alpha, const float* __restrict__ t, const float* __restrict__ rgb,
+    const float* __restrict__ nrm, const int64_t* __restrict__ pi, int64_t P, int normalized_depth,
+    float* __restrict__ vw, float* __restrict__ trans, float* __restrict__ mask, float* __restrict__ depth,
+    float* __restrict__ rgb_out, float* __restrict__ nrm_out) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  float carry = 1.0f;
+  float am = 0.f, ad = 0.f, ar[3] = {0.f, 0.f, 0.f}, an[3] = {0.f, 0.f, 0.f};
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < n;
+    const float a = valid ? alpha[st + i] : 0.f;
+    float T;
+    vw_chunk(a, valid, 1e-10f, carry, T);
+    if (valid) {
+      const float w = a * T;
+      vw[st + i] = w;
+      trans[st + i] = T;
+      am += w;
+      ad += w * t[st + i];
+      if (rgb) {
+        ar[0] += w * rgb[(st + i) * 3 + 0];
+        ar[1] += w * rgb[(st + i) * 3 + 1];
+        ar[2] += w * rgb[(st + i) * 3 + 2];
+      }
+      if (nrm) {
+        an[0] += w * nrm[(st + i) * 3 + 0];
+        an[1] += w * nrm[(st + i) * 3 + 1];
+        an[2] += w * nrm[(st + i) * 3 + 2];
+      }
+    }
+  }
+  am = wave_sum(am);
+  ad = wave_sum(ad);
+  if (rgb) for (int c = 0; c < 3; ++c) ar[c] = wave_sum(ar[c]);
+  if (nrm) for (int c = 0; c < 3; ++c) an[c] = wave_sum(an[c]);
+  if (lane == 0) {
+    mask[p] = am;
+    depth[p] = normalized_depth ? ad / (am + 1e-10f) : ad;
+    if (rgb) for (int c = 0; c < 3; ++c) rgb_out[p * 3 + c] = ar[c];
+    if (nrm) for (int c = 0; c < 3; ++c) nrm_out[p * 3 + c] = an[c];
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_composite_bwd(
+    const float* __restrict__ alpha, const float* __restrict__ trans, const float* __restrict__ vw,
+    const float* __restrict__ t, const float* __restrict__ rgb, const float* __restrict__ nrm,
+    const int64_t* __restrict__ pi, int64_t P, int normalized_depth, const float* __restrict__ mask,
+    const float* __restrict__ depth, const float* __restrict__ dmask, const float* __restrict__ ddepth,
+    const float* __restrict__ drgb_out, const float* __restrict__ dnrm_out,
+    const float* __restrict__ dvw_ext, float* __restrict__ dalpha, float* __restrict__ drgb,
+    float* __restrict__ dnrm) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  float gm = dmask ? dmask[p] : 0.f;
+  float gd = ddepth ? ddepth[p] : 0.f;
+  if (normalized_depth) {
+    // depth = D / (m + eps): dD = gd / (m+eps) ; dm += -gd * depth / (m+eps)
+    const float den = mask[p] + 1e-10f;
+    gm += -gd * depth[p] / den;
+    gd = gd / den;
+  }
+  float gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+  if (rgb && drgb_out) for (int c = 0; c < 3; ++c) gr[c] = drgb_out[p * 3 + c];
+  if (nrm && dnrm_out) for (int c = 0; c < 3; ++c) gn[c] = dnrm_out[p * 3 + c];
+  float carry = 0.f;
+  const int64_t nchunks = (n + 63) / 64;
+  for (int64_t c = nchunks - 1; c >= 0; --c) {
+    const int64_t i = c * 64 + lane;
+    const bool valid = i < n;
+    float gvw = 0.f, w = 0.f;
+    if (valid) {
+      w = vw[st + i];
+      gvw = gm + gd * t[st + i];
+      if (dvw_ext) gvw += dvw_ext[st + i];
+      if (rgb) {
+        const float r0 = rgb[(st + i) * 3 + 0], r1 = rgb[(st + i) * 3 + 1], r2 = rgb[(st + i) * 3 + 2];
+        gvw += gr[0] * r0 + gr[1] * r1 + gr[2] * r2;
+        if (drgb) {
+          drgb[(st + i) * 3 + 0] = w * gr[0];
+          drgb[(st + i) * 3 + 1] = w * gr[1];
+          drgb[(st + i) * 3 + 2] = w * gr[2];
+        }
+      }
+      if (nrm) {
+        const float n0 = nrm[(st + i) * 3 + 0], n1 = nrm[(st + i) * 3 + 1], n2 = nrm[(st + i) * 3 + 2];
+        gvw += gn[0] * n0 + gn[1] * n1 + gn[2] * n2;
+        if (dnrm) {
+          dnrm[(st + i) * 3 + 0] = w * gn[0];
+          dnrm[(st + i) * 3 + 1] = w * gn[1];
+          dnrm[(st + i) * 3 + 2] = w * gn[2];
+        }
+      }
+    }
+    const float g = gvw * w;
+    const float incl = wave_incl_sum(g);
+    const float tot = wave_shfl(incl, 63);
+    const float suffix = carry + (tot - incl);
+    if (valid) {
+      const float a = alpha[st + i];
+      dalpha[st + i] = gvw * trans[st + i] - suffix / (1.0f - a + 1e-10f);
+    }
+    carry += tot;
+  }
+}
+
+// ------------------------------------------------------------------------------- NeuS sdf -> alpha
+__device__ __forceinline__ float nsim_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float neus_inv_s(const float* ln_inv_s, float factor, float forward_inv_s) {
+  return forward_inv_s > 0.f ? forward_inv_s : expf(ln_inv_s[0] * factor);
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_fwd(const float* __restrict__ sdf,
+                                                                 const int64_t* __restrict__ pi, int64_t P,
+                                                                 const float* __restrict__ ln_inv_s,
+                                                                 float factor, float forward_inv_s,
+                                                                 float* __restrict__ alpha) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  const float s = neus_inv_s(ln_inv_s, factor, forward_inv_s);
+  for (int64_t i = lane; i < n; i += 64) {
+    float a = 0.f;
+    if (i + 1 < n) {
+      const float c0 = nsim_sigmoid(sdf[st + i] * s), c1 = nsim_sigmoid(sdf[st + i + 1] * s);
+      a = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+      a = fminf(fmaxf(a, 0.f), 1.f);
+    }
+    alpha[st + i] = a;
+  }
+}
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
+    const float* __restrict__ sdf, const float* __restrict__ dalpha, const int64_t* __restrict__ pi, int64_t P,
+    const float* __restrict__ ln_inv_s, float factor, float forward_inv_s, float* __restrict__ dsdf,
+    float* __restrict__ d_ln_inv_s) {
+  const int64_t p = pack_wave_id();
+  if (p >= P) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  const float s = neus_inv_s(ln_inv_s, factor, forward_inv_s);
+  float ds_acc = 0.f;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    float g = 0.f;
+    if (i < n) {
+      const float x0 = sdf[st + i];
+      const float c0 = nsim_sigmoid(x0 * s);
+      // as the left end of interval i
+      if (i + 1 < n) {
+        const float x1 = sdf[st + i + 1];
+        const float c1 = nsim_sigmoid(x1 * s);
+        const float raw = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+        if (raw >= 0.f && raw <= 1.f) {
+          const float ga = dalpha[st + i];
+          const float den = c0 + 1e-5f;
+          const float da_dc0 = (c1) / (den * den);
+          const float da_dc1 = -1.0f / den;
+          g += ga * da_dc0 * s * c0 * (1.f - c0);
+          ds_acc += ga * (da_dc0 * x0 * c0 * (1.f - c0) + da_dc1 * x1 * c1 * (1.f - c1));
+        }
+      }
+      // as the right end of interval i-1
+      if (i >= 1) {
+        const float xm = sdf[st + i - 1];
+        const float cm = nsim_sigmoid(xm * s);
+        const float raw = (cm - c0 + 1e-5f) / (cm + 1e-5f);
+        if (raw >= 0.f && raw <= 1.f) {
+          const float ga = dalpha[st + i - 1];
+          g += ga * (-1.0f / (cm + 1e-5f)) * s * c0 * (1.f - c0);
+        }
+      }
+      dsdf[st + i] = g;
+    }
+  }
+  if (d_ln_inv_s && forward_inv_s <= 0.f) {
+    ds_acc = wave_sum(ds_acc);
+    if (lane == 0 && ds_acc != 0.f) atomicAdd(d_ln_inv_s, ds_acc * s * factor);
+  }
+}
+
+// ================================================================================== C ABI
+extern "C" {
+
+int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, void* stream) {
+  if (P < 0) return 2;
+  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(256), 0, (hipStream_t)stream, n, P, pack_infos, total);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream) {
+  if (P <= 0) return 0;
+  if (C < 1) return 3;
+  hipLaunchKernelGGL(k_packed_sum, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, C, pack_infos, P, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_packed_binary(const float* x, int C, const float* per_pack, int Cp, const int64_t* pack_infos,
+                       int64_t P, int op, float* out, void* stream) {
+  if (P <= 0) return 0;
+  if (C < 1 || (Cp != 1 && Cp != C) || op < 0 || op > 3) return 3;
+  hipLaunchKernelGGL(k_packed_binary, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, C, per_pack, Cp,
+                     pack_infos, P, op, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_packed_cmp(const float* x, const float* per_pack, const int64_t* pack_infos, int64_t P, int op,
+                    uint8_t* out, void* stream) {
+  if (P <= 0) return 0;
+  if (op < 0 || op > 3) return 3;
+  hipLaunchKernelGGL(k_packed_cmp, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, per_pack, pack_infos, P, op, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_packed_matmul3(const float* x, const float* rot, const int64_t* pack_infos, int64_t P, int transpose,
+                        float* out, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_packed_matmul3, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, rot, pack_infos, P,
+                     transpose, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_packed_sort(const float* x, const int64_t* pack_infos, int64_t P, float* sorted, int64_t* indices,
+                     void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_packed_sort, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, pack_infos, P, sorted, indices);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_interleave_linstep(const int64_t* start, const int64_t* pack_infos, int64_t P, int64_t step,
+                            int64_t* out, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_interleave_linstep, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, start, pack_infos, P, step, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_merge_two_packs(const float* va, const int64_t* pia, const int64_t* slot_a, int64_t Pa,
+                         const float* vb, const int64_t* pib, const int64_t* slot_b, int64_t Pb,
+                         const int64_t* pack_infos_out, int64_t U, int64_t* pidx_a, int64_t* pidx_b,
+                         void* stream) {
+  (void)U;
+  if (Pa > 0) {
+    hipLaunchKernelGGL(k_merge_two_packs, pack_grid(Pa), dim3(PACK_BLOCK), 0, (hipStream_t)stream, va, pia, slot_a, Pa,
+                       vb, pib, slot_b, Pb, pack_infos_out, 1, pidx_a);
+    NSIM_CHECK_LAUNCH();
+  }
+  if (Pb > 0) {
+    hipLaunchKernelGGL(k_merge_two_packs, pack_grid(Pb), dim3(PACK_BLOCK), 0, (hipStream_t)stream, vb, pib, slot_b, Pb,
+                       va, pia, slot_a, Pa, pack_infos_out, 0, pidx_b);
+    NSIM_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int nsim_alpha_to_vw_fwd(const float* alpha, const int64_t* pack_infos, int64_t P, float* vw, float* trans,
+                         void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_alpha_to_vw_fwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, pack_infos, P, vw, trans);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw, const float* dvw,
+                         const int64_t* pack_infos, int64_t P, float* dalpha, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_alpha_to_vw_bwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, trans, vw, dvw,
+                     pack_infos, P, dalpha);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_composite_fwd(const float* alpha, const float* t, const float* rgb, const float* nrm,
+                       const int64_t* pack_infos, int64_t P, int normalized_depth, float* vw, float* trans,
+                       float* mask, float* depth, float* rgb_out, float* nrm_out, void* stream) {
+  if (P <= 0) return 0;
+  if (!vw || !trans || !mask || !depth) return 4;
+  hipLaunchKernelGGL(k_composite_fwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, t, rgb, nrm,
+                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_composite_bwd(const float* alpha, const float* trans, const float* vw, const float* t,
+                       const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
+                       int normalized_depth, const float* mask, const float* depth, const float* dmask,
+                       const float* ddepth, const float* drgb_out, const float* dnrm_out,
+                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_composite_bwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, trans, vw, t, rgb,
+                     nrm, pack_infos, P, normalized_depth, mask, depth, dmask, ddepth, drgb_out, dnrm_out, dvw_ext,
+                     dalpha, drgb, dnrm);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_neus_alpha_fwd(const float* sdf, const int64_t* pack_infos, int64_t P, const float* ln_inv_s,
+                        float ln_inv_s_factor, float forward_inv_s, float* alpha, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_neus_alpha_fwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, sdf, pack_infos, P,
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, alpha);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_neus_alpha_bwd(const float* sdf, const float* dalpha, const int64_t* pack_infos, int64_t P,
+                        const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, float* dsdf,
+                        float* d_ln_inv_s, void* stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_neus_alpha_bwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, sdf, dalpha, pack_infos, P,
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, dsdf, d_ln_inv_s);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// sampling.hip -- ray generation, AABB ray test, occupancy-grid marching and NeuS up-sampling for gfx950.
+//
+// Replaces the native half of Camera.get_selected_rays (app/resources/observers/cameras.py:281-310),
+// AABBSpace.ray_test, OccGridAccel.ray_march / OccGridEma (accel_cfg, march_cfg in
+// code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:140-173) and the multi-stage inverse-CDF
+// up-sampler of NeusRendererMixin (num_fine, upsample_inv_s, upsample_use_estimate_alpha).
+//
+// Design: one wavefront per ray.  Marching tests 64 lattice steps per wave instruction against the
+// occupancy BITFIELD (64^3 bits = 32 KiB: L1/LDS resident), ballots the hits and emits them already
+// sorted; up-sampling is a chunked wave scan (alpha -> transmittance -> cdf) followed by one binary search
+// per new sample.  All arithmetic that decides sample membership is written mul-then-add (the library is
+// built with -ffp-contract=off) so the sample set is bit-identical to the oracle's.
+#include "nsim_common.h"
+
+#define SMP_WAVES_PER_BLOCK 4
+#define SMP_BLOCK (64 * SMP_WAVES_PER_BLOCK)
+
+__device__ __forceinline__ int64_t smp_wave_id() {
+  return (int64_t)blockIdx.x * SMP_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+}
+static inline dim3 smp_grid(int64_t R) { return dim3(nsim_blocks(R, SMP_WAVES_PER_BLOCK)); }
+
+struct OccDev {
+  float mn[3], mx[3], sc[3];
+  int res[3];
+};
+static inline OccDev occ_dev(const NsimOccMeta* m) {
+  OccDev o;
+  for (int i = 0; i < 3; ++i) {
+    o.mn[i] = m->aabb_min[i];
+    o.mx[i] = m->aabb_max[i];
+    o.sc[i] = m->scale[i];
+    o.res[i] = m->res[i];
+  }
+  return o;
+}
+
+// ----------------------------------------------------------------------------------- ray generation
+__global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict__ xy,
+                                                         const int64_t* __restrict__ fidx,
+                                                         const float* __restrict__ intr,
+                                                         const float* __restrict__ c2w,
+                                                         const int64_t* __restrict__ WH, int64_t N, int snap,
+                                                         float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t f = fidx[i];
+  const float W = (float)WH[2 * f], H = (float)WH[2 * f + 1];
+  float w = xy[2 * i] * W, h = xy[2 * i + 1] * H;
+  if (snap) {  // (xy*WH).long().clamp(0, WH-1) + 0.5   (cameras.py:302-303)
+    float wi = truncf(w), hi = truncf(h);
+    wi = fminf(fmaxf(wi, 0.f), W - 1.f);
+    hi = fminf(fmaxf(hi, 0.f), H - 1.f);
+    w = wi + 0.5f;
+    h = hi + 0.5f;
+  }
+  const float* K = intr + f * 9;
+  const float dx = (w - K[2]) / K[0];
+  const float dy = (h - K[5]) / K[4];
+  const float* M = c2w + f * 16;
+  // broadcast-multiply-sum, never a reduced-precision matmul (cameras.py:355-359)
+  float d0 = M[0] * dx + M[1] * dy + M[2] * 1.0f;
+  float d1 = M[4] * dx + M[5] * dy + M[6] * 1.0f;
+  float d2 = M[8] * dx + M[9] * dy + M[10] * 1.0f;
+  const float nrm = fmaxf(sqrtf(d0 * d0 + d1 * d1 + d2 * d2), 1e-12f);
+  rays_d[3 * i + 0] = d0 / nrm;
+  rays_d[3 * i + 1] = d1 / nrm;
+  rays_d[3 * i + 2] = d2 / nrm;
+  rays_o[3 * i + 0] = M[3];
+  rays_o[3 * i + 1] = M[7];
+  rays_o[3 * i + 2] = M[11];
+}
+
+// ------------------------------------------------------------------------------------ AABB ray test
+__global__ void __launch_bounds__(256) k_aabb_ray_test(const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, int64_t N, OccDev m,
+                                                        float near, float far, float* __restrict__ near_out,
+                                                        float* __restrict__ far_out, uint8_t* __restrict__ hit) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float o = rays_o[3 * i + a];
+    float d = rays_d[3 * i + a];
+    if (fabsf(d) < 1e-12f) d = (d < 0.f) ? -1e-12f : 1e-12f;
+    const float inv = 1.0f / d;
+    const float t1 = (m.mn[a] - o) * inv, t2 = (m.mx[a] - o) * inv;
+    tmin = fmaxf(tmin, fminf(t1, t2));
+    tmax = fminf(tmax, fmaxf(t1, t2));
+  }
+  const float n = fmaxf(tmin, near);
+  const float f = (far >= 0.f) ? fminf(tmax, far) : tmax;
+  near_out[i] = n;
+  far_out[i] = f;
+  hit[i] = (f > n) ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------- occupancy grid
+__device__ __forceinline__ bool occ_voxel(const OccDev& m, float px, float py, float pz, int64_t& flat) {
+  const float gx = floorf((px - m.mn[0]) * m.sc[0]);
+  const float gy = floorf((py - m.mn[1]) * m.sc[1]);
+  const float gz = floorf((pz - m.mn[2]) * m.sc[2]);
+  const bool inside = gx >= 0.f && gy >= 0.f && gz >= 0.f && gx < (float)m.res[0] && gy < (float)m.res[1] &&
+                      gz < (float)m.res[2];
+  flat = inside ? ((int64_t)gx + (int64_t)m.res[0] * ((int64_t)gy + (int64_t)m.res[1] * (int64_t)gz)) : 0;
+  return inside;
+}
+
+__global__ void __launch_bounds__(256) k_occ_decay(float* __restrict__ val, int64_t n, float decay) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) val[i] = val[i] * decay;
+}
+
+// scatter-max of f(sdf) = 4 sig(s x)(1 - sig(s x)) >= 0: integer atomicMax on the bit pattern is exact
+__global__ void __launch_bounds__(256) k_occ_update(float* __restrict__ val, const float* __restrict__ pts,
+                                                     const float* __restrict__ sdf, int64_t n, OccDev m,
+                                                     float inv_s) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t flat;
+  if (!occ_voxel(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], flat)) return;
+  const float s = 1.0f / (1.0f + expf(-sdf[i] * inv_s));
+  const float v = 4.0f * s * (1.0f - s);
+  int iv;
+  memcpy(&iv, &v, 4);
+  atomicMax((int*)val + flat, iv);
+}
+
+__global__ void __launch_bounds__(256) k_occ_pack_bits(const float* __restrict__ val, int64_t nvox, float thre,
+                                                        uint32_t* __restrict__ bits) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nwords = (nvox + 31) / 32;
+  if (w >= nwords) return;
+  uint32_t b = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int64_t v = w * 32 + k;
+    if (v < nvox && val[v] > thre) b |= (1u << k);
+  }
+  bits[w] = b;
+}
+
+// ------------------------------------------------------------------------------------------ marching
+struct MarchRay {
+  float o[3], d[3], near, far, jit;
+  int K;
+};
+
+__device__ __forceinline__ MarchRay march_load(const float* rays_o, const float* rays_d, const float* near,
+                                               const float* far, const float* jitter, int64_t r, float step,
+                                               int max_steps) {
+  MarchRay m;
+  for (int a = 0; a < 3; ++a) {
+    m.o[a] = rays_o[3 * r + a];
+    m.d[a] = rays_d[3 * r + a];
+  }
+  m.near = near[r];
+  m.far = far[r];
+  m.jit = jitter ? jitter[r] : 0.5f;
+  float kf = ceilf((m.far - m.near) / step);
+  kf = fminf(fmaxf(kf, 0.f), (float)max_steps);
+  m.K = (int)kf;
+  return m;
+}
+
+__device__ __forceinline__ bool march_test(const MarchRay& m, const OccDev& occ, const uint32_t* bits, int k,
+                                           float step, float& t) {
+  t = m.near + ((float)k + m.jit) * step;
+  if (k >= m.K || !(t < m.far)) return false;
+  const float px = m.o[0] + t * m.d[0], py = m.o[1] + t * m.d[1], pz = m.o[2] + t * m.d[2];
+  int64_t flat;
+  if (!occ_voxel(occ, px, py, pz, flat)) return false;
+  return (bits[flat >> 5] >> (flat & 31)) & 1u;
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_march_count(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ near,
+    const float* __restrict__ far, const float* __restrict__ jitter, int64_t R, const uint32_t* __restrict__ bits,
+    OccDev occ, float step, int max_steps, int64_t* __restrict__ counts) {
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int lane = nsim_lane();
+  const MarchRay m = march_load(rays_o, rays_d, near, far, jitter, r, step, max_steps);
+  int cnt = 0;
+  for (int base = 0; base < m.K; base += 64) {
+    float t;
+    const bool hit = march_test(m, occ, bits, base + lane, step, t);
+    cnt += __popcll(wave_ballot(hit));
+  }
+  if (lane == 0) counts[r] = cnt;
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_march_emit(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ near,
+    const float* __restrict__ far, const float* __restrict__ jitter, int64_t R, const uint32_t* __restrict__ bits,
+    OccDev occ, float step, int max_steps, const int64_t* __restrict__ pi, float* __restrict__ t_out) {
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int lane = nsim_lane();
+  const MarchRay m = march_load(rays_o, rays_d, near, far, jitter, r, step, max_steps);
+  const int64_t st = pi[2 * r];
+  int cnt = 0;
+  for (int base = 0; base < m.K; base += 64) {
+    float t;
+    const bool hit = march_test(m, occ, bits, base + lane, step, t);
+    const unsigned long long mask = wave_ballot(hit);
+    if (hit) {
+      const int before = __popcll(mask & ((1ull << lane) - 1ull));
+      t_out[st + cnt + before] = t;
+    }
+    cnt += __popcll(mask);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_coarse_depths(const float* __restrict__ near, const float* __restrict__ far,
+                                                        const float* __restrict__ jc, int64_t R, int C,
+                                                        float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R * C) return;
+  const int64_t r = j / C;
+  const int i = (int)(j % C);
+  const float u = jc ? jc[j] : 0.5f;
+  out[j] = near[r] + (far[r] - near[r]) * (((float)i + u) / (float)C);
+}
+
+// ---------------------------------------------------------------------------------------- up-sampling
+__device__ __forceinline__ float smp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// interval opacity used for up-sampling (NeuS `up_sample`, or the plain consecutive-sdf form)
+__device__ __forceinline__ float upsample_alpha(const float* t, const float* sdf, int64_t i, float inv_s,
+                                                int use_est) {
+  const float s0 = sdf[i], s1 = sdf[i + 1];
+  if (use_est) {
+    const float t0 = t[i], t1 = t[i + 1];
+    const float dist = t1 - t0;
+    float cs = (s1 - s0) / (dist + 1e-5f);
+    float prev = 0.f;
+    if (i > 0) prev = (s0 - sdf[i - 1]) / ((t0 - t[i - 1]) + 1e-5f);
+    cs = fminf(prev, cs);
+    cs = fminf(fmaxf(cs, -1e3f), 0.f);
+    const float mid = (s0 + s1) * 0.5f;
+    const float half = cs * dist * 0.5f;
+    const float pc = smp_sigmoid((mid - half) * inv_s), nc = smp_sigmoid((mid + half) * inv_s);
+    return (pc - nc + 1e-5f) / (pc + 1e-5f);
+  } else {
+    const float c0 = smp_sigmoid(s0 * inv_s), c1 = smp_sigmoid(s1 * inv_s);
+    const float a = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+    return fminf(fmaxf(a, 0.f), 1.f);
+  }
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __restrict__ t,
+                                                                const float* __restrict__ sdf,
+                                                                const int64_t* __restrict__ pi, int64_t R,
+                                                                float inv_s, int n_fine, int use_est,
+                                                                float* __restrict__ csum,
+                                                                float* __restrict__ t_new) {
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * r], n = pi[2 * r + 1];
+  const int64_t ni = n - 1;  // intervals
+  const float* tt = t + st;
+  const float* ss = sdf + st;
+  float* cs = csum + st;
+  float carry_T = 1.0f, carry_S = 0.f;
+  for (int64_t base = 0; base < ni; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < ni;
+    const float a = valid ? upsample_alpha(tt, ss, i, inv_s, use_est) : 0.f;
+    const float f = valid ? (1.0f - a + 1e-7f) : 1.0f;
+    const float incl = wave_incl_prod(f);
+    float excl = wave_shfl(incl, lane - 1);
+    if (lane == 0) excl = 1.0f;
+    const float T = carry_T * excl;
+    carry_T = carry_T * wave_shfl(incl, 63);
+    const float w = valid ? (a * T + 1e-5f) : 0.f;
+    const float ws = wave_incl_sum(w);
+    if (valid) cs[i] = carry_S + ws;
+    carry_S = carry_S + wave_shfl(ws, 63);
+  }
+#ifndef NSIM_HOST_EMU
+  __threadfence_block();
+#endif
+  const float wsum = carry_S;
+  for (int kb = 0; kb < n_fine; kb += 64) {
+    const int k = kb + lane;
+    if (k < n_fine && ni > 0) {
+      const float u = ((float)k + 0.5f) / (float)n_fine;
+      // first interval i with cdf[i+1] = cs[i]/wsum > u, clamped to the last interval
+      int64_t lo = 0, hi = ni;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cs[mid] / wsum <= u) lo = mid + 1; else hi = mid;
+      }
+      if (lo > ni - 1) lo = ni - 1;
+      const float c_lo = (lo == 0) ? 0.f : cs[lo - 1] / wsum;
+      const float c_hi = cs[lo] / wsum;
+      float den = c_hi - c_lo;
+      if (den < 1e-5f) den = 1.0f;
+      float frac = (u - c_lo) / den;
+      frac = fminf(fmaxf(frac, 0.f), 1.f);
+      const float b_lo = tt[lo], b_hi = tt[lo + 1];
+      t_new[r * n_fine + k] = b_lo + frac * (b_hi - b_lo);
+    } else if (k < n_fine) {
+      t_new[r * n_fine + k] = (n > 0) ? tt[0] : 0.f;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------- sorted merge
+__device__ __forceinline__ int64_t smp_lower_bound(const float* a, int64_t n, float v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int64_t smp_upper_bound(const float* a, int64_t n, float v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restrict__ t_a,
+                                                              const float* __restrict__ v_a,
+                                                              const int64_t* __restrict__ pia,
+                                                              const float* __restrict__ t_b,
+                                                              const float* __restrict__ v_b, int64_t R, int nb,
+                                                              float* __restrict__ t_out, float* __restrict__ v_out,
+                                                              int64_t* __restrict__ pio) {
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int lane = nsim_lane();
+  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
+  const int64_t so = sa + r * (int64_t)nb;
+  const float* a = t_a + sa;
+  const float* b = t_b + r * (int64_t)nb;
+  if (lane == 0) {
+    pio[2 * r] = so;
+    pio[2 * r + 1] = na + nb;
+  }
+  for (int64_t i = lane; i < na; i += 64) {  // a first on ties: b elements strictly smaller precede
+    const float v = a[i];
+    const int64_t pos = i + smp_lower_bound(b, nb, v);
+    t_out[so + pos] = v;
+    if (v_out) v_out[so + pos] = v_a ? v_a[sa + i] : 0.f;
+  }
+  for (int64_t j = lane; j < nb; j += 64) {
+    const float v = b[j];
+    const int64_t pos = j + smp_upper_bound(a, na, v);
+    t_out[so + pos] = v;
+    if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
+  }
+}
+
+// ================================================================================== C ABI
+extern "C" {
+
+int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr, const float* c2w,
+                        const int64_t* WH, int64_t N, int snap, float* rays_o, float* rays_d, void* stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
+                     WH, N, snap, rays_o, rays_d);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_aabb_ray_test(const float* rays_o, const float* rays_d, int64_t N, const NsimOccMeta* meta, float near,
+                       float far, float* near_out, float* far_out, uint8_t* hit, void* stream) {
+  if (N <= 0) return 0;
+  if (!meta) return 5;
+  hipLaunchKernelGGL(k_aabb_ray_test, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, N,
+                     occ_dev(meta), near, far, near_out, far_out, hit);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_occ_decay(float* val, int64_t nvox, float decay, void* stream) {
+  if (nvox <= 0) return 0;
+  hipLaunchKernelGGL(k_occ_decay, dim3(nsim_blocks(nvox, 256)), dim3(256), 0, (hipStream_t)stream, val, nvox, decay);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_occ_update(float* val, const float* pts, const float* sdf, int64_t n, const NsimOccMeta* meta,
+                    float inv_s, void* stream) {
+  if (n <= 0) return 0;
+  if (!meta) return 5;
+  hipLaunchKernelGGL(k_occ_update, dim3(nsim_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, val, pts, sdf, n,
+                     occ_dev(meta), inv_s);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_occ_pack_bits(const float* val, int64_t nvox, float thre, uint32_t* bits, void* stream) {
+  if (nvox <= 0) return 0;
+  hipLaunchKernelGGL(k_occ_pack_bits, dim3(nsim_blocks((nvox + 31) / 32, 256)), dim3(256), 0, (hipStream_t)stream, val,
+                     nvox, thre, bits);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                     const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta, float step,
+                     int max_steps, int64_t* counts, void* stream) {
+  if (R <= 0) return 0;
+  if (!meta || !(step > 0.f)) return 5;
+  hipLaunchKernelGGL(k_march_count, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, near, far,
+                     jitter, R, bits, occ_dev(meta), step, max_steps, counts);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                    const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta, float step,
+                    int max_steps, const int64_t* pack_infos, float* t_out, void* stream) {
+  if (R <= 0) return 0;
+  if (!meta || !(step > 0.f)) return 5;
+  hipLaunchKernelGGL(k_march_emit, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, near, far, jitter,
+                     R, bits, occ_dev(meta), step, max_steps, pack_infos, t_out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C, float* out,
+                       void* stream) {
+  if (R <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(k_coarse_depths, dim3(nsim_blocks(R * C, 256)), dim3(256), 0, (hipStream_t)stream, near, far,
+                     jitter_c, R, C, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, void* stream) {
+  if (R <= 0 || n_fine <= 0) return 0;
+  hipLaunchKernelGGL(k_upsample_stage, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t, sdf, pack_infos, R, inv_s,
+                     n_fine, use_estimate_alpha, scratch, t_new);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
+                      const float* v_b, int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out,
+                      void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
+                     R, nb, t_out, v_out, pack_infos_out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+"""Test harness.
+
+Two backends run the SAME test bodies through the SAME host code (neuralsim_amd/*):
+  * ``hip``  -- the product: libnsim_hip.so on a real MI355X (marked ``gpu``);
+  * ``emu``  -- the identical kernel sources compiled for the host against the test-only SIMT emulator
+                (tests/emu/), injected by monkeypatching the three loader hooks of ``neuralsim_amd._lib``.
+                This exists so kernel logic can be checked against the oracle on a CPU-only machine; the
+                product itself has no such path (``_lib.get_lib`` only ever loads libnsim_hip.so).
+The checker is always ``oracle/`` (pure PyTorch on CPU).
+"""
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running emulator test")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    import build_emu
+    from neuralsim_amd import _lib
+    path = build_emu.build()
+    return _lib.bind(ctypes.CDLL(str(path)))
+
+
+@pytest.fixture
+def backend(request, monkeypatch):
+    """-> torch.device the tensors must live on for the selected backend."""
+    from neuralsim_amd import _lib
+    kind = request.param
+    if kind == "emu":
+        lib = request.getfixturevalue("emu_lib")
+        monkeypatch.setattr(_lib, "get_lib", lambda: lib)
+        monkeypatch.setattr(_lib, "stream_handle", lambda: 0)
+        monkeypatch.setattr(_lib, "require_device", lambda t, name="tensor": None)
+        return torch.device("cpu")
+    assert torch.cuda.is_available(), "gpu test selected but no HIP device is visible"
+    _lib.get_lib()
+    return torch.device("cuda", 0)
+
+
+def pytest_generate_tests(metafunc):
+    if "backend" in metafunc.fixturenames:
+        metafunc.parametrize("backend", BACKENDS, indirect=True)
+
+
+def sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize()
