@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- training rays/s (forward + backward + optimizer) of the NeuS render step on N MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run, one rank per
+GPU over RCCL).  Prints ONE JSON line on rank 0.  A "step" is one full training iteration of
+BASELINE.json configs[1] per GPU: 8192 synthetic rays (posed pinhole cameras 800x800) -> ray test -> occupancy
+marching + 3-stage NeuS up-sampling -> fused LoTD(L=16,T=2^19)+2x64 SDF MLP+radiance MLP forward -> compositing ->
+rgb-mse + eikonal loss -> backward (incl. second-order normal terms) -> gradient all-reduce -> Adam, with the
+occupancy-grid refresh every 16 iterations inside the timed region.  Weak scaling: rays per GPU are fixed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+RAYS_PER_GPU = 8192
+# algorithmic bytes per point of the three field kernels:
+#   gather: 16 levels x 8 corners x 2 feats x 2 B (fp16) = 512 B read
+#   backward: the 512 B gather again + 16 x 8 x 2 f32 atomic adds = 1024 B read-modify-write
+BYTES_PER_POINT = {"nsim_field_sdf": 512, "nsim_field_fwd": 512, "nsim_field_bwd": 512 + 1024}
+HBM_PEAK_GBS = 8000.0
+
+
+def build_trainer(device, rank, world, seed=42):
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    from neuralsim_amd import distributed as ndist
+    model = LoTDNeuSModel(sdf_D=2, precision="fp16", ln_inv_s_init=0.5, seed=seed).to(device)
+    model.geometric_init_sphere(0.5)
+    model.accel.init(model.query_sdf, generator=torch.Generator(device=device).manual_seed(seed))
+    ndist.broadcast_module(model)
+    intr, c2w, WH = look_at_cameras(V=100, seed=seed, device=device)
+    return RenderTrainer(model, intr, c2w, WH, num_rays=RAYS_PER_GPU, lr=1e-2, w_eikonal=0.1, num_uniform=4096,
+                         rank=rank, world_size=world, seed=seed)
+
+
+def cpu_baseline(tr, n_rays=1024, iters=2):
+    """The oracle (pure-PyTorch restatement, kind 'port') timed on this box's host cores on a bounded sample of
+    the same workload: same weights, same occupancy grid, same camera rig, n_rays rays, fwd + loss + bwd."""
+    from oracle import field as ofield, lotd as olotd, render as orr
+    m = tr.model
+    cfg = m.encoding.cfg
+    spec = olotd.make_lotd_spec(cfg.lod_res, 2, 19)
+    D = m.sdf_D
+    sw, sb, rw, rb = m.sdf_w.detach().cpu(), m.sdf_b.detach().cpu(), m.rad_w.detach().cpu(), m.rad_b.detach().cpu()
+    sdf_w = [sw[:2048].view(64, 32).clone()] + ([sw[2048:6144].view(64, 64).clone()] if D == 2 else []) + [sw[-64:].view(1, 64).clone()]
+    sdf_b = [sb[:64].clone()] + ([sb[64:128].clone()] if D == 2 else []) + [sb[-1:].clone()]
+    rad_w = [rw[:1664].view(64, 26).clone(), rw[1664:1664 + 4096].view(64, 64).clone(), rw[-192:].view(3, 64).clone()]
+    rad_b = [rb[:64].clone(), rb[64:128].clone(), rb[128:].clone()]
+    p = ofield.FieldParams(spec=spec, grid=m.encoding.flattened_params.detach().cpu().half().float(), sdf_w=sdf_w,
+                           sdf_b=sdf_b, rad_w=rad_w, rad_b=rad_b, ln_inv_s=m.ln_inv_s.detach().cpu().reshape(()).clone())
+    p.requires_grad_(True)
+    occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
+    aabb = m.accel.aabb.detach().cpu()
+    intr, c2w, WH = tr.intr.cpu(), tr.c2w.cpu(), tr.WH.cpu()
+    g = torch.Generator().manual_seed(7)
+    times = []
+    for it in range(iters + 1):
+        xy = torch.rand(n_rays, 2, generator=g).clamp(1e-6, 1 - 1e-6)
+        fidx = torch.randint(0, intr.shape[0], (n_rays,), generator=g)
+        gt = torch.rand(n_rays, 3, generator=g)
+        jit = torch.rand(n_rays, generator=g)
+        jit_c = torch.rand(n_rays, 64, generator=g)
+        t0 = time.perf_counter()
+        o, d = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
+        ha = tr.appear.detach().cpu()[fidx]
+        ret = orr.ray_query(p, o, d, ha, occ, aabb[0], aabb[1], m.accel.resolution, near=0.01, jitter=jit, jitter_c=jit_c)
+        loss, _ = orr.render_loss(ret, gt, n_rays, w_eikonal=0.1)
+        for t in p.tensors():
+            t.grad = None
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:          # first pass warms the allocator / thread pool
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=n_rays / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_rays} rays x {iters} timed iterations of the same step (fwd+loss+bwd, no optimizer), "
+                       f"pure-PyTorch oracle, f32")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    args = ap.parse_args()
+
+    from neuralsim_amd import _lib, distributed as ndist
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    rank, local_rank, world = ndist.init_env()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.get_lib()
+    tr = build_trainer(dev, rank, world)
+
+    it0 = 257                      # timed region starts right after an occupancy refresh (every 16 iterations)
+    it = it0 - max(args.warmup, 1)
+    for _ in range(args.warmup):
+        tr.train_step(it)
+        it += 1
+    it = it0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    _lib.TIMER = _lib.KernelTimer()
+    S_f = S_hit = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(it)
+        it += 1
+        S_f += tr.stats["S_f"]
+        S_hit += tr.stats["R_hit"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer, _lib.TIMER = _lib.TIMER, None
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        ksum = timer.summary()
+        total_rays = RAYS_PER_GPU * world * args.steps
+        ms = elapsed / args.steps * 1e3
+        dom = max((k for k in ksum if k in BYTES_PER_POINT), key=lambda k: ksum[k]["total_ms"])
+        kd = ksum[dom]
+        bytes_per_launch = kd["units"] * BYTES_PER_POINT[dom] / max(1, kd["calls"])
+        achieved = bytes_per_launch / (kd["avg_ms"] * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                        avg_launch_ms=round(kd["avg_ms"], 4), points_per_launch=kd["units"] / max(1, kd["calls"]),
+                        bytes_per_point=BYTES_PER_POINT[dom])
+        tf = ROOT / "profiles" / "traffic.json"      # per-launch HBM bytes from rocprofv3 PMC passes, if recorded
+        if tf.exists():
+            try:
+                roofline["traffic"] = json.loads(tf.read_text()).get(dom)
+            except Exception:
+                pass
+        out = dict(metric="training rays/sec (fwd+bwd) NeuS 800x800", value=round(total_rays / elapsed, 1),
+                   unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
+                   config=dict(workload="BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
+                                        "8192 rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + 2x64 SDF MLP + 2x64 radiance "
+                                        "MLP (SH4, appear 4), occ grid 64^3, num_coarse 64, num_fine [8,8,32], "
+                                        "step .005, inv_s=e^5, eikonal on render samples + 4096 uniform points, "
+                                        "Adam + occupancy refresh every 16 it inside the timed region",
+                               rays_per_gpu=RAYS_PER_GPU, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
+                               samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
+                               hit_fraction=round(S_hit / (RAYS_PER_GPU * args.steps), 3)),
+                   roofline=roofline,
+                   kernels={k: dict(calls=v["calls"], total_ms=round(v["total_ms"], 3)) for k, v in
+                            sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])[:8]})
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tr, n_rays=args.cpu_rays)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

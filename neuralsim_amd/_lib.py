@@ -127,10 +127,40 @@ def ptr(t, dtype=None, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing on the launch stream (used by bench.py for the roofline)."""
+
+    def __init__(self):
+        self.events = {}
+        self.units = {}
+
+    def note_units(self, name, n):
+        self.units[name] = self.units.get(name, 0) + int(n)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / max(1, len(ms)),
+                             units=self.units.get(name, 0))
+        return out
+
+
+TIMER = None   # set to a KernelTimer() to record events around every call
+
+
 def call(name: str, *args):
     """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code."""
     lib = get_lib()
-    rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
+    if TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
+        e1.record()
+        TIMER.events.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
     if rc != 0:
         msg = lib.nsim_strerror(rc)
         raise RuntimeError(f"{name} failed with code {rc}: {msg.decode() if msg else '?'}")

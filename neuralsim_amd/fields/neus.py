@@ -1,0 +1,544 @@
+"""LoTD NeuS model -- host side of the fused gfx950 field / sampling kernels.
+
+Mirrors ``nr3d_lib.models.fields.neus.LoTDNeuSModel`` (+ ``NeusRendererMixin``) at the API the reference's
+renderers and losses call:
+  * ``ray_test(rays_o, rays_d, near, far, rays_ts=, rays_pix=, rays_h_appear=) -> dict``
+    (app/renderers/single_volume_renderer.py:235-238, keys :289-300)
+  * ``ray_query(ray_input=, ray_tested=, config=, return_buffer=, return_details=, render_per_obj_individual=)``
+    (single_volume_renderer.py:244-246) -> ``volume_buffer{type,rays_inds_hit,pack_infos_hit,t,opacity_alpha,rgb,nablas}``
+  * ``forward_sdf / forward_sdf_nablas / query_sdf`` (code_single/tools/inspect_rendering.py:120-128,305,417),
+    ``sample_pts_uniform`` (app/loss/eikonal.py:215), ``forward_inv_s`` (code_single/tools/eval.py:218-219)
+Model hyper-parameters follow code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:80-173.
+
+All arithmetic runs in the HIP kernels (csrc/field.hip, csrc/sampling.hip, csrc/pack_ops.hip) through the C ABI;
+this file only allocates tensors, sequences launches on the current stream and defines autograd boundaries.
+Host synchronisations per render: two (hit-ray compaction, marched-sample total) -- the reference has three
+(single_volume_renderer.py:340,345,414).
+"""
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..grid_encodings.lotd import LoTDConfig, LoTDEncoding
+from ..graphics import pack_ops as po
+
+DEFAULT_LOD_RES = [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+RAD_IN = 26
+
+
+def _flat_sizes(D: int):
+    n_sdf_w = 64 * 32 + (64 * 64 if D == 2 else 0) + 64
+    n_sdf_b = 64 * D + 1
+    n_rad_w = 64 * RAD_IN + 64 * 64 + 3 * 64
+    n_rad_b = 131
+    return n_sdf_w, n_sdf_b, n_rad_w, n_rad_b
+
+
+# --------------------------------------------------------------------------------------------- autograd
+class _FieldFn(torch.autograd.Function):
+    """(grid, sdf_w, sdf_b, rad_w, rad_b, h_appear) -> (sdf [S], nablas [S,3], rgb [S,3]).
+    ``nablas`` is an ordinary differentiable output: its gradient w.r.t. grid and decoder weights (the
+    "double backward" of the reference, app/loss/eikonal.py:216-251) is produced analytically by nsim_field_bwd."""
+
+    @staticmethod
+    def forward(ctx, model, grid, sdf_w, sdf_b, rad_w, rad_b, h_appear, x, rays_o, rays_d, t, ridx, with_rgb):
+        S = x.shape[0] if x is not None else t.shape[0]
+        dev = grid.device
+        grid16, wpack = model._shadow()
+        sdf = torch.zeros([S], dtype=torch.float32, device=dev)
+        nablas = torch.zeros([S, 3], dtype=torch.float32, device=dev)
+        rgb = torch.zeros([S, 3], dtype=torch.float32, device=dev) if with_rgb else None
+        ha = h_appear.detach().float().contiguous() if h_appear is not None else None
+        _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S, _lib.ptr(sdf), _lib.ptr(nablas),
+                  _lib.ptr(rgb))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_field_fwd", S)
+        ctx.model, ctx.S, ctx.with_rgb = model, S, with_rgb
+        ctx.geom = (x, rays_o, rays_d, t, ridx, ha)
+        ctx.ha_shape = h_appear.shape if h_appear is not None else None
+        if with_rgb:
+            return sdf, nablas, rgb
+        return sdf, nablas
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_nab, g_rgb=None):
+        model = ctx.model
+        x, rays_o, rays_d, t, ridx, ha = ctx.geom
+        grid16, wpack = model._shadow()
+        dev = grid16.device
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
+        need = ctx.needs_input_grad
+        dgrid = torch.zeros([model.encoding.cfg.n_params], dtype=torch.float32, device=dev) if need[1] else None
+        dsdf_w = torch.zeros([n_sdf_w], dtype=torch.float32, device=dev)
+        dsdf_b = torch.zeros([n_sdf_b], dtype=torch.float32, device=dev)
+        drad_w = torch.zeros([n_rad_w], dtype=torch.float32, device=dev)
+        drad_b = torch.zeros([n_rad_b], dtype=torch.float32, device=dev)
+        dha = torch.zeros(ctx.ha_shape, dtype=torch.float32, device=dev) if (ha is not None and need[6]) else None
+        gs = g_sdf.float().contiguous() if g_sdf is not None else None
+        gn = g_nab.float().contiguous() if g_nab is not None else None
+        gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
+        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(x),
+                  _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), ctx.S, _lib.ptr(gs),
+                  _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(dgrid), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(drad_w),
+                  _lib.ptr(drad_b), _lib.ptr(dha))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_field_bwd", ctx.S)
+        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
+
+
+class _NeusAlphaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, ln_inv_s, pack_infos, factor, forward_inv_s):
+        sdf = sdf.float().contiguous()
+        alpha = torch.zeros_like(sdf)
+        _lib.call("nsim_neus_alpha_fwd", _lib.ptr(sdf), _lib.ptr(pack_infos), pack_infos.shape[0], _lib.ptr(ln_inv_s),
+                  float(factor), float(forward_inv_s), _lib.ptr(alpha))
+        ctx.save_for_backward(sdf, ln_inv_s, pack_infos)
+        ctx.factor, ctx.fis = float(factor), float(forward_inv_s)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g):
+        sdf, ln_inv_s, pack_infos = ctx.saved_tensors
+        dsdf = torch.zeros_like(sdf)
+        dln = torch.zeros_like(ln_inv_s)
+        _lib.call("nsim_neus_alpha_bwd", _lib.ptr(sdf), _lib.ptr(g.float().contiguous()), _lib.ptr(pack_infos),
+                  pack_infos.shape[0], _lib.ptr(ln_inv_s), ctx.factor, ctx.fis, _lib.ptr(dsdf), _lib.ptr(dln))
+        return dsdf, dln, None, None, None
+
+
+class _CompositeFn(torch.autograd.Function):
+    """Fused ``SingleVolumeRenderer._volume_integration`` (single_volume_renderer.py:73-102)."""
+
+    @staticmethod
+    def forward(ctx, alpha, t, rgb, nrm, pack_infos, normalized_depth):
+        alpha = alpha.float().contiguous()
+        t = t.float().contiguous()
+        rgbc = rgb.float().contiguous() if rgb is not None else None
+        nrmc = nrm.float().contiguous() if nrm is not None else None
+        P = pack_infos.shape[0]
+        dev = alpha.device
+        vw = torch.zeros_like(alpha)
+        trans = torch.ones_like(alpha)
+        mask = torch.zeros([P], dtype=torch.float32, device=dev)
+        depth = torch.zeros([P], dtype=torch.float32, device=dev)
+        rgb_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
+        nrm_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
+        _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgbc), _lib.ptr(nrmc),
+                  _lib.ptr(pack_infos), P, int(normalized_depth), _lib.ptr(vw), _lib.ptr(trans), _lib.ptr(mask),
+                  _lib.ptr(depth), _lib.ptr(rgb_o), _lib.ptr(nrm_o))
+        ctx.save_for_backward(alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth)
+        ctx.nd = int(normalized_depth)
+        ctx.mark_non_differentiable(trans)
+        return vw, mask, depth, rgb_o, nrm_o, trans
+
+    @staticmethod
+    def backward(ctx, g_vw, g_mask, g_depth, g_rgb, g_nrm, _g_trans):
+        alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth = ctx.saved_tensors
+        P = pack_infos.shape[0]
+
+        def c(g):
+            return g.float().contiguous() if g is not None else None
+        dalpha = torch.zeros_like(alpha)
+        drgb = torch.zeros_like(rgbc) if rgbc is not None else None
+        dnrm = torch.zeros_like(nrmc) if nrmc is not None else None
+        _lib.call("nsim_composite_bwd", _lib.ptr(alpha), _lib.ptr(trans), _lib.ptr(vw), _lib.ptr(t), _lib.ptr(rgbc),
+                  _lib.ptr(nrmc), _lib.ptr(pack_infos), P, ctx.nd, _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(c(g_mask)),
+                  _lib.ptr(c(g_depth)), _lib.ptr(c(g_rgb)), _lib.ptr(c(g_nrm)), _lib.ptr(c(g_vw)), _lib.ptr(dalpha),
+                  _lib.ptr(drgb), _lib.ptr(dnrm))
+        return dalpha, None, drgb, dnrm, None, None
+
+
+def volume_integration(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw=False) -> Dict[str, torch.Tensor]:
+    vw, mask, depth, rgb_o, nrm_o, _ = _CompositeFn.apply(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw)
+    out = dict(vw=vw, mask_volume=mask, depth_volume=depth)
+    if rgb is not None:
+        out["rgb_volume"] = rgb_o
+    if nablas is not None:
+        out["normals_volume"] = nrm_o
+    return out
+
+
+# ------------------------------------------------------------------------------------------ occupancy
+class OccGridAccel(nn.Module):
+    """``accel_cfg{type: occ_grid, resolution, occ_val_fn_cfg{type: sdf, inv_s}, occ_thre, ema_decay,
+    init_cfg/update_from_net_cfg{num_steps,num_pts}, n_steps_between_update, n_steps_warmup}``
+    (lotd_neus.dtu.230814.yaml:140-155; nr3d_lib.models.accelerations.OccGridAccel / OccGridEma)."""
+
+    def __init__(self, aabb: torch.Tensor, resolution=(64, 64, 64), occ_thre=0.3, ema_decay=0.95, inv_s=256.0,
+                 num_steps=4, num_pts=2 ** 20, n_steps_between_update=16, n_steps_warmup=256, device=None):
+        super().__init__()
+        self.resolution = [int(r) for r in resolution]
+        self.occ_thre, self.ema_decay, self.inv_s = float(occ_thre), float(ema_decay), float(inv_s)
+        self.num_steps, self.num_pts = int(num_steps), int(num_pts)
+        self.n_steps_between_update, self.n_steps_warmup = n_steps_between_update, n_steps_warmup
+        nvox = self.resolution[0] * self.resolution[1] * self.resolution[2]
+        self.register_buffer("aabb", aabb.float().reshape(2, 3).clone())
+        self.register_buffer("occ_val", torch.zeros(nvox, dtype=torch.float32))
+        # the bit-packed grid the marching kernels read (uint32 words stored as int32)
+        self.register_buffer("occ_bits", torch.full([(nvox + 31) // 32], -1, dtype=torch.int32))
+        if device is not None:
+            self.to(device)
+        self.meta = self._make_meta()
+
+    def _make_meta(self):
+        m = _lib.OccMeta()
+        a = self.aabb.detach().cpu()
+        res = torch.tensor(self.resolution, dtype=torch.float32)
+        scale = res / (a[1] - a[0])
+        for i in range(3):
+            m.aabb_min[i] = float(a[0, i])
+            m.aabb_max[i] = float(a[1, i])
+            m.scale[i] = float(scale[i])
+            m.res[i] = self.resolution[i]
+        return m
+
+    @property
+    def occ_grid(self) -> torch.Tensor:
+        """bool [X,Y,Z] view of the occupancy (``accel.occ.occ_grid``, code_single/tools/extract_occgrid.py:108)."""
+        r = self.resolution
+        return (self.occ_val > self.occ_thre).view(r[2], r[1], r[0]).permute(2, 1, 0)
+
+    def frac_occupied(self) -> float:
+        return float((self.occ_val > self.occ_thre).float().mean())
+
+    def set_all_occupied(self):
+        self.occ_val.fill_(1.0)
+        self.pack_bits()
+
+    def pack_bits(self):
+        _lib.call("nsim_occ_pack_bits", _lib.ptr(self.occ_val), self.occ_val.shape[0], self.occ_thre,
+                  _lib.ptr(self.occ_bits))
+
+    @torch.no_grad()
+    def update_from_net(self, query_sdf, num_steps=None, num_pts=None, generator=None):
+        """EMA-max refresh from random SDF queries (``init_cfg`` / ``update_from_net_cfg``)."""
+        dev = self.occ_val.device
+        lo, hi = self.aabb[0], self.aabb[1]
+        for _ in range(num_steps or self.num_steps):
+            pts = lo + torch.rand([num_pts or self.num_pts, 3], device=dev, generator=generator) * (hi - lo)
+            self.update_from_samples(pts, query_sdf(pts), pack=False)
+        self.pack_bits()
+
+    @torch.no_grad()
+    def update_from_samples(self, pts, sdf, pack=True):
+        pts = pts.detach().float().contiguous()
+        sdf = sdf.detach().float().contiguous()
+        nvox = self.occ_val.shape[0]
+        _lib.call("nsim_occ_decay", _lib.ptr(self.occ_val), nvox, self.ema_decay)
+        _lib.call("nsim_occ_update", _lib.ptr(self.occ_val), _lib.ptr(pts), _lib.ptr(sdf), pts.shape[0], self.meta,
+                  self.inv_s)
+        if pack:
+            self.pack_bits()
+
+    def init(self, query_sdf, logger=None, **kw):
+        self.occ_val.zero_()
+        self.update_from_net(query_sdf, **kw)
+
+    def cur_batch__step(self, it: int, query_sdf):
+        """``training_before_per_step`` hook (app/resources/asset_bank.py:291-298)."""
+        if it >= self.n_steps_warmup and it % self.n_steps_between_update == 0:
+            self.update_from_net(query_sdf)
+
+
+# ---------------------------------------------------------------------------------------------- model
+class LoTDNeuSModel(nn.Module):
+    is_ray_query_supported = True
+
+    def __init__(self, lod_res: Sequence[int] = None, log2_hashmap_size: int = 19, sdf_D: int = 2, W: int = 64,
+                 precision: str = "fp16", softplus_beta: float = 100.0, ln_inv_s_init: float = 0.1,
+                 ln_inv_s_factor: float = 10.0, bounding_size: float = 2.0, aabb: torch.Tensor = None,
+                 accel_cfg: dict = None, ray_query_cfg: dict = None, param_bound: float = 1e-4, seed: int = 42,
+                 device=None):
+        super().__init__()
+        assert W == 64 and sdf_D in (1, 2), "gfx950 fused kernels: hidden width 64, 1 or 2 hidden SDF layers"
+        lod_res = list(lod_res) if lod_res is not None else list(DEFAULT_LOD_RES)
+        assert len(lod_res) == 16, "gfx950 fused kernels: 16 levels x 2 features"
+        self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
+        self.encoding = LoTDEncoding(LoTDConfig(lod_res, 2, log2_hashmap_size), bound=param_bound, seed=seed)
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D)
+        g = torch.Generator().manual_seed(seed + 1)
+
+        def lin(o, i, scale=1.0):
+            b = 1.0 / math.sqrt(i)
+            return ((torch.rand(o, i, generator=g) * 2 - 1) * b * scale, (torch.rand(o, generator=g) * 2 - 1) * b * scale)
+        ws, bs = [], []
+        dims = [32] + [64] * sdf_D + [1]
+        for li in range(len(dims) - 1):
+            w, b = lin(dims[li + 1], dims[li])
+            ws.append(w.reshape(-1))
+            bs.append(b)
+        self.sdf_w = nn.Parameter(torch.cat(ws))
+        self.sdf_b = nn.Parameter(torch.cat(bs))
+        ws, bs = [], []
+        rdims = [RAD_IN, 64, 64, 3]
+        for li in range(3):
+            w, b = lin(rdims[li + 1], rdims[li])
+            ws.append(w.reshape(-1))
+            bs.append(b)
+        self.rad_w = nn.Parameter(torch.cat(ws))
+        self.rad_b = nn.Parameter(torch.cat(bs))
+        self.ln_inv_s = nn.Parameter(torch.tensor([float(ln_inv_s_init)]))
+        assert self.sdf_w.numel() == n_sdf_w and self.rad_w.numel() == n_rad_w
+        if aabb is None:
+            h = bounding_size / 2.0
+            aabb = torch.tensor([[-h, -h, -h], [h, h, h]])
+        accel_cfg = dict(accel_cfg or {})
+        self.accel = OccGridAccel(aabb, resolution=accel_cfg.get("resolution", (64, 64, 64)),
+                                  occ_thre=accel_cfg.get("occ_thre", 0.3), ema_decay=accel_cfg.get("ema_decay", 0.95),
+                                  inv_s=accel_cfg.get("occ_val_fn_cfg", {}).get("inv_s", 256.0),
+                                  num_steps=accel_cfg.get("update_from_net_cfg", {}).get("num_steps", 4),
+                                  num_pts=accel_cfg.get("update_from_net_cfg", {}).get("num_pts", 2 ** 20),
+                                  n_steps_between_update=accel_cfg.get("n_steps_between_update", 16),
+                                  n_steps_warmup=accel_cfg.get("n_steps_warmup", 256))
+        self.ray_query_cfg = dict(ray_query_cfg or dict(
+            query_mode="march_occ_multi_upsample",
+            query_param=dict(nablas_has_grad=True, num_coarse=64, num_fine=[8, 8, 32], upsample_inv_s=64.0,
+                             upsample_inv_s_factors=[1, 4, 16], upsample_use_estimate_alpha=True,
+                             march_cfg=dict(step_size=0.005, max_steps=4096))))
+        fm = _lib.FieldMeta()
+        fm.lotd = self.encoding.cfg.meta
+        fm.sdf_D = sdf_D
+        fm.precision = {"fp16": 0, "f32": 1}[precision]
+        fm.softplus_beta = float(softplus_beta)
+        self.field_meta = fm
+        self._wpack = None
+        self._wpack_versions = None
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------ bookkeeping
+    @property
+    def device(self):
+        return self.sdf_w.device
+
+    @property
+    def space_aabb(self):
+        return self.accel.aabb
+
+    def set_precision(self, precision: str):
+        self.field_meta.precision = {"fp16": 0, "f32": 1}[precision]
+        self._wpack_versions = None
+
+    def _shadow(self):
+        """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
+        grid16 = self.encoding.shadow()
+        vers = (self.sdf_w._version, self.sdf_b._version, self.rad_w._version, self.rad_b._version,
+                self.field_meta.precision, str(self.sdf_w.device))
+        if self._wpack is None or self._wpack_versions != vers:
+            lib = _lib.get_lib()
+            nbytes = int(lib.nsim_field_wpack_bytes(self.field_meta))
+            if self._wpack is None or self._wpack.numel() != nbytes or self._wpack.device != self.sdf_w.device:
+                self._wpack = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
+            _lib.call("nsim_field_pack_weights", self.field_meta, _lib.ptr(self.sdf_w.detach()),
+                      _lib.ptr(self.sdf_b.detach()), _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()),
+                      _lib.ptr(self._wpack))
+            self._wpack_versions = vers
+        return grid16, self._wpack
+
+    @torch.no_grad()
+    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25):
+        """Deterministic stand-in for the reference's SDF pre-training (``geo_init_method: pretrain_after_zero_out``,
+        ``radius_init`` -- lotd_neus.dtu.230814.yaml:125-126; app/models/single/neus.py:198-236): feature 0 of the
+        finest dense level holds |x_vertex| - radius and unit 0 of every hidden layer passes it through the linear
+        region of softplus(beta) (bias +2), so the initial SDF is a (trilinearly sampled) sphere; the remaining
+        weights keep a small random part so every gradient path is exercised."""
+        cfg = self.encoding.cfg
+        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense")
+        R = cfg.lod_res[lv]
+        ax = torch.linspace(-1.0, 1.0, R)
+        zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+        sdf = (torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) - radius).reshape(-1)
+        lvl = self.encoding.flattened_params.data[cfg.lod_offsets[lv]: cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2].view(-1, 2)
+        lvl[:, 0] = sdf.half().float().to(lvl.device)
+        D = self.sdf_D
+        w1 = self.sdf_w.data[:2048].view(64, 32)
+        w1.mul_(noise_scale)
+        w1[0].zero_()
+        w1[0, 2 * lv] = 1.0
+        self.sdf_b.data[:64].mul_(noise_scale)
+        self.sdf_b.data[0] = 2.0
+        if D == 2:
+            w2 = self.sdf_w.data[2048:2048 + 4096].view(64, 64)
+            w2.mul_(noise_scale)
+            w2[0].zero_()
+            w2[0, 0] = 1.0
+            self.sdf_b.data[64:128].mul_(noise_scale)
+            self.sdf_b.data[64] = 0.0
+        wh = self.sdf_w.data[-64:]
+        wh.mul_(noise_scale * 0.05)
+        wh[0] = 1.0
+        self.sdf_b.data[-1] = -2.0
+        self.encoding.flattened_params.add_(0)      # bump versions: refresh fp16 shadow / weight pack lazily
+        self.sdf_w.add_(0)
+        return self
+
+    def forward_inv_s(self) -> torch.Tensor:
+        return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
+
+    # ------------------------------------------------------------------ point queries
+    @torch.no_grad()
+    def query_sdf(self, x: torch.Tensor) -> torch.Tensor:
+        """No-grad SDF at points in [-1,1]^3 (inspect_rendering.py:120-128)."""
+        shape = x.shape[:-1]
+        x = x.detach().float().reshape(-1, 3).contiguous()
+        grid16, wpack = self._shadow()
+        sdf = torch.zeros([x.shape[0]], dtype=torch.float32, device=x.device)
+        _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), None, None, None,
+                  None, x.shape[0], _lib.ptr(sdf))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_field_sdf", x.shape[0])
+        return sdf.reshape(shape)
+
+    @torch.no_grad()
+    def _query_sdf_rays(self, rays_o, rays_d, t, ridx):
+        grid16, wpack = self._shadow()
+        sdf = torch.zeros([t.shape[0]], dtype=torch.float32, device=t.device)
+        _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), t.shape[0], _lib.ptr(sdf))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_field_sdf", t.shape[0])
+        return sdf
+
+    def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
+        shape = x.shape[:-1]
+        xf = x.detach().float().reshape(-1, 3).contiguous()
+        sdf, nablas = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w,
+                                     self.rad_b, None, xf, None, None, None, None, False)
+        if not nablas_has_grad:
+            nablas = nablas.detach()
+        return dict(sdf=sdf.reshape(shape), nablas=nablas.reshape(*shape, 3))
+
+    def forward_sdf(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return dict(sdf=self.forward_sdf_nablas(x, nablas_has_grad=False)["sdf"])
+
+    def sample_pts_uniform(self, num_pts: int, generator=None) -> Dict[str, torch.Tensor]:
+        """Random points in the AABB -> forward_sdf_nablas (code_single/tools/train.py:602-613)."""
+        lo, hi = self.accel.aabb[0], self.accel.aabb[1]
+        x = lo + torch.rand([num_pts, 3], device=self.device, generator=generator) * (hi - lo)
+        ret = self.forward_sdf_nablas(x)
+        ret["net_x"] = x
+        return ret
+
+    # ------------------------------------------------------------------ rays
+    def ray_test(self, rays_o, rays_d, near=None, far=None, **extra) -> Dict:
+        """AABB slab test + compaction of the hit rays (single_volume_renderer.py:235-238)."""
+        rays_o = rays_o.float().contiguous()
+        rays_d = rays_d.float().contiguous()
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        near_t = torch.zeros([N], dtype=torch.float32, device=dev)
+        far_t = torch.zeros([N], dtype=torch.float32, device=dev)
+        hit = torch.zeros([N], dtype=torch.uint8, device=dev)
+        _lib.call("nsim_aabb_ray_test", _lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), N, self.accel.meta,
+                  float(near) if near is not None else 0.0, float(far) if far is not None else -1.0, _lib.ptr(near_t),
+                  _lib.ptr(far_t), _lib.ptr(hit))
+        rays_inds = hit.nonzero()[:, 0]     # host sync #1 (the reference compacts here as well)
+        ret = dict(num_rays=int(rays_inds.shape[0]), rays_inds=rays_inds, rays_o=rays_o[rays_inds],
+                   rays_d=rays_d[rays_inds], near=near_t[rays_inds], far=far_t[rays_inds])
+        for k, v in extra.items():
+            ret[k] = v[rays_inds] if isinstance(v, torch.Tensor) and v.shape[:1] == (N,) else v
+        return ret
+
+    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c):
+        """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling."""
+        R = o.shape[0]
+        dev = o.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        march = qp.get("march_cfg", {})
+        step, max_steps = float(march.get("step_size", 0.005)), int(march.get("max_steps", 4096))
+        C = int(qp.get("num_coarse", 64))
+        bits, occm = self.accel.occ_bits, self.accel.meta
+        counts = torch.zeros([R], dtype=torch.long, device=dev)
+        _lib.call("nsim_march_count", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
+                  _lib.ptr(bits), occm, step, max_steps, _lib.ptr(counts))
+        pi_m, total = po.get_pack_infos_from_n(counts, return_total=True)
+        M = int(total.item())               # host sync #2: size of the marched set
+        t_m = torch.zeros([max(M, 1)], **f32)
+        _lib.call("nsim_march_emit", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
+                  _lib.ptr(bits), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
+        t_c = torch.zeros([R, C], **f32)
+        _lib.call("nsim_coarse_depths", _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter_c), R, C, _lib.ptr(t_c))
+        S = M + R * C
+        t = torch.zeros([S], **f32)
+        pi = torch.zeros([R, 2], dtype=torch.long, device=dev)
+        _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
+                  _lib.ptr(pi))
+        ar = torch.arange(R, device=dev)
+        ridx = torch.repeat_interleave(ar, pi[:, 1], output_size=S)
+        sdf = self._query_sdf_rays(o, d, t, ridx)
+        inv_s0 = float(qp.get("upsample_inv_s", 64.0))
+        use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
+        for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
+            nf = int(nf)
+            t_new = torch.zeros([R, nf], **f32)
+            scratch = torch.zeros([S], **f32)
+            _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
+                      _lib.ptr(scratch), _lib.ptr(t_new))
+            ridx_new = ar.repeat_interleave(nf)
+            sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new)
+            S2 = S + R * nf
+            t2 = torch.zeros([S2], **f32)
+            sdf2 = torch.zeros([S2], **f32)
+            pi2 = torch.zeros([R, 2], dtype=torch.long, device=dev)
+            _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
+                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2))
+            t, sdf, pi, S = t2, sdf2, pi2, S2
+        ridx = torch.repeat_interleave(ar, pi[:, 1], output_size=S)
+        self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
+        return t, sdf, pi, ridx, counts
+
+    def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,
+                  return_details: bool = False, render_per_obj_individual: bool = False) -> Dict:
+        """``query_mode = march_occ_multi_upsample`` (single_volume_renderer.py:244-246)."""
+        cfg = dict(config)
+        qp = dict(cfg.get("query_param", self.ray_query_cfg.get("query_param", {})))
+        with_rgb = cfg.get("with_rgb", True)
+        with_normal = cfg.get("with_normal", False)
+        ret = dict()
+        R = ray_tested["num_rays"]
+        if R == 0:
+            ret["volume_buffer"] = dict(type="empty")
+            if return_details:
+                ret["details"] = dict()
+            return ret
+        o = ray_tested["rays_o"].detach().float().contiguous()
+        d = ray_tested["rays_d"].detach().float().contiguous()
+        near, far = ray_tested["near"].contiguous(), ray_tested["far"].contiguous()
+        dev = o.device
+        perturb = cfg.get("perturb", False)
+        jitter = cfg.get("_jitter", None)
+        jitter_c = cfg.get("_jitter_c", None)
+        if jitter is None and perturb:
+            jitter = torch.rand([R], device=dev)
+            jitter_c = torch.rand([R, int(qp.get("num_coarse", 64))], device=dev)
+        if jitter is not None:
+            jitter = jitter.float().contiguous()
+        if jitter_c is not None:
+            jitter_c = jitter_c.float().contiguous()
+        with torch.no_grad():
+            t, sdf_ng, pi, ridx, march_counts = self._sample(o, d, near, far, qp, jitter, jitter_c)
+        h_appear = ray_tested.get("rays_h_appear", None)
+        outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
+                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb))
+        sdf, nablas = outs[0], outs[1]
+        rgb = outs[2] if with_rgb else None
+        if not qp.get("nablas_has_grad", True):
+            nablas = nablas.detach()
+        fis = cfg.get("forward_inv_s", None)
+        alpha = _NeusAlphaFn.apply(sdf, self.ln_inv_s, pi, self.ln_inv_s_factor, float(fis) if fis else 0.0)
+        vb = dict(type="packed", rays_inds_hit=ray_tested["rays_inds"], pack_infos_hit=pi, t=t, opacity_alpha=alpha,
+                  nablas=nablas, sdf=sdf)
+        if with_rgb:
+            vb["rgb"] = rgb
+        ret["volume_buffer"] = vb
+        if render_per_obj_individual or cfg.get("_render", False):
+            ret["rendered"] = volume_integration(alpha, t, rgb, nablas if (with_normal or cfg.get("_render", False)) else None,
+                                                 pi, cfg.get("depth_use_normalized_vw", True))
+        if return_details:
+            ret["details"] = dict(march_counts=march_counts, sdf_nograd=sdf_ng, ridx=ridx)
+        return ret

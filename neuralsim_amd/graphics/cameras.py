@@ -1,0 +1,39 @@
+"""Pinhole ray generation -- mirrors ``Camera.get_selected_rays`` / ``_get_selected_rays_from_ixy``
+(app/resources/observers/cameras.py:281-330) on top of csrc/sampling.hip::k_raygen_pinhole."""
+import torch
+
+from .. import _lib
+
+
+def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
+                          WH: torch.Tensor, snap_to_pixel_centers: bool = True):
+    """xy [N,2] in [0,1], fidx [N] int64, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] int64 -> rays_o, rays_d [N,3]."""
+    N = xy.shape[0]
+    o = torch.zeros([N, 3], dtype=torch.float32, device=xy.device)
+    d = torch.zeros([N, 3], dtype=torch.float32, device=xy.device)
+    _lib.call("nsim_raygen_pinhole", _lib.ptr(xy.float().contiguous()), _lib.ptr(fidx.long().contiguous()),
+              _lib.ptr(intr.float().contiguous()), _lib.ptr(c2w.float().contiguous()), _lib.ptr(WH.long().contiguous()),
+              N, 1 if snap_to_pixel_centers else 0, _lib.ptr(o), _lib.ptr(d))
+    return o, d
+
+
+def look_at_cameras(V=100, radius=3.0, H=800, W=800, f=1111.1, seed=42, device=None):
+    """Synthetic posed-camera rig of SURVEY.md sec. 8d: V pinhole views (OpenCV convention, +z forward, +y down)
+    on a sphere of ``radius`` around the AABB, looking at the origin."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    c2w = torch.eye(4).repeat(V, 1, 1)
+    for i in range(V):
+        u = torch.rand(2, generator=g)
+        th, ph = float(2 * math.pi * u[0]), float(math.acos(1 - 2 * (0.15 + 0.7 * float(u[1]))))
+        eye = radius * torch.tensor([math.sin(ph) * math.cos(th), math.cos(ph), math.sin(ph) * math.sin(th)])
+        fwd = -eye / eye.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, -1.0, 0.0]))
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)
+        c2w[i, :3, 0], c2w[i, :3, 1], c2w[i, :3, 2], c2w[i, :3, 3] = right, down, fwd, eye
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]]).repeat(V, 1, 1)
+    WH = torch.tensor([[W, H]], dtype=torch.long).repeat(V, 1)
+    if device is not None:
+        intr, c2w, WH = intr.to(device), c2w.to(device), WH.to(device)
+    return intr, c2w, WH

@@ -1,0 +1,50 @@
+"""Fused Adam over the model's flat f32 master parameters (csrc/optim.hip).
+
+Mirrors the reference's optimizer setup ``training_cfg{lr, eps 1e-15, betas [0.9, 0.99], invs_betas [0.9, 0.999]}``
+(code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:178-184; step at code_single/tools/train.py:1494-1502).
+The LoTD table update also refreshes the fp16 shadow the gather kernels read, in the same pass.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), eps=1e-15):
+        self.model = model
+        self.lr, self.eps = lr, eps
+        self.groups = []
+        enc = model.encoding
+        enc.shadow()
+        self.groups.append(dict(p=enc.flattened_params, p16=lambda: enc.params16, betas=betas))
+        for p in (model.sdf_w, model.sdf_b, model.rad_w, model.rad_b):
+            self.groups.append(dict(p=p, p16=None, betas=betas))
+        self.groups.append(dict(p=model.ln_inv_s, p16=None, betas=invs_betas))
+        for g in self.groups:
+            g["m"] = torch.zeros_like(g["p"], dtype=torch.float32)
+            g["v"] = torch.zeros_like(g["p"], dtype=torch.float32)
+        self.t = 0
+
+    def params(self) -> List[torch.Tensor]:
+        return [g["p"] for g in self.groups]
+
+    @torch.no_grad()
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        for g in self.groups:
+            p = g["p"]
+            if p.grad is None:
+                continue
+            b1, b2 = g["betas"]
+            p16 = g["p16"]() if g["p16"] is not None else None
+            _lib.call("nsim_adam_step", _lib.ptr(p.data), _lib.ptr(p16), _lib.ptr(p.grad.contiguous()), _lib.ptr(g["m"]),
+                      _lib.ptr(g["v"]), p.numel(), float(lr), float(b1), float(b2), float(self.eps),
+                      1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(grad_scale), 0)
+        self.model._wpack_versions = None      # MLP weights changed in place: re-pack the MFMA fragments lazily
+
+    def zero_grad(self):
+        for g in self.groups:
+            g["p"].grad = None

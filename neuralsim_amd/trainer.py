@@ -1,0 +1,91 @@
+"""One training iteration of the NeuS render step: ray generation -> ray_test -> ray_query -> volume
+integration -> losses -> backward -> gradient all-reduce -> Adam (+ the periodic occupancy refresh).
+
+Follows ``Trainer.train_step_pixel`` and the main loop of the reference
+(code_single/tools/train.py:544-696, 1444-1502): photometric ``mse`` on the rendered rgb
+(app/loss/photometric.py:88-146), eikonal on the render samples and on uniformly sampled points
+(app/loss/eikonal.py:216-251; ``num_uniform`` code_single/tools/train.py:602-613), per-frame appearance
+embeddings (app/models/scene/image_embeddings.py:23-80).  Data is synthetic (posed pinhole cameras of
+SURVEY.md sec. 8d, random target colours).
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, distributed as ndist
+from .fields.neus import LoTDNeuSModel, volume_integration
+from .graphics.cameras import pinhole_selected_rays
+from .optim import FusedAdam
+
+
+class RenderTrainer:
+    def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
+                 num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
+                 perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42):
+        self.model = model
+        self.intr, self.c2w, self.WH = intr, c2w, WH
+        self.V = intr.shape[0]
+        self.num_rays = num_rays             # rays per rank per iteration (weak scaling, as the reference's DDP)
+        self.w_eikonal, self.num_uniform = w_eikonal, num_uniform
+        self.near, self.far, self.perturb = near, far, perturb
+        self.rank, self.world_size = rank, world_size
+        dev = model.device
+        self.gen = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)
+        self.gen_shared = torch.Generator(device=dev).manual_seed(seed)     # rank-shared (occupancy refresh)
+        g = torch.Generator().manual_seed(seed)
+        self.appear = nn.Parameter((torch.randn(self.V, n_appear, generator=g) * 0.1).to(dev))
+        self.optim = FusedAdam(model, lr=lr)
+        self.optim.groups.append(dict(p=self.appear, p16=None, betas=(0.9, 0.99), m=torch.zeros_like(self.appear),
+                                      v=torch.zeros_like(self.appear)))
+        self.stats: Dict[str, float] = {}
+
+    def sample_batch(self):
+        dev = self.model.device
+        N = self.num_rays
+        xy = torch.rand([N, 2], device=dev, generator=self.gen).clamp_(1e-6, 1 - 1e-6)   # cameras.py:247
+        fidx = torch.randint(0, self.V, [N], device=dev, generator=self.gen)
+        gt = torch.rand([N, 3], device=dev, generator=self.gen)
+        return xy, fidx, gt
+
+    def render(self, xy, fidx, with_normal=True):
+        rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
+        h_appear = self.appear[fidx]
+        tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far, rays_h_appear=h_appear)
+        cfg = dict(self.model.ray_query_cfg)
+        cfg.update(with_rgb=True, with_normal=with_normal, perturb=self.perturb, depth_use_normalized_vw=False,
+                   _render=True)
+        ret = self.model.ray_query(ray_tested=tested, config=cfg, return_details=True)
+        return tested, ret
+
+    def loss(self, tested, ret, gt):
+        N = gt.shape[0]
+        dev = gt.device
+        rgb_full = torch.zeros([N, 3], dtype=torch.float32, device=dev)
+        eik = torch.zeros([], device=dev)
+        if tested["num_rays"] > 0:
+            rgb_full = rgb_full.index_put((tested["rays_inds"],), ret["rendered"]["rgb_volume"])
+            nab = ret["volume_buffer"]["nablas"]
+            eik = ((nab.norm(dim=-1) - 1.0) ** 2).mean()
+        loss_rgb = ((rgb_full - gt) ** 2).mean()
+        if self.num_uniform > 0:
+            uni = self.model.sample_pts_uniform(self.num_uniform, generator=self.gen)
+            eik = eik + ((uni["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+        return loss_rgb + self.w_eikonal * eik, dict(loss_rgb=loss_rgb.detach(), loss_eikonal=eik.detach())
+
+    def train_step(self, it: int) -> torch.Tensor:
+        model = self.model
+        # training_before_per_step: occupancy refresh with a rank-shared seed keeps replicas consistent
+        acc = model.accel
+        if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
+            acc.update_from_net(model.query_sdf, generator=self.gen_shared)
+        xy, fidx, gt = self.sample_batch()
+        tested, ret = self.render(xy, fidx)
+        loss, parts = self.loss(tested, ret, gt)
+        self.optim.zero_grad()
+        loss.backward()
+        ndist.allreduce_grads(self.optim.params(), average=True)
+        self.optim.step()
+        vb = ret["volume_buffer"]
+        self.stats = dict(R_hit=tested["num_rays"], S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
+        return loss.detach()

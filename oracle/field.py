@@ -19,7 +19,8 @@ from typing import List, Optional
 import torch
 import torch.nn.functional as F
 
-from .lotd import LoTDSpec, lotd_forward, init_params_uniform, write_sphere_level0, make_lotd_spec
+from .lotd import (LoTDSpec, lotd_forward, init_params_uniform, write_sphere_level, make_lotd_spec,
+                   finest_dense_level)
 
 SOFTPLUS_BETA = 100.0
 RAD_IN = 26          # 3 + 16 + 3 + 4
@@ -105,12 +106,13 @@ def make_field_params(lod_res=None, n_feats=2, log2_hashmap_size=19, sdf_D=2, W=
         sdf_w.append(w)
         sdf_b.append(b)
     if sphere_init:
-        grid = write_sphere_level0(grid, spec, radius_init)
-        # unit 0 of every hidden layer carries (level0 feat0) + 2 through the linear region of
+        grid = write_sphere_level(grid, spec, radius_init)
+        f_in = 2 * finest_dense_level(spec)
+        # unit 0 of every hidden layer carries (sphere level, feat 0) + 2 through the linear region of
         # softplus(beta=100) (exactly linear above the threshold 20/beta); output subtracts the 2.
         for li in range(sdf_D):
             sdf_w[li][0].zero_()
-            sdf_w[li][0, 0] = 1.0
+            sdf_w[li][0, f_in if li == 0 else 0] = 1.0
             sdf_b[li][0] = 2.0 if li == 0 else 0.0
         sdf_w[-1][0] *= 0.05
         sdf_w[-1][0, 0] = 1.0

@@ -113,17 +113,22 @@ def init_params_uniform(spec: LoTDSpec, bound: float = 1e-4, seed: int = 42) -> 
     return p.half()
 
 
-def write_sphere_level0(params: torch.Tensor, spec: LoTDSpec, radius: float = 0.5):
-    """Synthetic geometric init: feature 0 of (dense) level 0 := |x_vertex| - radius, so that a
+def finest_dense_level(spec: LoTDSpec) -> int:
+    return max(l for l, t in enumerate(spec.lod_types) if t == 'Dense')
+
+
+def write_sphere_level(params: torch.Tensor, spec: LoTDSpec, radius: float = 0.5, level: int = None):
+    """Synthetic geometric init: feature 0 of a dense level (default: the finest one) := |x_vertex| - radius, so that a
     pass-through decoder yields a sphere SDF of ``radius_init`` (lotd_neus.dtu.230814.yaml:125).
     The reference reaches the same state by 500 iterations of SDF pre-training
     (app/models/single/neus.py:198-236); this is the deterministic stand-in used for synthetic weights."""
-    R = spec.lod_res[0]
-    assert spec.lod_types[0] == 'Dense'
+    level = finest_dense_level(spec) if level is None else level
+    R = spec.lod_res[level]
+    assert spec.lod_types[level] == 'Dense'
     F = spec.n_feats
     ax = torch.linspace(-1.0, 1.0, R)
     zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing='ij')  # index = x + R*(y + R*z)
     sdf = torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) - radius
-    lvl = params[spec.lod_offsets[0]: spec.lod_offsets[0] + spec.lod_sizes[0] * F].view(-1, F)
+    lvl = params[spec.lod_offsets[level]: spec.lod_offsets[level] + spec.lod_sizes[level] * F].view(-1, F)
     lvl[:, 0] = sdf.reshape(-1).to(params.dtype)
     return params

@@ -1,0 +1,133 @@
+"""LoTD encoding and the fused MFMA field kernels (forward, backward incl. the second-order normal terms)
+vs the oracle (oracle/lotd.py, oracle/field.py)."""
+import pytest
+import torch
+
+from oracle import field as ofield, lotd as olotd
+from neuralsim_amd import _lib
+from neuralsim_amd.fields.neus import _FieldFn
+from neuralsim_amd.grid_encodings.lotd import LoTDConfig, LoTDEncoding, gen_ngp_res
+from util import leaf, make_params, model_from_params, oracle_flat_grads, rel_l2
+
+
+def test_gen_ngp_matches_reference_comment():
+    # lotd_neus.dtu.230814.yaml:97
+    assert gen_ngp_res(16, 2048, 16) == [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+    cfg = LoTDConfig(gen_ngp_res(16, 2048, 16), 2, 19)
+    assert cfg.n_params == 12196216 and cfg.lod_types.count("Dense") == 5
+
+
+def test_mfma_selftest(backend):
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(32, 16, generator=g)
+    B = torch.randn(16, 32, generator=g)          # asymmetric on purpose (CDNA4 guide sec. 3)
+    for use_f32 in (0, 1):
+        D = torch.zeros(32, 32, device=backend)
+        _lib.call("nsim_selftest_mfma", _lib.ptr(A.to(backend)), _lib.ptr(B.to(backend)), _lib.ptr(D), use_f32)
+        ref = (A.half().float() @ B.half().float()) if not use_f32 else A @ B
+        assert torch.allclose(D.cpu(), ref, atol=1e-4 if use_f32 else 2e-3), use_f32
+
+
+def test_lotd_fwd_dydx_bwd(backend):
+    p = make_params(small=True, sphere=False, grid_bound=0.5)
+    spec = p.spec
+    g = torch.Generator().manual_seed(1)
+    S = 257
+    x = torch.rand(S, 3, generator=g) * 2 - 1
+    x[0] = torch.tensor([-1.0, -1.0, -1.0]); x[1] = torch.tensor([1.0, 1.0, 1.0]); x[2] = torch.tensor([0.0, 1.0, -1.0])
+    enc = LoTDEncoding(LoTDConfig(spec.lod_res, 2, 12)).to(backend)
+    with torch.no_grad():
+        enc.flattened_params.copy_(p.grid.to(backend))
+    xo = leaf(x)
+    grid_o = leaf(p.grid)
+    h_ref = olotd.lotd_forward(xo, grid_o, spec)
+    h, dydx = enc.forward_dydx(x.to(backend))
+    assert torch.allclose(h.cpu(), h_ref, atol=1e-6)
+    # d h / d x via autograd on the oracle, one output feature at a time for a few features
+    for f in (0, 7, 16, 31):
+        gx = torch.autograd.grad(h_ref[:, f].sum(), xo, retain_graph=True)[0]
+        assert torch.allclose(dydx.cpu()[3:, f], gx[3:], atol=2e-4, rtol=1e-4), f
+    # backward to the grid: first-order and the dy/dx (second-order) path
+    w_h = torch.randn(S, 32, generator=g)
+    w_j = torch.randn(S, 32, 3, generator=g)
+    xo2 = leaf(x)
+    h2 = olotd.lotd_forward(xo2, grid_o, spec)
+    J_rows = []
+    loss_ref = (h2 * w_h).sum()
+    # sum_f,d w_j[s,f,d] * d h[s,f]/d x[s,d]  == grad of (h * 1) contracted; build with create_graph
+    for f in range(32):
+        gx = torch.autograd.grad(h2[:, f].sum(), xo2, create_graph=True)[0]
+        loss_ref = loss_ref + (gx * w_j[:, f]).sum()
+    loss_ref.backward()
+    h3, dydx3 = enc.forward_dydx(x.to(backend))
+    ((h3 * w_h.to(backend)).sum() + (dydx3 * w_j.to(backend)).sum()).backward()
+    assert rel_l2(enc.flattened_params.grad.cpu(), grid_o.grad) < 1e-5
+
+
+@pytest.mark.parametrize("sdf_D", [1, 2])
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_field_fwd_bwd(backend, sdf_D, precision):
+    p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=5, noise_scale=1.0)
+    for t in p.tensors():
+        t.requires_grad_(True)
+    model = model_from_params(p, backend, precision=precision)
+    g = torch.Generator().manual_seed(2)
+    R, S = 7, 77                                  # 2.4 tiles: exercises the ragged last tile
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    ha_d = leaf(h_appear, backend)
+    dv = lambda a: a.to(backend).contiguous()
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    tol = dict(f32=(2e-5, 2e-4, 2e-5), fp16=(4e-3, 5e-2, 4e-3))[precision]
+    assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < tol[1] * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < tol[2]
+    # no-grad SDF kernel agrees with the with-grad one
+    assert torch.allclose(model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu(), sdf.cpu().detach(), atol=1e-6)
+    assert torch.allclose(model.query_sdf(dv(x)).cpu(), sdf.cpu().detach(), atol=2e-5 if precision == "f32" else 4e-3)
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    gtol = dict(f32=2e-4, fp16=3e-2)[precision]
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < gtol, (k, e)
+    assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < gtol
+
+
+@pytest.mark.parametrize("which", ["sdf_only", "nablas_only", "no_rgb"])
+def test_field_partial_upstream(backend, which):
+    """Each upstream gradient alone (isolates the second-order path) and the with_rgb=False variant
+    (lidar batches, code_single/tools/train.py:896-902)."""
+    p = make_params(sdf_D=2, small=True, sphere=False, grid_bound=0.3, seed=9, noise_scale=1.0)
+    for t in p.tensors():
+        t.requires_grad_(True)
+    model = model_from_params(p, backend, precision="f32")
+    g = torch.Generator().manual_seed(4)
+    S = 40
+    x = torch.rand(S, 3, generator=g) * 1.6 - 0.8
+    sdf_r, nab_r = ofield.forward_sdf_nablas(x, p)
+    out = model.forward_sdf_nablas(x.to(backend))
+    assert torch.allclose(out["sdf"].cpu(), sdf_r, atol=2e-5) and torch.allclose(out["nablas"].cpu(), nab_r, atol=5e-4)
+    ws, wn = torch.randn(S, generator=g), torch.randn(S, 3, generator=g)
+    if which == "sdf_only":
+        (sdf_r * ws).sum().backward(); (out["sdf"] * ws.to(backend)).sum().backward()
+    elif which == "nablas_only":
+        (nab_r * wn).sum().backward(); (out["nablas"] * wn.to(backend)).sum().backward()
+    else:
+        ((nab_r.norm(dim=-1) - 1) ** 2).mean().add((sdf_r * ws).sum()).backward()
+        ((out["nablas"].norm(dim=-1) - 1) ** 2).mean().add((out["sdf"] * ws.to(backend)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    for k, v in dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad).items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < 2e-4, (which, k, e)

@@ -1,0 +1,184 @@
+"""Ray generation, AABB test, occupancy marching, up-sampling, sdf->alpha and fused compositing vs the oracle."""
+import torch
+
+from oracle import pack_ops as opo, render as orr
+from neuralsim_amd import _lib
+from neuralsim_amd.fields.neus import OccGridAccel, _NeusAlphaFn, volume_integration
+from neuralsim_amd.graphics import pack_ops as po
+from util import leaf, look_at_cameras
+
+AABB = torch.tensor([[-1.0, -1, -1], [1.0, 1, 1]])
+
+
+def _rays(N=300, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    intr, c2w, WH = look_at_cameras(V=5, seed=seed)
+    xy = torch.rand(N, 2, generator=g)
+    fidx = torch.randint(0, 5, (N,), generator=g)
+    return xy, fidx, intr, c2w, WH
+
+
+def test_raygen_and_aabb(backend):
+    xy, fidx, intr, c2w, WH = _rays()
+    o_ref, d_ref = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
+    N = xy.shape[0]
+    o = torch.zeros(N, 3, device=backend)
+    d = torch.zeros(N, 3, device=backend)
+    _lib.call("nsim_raygen_pinhole", _lib.ptr(xy.to(backend)), _lib.ptr(fidx.to(backend)), _lib.ptr(intr.to(backend)),
+              _lib.ptr(c2w.to(backend)), _lib.ptr(WH.to(backend)), N, 1, _lib.ptr(o), _lib.ptr(d))
+    assert torch.allclose(o.cpu(), o_ref, atol=0) and torch.allclose(d.cpu(), d_ref, atol=2e-7)
+    # zoom some rays out of the box
+    o_ref[::3] += torch.tensor([0.0, 5.0, 0.0])
+    acc = OccGridAccel(AABB, device=backend)
+    n_ref, f_ref, hit_ref = orr.aabb_ray_test(o_ref, d_ref, AABB[0], AABB[1], 0.01, None)
+    nt = torch.zeros(N, device=backend); ft = torch.zeros(N, device=backend)
+    hit = torch.zeros(N, dtype=torch.uint8, device=backend)
+    _lib.call("nsim_aabb_ray_test", _lib.ptr(o_ref.to(backend)), _lib.ptr(d_ref.to(backend)), N, acc.meta, 0.01, -1.0,
+              _lib.ptr(nt), _lib.ptr(ft), _lib.ptr(hit))
+    assert torch.equal(hit.cpu().bool(), hit_ref)
+    assert 0 < int(hit_ref.sum()) < N
+    assert torch.allclose(nt.cpu()[hit_ref], n_ref[hit_ref], atol=1e-6) and torch.allclose(ft.cpu()[hit_ref], f_ref[hit_ref], atol=1e-6)
+
+
+def _sphere_occ(res=(64, 64, 64), shell=0.03):
+    ax = [(torch.arange(r) + 0.5) / r * 2 - 1 for r in res]
+    zz, yy, xx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    occ = ((xx ** 2 + yy ** 2 + zz ** 2).sqrt() - 0.5).abs() < shell
+    return occ.reshape(-1)
+
+
+def test_march_bit_exact(backend):
+    xy, fidx, intr, c2w, WH = _rays(N=200, seed=3)
+    o, d = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
+    near, far, hit = orr.aabb_ray_test(o, d, AABB[0], AABB[1], 0.01, None)
+    o, d, near, far = o[hit], d[hit], near[hit], far[hit]
+    R = o.shape[0]
+    occ = _sphere_occ()
+    res = torch.tensor([64, 64, 64])
+    scale = res.float() / (AABB[1] - AABB[0])
+    g = torch.Generator().manual_seed(0)
+    for jitter in (None, torch.rand(R, generator=g)):
+        jit = jitter if jitter is not None else torch.full((R,), 0.5)
+        t_ref, ridx_ref, cnt_ref = orr.march_lattice(o, d, near, far, jit, occ, AABB[0], scale, res, 0.005, 4096)
+        acc = OccGridAccel(AABB, device=backend)
+        acc.occ_val.copy_(occ.float().to(backend))
+        acc.pack_bits()
+        dv = lambda t: t.to(backend).contiguous()
+        counts = torch.zeros(R, dtype=torch.long, device=backend)
+        jp = _lib.ptr(dv(jitter)) if jitter is not None else None
+        args = (_lib.ptr(dv(o)), _lib.ptr(dv(d)), _lib.ptr(dv(near)), _lib.ptr(dv(far)), jp, R, _lib.ptr(acc.occ_bits),
+                acc.meta, 0.005, 4096)
+        _lib.call("nsim_march_count", *args, _lib.ptr(counts))
+        assert torch.equal(counts.cpu(), cnt_ref)          # bit-exact sample membership
+        assert int(cnt_ref.sum()) > 0
+        pi = po.get_pack_infos_from_n(counts)
+        t = torch.zeros(int(cnt_ref.sum()), device=backend)
+        _lib.call("nsim_march_emit", *args, _lib.ptr(pi), _lib.ptr(t))
+        assert torch.equal(t.cpu(), t_ref)
+    # max_steps clamp
+    t_ref, _, cnt_ref = orr.march_lattice(o, d, near, far, torch.full((R,), 0.5), torch.ones_like(occ), AABB[0], scale, res, 0.005, 100)
+    acc.set_all_occupied()
+    args = args[:4] + (None,) + args[5:-1]
+    _lib.call("nsim_march_count", *args, 100, _lib.ptr(counts))
+    assert torch.equal(counts.cpu(), cnt_ref) and int(cnt_ref.max()) == 100
+
+
+def test_occ_update_and_bits(backend):
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(5000, 3, generator=g) * 2.2 - 1.1     # some outside
+    sdf = pts.norm(dim=-1) - 0.5
+    res = torch.tensor([16, 8, 4])
+    scale = res.float() / (AABB[1] - AABB[0])
+    val0 = torch.rand(16 * 8 * 4, generator=g) * 0.5
+    ref = orr.occ_update(val0, pts, sdf, AABB[0], scale, res, decay=0.95, inv_s=64.0)
+    acc = OccGridAccel(AABB, resolution=(16, 8, 4), inv_s=64.0, device=backend)
+    acc.occ_val.copy_(val0.to(backend))
+    acc.update_from_samples(pts.to(backend), sdf.to(backend))
+    assert torch.allclose(acc.occ_val.cpu(), ref, atol=1e-6)
+    bits = acc.occ_bits.cpu().numpy().view("uint32")
+    occ = (ref > 0.3).numpy()
+    for v in range(occ.shape[0]):
+        assert bool((bits[v >> 5] >> (v & 31)) & 1) == bool(occ[v])
+
+
+def test_coarse_upsample_merge(backend):
+    g = torch.Generator().manual_seed(7)
+    R, C = 23, 64
+    near = torch.rand(R, generator=g) * 0.5 + 2.0
+    far = near + 1.0 + torch.rand(R, generator=g)
+    jc = torch.rand(R, C, generator=g)
+    dv = lambda t: t.to(backend).contiguous()
+    for j in (None, jc):
+        out = torch.zeros(R, C, device=backend)
+        _lib.call("nsim_coarse_depths", _lib.ptr(dv(near)), _lib.ptr(dv(far)), _lib.ptr(dv(j)) if j is not None else None,
+                  R, C, _lib.ptr(out))
+        assert torch.equal(out.cpu(), orr.coarse_depths(near, far, C, j))
+    # ragged packs incl. > 64 samples; sdf of a sphere crossing
+    n = torch.randint(2, 200, (R,), generator=g)
+    n[0], n[1], n[2] = 2, 64, 65
+    pi = opo.get_pack_infos_from_n(n)
+    S = int(n.sum())
+    ridx = opo.pack_ridx(pi, S)
+    u = torch.rand(S, generator=g)
+    t = near[ridx] + u * (far - near)[ridx]
+    t, _ = opo.packed_sort(t, pi)
+    sdf = (t - (near + 0.6 * (far - near))[ridx]) * -0.7 + 0.01 * torch.randn(S, generator=g)
+    for use_est in (True, False):
+        for inv_s, nf in ((64.0, 8), (1024.0, 32), (256.0, 70)):
+            ref = orr.upsample_stage(t, sdf, pi, inv_s, nf, use_est)
+            t_new = torch.zeros(R, nf, device=backend)
+            scratch = torch.zeros(S, device=backend)
+            _lib.call("nsim_upsample_stage", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, inv_s, nf,
+                      1 if use_est else 0, _lib.ptr(scratch), _lib.ptr(t_new))
+            assert torch.allclose(t_new.cpu(), ref, atol=2e-5), (use_est, inv_s, nf, (t_new.cpu() - ref).abs().max())
+            assert (t_new.cpu()[:, 1:] >= t_new.cpu()[:, :-1]).all()
+    # merge
+    nf = 8
+    t_b = orr.upsample_stage(t, sdf, pi, 64.0, nf, True)
+    t_b[3, 2] = t[int(pi[3, 0]) + 1]      # exact tie: a-first
+    t_b, _ = t_b.sort(dim=1)
+    v_b = torch.randn(R, nf, generator=g)
+    t_ref, pi_ref, pa, pb = orr.merge_sorted(t, pi, t_b)
+    v_ref = torch.empty_like(t_ref); v_ref[pa] = sdf; v_ref[pb.reshape(-1)] = v_b.reshape(-1)
+    t_out = torch.zeros(S + R * nf, device=backend); v_out = torch.zeros_like(t_out)
+    pi_out = torch.zeros(R, 2, dtype=torch.long, device=backend)
+    _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
+              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out))
+    assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
+
+
+def test_neus_alpha_and_composite(backend):
+    g = torch.Generator().manual_seed(11)
+    P = 19
+    n = torch.randint(1, 150, (P,), generator=g)
+    n[2], n[5] = 1, 130
+    pi = opo.get_pack_infos_from_n(n)
+    S = int(n.sum())
+    ridx = opo.pack_ridx(pi, S)
+    t = opo.packed_sort(torch.rand(S, generator=g) * 3, pi)[0]
+    sdf = 0.2 - 0.15 * (t - 1.0) + 0.01 * torch.randn(S, generator=g)
+    rgb = torch.rand(S, 3, generator=g)
+    nrm = torch.randn(S, 3, generator=g)
+    ln_inv_s = torch.tensor([0.35])
+    for fis in (0.0, 50.0):
+        for nd in (False, True):
+            s_o, l_o, r_o, n_o = leaf(sdf, dtype=torch.double), leaf(ln_inv_s, dtype=torch.double), leaf(rgb, dtype=torch.double), leaf(nrm, dtype=torch.double)
+            inv_s = torch.exp(l_o * 10.0) if fis == 0.0 else torch.tensor(fis, dtype=torch.double)
+            a_ref = orr.neus_alpha_packed(s_o, pi, inv_s)
+            out_ref = orr.volume_integration(a_ref, t.double(), r_o, n_o, pi, nd)
+            s_d, l_d, r_d, n_d = leaf(sdf, backend), leaf(ln_inv_s, backend), leaf(rgb, backend), leaf(nrm, backend)
+            a = _NeusAlphaFn.apply(s_d, l_d, pi.to(backend), 10.0, fis)
+            out = volume_integration(a, t.to(backend), r_d, n_d, pi.to(backend), nd)
+            assert torch.allclose(a.cpu().double(), a_ref, atol=2e-6)
+            ws = {k: torch.randn(out_ref[k].shape, generator=g, dtype=torch.double) for k in out_ref}
+            loss_ref = sum((out_ref[k] * ws[k]).sum() for k in out_ref)
+            loss = sum((out[k] * ws[k].float().to(backend)).sum() for k in out_ref)
+            for k in out_ref:
+                assert torch.allclose(out[k].cpu().double(), out_ref[k], atol=2e-5, rtol=1e-5), k
+            loss_ref.backward()
+            loss.backward()
+            for a_, b_, nm in ((s_d, s_o, "sdf"), (r_d, r_o, "rgb"), (n_d, n_o, "nrm")):
+                err = (a_.grad.cpu().double() - b_.grad).abs().max() / b_.grad.abs().max().clamp_min(1e-9)
+                assert err < 2e-4, (nm, fis, nd, float(err))
+            if fis == 0.0:
+                assert abs(float(l_d.grad.cpu()) - float(l_o.grad)) / max(1e-9, abs(float(l_o.grad))) < 2e-3

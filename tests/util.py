@@ -1,0 +1,82 @@
+"""Shared helpers for the parity tests (oracle <-> product weight exchange, synthetic cameras)."""
+import math
+
+import torch
+
+from oracle import field as ofield
+
+
+def leaf(t, dev=None, dtype=None):
+    t = t.detach().clone()
+    if dtype is not None:
+        t = t.to(dtype)
+    if dev is not None:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+SMALL_RES = [4, 6, 8, 11, 14, 18, 23, 29, 36, 44, 53, 63, 74, 86, 99, 113]
+
+
+def make_params(sdf_D=2, small=True, sphere=True, grid_bound=None, seed=42, ln_inv_s=0.3, noise_scale=0.25):
+    """Oracle FieldParams; ``small`` uses a 16-level pyramid with a 2^12 hash table so that emulator runs stay fast
+    while still exercising 8 dense + 8 hashed levels."""
+    if small:
+        p = ofield.make_field_params(lod_res=SMALL_RES, log2_hashmap_size=12, sdf_D=sdf_D, seed=seed,
+                                     sphere_init=sphere, grid_bound=grid_bound if grid_bound is not None else 1e-4,
+                                     ln_inv_s=ln_inv_s, noise_scale=noise_scale)
+    else:
+        p = ofield.make_field_params(sdf_D=sdf_D, seed=seed, sphere_init=sphere,
+                                     grid_bound=grid_bound if grid_bound is not None else 1e-4, ln_inv_s=ln_inv_s,
+                                     noise_scale=noise_scale)
+    p.grid = p.grid.float()   # fp16-representable values held in f32 (exact f32 grads in the oracle)
+    return p
+
+
+def model_from_params(p, device, precision="f32", log2_hashmap_size=None):
+    """Product model carrying exactly the oracle's weights."""
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    l2 = int(math.log2(p.spec.hashmap_size))
+    m = LoTDNeuSModel(lod_res=p.spec.lod_res, log2_hashmap_size=l2, sdf_D=len(p.sdf_w) - 1, precision=precision,
+                      ln_inv_s_init=float(p.ln_inv_s), ln_inv_s_factor=p.ln_inv_s_factor)
+    with torch.no_grad():
+        m.encoding.flattened_params.copy_(p.grid.detach().float())
+        m.sdf_w.copy_(torch.cat([w.detach().reshape(-1) for w in p.sdf_w]))
+        m.sdf_b.copy_(torch.cat([b.detach().reshape(-1) for b in p.sdf_b]))
+        m.rad_w.copy_(torch.cat([w.detach().reshape(-1) for w in p.rad_w]))
+        m.rad_b.copy_(torch.cat([b.detach().reshape(-1) for b in p.rad_b]))
+    return m.to(device)
+
+
+def oracle_flat_grads(p):
+    """Gradients of the oracle params flattened into the product's flat layouts."""
+    def g(t):
+        return t.grad if t.grad is not None else torch.zeros_like(t)
+    return dict(grid=g(p.grid), sdf_w=torch.cat([g(w).reshape(-1) for w in p.sdf_w]),
+                sdf_b=torch.cat([g(b).reshape(-1) for b in p.sdf_b]),
+                rad_w=torch.cat([g(w).reshape(-1) for w in p.rad_w]),
+                rad_b=torch.cat([g(b).reshape(-1) for b in p.rad_b]), ln_inv_s=g(p.ln_inv_s).reshape(-1))
+
+
+def look_at_cameras(V=4, radius=3.0, H=800, W=800, f=1111.1, seed=0):
+    """V pinhole cameras (OpenCV convention: +z forward, +y down) on a sphere looking at the origin
+    (SURVEY.md sec. 8d synthetic inputs)."""
+    g = torch.Generator().manual_seed(seed)
+    c2w = torch.eye(4).repeat(V, 1, 1)
+    for i in range(V):
+        u = torch.rand(2, generator=g)
+        th, ph = float(2 * math.pi * u[0]), float(math.acos(1 - 2 * (0.15 + 0.7 * u[1])))
+        eye = radius * torch.tensor([math.sin(ph) * math.cos(th), math.cos(ph), math.sin(ph) * math.sin(th)])
+        fwd = -eye / eye.norm()
+        up = torch.tensor([0.0, -1.0, 0.0])
+        right = torch.linalg.cross(fwd, up)
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)
+        c2w[i, :3, 0], c2w[i, :3, 1], c2w[i, :3, 2], c2w[i, :3, 3] = right, down, fwd, eye
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]]).repeat(V, 1, 1)
+    WH = torch.tensor([[W, H]], dtype=torch.long).repeat(V, 1)
+    return intr, c2w, WH
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
