@@ -183,12 +183,14 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 /* Backward of nsim_field_fwd given dL/dsdf [S], dL/dnablas [S,3], dL/drgb [S,3] (any may be NULL):
  * accumulates (atomics) into dgrid f32 [n_params], dsdf_w, dsdf_b, drad_w, drad_b (same layouts as
  * nsim_field_pack_weights) and, if non-NULL, dh_appear [R,4]. Includes the double-backward terms of
- * nablas w.r.t. grid and decoder weights (app/loss/eikonal.py:216-251 needs them). */
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* sdf_w,
-                   const float* x, const float* rays_o, const float* rays_d, const float* t,
+ * nablas w.r.t. grid and decoder weights (app/loss/eikonal.py:216-251 needs them).
+ * When drgb != NULL the saved forward outputs nablas_fwd / rgb_fwd [S,3] and a [S,3] float scratch are
+ * required (the radiance branch runs as its own launch and hands dL/dnablas to the SDF branch through it). */
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* nablas_fwd,
+                   const float* rgb_fwd, const float* x, const float* rays_o, const float* rays_d, const float* t,
                    const int64_t* ridx, const float* h_appear, int64_t S, const float* dsdf,
-                   const float* dnablas, const float* drgb, float* dgrid, float* dsdf_w, float* dsdf_b,
-                   float* drad_w, float* drad_b, float* dh_appear, void* stream);
+                   const float* dnablas, const float* drgb, float* scratch, float* dgrid, float* dsdf_w,
+                   float* dsdf_b, float* drad_w, float* drad_b, float* dh_appear, void* stream);
 
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;

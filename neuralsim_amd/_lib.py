@@ -65,8 +65,8 @@ SIGNATURES = {
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
-    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P,
-                       _P, _P],
+    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P,
+                       _P, _P, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }
@@ -115,8 +115,19 @@ def require_device(t: torch.Tensor, name: str = "tensor"):
         raise RuntimeError(f"neuralsim_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
 
 
+class TensorArg:
+    """A device pointer that keeps its tensor alive for as long as the argument tuple of the C call lives.
+    (A bare ``c_void_p(t.data_ptr())`` of a temporary such as ``g.contiguous()`` would let the caching allocator
+    hand the same block to the next temporary of the same argument list.)"""
+    __slots__ = ("_as_parameter_", "ref")
+
+    def __init__(self, t):
+        self.ref = t
+        self._as_parameter_ = C.c_void_p(t.data_ptr())
+
+
 def ptr(t, dtype=None, name="tensor"):
-    """Device pointer of a contiguous tensor (None -> NULL)."""
+    """Device pointer argument of a contiguous tensor (None -> NULL)."""
     if t is None:
         return None
     require_device(t, name)
@@ -124,7 +135,7 @@ def ptr(t, dtype=None, name="tensor"):
         raise TypeError(f"neuralsim_amd: {name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"neuralsim_amd: {name} must be contiguous")
-    return C.c_void_p(t.data_ptr())
+    return TensorArg(t)
 
 
 class KernelTimer:

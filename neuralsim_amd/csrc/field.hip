@@ -192,11 +192,15 @@ __device__ __forceinline__ float dyn_scale(const float (&v)[N]) {
     for (int i = 0; i < N; ++i) m = fmaxf(m, fabsf(v[i]));
     m = wave_max(m);
     if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
-    int ex;
-    frexpf(m, &ex);  // m = f * 2^ex, f in [0.5,1)
+    uint32_t bits;
+    memcpy(&bits, &m, 4);
+    const int ex = (int)((bits >> 23) & 0xffu) - 126;  // m = f * 2^ex, f in [0.5,1)
     int k = 4 - ex;
     k = k > 60 ? 60 : (k < -60 ? -60 : k);
-    return ldexpf(1.0f, k);
+    const uint32_t sb = (uint32_t)(127 + k) << 23;
+    float sc;
+    memcpy(&sc, &sb, 4);
+    return sc;
   }
 }
 
@@ -356,12 +360,14 @@ __device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16],
 }
 
 // ------------------------------------------------------------------------------------ activations
-__device__ __forceinline__ float softplus_b(float z, float beta) {
+// softplus(z; beta) with torch's threshold (beta z > 20 -> z), on the native exp2/log2 pipes.
+__device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) {
   const float bz = z * beta;
-  return bz > 20.f ? z : log1pf(expf(bz)) / beta;
+  const float soft = fmaxf(z, 0.f) + nsim_fast_log(1.0f + nsim_fast_exp(-fabsf(bz))) * inv_beta;
+  return bz > 20.f ? z : soft;
 }
-// sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)
-__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return -expm1f(-beta * a); }
+// sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)   (abs. error <= 6e-8)
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_fast_exp(-beta * a); }
 
 __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
   const float x = d[0], y = d[1], z = d[2];
@@ -384,7 +390,7 @@ __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
-// ------------------------------------------------------------------------------------------ kernel
+// ------------------------------------------------------------------------------------------ kernels
 struct FieldArgs {
   LotdDev lotd;
   FieldLayout lay;
@@ -395,15 +401,17 @@ struct FieldArgs {
   const int64_t* ridx;
   const float* h_appear;
   int64_t S;
-  float *sdf, *nablas, *rgb;
-  const float *dsdf, *dnablas, *drgb;
+  float *sdf, *nablas, *rgb;                       // forward outputs
+  const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
+  const float *dsdf, *dnablas, *drgb;              // upstream gradients
+  float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
 };
 
-// LDS accumulator layout (floats) for MODE 2
+// LDS accumulator layouts (floats)
 struct AccOff {
-  int w1, w2, wh, b1, b2, bh, r1, r2, r3, rb1, rb2, rb3, total;
+  int w1, w2, wh, b1, b2, bh, total;
 };
 __host__ __device__ inline AccOff acc_off() {
   AccOff a;
@@ -414,6 +422,15 @@ __host__ __device__ inline AccOff acc_off() {
   a.b1 = o; o += 64;
   a.b2 = o; o += 64;
   a.bh = o; o += 4;
+  a.total = o;
+  return a;
+}
+struct RadAccOff {
+  int r1, r2, r3, rb1, rb2, rb3, total;
+};
+__host__ __device__ inline RadAccOff rad_acc_off() {
+  RadAccOff a;
+  int o = 0;
   a.r1 = o; o += 64 * 26;
   a.r2 = o; o += 64 * 64;
   a.r3 = o; o += 3 * 64;
@@ -431,60 +448,124 @@ __host__ __device__ constexpr int stage_bytes_per_wave() {
 
 #define FIELD_WAVES 4
 
+// Copy the packed MFMA fragments into LDS (fp16 mode: 58 KB); f32 validation mode reads them from global/L2.
+template <int PREC>
+__device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs& a, int& lds_used) {
+  if constexpr (PREC == 0) {
+    const int n16 = (int)(a.lay.total >> 4);
+    const f16x8* src = reinterpret_cast<const f16x8*>(a.wpack);
+    f16x8* dst = reinterpret_cast<f16x8*>(smem);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    lds_used = (int)((a.lay.total + 15) & ~15);
+    __syncthreads();
+    return smem;
+  } else {
+    lds_used = 0;
+    return a.wpack;
+  }
+}
+
+__device__ __forceinline__ float vecf(const char* W, const FieldLayout& L, int v, int hi, int k) {
+  return reinterpret_cast<const float*>(W + L.vec[v])[hi * 32 + k];
+}
+
+struct TilePoint {
+  float xx[3], vd[3];
+  int64_t s, ray;
+  bool valid;
+};
+
+__device__ __forceinline__ TilePoint load_point(const FieldArgs& a, int64_t tile, int j, bool need_dir) {
+  TilePoint p;
+  p.s = tile * 32 + j;
+  p.valid = p.s < a.S;
+  p.ray = 0;
+  p.xx[0] = p.xx[1] = p.xx[2] = 0.f;
+  p.vd[0] = p.vd[1] = 0.f;
+  p.vd[2] = 1.f;
+  if (p.valid) {
+    if (a.x) {
+      p.xx[0] = a.x[3 * p.s]; p.xx[1] = a.x[3 * p.s + 1]; p.xx[2] = a.x[3 * p.s + 2];
+      if (a.ridx) p.ray = a.ridx[p.s];
+    } else {
+      p.ray = a.ridx[p.s];
+      const float tt = a.t[p.s];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.xx[c] = a.rays_o[3 * p.ray + c] + tt * a.rays_d[3 * p.ray + c];
+    }
+    if (need_dir && a.rays_d) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.vd[c] = a.rays_d[3 * p.ray + c];
+    }
+  }
+  return p;
+}
+
+// radiance input in activation-register order: slots 0-2 x, 3-18 SH4(view dir), 19-21 nablas, 22-25 appearance
+__device__ __forceinline__ void make_rin(float (&rin)[16], const TilePoint& p, const float nab[3], const float* h_appear,
+                                         int hi) {
+  float sh[16];
+  sh4_eval(p.vd, sh);
+  float ha[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.valid && h_appear) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ha[c] = h_appear[4 * p.ray + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int slot = unit_of(0, r, hi);
+    float v = 0.f;
+    if (slot < 3) v = p.xx[slot];
+    else if (slot < 19) v = sh[slot - 3];
+    else if (slot < 22) v = nab[slot - 19];
+    else if (slot < 26) v = ha[slot - 22];
+    rin[r] = v;
+  }
+}
+
+template <int PREC>
+__device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32], const float (&rin)[16], const char* W,
+                                                const FieldLayout& L, int hi) {
+  dense<PREC, 2, 1>(r1, W + L.mat[M_R1], rin, false);
+#pragma unroll
+  for (int k = 0; k < 32; ++k) r1[k] = fmaxf(r1[k] + vecf(W, L, V_RB1, hi, k), 0.f);
+  dense<PREC, 2, 2>(r2, W + L.mat[M_R2], r1, false);
+#pragma unroll
+  for (int k = 0; k < 32; ++k) r2[k] = fmaxf(r2[k] + vecf(W, L, V_RB2, hi, k), 0.f);
+}
+
+// MODE 0: sdf only; MODE 1: sdf + nablas (+ rgb); MODE 2: backward of the SDF branch (gradient w.r.t. grid and
+// decoder weights given dL/dsdf and the TOTAL dL/dnablas, which already includes the radiance net's share).
 template <int PREC, int SDF_D, int MODE>
 __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
-  const float beta = a.beta;
-  const char* W = a.wpack;
+  const float beta = a.beta, inv_beta = 1.0f / a.beta;
   const FieldLayout& L = a.lay;
+  int wbytes;
+  const char* W = stage_weights<PREC>(smem, a, wbytes);
 
   float* accum = nullptr;
   char* stA = nullptr;
   char* stB = nullptr;
   const AccOff AO = acc_off();
   if constexpr (MODE == 2) {
-    accum = reinterpret_cast<float*>(smem);
-    char* stbase = smem + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+    accum = reinterpret_cast<float*>(smem + wbytes);
+    char* stbase = smem + wbytes + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
     stA = stbase;
     stB = stbase + stage_bytes_per_wave<PREC>() / 2;
     for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
     __syncthreads();
-  }
-
-  // per-lane constant vectors (activation-register order)
-  float vb1[32], vwh[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    vb1[k] = reinterpret_cast<const float*>(W + L.vec[V_B1])[hi * 32 + k];
-    vwh[k] = reinterpret_cast<const float*>(W + L.vec[V_WH])[hi * 32 + k];
   }
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
-    const int64_t s = tile * 32 + j;
-    const bool valid = s < a.S;
-    // ---------------------------------------------------------------- point, view dir
-    float xx[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 1.f};
-    int64_t ray = 0;
-    if (valid) {
-      if (a.x) {
-        xx[0] = a.x[3 * s]; xx[1] = a.x[3 * s + 1]; xx[2] = a.x[3 * s + 2];
-        if (a.ridx) ray = a.ridx[s];
-      } else {
-        ray = a.ridx[s];
-        const float tt = a.t[s];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xx[c] = a.rays_o[3 * ray + c] + tt * a.rays_d[3 * ray + c];
-      }
-      if (MODE >= 1 && a.rays_d) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) vd[c] = a.rays_d[3 * ray + c];
-      }
-    }
+    const TilePoint p = load_point(a, tile, j, MODE == 1);
+    const bool valid = p.valid;
+    const int64_t s = p.s;
     // ---------------------------------------------------------------- gather (8 of 16 levels per lane)
     float h[16];
     float J[16][3];
@@ -494,7 +575,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       for (int b = 0; b < 2; ++b) {
         const int l = 4 * q + 2 * hi + b;
         const int R = a.lotd.res[l];
-        const LotdCell c = lotd_cell(xx, R);
+        const LotdCell c = lotd_cell(p.xx, R);
         float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
@@ -529,20 +610,19 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     float a1[32];
     dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vb1[k], beta);
+    for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(W, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];  // last hidden activation (== a1 when SDF_D == 1)
     if constexpr (SDF_D == 2) {
       dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        a2[k] = softplus_b(a2[k] + reinterpret_cast<const float*>(W + L.vec[V_B2])[hi * 32 + k], beta);
+      for (int k = 0; k < 32; ++k) a2[k] = softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
     } else {
 #pragma unroll
       for (int k = 0; k < 32; ++k) a2[k] = a1[k];
     }
     float sdf = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) sdf = sdf + vwh[k] * a2[k];
+    for (int k = 0; k < 32; ++k) sdf = sdf + vecf(W, L, V_WH, hi, k) * a2[k];
     sdf = sdf + wave_shfl_xor(sdf, 32);
     sdf = sdf + b_out;
     if constexpr (MODE == 0) {
@@ -555,67 +635,41 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     if constexpr (SDF_D == 2) {
       float d2[32];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vwh[k];
+      for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
       dense<PREC, 2, 2>(e1, W + L.mat[M_W2T], d2, false);
 #pragma unroll
       for (int k = 0; k < 32; ++k) d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
     } else {
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        e1[k] = vwh[k];
-        d1[k] = sig_from_softplus(a1[k], beta) * vwh[k];
+        e1[k] = vecf(W, L, V_WH, hi, k);
+        d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
       }
     }
     float g[16];
     dense<PREC, 1, 2>(g, W + L.mat[M_W1T], d1, false);
-    float nab[3];
-#pragma unroll
-    for (int c3 = 0; c3 < 3; ++c3) {
-      float acc = 0.f;
-#pragma unroll
-      for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
-      nab[c3] = acc + wave_shfl_xor(acc, 32);
-    }
-    // ---------------------------------------------------------------- radiance forward
-    float rin[16], r1[32], r2[32], rgbv[3] = {0.f, 0.f, 0.f};
-    if (a.has_rgb) {
-      float sh[16];
-      sh4_eval(vd, sh);
-      float ha[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid && a.h_appear) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ha[c] = a.h_appear[4 * ray + c];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int slot = unit_of(0, r, hi);  // 0-2 x, 3-18 SH, 19-21 nablas, 22-25 appearance, pad
-        float v = 0.f;
-        if (slot < 3) v = xx[slot];
-        else if (slot < 19) v = sh[slot - 3];
-        else if (slot < 22) v = nab[slot - 19];
-        else if (slot < 26) v = ha[slot - 22];
-        rin[r] = v;
-      }
-      dense<PREC, 2, 1>(r1, W + L.mat[M_R1], rin, false);
-#pragma unroll
-      for (int k = 0; k < 32; ++k)
-        r1[k] = fmaxf(r1[k] + reinterpret_cast<const float*>(W + L.vec[V_RB1])[hi * 32 + k], 0.f);
-      dense<PREC, 2, 2>(r2, W + L.mat[M_R2], r1, false);
-#pragma unroll
-      for (int k = 0; k < 32; ++k)
-        r2[k] = fmaxf(r2[k] + reinterpret_cast<const float*>(W + L.vec[V_RB2])[hi * 32 + k], 0.f);
-      float o3[16];
-      dense<PREC, 1, 2>(o3, W + L.mat[M_R3], r2, false);
-      // rows 0..2 live on the hi==0 half in registers 0..2; broadcast to both halves
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float v = o3[c] + reinterpret_cast<const float*>(W + L.vec[V_RB3])[hi * 32 + c];
-        v = 1.0f / (1.0f + expf(-v));
-        v = wave_shfl(v, j);  // value held by lane j (hi == 0)
-        rgbv[c] = v;
-      }
-    }
     if constexpr (MODE == 1) {
+      float nab[3];
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) {
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
+        nab[c3] = acc + wave_shfl_xor(acc, 32);
+      }
+      float rgbv[3] = {0.f, 0.f, 0.f};
+      if (a.has_rgb) {
+        float rin[16], r1[32], r2[32];
+        make_rin(rin, p, nab, a.h_appear, hi);
+        radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
+        float o3[16];
+        dense<PREC, 1, 2>(o3, W + L.mat[M_R3], r2, false);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // rows 0..2 live on the hi == 0 half in registers 0..2
+          const float v = o3[c] + vecf(W, L, V_RB3, hi, c);
+          rgbv[c] = 1.0f / (1.0f + nsim_fast_exp(-v));
+        }
+      }
       if (valid && hi == 0) {
         a.sdf[s] = sdf;
 #pragma unroll
@@ -629,56 +683,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     }
     // ======================================================================================= backward
     if constexpr (MODE == 2) {
-      const SrcOff so = src_off(SDF_D);
-      (void)so;
-      float gs = 0.f, gn[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f};
+      float gs = 0.f, gn[3] = {0.f, 0.f, 0.f};
       if (valid) {
         if (a.dsdf) gs = a.dsdf[s];
         if (a.dnablas) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) gn[c] = a.dnablas[3 * s + c];
-        }
-        if (a.has_rgb && a.drgb) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) gr[c] = a.drgb[3 * s + c];
-        }
-      }
-      // ------------------------------------------------------------ radiance backward
-      if (a.has_rgb) {
-        float dout[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dout[r] = 0.f;
-        if (hi == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
-        }
-        dw_product<PREC, 1, 2>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
-        float dr2[32];
-        dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
-        dw_product<PREC, 2, 2>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
-        float dr1[32];
-        dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
-        dw_product<PREC, 2, 1>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
-        float din[16];
-        dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
-        // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
-        float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
-        gn[0] += v0 + wave_shfl_xor(v0, 32);
-        gn[1] += v1 + wave_shfl_xor(v1, 32);
-        gn[2] += v2 + wave_shfl_xor(v2, 32);
-        // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
-        if (a.dh_appear && valid) {
-          if (hi == 1) {
-            if (din[10] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 0], din[10]);
-            if (din[11] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 1], din[11]);
-          } else {
-            if (din[12] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 2], din[12]);
-            if (din[13] != 0.f) atomicAdd(&a.dh_appear[4 * ray + 3], din[13]);
-          }
         }
       }
       // ------------------------------------------------------------ second-order path through the normals
@@ -700,7 +710,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
         float d2[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vwh[k];
+        for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
         dw_product<PREC, 2, 2>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
         float dh2[32];  // dL / d d2 = W2 . eh1
         dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
@@ -708,8 +718,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
           const float s2 = sig_from_softplus(a2[k], beta);
+          const float wh = vecf(W, L, V_WH, hi, k);
           whv[k] = dh2[k] * s2 + gs * a2[k];
-          dz2[k] = gs * vwh[k] * s2 + dh2[k] * vwh[k] * (beta * s2 * (1.0f - s2));
+          dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
         }
         dw_product<PREC, 2, 2>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
         float da1[32];
@@ -720,8 +731,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
           const float s1 = sig_from_softplus(a1[k], beta);
+          const float wh = vecf(W, L, V_WH, hi, k);
           whv[k] = dh1[k] * s1 + gs * a1[k];
-          dz1[k] = gs * vwh[k] * s1 + dh1[k] * vwh[k] * (beta * s1 * (1.0f - s1));
+          dz1[k] = gs * wh * s1 + dh1[k] * wh * (beta * s1 * (1.0f - s1));
         }
       }
       rowsum_acc<PREC, 2>(stA, whv, accum + AO.wh, 64);
@@ -741,7 +753,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           for (int b = 0; b < 2; ++b) {
             const int l = 4 * q + 2 * hi + b;
             const int R = a.lotd.res[l];
-            const LotdCell c = lotd_cell(xx, R);
+            const LotdCell c = lotd_cell(p.xx, R);
             const int r0 = 4 * q + 2 * b;
             const float q0[3] = {g[r0] * gn[0] * c.dscale, g[r0] * gn[1] * c.dscale, g[r0] * gn[2] * c.dscale};
             const float q1[3] = {g[r0 + 1] * gn[0] * c.dscale, g[r0 + 1] * gn[1] * c.dscale,
@@ -755,8 +767,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               const float v0 = w * dh[r0] + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
               const float v1 = w * dh[r0 + 1] + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
               float* dst = a.dgrid + a.lotd.offset[l] + 2 * (int64_t)idx;
-              if (v0 != 0.f) atomicAdd(dst, v0);
-              if (v1 != 0.f) atomicAdd(dst + 1, v1);
+              atomicAdd(dst, v0);
+              atomicAdd(dst + 1, v1);
             }
           }
         }
@@ -776,15 +788,101 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       else if (i < AO.b1) dst = a.dsdf_w + so.wh + (i - AO.wh);
       else if (i < AO.b2) dst = a.dsdf_b + so.b1 + (i - AO.b1);
       else if (i < AO.bh) dst = (SDF_D == 2) ? a.dsdf_b + so.b2 + (i - AO.b2) : nullptr;
-      else if (i < AO.r1) dst = (i == AO.bh) ? a.dsdf_b + so.bh : nullptr;
-      else if (i < AO.r2) dst = a.drad_w + so.r1 + (i - AO.r1);
-      else if (i < AO.r3) dst = a.drad_w + so.r2 + (i - AO.r2);
-      else if (i < AO.rb1) dst = a.drad_w + so.r3 + (i - AO.r3);
-      else if (i < AO.rb2) dst = a.drad_b + so.rb1 + (i - AO.rb1);
-      else if (i < AO.rb3) dst = a.drad_b + so.rb2 + (i - AO.rb2);
-      else dst = (i - AO.rb3 < 3) ? a.drad_b + so.rb3 + (i - AO.rb3) : nullptr;
+      else dst = (i == AO.bh) ? a.dsdf_b + so.bh : nullptr;
       if (dst) atomicAdd(dst, v);
     }
+  }
+}
+
+// Backward of the radiance branch: given dL/drgb, the saved forward nablas / rgb -> gradients of the radiance
+// weights, of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].
+// No grid access at all: per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
+template <int PREC>
+__global__ void __launch_bounds__(64 * FIELD_WAVES) k_rad_bwd(FieldArgs a) {
+  NSIM_DYN_SMEM(smem);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  const int wave = (int)(threadIdx.x >> 6);
+  const FieldLayout& L = a.lay;
+  int wbytes;
+  const char* W = stage_weights<PREC>(smem, a, wbytes);
+  const RadAccOff AO = rad_acc_off();
+  float* accum = reinterpret_cast<float*>(smem + wbytes);
+  char* stA = smem + wbytes + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+  char* stB = stA + stage_bytes_per_wave<PREC>() / 2;
+  for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+  __syncthreads();
+
+  const int64_t ntiles = (a.S + 31) / 32;
+  const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
+    const TilePoint p = load_point(a, tile, j, true);
+    const int64_t s = p.s;
+    float nab[3] = {0.f, 0.f, 0.f}, rgbv[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+    if (p.valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        nab[c] = a.nablas_fwd[3 * s + c];
+        rgbv[c] = a.rgb_fwd[3 * s + c];
+        gr[c] = a.drgb[3 * s + c];
+        if (a.dnablas) gn[c] = a.dnablas[3 * s + c];
+      }
+    }
+    float rin[16], r1[32], r2[32];
+    make_rin(rin, p, nab, a.h_appear, hi);
+    radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
+    float dout[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dout[r] = 0.f;
+    if (hi == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
+    }
+    dw_product<PREC, 1, 2>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
+    float dr2[32];
+    dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
+    dw_product<PREC, 2, 2>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
+    float dr1[32];
+    dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
+    dw_product<PREC, 2, 1>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
+    float din[16];
+    dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
+    // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
+    const float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
+    gn[0] += v0 + wave_shfl_xor(v0, 32);
+    gn[1] += v1 + wave_shfl_xor(v1, 32);
+    gn[2] += v2 + wave_shfl_xor(v2, 32);
+    if (p.valid && hi == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.dnab_total[3 * s + c] = gn[c];
+    }
+    // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
+    if (a.dh_appear && p.valid) {
+      if (hi == 1) {
+        atomicAdd(&a.dh_appear[4 * p.ray + 0], din[10]);
+        atomicAdd(&a.dh_appear[4 * p.ray + 1], din[11]);
+      } else {
+        atomicAdd(&a.dh_appear[4 * p.ray + 2], din[12]);
+        atomicAdd(&a.dh_appear[4 * p.ray + 3], din[13]);
+      }
+    }
+  }
+  __syncthreads();
+  const SrcOff so = src_off(1);
+  for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
+    const float v = accum[i];
+    if (v == 0.f) continue;
+    float* dst = nullptr;
+    if (i < AO.r2) dst = a.drad_w + so.r1 + (i - AO.r1);
+    else if (i < AO.r3) dst = a.drad_w + so.r2 + (i - AO.r2);
+    else if (i < AO.rb1) dst = a.drad_w + so.r3 + (i - AO.r3);
+    else if (i < AO.rb2) dst = a.drad_b + so.rb1 + (i - AO.rb1);
+    else if (i < AO.rb3) dst = a.drad_b + so.rb2 + (i - AO.rb2);
+    else dst = (i - AO.rb3 < 3) ? a.drad_b + so.rb3 + (i - AO.rb3) : nullptr;
+    if (dst) atomicAdd(dst, v);
   }
 }
 
@@ -841,6 +939,13 @@ static unsigned field_grid(int64_t S, int64_t max_blocks) {
   return (unsigned)b;
 }
 
+static size_t weights_lds_bytes(const NsimFieldMeta* meta) {
+  return meta->precision == 0 ? (size_t)((field_layout(0).total + 15) & ~15) : 0;
+}
+static size_t stage_bytes(const NsimFieldMeta* meta) {
+  return meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
+}
+
 template <int MODE>
 static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t shmem, int64_t max_blocks,
                         hipStream_t stream) {
@@ -855,6 +960,10 @@ static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t sh
   NSIM_CHECK_LAUNCH();
   return 0;
 }
+
+// persistent grids: the packed weights (58 KB) are staged into LDS once per workgroup
+#define FIELD_GRID_FWD 1024
+#define FIELD_GRID_BWD 512
 
 extern "C" {
 
@@ -895,7 +1004,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.S = S;
   a.sdf = sdf;
-  return field_launch<0>(meta, a, 0, 1 << 20, (hipStream_t)stream);
+  return field_launch<0>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
@@ -914,21 +1023,21 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.S = S;
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
   a.has_rgb = rgb ? 1 : 0;
-  return field_launch<1>(meta, a, 0, 1 << 20, (hipStream_t)stream);
+  return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* sdf_w,
-                   const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const float* h_appear, int64_t S, const float* dsdf, const float* dnablas, const float* drgb,
-                   float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w, float* drad_b, float* dh_appear,
-                   void* stream) {
-  (void)sdf_w;
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* nablas_fwd,
+                   const float* rgb_fwd, const float* x, const float* rays_o, const float* rays_d, const float* t,
+                   const int64_t* ridx, const float* h_appear, int64_t S, const float* dsdf, const float* dnablas,
+                   const float* drgb, float* scratch, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w,
+                   float* drad_b, float* dh_appear, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (drgb && !(rays_d && ridx)) return 25;
   if (!dsdf_w || !dsdf_b || !drad_w || !drad_b) return 26;
+  if (drgb && !(nablas_fwd && rgb_fwd && scratch)) return 27;
   FieldArgs a = field_args(meta);
   a.grid = (const f16*)grid_f16;
   a.wpack = (const char*)wpack;
@@ -936,14 +1045,23 @@ int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.h_appear = h_appear;
   a.S = S;
   a.dsdf = dsdf; a.dnablas = dnablas; a.drgb = drgb;
+  a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = scratch;
   a.dgrid = dgrid; a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
   a.dh_appear = dh_appear;
   a.has_rgb = drgb ? 1 : 0;
+  const dim3 block(64 * FIELD_WAVES);
+  if (drgb) {  // radiance branch first: produces the total gradient w.r.t. the normals
+    const RadAccOff RO = rad_acc_off();
+    const size_t shmem = weights_lds_bytes(meta) + ((RO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
+    const dim3 grid(field_grid(S, FIELD_GRID_BWD));
+    if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
+    NSIM_CHECK_LAUNCH();
+    a.dnablas = scratch;
+  }
   const AccOff AO = acc_off();
-  const size_t stage = meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
-  const size_t shmem = ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage;
-  // one workgroup per CU, two rounds: every block flushes its LDS accumulator once
-  return field_launch<2>(meta, a, shmem, 512, (hipStream_t)stream);
+  const size_t shmem = weights_lds_bytes(meta) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
+  return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
 }
 
 int nsim_selftest_mfma(const float* a, const float* b, float* d, int use_f32, void* stream) {

@@ -35,7 +35,9 @@ static inline int lotd_meta_check(const NsimLotdMeta* m) {
     if (m->res[l] < 2) return 13;
     if (m->type[l] == NSIM_LOTD_DENSE) {
       if ((uint64_t)m->res[l] * m->res[l] * m->res[l] != (uint64_t)m->size[l]) return 14;
-    } else if (m->type[l] != NSIM_LOTD_HASH) {
+    } else if (m->type[l] == NSIM_LOTD_HASH) {
+      if (m->size[l] == 0 || (m->size[l] & (m->size[l] - 1)) != 0) return 17;  // hash tables: power of two
+    } else {
       return 15;
     }
     if (m->offset[l] & 1) return 16;
@@ -68,7 +70,7 @@ __device__ __forceinline__ LotdCell lotd_cell(const float x[3], int R) {
 __device__ __forceinline__ uint32_t lotd_index(int cx, int cy, int cz, int R, int type, uint32_t T) {
   if (type == NSIM_LOTD_DENSE) return (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
   const uint32_t h = (uint32_t)cx ^ ((uint32_t)cy * 2654435761u) ^ ((uint32_t)cz * 805459861u);
-  return h % T;
+  return h & (T - 1u);  // T is a power of two (checked on the host)
 }
 
 // trilinear weight of corner (dx,dy,dz) and its derivative w.r.t. the three cell coordinates

@@ -19,6 +19,8 @@ const char* nsim_strerror(int code) {
     case 14: return "LoTD dense level size != res^3";
     case 15: return "LoTD unknown level type";
     case 16: return "LoTD level offset must be even";
+    case 17: return "LoTD hash table size must be a power of two";
+    case 27: return "radiance backward needs the saved forward nablas / rgb and a [S,3] scratch buffer";
     case 20: return "field meta is NULL";
     case 21: return "fused field kernels need exactly 16 LoTD levels (32 features)";
     case 22: return "sdf_D must be 1 or 2";

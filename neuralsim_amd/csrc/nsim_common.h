@@ -97,6 +97,22 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
+// native exp / log (v_exp_f32 / v_log_f32 based on the device; libm under the host emulator)
+__device__ __forceinline__ float nsim_fast_exp(float x) {
+#ifdef NSIM_HOST_EMU
+  return expf(x);
+#else
+  return __expf(x);
+#endif
+}
+__device__ __forceinline__ float nsim_fast_log(float x) {
+#ifdef NSIM_HOST_EMU
+  return logf(x);
+#else
+  return __logf(x);
+#endif
+}
+
 // ------------------------------------------------------------------------ MFMA
 // v_mfma_f32_32x32x16_f16: A lane l -> row (l&31), B lane l -> col (l&31),
 // 8 K-slots per lane indexed by (l>>5, e); C/D: col = l&31,

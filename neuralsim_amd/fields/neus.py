@@ -58,7 +58,7 @@ class _FieldFn(torch.autograd.Function):
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb = model, S, with_rgb
-        ctx.geom = (x, rays_o, rays_d, t, ridx, ha)
+        ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb)
         ctx.ha_shape = h_appear.shape if h_appear is not None else None
         if with_rgb:
             return sdf, nablas, rgb
@@ -67,7 +67,7 @@ class _FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sdf, g_nab, g_rgb=None):
         model = ctx.model
-        x, rays_o, rays_d, t, ridx, ha = ctx.geom
+        x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd = ctx.geom
         grid16, wpack = model._shadow()
         dev = grid16.device
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
@@ -81,10 +81,12 @@ class _FieldFn(torch.autograd.Function):
         gs = g_sdf.float().contiguous() if g_sdf is not None else None
         gn = g_nab.float().contiguous() if g_nab is not None else None
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
-        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(x),
-                  _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), ctx.S, _lib.ptr(gs),
-                  _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(dgrid), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(drad_w),
-                  _lib.ptr(drad_b), _lib.ptr(dha))
+        scratch = torch.empty([ctx.S, 3], dtype=torch.float32, device=dev) if gr is not None else None
+        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack),
+                  _lib.ptr(nab_fwd.detach()) if gr is not None else None, _lib.ptr(rgb_fwd.detach()) if gr is not None else None,
+                  _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), ctx.S,
+                  _lib.ptr(gs), _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(scratch), _lib.ptr(dgrid), _lib.ptr(dsdf_w),
+                  _lib.ptr(dsdf_b), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd", ctx.S)
         return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
