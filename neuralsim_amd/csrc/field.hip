@@ -26,6 +26,7 @@
 //    upstream gradients of a volume-render loss do not underflow -- no global loss scaler is required;
 //  * PREC=1 selects v_mfma_f32_32x32x2_f32 (exact f32 at the vector rate) for tight parity tests.
 #include "lotd_dev.h"
+#include <stdlib.h>
 
 // ----------------------------------------------------------------------------------------- layout
 enum { M_W1 = 0, M_W2, M_W2T, M_W1T, M_R1, M_R2, M_R3, M_R3T, M_R2T, M_R1T, M_COUNT };
@@ -405,6 +406,8 @@ struct FieldArgs {
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
+  int dedup_max_res;                               // scatter: wave-level run reduction for levels up to this res
+  int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
 };
@@ -697,7 +700,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       for (int f = 0; f < 16; ++f) gh[f] = J[f][0] * gn[0] + J[f][1] * gn[1] + J[f][2] * gn[2];
       float dh1[32];  // dL / d d1  = W1 . gh
       dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
-      dw_product<PREC, 2, 1>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
+      const bool do_dw = !(a.ablate & 4);
+      if (do_dw) dw_product<PREC, 2, 1>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
       float dz1[32];
       float whv[32];  // vector-shaped gradient of the SDF head weights
       if constexpr (SDF_D == 2) {
@@ -711,7 +715,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         float d2[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
-        dw_product<PREC, 2, 2>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
+        if (do_dw) dw_product<PREC, 2, 2>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
         float dh2[32];  // dL / d d2 = W2 . eh1
         dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
         float dz2[32];
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           whv[k] = dh2[k] * s2 + gs * a2[k];
           dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
         }
-        dw_product<PREC, 2, 2>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
+        if (do_dw) dw_product<PREC, 2, 2>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
         float da1[32];
         dense<PREC, 2, 2>(da1, W + L.mat[M_W2T], dz2, true);
 #pragma unroll
@@ -736,39 +740,89 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           dz1[k] = gs * wh * s1 + dh1[k] * wh * (beta * s1 * (1.0f - s1));
         }
       }
-      rowsum_acc<PREC, 2>(stA, whv, accum + AO.wh, 64);
+      if (do_dw) rowsum_acc<PREC, 2>(stA, whv, accum + AO.wh, 64);
       {
         float v = (hi == 0) ? gs : 0.f;
         v = wave_sum(v);
         if (lane == 0 && v != 0.f) atomicAdd(&accum[AO.bh], v);
       }
-      dw_product<PREC, 2, 1>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
+      if (do_dw) dw_product<PREC, 2, 1>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
       float dh[16];
       dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
       // ------------------------------------------------------------ scatter to the grid
-      if (valid && a.dgrid) {
+      // Measured on MI355X (tools/atomic_bench*.hip): f32 atomics retire at ~21 G *64-byte-line requests*/s
+      // chip-wide, and lanes of ONE instruction that hit adjacent dwords share a request (x2 / x4 / x16 lane-ops
+      // per request).  So (1) consecutive lanes are consecutive samples of a ray: on coarse levels whole runs of
+      // lanes hit the SAME vertex and are collapsed by a segmented shuffle reduction; (2) the remaining adds are
+      // issued quad-transposed: the 4 lanes of a quad serve one point at a time and write the 4 dwords
+      // {x0.f0, x0.f1, x1.f0, x1.f1} of an x-adjacent corner pair -- one 16-byte request on dense levels (and on
+      // hashed levels whenever x0 is even) instead of four.
+      if (a.dgrid && !(a.ablate & 1)) {
+        const int rq = lane & 3;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = 4 * q + 2 * hi + b;
             const int R = a.lotd.res[l];
+            const bool dedup = a.lotd.res[4 * q + 2 + b] <= a.dedup_max_res;  // wave-uniform (finer of the pair)
             const LotdCell c = lotd_cell(p.xx, R);
             const int r0 = 4 * q + 2 * b;
             const float q0[3] = {g[r0] * gn[0] * c.dscale, g[r0] * gn[1] * c.dscale, g[r0] * gn[2] * c.dscale};
             const float q1[3] = {g[r0 + 1] * gn[0] * c.dscale, g[r0 + 1] * gn[1] * c.dscale,
                                  g[r0 + 1] * gn[2] * c.dscale};
+            float* base = a.dgrid + a.lotd.offset[l];
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-              float w, dw[3];
-              lotd_corner_w(c, corner, w, dw);
-              const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
-                                              c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
-              const float v0 = w * dh[r0] + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
-              const float v1 = w * dh[r0 + 1] + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
-              float* dst = a.dgrid + a.lotd.offset[l] + 2 * (int64_t)idx;
-              atomicAdd(dst, v0);
-              atomicAdd(dst + 1, v1);
+            for (int yz = 0; yz < 4; ++yz) {
+              uint32_t idx[2];
+              float v0[2], v1[2];
+              bool emit[2];
+#pragma unroll
+              for (int dx = 0; dx < 2; ++dx) {
+                const int corner = dx | (yz << 1);
+                float w, dw[3];
+                lotd_corner_w(c, corner, w, dw);
+                idx[dx] = lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l],
+                                     a.lotd.size[l]);
+                v0[dx] = w * dh[r0] + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
+                v1[dx] = w * dh[r0 + 1] + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
+                emit[dx] = valid;
+                if (dedup) {
+                  // contiguous runs of equal vertex index inside each 32-lane half: run heads by ballot,
+                  // run start = highest head bit at or below this lane, then a shuffle scan limited to the run
+                  const uint32_t key = valid ? idx[dx] : 0xffffffffu;
+                  const uint32_t pk = wave_shfl(key, lane - 1);
+                  const unsigned long long heads = wave_ballot(j == 0 || pk != key);
+                  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+                  const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+                  for (int d = 1; d < 32; d <<= 1) {
+                    const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
+                    if (lane - d >= run_start) {
+                      v0[dx] += o0;
+                      v1[dx] += o1;
+                    }
+                  }
+                  emit[dx] = valid && (j == 31 || ((heads >> (lane + 1)) & 1ull));  // last lane of the run
+                }
+              }
+              // quad-transposed issue: instruction i serves point i of the quad with 4 adjacent-dword lanes
+#define NSIM_QUAD_ISSUE(I)                                                                                   \
+  {                                                                                                          \
+    const uint32_t i0 = quad_bcast<I>(idx[0]), i1 = quad_bcast<I>(idx[1]);                                   \
+    const float a0 = quad_bcast<I>(v0[0]), a1 = quad_bcast<I>(v1[0]);                                        \
+    const float b0 = quad_bcast<I>(v0[1]), b1 = quad_bcast<I>(v1[1]);                                        \
+    const int e0 = quad_bcast<I>((int)emit[0]), e1 = quad_bcast<I>((int)emit[1]);                            \
+    const uint32_t ii = rq < 2 ? i0 : i1;                                                                    \
+    const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));                                    \
+    const int ee = rq < 2 ? e0 : e1;                                                                         \
+    if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
+  }
+              NSIM_QUAD_ISSUE(0)
+              NSIM_QUAD_ISSUE(1)
+              NSIM_QUAD_ISSUE(2)
+              NSIM_QUAD_ISSUE(3)
+#undef NSIM_QUAD_ISSUE
             }
           }
         }
@@ -1049,6 +1103,13 @@ int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.dgrid = dgrid; a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
   a.dh_appear = dh_appear;
   a.has_rgb = drgb ? 1 : 0;
+  a.dedup_max_res = 600;
+  {
+    const char* e = getenv("NSIM_DEDUP_MAX_RES");
+    if (e) a.dedup_max_res = atoi(e);
+    const char* ab = getenv("NSIM_ABLATE");
+    if (ab) a.ablate = atoi(ab);
+  }
   const dim3 block(64 * FIELD_WAVES);
   if (drgb) {  // radiance branch first: produces the total gradient w.r.t. the normals
     const RadAccOff RO = rad_acc_off();

@@ -57,6 +57,22 @@ __device__ __forceinline__ unsigned long long wave_ballot(int pred) {
 #endif
 }
 
+// broadcast the value of lane I of every aligned group of 4 lanes (DPP quad_perm on the device)
+template <int I, class T>
+__device__ __forceinline__ T quad_bcast(T v) {
+#ifdef NSIM_HOST_EMU
+  return emu::shfl(v, (emu::lane_id() & ~3) + I);
+#else
+  static_assert(sizeof(T) == 4, "quad_bcast: 32-bit types only");
+  int iv;
+  __builtin_memcpy(&iv, &v, 4);
+  iv = __builtin_amdgcn_update_dpp(0, iv, I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true);
+  T r;
+  __builtin_memcpy(&r, &iv, 4);
+  return r;
+#endif
+}
+
 // inclusive scans across the 64 lanes (Hillis-Steele over shuffles)
 template <class T>
 __device__ __forceinline__ T wave_incl_sum(T v) {
