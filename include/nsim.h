@@ -137,10 +137,11 @@ int nsim_coarse_depths(const float* near, const float* far, const float* jitter_
 int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
                         int n_fine, int use_estimate_alpha, float* scratch, float* t_new, void* stream);
 /* Sorted merge of packed (t_a, v_a) with batched (t_b, v_b) [R,nb]; packs must tile the arrays in order.
- * v_a / v_b / v_out may be NULL. pack_infos_out [R,2] is written. */
+ * v_a / v_b / v_out may be NULL. pack_infos_out [R,2] is written; ridx_out [S_out] (may be NULL) receives the
+ * ray (pack) index of every merged sample. */
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
-                      int64_t* pack_infos_out, void* stream);
+                      int64_t* pack_infos_out, int64_t* ridx_out, void* stream);
 
 /* ------------------------------------------------------------------- LoTD encoding (standalone) */
 /* LoTDEncoding.forward / forward_dydx (inspect_rendering.py:468-474): x [S,3] in [-1,1], grid fp16.
@@ -176,21 +177,25 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    int64_t S, float* sdf, void* stream);
 /* With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
- * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902). */
+ * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
+ * h_planes [16,S,2] / J_planes [16,S,2,3] (both or neither): when given, the gathered features and their
+ * derivative w.r.t. x are saved level-major for nsim_field_bwd (which then never gathers again). */
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, void* stream);
+                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, float* h_planes,
+                   float* J_planes, void* stream);
 /* Backward of nsim_field_fwd given dL/dsdf [S], dL/dnablas [S,3], dL/drgb [S,3] (any may be NULL):
  * accumulates (atomics) into dgrid f32 [n_params], dsdf_w, dsdf_b, drad_w, drad_b (same layouts as
  * nsim_field_pack_weights) and, if non-NULL, dh_appear [R,4]. Includes the double-backward terms of
  * nablas w.r.t. grid and decoder weights (app/loss/eikonal.py:216-251 needs them).
- * When drgb != NULL the saved forward outputs nablas_fwd / rgb_fwd [S,3] and a [S,3] float scratch are
- * required (the radiance branch runs as its own launch and hands dL/dnablas to the SDF branch through it). */
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* nablas_fwd,
-                   const float* rgb_fwd, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                   const int64_t* ridx, const float* h_appear, int64_t S, const float* dsdf,
-                   const float* dnablas, const float* drgb, float* scratch, float* dgrid, float* dsdf_w,
-                   float* dsdf_b, float* drad_w, float* drad_b, float* dh_appear, void* stream);
+ * Three launches: radiance branch (if drgb; needs the saved nablas_fwd / rgb_fwd and scratch_gn [S,3]) ->
+ * SDF-decoder branch on the saved h / J planes (writes dh / g planes [16,S,2]) -> LoTD scatter (if dgrid). */
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+                   const float* nablas_fwd, const float* rgb_fwd, const float* x, const float* rays_o,
+                   const float* rays_d, const float* t, const int64_t* ridx, const float* h_appear, int64_t S,
+                   const float* dsdf, const float* dnablas, const float* drgb, float* scratch_gn,
+                   float* dh_planes, float* g_planes, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w,
+                   float* drad_b, float* dh_appear, void* stream);
 
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;

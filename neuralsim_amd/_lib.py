@@ -59,14 +59,14 @@ SIGNATURES = {
     "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
     "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],
     "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P],
-    "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
+    "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P],
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],
     "nsim_lotd_bwd": [_P, _P, _P, C.POINTER(LotdMeta), _I64, _P],
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
-    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
-    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P,
-                       _P, _P, _P],
+    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
+    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P,
+                       _P, _P, _P, _P, _P, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }

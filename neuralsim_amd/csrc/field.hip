@@ -406,7 +406,8 @@ struct FieldArgs {
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
-  int dedup_max_res;                               // scatter: wave-level run reduction for levels up to this res
+  float *h_pl, *J_pl;                              // level-major planes [16][S][2] / [16][S][2][3] saved by the forward
+  float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16][S][2]
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
@@ -570,41 +571,82 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     const bool valid = p.valid;
     const int64_t s = p.s;
     // ---------------------------------------------------------------- gather (8 of 16 levels per lane)
+    // The backward does NOT gather again: the forward saved h and dh/dx as level-major planes
+    // ([level][sample][..], coalesced across the 32 samples of a tile) -- 512 B per sample of sequential HBM
+    // traffic instead of a second latency-bound random gather.
     float h[16];
     float J[16][3];
+    if constexpr (MODE == 2) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int l = 4 * q + 2 * hi + b;
-        const int R = a.lotd.res[l];
-        const LotdCell c = lotd_cell(p.xx, R);
-        float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b;
+          const int r0 = 4 * q + 2 * b;
+          if (valid) {
+            const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+            const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+            h[r0] = hp[0];
+            h[r0 + 1] = hp[1];
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-          float w, dw[3];
-          lotd_corner_w(c, corner, w, dw);
-          const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
-                                          c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
-          float g0, g1;
-          lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
-          f0 = f0 + w * g0;
-          f1 = f1 + w * g1;
+            for (int c3 = 0; c3 < 3; ++c3) {
+              J[r0][c3] = jp[c3];
+              J[r0 + 1][c3] = jp[3 + c3];
+            }
+          } else {
+            h[r0] = h[r0 + 1] = 0.f;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b;
+          const int R = a.lotd.res[l];
+          const LotdCell c = lotd_cell(p.xx, R);
+          float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+          for (int corner = 0; corner < 8; ++corner) {
+            float w, dw[3];
+            lotd_corner_w(c, corner, w, dw);
+            const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
+                                            c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
+            float g0, g1;
+            lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
+            f0 = f0 + w * g0;
+            f1 = f1 + w * g1;
+            if (MODE >= 1) {
+#pragma unroll
+              for (int c3 = 0; c3 < 3; ++c3) {
+                j0[c3] = j0[c3] + dw[c3] * g0;
+                j1[c3] = j1[c3] + dw[c3] * g1;
+              }
+            }
+          }
+          const int r0 = 4 * q + 2 * b;
+          h[r0] = f0;
+          h[r0 + 1] = f1;
           if (MODE >= 1) {
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) {
-              j0[c3] = j0[c3] + dw[c3] * g0;
-              j1[c3] = j1[c3] + dw[c3] * g1;
+              J[r0][c3] = j0[c3] * c.dscale;
+              J[r0 + 1][c3] = j1[c3] * c.dscale;
             }
-          }
-        }
-        h[4 * q + 2 * b] = f0;
-        h[4 * q + 2 * b + 1] = f1;
-        if (MODE >= 1) {
+            if (a.h_pl && valid) {
+              float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+              float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+              hp[0] = f0;
+              hp[1] = f1;
 #pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            J[4 * q + 2 * b][c3] = j0[c3] * c.dscale;
-            J[4 * q + 2 * b + 1][c3] = j1[c3] * c.dscale;
+              for (int c3 = 0; c3 < 3; ++c3) {
+                jp[c3] = J[r0][c3];
+                jp[3 + c3] = J[r0 + 1][c3];
+              }
+            }
           }
         }
       }
@@ -749,81 +791,22 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       if (do_dw) dw_product<PREC, 2, 1>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
       float dh[16];
       dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
-      // ------------------------------------------------------------ scatter to the grid
-      // Measured on MI355X (tools/atomic_bench*.hip): f32 atomics retire at ~21 G *64-byte-line requests*/s
-      // chip-wide, and lanes of ONE instruction that hit adjacent dwords share a request (x2 / x4 / x16 lane-ops
-      // per request).  So (1) consecutive lanes are consecutive samples of a ray: on coarse levels whole runs of
-      // lanes hit the SAME vertex and are collapsed by a segmented shuffle reduction; (2) the remaining adds are
-      // issued quad-transposed: the 4 lanes of a quad serve one point at a time and write the 4 dwords
-      // {x0.f0, x0.f1, x1.f0, x1.f1} of an x-adjacent corner pair -- one 16-byte request on dense levels (and on
-      // hashed levels whenever x0 is even) instead of four.
-      if (a.dgrid && !(a.ablate & 1)) {
-        const int rq = lane & 3;
+      // ------------------------------------------------------------ hand-off to the scatter kernel
+      // dL/dh and g = d sdf/d h as level-major planes + the total dL/dnablas per sample; k_lotd_scatter turns
+      // them into grid gradients at full occupancy (it is bound by the atomic unit, not by this kernel's MFMA chain)
+      if (valid && a.dh_pl) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = 4 * q + 2 * hi + b;
-            const int R = a.lotd.res[l];
-            const bool dedup = a.lotd.res[4 * q + 2 + b] <= a.dedup_max_res;  // wave-uniform (finer of the pair)
-            const LotdCell c = lotd_cell(p.xx, R);
             const int r0 = 4 * q + 2 * b;
-            const float q0[3] = {g[r0] * gn[0] * c.dscale, g[r0] * gn[1] * c.dscale, g[r0] * gn[2] * c.dscale};
-            const float q1[3] = {g[r0 + 1] * gn[0] * c.dscale, g[r0 + 1] * gn[1] * c.dscale,
-                                 g[r0 + 1] * gn[2] * c.dscale};
-            float* base = a.dgrid + a.lotd.offset[l];
-#pragma unroll
-            for (int yz = 0; yz < 4; ++yz) {
-              uint32_t idx[2];
-              float v0[2], v1[2];
-              bool emit[2];
-#pragma unroll
-              for (int dx = 0; dx < 2; ++dx) {
-                const int corner = dx | (yz << 1);
-                float w, dw[3];
-                lotd_corner_w(c, corner, w, dw);
-                idx[dx] = lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l],
-                                     a.lotd.size[l]);
-                v0[dx] = w * dh[r0] + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
-                v1[dx] = w * dh[r0 + 1] + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
-                emit[dx] = valid;
-                if (dedup) {
-                  // contiguous runs of equal vertex index inside each 32-lane half: run heads by ballot,
-                  // run start = highest head bit at or below this lane, then a shuffle scan limited to the run
-                  const uint32_t key = valid ? idx[dx] : 0xffffffffu;
-                  const uint32_t pk = wave_shfl(key, lane - 1);
-                  const unsigned long long heads = wave_ballot(j == 0 || pk != key);
-                  const unsigned long long below = heads & ((2ull << lane) - 1ull);
-                  const int run_start = 63 - __builtin_clzll(below);
-#pragma unroll
-                  for (int d = 1; d < 32; d <<= 1) {
-                    const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
-                    if (lane - d >= run_start) {
-                      v0[dx] += o0;
-                      v1[dx] += o1;
-                    }
-                  }
-                  emit[dx] = valid && (j == 31 || ((heads >> (lane + 1)) & 1ull));  // last lane of the run
-                }
-              }
-              // quad-transposed issue: instruction i serves point i of the quad with 4 adjacent-dword lanes
-#define NSIM_QUAD_ISSUE(I)                                                                                   \
-  {                                                                                                          \
-    const uint32_t i0 = quad_bcast<I>(idx[0]), i1 = quad_bcast<I>(idx[1]);                                   \
-    const float a0 = quad_bcast<I>(v0[0]), a1 = quad_bcast<I>(v1[0]);                                        \
-    const float b0 = quad_bcast<I>(v0[1]), b1 = quad_bcast<I>(v1[1]);                                        \
-    const int e0 = quad_bcast<I>((int)emit[0]), e1 = quad_bcast<I>((int)emit[1]);                            \
-    const uint32_t ii = rq < 2 ? i0 : i1;                                                                    \
-    const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));                                    \
-    const int ee = rq < 2 ? e0 : e1;                                                                         \
-    if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
-  }
-              NSIM_QUAD_ISSUE(0)
-              NSIM_QUAD_ISSUE(1)
-              NSIM_QUAD_ISSUE(2)
-              NSIM_QUAD_ISSUE(3)
-#undef NSIM_QUAD_ISSUE
-            }
+            float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
+            float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
+            dp[0] = dh[r0];
+            dp[1] = dh[r0 + 1];
+            gp[0] = g[r0];
+            gp[1] = g[r0 + 1];
           }
         }
       }
@@ -937,6 +920,113 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_rad_bwd(FieldArgs a) {
     else if (i < AO.rb3) dst = a.drad_b + so.rb2 + (i - AO.rb2);
     else dst = (i - AO.rb3 < 3) ? a.drad_b + so.rb3 + (i - AO.rb3) : nullptr;
     if (dst) atomicAdd(dst, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------ grid scatter
+// dgrid[level][vertex][f] += w_c * dh[f] + g[f] * dscale * (dw_c . gn)      (first + second order terms)
+//
+// Measured on MI355X (tools/atomic_bench*.hip): f32 atomics retire at ~21 G *64-byte-line requests*/s chip-wide,
+// independent of scope, and lanes of ONE instruction that hit adjacent dwords share a request (x2/x4/x16 lane-ops
+// per request).  So: one block row per LEVEL (the level's table stays L2-resident), one lane per sample with
+// consecutive lanes = consecutive samples of a ray; (1) on coarse levels whole runs of lanes hit the SAME vertex and
+// are collapsed by a segmented shuffle reduction; (2) the remaining adds are issued quad-transposed: the 4 lanes of
+// a quad serve one sample at a time and write the 4 dwords {x0.f0, x0.f1, x1.f0, x1.f1} of an x-adjacent corner
+// pair -- one 16-byte request on dense levels (and on hashed levels whenever x0 is even) instead of four.
+struct ScatterArgs {
+  LotdDev lotd;
+  const float *x, *rays_o, *rays_d, *t;
+  const int64_t* ridx;
+  int64_t S;
+  const float *dh_pl, *g_pl, *gn;
+  float* dgrid;
+  int dedup_max_res;
+};
+
+__global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
+  const int lane = nsim_lane();
+  const int l = blockIdx.y;
+  const int R = a.lotd.res[l];
+  const bool dedup = R <= a.dedup_max_res;
+  const int rq = lane & 3;
+  float* base = a.dgrid + a.lotd.offset[l];
+  const int64_t nchunks = (a.S + 63) / 64;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunks; chunk += wstride) {
+    const int64_t s = chunk * 64 + lane;
+    const bool valid = s < a.S;
+    float xx[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f}, dh0 = 0.f, dh1 = 0.f, g0 = 0.f, g1 = 0.f;
+    if (valid) {
+      if (a.x) {
+        xx[0] = a.x[3 * s]; xx[1] = a.x[3 * s + 1]; xx[2] = a.x[3 * s + 2];
+      } else {
+        const int64_t ray = a.ridx[s];
+        const float tt = a.t[s];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xx[c] = a.rays_o[3 * ray + c] + tt * a.rays_d[3 * ray + c];
+      }
+      const float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
+      const float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
+      dh0 = dp[0]; dh1 = dp[1];
+      g0 = gp[0]; g1 = gp[1];
+      if (a.gn) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gn[c] = a.gn[3 * s + c];
+      }
+    }
+    const LotdCell c = lotd_cell(xx, R);
+    const float q0[3] = {g0 * gn[0] * c.dscale, g0 * gn[1] * c.dscale, g0 * gn[2] * c.dscale};
+    const float q1[3] = {g1 * gn[0] * c.dscale, g1 * gn[1] * c.dscale, g1 * gn[2] * c.dscale};
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      uint32_t idx[2];
+      float v0[2], v1[2];
+      bool emit[2];
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int corner = dx | (yz << 1);
+        float w, dw[3];
+        lotd_corner_w(c, corner, w, dw);
+        idx[dx] = lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l], a.lotd.size[l]);
+        v0[dx] = w * dh0 + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
+        v1[dx] = w * dh1 + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
+        emit[dx] = valid;
+        if (dedup) {
+          // contiguous runs of equal vertex index across the wave: run heads by ballot, run start = highest
+          // head bit at or below this lane, then a shuffle scan limited to the run
+          const uint32_t key = valid ? idx[dx] : 0xffffffffu;
+          const uint32_t pk = wave_shfl(key, lane - 1);
+          const unsigned long long heads = wave_ballot(lane == 0 || pk != key);
+          const unsigned long long below = heads & ((2ull << lane) - 1ull);
+          const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
+            if (lane - d >= run_start) {
+              v0[dx] += o0;
+              v1[dx] += o1;
+            }
+          }
+          emit[dx] = valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));  // last lane of the run
+        }
+      }
+#define NSIM_QUAD_ISSUE(I)                                                                                   \
+  {                                                                                                          \
+    const uint32_t i0 = quad_bcast<I>(idx[0]), i1 = quad_bcast<I>(idx[1]);                                   \
+    const float a0 = quad_bcast<I>(v0[0]), a1 = quad_bcast<I>(v1[0]);                                        \
+    const float b0 = quad_bcast<I>(v0[1]), b1 = quad_bcast<I>(v1[1]);                                        \
+    const int e0 = quad_bcast<I>((int)emit[0]), e1 = quad_bcast<I>((int)emit[1]);                            \
+    const uint32_t ii = rq < 2 ? i0 : i1;                                                                    \
+    const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));                                    \
+    const int ee = rq < 2 ? e0 : e1;                                                                         \
+    if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
+  }
+      NSIM_QUAD_ISSUE(0)
+      NSIM_QUAD_ISSUE(1)
+      NSIM_QUAD_ISSUE(2)
+      NSIM_QUAD_ISSUE(3)
+#undef NSIM_QUAD_ISSUE
+    }
   }
 }
 
@@ -1063,12 +1153,14 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, void* stream) {
+                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, float* h_planes,
+                   float* J_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (rgb && !(rays_d && ridx)) return 25;
+  if ((h_planes != nullptr) != (J_planes != nullptr)) return 28;
   FieldArgs a = field_args(meta);
   a.grid = (const f16*)grid_f16;
   a.wpack = (const char*)wpack;
@@ -1076,37 +1168,42 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.h_appear = h_appear;
   a.S = S;
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
+  a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* nablas_fwd,
-                   const float* rgb_fwd, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                   const int64_t* ridx, const float* h_appear, int64_t S, const float* dsdf, const float* dnablas,
-                   const float* drgb, float* scratch, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w,
-                   float* drad_b, float* dh_appear, void* stream) {
+int nsim_field_bwd(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+                   const float* nablas_fwd, const float* rgb_fwd, const float* x, const float* rays_o,
+                   const float* rays_d, const float* t, const int64_t* ridx, const float* h_appear, int64_t S,
+                   const float* dsdf, const float* dnablas, const float* drgb, float* scratch_gn, float* dh_planes,
+                   float* g_planes, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w, float* drad_b,
+                   float* dh_appear, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (drgb && !(rays_d && ridx)) return 25;
   if (!dsdf_w || !dsdf_b || !drad_w || !drad_b) return 26;
-  if (drgb && !(nablas_fwd && rgb_fwd && scratch)) return 27;
+  if (drgb && !(nablas_fwd && rgb_fwd && scratch_gn)) return 27;
+  if (!h_planes || !J_planes) return 28;
+  if (dgrid && !(dh_planes && g_planes)) return 28;
   FieldArgs a = field_args(meta);
-  a.grid = (const f16*)grid_f16;
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.h_appear = h_appear;
   a.S = S;
   a.dsdf = dsdf; a.dnablas = dnablas; a.drgb = drgb;
-  a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = scratch;
-  a.dgrid = dgrid; a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
+  a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = scratch_gn;
+  a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
+  a.dh_pl = dgrid ? dh_planes : nullptr; a.g_pl = dgrid ? g_planes : nullptr;
+  a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
   a.dh_appear = dh_appear;
   a.has_rgb = drgb ? 1 : 0;
-  a.dedup_max_res = 600;
+  int dedup_max_res = 600;
   {
     const char* e = getenv("NSIM_DEDUP_MAX_RES");
-    if (e) a.dedup_max_res = atoi(e);
+    if (e) dedup_max_res = atoi(e);
     const char* ab = getenv("NSIM_ABLATE");
     if (ab) a.ablate = atoi(ab);
   }
@@ -1118,11 +1215,26 @@ int nsim_field_bwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
     NSIM_CHECK_LAUNCH();
-    a.dnablas = scratch;
+    a.dnablas = scratch_gn;
   }
   const AccOff AO = acc_off();
   const size_t shmem = weights_lds_bytes(meta) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
-  return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
+  const int rc2 = field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
+  if (rc2) return rc2;
+  if (dgrid && !(a.ablate & 1)) {
+    ScatterArgs sa;
+    sa.lotd = a.lotd;
+    sa.x = x; sa.rays_o = rays_o; sa.rays_d = rays_d; sa.t = t; sa.ridx = ridx;
+    sa.S = S;
+    sa.dh_pl = dh_planes; sa.g_pl = g_planes; sa.gn = a.dnablas;
+    sa.dgrid = dgrid;
+    sa.dedup_max_res = dedup_max_res;
+    const int64_t chunks = (S + 63) / 64;
+    const dim3 grid(nsim_blocks(chunks, 4, 4096), meta->lotd.num_levels);
+    hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
+    NSIM_CHECK_LAUNCH();
+  }
+  return 0;
 }
 
 int nsim_selftest_mfma(const float* a, const float* b, float* d, int use_f32, void* stream) {

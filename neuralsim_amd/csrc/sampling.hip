@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
                                                               const float* __restrict__ t_b,
                                                               const float* __restrict__ v_b, int64_t R, int nb,
                                                               float* __restrict__ t_out, float* __restrict__ v_out,
-                                                              int64_t* __restrict__ pio) {
+                                                              int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
@@ -349,12 +349,14 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
     const int64_t pos = i + smp_lower_bound(b, nb, v);
     t_out[so + pos] = v;
     if (v_out) v_out[so + pos] = v_a ? v_a[sa + i] : 0.f;
+    if (ridx_out) ridx_out[so + pos] = r;
   }
   for (int64_t j = lane; j < nb; j += 64) {
     const float v = b[j];
     const int64_t pos = j + smp_upper_bound(a, na, v);
     t_out[so + pos] = v;
     if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
+    if (ridx_out) ridx_out[so + pos] = r;
   }
 }
 
@@ -447,10 +449,10 @@ int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_in
 
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out,
-                      void* stream) {
+                      int64_t* ridx_out, void* stream) {
   if (R <= 0) return 0;
   hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
-                     R, nb, t_out, v_out, pack_infos_out);
+                     R, nb, t_out, v_out, pack_infos_out, ridx_out);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -48,17 +48,21 @@ class _FieldFn(torch.autograd.Function):
         S = x.shape[0] if x is not None else t.shape[0]
         dev = grid.device
         grid16, wpack = model._shadow()
-        sdf = torch.zeros([S], dtype=torch.float32, device=dev)
-        nablas = torch.zeros([S, 3], dtype=torch.float32, device=dev)
-        rgb = torch.zeros([S, 3], dtype=torch.float32, device=dev) if with_rgb else None
+        sdf = torch.empty([S], dtype=torch.float32, device=dev)
+        nablas = torch.empty([S, 3], dtype=torch.float32, device=dev)
+        rgb = torch.empty([S, 3], dtype=torch.float32, device=dev) if with_rgb else None
         ha = h_appear.detach().float().contiguous() if h_appear is not None else None
+        need_bwd = any(ctx.needs_input_grad)
+        # level-major planes of the gathered features / their x-derivative, saved so the backward never re-gathers
+        h_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if need_bwd else None
+        J_pl = torch.empty([16, S, 2, 3], dtype=torch.float32, device=dev) if need_bwd else None
         _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S, _lib.ptr(sdf), _lib.ptr(nablas),
-                  _lib.ptr(rgb))
+                  _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb = model, S, with_rgb
-        ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb)
+        ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
         ctx.ha_shape = h_appear.shape if h_appear is not None else None
         if with_rgb:
             return sdf, nablas, rgb
@@ -67,7 +71,7 @@ class _FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sdf, g_nab, g_rgb=None):
         model = ctx.model
-        x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd = ctx.geom
+        x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd, h_pl, J_pl = ctx.geom
         grid16, wpack = model._shadow()
         dev = grid16.device
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
@@ -82,11 +86,13 @@ class _FieldFn(torch.autograd.Function):
         gn = g_nab.float().contiguous() if g_nab is not None else None
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
         scratch = torch.empty([ctx.S, 3], dtype=torch.float32, device=dev) if gr is not None else None
-        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack),
+        dh_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        g_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl),
                   _lib.ptr(nab_fwd.detach()) if gr is not None else None, _lib.ptr(rgb_fwd.detach()) if gr is not None else None,
                   _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), ctx.S,
-                  _lib.ptr(gs), _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(scratch), _lib.ptr(dgrid), _lib.ptr(dsdf_w),
-                  _lib.ptr(dsdf_b), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
+                  _lib.ptr(gs), _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(scratch), _lib.ptr(dh_pl), _lib.ptr(g_pl),
+                  _lib.ptr(dgrid), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd", ctx.S)
         return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
@@ -96,7 +102,7 @@ class _NeusAlphaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf, ln_inv_s, pack_infos, factor, forward_inv_s):
         sdf = sdf.float().contiguous()
-        alpha = torch.zeros_like(sdf)
+        alpha = torch.empty_like(sdf)
         _lib.call("nsim_neus_alpha_fwd", _lib.ptr(sdf), _lib.ptr(pack_infos), pack_infos.shape[0], _lib.ptr(ln_inv_s),
                   float(factor), float(forward_inv_s), _lib.ptr(alpha))
         ctx.save_for_backward(sdf, ln_inv_s, pack_infos)
@@ -106,7 +112,7 @@ class _NeusAlphaFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         sdf, ln_inv_s, pack_infos = ctx.saved_tensors
-        dsdf = torch.zeros_like(sdf)
+        dsdf = torch.empty_like(sdf)
         dln = torch.zeros_like(ln_inv_s)
         _lib.call("nsim_neus_alpha_bwd", _lib.ptr(sdf), _lib.ptr(g.float().contiguous()), _lib.ptr(pack_infos),
                   pack_infos.shape[0], _lib.ptr(ln_inv_s), ctx.factor, ctx.fis, _lib.ptr(dsdf), _lib.ptr(dln))
@@ -124,10 +130,10 @@ class _CompositeFn(torch.autograd.Function):
         nrmc = nrm.float().contiguous() if nrm is not None else None
         P = pack_infos.shape[0]
         dev = alpha.device
-        vw = torch.zeros_like(alpha)
-        trans = torch.ones_like(alpha)
-        mask = torch.zeros([P], dtype=torch.float32, device=dev)
-        depth = torch.zeros([P], dtype=torch.float32, device=dev)
+        vw = torch.empty_like(alpha)
+        trans = torch.empty_like(alpha)
+        mask = torch.empty([P], dtype=torch.float32, device=dev)
+        depth = torch.empty([P], dtype=torch.float32, device=dev)
         rgb_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
         nrm_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
         _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgbc), _lib.ptr(nrmc),
@@ -145,9 +151,9 @@ class _CompositeFn(torch.autograd.Function):
 
         def c(g):
             return g.float().contiguous() if g is not None else None
-        dalpha = torch.zeros_like(alpha)
-        drgb = torch.zeros_like(rgbc) if rgbc is not None else None
-        dnrm = torch.zeros_like(nrmc) if nrmc is not None else None
+        dalpha = torch.empty_like(alpha)
+        drgb = torch.empty_like(rgbc) if rgbc is not None else None
+        dnrm = torch.empty_like(nrmc) if nrmc is not None else None
         _lib.call("nsim_composite_bwd", _lib.ptr(alpha), _lib.ptr(trans), _lib.ptr(vw), _lib.ptr(t), _lib.ptr(rgbc),
                   _lib.ptr(nrmc), _lib.ptr(pack_infos), P, ctx.nd, _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(c(g_mask)),
                   _lib.ptr(c(g_depth)), _lib.ptr(c(g_rgb)), _lib.ptr(c(g_nrm)), _lib.ptr(c(g_vw)), _lib.ptr(dalpha),
@@ -389,7 +395,7 @@ class LoTDNeuSModel(nn.Module):
         shape = x.shape[:-1]
         x = x.detach().float().reshape(-1, 3).contiguous()
         grid16, wpack = self._shadow()
-        sdf = torch.zeros([x.shape[0]], dtype=torch.float32, device=x.device)
+        sdf = torch.empty([x.shape[0]], dtype=torch.float32, device=x.device)
         _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), None, None, None,
                   None, x.shape[0], _lib.ptr(sdf))
         if _lib.TIMER is not None:
@@ -399,7 +405,7 @@ class LoTDNeuSModel(nn.Module):
     @torch.no_grad()
     def _query_sdf_rays(self, rays_o, rays_d, t, ridx):
         grid16, wpack = self._shadow()
-        sdf = torch.zeros([t.shape[0]], dtype=torch.float32, device=t.device)
+        sdf = torch.empty([t.shape[0]], dtype=torch.float32, device=t.device)
         _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), t.shape[0], _lib.ptr(sdf))
         if _lib.TIMER is not None:
@@ -446,6 +452,18 @@ class LoTDNeuSModel(nn.Module):
             ret[k] = v[rays_inds] if isinstance(v, torch.Tensor) and v.shape[:1] == (N,) else v
         return ret
 
+    def _arange_repeat(self, R: int, n: int, dev):
+        """arange(R).repeat_interleave(n), cached (ray index of the batched up-sampling points)."""
+        key = (R, n, str(dev))
+        c = getattr(self, "_ar_cache", None)
+        if c is None:
+            c = self._ar_cache = {}
+        if key not in c:
+            if len(c) > 16:
+                c.clear()
+            c[key] = torch.arange(R, device=dev).repeat_interleave(n)
+        return c[key]
+
     def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c):
         """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling."""
         R = o.shape[0]
@@ -455,42 +473,41 @@ class LoTDNeuSModel(nn.Module):
         step, max_steps = float(march.get("step_size", 0.005)), int(march.get("max_steps", 4096))
         C = int(qp.get("num_coarse", 64))
         bits, occm = self.accel.occ_bits, self.accel.meta
-        counts = torch.zeros([R], dtype=torch.long, device=dev)
+        counts = torch.empty([R], dtype=torch.long, device=dev)
         _lib.call("nsim_march_count", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), occm, step, max_steps, _lib.ptr(counts))
         pi_m, total = po.get_pack_infos_from_n(counts, return_total=True)
         M = int(total.item())               # host sync #2: size of the marched set
-        t_m = torch.zeros([max(M, 1)], **f32)
+        t_m = torch.empty([max(M, 1)], **f32)
         _lib.call("nsim_march_emit", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
-        t_c = torch.zeros([R, C], **f32)
+        t_c = torch.empty([R, C], **f32)
         _lib.call("nsim_coarse_depths", _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter_c), R, C, _lib.ptr(t_c))
         S = M + R * C
-        t = torch.zeros([S], **f32)
-        pi = torch.zeros([R, 2], dtype=torch.long, device=dev)
+        t = torch.empty([S], **f32)
+        pi = torch.empty([R, 2], dtype=torch.long, device=dev)
+        ridx = torch.empty([S], dtype=torch.long, device=dev)
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
-                  _lib.ptr(pi))
-        ar = torch.arange(R, device=dev)
-        ridx = torch.repeat_interleave(ar, pi[:, 1], output_size=S)
+                  _lib.ptr(pi), _lib.ptr(ridx))
         sdf = self._query_sdf_rays(o, d, t, ridx)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
             nf = int(nf)
-            t_new = torch.zeros([R, nf], **f32)
-            scratch = torch.zeros([S], **f32)
+            t_new = torch.empty([R, nf], **f32)
+            scratch = torch.empty([S], **f32)
             _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
                       _lib.ptr(scratch), _lib.ptr(t_new))
-            ridx_new = ar.repeat_interleave(nf)
+            ridx_new = self._arange_repeat(R, nf, dev)
             sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new)
             S2 = S + R * nf
-            t2 = torch.zeros([S2], **f32)
-            sdf2 = torch.zeros([S2], **f32)
-            pi2 = torch.zeros([R, 2], dtype=torch.long, device=dev)
+            t2 = torch.empty([S2], **f32)
+            sdf2 = torch.empty([S2], **f32)
+            pi2 = torch.empty([R, 2], dtype=torch.long, device=dev)
+            ridx = torch.empty([S2], dtype=torch.long, device=dev)
             _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
-                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2))
+                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx))
             t, sdf, pi, S = t2, sdf2, pi2, S2
-        ridx = torch.repeat_interleave(ar, pi[:, 1], output_size=S)
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts
 

@@ -142,9 +142,11 @@ def test_coarse_upsample_merge(backend):
     v_ref = torch.empty_like(t_ref); v_ref[pa] = sdf; v_ref[pb.reshape(-1)] = v_b.reshape(-1)
     t_out = torch.zeros(S + R * nf, device=backend); v_out = torch.zeros_like(t_out)
     pi_out = torch.zeros(R, 2, dtype=torch.long, device=backend)
+    ridx_out = torch.zeros(S + R * nf, dtype=torch.long, device=backend)
     _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
-              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out))
+              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out))
     assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
+    assert torch.equal(ridx_out.cpu(), opo.pack_ridx(pi_ref, t_ref.shape[0]))
 
 
 def test_neus_alpha_and_composite(backend):
