@@ -22,11 +22,21 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 RAYS_PER_GPU = 8192
-# algorithmic bytes per point of the three field kernels:
-#   gather: 16 levels x 8 corners x 2 feats x 2 B (fp16) = 512 B read
-#   backward: the 512 B gather again + 16 x 8 x 2 f32 atomic adds = 1024 B read-modify-write
-BYTES_PER_POINT = {"nsim_field_sdf": 512, "nsim_field_fwd": 512, "nsim_field_bwd": 512 + 1024}
-HBM_PEAK_GBS = 8000.0
+# Algorithmic work per sample point of the field kernels, L=16, F=2, D=2:
+#   gather                16 levels x 8 corners x 2 feats x 2 B (fp16)                          = 512 B read
+#   forward (with grad)   gather + the saved h / dh-dx planes (128 + 384 B) + 28 B outputs       = 1052 B
+#   scatter               256 f32 atomic adds (1024 B RMW) + dh / g planes (256 B) + gn, x (24 B) = 1304 B
+#   SDF-branch backward   72 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 73 728 FLOP
+#   radiance backward     44 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 45 056 FLOP
+KERNEL_MODEL = {
+    "nsim_field_sdf": ("hbm", 512.0),
+    "nsim_field_fwd": ("hbm", 1052.0),
+    "nsim_lotd_scatter": ("hbm", 1304.0),
+    "nsim_field_bwd_sdf": ("mfma", 73728.0),
+    "nsim_field_bwd_rad": ("mfma", 45056.0),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
 
 def build_trainer(device, rank, world, seed=42):
@@ -139,14 +149,17 @@ def main():
         ksum = timer.summary()
         total_rays = RAYS_PER_GPU * world * args.steps
         ms = elapsed / args.steps * 1e3
-        dom = max((k for k in ksum if k in BYTES_PER_POINT), key=lambda k: ksum[k]["total_ms"])
+        dom = max((k for k in ksum if k in KERNEL_MODEL), key=lambda k: ksum[k]["total_ms"])
         kd = ksum[dom]
-        bytes_per_launch = kd["units"] * BYTES_PER_POINT[dom] / max(1, kd["calls"])
-        achieved = bytes_per_launch / (kd["avg_ms"] * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                        avg_launch_ms=round(kd["avg_ms"], 4), points_per_launch=kd["units"] / max(1, kd["calls"]),
-                        bytes_per_point=BYTES_PER_POINT[dom])
+        bound, per_pt = KERNEL_MODEL[dom]
+        work_per_launch = kd["units"] * per_pt / max(1, kd["calls"])
+        if bound == "hbm":
+            achieved, peak, unit = work_per_launch / (kd["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = work_per_launch / (kd["avg_ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 3), peak=peak, unit=unit,
+                        frac=round(achieved / peak, 5), traffic=None, avg_launch_ms=round(kd["avg_ms"], 4),
+                        points_per_launch=kd["units"] / max(1, kd["calls"]), work_per_point=per_pt)
         tf = ROOT / "profiles" / "traffic.json"      # per-launch HBM bytes from rocprofv3 PMC passes, if recorded
         if tf.exists():
             try:

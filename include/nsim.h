@@ -179,23 +179,32 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
  * h_planes [16,S,2] / J_planes [16,S,2,3] (both or neither): when given, the gathered features and their
- * derivative w.r.t. x are saved level-major for nsim_field_bwd (which then never gathers again). */
+ * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again). */
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, float* h_planes,
                    float* J_planes, void* stream);
-/* Backward of nsim_field_fwd given dL/dsdf [S], dL/dnablas [S,3], dL/drgb [S,3] (any may be NULL):
- * accumulates (atomics) into dgrid f32 [n_params], dsdf_w, dsdf_b, drad_w, drad_b (same layouts as
- * nsim_field_pack_weights) and, if non-NULL, dh_appear [R,4]. Includes the double-backward terms of
- * nablas w.r.t. grid and decoder weights (app/loss/eikonal.py:216-251 needs them).
- * Three launches: radiance branch (if drgb; needs the saved nablas_fwd / rgb_fwd and scratch_gn [S,3]) ->
- * SDF-decoder branch on the saved h / J planes (writes dh / g planes [16,S,2]) -> LoTD scatter (if dgrid). */
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
-                   const float* nablas_fwd, const float* rgb_fwd, const float* x, const float* rays_o,
-                   const float* rays_d, const float* t, const int64_t* ridx, const float* h_appear, int64_t S,
-                   const float* dsdf, const float* dnablas, const float* drgb, float* scratch_gn,
-                   float* dh_planes, float* g_planes, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w,
-                   float* drad_b, float* dh_appear, void* stream);
+/* Backward of nsim_field_fwd = three launches (each its own entry point so that callers can time / overlap them):
+ *
+ * (1) radiance branch: given dL/drgb [S,3], the saved forward nablas_fwd / rgb_fwd [S,3] and the upstream
+ *     dL/dnablas (may be NULL): accumulates drad_w / drad_b (layouts of nsim_field_pack_weights), dh_appear [R,4]
+ *     (may be NULL) and writes gn_out [S,3] = dL/dnablas + d(radiance)/d nablas. */
+int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
+                       const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                       const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
+                       float* drad_w, float* drad_b, float* dh_appear, void* stream);
+/* (2) SDF-decoder branch on the saved h / J planes: given dL/dsdf [S] and the total dL/dnablas gn [S,3] (either may
+ *     be NULL) accumulates dsdf_w / dsdf_b -- including the double-backward terms of nablas w.r.t. the decoder
+ *     weights (app/loss/eikonal.py:216-251) -- and writes the hand-off planes dh_planes = dL/dh and
+ *     g_planes = d sdf/d h, both [16,S,2] (both or neither). */
+int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+                       int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
+                       float* dsdf_w, float* dsdf_b, void* stream);
+/* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
+ *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term). */
+int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d,
+                      const float* t, const int64_t* ridx, int64_t S, const float* dh_planes, const float* g_planes,
+                      const float* gn, float* dgrid, void* stream);
 
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;

@@ -65,8 +65,9 @@ SIGNATURES = {
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
-    "nsim_field_bwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P,
-                       _P, _P, _P, _P, _P, _P],
+    "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }

@@ -1173,67 +1173,84 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
-int nsim_field_bwd(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
-                   const float* nablas_fwd, const float* rgb_fwd, const float* x, const float* rays_o,
-                   const float* rays_d, const float* t, const int64_t* ridx, const float* h_appear, int64_t S,
-                   const float* dsdf, const float* dnablas, const float* drgb, float* scratch_gn, float* dh_planes,
-                   float* g_planes, float* dgrid, float* dsdf_w, float* dsdf_b, float* drad_w, float* drad_b,
-                   float* dh_appear, void* stream) {
+static int bwd_ablate() {
+  const char* ab = getenv("NSIM_ABLATE");
+  return ab ? atoi(ab) : 0;
+}
+
+int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
+                       const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                       const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
+                       float* drad_w, float* drad_b, float* dh_appear, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
-  if (drgb && !(rays_d && ridx)) return 25;
-  if (!dsdf_w || !dsdf_b || !drad_w || !drad_b) return 26;
-  if (drgb && !(nablas_fwd && rgb_fwd && scratch_gn)) return 27;
-  if (!h_planes || !J_planes) return 28;
-  if (dgrid && !(dh_planes && g_planes)) return 28;
+  if (!(rays_d && ridx)) return 25;
+  if (!drad_w || !drad_b) return 26;
+  if (!(nablas_fwd && rgb_fwd && gn_out && drgb)) return 27;
   FieldArgs a = field_args(meta);
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.h_appear = h_appear;
   a.S = S;
-  a.dsdf = dsdf; a.dnablas = dnablas; a.drgb = drgb;
-  a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = scratch_gn;
+  a.dnablas = dnablas; a.drgb = drgb;
+  a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = gn_out;
+  a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
+  a.has_rgb = 1;
+  const RadAccOff RO = rad_acc_off();
+  const size_t shmem = weights_lds_bytes(meta) + ((RO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
+  const dim3 grid(field_grid(S, FIELD_GRID_BWD)), block(64 * FIELD_WAVES);
+  if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+                       int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
+                       float* dsdf_b, void* stream) {
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!dsdf_w || !dsdf_b) return 26;
+  if (!h_planes || !J_planes) return 28;
+  if ((dh_planes != nullptr) != (g_planes != nullptr)) return 28;
+  FieldArgs a = field_args(meta);
+  a.wpack = (const char*)wpack;
+  a.S = S;
+  a.dsdf = dsdf; a.dnablas = gn;
   a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
-  a.dh_pl = dgrid ? dh_planes : nullptr; a.g_pl = dgrid ? g_planes : nullptr;
-  a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b; a.drad_w = drad_w; a.drad_b = drad_b;
-  a.dh_appear = dh_appear;
-  a.has_rgb = drgb ? 1 : 0;
-  int dedup_max_res = 600;
-  {
-    const char* e = getenv("NSIM_DEDUP_MAX_RES");
-    if (e) dedup_max_res = atoi(e);
-    const char* ab = getenv("NSIM_ABLATE");
-    if (ab) a.ablate = atoi(ab);
-  }
-  const dim3 block(64 * FIELD_WAVES);
-  if (drgb) {  // radiance branch first: produces the total gradient w.r.t. the normals
-    const RadAccOff RO = rad_acc_off();
-    const size_t shmem = weights_lds_bytes(meta) + ((RO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
-    const dim3 grid(field_grid(S, FIELD_GRID_BWD));
-    if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
-    NSIM_CHECK_LAUNCH();
-    a.dnablas = scratch_gn;
-  }
+  a.dh_pl = dh_planes; a.g_pl = g_planes;
+  a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
+  a.ablate = bwd_ablate();
   const AccOff AO = acc_off();
   const size_t shmem = weights_lds_bytes(meta) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
-  const int rc2 = field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
-  if (rc2) return rc2;
-  if (dgrid && !(a.ablate & 1)) {
-    ScatterArgs sa;
-    sa.lotd = a.lotd;
-    sa.x = x; sa.rays_o = rays_o; sa.rays_d = rays_d; sa.t = t; sa.ridx = ridx;
-    sa.S = S;
-    sa.dh_pl = dh_planes; sa.g_pl = g_planes; sa.gn = a.dnablas;
-    sa.dgrid = dgrid;
-    sa.dedup_max_res = dedup_max_res;
-    const int64_t chunks = (S + 63) / 64;
-    const dim3 grid(nsim_blocks(chunks, 4, 4096), meta->lotd.num_levels);
-    hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
-    NSIM_CHECK_LAUNCH();
-  }
+  return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
+}
+
+int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d, const float* t,
+                      const int64_t* ridx, int64_t S, const float* dh_planes, const float* g_planes, const float* gn,
+                      float* dgrid, void* stream) {
+  const int rc = lotd_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (!dh_planes || !g_planes || !dgrid) return 28;
+  if (bwd_ablate() & 1) return 0;
+  ScatterArgs sa;
+  sa.lotd = lotd_dev(meta);
+  sa.x = x; sa.rays_o = rays_o; sa.rays_d = rays_d; sa.t = t; sa.ridx = ridx;
+  sa.S = S;
+  sa.dh_pl = dh_planes; sa.g_pl = g_planes; sa.gn = gn;
+  sa.dgrid = dgrid;
+  sa.dedup_max_res = 600;
+  const char* e = getenv("NSIM_DEDUP_MAX_RES");
+  if (e) sa.dedup_max_res = atoi(e);
+  const int64_t chunks = (S + 63) / 64;
+  const dim3 grid(nsim_blocks(chunks, 4, 4096), meta->num_levels);
+  hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  NSIM_CHECK_LAUNCH();
   return 0;
 }
 

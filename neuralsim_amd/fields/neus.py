@@ -85,16 +85,28 @@ class _FieldFn(torch.autograd.Function):
         gs = g_sdf.float().contiguous() if g_sdf is not None else None
         gn = g_nab.float().contiguous() if g_nab is not None else None
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
-        scratch = torch.empty([ctx.S, 3], dtype=torch.float32, device=dev) if gr is not None else None
-        dh_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
-        g_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
-        _lib.call("nsim_field_bwd", model.field_meta, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl),
-                  _lib.ptr(nab_fwd.detach()) if gr is not None else None, _lib.ptr(rgb_fwd.detach()) if gr is not None else None,
-                  _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), ctx.S,
-                  _lib.ptr(gs), _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(scratch), _lib.ptr(dh_pl), _lib.ptr(g_pl),
-                  _lib.ptr(dgrid), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
+        S = ctx.S
+        fm = model.field_meta
+        gn_total = gn
+        if gr is not None:      # (1) radiance branch: weight grads + total gradient w.r.t. the normals
+            gn_total = torch.empty([S, 3], dtype=torch.float32, device=dev)
+            _lib.call("nsim_field_bwd_rad", fm, _lib.ptr(wpack), _lib.ptr(nab_fwd.detach()), _lib.ptr(rgb_fwd.detach()),
+                      _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S,
+                      _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(gn_total), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
+        dh_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        g_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        # (2) SDF-decoder branch on the saved planes
+        _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
+                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b))
+        if dgrid is not None:   # (3) scatter to the hash grid
+            _lib.call("nsim_lotd_scatter", model.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(gn_total), _lib.ptr(dgrid))
         if _lib.TIMER is not None:
-            _lib.TIMER.note_units("nsim_field_bwd", ctx.S)
+            _lib.TIMER.note_units("nsim_field_bwd_sdf", S)
+            if dgrid is not None:
+                _lib.TIMER.note_units("nsim_lotd_scatter", S)
+            if gr is not None:
+                _lib.TIMER.note_units("nsim_field_bwd_rad", S)
         return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
 
 
