@@ -452,15 +452,26 @@ __host__ __device__ constexpr int stage_bytes_per_wave() {
 
 #define FIELD_WAVES 4
 
-// Copy the packed MFMA fragments into LDS (fp16 mode: 58 KB); f32 validation mode reads them from global/L2.
+// Copy the MFMA fragments a kernel needs into LDS (fp16 mode) and return a layout whose offsets are relative to the
+// LDS copy: matrices [first, first+count) are contiguous in the pack, the per-lane vectors follow.  The f32
+// validation mode reads fragments from global/L2.
 template <int PREC>
-__device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs& a, int& lds_used) {
+__device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs& a, int first, int count,
+                                                     FieldLayout& Lk, int& lds_used) {
+  Lk = a.lay;
   if constexpr (PREC == 0) {
-    const int n16 = (int)(a.lay.total >> 4);
-    const f16x8* src = reinterpret_cast<const f16x8*>(a.wpack);
+    const int64_t m0 = a.lay.mat[first];
+    const int64_t m1 = (first + count < M_COUNT) ? a.lay.mat[first + count] : a.lay.vec[0];
+    const int64_t mbytes = m1 - m0, vbytes = a.lay.total - a.lay.vec[0];
+    const f16x8* src = reinterpret_cast<const f16x8*>(a.wpack + m0);
     f16x8* dst = reinterpret_cast<f16x8*>(smem);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-    lds_used = (int)((a.lay.total + 15) & ~15);
+    for (int i = threadIdx.x; i < (int)(mbytes >> 4); i += blockDim.x) dst[i] = src[i];
+    const f16x8* vsrc = reinterpret_cast<const f16x8*>(a.wpack + a.lay.vec[0]);
+    f16x8* vdst = reinterpret_cast<f16x8*>(smem + mbytes);
+    for (int i = threadIdx.x; i < (int)(vbytes >> 4); i += blockDim.x) vdst[i] = vsrc[i];
+    for (int m = 0; m < M_COUNT; ++m) Lk.mat[m] = a.lay.mat[m] - m0;
+    for (int v = 0; v < V_COUNT; ++v) Lk.vec[v] = mbytes + (a.lay.vec[v] - a.lay.vec[0]);
+    lds_used = (int)((mbytes + vbytes + 15) & ~15);
     __syncthreads();
     return smem;
   } else {
@@ -546,9 +557,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
   const float beta = a.beta, inv_beta = 1.0f / a.beta;
-  const FieldLayout& L = a.lay;
+  FieldLayout L;
   int wbytes;
-  const char* W = stage_weights<PREC>(smem, a, wbytes);
+  // MODE 0 / 2 touch only the SDF decoder (W1, W2, W2T, W1T); MODE 1 also the radiance matrices
+  const char* W = stage_weights<PREC>(smem, a, 0, MODE == 1 ? M_COUNT : 4, L, wbytes);
 
   float* accum = nullptr;
   char* stA = nullptr;
@@ -834,14 +846,15 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // Backward of the radiance branch: given dL/drgb, the saved forward nablas / rgb -> gradients of the radiance
 // weights, of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].
 // No grid access at all: per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
+#define RAD_WAVES 8
 template <int PREC>
-__global__ void __launch_bounds__(64 * FIELD_WAVES) k_rad_bwd(FieldArgs a) {
+__global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
-  const FieldLayout& L = a.lay;
+  FieldLayout L;
   int wbytes;
-  const char* W = stage_weights<PREC>(smem, a, wbytes);
+  const char* W = stage_weights<PREC>(smem, a, M_R1, 6, L, wbytes);
   const RadAccOff AO = rad_acc_off();
   float* accum = reinterpret_cast<float*>(smem + wbytes);
   char* stA = smem + wbytes + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
@@ -850,8 +863,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_rad_bwd(FieldArgs a) {
   __syncthreads();
 
   const int64_t ntiles = (a.S + 31) / 32;
-  const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
+  const int64_t wstride = (int64_t)gridDim.x * RAD_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * RAD_WAVES + wave; tile < ntiles; tile += wstride) {
     const TilePoint p = load_point(a, tile, j, true);
     const int64_t s = p.s;
     float nab[3] = {0.f, 0.f, 0.f}, rgbv[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
@@ -1083,8 +1096,11 @@ static unsigned field_grid(int64_t S, int64_t max_blocks) {
   return (unsigned)b;
 }
 
-static size_t weights_lds_bytes(const NsimFieldMeta* meta) {
-  return meta->precision == 0 ? (size_t)((field_layout(0).total + 15) & ~15) : 0;
+static size_t weights_lds_bytes(const NsimFieldMeta* meta, int first = 0, int count = M_COUNT) {
+  if (meta->precision != 0) return 0;
+  const FieldLayout L = field_layout(0);
+  const int64_t m1 = (first + count < M_COUNT) ? L.mat[first + count] : L.vec[0];
+  return (size_t)(((m1 - L.mat[first]) + (L.total - L.vec[0]) + 15) & ~15);
 }
 static size_t stage_bytes(const NsimFieldMeta* meta) {
   return meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
@@ -1148,7 +1164,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.S = S;
   a.sdf = sdf;
-  return field_launch<0>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
+  return field_launch<0>(meta, a, weights_lds_bytes(meta, 0, 4), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
@@ -1199,8 +1215,11 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
   a.has_rgb = 1;
   const RadAccOff RO = rad_acc_off();
-  const size_t shmem = weights_lds_bytes(meta) + ((RO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
-  const dim3 grid(field_grid(S, FIELD_GRID_BWD)), block(64 * FIELD_WAVES);
+  const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + ((RO.total * 4 + 15) & ~15) + RAD_WAVES * stage_bytes(meta);
+  const int64_t tiles = (S + 31) / 32;
+  int64_t nb = (tiles + RAD_WAVES - 1) / RAD_WAVES;
+  nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
+  const dim3 grid((unsigned)nb), block(64 * RAD_WAVES);
   if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
@@ -1225,7 +1244,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
   a.ablate = bwd_ablate();
   const AccOff AO = acc_off();
-  const size_t shmem = weights_lds_bytes(meta) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
+  const size_t shmem = weights_lds_bytes(meta, 0, 4) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
   return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
 }
 
