@@ -10,6 +10,7 @@ occupancy-grid refresh every 16 iterations inside the timed region.  Weak scalin
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -93,9 +94,29 @@ def cpu_baseline(tr, n_rays=1024, iters=2):
             times.append(dt)
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=n_rays / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+    base = dict(value=n_rays / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_rays} rays x {iters} timed iterations of the same step (fwd+loss+bwd, no optimizer), "
                        f"pure-PyTorch oracle, f32")
+    # "PSNR vs ref": the same rays rendered by the HIP path (eval mode, no perturbation) and by the oracle
+    with torch.no_grad():
+        dev = m.device
+        n_par = min(n_rays, 512)
+        xy = torch.rand(n_par, 2, generator=g).clamp(1e-6, 1 - 1e-6)
+        fidx = torch.randint(0, intr.shape[0], (n_par,), generator=g)
+        o, d = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
+        ha = tr.appear.detach().cpu()[fidx]
+        mode = m.ray_query_cfg.get("query_mode", "")
+        ret = orr.ray_query(p, o, d, ha, occ, aabb[0], aabb[1], m.accel.resolution, near=0.01,
+                            depth_use_normalized_vw=True, compress=mode.endswith("_compressed"))
+        rgb_o = torch.zeros(n_par, 3).index_put((ret["rays_inds"],), ret["rendered"]["rgb_volume"])
+        from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+        rend = SingleVolumeRenderer(dict(with_rgb=True, near=0.01, depth_use_normalized_vw=True)).eval()
+        out = rend.render(m, rays=[o.to(dev), d.to(dev)], rays_h_appear=ha.to(dev))
+        rgb_h = out["rendered"]["rgb_volume"].cpu()
+        mse = float(((rgb_h - rgb_o) ** 2).mean())
+        parity = dict(rays=n_par, psnr_rgb_db=round(-10.0 * math.log10(max(mse, 1e-20)), 2),
+                      max_abs_rgb=round(float((rgb_h - rgb_o).abs().max()), 5), precision="fp16 MFMA vs f32 oracle")
+    return base, parity
 
 
 def main():
@@ -172,7 +193,8 @@ def main():
                    config=dict(workload="BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
                                         "8192 rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + 2x64 SDF MLP + 2x64 radiance "
                                         "MLP (SH4, appear 4), occ grid 64^3, num_coarse 64, num_fine [8,8,32], "
-                                        "step .005, inv_s=e^5, eikonal on render samples + 4096 uniform points, "
+                                        "step .005, query_mode march_occ_multi_upsample_compressed (reference default), inv_s=e^5, eikonal on "
+                                        "render samples + 4096 uniform points, "
                                         "Adam + occupancy refresh every 16 it inside the timed region",
                                rays_per_gpu=RAYS_PER_GPU, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
                                samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
@@ -181,7 +203,7 @@ def main():
                    kernels={k: dict(calls=v["calls"], total_ms=round(v["total_ms"], 3)) for k, v in
                             sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])[:8]})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tr, n_rays=args.cpu_rays)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -143,6 +143,15 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
                       int64_t* pack_infos_out, int64_t* ridx_out, void* stream);
 
+/* ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): from the no-grad SDF of all
+ * samples keep those that bound an interval with visibility weight > thre.  count -> counts [R]; emit (given
+ * pack_infos_out from the counts) -> compacted t_out / ridx_out. */
+int nsim_compress_count(const float* sdf, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
+                        float ln_inv_s_factor, float forward_inv_s, float thre, int64_t* counts, void* stream);
+int nsim_compress_emit(const float* sdf, const float* t, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
+                       float ln_inv_s_factor, float forward_inv_s, float thre, const int64_t* pack_infos_out,
+                       float* t_out, int64_t* ridx_out, void* stream);
+
 /* ------------------------------------------------------------------- LoTD encoding (standalone) */
 /* LoTDEncoding.forward / forward_dydx (inspect_rendering.py:468-474): x [S,3] in [-1,1], grid fp16.
  * out f32 [S, L*2]; dydx (may be NULL) f32 [S, L*2, 3] = d out / d x. */

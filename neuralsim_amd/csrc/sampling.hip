@@ -360,6 +360,62 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ compressed query mode
+// ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): after up-sampling every
+// sample carries a no-grad SDF; samples whose visibility weight is negligible are dropped before the expensive
+// with-grad query.  A sample is kept iff one of the two intervals it bounds has vw > thre; surviving neighbours
+// form merged intervals (the NeuS opacity telescopes: 1 - alpha(i,j) = Phi(s_j)/Phi(s_i)).
+// One wave per ray: alpha -> transmittance scan -> keep flags -> ballot compaction.
+__device__ __forceinline__ float compress_alpha(const float* sdf, int64_t i, int64_t n, float s) {
+  if (i + 1 >= n) return 0.f;
+  const float c0 = smp_sigmoid(sdf[i] * s), c1 = smp_sigmoid(sdf[i + 1] * s);
+  const float a = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+  return fminf(fmaxf(a, 0.f), 1.f);
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(SMP_BLOCK) k_compress(const float* __restrict__ sdf, const float* __restrict__ t,
+                                                         const int64_t* __restrict__ pi, int64_t R,
+                                                         const float* __restrict__ ln_inv_s, float factor,
+                                                         float forward_inv_s, float thre, int64_t* __restrict__ counts,
+                                                         const int64_t* __restrict__ pi_out, float* __restrict__ t_out,
+                                                         int64_t* __restrict__ ridx_out) {
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int lane = nsim_lane();
+  const int64_t st = pi[2 * r], n = pi[2 * r + 1];
+  const float s = forward_inv_s > 0.f ? forward_inv_s : expf(ln_inv_s[0] * factor);
+  const float* ss = sdf + st;
+  float carry = 1.0f;
+  bool prev_sig = false;  // significance of the interval ending at the first sample of the chunk
+  int cnt = 0;
+  const int64_t ost = EMIT ? pi_out[2 * r] : 0;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < n;
+    const float a = valid ? compress_alpha(ss, i, n, s) : 0.f;
+    const float f = valid ? (1.0f - a + 1e-10f) : 1.0f;
+    const float incl = wave_incl_prod(f);
+    float excl = wave_shfl(incl, lane - 1);
+    if (lane == 0) excl = 1.0f;
+    const float vw = a * (carry * excl);
+    carry = carry * wave_shfl(incl, 63);
+    const bool sig = valid && (vw > thre);
+    int psig = wave_shfl((int)sig, lane - 1);
+    if (lane == 0) psig = prev_sig ? 1 : 0;
+    prev_sig = wave_shfl((int)sig, 63) != 0;
+    const bool keep = valid && (sig || psig != 0);
+    const unsigned long long m = wave_ballot(keep);
+    if (EMIT && keep) {
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      t_out[ost + cnt + before] = t[st + i];
+      ridx_out[ost + cnt + before] = r;
+    }
+    cnt += __popcll(m);
+  }
+  if (!EMIT && lane == 0) counts[r] = cnt;
+}
+
 // ================================================================================== C ABI
 extern "C" {
 
@@ -453,6 +509,25 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
   if (R <= 0) return 0;
   hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
                      R, nb, t_out, v_out, pack_infos_out, ridx_out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_compress_count(const float* sdf, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
+                        float ln_inv_s_factor, float forward_inv_s, float thre, int64_t* counts, void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL((k_compress<false>), smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, sdf, nullptr, pack_infos, R,
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, counts, nullptr, nullptr, nullptr);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_compress_emit(const float* sdf, const float* t, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
+                       float ln_inv_s_factor, float forward_inv_s, float thre, const int64_t* pack_infos_out,
+                       float* t_out, int64_t* ridx_out, void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL((k_compress<true>), smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, sdf, t, pack_infos, R,
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, nullptr, pack_infos_out, t_out, ridx_out);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -316,7 +316,7 @@ class LoTDNeuSModel(nn.Module):
                                   n_steps_between_update=accel_cfg.get("n_steps_between_update", 16),
                                   n_steps_warmup=accel_cfg.get("n_steps_warmup", 256))
         self.ray_query_cfg = dict(ray_query_cfg or dict(
-            query_mode="march_occ_multi_upsample",
+            query_mode="march_occ_multi_upsample_compressed",     # the reference's default (dtu yaml:157)
             query_param=dict(nablas_has_grad=True, num_coarse=64, num_fine=[8, 8, 32], upsample_inv_s=64.0,
                              upsample_inv_s_factors=[1, 4, 16], upsample_use_estimate_alpha=True,
                              march_cfg=dict(step_size=0.005, max_steps=4096))))
@@ -523,6 +523,23 @@ class LoTDNeuSModel(nn.Module):
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts
 
+    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float):
+        """``march_occ_multi_upsample_compressed``: drop the samples whose visibility weight (from the no-grad SDFs
+        of the sampling pass) is negligible before the with-grad query.  Host sync #3 (size of the kept set)."""
+        R = pi.shape[0]
+        dev = t.device
+        counts = torch.empty([R], dtype=torch.long, device=dev)
+        _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
+                  self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(counts))
+        pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
+        Sk = int(total.item())
+        t_k = torch.empty([Sk], dtype=torch.float32, device=dev)
+        ridx_k = torch.empty([Sk], dtype=torch.long, device=dev)
+        if Sk > 0:
+            _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
+                      self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
+        return t_k, pi_k, ridx_k
+
     def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,
                   return_details: bool = False, render_per_obj_individual: bool = False) -> Dict:
         """``query_mode = march_occ_multi_upsample`` (single_volume_renderer.py:244-246)."""
@@ -551,8 +568,18 @@ class LoTDNeuSModel(nn.Module):
             jitter = jitter.float().contiguous()
         if jitter_c is not None:
             jitter_c = jitter_c.float().contiguous()
+        fis = cfg.get("forward_inv_s", None)
+        fis = float(fis) if fis else 0.0
+        mode = cfg.get("query_mode", self.ray_query_cfg.get("query_mode", "march_occ_multi_upsample"))
         with torch.no_grad():
             t, sdf_ng, pi, ridx, march_counts = self._sample(o, d, near, far, qp, jitter, jitter_c)
+            if mode.endswith("_compressed"):
+                t, pi, ridx = self._compress(t, sdf_ng, pi, fis, float(qp.get("compress_thre", 1e-4)))
+        if t.shape[0] == 0:
+            ret["volume_buffer"] = dict(type="empty")
+            if return_details:
+                ret["details"] = dict(march_counts=march_counts)
+            return ret
         h_appear = ray_tested.get("rays_h_appear", None)
         outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
                               h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb))
@@ -560,8 +587,7 @@ class LoTDNeuSModel(nn.Module):
         rgb = outs[2] if with_rgb else None
         if not qp.get("nablas_has_grad", True):
             nablas = nablas.detach()
-        fis = cfg.get("forward_inv_s", None)
-        alpha = _NeusAlphaFn.apply(sdf, self.ln_inv_s, pi, self.ln_inv_s_factor, float(fis) if fis else 0.0)
+        alpha = _NeusAlphaFn.apply(sdf, self.ln_inv_s, pi, self.ln_inv_s_factor, fis)
         vb = dict(type="packed", rays_inds_hit=ray_tested["rays_inds"], pack_infos_hit=pi, t=t, opacity_alpha=alpha,
                   nablas=nablas, sdf=sdf)
         if with_rgb:

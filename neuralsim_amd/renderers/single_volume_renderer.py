@@ -1,0 +1,155 @@
+"""Single-scene volume renderer -- mirrors ``app/renderers/single_volume_renderer.py`` of the reference for the
+close-range ("cr") object, which is the part of that file that sits on the hot path:
+
+* ``ray_query``  (reference :136-492): ``model.ray_test`` -> ``model.ray_query`` -> volume integration of the returned
+  packed buffer into per-ray ``mask_volume / depth_volume / rgb_volume / normals_volume`` scattered to all N rays
+  (``prepare_empty_rendered``, app/renderers/utils.py:30-43), ``ray_intersections.samples_cnt``, the in-place
+  additions to the volume buffer (``vw``, ``vw_in_total``, ``rays_inds_collect``, ``pack_infos_collect``, :416-442);
+* ``render`` (reference :495-581): flattening of ray batches, ``rayschunk`` batching in eval mode
+  (``batchify_query``, :553-565), training/eval grad mode, normalised normals in eval (:99-101).
+
+Not mirrored yet ("next"): the distant NeRF++ model merge (:281-375) and the sky blend
+(:447-457).  There is no Scene graph here: the model is passed directly (the reference looks it up through
+``scene.get_drawable_groups_by_class_name``), rays are expected in the model's object space.
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..fields.neus import LoTDNeuSModel, volume_integration
+
+
+def batchify_query(fn: Callable, *args: torch.Tensor, chunk: int, dim_batchify: int = 0, show_progress: bool = False):
+    """``nr3d_lib.models.utils.batchify_query`` (reference call site single_volume_renderer.py:565): run ``fn`` on
+    chunks of the leading dimension and concatenate (nested dicts of) tensors."""
+    N = args[0].shape[dim_batchify]
+    outs = []
+    for i in range(0, N, chunk):
+        outs.append(fn(*[a[i:i + chunk] if isinstance(a, torch.Tensor) else a for a in args]))
+
+    def cat(items):
+        first = items[0]
+        if isinstance(first, dict):
+            return {k: cat([it[k] for it in items]) for k in first}
+        if isinstance(first, torch.Tensor):
+            return torch.cat(items, dim=dim_batchify)
+        return first
+    return cat(outs)
+
+
+def prepare_empty_rendered(prefix, device, with_rgb=True, with_normal=True):
+    """app/renderers/utils.py:30-43"""
+    r = dict(mask_volume=torch.zeros(prefix, dtype=torch.float32, device=device),
+             depth_volume=torch.zeros(prefix, dtype=torch.float32, device=device))
+    if with_rgb:
+        r["rgb_volume"] = torch.zeros([*prefix, 3], dtype=torch.float32, device=device)
+    if with_normal:
+        r["normals_volume"] = torch.zeros([*prefix, 3], dtype=torch.float32, device=device)
+    return r
+
+
+class SingleVolumeRenderer(nn.Module):
+    def __init__(self, config: Optional[dict] = None):
+        super().__init__()
+        self.config = dict(config or {})
+        self.image_keys = ["depth_volume", "mask_volume", "rgb_volume", "normals_volume"]
+
+    def forward(self, *args, **kwargs):
+        return self.ray_query(*args, **kwargs)
+
+    def ray_query(self, rays_o: torch.Tensor, rays_d: torch.Tensor, rays_ts: torch.Tensor = None,
+                  rays_pix: torch.Tensor = None, *, model: LoTDNeuSModel, rays_h_appear: torch.Tensor = None,
+                  near=None, far=None, with_rgb: bool = None, with_normal: bool = None, return_buffer=False,
+                  return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None) -> Dict:
+        assert rays_o.dim() == rays_d.dim() == 2, "rays_o and rays_d should have size of [N, 3]"
+        config = self.config
+        if with_rgb is None:
+            with_rgb = config.get("with_rgb", True)
+        if with_normal is None:
+            with_normal = config.get("with_normal", False)
+        if near is None:
+            near = config.get("near", None)
+        if far is None:
+            far = config.get("far", None)
+        N, device = rays_o.shape[0], rays_o.device
+        total_num_samples_per_ray = torch.zeros(N, dtype=torch.long, device=device)
+        total_rendered = prepare_empty_rendered([N], device, with_rgb=with_rgb, with_normal=with_normal)
+
+        cr_ray_input = dict(rays_o=rays_o, rays_d=rays_d, near=near, far=far, rays_ts=rays_ts, rays_pix=rays_pix,
+                            rays_h_appear=rays_h_appear)
+        cr_ray_tested = model.ray_test(**cr_ray_input)
+        ray_query_config = dict(model.ray_query_cfg)
+        ray_query_config.update({k: v for k, v in config.items()})
+        ray_query_config.update(with_rgb=with_rgb, with_normal=with_normal)
+        for k, v in (bypass_ray_query_cfg or {}).items():
+            ray_query_config[k] = v
+        cr_ret = model.ray_query(ray_input=cr_ray_input, ray_tested=cr_ray_tested, config=ray_query_config,
+                                 return_buffer=True, return_details=return_details,
+                                 render_per_obj_individual=render_per_obj_individual)
+        vb = cr_ret["volume_buffer"]
+        total_volume_buffer = dict(type="empty")
+        if vb["type"] != "empty":
+            rih, pih = vb["rays_inds_hit"], vb["pack_infos_hit"]
+            total_num_samples_per_ray[rih] += pih[:, 1]
+            vb.update(rays_inds_collect=rih, pack_infos_collect=pih)
+            if "nablas" in vb:
+                vb["nablas_in_world"] = vb["nablas"]          # identity object->world rotation (single object)
+            # ---- volume integration (reference :73-102) through the fused compositing kernel
+            nab = vb.get("nablas_in_world") if with_normal else None
+            if nab is not None and not self.training:
+                nab = F.normalize(nab.clamp(-1, 1), dim=-1)
+            out = volume_integration(vb["opacity_alpha"], vb["t"], vb.get("rgb") if with_rgb else None, nab, pih,
+                                     config.get("depth_use_normalized_vw", True))
+            vb["vw"] = vb["vw_in_total"] = out["vw"]
+            total_rendered["mask_volume"] = total_rendered["mask_volume"].index_put((rih,), out["mask_volume"])
+            total_rendered["depth_volume"] = total_rendered["depth_volume"].index_put((rih,), out["depth_volume"])
+            if with_rgb and "rgb_volume" in out:
+                total_rendered["rgb_volume"] = total_rendered["rgb_volume"].index_put((rih,), out["rgb_volume"])
+            if with_normal and "normals_volume" in out:
+                total_rendered["normals_volume"] = total_rendered["normals_volume"].index_put((rih,), out["normals_volume"])
+            total_volume_buffer = dict(type=vb["type"], rays_inds_hit=rih, pack_infos_hit=pih, t=vb["t"],
+                                       opacity_alpha=vb["opacity_alpha"], vw=out["vw"])
+            for k in ("rgb", "nablas_in_world"):
+                if k in vb:
+                    total_volume_buffer[k] = vb[k]
+        if with_rgb:
+            total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]
+        ret = dict(ray_intersections=dict(samples_cnt=total_num_samples_per_ray), rendered=total_rendered)
+        if return_buffer:
+            ret["volume_buffer"] = total_volume_buffer
+        if return_details:
+            ret["raw_per_obj_model"] = {"main": cr_ret}
+        return ret
+
+    def render(self, model: LoTDNeuSModel, *, rays: List[torch.Tensor], rays_h_appear: torch.Tensor = None, near=None,
+               far=None, rayschunk: int = None, with_rgb=None, with_normal=None, return_buffer=False,
+               return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None) -> Dict:
+        """rays = [rays_o, rays_d(, rays_ts, rays_pix)] with arbitrary prefix shape (reference :495-581)."""
+        if rayschunk is None:
+            rayschunk = self.config.get("rayschunk", 0)
+        with torch.set_grad_enabled(self.training):
+            prefix_shape = rays[0].shape[:-1]
+            flat = [r.flatten(0, len(prefix_shape) - 1) if r is not None else None for r in rays]
+            ha = rays_h_appear.flatten(0, len(prefix_shape) - 1) if rays_h_appear is not None else None
+            kwargs = dict(model=model, near=near, far=far, with_rgb=with_rgb, with_normal=with_normal,
+                          return_buffer=return_buffer, return_details=return_details,
+                          render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg)
+            if self.training or (not rayschunk) or flat[0].shape[0] <= rayschunk:
+                ret = self(*flat[:2], rays_h_appear=ha, **kwargs)
+            else:
+                assert (not return_buffer) and (not return_details), \
+                    "batchify_query does not work when return_buffer=True or return_details=True"
+                if ha is None:
+                    fn = lambda o, d: self(o, d, **kwargs)                       # noqa: E731
+                    ret = batchify_query(fn, flat[0], flat[1], chunk=rayschunk)
+                else:
+                    fn = lambda o, d, h: self(o, d, rays_h_appear=h, **kwargs)   # noqa: E731
+                    ret = batchify_query(fn, flat[0], flat[1], ha, chunk=rayschunk)
+            ret.update(rays_o=flat[0], rays_d=flat[1])
+            if len(prefix_shape) > 1:
+                for k in self.image_keys:
+                    if k in ret["rendered"]:
+                        ret["rendered"][k] = ret["rendered"][k].unflatten(0, prefix_shape)
+        return ret

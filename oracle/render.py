@@ -226,7 +226,7 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
               near=0.01, far=None, num_coarse=64, num_fine=(8, 8, 32), upsample_inv_s=64.0,
               upsample_inv_s_factors=(1, 4, 16), step_size=0.005, max_steps=4096,
               use_estimate_alpha=True, jitter=None, jitter_c=None, forward_inv_s=None,
-              depth_use_normalized_vw=False, sdf_fn=None) -> Dict:
+              depth_use_normalized_vw=False, sdf_fn=None, compress=False, compress_thre=1e-4) -> Dict:
     """``query_mode = march_occ_multi_upsample`` on N rays (already in object space, AABB-normalised).
     Returns the volume buffer + per-hit-ray renderings.  ``jitter`` [N] / ``jitter_c`` [N,C] carry the
     perturbation randoms so that the HIP path can consume the identical numbers."""
@@ -262,6 +262,19 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
             sdf[pb.reshape(-1)] = sdf_new
             ridx = po.pack_ridx(pi, t.shape[0])
     ret['debug'] = dict(t=t, sdf_nograd=sdf, pack_infos=pi, march_counts=cnt_m)
+    if compress:
+        # ``march_occ_multi_upsample_compressed``: keep the samples that bound an interval with vw > thre
+        with torch.no_grad():
+            inv_s_c = p.inv_s().detach() if forward_inv_s is None else torch.as_tensor(float(forward_inv_s))
+            vw = po.packed_alpha_to_vw(neus_alpha_packed(sdf, pi, inv_s_c), pi)
+            sig = vw > compress_thre
+            first = torch.zeros_like(sig)
+            first[pi[:, 0][pi[:, 1] > 0]] = True
+            prev_sig = torch.cat([sig[:1] & False, sig[:-1]]) & ~first
+            keep = sig | prev_sig
+            cnt_k = torch.zeros(R, dtype=torch.long).index_add_(0, ridx[keep], torch.ones(int(keep.sum()), dtype=torch.long))
+            t, ridx, pi = t[keep], ridx[keep], po.get_pack_infos_from_n(cnt_k)
+        ret['debug']['compress_counts'] = cnt_k
     x = o[ridx] + t[:, None] * d[ridx]
     v = d[ridx]
     ha = h_appear[rays_inds][ridx] if h_appear is not None else torch.zeros(x.shape[0], 4)
