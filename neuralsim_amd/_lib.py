@@ -110,7 +110,7 @@ def get_lib():
 
 def stream_handle() -> int:
     """Current HIP stream of the current device (ops run on the caller's stream)."""
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_device(t: torch.Tensor, name: str = "tensor"):
@@ -144,9 +144,10 @@ def ptr(t, dtype=None, name="tensor"):
 class KernelTimer:
     """Optional per-entry-point HIP-event timing on the launch stream (used by bench.py for the roofline)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
         self.units = {}
+        self.only = set(only) if only is not None else None
 
     def note_units(self, name, n):
         self.units[name] = self.units.get(name, 0) + int(n)
@@ -161,13 +162,13 @@ class KernelTimer:
         return out
 
 
-TIMER = None   # set to a KernelTimer() to record events around every call
+TIMER = None   # set to a KernelTimer() to record events around the calls named in TIMER.only (all if None)
 
 
 def call(name: str, *args):
     """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code."""
     lib = get_lib()
-    if TIMER is not None:
+    if TIMER is not None and (TIMER.only is None or name in TIMER.only):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))

@@ -843,6 +843,92 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   }
 }
 
+// No-grad SDF query (all sampling / occupancy-refresh traffic goes through here).  Lean variant of the forward:
+// the gather is split in two phases of 4 levels per lane whose 8 features feed one MFMA K-step each, so only 8
+// features (and 32 corner loads) are live at a time -> ~half the registers of the fused forward -> more waves per
+// SIMD to hide the gather latency.  Features are scaled by a fixed exact power of two before the f16 conversion.
+#define SDF_H_SCALE 1024.0f
+template <int PREC, int SDF_D>
+__global__ void __launch_bounds__(64 * FIELD_WAVES) k_field_sdf(FieldArgs a) {
+  NSIM_DYN_SMEM(smem);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  const int wave = (int)(threadIdx.x >> 6);
+  const float beta = a.beta, inv_beta = 1.0f / a.beta;
+  FieldLayout L;
+  int wbytes;
+  const char* W = stage_weights<PREC>(smem, a, 0, 2, L, wbytes);   // W1, W2 only
+  const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
+  const int64_t ntiles = (a.S + 31) / 32;
+  const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
+    const TilePoint p = load_point(a, tile, j, false);
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll 1
+    for (int rb = 0; rb < 2; ++rb) {
+      float f8[8];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * (2 * rb + qq) + 2 * hi + b;
+          const int R = a.lotd.res[l];
+          const LotdCell c = lotd_cell(p.xx, R);
+          float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+          for (int corner = 0; corner < 8; ++corner) {
+            float w, dw[3];
+            lotd_corner_w(c, corner, w, dw);
+            const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
+                                            c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
+            float g0, g1;
+            lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
+            f0 = f0 + w * g0;
+            f1 = f1 + w * g1;
+          }
+          f8[4 * qq + 2 * b] = f0;
+          f8[4 * qq + 2 * b + 1] = f1;
+        }
+      }
+      if constexpr (PREC == 0) {
+        f16x8 bv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (f16)(f8[e] * SDF_H_SCALE);
+        const f16x8* A = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 + rb) * 64 + lane], bv, acc[mo]);
+      } else {
+        const float* A = reinterpret_cast<const float*>(W + L.mat[M_W1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int mo = 0; mo < 2; ++mo)
+            acc[mo] = mfma_32x32x2_f32(A[(mo * 16 + 8 * rb + e) * 64 + lane], f8[e], acc[mo]);
+      }
+    }
+    const float inv_h = PREC == 0 ? 1.0f / SDF_H_SCALE : 1.0f;
+    float a1[32];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        a1[mo * 16 + r] = softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+    float sdf = 0.f;
+    if constexpr (SDF_D == 2) {
+      float a2[32];
+      dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        sdf = sdf + vecf(W, L, V_WH, hi, k) * softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) sdf = sdf + vecf(W, L, V_WH, hi, k) * a1[k];
+    }
+    sdf = sdf + wave_shfl_xor(sdf, 32);
+    sdf = sdf + b_out;
+    if (p.valid && hi == 0) a.sdf[p.s] = sdf;
+  }
+}
+
 // Backward of the radiance branch: given dL/drgb, the saved forward nablas / rgb -> gradients of the radiance
 // weights, of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].
 // No grid access at all: per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
@@ -1164,7 +1250,17 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.S = S;
   a.sdf = sdf;
-  return field_launch<0>(meta, a, weights_lds_bytes(meta, 0, 4), FIELD_GRID_FWD, (hipStream_t)stream);
+  const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
+  const size_t shmem = weights_lds_bytes(meta, 0, 2);
+  const int key = meta->precision * 2 + (meta->sdf_D - 1);
+  switch (key) {
+    case 0: hipLaunchKernelGGL((k_field_sdf<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL((k_field_sdf<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((k_field_sdf<1, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL((k_field_sdf<1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+  }
+  NSIM_CHECK_LAUNCH();
+  return 0;
 }
 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,

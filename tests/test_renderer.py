@@ -46,6 +46,6 @@ def test_image_psnr_vs_oracle(backend, precision):
     assert float(mask_o.max()) > 0.5                                               # the object is actually visible
     db = psnr(img["rgb_volume"].cpu(), rgb_o)
     assert db > (60.0 if precision == "f32" else 35.0), db
-    assert (img["mask_volume"].cpu() - mask_o).abs().max() < (1e-3 if precision == "f32" else 5e-2)
+    assert (img["mask_volume"].cpu() - mask_o).abs().max() < (5e-3 if precision == "f32" else 5e-2)
     n = img["normals_volume"].cpu().norm(dim=-1)
     assert float(n.max()) <= 1.0 + 1e-4                                            # eval normals are normalised (:99-101)
