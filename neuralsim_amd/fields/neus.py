@@ -444,7 +444,34 @@ class LoTDNeuSModel(nn.Module):
         ret["net_x"] = x
         return ret
 
+    def sample_pts_in_occupied(self, num_pts: int, generator=None) -> Dict[str, torch.Tensor]:
+        """Random points inside occupied voxels -> forward_sdf_nablas (app/loss/eikonal.py:226-227: eikonal
+        ``on_occ_ratio``).  Voxels are drawn uniformly among the occupied ones, points uniformly inside the voxel."""
+        acc = self.accel
+        occ_idx = (acc.occ_val > acc.occ_thre).nonzero()[:, 0]
+        if occ_idx.numel() == 0:
+            return self.sample_pts_uniform(num_pts, generator=generator)
+        dev = self.device
+        pick = occ_idx[torch.randint(0, occ_idx.numel(), [num_pts], device=dev, generator=generator)]
+        rx, ry = acc.resolution[0], acc.resolution[1]
+        vox = torch.stack([pick % rx, (pick // rx) % ry, pick // (rx * ry)], dim=-1).to(torch.float32)
+        res = torch.tensor(acc.resolution, dtype=torch.float32, device=dev)
+        lo, hi = acc.aabb[0], acc.aabb[1]
+        x = lo + (vox + torch.rand([num_pts, 3], device=dev, generator=generator)) / res * (hi - lo)
+        ret = self.forward_sdf_nablas(x)
+        ret["net_x"] = x
+        return ret
+
     # ------------------------------------------------------------------ rays
+    @staticmethod
+    def convert_rays_in_node(rays_o, rays_d, rotation: torch.Tensor, translation: torch.Tensor, scale=1.0):
+        """World -> object rays, ``R^-1 (o - t) / s`` and ``R^-1 d / s`` (app/resources/scenes.py:686-708), with the
+        broadcast-multiply-sum the reference insists on instead of mm/bmm (app/resources/nodes.py:79-84)."""
+        Rt = rotation.transpose(-1, -2)
+        o = ((rays_o - translation).unsqueeze(-2) * Rt).sum(-1) / scale
+        d = (rays_d.unsqueeze(-2) * Rt).sum(-1) / scale
+        return o, d
+
     def ray_test(self, rays_o, rays_d, near=None, far=None, **extra) -> Dict:
         """AABB slab test + compaction of the hit rays (single_volume_renderer.py:235-238)."""
         rays_o = rays_o.float().contiguous()

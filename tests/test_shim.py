@@ -1,0 +1,39 @@
+"""The reference's hot-path import lines resolve against the nr3d_lib shim and hit the HIP-backed implementation."""
+import torch
+
+
+def test_reference_import_lines_resolve():
+    # app/renderers/single_volume_renderer.py:19-20
+    from nr3d_lib.graphics.nerf import packed_alpha_to_vw, ray_alpha_to_vw  # noqa: F401
+    from nr3d_lib.graphics.pack_ops import get_pack_infos_from_n, merge_two_packs_sorted, packed_div, packed_sum  # noqa: F401
+    # app/renderers/buffer_compose_renderer.py:33 ; app/renderers/utils.py:15 ; app/loss/lidar.py:17
+    from nr3d_lib.graphics.pack_ops import interleave_linstep, packed_geq, packed_leq, packed_lt, packed_matmul, packed_sort  # noqa: F401
+    from nr3d_lib.models.utils import batchify_query  # noqa: F401
+    from nr3d_lib.models.fields.neus import LoTDNeuSModel
+    from nr3d_lib.models.accelerations import OccGridAccel, OccGridEma  # noqa: F401
+    from nr3d_lib.models.grid_encodings.lotd import LoTDEncoding  # noqa: F401
+    from nr3d_lib.distributed import get_rank, get_world_size, init_env, is_master  # noqa: F401
+    import neuralsim_amd.fields.neus as impl
+    assert LoTDNeuSModel is impl.LoTDNeuSModel and get_world_size() == 1 and is_master()
+
+
+def test_occupied_sampling_and_ray_conversion(backend):
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    from util import SMALL_RES
+    m = LoTDNeuSModel(lod_res=SMALL_RES, log2_hashmap_size=10, sdf_D=1, precision="f32",
+                      accel_cfg=dict(resolution=(8, 8, 8))).to(backend)
+    m.geometric_init_sphere(0.5)
+    m.accel.occ_val.zero_()
+    m.accel.occ_val[5 + 8 * (2 + 8 * 7)] = 1.0          # voxel (5,2,7)
+    m.accel.pack_bits()
+    out = m.sample_pts_in_occupied(64)
+    x = out["net_x"].cpu()
+    lo = torch.tensor([5, 2, 7]) / 8 * 2 - 1
+    assert ((x >= lo - 1e-6) & (x <= lo + 0.25 + 1e-6)).all() and out["nablas"].shape == (64, 3)
+    th = 0.3
+    R = torch.tensor([[1.0, 0, 0], [0, torch.cos(torch.tensor(th)), -torch.sin(torch.tensor(th))],
+                      [0, torch.sin(torch.tensor(th)), torch.cos(torch.tensor(th))]])
+    t = torch.tensor([0.1, -0.2, 0.3])
+    o, d = torch.randn(5, 3), torch.randn(5, 3)
+    oo, dd = LoTDNeuSModel.convert_rays_in_node(o, d, R, t, 2.0)
+    assert torch.allclose(oo, (o - t) @ R / 2.0, atol=1e-6) and torch.allclose(dd, d @ R / 2.0, atol=1e-6)
