@@ -134,17 +134,32 @@ def main():
     args = ap.parse_args()
 
     from neuralsim_amd import _lib, distributed as ndist
-    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     rank, local_rank, world = ndist.init_env()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.get_lib()
     tr = build_trainer(dev, rank, world)
+    out = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=RAYS_PER_GPU)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; the elapsed
+    time is the MAX over ranks; rank 0 returns the JSON record (other ranks return None)."""
+    from neuralsim_amd import _lib
+    import torch.distributed as dist
+    on_gpu = dev.type == "cuda"
     it0 = 257                      # timed region starts right after an occupancy refresh (every 16 iterations)
-    it = it0 - max(args.warmup, 1)
-    for _ in range(args.warmup):
+    it = it0 - max(warmup, 1)
+    for _ in range(warmup):
         tr.train_step(it)
         it += 1
     it = it0
@@ -152,13 +167,15 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     fence()
-    _lib.TIMER = _lib.KernelTimer(only=KERNEL_MODEL.keys())   # HIP events around the modelled kernels only
+    # HIP events around the modelled kernels only (on the launch stream)
+    _lib.TIMER = _lib.KernelTimer(only=KERNEL_MODEL.keys()) if on_gpu else None
     S_f = S_hit = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         tr.train_step(it)
         it += 1
         S_f += tr.stats["S_f"]
@@ -171,10 +188,17 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    if rank == 0:
-        ksum = timer.summary()
-        total_rays = RAYS_PER_GPU * world * args.steps
-        ms = elapsed / args.steps * 1e3
+    if rank != 0:
+        return None
+    if True:
+        ksum = timer.summary() if timer is not None else {}
+        total_rays = rays_per_gpu * world * steps
+        ms = elapsed / steps * 1e3
+        if not ksum:
+            return dict(metric="training rays/sec (fwd+bwd) NeuS 800x800", value=round(total_rays / elapsed, 1),
+                        unit="rays/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(ms, 3),
+                        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
+                        config=dict(workload="emulator smoke run"), roofline=None)
         dom = max((k for k in ksum if k in KERNEL_MODEL), key=lambda k: ksum[k]["total_ms"])
         kd = ksum[dom]
         bound, per_pt = KERNEL_MODEL[dom]
@@ -193,7 +217,7 @@ def main():
             except Exception:
                 pass
         out = dict(metric="training rays/sec (fwd+bwd) NeuS 800x800", value=round(total_rays / elapsed, 1),
-                   unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
+                   unit="rays/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
                    config=dict(workload="BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
                                         "8192 rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + 2x64 SDF MLP + 2x64 radiance "
@@ -202,18 +226,13 @@ def main():
                                         "step .005, query_mode march_occ_multi_upsample_compressed (reference default), inv_s=e^5, eikonal on "
                                         "render samples + 4096 uniform points, "
                                         "Adam + occupancy refresh every 16 it inside the timed region",
-                               rays_per_gpu=RAYS_PER_GPU, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
+                               rays_per_gpu=rays_per_gpu, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
                                samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
-                               hit_fraction=round(S_hit / (RAYS_PER_GPU * args.steps), 3)),
+                               hit_fraction=round(S_hit / (rays_per_gpu * steps), 3)),
                    roofline=roofline,
                    kernels={k: dict(calls=v["calls"], total_ms=round(v["total_ms"], 3)) for k, v in
                             sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])[:8]})
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
 
 
 if __name__ == "__main__":

@@ -88,3 +88,51 @@ def test_shard_range_covers_batch():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _bench_worker(rank, world, port, out_dir):
+    """bench.timed_run under two gloo ranks, with the kernel emulator standing in for the GPU (control flow of the
+    N>1 path: sharded rays, gradient all-reduce inside train_step, barrier + max-over-ranks timing, rank-0 JSON)."""
+    import ctypes
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import build_emu
+    from neuralsim_amd import _lib, distributed as nd
+    lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
+    _lib.get_lib = lambda: lib
+    _lib.stream_handle = lambda: 0
+    _lib.require_device = lambda t, name="tensor": None
+    import bench
+    from test_trainer import _tiny
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    nd.init_env(backend="gloo", device_type="cpu")
+    dev = torch.device("cpu")
+    m = _tiny(dev, seed=42 + rank)                    # replicas differ until broadcast
+    nd.broadcast_module(m)
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=dev)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=16, lr=1e-3, num_uniform=16, rank=rank, world_size=world)
+    out = bench.timed_run(tr, steps=2, warmup=1, rank=rank, world=world, dev=dev, rays_per_gpu=16)
+    # replicas must still agree after the all-reduced updates
+    w = m.sdf_w.detach().clone()
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    assert torch.equal(ws[0], ws[1])
+    if rank == 0:
+        assert out["n_gpus"] == world and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+        assert abs(out["value"] - 16 * world * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2
+    else:
+        assert out is None
+    dist.barrier()
+    (Path(out_dir) / f"bench_ok{rank}").write_text("ok")
+    dist.destroy_process_group()
+
+
+def test_bench_control_flow_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"bench_ok{r}").exists() for r in range(world))
