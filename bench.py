@@ -56,7 +56,7 @@ def build_trainer(device, rank, world, seed=42):
     # lr 1e-3 (reference fglr is 1e-2 with warm-up): the targets are random colours, so a small rate keeps the
     # synthetic geometry -- and with it the sample statistics -- stationary over the timed steps; the work is identical
     return RenderTrainer(model, intr, c2w, WH, num_rays=RAYS_PER_GPU, lr=1e-3, w_eikonal=0.1, num_uniform=4096,
-                         rank=rank, world_size=world, seed=seed)
+                         rank=rank, world_size=world, seed=seed, learn_inv_s=False)   # inv_s is scheduled (mix_linear), held at e^5
 
 
 def cpu_baseline(tr, n_rays=1024, iters=2):

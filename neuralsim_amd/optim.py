@@ -12,7 +12,7 @@ from . import _lib
 
 
 class FusedAdam:
-    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), eps=1e-15):
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), eps=1e-15, learn_inv_s=True):
         self.model = model
         self.lr, self.eps = lr, eps
         self.groups = []
@@ -21,7 +21,8 @@ class FusedAdam:
         self.groups.append(dict(p=enc.flattened_params, p16=lambda: enc.params16, betas=betas))
         for p in (model.sdf_w, model.sdf_b, model.rad_w, model.rad_b):
             self.groups.append(dict(p=p, p16=None, betas=betas))
-        self.groups.append(dict(p=model.ln_inv_s, p16=None, betas=invs_betas))
+        if learn_inv_s:   # var_ctrl_cfg{ctrl_type: mix_linear} schedules inv_s instead of learning it (dtu yaml:85-91)
+            self.groups.append(dict(p=model.ln_inv_s, p16=None, betas=invs_betas))
         for g in self.groups:
             g["m"] = torch.zeros_like(g["p"], dtype=torch.float32)
             g["v"] = torch.zeros_like(g["p"], dtype=torch.float32)

@@ -22,7 +22,7 @@ from .optim import FusedAdam
 class RenderTrainer:
     def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
-                 perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42):
+                 perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True):
         self.model = model
         self.intr, self.c2w, self.WH = intr, c2w, WH
         self.V = intr.shape[0]
@@ -35,7 +35,7 @@ class RenderTrainer:
         self.gen_shared = torch.Generator(device=dev).manual_seed(seed)     # rank-shared (occupancy refresh)
         g = torch.Generator().manual_seed(seed)
         self.appear = nn.Parameter((torch.randn(self.V, n_appear, generator=g) * 0.1).to(dev))
-        self.optim = FusedAdam(model, lr=lr)
+        self.optim = FusedAdam(model, lr=lr, learn_inv_s=learn_inv_s)
         self.optim.groups.append(dict(p=self.appear, p16=None, betas=(0.9, 0.99), m=torch.zeros_like(self.appear),
                                       v=torch.zeros_like(self.appear)))
         self.stats: Dict[str, float] = {}
