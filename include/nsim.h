@@ -215,6 +215,53 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
                       const float* t, const int64_t* ridx, int64_t S, const float* dh_planes, const float* g_planes,
                       const float* gn, float* dgrid, void* stream);
 
+/* ------------------------------------------------ NeRF++ distant-view model (LoTDNeRFDistant) */
+/* 4-D LoTD level table of ``lotd_auto_compute_cfg{type: ngp4d}`` (lotd_neus.dtu.230814.yaml:193-200): level l has
+ * res_xyz^3 * res_w vertices (Dense) or a 2^k-entry hash table; 2 features per level; <= 16 levels. */
+typedef struct NsimLotd4Meta {
+  int32_t num_levels;
+  int32_t res_xyz[16];
+  int32_t res_w[16];
+  int32_t type[16];
+  uint32_t size[16];
+  int64_t offset[16];
+} NsimLotd4Meta;
+
+typedef struct NsimDistantMeta {
+  NsimLotd4Meta lotd;
+  int32_t precision;     /* 0: fp16 MFMA, 1: exact f32 MFMA */
+} NsimDistantMeta;
+
+int64_t nsim_distant_wpack_bytes(const NsimDistantMeta* meta);
+/* den_w: [D1 (64 x F), Dhead (1 x 64)], den_b: [64, 1]; rad_w: [Q1 (64 x (F+20)), Q2 (64x64), Q3 (3x64)], rad_b [64,64,3];
+ * F = 2 * num_levels; radiance input = [features F, SH-4 (16), appearance (4)]  (yaml :221-234). */
+int nsim_distant_pack_weights(const NsimDistantMeta* meta, const float* den_w, const float* den_b, const float* rad_w,
+                              const float* rad_b, void* wpack, void* stream);
+/* ``ray_query_cfg{query_mode: march, march_cfg{sample_mode: box, max_steps: K}}`` with ``radius_scale_min/max``:
+ * K shells per ray, 1/r uniform; t [N,K] = exit depth of the AABB (host float[6] = min,max) scaled by r about its
+ * centre, u4 [N,K,4] = network input in [0,1]^4, valid [N,K] (shell crossed beyond near[ray]). jitter [N,K] or NULL. */
+int nsim_distant_shells(const float* rays_o, const float* rays_d, const float* near, const float* jitter, int64_t N,
+                        int K, const float* aabb, float r_min, float r_max, float* t, float* u4, uint8_t* valid,
+                        void* stream);
+/* alpha = 1 - exp(-sigma * delta), delta = t[k+1]-t[k] (1e10 for the last shell: include_inf_distance); 0 if !valid */
+int nsim_density_alpha_fwd(const float* sigma, const float* t, const uint8_t* valid, int64_t N, int K, float* alpha,
+                           void* stream);
+int nsim_density_alpha_bwd(const float* sigma, const float* t, const uint8_t* valid, const float* dalpha, int64_t N,
+                           int K, float* dsigma, void* stream);
+/* fused 4-D gather + density MLP + radiance MLP on S = N*K points (ray = s / K): sigma [S], rgb [S,3];
+ * h_planes [16,S,2] (may be NULL) saves the features for the backward. */
+int nsim_distant_fwd(const NsimDistantMeta* meta, const void* grid_f16, const void* wpack, const float* u4,
+                     const float* rays_d, const float* h_appear, int64_t S, int K, float* sigma, float* rgb,
+                     float* h_planes, void* stream);
+/* backward of nsim_distant_fwd: accumulates dden_w/dden_b/drad_w/drad_b (layouts above), dh_appear [N,4] (may be
+ * NULL) and writes dh_planes [16,S,2] for nsim_lotd4_scatter. */
+int nsim_distant_bwd(const NsimDistantMeta* meta, const void* wpack, const float* h_planes, const float* sigma_fwd,
+                     const float* rgb_fwd, const float* rays_d, const float* h_appear, const uint8_t* valid,
+                     int64_t S, int K, const float* dsigma, const float* drgb, float* dh_planes, float* dden_w,
+                     float* dden_b, float* drad_w, float* drad_b, float* dh_appear, void* stream);
+int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t* valid, int64_t S,
+                       const float* dh_planes, float* dgrid, void* stream);
+
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;
  * p16 (may be NULL) receives the fp16 copy used by the kernels; grad is scaled by grad_scale and zeroed. */

@@ -25,6 +25,15 @@ class OccMeta(C.Structure):
                 ("res", C.c_int32 * 3)]
 
 
+class Lotd4Meta(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("res_xyz", C.c_int32 * 16), ("res_w", C.c_int32 * 16),
+                ("type", C.c_int32 * 16), ("size", C.c_uint32 * 16), ("offset", C.c_int64 * 16)]
+
+
+class DistantMeta(C.Structure):
+    _fields_ = [("lotd", Lotd4Meta), ("precision", C.c_int32)]
+
+
 class FieldMeta(C.Structure):
     _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
 
@@ -70,6 +79,13 @@ SIGNATURES = {
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "nsim_distant_pack_weights": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P],
+    "nsim_distant_shells": [_P, _P, _P, _P, _I64, _I, C.POINTER(C.c_float * 6), _F, _F, _P, _P, _P],
+    "nsim_density_alpha_fwd": [_P, _P, _P, _I64, _I, _P],
+    "nsim_density_alpha_bwd": [_P, _P, _P, _P, _I64, _I, _P],
+    "nsim_distant_fwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
+    "nsim_distant_bwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_lotd4_scatter": [C.POINTER(Lotd4Meta), _P, _P, _I64, _P, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }
@@ -77,6 +93,7 @@ NOSTREAM = {
     "nsim_strerror": ([_I], C.c_char_p),
     "nsim_version": ([], _I),
     "nsim_field_wpack_bytes": ([C.POINTER(FieldMeta)], _I64),
+    "nsim_distant_wpack_bytes": ([C.POINTER(DistantMeta)], _I64),
 }
 
 

@@ -8,8 +8,11 @@ close-range ("cr") object, which is the part of that file that sits on the hot p
 * ``render`` (reference :495-581): flattening of ray batches, ``rayschunk`` batching in eval mode
   (``batchify_query``, :553-565), training/eval grad mode, normalised normals in eval (:99-101).
 
-Not mirrored yet ("next"): the distant NeRF++ model merge (:281-375) and the sky blend
-(:447-457).  There is no Scene graph here: the model is passed directly (the reference looks it up through
+* the distant NeRF++ model (reference :281-375): queried on ALL rays with ``near`` := the close-range ``far`` on the
+  rays that hit the AABB, pose gradients detached, its batched buffer merged with the close-range packed buffer by
+  ``merge_two_packs_sorted`` and scattered into the total buffers.
+
+Not mirrored yet ("next"): the sky blend (:447-457).  There is no Scene graph here: the model is passed directly (the reference looks it up through
 ``scene.get_drawable_groups_by_class_name``), rays are expected in the model's object space.
 """
 from typing import Callable, Dict, List, Optional
@@ -19,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..fields.neus import LoTDNeuSModel, volume_integration
+from ..graphics import pack_ops as po
 
 
 def batchify_query(fn: Callable, *args: torch.Tensor, chunk: int, dim_batchify: int = 0, show_progress: bool = False):
@@ -62,7 +66,8 @@ class SingleVolumeRenderer(nn.Module):
     def ray_query(self, rays_o: torch.Tensor, rays_d: torch.Tensor, rays_ts: torch.Tensor = None,
                   rays_pix: torch.Tensor = None, *, model: LoTDNeuSModel, rays_h_appear: torch.Tensor = None,
                   near=None, far=None, with_rgb: bool = None, with_normal: bool = None, return_buffer=False,
-                  return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None) -> Dict:
+                  return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
+                  distant_model=None) -> Dict:
         assert rays_o.dim() == rays_d.dim() == 2, "rays_o and rays_d should have size of [N, 3]"
         config = self.config
         if with_rgb is None:
@@ -89,31 +94,88 @@ class SingleVolumeRenderer(nn.Module):
                                  return_buffer=True, return_details=return_details,
                                  render_per_obj_individual=render_per_obj_individual)
         vb = cr_ret["volume_buffer"]
-        total_volume_buffer = dict(type="empty")
         if vb["type"] != "empty":
             rih, pih = vb["rays_inds_hit"], vb["pack_infos_hit"]
             total_num_samples_per_ray[rih] += pih[:, 1]
             vb.update(rays_inds_collect=rih, pack_infos_collect=pih)
             if "nablas" in vb:
                 vb["nablas_in_world"] = vb["nablas"]          # identity object->world rotation (single object)
-            # ---- volume integration (reference :73-102) through the fused compositing kernel
-            nab = vb.get("nablas_in_world") if with_normal else None
+        # ---- distant-view model on ALL rays (reference :281-335)
+        dv_vb = None
+        if distant_model is not None:
+            near_dv = torch.full([N], float(near) if near is not None else 0.0, dtype=torch.float32, device=device)
+            if cr_ray_tested["num_rays"] > 0:
+                near_dv[cr_ray_tested["rays_inds"]] = cr_ray_tested["far"]
+            dv_tested = dict(rays_o=rays_o.detach(), rays_d=rays_d.detach(), near=near_dv, rays_h_appear=rays_h_appear,
+                             num_rays=N, rays_inds=torch.arange(N, device=device))
+            dv_cfg = dict(distant_model.ray_query_cfg)
+            dv_cfg.update({k: v for k, v in config.items()})
+            for k, v in (bypass_ray_query_cfg or {}).items():
+                dv_cfg[k] = v
+            dv_ret = distant_model.ray_query(ray_tested=dv_tested, config=dv_cfg, return_buffer=True,
+                                             return_details=return_details)
+            dv_vb = dv_ret["volume_buffer"]
+            K = dv_vb["num_per_hit"]
+            total_num_samples_per_ray += K
+            dv_vb.update(rays_inds_collect=dv_vb["rays_inds_hit"],
+                         pack_infos_collect=po.get_pack_infos_from_n(torch.full([N], K, dtype=torch.long, device=device)))
+        # ---- total volume buffer (reference :337-407)
+        total_volume_buffer = dict(type="empty")
+        pidx_cr = pidx_dv = None
+        if vb["type"] != "empty" and dv_vb is not None:
+            pidx_dv, pidx_cr, total_pi = po.merge_two_packs_sorted(
+                dv_vb["t"].flatten(), dv_vb["pack_infos_collect"], dv_vb["rays_inds_collect"],
+                vb["t"].flatten(), vb["pack_infos_collect"], vb["rays_inds_collect"])
+            S_tot = dv_vb["t"].numel() + vb["t"].numel()
+
+            def place(a_dv, a_cr, tail=()):
+                z = torch.zeros([S_tot, *tail], dtype=torch.float32, device=device)
+                if a_dv is not None:
+                    z = z.index_put((pidx_dv,), a_dv)
+                if a_cr is not None:
+                    z = z.index_put((pidx_cr,), a_cr)
+                return z
+            total_volume_buffer = dict(type="packed", rays_inds_hit=torch.arange(N, device=device), pack_infos_hit=total_pi,
+                                       t=place(dv_vb["t"].flatten(), vb["t"].flatten()),
+                                       opacity_alpha=place(dv_vb["opacity_alpha"].flatten(), vb["opacity_alpha"].flatten()))
+            if with_rgb:
+                total_volume_buffer["rgb"] = place(dv_vb["rgb"].flatten(0, -2), vb["rgb"].flatten(0, -2), (3,))
+            if with_normal and "nablas_in_world" in vb:
+                total_volume_buffer["nablas_in_world"] = place(None, vb["nablas_in_world"].flatten(0, -2), (3,))
+        elif vb["type"] != "empty":
+            total_volume_buffer = dict(type="packed", rays_inds_hit=vb["rays_inds_hit"], pack_infos_hit=vb["pack_infos_hit"],
+                                       t=vb["t"], opacity_alpha=vb["opacity_alpha"])
+            for k in ("rgb", "nablas_in_world"):
+                if k in vb:
+                    total_volume_buffer[k] = vb[k]
+        elif dv_vb is not None:
+            total_volume_buffer = dict(type="packed", rays_inds_hit=dv_vb["rays_inds_hit"],
+                                       pack_infos_hit=dv_vb["pack_infos_collect"], t=dv_vb["t"].flatten(),
+                                       opacity_alpha=dv_vb["opacity_alpha"].flatten())
+            if with_rgb:
+                total_volume_buffer["rgb"] = dv_vb["rgb"].flatten(0, -2)
+        # ---- volume rendering (reference :73-102, :412-442) through the fused compositing kernel
+        if total_volume_buffer["type"] != "empty":
+            tvb = total_volume_buffer
+            rih, pih = tvb["rays_inds_hit"], tvb["pack_infos_hit"]
+            nab = tvb.get("nablas_in_world") if with_normal else None
             if nab is not None and not self.training:
                 nab = F.normalize(nab.clamp(-1, 1), dim=-1)
-            out = volume_integration(vb["opacity_alpha"], vb["t"], vb.get("rgb") if with_rgb else None, nab, pih,
+            out = volume_integration(tvb["opacity_alpha"], tvb["t"], tvb.get("rgb") if with_rgb else None, nab, pih,
                                      config.get("depth_use_normalized_vw", True))
-            vb["vw"] = vb["vw_in_total"] = out["vw"]
+            tvb["vw"] = out["vw"]
+            if pidx_cr is not None:
+                vb["vw_in_total"], dv_vb["vw_in_total"] = out["vw"][pidx_cr], out["vw"][pidx_dv]
+            elif vb["type"] != "empty":
+                vb["vw"] = vb["vw_in_total"] = out["vw"]
+            else:
+                dv_vb["vw_in_total"] = out["vw"]
             total_rendered["mask_volume"] = total_rendered["mask_volume"].index_put((rih,), out["mask_volume"])
             total_rendered["depth_volume"] = total_rendered["depth_volume"].index_put((rih,), out["depth_volume"])
             if with_rgb and "rgb_volume" in out:
                 total_rendered["rgb_volume"] = total_rendered["rgb_volume"].index_put((rih,), out["rgb_volume"])
             if with_normal and "normals_volume" in out:
                 total_rendered["normals_volume"] = total_rendered["normals_volume"].index_put((rih,), out["normals_volume"])
-            total_volume_buffer = dict(type=vb["type"], rays_inds_hit=rih, pack_infos_hit=pih, t=vb["t"],
-                                       opacity_alpha=vb["opacity_alpha"], vw=out["vw"])
-            for k in ("rgb", "nablas_in_world"):
-                if k in vb:
-                    total_volume_buffer[k] = vb[k]
         if with_rgb:
             total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]
         ret = dict(ray_intersections=dict(samples_cnt=total_num_samples_per_ray), rendered=total_rendered)
@@ -121,11 +183,14 @@ class SingleVolumeRenderer(nn.Module):
             ret["volume_buffer"] = total_volume_buffer
         if return_details:
             ret["raw_per_obj_model"] = {"main": cr_ret}
+            if dv_vb is not None:
+                ret["raw_per_obj_model"]["distant"] = dv_ret
         return ret
 
     def render(self, model: LoTDNeuSModel, *, rays: List[torch.Tensor], rays_h_appear: torch.Tensor = None, near=None,
                far=None, rayschunk: int = None, with_rgb=None, with_normal=None, return_buffer=False,
-               return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None) -> Dict:
+               return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
+               distant_model=None) -> Dict:
         """rays = [rays_o, rays_d(, rays_ts, rays_pix)] with arbitrary prefix shape (reference :495-581)."""
         if rayschunk is None:
             rayschunk = self.config.get("rayschunk", 0)
@@ -135,7 +200,8 @@ class SingleVolumeRenderer(nn.Module):
             ha = rays_h_appear.flatten(0, len(prefix_shape) - 1) if rays_h_appear is not None else None
             kwargs = dict(model=model, near=near, far=far, with_rgb=with_rgb, with_normal=with_normal,
                           return_buffer=return_buffer, return_details=return_details,
-                          render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg)
+                          render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg,
+                          distant_model=distant_model)
             if self.training or (not rayschunk) or flat[0].shape[0] <= rayschunk:
                 ret = self(*flat[:2], rays_h_appear=ha, **kwargs)
             else:

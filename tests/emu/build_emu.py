@@ -7,7 +7,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE.parent.parent / "neuralsim_amd" / "csrc"
-SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "optim.hip", "misc.hip"]
+SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "optim.hip", "misc.hip"]
 LIB = HERE / "_build" / "libnsim_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DNSIM_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", f"-I{CSRC}",
@@ -17,7 +17,7 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DNSIM_HOST_EMU", "-ffp-con
 def build(force=False):
     LIB.parent.mkdir(exist_ok=True)
     h = hashlib.sha256()
-    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", HERE / "hip_emu.h",
+    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", HERE / "hip_emu.h",
                                             HERE / "hip_emu.cpp", CSRC.parent.parent / "include" / "nsim.h"]:
         h.update(f.read_bytes())
     stamp = LIB.parent / "stamp"
