@@ -31,6 +31,8 @@ SPHERE_RADIUS = 0.75
 #   SDF-branch backward   72 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 73 728 FLOP
 #   radiance backward     44 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 45 056 FLOP
 KERNEL_MODEL = {
+    "nsim_distant_fwd": ("hbm", 12 * 16 * 4 + 128 + 16.0),      # 12 levels x 16 corners x 4 B + planes + outputs
+    "nsim_distant_bwd": ("mfma", 56 * 32768 / 32.0),            # 56 MFMA 32x32x16 per 32-point tile
     "nsim_field_sdf": ("hbm", 512.0),
     "nsim_field_fwd": ("hbm", 1052.0),
     "nsim_lotd_scatter": ("hbm", 1304.0),
@@ -41,7 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
 
-def build_trainer(device, rank, world, seed=42):
+def build_trainer(device, rank, world, seed=42, distant=False):
     from neuralsim_amd.fields.neus import LoTDNeuSModel
     from neuralsim_amd.graphics.cameras import look_at_cameras
     from neuralsim_amd.trainer import RenderTrainer
@@ -53,10 +55,16 @@ def build_trainer(device, rank, world, seed=42):
     model.accel.init(model.query_sdf, generator=torch.Generator(device=device).manual_seed(seed))
     ndist.broadcast_module(model)
     intr, c2w, WH = look_at_cameras(V=100, seed=seed, device=device)
+    dm = None
+    if distant:      # NeRF++ distant-view model of the reference config (dtu yaml :186-247): 64 shells on EVERY ray
+        from neuralsim_amd.fields.nerf_distant import LoTDNeRFDistantModel
+        dm = LoTDNeRFDistantModel(aabb=model.accel.aabb.detach().cpu(), precision="fp16", seed=seed + 7).to(device)
+        ndist.broadcast_module(dm)
     # lr 1e-3 (reference fglr is 1e-2 with warm-up): the targets are random colours, so a small rate keeps the
     # synthetic geometry -- and with it the sample statistics -- stationary over the timed steps; the work is identical
     return RenderTrainer(model, intr, c2w, WH, num_rays=RAYS_PER_GPU, lr=1e-3, w_eikonal=0.1, num_uniform=4096,
-                         rank=rank, world_size=world, seed=seed, learn_inv_s=False)   # inv_s is scheduled (mix_linear), held at e^5
+                         rank=rank, world_size=world, seed=seed, learn_inv_s=False,   # inv_s is scheduled (mix_linear), held at e^5
+                         distant_model=dm)
 
 
 def cpu_baseline(tr, n_rays=1024, iters=2):
@@ -131,6 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--distant", action="store_true",
+                    help="add the NeRF++ distant-view model (64 shells on every ray), as in the reference's full config")
     args = ap.parse_args()
 
     from neuralsim_amd import _lib, distributed as ndist
@@ -139,10 +149,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.get_lib()
-    tr = build_trainer(dev, rank, world)
+    tr = build_trainer(dev, rank, world, distant=args.distant)
     out = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=RAYS_PER_GPU)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        out["config"]["distant_model"] = bool(args.distant)
+        if world == 1 and not args.no_cpu_baseline and not args.distant:
             out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
         print(json.dumps(out), flush=True)
     if world > 1:

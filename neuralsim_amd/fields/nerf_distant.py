@@ -63,6 +63,9 @@ class _DistantFn(torch.autograd.Function):
         ha = h_appear.detach().float().contiguous() if h_appear is not None else None
         _lib.call("nsim_distant_fwd", model.meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(u4), _lib.ptr(rays_d),
                   _lib.ptr(ha), S, K, _lib.ptr(sigma), _lib.ptr(rgb), _lib.ptr(h_pl))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_distant_fwd", S)
+            _lib.TIMER.note_units("nsim_distant_bwd", S)
         ctx.model, ctx.S, ctx.K = model, S, K
         ctx.saved = (u4, rays_d, valid, ha, h_pl, sigma, rgb)
         ctx.ha_shape = h_appear.shape if h_appear is not None else None

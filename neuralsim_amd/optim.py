@@ -27,6 +27,16 @@ class FusedAdam:
             g["m"] = torch.zeros_like(g["p"], dtype=torch.float32)
             g["v"] = torch.zeros_like(g["p"], dtype=torch.float32)
         self.t = 0
+        self._dirty = [model]
+
+    def add_distant_model(self, dm, betas=(0.9, 0.99)):
+        """Parameters of a ``LoTDNeRFDistantModel`` (``training_cfg{lr: bglr, betas [.9,.99]}``, dtu yaml :242-247)."""
+        dm._shadow()
+        for p, p16 in ((dm.flattened_params, lambda: dm.params16), (dm.den_w, None), (dm.den_b, None), (dm.rad_w, None),
+                       (dm.rad_b, None)):
+            self.groups.append(dict(p=p, p16=p16, betas=betas, m=torch.zeros_like(p, dtype=torch.float32),
+                                    v=torch.zeros_like(p, dtype=torch.float32)))
+        self._dirty.append(dm)
 
     def params(self) -> List[torch.Tensor]:
         return [g["p"] for g in self.groups]
@@ -44,7 +54,8 @@ class FusedAdam:
             _lib.call("nsim_adam_step", _lib.ptr(p.data), _lib.ptr(p16), _lib.ptr(p.grad.contiguous()), _lib.ptr(g["m"]),
                       _lib.ptr(g["v"]), p.numel(), float(lr), float(b1), float(b2), float(self.eps),
                       1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(grad_scale), 0)
-        self.model._wpack_versions = None      # MLP weights changed in place: re-pack the MFMA fragments lazily
+        for m in self._dirty:
+            m._wpack_versions = None           # MLP weights changed in place: re-pack the MFMA fragments lazily
 
     def zero_grad(self):
         for g in self.groups:

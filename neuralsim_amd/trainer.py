@@ -22,7 +22,8 @@ from .optim import FusedAdam
 class RenderTrainer:
     def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
-                 perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True):
+                 perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
+                 distant_model=None):
         self.model = model
         self.intr, self.c2w, self.WH = intr, c2w, WH
         self.V = intr.shape[0]
@@ -38,6 +39,12 @@ class RenderTrainer:
         self.optim = FusedAdam(model, lr=lr, learn_inv_s=learn_inv_s)
         self.optim.groups.append(dict(p=self.appear, p16=None, betas=(0.9, 0.99), m=torch.zeros_like(self.appear),
                                       v=torch.zeros_like(self.appear)))
+        self.distant_model = distant_model
+        if distant_model is not None:
+            self.optim.add_distant_model(distant_model)
+        from .renderers.single_volume_renderer import SingleVolumeRenderer
+        self.renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=near, far=far, perturb=perturb,
+                                                  depth_use_normalized_vw=False)).train()
         self.stats: Dict[str, float] = {}
 
     def sample_batch(self):
@@ -49,25 +56,20 @@ class RenderTrainer:
         return xy, fidx, gt
 
     def render(self, xy, fidx, with_normal=True):
+        """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration)."""
         rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
         h_appear = self.appear[fidx]
-        tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far, rays_h_appear=h_appear)
-        cfg = dict(self.model.ray_query_cfg)
-        cfg.update(with_rgb=True, with_normal=with_normal, perturb=self.perturb, depth_use_normalized_vw=False,
-                   _render=True)
-        ret = self.model.ray_query(ray_tested=tested, config=cfg, return_details=True)
-        return tested, ret
+        ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
+                                   return_buffer=True, return_details=True, distant_model=self.distant_model)
+        return ret
 
-    def loss(self, tested, ret, gt):
-        N = gt.shape[0]
-        dev = gt.device
-        rgb_full = torch.zeros([N, 3], dtype=torch.float32, device=dev)
-        eik = torch.zeros([], device=dev)
-        if tested["num_rays"] > 0:
-            rgb_full = rgb_full.index_put((tested["rays_inds"],), ret["rendered"]["rgb_volume"])
-            nab = ret["volume_buffer"]["nablas"]
-            eik = ((nab.norm(dim=-1) - 1.0) ** 2).mean()
-        loss_rgb = ((rgb_full - gt) ** 2).mean()
+    def loss(self, ret, gt):
+        """photometric mse on all rays + eikonal on the close-range render samples and on uniform points."""
+        loss_rgb = ((ret["rendered"]["rgb_volume"] - gt) ** 2).mean()
+        eik = torch.zeros([], device=gt.device)
+        cr_vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
+        if cr_vb["type"] != "empty":
+            eik = ((cr_vb["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
         if self.num_uniform > 0:
             uni = self.model.sample_pts_uniform(self.num_uniform, generator=self.gen)
             eik = eik + ((uni["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
@@ -80,12 +82,13 @@ class RenderTrainer:
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         xy, fidx, gt = self.sample_batch()
-        tested, ret = self.render(xy, fidx)
-        loss, parts = self.loss(tested, ret, gt)
+        ret = self.render(xy, fidx)
+        loss, parts = self.loss(ret, gt)
         self.optim.zero_grad()
         loss.backward()
         ndist.allreduce_grads(self.optim.params(), average=True)
         self.optim.step()
-        vb = ret["volume_buffer"]
-        self.stats = dict(R_hit=tested["num_rays"], S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
+        vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
+        self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
+                          S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
         return loss.detach()
