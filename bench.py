@@ -33,6 +33,7 @@ SPHERE_RADIUS = 0.75
 KERNEL_MODEL = {
     "nsim_distant_fwd": ("hbm", 12 * 16 * 4 + 128 + 16.0),      # 12 levels x 16 corners x 4 B + planes + outputs
     "nsim_distant_bwd": ("mfma", 56 * 32768 / 32.0),            # 56 MFMA 32x32x16 per 32-point tile
+    "nsim_lotd4_scatter": ("hbm", 12 * 16 * 2 * 4 + 128 + 16.0),
     "nsim_field_sdf": ("hbm", 512.0),
     "nsim_field_fwd": ("hbm", 1052.0),
     "nsim_lotd_scatter": ("hbm", 1304.0),

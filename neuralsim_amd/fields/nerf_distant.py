@@ -66,6 +66,7 @@ class _DistantFn(torch.autograd.Function):
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_distant_fwd", S)
             _lib.TIMER.note_units("nsim_distant_bwd", S)
+            _lib.TIMER.note_units("nsim_lotd4_scatter", S)
         ctx.model, ctx.S, ctx.K = model, S, K
         ctx.saved = (u4, rays_d, valid, ha, h_pl, sigma, rgb)
         ctx.ha_shape = h_appear.shape if h_appear is not None else None

@@ -125,7 +125,7 @@ class SingleVolumeRenderer(nn.Module):
         if vb["type"] != "empty" and dv_vb is not None:
             pidx_dv, pidx_cr, total_pi = po.merge_two_packs_sorted(
                 dv_vb["t"].flatten(), dv_vb["pack_infos_collect"], dv_vb["rays_inds_collect"],
-                vb["t"].flatten(), vb["pack_infos_collect"], vb["rays_inds_collect"])
+                vb["t"].flatten(), vb["pack_infos_collect"], vb["rays_inds_collect"], a_is_arange=True)
             S_tot = dv_vb["t"].numel() + vb["t"].numel()
 
             def place(a_dv, a_cr, tail=()):
@@ -170,12 +170,10 @@ class SingleVolumeRenderer(nn.Module):
                 vb["vw"] = vb["vw_in_total"] = out["vw"]
             else:
                 dv_vb["vw_in_total"] = out["vw"]
-            total_rendered["mask_volume"] = total_rendered["mask_volume"].index_put((rih,), out["mask_volume"])
-            total_rendered["depth_volume"] = total_rendered["depth_volume"].index_put((rih,), out["depth_volume"])
-            if with_rgb and "rgb_volume" in out:
-                total_rendered["rgb_volume"] = total_rendered["rgb_volume"].index_put((rih,), out["rgb_volume"])
-            if with_normal and "normals_volume" in out:
-                total_rendered["normals_volume"] = total_rendered["normals_volume"].index_put((rih,), out["normals_volume"])
+            every_ray = rih.shape[0] == N          # rays_inds are sorted & unique: R == N means identity
+            for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+                if k in out and k in total_rendered:
+                    total_rendered[k] = out[k] if every_ray else total_rendered[k].index_put((rih,), out[k])
         if with_rgb:
             total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]
         ret = dict(ray_intersections=dict(samples_cnt=total_num_samples_per_ray), rendered=total_rendered)
