@@ -18,7 +18,7 @@ BUILD = HERE / "_build"
 # -ffp-contract=off: sample-membership arithmetic must round exactly like the oracle (mul then add);
 # the hot arithmetic lives on the MFMA pipe, not in contracted VALU FMAs.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-munsafe-fp-atomics", "-Wno-unused-result"]
+               "-munsafe-fp-atomics", "-Wno-unused-result"] + os.environ.get("NSIM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

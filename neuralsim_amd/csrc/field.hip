@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     __syncthreads();
   }
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
+  const GridRef gref = grid_ref(a.grid);
 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                             c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
             float g0, g1;
-            lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
+            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + 2u * idx, g0, g1);
             f0 = f0 + w * g0;
             f1 = f1 + w * g1;
             if (MODE >= 1) {
@@ -648,8 +649,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // features (and 32 corner loads) are live at a time -> ~half the registers of the fused forward -> more waves per
 // SIMD to hide the gather latency.  Features are scaled by a fixed exact power of two before the f16 conversion.
 #define SDF_H_SCALE 1024.0f
+#ifndef NSIM_SDF_MIN_WAVES
+#define NSIM_SDF_MIN_WAVES 2
+#endif
 template <int PREC, int SDF_D>
-__global__ void __launch_bounds__(64 * FIELD_WAVES) k_field_sdf(FieldArgs a) {
+__global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_sdf(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -658,6 +662,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field_sdf(FieldArgs a) {
   int wbytes;
   const char* W = stage_weights<PREC>(smem, a, 0, 2, L, wbytes);   // W1, W2 only
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
+  const GridRef gref = grid_ref(a.grid);
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
@@ -681,7 +686,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field_sdf(FieldArgs a) {
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                             c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
             float g0, g1;
-            lotd_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
+            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + 2u * idx, g0, g1);
             f0 = f0 + w * g0;
             f1 = f1 + w * g1;
           }
@@ -706,22 +711,45 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field_sdf(FieldArgs a) {
       }
     }
     const float inv_h = PREC == 0 ? 1.0f / SDF_H_SCALE : 1.0f;
-    float a1[32];
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        a1[mo * 16 + r] = softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
     float sdf = 0.f;
-    if constexpr (SDF_D == 2) {
-      float a2[32];
-      dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+    if constexpr (PREC == 0 && SDF_D == 2) {
+      // register-lean second layer: layer-1 activations are packed to f16 B fragments at once (16 VGPRs), each
+      // output M-tile is consumed by the head dot-product as soon as its four MFMAs retire
+      f16x8 bq[4];
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        sdf = sdf + vecf(W, L, V_WH, hi, k) * softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          bq[2 * mo + (r >> 3)][r & 7] =
+              (f16)softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+      const f16x8* A2 = reinterpret_cast<const f16x8*>(W + L.mat[M_W2]);
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) {
+        f32x16 acc2 = zero16();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) acc2 = mfma_32x32x16_f16(A2[(mo * 4 + st) * 64 + lane], bq[st], acc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
+                          softplus_b(acc2[r] + vecf(W, L, V_B2, hi, mo * 16 + r), beta, inv_beta);
+      }
     } else {
+      float a1[32];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) sdf = sdf + vecf(W, L, V_WH, hi, k) * a1[k];
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          a1[mo * 16 + r] = softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+      if constexpr (SDF_D == 2) {
+        float a2[32];
+        dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          sdf = sdf + vecf(W, L, V_WH, hi, k) * softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sdf = sdf + vecf(W, L, V_WH, hi, k) * a1[k];
+      }
     }
     sdf = sdf + wave_shfl_xor(sdf, 32);
     sdf = sdf + b_out;
