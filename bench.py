@@ -136,8 +136,8 @@ def cpu_baseline(tr, n_rays=1024, iters=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--distant", action="store_true",
@@ -182,24 +182,47 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
         if on_gpu:
             torch.cuda.synchronize()
 
+    # the cyclic collector is parked over the timed steps (a generation-2 pass over torch's module graph costs tens
+    # of ms, i.e. ~10 steps); NSIM_BENCH_GC=1 leaves it on
+    import gc
+    gc.collect()
+    if os.environ.get("NSIM_BENCH_GC") != "1":
+        gc.freeze()
+        gc.disable()
     fence()
     # HIP events around the modelled kernels only (on the launch stream)
     _lib.TIMER = _lib.KernelTimer(only=KERNEL_MODEL.keys()) if on_gpu else None
     S_f = S_hit = 0
+    trace = []
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(it)
         it += 1
         S_f += tr.stats["S_f"]
         S_hit += tr.stats["R_hit"]
+        if os.environ.get("NSIM_BENCH_TRACE"):
+            trace.append((time.perf_counter() - t0, tr.stats["S_f"]))
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timer, _lib.TIMER = _lib.TIMER, None
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    if trace and rank == 0:
+        prev = 0.0
+        if os.environ.get("NSIM_BENCH_TRACE") == "2":
+            pp = 0.0
+            for i, (tt, sf) in enumerate(trace):
+                print(f"[step] {i} {1e3 * (tt - pp):.3f} ms S_f {sf} occ {int((tr.model.accel.occ_val > tr.model.accel.occ_thre).sum()) if i == len(trace) - 1 else -1}", file=sys.stderr)
+                pp = tt
+        for i in range(0, len(trace), 8):
+            chunk = trace[i:i + 8]
+            print(f"[trace] steps {i}-{i + len(chunk) - 1}: {(chunk[-1][0] - prev) / len(chunk) * 1e3:.3f} ms/step, "
+                  f"S_f {sum(c[1] for c in chunk) / len(chunk):.0f}", file=sys.stderr)
+            prev = chunk[-1][0]
     if rank != 0:
         return None
     if True:
