@@ -262,6 +262,19 @@ int nsim_distant_bwd(const NsimDistantMeta* meta, const void* wpack, const float
 int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t* valid, int64_t S,
                        const float* dh_planes, float* dgrid, void* stream);
 
+/* ------------------------------------------------------------------------------- losses (row a18) */
+/* Fused reductions of the two losses of the object-centric configs and the gradient of the appearance-embedding
+ * lookup.  *out is a device scalar the caller zeroes; the kernels ADD the mean into it.
+ *   eikonal: mean((|nablas_i| - 1)^2), nablas [S,3]          replaces app/loss/eikonal.py:96-105 (fn, plain mse) + .mean()
+ *   mse:     mean((pred - gt)^2) over n floats               replaces app/loss/photometric.py:88-146 (fn_type mse)
+ *   rows_scatter_add: out[idx[i], :] += g[i, :], g [n,C], out [rows,C]
+ *                                                            backward of ``embed[fidx]``, app/models/scene/image_embeddings.py:23-80 */
+int nsim_eikonal_loss_fwd(const float* nablas, int64_t S, float* out, void* stream);
+int nsim_eikonal_loss_bwd(const float* nablas, int64_t S, const float* gout, float* dnablas, void* stream);
+int nsim_mse_loss_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);
+int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float* gout, float* dpred, void* stream);
+int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, int64_t rows, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;
  * p16 (may be NULL) receives the fp16 copy used by the kernels; grad is scaled by grad_scale and zeroed. */

@@ -86,6 +86,11 @@ SIGNATURES = {
     "nsim_distant_fwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_distant_bwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_lotd4_scatter": [C.POINTER(Lotd4Meta), _P, _P, _I64, _P, _P],
+    "nsim_eikonal_loss_fwd": [_P, _I64, _P],
+    "nsim_eikonal_loss_bwd": [_P, _I64, _P, _P],
+    "nsim_mse_loss_fwd": [_P, _P, _I64, _P],
+    "nsim_mse_loss_bwd": [_P, _P, _I64, _P, _P],
+    "nsim_rows_scatter_add": [_P, _P, _I64, _I, _I64, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }

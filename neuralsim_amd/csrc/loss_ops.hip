@@ -1,0 +1,157 @@
+// loss_ops.hip -- fused reductions of the losses the training step evaluates on the path's outputs (SURVEY sec. 8 row
+// a18) and the gradient of the per-frame appearance-embedding lookup.
+//   * eikonal: mean((|nablas| - 1)^2)                 (app/loss/eikonal.py:96-105 with safe_mse off, alpha_reg_zero 0)
+//   * photometric mse: mean((pred - gt)^2)            (app/loss/photometric.py:88-146, fn_type mse, no mask)
+//   * rows_scatter_add: d embed[idx[i], :] += g[i, :]  (app/models/scene/image_embeddings.py:23-80: ``embed[fidx]``)
+// The reference evaluates these with a handful of torch ops each; here one launch per direction, because at 8192
+// rays per iteration the step is bounded by launch count, not by bytes.
+#include "nsim_common.h"
+
+#define LOSS_BLOCK 256
+#define LOSS_MAX_BLOCKS 256
+
+__device__ __forceinline__ void block_sum_atomic(float v, float scale, float* out) {
+  __shared__ float red[LOSS_BLOCK / 64];
+  v = wave_sum(v);
+  if (nsim_lane() == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < LOSS_BLOCK / 64; ++w) tot += red[w];
+    if (tot != 0.f) atomicAdd(out, tot * scale);
+  }
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_eikonal_fwd(const float* __restrict__ nab, int64_t S, float inv_S,
+                                                            float* __restrict__ out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < S; i += (int64_t)gridDim.x * LOSS_BLOCK) {
+    const float a = nab[3 * i], b = nab[3 * i + 1], c = nab[3 * i + 2];
+    const float e = sqrtf(a * a + b * b + c * c) - 1.0f;
+    acc += e * e;
+  }
+  block_sum_atomic(acc, inv_S, out);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_eikonal_bwd(const float* __restrict__ nab, int64_t S, float inv_S,
+                                                            const float* __restrict__ gout, float* __restrict__ dnab) {
+  const int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+  if (i >= S) return;
+  const float a = nab[3 * i], b = nab[3 * i + 1], c = nab[3 * i + 2];
+  const float nrm = sqrtf(a * a + b * b + c * c);
+  // d/dn (|n|-1)^2 = 2 (|n|-1) n/|n|; the sub-gradient at n = 0 is 0 (as torch.norm's backward)
+  const float k = nrm > 0.f ? gout[0] * inv_S * 2.0f * (nrm - 1.0f) / nrm : 0.f;
+  dnab[3 * i] = k * a;
+  dnab[3 * i + 1] = k * b;
+  dnab[3 * i + 2] = k * c;
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_mse_fwd(const float* __restrict__ a, const float* __restrict__ b,
+                                                        int64_t n, float inv_n, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_BLOCK) {
+    const float e = a[i] - b[i];
+    acc += e * e;
+  }
+  block_sum_atomic(acc, inv_n, out);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK) k_mse_bwd(const float* __restrict__ a, const float* __restrict__ b,
+                                                        int64_t n, float inv_n, const float* __restrict__ gout,
+                                                        float* __restrict__ da) {
+  const int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  da[i] = gout[0] * inv_n * 2.0f * (a[i] - b[i]);
+}
+
+// rows * C <= ROWS_LDS_MAX: per-block LDS histogram (the few hundred frame embeddings are hit by thousands of rays),
+// flushed with one global atomic per touched entry; larger tables go straight to global atomics.
+#define ROWS_LDS_MAX 4096
+__global__ void __launch_bounds__(LOSS_BLOCK) k_rows_scatter_add(const float* __restrict__ g,
+                                                                 const int64_t* __restrict__ idx, int64_t n, int C,
+                                                                 int64_t rows, float* __restrict__ out) {
+  __shared__ float acc[ROWS_LDS_MAX];
+  const int64_t tot = rows * C;
+  const bool use_lds = tot <= ROWS_LDS_MAX;
+  if (use_lds) {
+    for (int j = threadIdx.x; j < tot; j += LOSS_BLOCK) acc[j] = 0.f;
+    __syncthreads();
+  }
+  const int64_t nC = n * C;
+  for (int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < nC; i += (int64_t)gridDim.x * LOSS_BLOCK) {
+    const int64_t r = idx[i / C];
+    if (r < 0 || r >= rows) continue;
+    const int64_t j = r * C + (i % C);
+    if (use_lds) atomicAdd(&acc[j], g[i]);
+    else atomicAdd(&out[j], g[i]);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < tot; j += LOSS_BLOCK) {
+      const float v = acc[j];
+      if (v != 0.f) atomicAdd(&out[j], v);
+    }
+  }
+}
+
+static inline dim3 loss_grid(int64_t n) {
+  int64_t b = nsim_blocks(n, LOSS_BLOCK);
+  return dim3((unsigned)(b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : b));
+}
+
+extern "C" {
+
+// out[0] must be zero on entry (the caller's memset is part of the op); out[0] += mean((|nab_i| - 1)^2)
+int nsim_eikonal_loss_fwd(const float* nablas, int64_t S, float* out, void* stream) {
+  if (S < 0) return 2;
+  if (!out) return 4;
+  if (S == 0) return 0;
+  hipLaunchKernelGGL(k_eikonal_fwd, loss_grid(S), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, nablas, S,
+                     1.0f / (float)S, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_eikonal_loss_bwd(const float* nablas, int64_t S, const float* gout, float* dnablas, void* stream) {
+  if (S < 0) return 2;
+  if (S == 0) return 0;
+  if (!dnablas || !gout) return 26;
+  hipLaunchKernelGGL(k_eikonal_bwd, dim3(nsim_blocks(S, LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, nablas,
+                     S, 1.0f / (float)S, gout, dnablas);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_mse_loss_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream) {
+  if (n < 0) return 2;
+  if (!out) return 4;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_mse_fwd, loss_grid(n), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, pred, gt, n, 1.0f / (float)n,
+                     out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float* gout, float* dpred, void* stream) {
+  if (n < 0) return 2;
+  if (n == 0) return 0;
+  if (!dpred || !gout) return 26;
+  hipLaunchKernelGGL(k_mse_bwd, dim3(nsim_blocks(n, LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, pred, gt, n,
+                     1.0f / (float)n, gout, dpred);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+// out [rows, C] must be initialised by the caller (zeros for a plain gradient)
+int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, int64_t rows, float* out, void* stream) {
+  if (n < 0 || rows < 0) return 2;
+  if (C <= 0) return 3;
+  if (n == 0) return 0;
+  if (!out) return 4;
+  hipLaunchKernelGGL(k_rows_scatter_add, loss_grid(n * C), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, g, idx, n, C, rows,
+                     out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -411,12 +411,15 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
     const float* __restrict__ sdf, const float* __restrict__ dalpha, const int64_t* __restrict__ pi, int64_t P,
     const float* __restrict__ ln_inv_s, float factor, float forward_inv_s, float* __restrict__ dsdf,
     float* __restrict__ d_ln_inv_s) {
-  const int64_t p = pack_wave_id();
-  if (p >= P) return;
+  // a capped grid walks the packs wave by wave; d(ln_inv_s) is reduced per block before the single-address atomic
+  // (one atomic per pack serialises at L2: 8192 rays cost ~0.1 ms)
+  __shared__ float red[PACK_WAVES_PER_BLOCK];
   const int lane = nsim_lane();
-  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
   const float s = neus_inv_s(ln_inv_s, factor, forward_inv_s);
+  const int64_t nw = (int64_t)gridDim.x * PACK_WAVES_PER_BLOCK;
   float ds_acc = 0.f;
+  for (int64_t p = pack_wave_id(); p < P; p += nw) {
+  const int64_t st = pi[2 * p], n = pi[2 * p + 1];
   for (int64_t base = 0; base < n; base += 64) {
     const int64_t i = base + lane;
     float g = 0.f;
@@ -450,9 +453,16 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
       dsdf[st + i] = g;
     }
   }
+  }
   if (d_ln_inv_s && forward_inv_s <= 0.f) {
     ds_acc = wave_sum(ds_acc);
-    if (lane == 0 && ds_acc != 0.f) atomicAdd(d_ln_inv_s, ds_acc * s * factor);
+    if (lane == 0) red[threadIdx.x >> 6] = ds_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < PACK_WAVES_PER_BLOCK; ++w) tot += red[w];
+      if (tot != 0.f) atomicAdd(d_ln_inv_s, tot * s * factor);
+    }
   }
 }
 
@@ -590,7 +600,9 @@ int nsim_neus_alpha_bwd(const float* sdf, const float* dalpha, const int64_t* pa
                         const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, float* dsdf,
                         float* d_ln_inv_s, void* stream) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(k_neus_alpha_bwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, sdf, dalpha, pack_infos, P,
+  dim3 grid = pack_grid(P);
+  if (grid.x > 512) grid.x = 512;
+  hipLaunchKernelGGL(k_neus_alpha_bwd, grid, dim3(PACK_BLOCK), 0, (hipStream_t)stream, sdf, dalpha, pack_infos, P,
                      ln_inv_s, ln_inv_s_factor, forward_inv_s, dsdf, d_ln_inv_s);
   NSIM_CHECK_LAUNCH();
   return 0;

@@ -77,10 +77,9 @@ class _FieldFn(torch.autograd.Function):
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
         need = ctx.needs_input_grad
         dgrid = torch.zeros([model.encoding.cfg.n_params], dtype=torch.float32, device=dev) if need[1] else None
-        dsdf_w = torch.zeros([n_sdf_w], dtype=torch.float32, device=dev)
-        dsdf_b = torch.zeros([n_sdf_b], dtype=torch.float32, device=dev)
-        drad_w = torch.zeros([n_rad_w], dtype=torch.float32, device=dev)
-        drad_b = torch.zeros([n_rad_b], dtype=torch.float32, device=dev)
+        # one memset for the four small accumulators
+        dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], dtype=torch.float32,
+                                                     device=dev).split([n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
         dha = torch.zeros(ctx.ha_shape, dtype=torch.float32, device=dev) if (ha is not None and need[6]) else None
         gs = g_sdf.float().contiguous() if g_sdf is not None else None
         gn = g_nab.float().contiguous() if g_nab is not None else None
@@ -478,9 +477,9 @@ class LoTDNeuSModel(nn.Module):
         rays_d = rays_d.float().contiguous()
         N = rays_o.shape[0]
         dev = rays_o.device
-        near_t = torch.zeros([N], dtype=torch.float32, device=dev)
-        far_t = torch.zeros([N], dtype=torch.float32, device=dev)
-        hit = torch.zeros([N], dtype=torch.uint8, device=dev)
+        near_t = torch.empty([N], dtype=torch.float32, device=dev)
+        far_t = torch.empty([N], dtype=torch.float32, device=dev)
+        hit = torch.empty([N], dtype=torch.uint8, device=dev)
         _lib.call("nsim_aabb_ray_test", _lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), N, self.accel.meta,
                   float(near) if near is not None else 0.0, float(far) if far is not None else -1.0, _lib.ptr(near_t),
                   _lib.ptr(far_t), _lib.ptr(hit))
@@ -488,7 +487,14 @@ class LoTDNeuSModel(nn.Module):
         ret = dict(num_rays=int(rays_inds.shape[0]), rays_inds=rays_inds, rays_o=rays_o[rays_inds],
                    rays_d=rays_d[rays_inds], near=near_t[rays_inds], far=far_t[rays_inds])
         for k, v in extra.items():
-            ret[k] = v[rays_inds] if isinstance(v, torch.Tensor) and v.shape[:1] == (N,) else v
+            if isinstance(v, torch.Tensor) and v.shape[:1] == (N,):
+                if v.requires_grad and v.dim() == 2 and v.dtype == torch.float32:
+                    from ..losses import embedding_lookup      # row gather with a one-launch backward
+                    ret[k] = embedding_lookup(v, rays_inds)
+                else:
+                    ret[k] = v[rays_inds]
+            else:
+                ret[k] = v
         return ret
 
     def _arange_repeat(self, R: int, n: int, dev):

@@ -9,8 +9,8 @@ def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tens
                           WH: torch.Tensor, snap_to_pixel_centers: bool = True):
     """xy [N,2] in [0,1], fidx [N] int64, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] int64 -> rays_o, rays_d [N,3]."""
     N = xy.shape[0]
-    o = torch.zeros([N, 3], dtype=torch.float32, device=xy.device)
-    d = torch.zeros([N, 3], dtype=torch.float32, device=xy.device)
+    o = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
+    d = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
     _lib.call("nsim_raygen_pinhole", _lib.ptr(xy.float().contiguous()), _lib.ptr(fidx.long().contiguous()),
               _lib.ptr(intr.float().contiguous()), _lib.ptr(c2w.float().contiguous()), _lib.ptr(WH.long().contiguous()),
               N, 1 if snap_to_pixel_centers else 0, _lib.ptr(o), _lib.ptr(d))

@@ -17,6 +17,7 @@ from . import _lib, distributed as ndist
 from .fields.neus import LoTDNeuSModel, volume_integration
 from .graphics.cameras import pinhole_selected_rays
 from .optim import FusedAdam
+from .losses import eikonal_loss, mse_loss, embedding_lookup
 
 
 class RenderTrainer:
@@ -58,21 +59,25 @@ class RenderTrainer:
     def render(self, xy, fidx, with_normal=True):
         """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration)."""
         rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
-        h_appear = self.appear[fidx]
+        h_appear = embedding_lookup(self.appear, fidx)
         ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
                                    return_buffer=True, return_details=True, distant_model=self.distant_model)
         return ret
 
-    def loss(self, ret, gt):
+    def loss(self, ret, gt, uni=None):
         """photometric mse on all rays + eikonal on the close-range render samples and on uniform points."""
-        loss_rgb = ((ret["rendered"]["rgb_volume"] - gt) ** 2).mean()
-        eik = torch.zeros([], device=gt.device)
+        loss_rgb = mse_loss(ret["rendered"]["rgb_volume"], gt)
+        eik = None
         cr_vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
         if cr_vb["type"] != "empty":
-            eik = ((cr_vb["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+            eik = eikonal_loss(cr_vb["nablas"])
         if self.num_uniform > 0:
-            uni = self.model.sample_pts_uniform(self.num_uniform, generator=self.gen)
-            eik = eik + ((uni["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+            if uni is None:
+                uni = self.model.sample_pts_uniform(self.num_uniform, generator=self.gen)
+            e2 = eikonal_loss(uni["nablas"])
+            eik = e2 if eik is None else eik + e2
+        if eik is None:
+            eik = torch.zeros([], device=gt.device)
         return loss_rgb + self.w_eikonal * eik, dict(loss_rgb=loss_rgb.detach(), loss_eikonal=eik.detach())
 
     def train_step(self, it: int) -> torch.Tensor:
@@ -82,8 +87,11 @@ class RenderTrainer:
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         xy, fidx, gt = self.sample_batch()
+        # the uniform-point branch has a static shape and no dependence on the rays: issued first, its launches hide
+        # behind the device draining the previous step (ray_test's compaction is the first host sync of the step)
+        uni = model.sample_pts_uniform(self.num_uniform, generator=self.gen) if self.num_uniform > 0 else None
         ret = self.render(xy, fidx)
-        loss, parts = self.loss(ret, gt)
+        loss, parts = self.loss(ret, gt, uni)
         self.optim.zero_grad()
         loss.backward()
         ndist.allreduce_grads(self.optim.params(), average=True)

@@ -13,7 +13,7 @@ import bench  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     tr = bench.build_trainer(dev, 0, 1)
-    for it in range(260, 268):
+    for it in range(212, 268):
         tr.train_step(it)
     torch.cuda.synchronize()
     import cProfile
@@ -29,6 +29,7 @@ def main():
     print(f"avg step {(time.perf_counter() - t0) / n * 1e3:.3f} ms (with cProfile overhead)")
     st = pstats.Stats(pr)
     st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(35)
 
 
 if __name__ == "__main__":
