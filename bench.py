@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
 
-def build_trainer(device, rank, world, seed=42, distant=False):
+def build_trainer(device, rank, world, seed=42, distant=False, sky=False):
     from neuralsim_amd.fields.neus import LoTDNeuSModel
     from neuralsim_amd.graphics.cameras import look_at_cameras
     from neuralsim_amd.trainer import RenderTrainer
@@ -61,11 +61,16 @@ def build_trainer(device, rank, world, seed=42, distant=False):
         from neuralsim_amd.fields.nerf_distant import LoTDNeRFDistantModel
         dm = LoTDNeRFDistantModel(aabb=model.accel.aabb.detach().cpu(), precision="fp16", seed=seed + 7).to(device)
         ndist.broadcast_module(dm)
+    sm = None
+    if sky:          # directional sky MLP of the street configs (row a16): one 67 -> 256 -> 256 -> 3 query per ray
+        from neuralsim_amd.env import SimpleSky
+        sm = SimpleSky(n_appear_embedding=4, precision="fp16", seed=seed + 11).to(device)
+        ndist.broadcast_module(sm)
     # lr 1e-3 (reference fglr is 1e-2 with warm-up): the targets are random colours, so a small rate keeps the
     # synthetic geometry -- and with it the sample statistics -- stationary over the timed steps; the work is identical
     return RenderTrainer(model, intr, c2w, WH, num_rays=RAYS_PER_GPU, lr=1e-3, w_eikonal=0.1, num_uniform=4096,
                          rank=rank, world_size=world, seed=seed, learn_inv_s=False,   # inv_s is scheduled (mix_linear), held at e^5
-                         distant_model=dm)
+                         distant_model=dm, sky_model=sm)
 
 
 def cpu_baseline(tr, n_rays=1024, iters=2):
@@ -142,6 +147,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--distant", action="store_true",
                     help="add the NeRF++ distant-view model (64 shells on every ray), as in the reference's full config")
+    ap.add_argument("--sky", action="store_true", help="add the sky MLP (SimpleSky, street configs) blended per ray")
     args = ap.parse_args()
 
     from neuralsim_amd import _lib, distributed as ndist
@@ -150,11 +156,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.get_lib()
-    tr = build_trainer(dev, rank, world, distant=args.distant)
+    tr = build_trainer(dev, rank, world, distant=args.distant, sky=args.sky)
     out = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=RAYS_PER_GPU)
     if rank == 0:
         out["config"]["distant_model"] = bool(args.distant)
-        if world == 1 and not args.no_cpu_baseline and not args.distant:
+        out["config"]["sky_model"] = bool(args.sky)
+        if world == 1 and not args.no_cpu_baseline and not args.distant and not args.sky:
             out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
         print(json.dumps(out), flush=True)
     if world > 1:

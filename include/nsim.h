@@ -262,6 +262,31 @@ int nsim_distant_bwd(const NsimDistantMeta* meta, const void* wpack, const float
 int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t* valid, int64_t S,
                        const float* dh_planes, float* dgrid, void* stream);
 
+/* ------------------------------------------------------------------------------- sky MLP (row a16) */
+/* ``SimpleSky`` (app/models/env/sky.py:16-51) as configured by the street configs
+ * (code_single/configs/waymo/streetsurf/withmask_withlidar_joint.240219.yaml:312-322): sinusoidal embedding of the
+ * unit view direction [v, {sin(2^f v), cos(2^f v)}_{f<F}] (3 + 6F dims) ++ h_appear (A dims) -> 256 -> 256 -> 3,
+ * ReLU hidden, sigmoid output (D = 2, W = 256 are fixed; 3 + 6F + A <= 96).  One query per RAY
+ * (call site app/renderers/single_volume_renderer.py:449-457).
+ * Flat weights in layer order: w = [W1 (256 x IN), W2 (256 x 256), W3 (3 x 256)] row-major, b = [256, 256, 3],
+ * IN = 3 + 6F + A.  planes_fwd: [(96 + 256 + 256) * pitch] floats, planes_bwd: [(32 + 256 + 256) * pitch] floats
+ * scratch, pitch = nsim_sky_plane_pitch(N) (N rounded up to 128). */
+typedef struct NsimSkyMeta {
+  int32_t n_frequencies;  /* F */
+  int32_t n_appear;       /* A */
+  int32_t precision;      /* 0: fp16 MFMA, 1: exact f32 MFMA */
+} NsimSkyMeta;
+
+int64_t nsim_sky_wpack_bytes(const NsimSkyMeta* meta);
+int64_t nsim_sky_plane_pitch(int64_t N);
+int nsim_sky_pack_weights(const NsimSkyMeta* meta, const float* w, const float* b, void* wpack, void* stream);
+/* rgb [N,3] = sky(v [N,3], h_appear [N,A] (NULL iff A == 0)); planes_fwd (may be NULL) saves the activations. */
+int nsim_sky_fwd(const NsimSkyMeta* meta, const void* wpack, const float* v, const float* h_appear, int64_t N,
+                 float* rgb, float* planes_fwd, void* stream);
+/* accumulates dw / db (layouts above, caller zeroes) and writes dh_appear [N,A] (may be NULL). */
+int nsim_sky_bwd(const NsimSkyMeta* meta, const void* wpack, const float* rgb_fwd, const float* drgb, int64_t N,
+                 const float* planes_fwd, float* planes_bwd, float* dw, float* db, float* dh_appear, void* stream);
+
 /* ------------------------------------------------------------------------------- losses (row a18) */
 /* Fused reductions of the two losses of the object-centric configs and the gradient of the appearance-embedding
  * lookup.  *out is a device scalar the caller zeroes; the kernels ADD the mean into it.

@@ -34,6 +34,10 @@ class DistantMeta(C.Structure):
     _fields_ = [("lotd", Lotd4Meta), ("precision", C.c_int32)]
 
 
+class SkyMeta(C.Structure):
+    _fields_ = [("n_frequencies", C.c_int32), ("n_appear", C.c_int32), ("precision", C.c_int32)]
+
+
 class FieldMeta(C.Structure):
     _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
 
@@ -86,6 +90,9 @@ SIGNATURES = {
     "nsim_distant_fwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_distant_bwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_lotd4_scatter": [C.POINTER(Lotd4Meta), _P, _P, _I64, _P, _P],
+    "nsim_sky_pack_weights": [C.POINTER(SkyMeta), _P, _P, _P],
+    "nsim_sky_fwd": [C.POINTER(SkyMeta), _P, _P, _P, _I64, _P, _P],
+    "nsim_sky_bwd": [C.POINTER(SkyMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P],
     "nsim_eikonal_loss_fwd": [_P, _I64, _P],
     "nsim_eikonal_loss_bwd": [_P, _I64, _P, _P],
     "nsim_mse_loss_fwd": [_P, _P, _I64, _P],
@@ -99,6 +106,8 @@ NOSTREAM = {
     "nsim_version": ([], _I),
     "nsim_field_wpack_bytes": ([C.POINTER(FieldMeta)], _I64),
     "nsim_distant_wpack_bytes": ([C.POINTER(DistantMeta)], _I64),
+    "nsim_sky_wpack_bytes": ([C.POINTER(SkyMeta)], _I64),
+    "nsim_sky_plane_pitch": ([_I64], _I64),
 }
 
 

@@ -22,6 +22,9 @@ const char* nsim_strerror(int code) {
     case 17: return "LoTD hash table size must be a power of two";
     case 28: return "h / dh/dx planes (and dh / g hand-off planes when dgrid is requested) are required";
     case 27: return "radiance backward needs the saved forward nablas / rgb and a [S,3] scratch buffer";
+    case 30: return "sky meta is NULL";
+    case 31: return "sky input width 3 + 6 n_frequencies + n_appear must be <= 96";
+    case 32: return "sky model with n_appear > 0 needs h_appear";
     case 20: return "field meta is NULL";
     case 21: return "fused field kernels need exactly 16 LoTD levels (32 features)";
     case 22: return "sdf_D must be 1 or 2";

@@ -38,6 +38,13 @@ class FusedAdam:
                                     v=torch.zeros_like(p, dtype=torch.float32)))
         self._dirty.append(dm)
 
+    def add_sky_model(self, sky, betas=(0.9, 0.99)):
+        """Parameters of a ``SimpleSky`` (``training_cfg{lr: skylr}``, withmask_withlidar_joint.240219.yaml:322-325)."""
+        for p in (sky.w, sky.b):
+            self.groups.append(dict(p=p, p16=None, betas=betas, m=torch.zeros_like(p, dtype=torch.float32),
+                                    v=torch.zeros_like(p, dtype=torch.float32)))
+        self._dirty.append(sky)
+
     def params(self) -> List[torch.Tensor]:
         return [g["p"] for g in self.groups]
 

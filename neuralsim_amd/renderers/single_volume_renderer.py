@@ -58,7 +58,8 @@ class SingleVolumeRenderer(nn.Module):
     def __init__(self, config: Optional[dict] = None):
         super().__init__()
         self.config = dict(config or {})
-        self.image_keys = ["depth_volume", "mask_volume", "rgb_volume", "normals_volume"]
+        self.image_keys = ["depth_volume", "mask_volume", "rgb_volume", "normals_volume", "rgb_sky",
+                           "rgb_volume_occupied", "rgb_volume_non_occupied"]
 
     def forward(self, *args, **kwargs):
         return self.ray_query(*args, **kwargs)
@@ -67,7 +68,7 @@ class SingleVolumeRenderer(nn.Module):
                   rays_pix: torch.Tensor = None, *, model: LoTDNeuSModel, rays_h_appear: torch.Tensor = None,
                   near=None, far=None, with_rgb: bool = None, with_normal: bool = None, return_buffer=False,
                   return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-                  distant_model=None) -> Dict:
+                  distant_model=None, sky_model=None, with_env: bool = None) -> Dict:
         assert rays_o.dim() == rays_d.dim() == 2, "rays_o and rays_d should have size of [N, 3]"
         config = self.config
         if with_rgb is None:
@@ -174,8 +175,17 @@ class SingleVolumeRenderer(nn.Module):
             for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
                 if k in out and k in total_rendered:
                     total_rendered[k] = out[k] if every_ray else total_rendered[k].index_put((rih,), out[k])
+        # ---- sky model (reference :449-457): one query per ray, blended with the residual transmittance
         if with_rgb:
             total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]
+            if with_env is None:
+                with_env = config.get("with_env", True)
+            if with_env and sky_model is not None:
+                env_rgb = sky_model(v=F.normalize(rays_d, dim=-1), h_appear=rays_h_appear)
+                total_rendered["rgb_sky"] = env_rgb
+                total_rendered["rgb_volume_non_occupied"] = env_blend = \
+                    (1.0 - total_rendered["mask_volume"][..., None]) * env_rgb
+                total_rendered["rgb_volume"] = total_rendered["rgb_volume"] + env_blend
         ret = dict(ray_intersections=dict(samples_cnt=total_num_samples_per_ray), rendered=total_rendered)
         if return_buffer:
             ret["volume_buffer"] = total_volume_buffer
@@ -188,7 +198,7 @@ class SingleVolumeRenderer(nn.Module):
     def render(self, model: LoTDNeuSModel, *, rays: List[torch.Tensor], rays_h_appear: torch.Tensor = None, near=None,
                far=None, rayschunk: int = None, with_rgb=None, with_normal=None, return_buffer=False,
                return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-               distant_model=None) -> Dict:
+               distant_model=None, sky_model=None, with_env: bool = None) -> Dict:
         """rays = [rays_o, rays_d(, rays_ts, rays_pix)] with arbitrary prefix shape (reference :495-581)."""
         if rayschunk is None:
             rayschunk = self.config.get("rayschunk", 0)
@@ -199,7 +209,7 @@ class SingleVolumeRenderer(nn.Module):
             kwargs = dict(model=model, near=near, far=far, with_rgb=with_rgb, with_normal=with_normal,
                           return_buffer=return_buffer, return_details=return_details,
                           render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg,
-                          distant_model=distant_model)
+                          distant_model=distant_model, sky_model=sky_model, with_env=with_env)
             if self.training or (not rayschunk) or flat[0].shape[0] <= rayschunk:
                 ret = self(*flat[:2], rays_h_appear=ha, **kwargs)
             else:

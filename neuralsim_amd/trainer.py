@@ -24,7 +24,7 @@ class RenderTrainer:
     def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
-                 distant_model=None):
+                 distant_model=None, sky_model=None):
         self.model = model
         self.intr, self.c2w, self.WH = intr, c2w, WH
         self.V = intr.shape[0]
@@ -43,6 +43,9 @@ class RenderTrainer:
         self.distant_model = distant_model
         if distant_model is not None:
             self.optim.add_distant_model(distant_model)
+        self.sky_model = sky_model
+        if sky_model is not None:
+            self.optim.add_sky_model(sky_model)
         from .renderers.single_volume_renderer import SingleVolumeRenderer
         self.renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=near, far=far, perturb=perturb,
                                                   depth_use_normalized_vw=False)).train()
@@ -61,7 +64,8 @@ class RenderTrainer:
         rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
         h_appear = embedding_lookup(self.appear, fidx)
         ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
-                                   return_buffer=True, return_details=True, distant_model=self.distant_model)
+                                   return_buffer=True, return_details=True, distant_model=self.distant_model,
+                                   sky_model=self.sky_model)
         return ret
 
     def loss(self, ret, gt, uni=None):

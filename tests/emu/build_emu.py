@@ -7,7 +7,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE.parent.parent / "neuralsim_amd" / "csrc"
-SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
+SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
 LIB = HERE / "_build" / "libnsim_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DNSIM_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", f"-I{CSRC}",

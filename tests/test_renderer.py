@@ -49,3 +49,40 @@ def test_image_psnr_vs_oracle(backend, precision):
     assert (img["mask_volume"].cpu() - mask_o).abs().max() < (5e-3 if precision == "f32" else 5e-2)
     n = img["normals_volume"].cpu().norm(dim=-1)
     assert float(n.max()) <= 1.0 + 1e-4                                            # eval normals are normalised (:99-101)
+
+
+def test_sky_blend_in_renderer(backend):
+    """rgb = rgb_volume_occupied + (1 - mask_volume) * sky(v, h_appear) (single_volume_renderer.py:449-457), with
+    gradients reaching the sky weights."""
+    from oracle import sky as osky
+    from neuralsim_amd.env import SimpleSky
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=3, ln_inv_s=0.6, grid_bound=2e-2, noise_scale=1.0)
+    intr, c2w, WH = look_at_cameras(V=2, seed=5, H=16, W=16, f=12.0)     # wide view: many rays miss the object
+    model = model_from_params(p, backend, precision="f32")
+    model.ray_query_cfg = dict(query_mode="march_occ_multi_upsample", query_param=QP)
+    model.accel = OccGridAccel(AABB, resolution=RES, device=backend)
+    val, occ = orr.build_occ_grid(p, AABB[0], AABB[1], RES, n_pts=2 ** 14, n_steps=2)
+    model.accel.occ_val.copy_(val.to(backend))
+    model.accel.pack_bits()
+    ws, bs = osky.make_sky_params(10, 4, seed=21)
+    sky = SimpleSky(n_appear_embedding=4, precision="f32").to(backend)
+    with torch.no_grad():
+        sky.w.copy_(torch.cat([w.reshape(-1) for w in ws]).to(backend))
+        sky.b.copy_(torch.cat(bs).to(backend))
+    xy = all_pixel_xy(16, 16, torch.device("cpu"))
+    fidx = torch.zeros([256], dtype=torch.long)
+    o, d = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
+    ha = torch.tensor([[0.1, -0.2, 0.3, 0.05]]).expand(256, -1).contiguous()
+    renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=False, near=0.01, depth_use_normalized_vw=True,
+                                         query_mode="march_occ_multi_upsample")).train()
+    out = renderer.render(model, rays=[o.to(backend), d.to(backend)], rays_h_appear=ha.to(backend), sky_model=sky,
+                          bypass_ray_query_cfg=dict(perturb=False))
+    r = out["rendered"]
+    sky_ref = osky.sky_forward(torch.nn.functional.normalize(d, dim=-1), ha, ws, bs)
+    assert float((r["rgb_sky"].detach().cpu() - sky_ref).abs().max()) <= 2e-5
+    blend = osky.blend_sky(r["rgb_volume_occupied"].detach().cpu(), r["mask_volume"].detach().cpu(), sky_ref)
+    assert float((r["rgb_volume"].detach().cpu() - blend).abs().max()) <= 3e-5
+    assert float(r["mask_volume"].detach().min()) < 0.05 < 0.5 < float(r["mask_volume"].detach().max())   # both regimes present
+    r["rgb_volume"].sum().backward()
+    assert sky.w.grad is not None and float(sky.w.grad.abs().sum()) > 0
+    assert model.encoding.flattened_params.grad is not None                 # (1 - mask) carries gradient to the SDF
