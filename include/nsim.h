@@ -180,10 +180,13 @@ int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta);
 int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b,
                             const float* rad_w, const float* rad_b, void* wpack, void* stream);
 /* No-grad SDF query (model.query_sdf / forward_sdf; inspect_rendering.py:120-128).
- * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]]. */
+ * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]].
+ * feat_scratch: NULL -> one fused point-major kernel; otherwise a caller-owned buffer of 16 * S * (4 | 8) bytes
+ * (fp16 | f32 precision) and the query runs as a level-major gather into it followed by the decoder (same values;
+ * the table traffic stays inside each XCD's L2). */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   int64_t S, float* sdf, void* stream);
+                   int64_t S, float* sdf, void* feat_scratch, void* stream);
 /* With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).

@@ -210,6 +210,8 @@ struct FieldArgs {
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
+  void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16][S] x (f16x2 | f32x2)
+  signed char glm_n[8], glm_lv[8][16];             // levels gathered by the blocks of XCD x (blockIdx % 8)
   float *h_pl, *J_pl;                              // level-major planes [16][S][2] / [16][S][2][3] saved by the forward
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16][S][2]
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
@@ -652,7 +654,84 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #ifndef NSIM_SDF_MIN_WAVES
 #define NSIM_SDF_MIN_WAVES 2
 #endif
-template <int PREC, int SDF_D>
+// Level-major gather of the no-grad SDF query (sampling pass, occupancy refresh): every wave owns GLM_PTS x 64 points
+// and walks the 16 levels in the same order as every other wave of the launch, so at any moment the chip reads ONE
+// level's table (<= 2 MB for T = 2^19), which stays resident in each XCD's 4 MB L2 -- the point-major fused kernel
+// spreads its accesses over all 24 MB at once and fetched 3.6x the algorithmic bytes from beyond L2.  GLM_PTS x 8
+// independent 4-byte loads are in flight per lane.  Output: planes [16][S] of (f16x2 * SDF_H_SCALE | f32x2).
+// The levels are dealt to the 8 XCDs (block b runs on XCD b % 8 -- an observed placement used for speed only, the
+// result does not depend on it): an XCD pulls only ITS levels' tables (~3 MB) through its L2 instead of all 24 MB.
+// Measured ceiling (tools/gather_bench.hip): a random 4-byte gather retires 267 G lines/s from an L2-resident 2 MB
+// table (= the 34 TB/s aggregate L2->L1 rate at 128 B per miss) but only 65-120 G/s from an 8-32 MB one.
+#define GLM_PTS 4
+template <int PREC>
+__global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
+  const int lane = nsim_lane();
+  const int xcd = (int)(blockIdx.x & 7u);
+  const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * GLM_PTS) + lane;
+  float xx[GLM_PTS][3];
+#pragma unroll
+  for (int q = 0; q < GLM_PTS; ++q) {
+    const int64_t s = s0 + 64 * q;
+    xx[q][0] = xx[q][1] = xx[q][2] = 0.f;
+    if (s < a.S) {
+      if (a.x) {
+        xx[q][0] = a.x[3 * s]; xx[q][1] = a.x[3 * s + 1]; xx[q][2] = a.x[3 * s + 2];
+      } else {
+        const int64_t ray = a.ridx[s];
+        const float tt = a.t[s];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xx[q][c] = a.rays_o[3 * ray + c] + tt * a.rays_d[3 * ray + c];
+      }
+    }
+  }
+  const GridRef gref = grid_ref(a.grid);
+  const int nl = a.glm_n[xcd];
+#pragma unroll 1
+  for (int k = 0; k < nl; ++k) {
+    const int l = a.glm_lv[xcd][k];
+    const int R = a.lotd.res[l], type = a.lotd.type[l];
+    const uint32_t T = a.lotd.size[l], off = (uint32_t)a.lotd.offset[l];
+    float f0[GLM_PTS], f1[GLM_PTS];
+#pragma unroll
+    for (int q = 0; q < GLM_PTS; ++q) {
+      const LotdCell c = lotd_cell(xx[q], R);
+      f0[q] = f1[q] = 0.f;
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) {
+        float w, dw[3];
+        lotd_corner_w(c, corner, w, dw);
+        const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
+                                        c.c0[2] + ((corner >> 2) & 1), R, type, T);
+        float g0, g1;
+        lotd_load2(gref, off + 2u * idx, g0, g1);
+        f0[q] = f0[q] + w * g0;
+        f1[q] = f1[q] + w * g1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < GLM_PTS; ++q) {
+      const int64_t s = s0 + 64 * q;
+      if (s < a.S) {
+        const int64_t e = (int64_t)l * a.S + s;
+        if constexpr (PREC == 0) {
+          union {
+            uint32_t u;
+            f16 h[2];
+          } cv;
+          cv.h[0] = (f16)(f0[q] * SDF_H_SCALE);
+          cv.h[1] = (f16)(f1[q] * SDF_H_SCALE);
+          reinterpret_cast<uint32_t*>(a.feat_pl)[e] = cv.u;
+        } else {
+          reinterpret_cast<float*>(a.feat_pl)[2 * e] = f0[q];
+          reinterpret_cast<float*>(a.feat_pl)[2 * e + 1] = f1[q];
+        }
+      }
+    }
+  }
+}
+
+template <int PREC, int SDF_D, bool PLANES>
 __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_sdf(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -666,11 +745,40 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
-    const TilePoint p = load_point(a, tile, j, false);
+    TilePoint p;
+    if constexpr (PLANES) {
+      p.s = tile * 32 + j;
+      p.valid = p.s < a.S;
+    } else {
+      p = load_point(a, tile, j, false);
+    }
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll 1
     for (int rb = 0; rb < 2; ++rb) {
       float f8[8];
+      f16x8 bvp;
+      if constexpr (PLANES) {
+        // features were gathered level-major by k_lotd_gather_lm (fp16 mode: already scaled by SDF_H_SCALE)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 4 * (2 * rb + qq) + 2 * hi + b;
+            const int64_t e = (int64_t)l * a.S + (p.valid ? p.s : 0);
+            if constexpr (PREC == 0) {
+              union {
+                uint32_t u;
+                f16 h[2];
+              } cv;
+              cv.u = reinterpret_cast<const uint32_t*>(a.feat_pl)[e];
+              bvp[4 * qq + 2 * b] = cv.h[0];
+              bvp[4 * qq + 2 * b + 1] = cv.h[1];
+            } else {
+              f8[4 * qq + 2 * b] = reinterpret_cast<const float*>(a.feat_pl)[2 * e];
+              f8[4 * qq + 2 * b + 1] = reinterpret_cast<const float*>(a.feat_pl)[2 * e + 1];
+            }
+          }
+      } else {
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
@@ -694,10 +802,15 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
           f8[4 * qq + 2 * b + 1] = f1;
         }
       }
+      }
       if constexpr (PREC == 0) {
         f16x8 bv;
+        if constexpr (PLANES) {
+          bv = bvp;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (f16)(f8[e] * SDF_H_SCALE);
+          for (int e = 0; e < 8; ++e) bv[e] = (f16)(f8[e] * SDF_H_SCALE);
+        }
         const f16x8* A = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
 #pragma unroll
         for (int mo = 0; mo < 2; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 + rb) * 64 + lane], bv, acc[mo]);
@@ -1067,7 +1180,7 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                   float* sdf, void* stream) {
+                   float* sdf, void* feat_scratch, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -1078,14 +1191,44 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.S = S;
   a.sdf = sdf;
+  a.feat_pl = feat_scratch;
   const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
-  switch (key) {
-    case 0: hipLaunchKernelGGL((k_field_sdf<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
-    case 1: hipLaunchKernelGGL((k_field_sdf<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL((k_field_sdf<1, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL((k_field_sdf<1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+  if (feat_scratch) {   // level-major gather into planes, then the decoder on the planes
+    // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
+    {
+      int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      bool used[16] = {false};
+      for (int x = 0; x < 8; ++x) a.glm_n[x] = 0;
+      for (int it = 0; it < 16; ++it) {
+        int best = -1;
+        for (int l = 0; l < 16; ++l)
+          if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
+        used[best] = true;
+        int tx = 0;
+        for (int x = 1; x < 8; ++x)
+          if (load[x] < load[tx]) tx = x;
+        a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
+        load[tx] += (int64_t)meta->lotd.size[best] + 65536;
+      }
+    }
+    const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+    if (meta->precision == 0) hipLaunchKernelGGL(k_lotd_gather_lm<0>, gg, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_lotd_gather_lm<1>, gg, dim3(64), 0, (hipStream_t)stream, a);
+    switch (key) {
+      case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+    }
+  } else {
+    switch (key) {
+      case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+    }
   }
   NSIM_CHECK_LAUNCH();
   return 0;

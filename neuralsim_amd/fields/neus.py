@@ -16,6 +16,7 @@ Host synchronisations per render: two (hit-ray compaction, marched-sample total)
 (single_volume_renderer.py:340,345,414).
 """
 import math
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -326,6 +327,7 @@ class LoTDNeuSModel(nn.Module):
         fm.softplus_beta = float(softplus_beta)
         self.field_meta = fm
         self._wpack = None
+        self._sdf_fused = os.environ.get("NSIM_SDF_FUSED", "0") == "1"
         self._wpack_versions = None
         if device is not None:
             self.to(device)
@@ -400,6 +402,13 @@ class LoTDNeuSModel(nn.Module):
         return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
 
     # ------------------------------------------------------------------ point queries
+    def _feat_scratch(self, S: int, dev):
+        """Feature planes [16][S] (f16x2 | f32x2) of the level-major no-grad query (csrc/field.hip:k_lotd_gather_lm);
+        NSIM_SDF_FUSED=1 selects the single fused point-major kernel instead."""
+        if self._sdf_fused or S == 0:
+            return None
+        return torch.empty([16 * S * (1 if self.field_meta.precision == 0 else 2)], dtype=torch.float32, device=dev)
+
     @torch.no_grad()
     def query_sdf(self, x: torch.Tensor) -> torch.Tensor:
         """No-grad SDF at points in [-1,1]^3 (inspect_rendering.py:120-128)."""
@@ -408,7 +417,7 @@ class LoTDNeuSModel(nn.Module):
         grid16, wpack = self._shadow()
         sdf = torch.empty([x.shape[0]], dtype=torch.float32, device=x.device)
         _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), None, None, None,
-                  None, x.shape[0], _lib.ptr(sdf))
+                  None, x.shape[0], _lib.ptr(sdf), _lib.ptr(self._feat_scratch(x.shape[0], x.device)))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_sdf", x.shape[0])
         return sdf.reshape(shape)
@@ -418,7 +427,8 @@ class LoTDNeuSModel(nn.Module):
         grid16, wpack = self._shadow()
         sdf = torch.empty([t.shape[0]], dtype=torch.float32, device=t.device)
         _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), t.shape[0], _lib.ptr(sdf))
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), t.shape[0], _lib.ptr(sdf),
+                  _lib.ptr(self._feat_scratch(t.shape[0], t.device)))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_sdf", t.shape[0])
         return sdf
