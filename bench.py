@@ -34,7 +34,11 @@ KERNEL_MODEL = {
     "nsim_distant_fwd": ("hbm", 12 * 16 * 4 + 128 + 16.0),      # 12 levels x 16 corners x 4 B + planes + outputs
     "nsim_distant_bwd": ("mfma", 56 * 32768 / 32.0),            # 56 MFMA 32x32x16 per 32-point tile
     "nsim_lotd4_scatter": ("hbm", 12 * 16 * 2 * 4 + 128 + 16.0),
-    "nsim_field_sdf": ("hbm", 512.0),
+    # no-grad SDF query = level-major gather (512 B table reads + 64 B fp16 feature planes written per point) ...
+    "nsim_lotd_gather_lm": ("hbm", 576.0),
+    # ... + the decoder on the planes (64 B read; 12 v_mfma_f32_32x32x16_f16 per 32-point tile); with NSIM_SDF_FUSED=1
+    # it is the single fused point-major kernel (gather + decoder, 512 B per point)
+    "nsim_field_sdf": ("hbm", 512.0) if os.environ.get("NSIM_SDF_FUSED", "0") == "1" else ("mfma", 12 * 32768 / 32.0),
     "nsim_field_fwd": ("hbm", 1052.0),
     "nsim_lotd_scatter": ("hbm", 1304.0),
     "nsim_field_bwd_sdf": ("mfma", 73728.0),

@@ -181,12 +181,18 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
                             const float* rad_w, const float* rad_b, void* wpack, void* stream);
 /* No-grad SDF query (model.query_sdf / forward_sdf; inspect_rendering.py:120-128).
  * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]].
- * feat_scratch: NULL -> one fused point-major kernel; otherwise a caller-owned buffer of 16 * S * (4 | 8) bytes
- * (fp16 | f32 precision) and the query runs as a level-major gather into it followed by the decoder (same values;
- * the table traffic stays inside each XCD's L2). */
+ * feat_planes == NULL: one fused point-major kernel (gather + decoder).
+ * feat_planes != NULL: decoder only, on the level-major feature planes written by nsim_lotd_gather_lm for the same
+ * points (x / rays / grid are then unused and may be NULL).  Same values either way. */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   int64_t S, float* sdf, void* feat_scratch, void* stream);
+                   int64_t S, float* sdf, const void* feat_planes, void* stream);
+/* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [16][S] of
+ * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
+ * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */
+int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                        const float* rays_d, const float* t, const int64_t* ridx, int64_t S, void* feat_planes,
+                        void* stream);
 /* With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).

@@ -1178,13 +1178,49 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   return 0;
 }
 
-int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
-                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                   float* sdf, void* feat_scratch, void* stream) {
+int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                        const float* rays_d, const float* t, const int64_t* ridx, int64_t S, void* feat_planes,
+                        void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (!feat_planes || !grid_f16) return 4;
+  FieldArgs a = field_args(meta);
+  a.grid = (const f16*)grid_f16;
+  a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.S = S;
+  a.feat_pl = feat_planes;
+  // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
+  int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool used[16] = {false};
+  for (int xc = 0; xc < 8; ++xc) a.glm_n[xc] = 0;
+  for (int it = 0; it < 16; ++it) {
+    int best = -1;
+    for (int l = 0; l < 16; ++l)
+      if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
+    used[best] = true;
+    int tx = 0;
+    for (int xc = 1; xc < 8; ++xc)
+      if (load[xc] < load[tx]) tx = xc;
+    a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
+    load[tx] += (int64_t)meta->lotd.size[best] + 65536;
+  }
+  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+  if (meta->precision == 0) hipLaunchKernelGGL(k_lotd_gather_lm<0>, gg, dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_lotd_gather_lm<1>, gg, dim3(64), 0, (hipStream_t)stream, a);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
+                   float* sdf, const void* feat_planes, void* stream) {
+  const int rc = field_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!feat_planes && !x && !(rays_o && rays_d && t && ridx)) return 24;
+  void* feat_scratch = const_cast<void*>(feat_planes);
   FieldArgs a = field_args(meta);
   a.grid = (const f16*)grid_f16;
   a.wpack = (const char*)wpack;
@@ -1195,27 +1231,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
-  if (feat_scratch) {   // level-major gather into planes, then the decoder on the planes
-    // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
-    {
-      int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      bool used[16] = {false};
-      for (int x = 0; x < 8; ++x) a.glm_n[x] = 0;
-      for (int it = 0; it < 16; ++it) {
-        int best = -1;
-        for (int l = 0; l < 16; ++l)
-          if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
-        used[best] = true;
-        int tx = 0;
-        for (int x = 1; x < 8; ++x)
-          if (load[x] < load[tx]) tx = x;
-        a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
-        load[tx] += (int64_t)meta->lotd.size[best] + 65536;
-      }
-    }
-    const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
-    if (meta->precision == 0) hipLaunchKernelGGL(k_lotd_gather_lm<0>, gg, dim3(64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_lotd_gather_lm<1>, gg, dim3(64), 0, (hipStream_t)stream, a);
+  if (feat_scratch) {   // decoder on the planes gathered by nsim_lotd_gather_lm
     switch (key) {
       case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;

@@ -402,12 +402,26 @@ class LoTDNeuSModel(nn.Module):
         return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
 
     # ------------------------------------------------------------------ point queries
-    def _feat_scratch(self, S: int, dev):
-        """Feature planes [16][S] (f16x2 | f32x2) of the level-major no-grad query (csrc/field.hip:k_lotd_gather_lm);
-        NSIM_SDF_FUSED=1 selects the single fused point-major kernel instead."""
-        if self._sdf_fused or S == 0:
-            return None
-        return torch.empty([16 * S * (1 if self.field_meta.precision == 0 else 2)], dtype=torch.float32, device=dev)
+    def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev) -> torch.Tensor:
+        """No-grad SDF of S points: level-major gather into feature planes [16][S] (f16x2 | f32x2), then the decoder
+        on the planes (csrc/field.hip: k_lotd_gather_lm, k_field_sdf<.., true>).  NSIM_SDF_FUSED=1 selects the single
+        fused point-major kernel instead (same values)."""
+        sdf = torch.empty([S], dtype=torch.float32, device=dev)
+        if S == 0:
+            return sdf
+        fm = self.field_meta
+        planes = None
+        if not self._sdf_fused:
+            planes = torch.empty([16 * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32, device=dev)
+            _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
+                      _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(planes))
+        _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(sdf), _lib.ptr(planes))
+        if _lib.TIMER is not None:
+            _lib.TIMER.note_units("nsim_field_sdf", S)
+            if planes is not None:
+                _lib.TIMER.note_units("nsim_lotd_gather_lm", S)
+        return sdf
 
     @torch.no_grad()
     def query_sdf(self, x: torch.Tensor) -> torch.Tensor:
@@ -415,23 +429,13 @@ class LoTDNeuSModel(nn.Module):
         shape = x.shape[:-1]
         x = x.detach().float().reshape(-1, 3).contiguous()
         grid16, wpack = self._shadow()
-        sdf = torch.empty([x.shape[0]], dtype=torch.float32, device=x.device)
-        _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), None, None, None,
-                  None, x.shape[0], _lib.ptr(sdf), _lib.ptr(self._feat_scratch(x.shape[0], x.device)))
-        if _lib.TIMER is not None:
-            _lib.TIMER.note_units("nsim_field_sdf", x.shape[0])
+        sdf = self._sdf_query(grid16, wpack, x, None, None, None, None, x.shape[0], x.device)
         return sdf.reshape(shape)
 
     @torch.no_grad()
     def _query_sdf_rays(self, rays_o, rays_d, t, ridx):
         grid16, wpack = self._shadow()
-        sdf = torch.empty([t.shape[0]], dtype=torch.float32, device=t.device)
-        _lib.call("nsim_field_sdf", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), t.shape[0], _lib.ptr(sdf),
-                  _lib.ptr(self._feat_scratch(t.shape[0], t.device)))
-        if _lib.TIMER is not None:
-            _lib.TIMER.note_units("nsim_field_sdf", t.shape[0])
-        return sdf
+        return self._sdf_query(grid16, wpack, None, rays_o, rays_d, t, ridx, t.shape[0], t.device)
 
     def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
         shape = x.shape[:-1]
