@@ -107,6 +107,9 @@ class _FieldFn(torch.autograd.Function):
                 _lib.TIMER.note_units("nsim_lotd_scatter", S)
             if gr is not None:
                 _lib.TIMER.note_units("nsim_field_bwd_rad", S)
+        if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
+            dsdf_w[-64:] /= model.sdf_scale
+            dsdf_b[-1:] /= model.sdf_scale
         return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
 
 
@@ -273,9 +276,14 @@ class LoTDNeuSModel(nn.Module):
                  precision: str = "fp16", softplus_beta: float = 100.0, ln_inv_s_init: float = 0.1,
                  ln_inv_s_factor: float = 10.0, bounding_size: float = 2.0, aabb: torch.Tensor = None,
                  accel_cfg: dict = None, ray_query_cfg: dict = None, param_bound: float = 1e-4, seed: int = 42,
-                 device=None):
+                 sdf_scale: float = 1.0, inside_out: bool = False, device=None):
+        """``sdf_scale``: the decoder output is divided by it (street config ``sdf_scale: 25``,
+        withmask_withlidar_joint.240219.yaml:158); ``inside_out``: sign of the geometric initialisation (indoor config
+        ``inside_out: true``, lotd_neus.replica.230814.yaml:95).  Both live in the absent nr3d_lib -- semantics fixed
+        here: sdf = head(h) / sdf_scale (folded into the packed head weights), inside_out => initial sdf = r - |x|."""
         super().__init__()
         assert W == 64 and sdf_D in (1, 2), "gfx950 fused kernels: hidden width 64, 1 or 2 hidden SDF layers"
+        self.sdf_scale, self.inside_out = float(sdf_scale), bool(inside_out)
         lod_res = list(lod_res) if lod_res is not None else list(DEFAULT_LOD_RES)
         assert len(lod_res) == 16, "gfx950 fused kernels: 16 levels x 2 features"
         self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
@@ -355,14 +363,18 @@ class LoTDNeuSModel(nn.Module):
             nbytes = int(lib.nsim_field_wpack_bytes(self.field_meta))
             if self._wpack is None or self._wpack.numel() != nbytes or self._wpack.device != self.sdf_w.device:
                 self._wpack = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
-            _lib.call("nsim_field_pack_weights", self.field_meta, _lib.ptr(self.sdf_w.detach()),
-                      _lib.ptr(self.sdf_b.detach()), _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()),
-                      _lib.ptr(self._wpack))
+            sw, sb = self.sdf_w.detach(), self.sdf_b.detach()
+            if self.sdf_scale != 1.0:       # sdf = head / sdf_scale: fold the divisor into the packed head weights
+                sw, sb = sw.clone(), sb.clone()
+                sw[-64:] /= self.sdf_scale
+                sb[-1:] /= self.sdf_scale
+            _lib.call("nsim_field_pack_weights", self.field_meta, _lib.ptr(sw), _lib.ptr(sb),
+                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(self._wpack))
             self._wpack_versions = vers
         return grid16, self._wpack
 
     @torch.no_grad()
-    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25):
+    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None):
         """Deterministic stand-in for the reference's SDF pre-training (``geo_init_method: pretrain_after_zero_out``,
         ``radius_init`` -- lotd_neus.dtu.230814.yaml:125-126; app/models/single/neus.py:198-236): feature 0 of the
         finest dense level holds |x_vertex| - radius and unit 0 of every hidden layer passes it through the linear
@@ -374,6 +386,9 @@ class LoTDNeuSModel(nn.Module):
         ax = torch.linspace(-1.0, 1.0, R)
         zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
         sdf = (torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) - radius).reshape(-1)
+        if self.inside_out if inside_out is None else inside_out:
+            sdf = -sdf                     # camera inside the surface (indoor scenes): positive inside the sphere
+        sdf = sdf * self.sdf_scale         # the head divides by sdf_scale
         lvl = self.encoding.flattened_params.data[cfg.lod_offsets[lv]: cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2].view(-1, 2)
         lvl[:, 0] = sdf.half().float().to(lvl.device)
         D = self.sdf_D
@@ -382,7 +397,7 @@ class LoTDNeuSModel(nn.Module):
         w1[0].zero_()
         w1[0, 2 * lv] = 1.0
         self.sdf_b.data[:64].mul_(noise_scale)
-        self.sdf_b.data[0] = 2.0
+        self.sdf_b.data[0] = 2.0 * self.sdf_scale      # keeps the pass-through unit in softplus' linear region
         if D == 2:
             w2 = self.sdf_w.data[2048:2048 + 4096].view(64, 64)
             w2.mul_(noise_scale)
@@ -393,7 +408,7 @@ class LoTDNeuSModel(nn.Module):
         wh = self.sdf_w.data[-64:]
         wh.mul_(noise_scale * 0.05)
         wh[0] = 1.0
-        self.sdf_b.data[-1] = -2.0
+        self.sdf_b.data[-1] = -2.0 * self.sdf_scale
         self.encoding.flattened_params.add_(0)      # bump versions: refresh fp16 shadow / weight pack lazily
         self.sdf_w.add_(0)
         return self

@@ -131,3 +131,44 @@ def test_field_partial_upstream(backend, which):
     for k, v in dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad).items():
         e = rel_l2(v.cpu(), ref[k])
         assert e < 2e-4, (which, k, e)
+
+
+def test_sdf_scale_and_inside_out(backend):
+    """``sdf_scale`` (street config :158) divides the decoder output; ``inside_out`` (indoor config :95) flips the sign
+    of the geometric initialisation.  Checked against the oracle evaluated with the head weights pre-divided."""
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    scale = 25.0
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=5, grid_bound=2e-2, noise_scale=1.0)
+    m = model_from_params(p, backend, precision="f32")
+    m.sdf_scale = scale
+    m._wpack_versions = None
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(300, 3, generator=g) * 2 - 1) * 0.9
+    # oracle with the effective head
+    p.sdf_w[-1] = p.sdf_w[-1] / scale
+    p.sdf_b[-1] = p.sdf_b[-1] / scale
+    p.requires_grad_(True)
+    sdf_o, nab_o = ofield.forward_sdf_nablas(x, p)
+    loss_o = (sdf_o * 0.7).sum() + ((nab_o.norm(dim=-1) - 1.0) ** 2).mean()
+    loss_o.backward()
+    out = m.forward_sdf_nablas(x.to(backend))
+    loss = (out["sdf"] * 0.7).sum() + ((out["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+    loss.backward()
+    assert float((out["sdf"].detach().cpu() - sdf_o.detach()).abs().max()) <= 2e-5
+    assert float((m.query_sdf(x.to(backend)).cpu() - sdf_o.detach()).abs().max()) <= 2e-5
+    gw = m.sdf_w.grad.cpu()
+    head_o = p.sdf_w[-1].grad.reshape(-1) / scale          # d/dW = d/dW_eff / scale
+    assert float((gw[-64:] - head_o).norm() / head_o.norm()) <= 2e-4
+    w1_o = p.sdf_w[0].grad.reshape(-1)
+    assert float((gw[:w1_o.numel()] - w1_o).norm() / w1_o.norm()) <= 2e-4
+    gg = m.encoding.flattened_params.grad.cpu()
+    assert float((gg - p.grid.grad).norm() / p.grid.grad.norm()) <= 2e-4
+    # geometric initialisation: sphere of radius 0.5, either sign, for a scaled head
+    for inside_out in (False, True):
+        mm = LoTDNeuSModel(lod_res=p.spec.lod_res, log2_hashmap_size=12, sdf_D=2, precision="f32", sdf_scale=scale,
+                           inside_out=inside_out).to(backend)
+        mm.geometric_init_sphere(0.5, noise_scale=0.0)
+        pts = torch.tensor([[0.25, 0.1, 0.0], [0.9, 0.0, 0.0], [0.0, -0.5, 0.0]])
+        sd = mm.query_sdf(pts.to(backend)).cpu()
+        want = (pts.norm(dim=-1) - 0.5) * (-1.0 if inside_out else 1.0)
+        assert float((sd - want).abs().max()) < 0.08, (inside_out, sd)
