@@ -33,7 +33,11 @@ extern "C" {
 typedef struct NsimLotdMeta {
   int32_t num_levels;
   int32_t n_feats;                     /* must be 2 */
-  int32_t res[NSIM_MAX_LEVELS];        /* vertices per axis */
+  int32_t n_active_levels;             /* hardmask level annealing (encoding_cfg.anneal_cfg{type: hardmask},
+                                        * lotd_neus.dtu.230814.yaml:104-108): levels >= n_active_levels yield zero
+                                        * features and receive no gradient; 0 or >= num_levels = all active */
+  int32_t res[NSIM_MAX_LEVELS][3];     /* vertices per axis (x, y, z); equal for cubic levels, per-axis for
+                                        * ``lotd_use_cuboid`` (withmask_withlidar_joint.240219.yaml:160) */
   int32_t type[NSIM_MAX_LEVELS];       /* NSIM_LOTD_DENSE | NSIM_LOTD_HASH */
   uint32_t size[NSIM_MAX_LEVELS];      /* entries (vertices or hash slots) */
   int64_t offset[NSIM_MAX_LEVELS];     /* offset of the level in the flat param tensor, in scalars */

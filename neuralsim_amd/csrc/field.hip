@@ -421,9 +421,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b;
-          const int R = a.lotd.res[l];
+          const LotdRes R = a.lotd.res[l];
           const LotdCell c = lotd_cell(p.xx, R);
           float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+          if (l < a.lotd.n_active)      // hardmask annealing: masked levels are never read
 #pragma unroll
           for (int corner = 0; corner < 8; ++corner) {
             float w, dw[3];
@@ -448,8 +449,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           if (MODE >= 1) {
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) {
-              J[r0][c3] = j0[c3] * c.dscale;
-              J[r0 + 1][c3] = j1[c3] * c.dscale;
+              J[r0][c3] = j0[c3] * c.dscale[c3];
+              J[r0 + 1][c3] = j1[c3] * c.dscale[c3];
             }
             if (a.h_pl && valid) {
               float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
@@ -690,13 +691,15 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 #pragma unroll 1
   for (int k = 0; k < nl; ++k) {
     const int l = a.glm_lv[xcd][k];
-    const int R = a.lotd.res[l], type = a.lotd.type[l];
+    const LotdRes R = a.lotd.res[l];
+    const int type = a.lotd.type[l];
     const uint32_t T = a.lotd.size[l], off = (uint32_t)a.lotd.offset[l];
     float f0[GLM_PTS], f1[GLM_PTS];
 #pragma unroll
     for (int q = 0; q < GLM_PTS; ++q) {
       const LotdCell c = lotd_cell(xx[q], R);
       f0[q] = f1[q] = 0.f;
+      if (l < a.lotd.n_active)
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
         float w, dw[3];
@@ -784,9 +787,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * (2 * rb + qq) + 2 * hi + b;
-          const int R = a.lotd.res[l];
+          const LotdRes R = a.lotd.res[l];
           const LotdCell c = lotd_cell(p.xx, R);
           float f0 = 0.f, f1 = 0.f;
+          if (l < a.lotd.n_active)
 #pragma unroll
           for (int corner = 0; corner < 8; ++corner) {
             float w, dw[3];
@@ -986,8 +990,9 @@ struct ScatterArgs {
 __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
   const int l = blockIdx.y;
-  const int R = a.lotd.res[l];
-  const bool dedup = R <= a.dedup_max_res;
+  const LotdRes R = a.lotd.res[l];
+  if (l >= a.lotd.n_active) return;     // masked level: no gradient
+  const bool dedup = R.max() <= a.dedup_max_res;
   const int rq = lane & 3;
   float* base = a.dgrid + a.lotd.offset[l];
   const int64_t nchunks = (a.S + 63) / 64;
@@ -1015,8 +1020,8 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
       }
     }
     const LotdCell c = lotd_cell(xx, R);
-    const float q0[3] = {g0 * gn[0] * c.dscale, g0 * gn[1] * c.dscale, g0 * gn[2] * c.dscale};
-    const float q1[3] = {g1 * gn[0] * c.dscale, g1 * gn[1] * c.dscale, g1 * gn[2] * c.dscale};
+    const float q0[3] = {g0 * gn[0] * c.dscale[0], g0 * gn[1] * c.dscale[1], g0 * gn[2] * c.dscale[2]};
+    const float q1[3] = {g1 * gn[0] * c.dscale[0], g1 * gn[1] * c.dscale[1], g1 * gn[2] * c.dscale[2]};
 #pragma unroll
     for (int yz = 0; yz < 4; ++yz) {
       uint32_t idx[2];

@@ -18,10 +18,11 @@ __global__ void __launch_bounds__(256) k_lotd_fwd(const float* __restrict__ x, c
   const int64_t s = tid / L;
   const int l = (int)(tid % L);
   const float xx[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
-  const int R = m.res[l];
+  const LotdRes R = m.res[l];
   const LotdCell c = lotd_cell(xx, R);
   float f0 = 0.f, f1 = 0.f;
   float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+  if (l < m.n_active)
 #pragma unroll
   for (int corner = 0; corner < 8; ++corner) {
     float w, dw[3];
@@ -46,8 +47,8 @@ __global__ void __launch_bounds__(256) k_lotd_fwd(const float* __restrict__ x, c
   if (dydx) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      dydx[o * 3 + a] = j0[a] * c.dscale;
-      dydx[(o + 1) * 3 + a] = j1[a] * c.dscale;
+      dydx[o * 3 + a] = j0[a] * c.dscale[a];
+      dydx[(o + 1) * 3 + a] = j1[a] * c.dscale[a];
     }
   }
 }
@@ -60,8 +61,9 @@ __global__ void __launch_bounds__(256) k_lotd_bwd(const float* __restrict__ x, c
   if (tid >= S * L) return;
   const int64_t s = tid / L;
   const int l = (int)(tid % L);
+  if (l >= m.n_active) return;   // masked level: no gradient
   const float xx[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
-  const int R = m.res[l];
+  const LotdRes R = m.res[l];
   const LotdCell c = lotd_cell(xx, R);
   const int64_t o = s * (2 * L) + 2 * l;
   const float d0 = dout ? dout[o] : 0.f, d1 = dout ? dout[o + 1] : 0.f;
@@ -69,8 +71,8 @@ __global__ void __launch_bounds__(256) k_lotd_bwd(const float* __restrict__ x, c
   if (ddydx) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      q0[a] = ddydx[o * 3 + a] * c.dscale;
-      q1[a] = ddydx[(o + 1) * 3 + a] * c.dscale;
+      q0[a] = ddydx[o * 3 + a] * c.dscale[a];
+      q1[a] = ddydx[(o + 1) * 3 + a] * c.dscale[a];
     }
   }
 #pragma unroll

@@ -1,15 +1,23 @@
 // lotd_dev.h -- device-side LoTD (multi-resolution Dense/Hash grid) addressing shared by lotd.hip and
 // field.hip.  Conventions are those of oracle/lotd.py (the executable spec standing in for the absent
 // nr3d_lib.models.grid_encodings.lotd; config: lotd_neus.dtu.230814.yaml:96-111):
-//   u = x/2 + 0.5 ; pos = u * (R-1) ; c0 = clamp(floor(pos), 0, R-2) ; w = pos - c0
-//   Dense index = cx + R*(cy + R*cz) ; Hash index = (cx ^ cy*2654435761 ^ cz*805459861) mod T (uint32)
+//   u = x/2 + 0.5 ; pos_a = u_a * (R_a-1) ; c0 = clamp(floor(pos), 0, R-2) ; w = pos - c0   (R_a: vertices on axis a;
+//   cubic levels have R_x = R_y = R_z, ``lotd_use_cuboid`` levels follow the aspect of the AABB)
+//   Dense index = cx + Rx*(cy + Ry*cz) ; Hash index = (cx ^ cy*2654435761 ^ cz*805459861) mod T (uint32)
+//   levels l >= n_active are masked (``anneal_cfg{type: hardmask}``): feature 0, no gradient, no memory access.
 //   params: flat fp16, level l at [offset_l, offset_l + size_l*2), feature index fastest.
 #pragma once
 #include "nsim_common.h"
 
+struct LotdRes {
+  int r[3];
+  __host__ __device__ int max() const { return r[0] > r[1] ? (r[0] > r[2] ? r[0] : r[2]) : (r[1] > r[2] ? r[1] : r[2]); }
+};
+
 struct LotdDev {
   int num_levels;
-  int res[NSIM_MAX_LEVELS];
+  int n_active;                        // levels >= n_active are masked (hardmask annealing)
+  LotdRes res[NSIM_MAX_LEVELS];
   int type[NSIM_MAX_LEVELS];
   uint32_t size[NSIM_MAX_LEVELS];
   int64_t offset[NSIM_MAX_LEVELS];
@@ -18,8 +26,9 @@ struct LotdDev {
 static inline LotdDev lotd_dev(const NsimLotdMeta* m) {
   LotdDev d;
   d.num_levels = m->num_levels;
+  d.n_active = (m->n_active_levels > 0 && m->n_active_levels < m->num_levels) ? m->n_active_levels : m->num_levels;
   for (int l = 0; l < NSIM_MAX_LEVELS; ++l) {
-    d.res[l] = l < m->num_levels ? m->res[l] : 2;
+    for (int a = 0; a < 3; ++a) d.res[l].r[a] = l < m->num_levels ? m->res[l][a] : 2;
     d.type[l] = l < m->num_levels ? m->type[l] : 0;
     d.size[l] = l < m->num_levels ? m->size[l] : 8;
     d.offset[l] = l < m->num_levels ? m->offset[l] : 0;
@@ -32,9 +41,9 @@ static inline int lotd_meta_check(const NsimLotdMeta* m) {
   if (m->n_feats != 2) return 11;
   if (m->num_levels < 1 || m->num_levels > NSIM_MAX_LEVELS) return 12;
   for (int l = 0; l < m->num_levels; ++l) {
-    if (m->res[l] < 2) return 13;
+    if (m->res[l][0] < 2 || m->res[l][1] < 2 || m->res[l][2] < 2) return 13;
     if (m->type[l] == NSIM_LOTD_DENSE) {
-      if ((uint64_t)m->res[l] * m->res[l] * m->res[l] != (uint64_t)m->size[l]) return 14;
+      if ((uint64_t)m->res[l][0] * m->res[l][1] * m->res[l][2] != (uint64_t)m->size[l]) return 14;
     } else if (m->type[l] == NSIM_LOTD_HASH) {
       if (m->size[l] == 0 || (m->size[l] & (m->size[l] - 1)) != 0) return 17;  // hash tables: power of two
     } else {
@@ -48,27 +57,28 @@ static inline int lotd_meta_check(const NsimLotdMeta* m) {
 struct LotdCell {
   int c0[3];
   float w[3];
-  float dscale;  // d pos / d x = 0.5 * (R-1)
+  float dscale[3];  // d pos_a / d x_a = 0.5 * (R_a - 1)
 };
 
-__device__ __forceinline__ LotdCell lotd_cell(const float x[3], int R) {
+__device__ __forceinline__ LotdCell lotd_cell(const float x[3], const LotdRes& R) {
   LotdCell c;
-  const float rm1 = (float)(R - 1);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
+    const float rm1 = (float)(R.r[a] - 1);
     const float u = x[a] * 0.5f + 0.5f;
     const float pos = u * rm1;
     float f = floorf(pos);
-    f = fminf(fmaxf(f, 0.f), (float)(R - 2));
+    f = fminf(fmaxf(f, 0.f), (float)(R.r[a] - 2));
     c.c0[a] = (int)f;
     c.w[a] = pos - f;
+    c.dscale[a] = 0.5f * rm1;
   }
-  c.dscale = 0.5f * rm1;
   return c;
 }
 
-__device__ __forceinline__ uint32_t lotd_index(int cx, int cy, int cz, int R, int type, uint32_t T) {
-  if (type == NSIM_LOTD_DENSE) return (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+__device__ __forceinline__ uint32_t lotd_index(int cx, int cy, int cz, const LotdRes& R, int type, uint32_t T) {
+  if (type == NSIM_LOTD_DENSE)
+    return (uint32_t)cx + (uint32_t)R.r[0] * ((uint32_t)cy + (uint32_t)R.r[1] * (uint32_t)cz);
   const uint32_t h = (uint32_t)cx ^ ((uint32_t)cy * 2654435761u) ^ ((uint32_t)cz * 805459861u);
   return h & (T - 1u);  // T is a power of two (checked on the host)
 }

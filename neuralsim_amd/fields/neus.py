@@ -353,6 +353,21 @@ class LoTDNeuSModel(nn.Module):
         self.field_meta.precision = {"fp16": 0, "f32": 1}[precision]
         self._wpack_versions = None
 
+    def set_active_levels(self, n: Optional[int]):
+        """Hardmask level annealing state (``encoding_cfg.anneal_cfg{type: hardmask}``, lotd_neus.dtu.230814.yaml:104-108):
+        only the first n levels are read / trained; None or >= 16 = all."""
+        self.encoding.cfg.set_active_levels(n)
+        self.field_meta.lotd.n_active_levels = self.encoding.cfg.meta.n_active_levels
+
+    def anneal_levels(self, it: int, start_it: int = 0, stop_it: int = 1000, start_level: int = 2):
+        """Level l is active once it >= start_it + (l - start_level) / (L - 1 - start_level) * (stop_it - start_it)
+        (levels <= start_level from the start, all L by stop_it).  Returns the number of active levels."""
+        L = self.encoding.cfg.num_levels
+        r = min(max((it - start_it) / max(1, stop_it - start_it), 0.0), 1.0)
+        n = int(math.floor(start_level + r * (L - 1 - start_level) + 1e-9)) + 1
+        self.set_active_levels(n)
+        return n
+
     def _shadow(self):
         """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
         grid16 = self.encoding.shadow()
@@ -374,17 +389,19 @@ class LoTDNeuSModel(nn.Module):
         return grid16, self._wpack
 
     @torch.no_grad()
-    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None):
+    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None,
+                              level: int = None):
         """Deterministic stand-in for the reference's SDF pre-training (``geo_init_method: pretrain_after_zero_out``,
         ``radius_init`` -- lotd_neus.dtu.230814.yaml:125-126; app/models/single/neus.py:198-236): feature 0 of the
         finest dense level holds |x_vertex| - radius and unit 0 of every hidden layer passes it through the linear
         region of softplus(beta) (bias +2), so the initial SDF is a (trilinearly sampled) sphere; the remaining
         weights keep a small random part so every gradient path is exercised."""
         cfg = self.encoding.cfg
-        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense")
-        R = cfg.lod_res[lv]
-        ax = torch.linspace(-1.0, 1.0, R)
-        zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense") if level is None else int(level)
+        assert cfg.lod_types[lv] == "Dense", "the sphere is written to a dense level"
+        Rx, Ry, Rz = cfg.lod_res3[lv]
+        zz, yy, xx = torch.meshgrid(torch.linspace(-1.0, 1.0, Rz), torch.linspace(-1.0, 1.0, Ry),
+                                    torch.linspace(-1.0, 1.0, Rx), indexing="ij")
         sdf = (torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) - radius).reshape(-1)
         if self.inside_out if inside_out is None else inside_out:
             sdf = -sdf                     # camera inside the surface (indoor scenes): positive inside the sphere

@@ -24,32 +24,50 @@ def gen_ngp_res(min_res: int, max_res: int, num_levels: int) -> List[int]:
     return [int(math.ceil(min_res * s ** l - 1e-6)) for l in range(num_levels)]
 
 
+def cuboid_ngp_res(aspect, min_res: int, max_res: int, num_levels: int) -> List[List[int]]:
+    """``lotd_use_cuboid: true`` (withmask_withlidar_joint.240219.yaml:160): per-axis vertex counts following the aspect
+    of the AABB -- the SHORTEST axis gets the gen_ngp list, the others are stretched by their extent ratio.
+    (The generator lives in the absent nr3d_lib; this convention is fixed here and in oracle/lotd.py.)"""
+    base = gen_ngp_res(min_res, max_res, num_levels)
+    mn = min(aspect)
+    return [[int(math.ceil(r * a / mn - 1e-6)) for a in aspect] for r in base]
+
+
 class LoTDConfig:
-    def __init__(self, lod_res: List[int], n_feats: int = 2, log2_hashmap_size: int = 19):
+    def __init__(self, lod_res: List, n_feats: int = 2, log2_hashmap_size: int = 19):
+        """lod_res: per level either R (cubic) or [Rx, Ry, Rz] (cuboid)."""
         assert n_feats == 2, "the gfx950 kernels are specialised for 2 features per level"
         assert len(lod_res) <= _lib.NSIM_MAX_LEVELS
-        self.lod_res = [int(r) for r in lod_res]
+        self.lod_res3 = [[int(r)] * 3 if not isinstance(r, (list, tuple)) else [int(v) for v in r] for r in lod_res]
+        self.lod_res = [r[0] if r[0] == r[1] == r[2] else list(r) for r in self.lod_res3]
         self.n_feats = n_feats
         self.hashmap_size = 2 ** log2_hashmap_size
         self.lod_types, self.lod_sizes, self.lod_offsets = [], [], []
         off = 0
-        for R in self.lod_res:
-            dense = R ** 3 <= self.hashmap_size
+        for R in self.lod_res3:
+            nvert = R[0] * R[1] * R[2]
+            dense = nvert <= self.hashmap_size
             self.lod_types.append("Dense" if dense else "Hash")
-            self.lod_sizes.append(R ** 3 if dense else self.hashmap_size)
+            self.lod_sizes.append(nvert if dense else self.hashmap_size)
             self.lod_offsets.append(off)
             off += self.lod_sizes[-1] * n_feats
         self.n_params = off
-        self.num_levels = len(self.lod_res)
+        self.num_levels = len(self.lod_res3)
         self.out_features = self.num_levels * n_feats
         m = _lib.LotdMeta()
-        m.num_levels, m.n_feats = self.num_levels, n_feats
+        m.num_levels, m.n_feats, m.n_active_levels = self.num_levels, n_feats, 0
         for l in range(self.num_levels):
-            m.res[l] = self.lod_res[l]
+            for a in range(3):
+                m.res[l][a] = self.lod_res3[l][a]
             m.type[l] = 0 if self.lod_types[l] == "Dense" else 1
             m.size[l] = self.lod_sizes[l]
             m.offset[l] = self.lod_offsets[l]
         self.meta = m
+
+    def set_active_levels(self, n: int):
+        """Hardmask level annealing (``anneal_cfg{type: hardmask, start_level, start_it, stop_it}``,
+        lotd_neus.dtu.230814.yaml:104-108): levels >= n yield zero features and get no gradient."""
+        self.meta.n_active_levels = 0 if n is None or n >= self.num_levels else max(1, int(n))
 
     @classmethod
     def from_cfg(cls, lotd_cfg: Optional[dict] = None, lotd_auto_compute_cfg: Optional[dict] = None):

@@ -24,8 +24,10 @@ class RenderTrainer:
     def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
-                 distant_model=None, sky_model=None):
+                 distant_model=None, sky_model=None, level_anneal: Optional[dict] = None):
         self.model = model
+        # encoding_cfg.anneal_cfg{type: hardmask, start_it, stop_it, start_level} (dtu yaml:104-108)
+        self.level_anneal = dict(level_anneal) if level_anneal else None
         self.intr, self.c2w, self.WH = intr, c2w, WH
         self.V = intr.shape[0]
         self.num_rays = num_rays             # rays per rank per iteration (weak scaling, as the reference's DDP)
@@ -88,6 +90,8 @@ class RenderTrainer:
         model = self.model
         # training_before_per_step: occupancy refresh with a rank-shared seed keeps replicas consistent
         acc = model.accel
+        if self.level_anneal is not None:
+            model.anneal_levels(it, **self.level_anneal)
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         xy, fidx, gt = self.sample_batch()

@@ -46,14 +46,28 @@ class LoTDSpec:
         return self.num_levels * self.n_feats
 
 
-def make_lotd_spec(lod_res: List[int], n_feats: int = 2, log2_hashmap_size: int = 19) -> LoTDSpec:
+def _res3(R):
+    """per-level resolution: int (cubic) or [Rx, Ry, Rz] (``lotd_use_cuboid``)."""
+    return [int(R)] * 3 if not isinstance(R, (list, tuple)) else [int(v) for v in R]
+
+
+def cuboid_ngp_res(aspect, min_res: int, max_res: int, num_levels: int):
+    """``lotd_use_cuboid: true`` (withmask_withlidar_joint.240219.yaml:160) -- generator absent (nr3d_lib), convention
+    fixed here: the shortest axis gets the gen_ngp list, the others are stretched by their extent ratio."""
+    base = gen_ngp_res(min_res, max_res, num_levels)
+    mn = min(aspect)
+    return [[int(math.ceil(r * a / mn - 1e-6)) for a in aspect] for r in base]
+
+
+def make_lotd_spec(lod_res: List, n_feats: int = 2, log2_hashmap_size: int = 19) -> LoTDSpec:
     T = 2 ** log2_hashmap_size
     types, sizes, offs = [], [], []
     off = 0
     for R in lod_res:
-        if R ** 3 <= T:
+        rx, ry, rz = _res3(R)
+        if rx * ry * rz <= T:
             types.append('Dense')
-            sizes.append(R ** 3)
+            sizes.append(rx * ry * rz)
         else:
             types.append('Hash')
             sizes.append(T)
@@ -69,9 +83,10 @@ def gen_ngp_res(min_res: int, max_res: int, num_levels: int) -> List[int]:
     return [int(math.ceil(min_res * s ** l - 1e-6)) for l in range(num_levels)]
 
 
-def _vertex_index(cx, cy, cz, R: int, typ: str, T: int):
+def _vertex_index(cx, cy, cz, R, typ: str, T: int):
     if typ == 'Dense':
-        return cx + R * (cy + R * cz)
+        rx, ry, _ = _res3(R)
+        return cx + rx * (cy + ry * cz)
     m = 0xFFFFFFFF
     hx = cx & m
     hy = (cy * PRIME_Y) & m
@@ -79,7 +94,7 @@ def _vertex_index(cx, cy, cz, R: int, typ: str, T: int):
     return (hx ^ hy ^ hz) % T
 
 
-def lotd_forward(x: torch.Tensor, params: torch.Tensor, spec: LoTDSpec) -> torch.Tensor:
+def lotd_forward(x: torch.Tensor, params: torch.Tensor, spec: LoTDSpec, n_active: int = None) -> torch.Tensor:
     """x [S,3] in [-1,1] (may require grad) , params flat fp16/f32 [n_params] -> h [S, L*F] f32.
     Differentiable in both x (piecewise-trilinear) and params via autograd, so
     ``nablas = d sdf / d x`` and its double-backward come for free in the oracle."""
@@ -88,9 +103,14 @@ def lotd_forward(x: torch.Tensor, params: torch.Tensor, spec: LoTDSpec) -> torch
     u = x * 0.5 + 0.5
     p32 = params.float()
     outs = []
+    n_active = getattr(spec, 'n_active', None) if n_active is None else n_active
     for l, R in enumerate(spec.lod_res):
-        pos = u * float(R - 1)
-        c0 = torch.floor(pos.detach()).clamp(0, R - 2).long()
+        if n_active is not None and l >= n_active:      # hardmask level annealing (dtu yaml:104-108): zero features
+            outs.append(x.new_zeros([S, F]))
+            continue
+        R3 = torch.tensor(_res3(R), dtype=x.dtype)
+        pos = u * (R3 - 1.0)
+        c0 = torch.minimum(torch.floor(pos.detach()).clamp_min(0), R3 - 2.0).long()
         w = pos - c0.to(pos.dtype)
         table = p32[spec.lod_offsets[l]: spec.lod_offsets[l] + spec.lod_sizes[l] * F].view(-1, F)
         feat = x.new_zeros([S, F])
@@ -123,11 +143,11 @@ def write_sphere_level(params: torch.Tensor, spec: LoTDSpec, radius: float = 0.5
     The reference reaches the same state by 500 iterations of SDF pre-training
     (app/models/single/neus.py:198-236); this is the deterministic stand-in used for synthetic weights."""
     level = finest_dense_level(spec) if level is None else level
-    R = spec.lod_res[level]
+    rx, ry, rz = _res3(spec.lod_res[level])
     assert spec.lod_types[level] == 'Dense'
     F = spec.n_feats
-    ax = torch.linspace(-1.0, 1.0, R)
-    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing='ij')  # index = x + R*(y + R*z)
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1.0, 1.0, rz), torch.linspace(-1.0, 1.0, ry),
+                                torch.linspace(-1.0, 1.0, rx), indexing='ij')  # index = x + Rx*(y + Ry*z)
     sdf = torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) - radius
     lvl = params[spec.lod_offsets[level]: spec.lod_offsets[level] + spec.lod_sizes[level] * F].view(-1, F)
     lvl[:, 0] = sdf.reshape(-1).to(params.dtype)

@@ -7,7 +7,7 @@ from oracle import field as ofield, lotd as olotd
 from neuralsim_amd import _lib
 from neuralsim_amd.fields.neus import _FieldFn
 from neuralsim_amd.grid_encodings.lotd import LoTDConfig, LoTDEncoding, gen_ngp_res
-from util import leaf, make_params, model_from_params, oracle_flat_grads, rel_l2
+from util import SMALL_RES as SMALL_RES_T, leaf, make_params, model_from_params, oracle_flat_grads, rel_l2
 
 
 def test_gen_ngp_matches_reference_comment():
@@ -172,3 +172,70 @@ def test_sdf_scale_and_inside_out(backend):
         sd = mm.query_sdf(pts.to(backend)).cpu()
         want = (pts.norm(dim=-1) - 0.5) * (-1.0 if inside_out else 1.0)
         assert float((sd - want).abs().max()) < 0.08, (inside_out, sd)
+
+
+@pytest.mark.parametrize("case", ["cuboid", "anneal", "cuboid+anneal"])
+def test_field_cuboid_levels_and_hardmask(backend, case):
+    """Per-axis level resolutions (``lotd_use_cuboid``, street config :160) and hardmask level annealing
+    (``anneal_cfg{type: hardmask}``, dtu config :104-108): values, normals and every gradient vs the oracle; the masked
+    levels must get exactly zero gradient."""
+    from oracle import lotd as olotd
+    cub = "cuboid" in case
+    n_active = 9 if "anneal" in case else None
+    lod_res = olotd.cuboid_ngp_res([2.0, 1.0, 0.5], 3, 40, 16) if cub else list(SMALL_RES_T)
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=2, seed=5, sphere_init=False,
+                                 grid_bound=0.3, noise_scale=1.0)
+    p.grid = p.grid.float()
+    p.spec.n_active = n_active
+    for t in p.tensors():
+        t.requires_grad_(True)
+    model = model_from_params(p, backend, precision="f32")
+    model.set_active_levels(n_active)
+    assert ("Hash" in p.spec.lod_types) and ("Dense" in p.spec.lod_types)
+    g = torch.Generator().manual_seed(2)
+    R, S = 5, 90
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    dv = lambda a: a.to(backend).contiguous()
+    ha_d = leaf(h_appear, backend)
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    assert (sdf.cpu() - sdf_r).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < 2e-4 * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < 2e-5
+    for fused in (False, True):                   # level-major and fused no-grad query
+        model._sdf_fused = fused
+        assert torch.allclose(model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu(), sdf.cpu().detach(),
+                              atol=2e-6)
+    # standalone encoding (forward + dy/dx) sees the same levels
+    h_o = olotd.lotd_forward(x, p.grid, p.spec)
+    model.encoding.cfg.set_active_levels(n_active)
+    h_p, _ = model.encoding.forward_dydx(dv(x))
+    assert (h_p.detach().cpu() - h_o.detach()).abs().max() < 1e-5
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < 2e-4, (k, e)
+    if n_active is not None:
+        off = p.spec.lod_offsets[n_active]
+        assert float(got["grid"][off:].abs().max()) == 0.0
+        assert float(got["grid"][:off].abs().max()) > 0.0
+
+
+def test_anneal_schedule():
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    m = LoTDNeuSModel(lod_res=SMALL_RES_T, log2_hashmap_size=12)
+    assert m.anneal_levels(0, 0, 1000, 2) == 3 and m.field_meta.lotd.n_active_levels == 3
+    assert m.anneal_levels(500, 0, 1000, 2) == 9
+    assert m.anneal_levels(1000, 0, 1000, 2) == 16 and m.field_meta.lotd.n_active_levels == 0    # 0 = all
