@@ -126,13 +126,16 @@ int nsim_occ_decay(float* val, int64_t nvox, float decay, void* stream);
 int nsim_occ_update(float* val, const float* pts, const float* sdf, int64_t n, const NsimOccMeta* meta,
                     float inv_s, void* stream);
 int nsim_occ_pack_bits(const float* val, int64_t nvox, float thre, uint32_t* bits, void* stream);
-/* OccGridAccel.ray_march (march_cfg{step_size,max_steps}): lattice t_k = near + (k + jitter) * step */
+/* OccGridAccel.ray_march (march_cfg{step_size,max_steps}): lattice t_k = near + (k + jitter) * step.
+ * ray_word_off (may be NULL): batched occupancy grid (``accel_cfg{type: occ_grid_batched}``,
+ * code_multi/.../no_fg_occ.221218.yaml:369-377) -- offset in 32-bit words of ray r's instance inside ``bits``. */
 int nsim_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far,
-                     const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta,
-                     float step, int max_steps, int64_t* counts, void* stream);
+                     const float* jitter, int64_t R, const uint32_t* bits, const int64_t* ray_word_off,
+                     const NsimOccMeta* meta, float step, int max_steps, int64_t* counts, void* stream);
 int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far,
-                    const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta,
-                    float step, int max_steps, const int64_t* pack_infos, float* t_out, void* stream);
+                    const float* jitter, int64_t R, const uint32_t* bits, const int64_t* ray_word_off,
+                    const NsimOccMeta* meta, float step, int max_steps, const int64_t* pack_infos, float* t_out,
+                    void* stream);
 /* coarse_step_cfg{step_mode: linear}: t = near + (far-near) * ((i + u)/C); jitter_c NULL => u = 0.5 */
 int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C,
                        float* out, void* stream);
@@ -190,22 +193,27 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
  * points (x / rays / grid are then unused and may be NULL).  Same values either way. */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   int64_t S, float* sdf, const void* feat_planes, void* stream);
+                   const int64_t* ray_goff, int64_t S, float* sdf, const void* feat_planes, void* stream);
 /* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [16][S] of
  * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
  * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
-                        const float* rays_d, const float* t, const int64_t* ridx, int64_t S, void* feat_planes,
-                        void* stream);
-/* With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
+                        const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
+                        void* feat_planes, void* stream);
+/* Batched / multi-instance models (``batched_ray_query`` + ``set_condition``,
+ * app/renderers/buffer_compose_renderer.py:222-265, app/models/shared/batched_neus.py:380-407): the tables of all
+ * instances live in ONE flat tensor and ``ray_goff[r]`` (may be NULL) is the offset, in scalars (even), of ray r's
+ * instance; every kernel that touches the table takes it next to ``ridx`` (required then, also with ``x``).
+ *
+ * With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
  * h_planes [16,S,2] / J_planes [16,S,2,3] (both or neither): when given, the gathered features and their
  * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again). */
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, float* h_planes,
-                   float* J_planes, void* stream);
+                   const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
+                   float* h_planes, float* J_planes, void* stream);
 /* Backward of nsim_field_fwd = three launches (each its own entry point so that callers can time / overlap them):
  *
  * (1) radiance branch: given dL/drgb [S,3], the saved forward nablas_fwd / rgb_fwd [S,3] and the upstream
@@ -225,8 +233,8 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term). */
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d,
-                      const float* t, const int64_t* ridx, int64_t S, const float* dh_planes, const float* g_planes,
-                      const float* gn, float* dgrid, void* stream);
+                      const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
+                      const float* dh_planes, const float* g_planes, const float* gn, float* dgrid, void* stream);
 
 /* ------------------------------------------------ NeRF++ distant-view model (LoTDNeRFDistant) */
 /* 4-D LoTD level table of ``lotd_auto_compute_cfg{type: ngp4d}`` (lotd_neus.dtu.230814.yaml:193-200): level l has

@@ -69,8 +69,8 @@ SIGNATURES = {
     "nsim_occ_decay": [_P, _I64, _F],
     "nsim_occ_update": [_P, _P, _P, _I64, C.POINTER(OccMeta), _F],
     "nsim_occ_pack_bits": [_P, _I64, _F, _P],
-    "nsim_march_count": [_P, _P, _P, _P, _P, _I64, _P, C.POINTER(OccMeta), _F, _I, _P],
-    "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
+    "nsim_march_count": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P],
+    "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
     "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],
     "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P],
     "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P],
@@ -79,12 +79,12 @@ SIGNATURES = {
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],
     "nsim_lotd_bwd": [_P, _P, _P, C.POINTER(LotdMeta), _I64, _P],
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
-    "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P],
-    "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _I64, _P],
-    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
+    "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P],
+    "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
-    "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_distant_pack_weights": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P],
     "nsim_distant_shells": [_P, _P, _P, _P, _I64, _I, C.POINTER(C.c_float * 6), _F, _F, _P, _P, _P],
     "nsim_density_alpha_fwd": [_P, _P, _P, _I64, _I, _P],

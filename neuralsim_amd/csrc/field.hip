@@ -204,6 +204,7 @@ struct FieldArgs {
   const char* wpack;
   const float *x, *rays_o, *rays_d, *t;
   const int64_t* ridx;
+  const int64_t* ray_goff;                         // batched model: table offset (in scalars, even) of ray r's instance
   const float* h_appear;
   int64_t S;
   float *sdf, *nablas, *rgb;                       // forward outputs
@@ -289,6 +290,7 @@ __device__ __forceinline__ float vecf(const char* W, const FieldLayout& L, int v
 struct TilePoint {
   float xx[3], vd[3];
   int64_t s, ray;
+  uint32_t goff;      // instance offset into the table (batched model), 0 otherwise
   bool valid;
 };
 
@@ -297,6 +299,7 @@ __device__ __forceinline__ TilePoint load_point(const FieldArgs& a, int64_t tile
   p.s = tile * 32 + j;
   p.valid = p.s < a.S;
   p.ray = 0;
+  p.goff = 0u;
   p.xx[0] = p.xx[1] = p.xx[2] = 0.f;
   p.vd[0] = p.vd[1] = 0.f;
   p.vd[2] = 1.f;
@@ -314,6 +317,7 @@ __device__ __forceinline__ TilePoint load_point(const FieldArgs& a, int64_t tile
 #pragma unroll
       for (int c = 0; c < 3; ++c) p.vd[c] = a.rays_d[3 * p.ray + c];
     }
+    if (a.ray_goff) p.goff = (uint32_t)a.ray_goff[p.ray];
   }
   return p;
 }
@@ -432,7 +436,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                             c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
             float g0, g1;
-            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + 2u * idx, g0, g1);
+            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + p.goff + 2u * idx, g0, g1);
             f0 = f0 + w * g0;
             f1 = f1 + w * g1;
             if (MODE >= 1) {
@@ -671,11 +675,14 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   const int xcd = (int)(blockIdx.x & 7u);
   const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * GLM_PTS) + lane;
   float xx[GLM_PTS][3];
+  uint32_t goff[GLM_PTS];
 #pragma unroll
   for (int q = 0; q < GLM_PTS; ++q) {
     const int64_t s = s0 + 64 * q;
     xx[q][0] = xx[q][1] = xx[q][2] = 0.f;
+    goff[q] = 0u;
     if (s < a.S) {
+      if (a.ray_goff) goff[q] = (uint32_t)a.ray_goff[a.ridx[s]];
       if (a.x) {
         xx[q][0] = a.x[3 * s]; xx[q][1] = a.x[3 * s + 1]; xx[q][2] = a.x[3 * s + 2];
       } else {
@@ -707,7 +714,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
         const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                         c.c0[2] + ((corner >> 2) & 1), R, type, T);
         float g0, g1;
-        lotd_load2(gref, off + 2u * idx, g0, g1);
+        lotd_load2(gref, off + goff[q] + 2u * idx, g0, g1);
         f0[q] = f0[q] + w * g0;
         f1[q] = f1[q] + w * g1;
       }
@@ -798,7 +805,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                             c.c0[2] + ((corner >> 2) & 1), R, a.lotd.type[l], a.lotd.size[l]);
             float g0, g1;
-            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + 2u * idx, g0, g1);
+            lotd_load2(gref, (uint32_t)a.lotd.offset[l] + p.goff + 2u * idx, g0, g1);
             f0 = f0 + w * g0;
             f1 = f1 + w * g1;
           }
@@ -983,6 +990,7 @@ struct ScatterArgs {
   const int64_t* ridx;
   int64_t S;
   const float *dh_pl, *g_pl, *gn;
+  const int64_t* ray_goff;
   float* dgrid;
   int dedup_max_res;
 };
@@ -1001,7 +1009,9 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
     const int64_t s = chunk * 64 + lane;
     const bool valid = s < a.S;
     float xx[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f}, dh0 = 0.f, dh1 = 0.f, g0 = 0.f, g1 = 0.f;
+    uint32_t voff = 0u;      // batched model: vertex offset of the sample's instance (also separates the dedup keys)
     if (valid) {
+      if (a.ray_goff) voff = (uint32_t)(a.ray_goff[a.ridx[s]] >> 1);
       if (a.x) {
         xx[0] = a.x[3 * s]; xx[1] = a.x[3 * s + 1]; xx[2] = a.x[3 * s + 2];
       } else {
@@ -1032,7 +1042,7 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
         const int corner = dx | (yz << 1);
         float w, dw[3];
         lotd_corner_w(c, corner, w, dw);
-        idx[dx] = lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l], a.lotd.size[l]);
+        idx[dx] = voff + lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l], a.lotd.size[l]);
         v0[dx] = w * dh0 + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
         v1[dx] = w * dh1 + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
         emit[dx] = valid;
@@ -1184,16 +1194,18 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 }
 
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
-                        const float* rays_d, const float* t, const int64_t* ridx, int64_t S, void* feat_planes,
-                        void* stream) {
+                        const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
+                        void* feat_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (ray_goff && !ridx) return 29;
   if (!feat_planes || !grid_f16) return 4;
   FieldArgs a = field_args(meta);
   a.grid = (const f16*)grid_f16;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.ray_goff = ray_goff;
   a.S = S;
   a.feat_pl = feat_planes;
   // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
@@ -1219,17 +1231,19 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
 }
 
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
-                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                   float* sdf, const void* feat_planes, void* stream) {
+                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
+                   const int64_t* ray_goff, int64_t S, float* sdf, const void* feat_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!feat_planes && !x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (ray_goff && !ridx) return 29;
   void* feat_scratch = const_cast<void*>(feat_planes);
   FieldArgs a = field_args(meta);
   a.grid = (const f16*)grid_f16;
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
+  a.ray_goff = ray_goff;
   a.S = S;
   a.sdf = sdf;
   a.feat_pl = feat_scratch;
@@ -1257,11 +1271,12 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb, float* h_planes,
-                   float* J_planes, void* stream) {
+                   const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
+                   float* h_planes, float* J_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
+  if (ray_goff && !ridx) return 29;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (rgb && !(rays_d && ridx)) return 25;
   if ((h_planes != nullptr) != (J_planes != nullptr)) return 28;
@@ -1270,6 +1285,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.h_appear = h_appear;
+  a.ray_goff = ray_goff;
   a.S = S;
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
   a.h_pl = h_planes; a.J_pl = J_planes;
@@ -1337,19 +1353,21 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
 }
 
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                      const int64_t* ridx, int64_t S, const float* dh_planes, const float* g_planes, const float* gn,
-                      float* dgrid, void* stream) {
+                      const int64_t* ridx, const int64_t* ray_goff, int64_t S, const float* dh_planes,
+                      const float* g_planes, const float* gn, float* dgrid, void* stream) {
   const int rc = lotd_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (!dh_planes || !g_planes || !dgrid) return 28;
+  if (ray_goff && !ridx) return 29;
   if (bwd_ablate() & 1) return 0;
   ScatterArgs sa;
   sa.lotd = lotd_dev(meta);
   sa.x = x; sa.rays_o = rays_o; sa.rays_d = rays_d; sa.t = t; sa.ridx = ridx;
   sa.S = S;
   sa.dh_pl = dh_planes; sa.g_pl = g_planes; sa.gn = gn;
+  sa.ray_goff = ray_goff;
   sa.dgrid = dgrid;
   sa.dedup_max_res = 600;
   const char* e = getenv("NSIM_DEDUP_MAX_RES");

@@ -20,6 +20,7 @@ const char* nsim_strerror(int code) {
     case 15: return "LoTD unknown level type";
     case 16: return "LoTD level offset must be even";
     case 17: return "LoTD hash table size must be a power of two";
+    case 29: return "per-ray instance offsets (batched model) need ridx";
     case 28: return "h / dh/dx planes (and dh / g hand-off planes when dgrid is requested) are required";
     case 27: return "radiance backward needs the saved forward nablas / rgb and a [S,3] scratch buffer";
     case 30: return "sky meta is NULL";

@@ -176,10 +176,11 @@ __device__ __forceinline__ bool march_test(const MarchRay& m, const OccDev& occ,
 __global__ void __launch_bounds__(SMP_BLOCK) k_march_count(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ near,
     const float* __restrict__ far, const float* __restrict__ jitter, int64_t R, const uint32_t* __restrict__ bits,
-    OccDev occ, float step, int max_steps, int64_t* __restrict__ counts) {
+    const int64_t* __restrict__ ray_word_off, OccDev occ, float step, int max_steps, int64_t* __restrict__ counts) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
+  if (ray_word_off) bits += ray_word_off[r];      // batched occupancy grid: this ray's instance
   const MarchRay m = march_load(rays_o, rays_d, near, far, jitter, r, step, max_steps);
   int cnt = 0;
   for (int base = 0; base < m.K; base += 64) {
@@ -193,10 +194,12 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_march_count(
 __global__ void __launch_bounds__(SMP_BLOCK) k_march_emit(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ near,
     const float* __restrict__ far, const float* __restrict__ jitter, int64_t R, const uint32_t* __restrict__ bits,
-    OccDev occ, float step, int max_steps, const int64_t* __restrict__ pi, float* __restrict__ t_out) {
+    const int64_t* __restrict__ ray_word_off, OccDev occ, float step, int max_steps, const int64_t* __restrict__ pi,
+    float* __restrict__ t_out) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
+  if (ray_word_off) bits += ray_word_off[r];
   const MarchRay m = march_load(rays_o, rays_d, near, far, jitter, r, step, max_steps);
   const int64_t st = pi[2 * r];
   int cnt = 0;
@@ -464,23 +467,24 @@ int nsim_occ_pack_bits(const float* val, int64_t nvox, float thre, uint32_t* bit
 }
 
 int nsim_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far,
-                     const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta, float step,
-                     int max_steps, int64_t* counts, void* stream) {
+                     const float* jitter, int64_t R, const uint32_t* bits, const int64_t* ray_word_off,
+                     const NsimOccMeta* meta, float step, int max_steps, int64_t* counts, void* stream) {
   if (R <= 0) return 0;
   if (!meta || !(step > 0.f)) return 5;
   hipLaunchKernelGGL(k_march_count, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, near, far,
-                     jitter, R, bits, occ_dev(meta), step, max_steps, counts);
+                     jitter, R, bits, ray_word_off, occ_dev(meta), step, max_steps, counts);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far,
-                    const float* jitter, int64_t R, const uint32_t* bits, const NsimOccMeta* meta, float step,
-                    int max_steps, const int64_t* pack_infos, float* t_out, void* stream) {
+                    const float* jitter, int64_t R, const uint32_t* bits, const int64_t* ray_word_off,
+                    const NsimOccMeta* meta, float step, int max_steps, const int64_t* pack_infos, float* t_out,
+                    void* stream) {
   if (R <= 0) return 0;
   if (!meta || !(step > 0.f)) return 5;
   hipLaunchKernelGGL(k_march_emit, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, near, far, jitter,
-                     R, bits, occ_dev(meta), step, max_steps, pack_infos, t_out);
+                     R, bits, ray_word_off, occ_dev(meta), step, max_steps, pack_infos, t_out);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

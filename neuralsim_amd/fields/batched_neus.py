@@ -1,0 +1,224 @@
+"""Batched (multi-instance) LoTD-NeuS model -- SURVEY sec. 8 row a20.
+
+Mirror of the API the reference's ``BufferComposeRenderer`` drives on a shared foreground model
+(app/renderers/buffer_compose_renderer.py:209-265; app/models/shared/batched_neus.py:295-407):
+``set_condition({'ins_ind' | 'ins_id' | 'z_ins'})`` -> ``batched_ray_test(..., compact_batch=True)`` ->
+``batched_ray_query(batched_ray_tested=, batched_ray_input=, config=, ...)`` -> ``clean_condition()``, over a batched
+occupancy grid (``accel_cfg{type: occ_grid_batched, resolution: [32,32,32]}``,
+code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml:369-377).
+
+What is batched here: every instance owns a LoTD table (what the reference's ``lotd_batched_growers`` emit per batch
+item) and an occupancy grid; the SDF / radiance decoders are shared.  All tables live in ONE flat parameter
+``[num_instances * n_params]`` and all grids in one bitfield, and every kernel on the path takes a per-ray instance
+offset (``ray_goff`` / ``ray_word_off`` in include/nsim.h) -- so B instances cost the launches of one.
+The hyper-network that GENERATES the tables from a latent code (StyleLoTD ``lotd_grower_cfg``, :322-352) lives in the
+absent nr3d_lib and is out of scope: tables are free auto-decoder parameters here (``z_ins`` is not supported).
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .neus import LoTDNeuSModel, OccGridAccel
+
+
+class OccGridAccelBatched(OccGridAccel):
+    """``occ_grid_batched``: B grids of one resolution over the shared object-space AABB; ``occ_val [B * nvox]``,
+    ``occ_bits [B * nvox / 32]`` (instance b at word offset b * nvox / 32)."""
+
+    def __init__(self, aabb: torch.Tensor, num_batches: int, resolution=(32, 32, 32), **kw):
+        super().__init__(aabb, resolution=resolution, **kw)
+        self.num_batches = int(num_batches)
+        self.nvox = self.resolution[0] * self.resolution[1] * self.resolution[2]
+        assert self.nvox % 32 == 0, "batched occupancy grids are word-aligned per instance"
+        dev = self.occ_val.device
+        self.register_buffer("occ_val", torch.zeros(self.num_batches * self.nvox, dtype=torch.float32, device=dev))
+        self.register_buffer("occ_bits", torch.full([self.num_batches * self.nvox // 32], -1, dtype=torch.int32,
+                                                    device=dev))
+
+    @property
+    def words_per_instance(self) -> int:
+        return self.nvox // 32
+
+    @property
+    def occ_grid(self) -> torch.Tensor:
+        r = self.resolution
+        return (self.occ_val > self.occ_thre).view(self.num_batches, r[2], r[1], r[0]).permute(0, 3, 2, 1)
+
+    @torch.no_grad()
+    def update_from_net(self, query_sdf, num_steps=None, num_pts=None, generator=None):
+        """``query_sdf(pts [n,3], ins_ind: int) -> sdf [n]``; every instance is refreshed from its own table."""
+        dev = self.occ_val.device
+        lo, hi = self.aabb[0], self.aabb[1]
+        n = num_pts or self.num_pts
+        for b in range(self.num_batches):
+            val = self.occ_val[b * self.nvox:(b + 1) * self.nvox]
+            for _ in range(num_steps or self.num_steps):
+                pts = lo + torch.rand([n, 3], device=dev, generator=generator) * (hi - lo)
+                sdf = query_sdf(pts, b).detach().float().contiguous()
+                _lib.call("nsim_occ_decay", _lib.ptr(val), self.nvox, self.ema_decay)
+                _lib.call("nsim_occ_update", _lib.ptr(val), _lib.ptr(pts), _lib.ptr(sdf), n, self.meta, self.inv_s)
+        self.pack_bits()
+
+
+class BatchedLoTDNeuSModel(LoTDNeuSModel):
+    is_ray_query_supported = True
+    is_batched_query_supported = True
+
+    def __init__(self, num_instances: int, ins_ids: Optional[Sequence[str]] = None, accel_cfg: dict = None,
+                 seed: int = 42, param_bound: float = 1e-4, **kw):
+        accel_cfg = dict(accel_cfg or {})
+        super().__init__(accel_cfg=accel_cfg, seed=seed, param_bound=param_bound, **kw)
+        B = self.num_instances = int(num_instances)
+        n = self.n_params_per_instance = self.encoding.cfg.n_params
+        assert B * n < 2 ** 31, "instance offsets are 32-bit inside the kernels"
+        g = torch.Generator().manual_seed(seed + 17)
+        p = ((torch.rand(B * n, generator=g) * 2 - 1) * param_bound).half().float()
+        self.encoding.flattened_params = nn.Parameter(p)
+        self.encoding.params16 = p.half()
+        self.encoding._shadow_version = -1
+        self.accel = OccGridAccelBatched(
+            self.accel.aabb, B, resolution=accel_cfg.get("resolution", (32, 32, 32)),
+            occ_thre=accel_cfg.get("occ_thre", 0.3), ema_decay=accel_cfg.get("ema_decay", 0.95),
+            inv_s=accel_cfg.get("occ_val_fn_cfg", {}).get("inv_s", 256.0), num_steps=accel_cfg.get("num_steps", 4),
+            num_pts=accel_cfg.get("num_pts", 2 ** 16), n_steps_between_update=accel_cfg.get("n_steps_between_update", 16),
+            n_steps_warmup=accel_cfg.get("n_steps_warmup", 256))
+        self._index_maps = {"ins_id": {k: i for i, k in enumerate(ins_ids or [str(i) for i in range(B)])}}
+        self.ins_inds_per_batch: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ conditions (batched_neus.py:380-407)
+    def set_condition(self, batched_infos: Dict):
+        if "z_ins" in batched_infos:
+            raise NotImplementedError("latent-conditioned table growers (StyleLoTD) live in nr3d_lib; out of scope")
+        if "ins_id" in batched_infos:
+            ids = batched_infos["ins_id"]
+            ids = [ids] if isinstance(ids, str) else ids
+            inds = torch.tensor([self._index_maps["ins_id"][i] for i in ids], dtype=torch.long, device=self.device)
+        elif "ins_ind" in batched_infos:
+            inds = torch.as_tensor(batched_infos["ins_ind"], dtype=torch.long, device=self.device).reshape(-1)
+        else:
+            raise RuntimeError("set_condition needs 'ins_id' or 'ins_ind'")
+        self.ins_inds_per_batch = inds
+
+    def clean_condition(self):
+        self.ins_inds_per_batch = None
+
+    def _offsets(self, ins_inds: torch.Tensor):
+        return ins_inds * self.n_params_per_instance, ins_inds * self.accel.words_per_instance
+
+    # ------------------------------------------------------------------ per-instance point queries
+    @torch.no_grad()
+    def query_sdf(self, x: torch.Tensor, ins_ind=None, bidx: torch.Tensor = None) -> torch.Tensor:
+        """SDF of points of ONE instance (``ins_ind: int``) or of per-point batch items (``bidx [S]`` indices into the
+        current condition)."""
+        shape = x.shape[:-1]
+        xf = x.detach().float().reshape(-1, 3).contiguous()
+        S = xf.shape[0]
+        if bidx is None:
+            goff = torch.tensor([int(ins_ind) * self.n_params_per_instance], dtype=torch.long, device=xf.device)
+            ridx = torch.zeros([S], dtype=torch.long, device=xf.device)
+        else:
+            goff, _ = self._offsets(self.ins_inds_per_batch)
+            ridx = bidx.reshape(-1).contiguous()
+        grid16, wpack = self._shadow()
+        return self._sdf_query(grid16, wpack, xf, None, None, None, ridx, S, xf.device, goff=goff).reshape(shape)
+
+    def forward_sdf_nablas(self, x: torch.Tensor, bidx: torch.Tensor = None, ins_ind=None, nablas_has_grad=True):
+        from .neus import _FieldFn
+        shape = x.shape[:-1]
+        xf = x.detach().float().reshape(-1, 3).contiguous()
+        if bidx is None:
+            goff = torch.tensor([int(ins_ind) * self.n_params_per_instance], dtype=torch.long, device=xf.device)
+            ridx = torch.zeros([xf.shape[0]], dtype=torch.long, device=xf.device)
+        else:
+            goff, _ = self._offsets(self.ins_inds_per_batch)
+            ridx = bidx.reshape(-1).contiguous()
+        sdf, nablas = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w,
+                                     self.rad_b, None, xf, None, None, None, ridx, False, goff)
+        if not nablas_has_grad:
+            nablas = nablas.detach()
+        return dict(sdf=sdf.reshape(shape), nablas=nablas.reshape(*shape, 3))
+
+    @torch.no_grad()
+    def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None,
+                              level: int = None):
+        """The single-instance initialisation, with the sphere level copied into every instance's table."""
+        n = self.n_params_per_instance
+        full = self.encoding.flattened_params
+        self.encoding.flattened_params = nn.Parameter(full.data[:n].clone())
+        super().geometric_init_sphere(radius, noise_scale, inside_out, level)
+        first = self.encoding.flattened_params.data
+        cfg = self.encoding.cfg
+        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense") if level is None else int(level)
+        lo, hi = cfg.lod_offsets[lv], cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2
+        for b in range(self.num_instances):
+            full.data[b * n + lo: b * n + hi] = first[lo:hi]
+        self.encoding.flattened_params = full
+        self.encoding.flattened_params.add_(0)
+        return self
+
+    def init_accel(self, generator=None, **kw):
+        self.accel.occ_val.zero_()
+        self.accel.update_from_net(lambda pts, b: self.query_sdf(pts, ins_ind=b), generator=generator, **kw)
+
+    # ------------------------------------------------------------------ batched rays (buffer_compose_renderer.py:222-265)
+    def batched_ray_test(self, rays_o: torch.Tensor, rays_d: torch.Tensor, near=None, far=None, compact_batch=True,
+                         **extra) -> Dict:
+        """rays_o / rays_d [B', N, 3] in the object space of each batch item.  Returns the flat list of (item, ray)
+        pairs that hit the AABB: ``rays_inds [R]`` (index into N), ``rays_full_bidx [R]`` (index into B'),
+        ``rays_bidx [R]`` (index into the compacted list of items that were hit at all), ``full_bidx_map [B'']``
+        (compact -> full), ``num_rays``, ``near``, ``far`` and the filtered inputs."""
+        Bq, N = rays_o.shape[0], rays_o.shape[1]
+        flat = super().ray_test(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), near=near, far=far)
+        pair = flat["rays_inds"]
+        full_bidx = torch.div(pair, N, rounding_mode="floor")
+        rinds = pair - full_bidx * N
+        if compact_batch:
+            full_bidx_map, bidx = torch.unique(full_bidx, return_inverse=True)      # sorted: order of items kept
+        else:
+            full_bidx_map, bidx = torch.arange(Bq, device=pair.device), full_bidx
+        ret = dict(num_rays=flat["num_rays"], rays_inds=rinds, rays_bidx=bidx, rays_full_bidx=full_bidx,
+                   full_bidx_map=full_bidx_map, rays_o=flat["rays_o"], rays_d=flat["rays_d"], near=flat["near"],
+                   far=flat["far"])
+        for k, v in extra.items():
+            if isinstance(v, torch.Tensor) and v.shape[:2] == (Bq, N):
+                vf = v.reshape(Bq * N, *v.shape[2:])
+                if vf.requires_grad and vf.dim() == 2 and vf.dtype == torch.float32:
+                    from ..losses import embedding_lookup
+                    ret[k] = embedding_lookup(vf, pair)
+                else:
+                    ret[k] = vf[pair]
+            else:
+                ret[k] = v
+        return ret
+
+    def batched_ray_query(self, *, batched_ray_input: dict = None, batched_ray_tested: dict, config,
+                          return_buffer: bool = True, return_details: bool = False,
+                          render_per_obj_individual: bool = False) -> Dict:
+        """``march_occ_multi_upsample[_compressed]`` on the tested (item, ray) pairs; the volume buffer is packed per
+        pair and carries ``rays_bidx_hit`` / ``rays_full_bidx_hit`` next to ``rays_inds_hit``."""
+        assert self.ins_inds_per_batch is not None, "set_condition() first"
+        bt = batched_ray_tested
+        ins = self.ins_inds_per_batch[bt["rays_full_bidx"]] if bt["num_rays"] > 0 else bt["rays_full_bidx"]
+        goff, woff = self._offsets(ins)
+        tested = dict(bt)
+        tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
+        ret = super().ray_query(ray_input=batched_ray_input, ray_tested=tested, config=config,
+                                return_buffer=return_buffer, return_details=return_details,
+                                render_per_obj_individual=render_per_obj_individual)
+        vb = ret["volume_buffer"]
+        if vb["type"] != "empty":
+            vb["rays_bidx_hit"] = bt["rays_bidx"]
+            vb["rays_full_bidx_hit"] = bt["rays_full_bidx"]
+        return ret
+
+    def ray_test(self, *a, **k):
+        raise RuntimeError("BatchedLoTDNeuSModel: use batched_ray_test / batched_ray_query")
+
+
+def num_instances_of(model) -> int:
+    return getattr(model, "num_instances", 1)
+
+
+__all__: List[str] = ["BatchedLoTDNeuSModel", "OccGridAccelBatched"]

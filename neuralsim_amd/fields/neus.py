@@ -45,7 +45,9 @@ class _FieldFn(torch.autograd.Function):
     "double backward" of the reference, app/loss/eikonal.py:216-251) is produced analytically by nsim_field_bwd."""
 
     @staticmethod
-    def forward(ctx, model, grid, sdf_w, sdf_b, rad_w, rad_b, h_appear, x, rays_o, rays_d, t, ridx, with_rgb):
+    def forward(ctx, model, grid, sdf_w, sdf_b, rad_w, rad_b, h_appear, x, rays_o, rays_d, t, ridx, with_rgb,
+                goff=None):
+        """goff [R] int64 (batched model only): table offset of every ray's instance; needs ridx."""
         S = x.shape[0] if x is not None else t.shape[0]
         dev = grid.device
         grid16, wpack = model._shadow()
@@ -58,12 +60,13 @@ class _FieldFn(torch.autograd.Function):
         h_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if need_bwd else None
         J_pl = torch.empty([16, S, 2, 3], dtype=torch.float32, device=dev) if need_bwd else None
         _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S, _lib.ptr(sdf), _lib.ptr(nablas),
-                  _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
+                  _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb = model, S, with_rgb
         ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
+        ctx.goff = goff
         ctx.ha_shape = h_appear.shape if h_appear is not None else None
         if with_rgb:
             return sdf, nablas, rgb
@@ -77,7 +80,7 @@ class _FieldFn(torch.autograd.Function):
         dev = grid16.device
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
         need = ctx.needs_input_grad
-        dgrid = torch.zeros([model.encoding.cfg.n_params], dtype=torch.float32, device=dev) if need[1] else None
+        dgrid = torch.zeros([model.encoding.flattened_params.numel()], dtype=torch.float32, device=dev) if need[1] else None
         # one memset for the four small accumulators
         dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], dtype=torch.float32,
                                                      device=dev).split([n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
@@ -100,7 +103,8 @@ class _FieldFn(torch.autograd.Function):
                   _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b))
         if dgrid is not None:   # (3) scatter to the hash grid
             _lib.call("nsim_lotd_scatter", model.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(gn_total), _lib.ptr(dgrid))
+                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
+                      _lib.ptr(gn_total), _lib.ptr(dgrid))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd_sdf", S)
             if dgrid is not None:
@@ -110,7 +114,7 @@ class _FieldFn(torch.autograd.Function):
         if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
             dsdf_w[-64:] /= model.sdf_scale
             dsdf_b[-1:] /= model.sdf_scale
-        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None)
+        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None, None)
 
 
 class _NeusAlphaFn(torch.autograd.Function):
@@ -434,7 +438,7 @@ class LoTDNeuSModel(nn.Module):
         return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
 
     # ------------------------------------------------------------------ point queries
-    def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev) -> torch.Tensor:
+    def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None) -> torch.Tensor:
         """No-grad SDF of S points: level-major gather into feature planes [16][S] (f16x2 | f32x2), then the decoder
         on the planes (csrc/field.hip: k_lotd_gather_lm, k_field_sdf<.., true>).  NSIM_SDF_FUSED=1 selects the single
         fused point-major kernel instead (same values)."""
@@ -446,9 +450,9 @@ class LoTDNeuSModel(nn.Module):
         if not self._sdf_fused:
             planes = torch.empty([16 * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32, device=dev)
             _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(planes))
+                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(planes))
         _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(sdf), _lib.ptr(planes))
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(sdf), _lib.ptr(planes))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_sdf", S)
             if planes is not None:
@@ -465,9 +469,9 @@ class LoTDNeuSModel(nn.Module):
         return sdf.reshape(shape)
 
     @torch.no_grad()
-    def _query_sdf_rays(self, rays_o, rays_d, t, ridx):
+    def _query_sdf_rays(self, rays_o, rays_d, t, ridx, goff=None):
         grid16, wpack = self._shadow()
-        return self._sdf_query(grid16, wpack, None, rays_o, rays_d, t, ridx, t.shape[0], t.device)
+        return self._sdf_query(grid16, wpack, None, rays_o, rays_d, t, ridx, t.shape[0], t.device, goff=goff)
 
     def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
         shape = x.shape[:-1]
@@ -555,7 +559,7 @@ class LoTDNeuSModel(nn.Module):
             c[key] = torch.arange(R, device=dev).repeat_interleave(n)
         return c[key]
 
-    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c):
+    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None):
         """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling."""
         R = o.shape[0]
         dev = o.device
@@ -566,12 +570,12 @@ class LoTDNeuSModel(nn.Module):
         bits, occm = self.accel.occ_bits, self.accel.meta
         counts = torch.empty([R], dtype=torch.long, device=dev)
         _lib.call("nsim_march_count", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
-                  _lib.ptr(bits), occm, step, max_steps, _lib.ptr(counts))
+                  _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(counts))
         pi_m, total = po.get_pack_infos_from_n(counts, return_total=True)
         M = int(total.item())               # host sync #2: size of the marched set
         t_m = torch.empty([max(M, 1)], **f32)
         _lib.call("nsim_march_emit", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
-                  _lib.ptr(bits), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
+                  _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
         t_c = torch.empty([R, C], **f32)
         _lib.call("nsim_coarse_depths", _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter_c), R, C, _lib.ptr(t_c))
         S = M + R * C
@@ -580,7 +584,7 @@ class LoTDNeuSModel(nn.Module):
         ridx = torch.empty([S], dtype=torch.long, device=dev)
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
                   _lib.ptr(pi), _lib.ptr(ridx))
-        sdf = self._query_sdf_rays(o, d, t, ridx)
+        sdf = self._query_sdf_rays(o, d, t, ridx, goff)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
@@ -590,7 +594,7 @@ class LoTDNeuSModel(nn.Module):
             _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
                       _lib.ptr(scratch), _lib.ptr(t_new))
             ridx_new = self._arange_repeat(R, nf, dev)
-            sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new)
+            sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
             S2 = S + R * nf
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
@@ -650,8 +654,10 @@ class LoTDNeuSModel(nn.Module):
         fis = cfg.get("forward_inv_s", None)
         fis = float(fis) if fis else 0.0
         mode = cfg.get("query_mode", self.ray_query_cfg.get("query_mode", "march_occ_multi_upsample"))
+        goff = ray_tested.get("rays_goff", None)           # batched model: per-ray instance offsets (table / occupancy)
+        woff = ray_tested.get("rays_word_off", None)
         with torch.no_grad():
-            t, sdf_ng, pi, ridx, march_counts = self._sample(o, d, near, far, qp, jitter, jitter_c)
+            t, sdf_ng, pi, ridx, march_counts = self._sample(o, d, near, far, qp, jitter, jitter_c, goff, woff)
             if mode.endswith("_compressed"):
                 t, pi, ridx = self._compress(t, sdf_ng, pi, fis, float(qp.get("compress_thre", 1e-4)))
         if t.shape[0] == 0:
@@ -661,7 +667,7 @@ class LoTDNeuSModel(nn.Module):
             return ret
         h_appear = ray_tested.get("rays_h_appear", None)
         outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
-                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb))
+                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb), goff)
         sdf, nablas = outs[0], outs[1]
         rgb = outs[2] if with_rgb else None
         if not qp.get("nablas_has_grad", True):

@@ -67,7 +67,7 @@ def test_march_bit_exact(backend):
         counts = torch.zeros(R, dtype=torch.long, device=backend)
         jp = _lib.ptr(dv(jitter)) if jitter is not None else None
         args = (_lib.ptr(dv(o)), _lib.ptr(dv(d)), _lib.ptr(dv(near)), _lib.ptr(dv(far)), jp, R, _lib.ptr(acc.occ_bits),
-                acc.meta, 0.005, 4096)
+                None, acc.meta, 0.005, 4096)
         _lib.call("nsim_march_count", *args, _lib.ptr(counts))
         assert torch.equal(counts.cpu(), cnt_ref)          # bit-exact sample membership
         assert int(cnt_ref.sum()) > 0
