@@ -147,6 +147,6 @@ def test_batched_point_queries_and_occupancy(backend):
     m.accel.num_pts, m.accel.num_steps = 2 ** 14, 2
     m.init_accel(generator=torch.Generator(device=backend).manual_seed(1))
     fr = m.accel.occ_grid.float().mean(dim=(1, 2, 3)).cpu()
-    assert fr[1] < fr[0] < fr[2] and float(fr.min()) > 0.005, fr
+    assert fr[1] < fr[0] < fr[2] and float(fr.min()) > 0.002, fr
     with pytest.raises(NotImplementedError):
         m.set_condition({"z_ins": torch.zeros(2, 128)})
