@@ -301,3 +301,42 @@ def render_loss(ret: Dict, gt_rgb: torch.Tensor, N: int, w_eikonal: float = 0.1)
     else:
         loss_eik = torch.zeros(())
     return loss_rgb + w_eikonal * loss_eik, dict(loss_rgb=loss_rgb, loss_eikonal=loss_eik)
+
+
+def convert_rays_in_node(rays_o, rays_d, rotation, translation, scale=1.0):
+    """World -> object rays ``R^-1 (o - t) / s``, ``R^-1 d / s`` (app/resources/scenes.py:686-708)."""
+    Rt = rotation.transpose(-1, -2)
+    return ((rays_o - translation).unsqueeze(-2) * Rt).sum(-1) / scale, (rays_d.unsqueeze(-2) * Rt).sum(-1) / scale
+
+
+def compose_buffers(buffers, N: int, depth_use_normalized_vw: bool = True):
+    """Joint rendering of several objects' packed volume buffers (app/renderers/buffer_compose_renderer.py:644-718),
+    restated ray by ray: all samples of a ray, from every object, sorted by depth and composited.
+    ``buffers``: dicts with rays_inds [R], pack_infos [R,2], t [S], alpha [S], rgb [S,3] (several entries of one buffer
+    may name the same ray: batch items).  -> mask [N], depth [N], rgb [N,3], samples per ray [N]."""
+    per_ray = [[] for _ in range(N)]
+    for b in buffers:
+        for k in range(b['rays_inds'].shape[0]):
+            st, n = int(b['pack_infos'][k, 0]), int(b['pack_infos'][k, 1])
+            if n > 0:
+                per_ray[int(b['rays_inds'][k])].append((b['t'][st:st + n], b['alpha'][st:st + n], b['rgb'][st:st + n]))
+    mask, depth, rgb = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+    cnt = torch.zeros(N, dtype=torch.long)
+    masks, depths, rgbs = [], [], []
+    for r in range(N):
+        if not per_ray[r]:
+            masks.append(torch.zeros(())); depths.append(torch.zeros(())); rgbs.append(torch.zeros(3))
+            continue
+        t = torch.cat([c[0] for c in per_ray[r]])
+        a = torch.cat([c[1] for c in per_ray[r]])
+        c = torch.cat([c[2] for c in per_ray[r]])
+        order = torch.sort(t.detach(), stable=True).indices
+        t, a, c = t[order], a[order], c[order]
+        cnt[r] = t.shape[0]
+        trans = torch.cumprod(torch.cat([torch.ones(1), 1.0 - a + 1e-10])[:-1], dim=0)
+        vw = a * trans
+        m = vw.sum()
+        masks.append(m)
+        depths.append(((vw / (m + 1e-10)) * t).sum() if depth_use_normalized_vw else (vw * t).sum())
+        rgbs.append((vw[:, None] * c).sum(0))
+    return torch.stack(masks), torch.stack(depths), torch.stack(rgbs), cnt
