@@ -346,11 +346,15 @@ __device__ __forceinline__ void make_rin(float (&rin)[16], const TilePoint& p, c
 
 template <int PREC>
 __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32], const float (&rin)[16], const char* W,
-                                                const FieldLayout& L, int hi) {
-  dense<PREC, 2, 1>(r1, W + L.mat[M_R1], rin, false);
+                                                const FieldLayout& L, int hi, const char* WM = nullptr,
+                                                const FieldLayout* LMp = nullptr) {
+  // W / L: per-lane vectors; WM / LM: matrix fragments when they live elsewhere (L2 instead of LDS)
+  const char* Wm = WM ? WM : W;
+  const FieldLayout& LM = LMp ? *LMp : L;
+  dense<PREC, 2, 1>(r1, Wm + LM.mat[M_R1], rin, false);
 #pragma unroll
   for (int k = 0; k < 32; ++k) r1[k] = fmaxf(r1[k] + vecf(W, L, V_RB1, hi, k), 0.f);
-  dense<PREC, 2, 2>(r2, W + L.mat[M_R2], r1, false);
+  dense<PREC, 2, 2>(r2, Wm + LM.mat[M_R2], r1, false);
 #pragma unroll
   for (int k = 0; k < 32; ++k) r2[k] = fmaxf(r2[k] + vecf(W, L, V_RB2, hi, k), 0.f);
 }
@@ -364,20 +368,33 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const int wave = (int)(threadIdx.x >> 6);
   const float beta = a.beta, inv_beta = 1.0f / a.beta;
   FieldLayout L;
-  int wbytes;
+  int wbytes = 0;
+  // fp16 backward: every wave owns a private copy of the weight-gradient accumulators in LDS (plain read-add-write;
+  // LDS float atomics cost ~800 cycles per instruction) and reads the weight fragments from L2 instead of LDS to
+  // make room for the four copies; the f32 validation mode keeps one shared accumulator with atomics.
+  constexpr bool PRIV = (MODE == 2 && PREC == 0);
+  // W / L: per-lane vectors (always LDS in fp16 mode); WM / LM: matrix fragments (LDS, or L2 when PRIV)
   // MODE 0 / 2 touch only the SDF decoder (W1, W2, W2T, W1T); MODE 1 also the radiance matrices
-  const char* W = stage_weights<PREC>(smem, a, 0, MODE == 1 ? M_COUNT : 4, L, wbytes);
+  const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (MODE == 1 ? M_COUNT : 4), L, wbytes);
+  const char* WM = PRIV ? a.wpack : W;
+  const FieldLayout LM = PRIV ? a.lay : L;
 
   float* accum = nullptr;
   char* stA = nullptr;
   char* stB = nullptr;
   const AccOff AO = acc_off();
+  constexpr int ACC_BYTES = ((6400 * 4 + 15) & ~15);      // >= AO.total floats, one copy
   if constexpr (MODE == 2) {
-    accum = reinterpret_cast<float*>(smem + wbytes);
-    char* stbase = smem + wbytes + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+    const int ncopies = PRIV ? FIELD_WAVES : 1;
+    accum = reinterpret_cast<float*>(smem + wbytes + (PRIV ? wave * ACC_BYTES : 0));
+    char* stbase = smem + wbytes + ncopies * ACC_BYTES + wave * stage_bytes_per_wave<PREC>();
     stA = stbase;
     stB = stbase + stage_bytes_per_wave<PREC>() / 2;
-    for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+    if constexpr (PRIV) {
+      for (int i = lane; i < AO.total; i += 64) accum[i] = 0.f;
+    } else {
+      for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+    }
     __syncthreads();
   }
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
@@ -473,12 +490,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     }
     // ---------------------------------------------------------------- SDF decoder forward
     float a1[32];
-    dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
+    dense<PREC, 2, 1>(a1, WM + LM.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(W, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];  // last hidden activation (== a1 when SDF_D == 1)
     if constexpr (SDF_D == 2) {
-      dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+      dense<PREC, 2, 2>(a2, WM + LM.mat[M_W2], a1, false);
 #pragma unroll
       for (int k = 0; k < 32; ++k) a2[k] = softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
     } else {
@@ -501,7 +518,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       float d2[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
-      dense<PREC, 2, 2>(e1, W + L.mat[M_W2T], d2, false);
+      dense<PREC, 2, 2>(e1, WM + LM.mat[M_W2T], d2, false);
 #pragma unroll
       for (int k = 0; k < 32; ++k) d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
     } else {
@@ -512,7 +529,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       }
     }
     float g[16];
-    dense<PREC, 1, 2>(g, W + L.mat[M_W1T], d1, false);
+    dense<PREC, 1, 2>(g, WM + LM.mat[M_W1T], d1, false);
     if constexpr (MODE == 1) {
       float nab[3];
 #pragma unroll
@@ -528,7 +545,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         make_rin(rin, p, nab, a.h_appear, hi);
         radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
         float o3[16];
-        dense<PREC, 1, 2>(o3, W + L.mat[M_R3], r2, false);
+        dense<PREC, 1, 2>(o3, WM + LM.mat[M_R3], r2, false);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {  // rows 0..2 live on the hi == 0 half in registers 0..2
           const float v = o3[c] + vecf(W, L, V_RB3, hi, c);
@@ -561,9 +578,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
       for (int f = 0; f < 16; ++f) gh[f] = J[f][0] * gn[0] + J[f][1] * gn[1] + J[f][2] * gn[2];
       float dh1[32];  // dL / d d1  = W1 . gh
-      dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
+      dense<PREC, 2, 1>(dh1, WM + LM.mat[M_W1], gh, true);
       const bool do_dw = !(a.ablate & 4);
-      if (do_dw) dw_product<PREC, 2, 1>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
+      if (do_dw) dw_product<PREC, 2, 1, PRIV>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
       float dz1[32];
       float whv[32];  // vector-shaped gradient of the SDF head weights
       if constexpr (SDF_D == 2) {
@@ -577,9 +594,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         float d2[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
-        if (do_dw) dw_product<PREC, 2, 2>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
+        if (do_dw) dw_product<PREC, 2, 2, PRIV>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
         float dh2[32];  // dL / d d2 = W2 . eh1
-        dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
+        dense<PREC, 2, 2>(dh2, WM + LM.mat[M_W2], eh1, true);
         float dz2[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
@@ -588,9 +605,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           whv[k] = dh2[k] * s2 + gs * a2[k];
           dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
         }
-        if (do_dw) dw_product<PREC, 2, 2>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
+        if (do_dw) dw_product<PREC, 2, 2, PRIV>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
         float da1[32];
-        dense<PREC, 2, 2>(da1, W + L.mat[M_W2T], dz2, true);
+        dense<PREC, 2, 2>(da1, WM + LM.mat[M_W2T], dz2, true);
 #pragma unroll
         for (int k = 0; k < 32; ++k) dz1[k] = dz1[k] + da1[k] * sig_from_softplus(a1[k], beta);
       } else {
@@ -602,15 +619,18 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           dz1[k] = gs * wh * s1 + dh1[k] * wh * (beta * s1 * (1.0f - s1));
         }
       }
-      if (do_dw) rowsum_acc<PREC, 2>(stA, whv, accum + AO.wh, 64);
+      if (do_dw) rowsum_acc<PREC, 2, PRIV>(stA, whv, accum + AO.wh, 64);
       {
         float v = (hi == 0) ? gs : 0.f;
         v = wave_sum(v);
-        if (lane == 0 && v != 0.f) atomicAdd(&accum[AO.bh], v);
+        if (lane == 0 && v != 0.f) {
+          if constexpr (PRIV) accum[AO.bh] = accum[AO.bh] + v;
+          else atomicAdd(&accum[AO.bh], v);
+        }
       }
-      if (do_dw) dw_product<PREC, 2, 1>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
+      if (do_dw) dw_product<PREC, 2, 1, PRIV>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
       float dh[16];
-      dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
+      dense<PREC, 1, 2>(dh, WM + LM.mat[M_W1T], dz1, true);
       // ------------------------------------------------------------ hand-off to the scatter kernel
       // dL/dh and g = d sdf/d h as level-major planes + the total dL/dnablas per sample; k_lotd_scatter turns
       // them into grid gradients at full occupancy (it is bound by the atomic unit, not by this kernel's MFMA chain)
@@ -637,7 +657,15 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     __syncthreads();
     const SrcOff so = src_off(SDF_D);
     for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
-      const float v = accum[i];
+      float v;
+      if constexpr (PRIV) {      // sum the four private copies
+        const float* a0 = reinterpret_cast<const float*>(smem + wbytes);
+        v = 0.f;
+#pragma unroll
+        for (int w = 0; w < FIELD_WAVES; ++w) v += a0[w * (ACC_BYTES / 4) + i];
+      } else {
+        v = accum[i];
+      }
       if (v == 0.f) continue;
       float* dst = nullptr;
       if (i < AO.w2) dst = a.dsdf_w + so.w1 + (i - AO.w1);
@@ -884,7 +912,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 // Backward of the radiance branch: given dL/drgb, the saved forward nablas / rgb -> gradients of the radiance
 // weights, of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].
 // No grid access at all: per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
-#define RAD_WAVES 8
+#define RAD_WAVES 4
 template <int PREC>
 __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
@@ -892,12 +920,21 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
   const int wave = (int)(threadIdx.x >> 6);
   FieldLayout L;
   int wbytes;
-  const char* W = stage_weights<PREC>(smem, a, M_R1, 6, L, wbytes);
+  // fp16: private per-wave accumulators (plain LDS read-add-write, see mfma_mlp.h:dw_flush), matrices from L2
+  constexpr bool PRIV = (PREC == 0);
+  constexpr int ACC_BYTES = ((6144 * 4 + 15) & ~15);      // >= RadAccOff.total floats
+  const char* W = stage_weights<PREC>(smem, a, M_R1, PRIV ? 0 : 6, L, wbytes);
+  const char* WM = PRIV ? a.wpack : W;
+  const FieldLayout LM = PRIV ? a.lay : L;
   const RadAccOff AO = rad_acc_off();
-  float* accum = reinterpret_cast<float*>(smem + wbytes);
-  char* stA = smem + wbytes + ((AO.total * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+  float* accum = reinterpret_cast<float*>(smem + wbytes + (PRIV ? wave * ACC_BYTES : 0));
+  char* stA = smem + wbytes + (PRIV ? RAD_WAVES : 1) * ACC_BYTES + wave * stage_bytes_per_wave<PREC>();
   char* stB = stA + stage_bytes_per_wave<PREC>() / 2;
-  for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+  if constexpr (PRIV) {
+    for (int i = lane; i < AO.total; i += 64) accum[i] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
+  }
   __syncthreads();
 
   const int64_t ntiles = (a.S + 31) / 32;
@@ -917,7 +954,7 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
     }
     float rin[16], r1[32], r2[32];
     make_rin(rin, p, nab, a.h_appear, hi);
-    radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
+    radiance_hidden<PREC>(r1, r2, rin, W, L, hi, WM, &LM);
     float dout[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dout[r] = 0.f;
@@ -925,19 +962,19 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
     }
-    dw_product<PREC, 1, 2>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
+    dw_product<PREC, 1, 2, PRIV>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
     float dr2[32];
-    dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
+    dense<PREC, 2, 1>(dr2, WM + LM.mat[M_R3T], dout, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
-    dw_product<PREC, 2, 2>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
+    dw_product<PREC, 2, 2, PRIV>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
     float dr1[32];
-    dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
+    dense<PREC, 2, 2>(dr1, WM + LM.mat[M_R2T], dr2, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
-    dw_product<PREC, 2, 1>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
+    dw_product<PREC, 2, 1, PRIV>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
     float din[16];
-    dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
+    dense<PREC, 1, 2>(din, WM + LM.mat[M_R1T], dr1, true);
     // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
     const float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
     gn[0] += v0 + wave_shfl_xor(v0, 32);
@@ -961,7 +998,15 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
   __syncthreads();
   const SrcOff so = src_off(1);
   for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
-    const float v = accum[i];
+    float v;
+    if constexpr (PRIV) {
+      const float* a0 = reinterpret_cast<const float*>(smem + wbytes);
+      v = 0.f;
+#pragma unroll
+      for (int w = 0; w < RAD_WAVES; ++w) v += a0[w * (ACC_BYTES / 4) + i];
+    } else {
+      v = accum[i];
+    }
     if (v == 0.f) continue;
     float* dst = nullptr;
     if (i < AO.r2) dst = a.drad_w + so.r1 + (i - AO.r1);
@@ -1165,7 +1210,7 @@ static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t sh
 
 // persistent grids: the packed weights (58 KB) are staged into LDS once per workgroup
 #define FIELD_GRID_FWD 1024
-#define FIELD_GRID_BWD 512
+#define FIELD_GRID_BWD 256      // one resident workgroup per CU (LDS-limited): persistent waves amortise the accumulator flush
 
 extern "C" {
 
@@ -1319,7 +1364,10 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
   a.has_rgb = 1;
   const RadAccOff RO = rad_acc_off();
-  const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + ((RO.total * 4 + 15) & ~15) + RAD_WAVES * stage_bytes(meta);
+  const size_t racc = (6144 * 4 + 15) & ~15;
+  const size_t shmem = meta->precision == 0
+                           ? weights_lds_bytes(meta, M_R1, 0) + RAD_WAVES * racc + RAD_WAVES * stage_bytes(meta)
+                           : weights_lds_bytes(meta, M_R1, 6) + racc + RAD_WAVES * stage_bytes(meta);
   const int64_t tiles = (S + 31) / 32;
   int64_t nb = (tiles + RAD_WAVES - 1) / RAD_WAVES;
   nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
@@ -1348,7 +1396,10 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
   a.ablate = bwd_ablate();
   const AccOff AO = acc_off();
-  const size_t shmem = weights_lds_bytes(meta, 0, 4) + ((AO.total * 4 + 15) & ~15) + FIELD_WAVES * stage_bytes(meta);
+  // fp16: four private accumulator copies + staging, weights from L2; f32: staged weights + one shared accumulator
+  const size_t acc_bytes = (6400 * 4 + 15) & ~15;
+  const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + FIELD_WAVES * acc_bytes + FIELD_WAVES * stage_bytes(meta)
+                                            : weights_lds_bytes(meta, 0, 4) + acc_bytes + FIELD_WAVES * stage_bytes(meta);
   return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
 }
 

@@ -154,20 +154,38 @@ __device__ __forceinline__ f32x16 dw_tile(const void* stA, int mo, const void* s
   return acc;
 }
 
-// accumulate a dW tile into the workgroup accumulator: dst[(32mo+row)*ld + 32no + col]
+// accumulate a dW tile into an LDS accumulator: dst[(32mo+row)*ld + 32no + col].
+// PRIV = the accumulator belongs to THIS wave alone -> plain read-add-write.  Measured on MI355X: ds_add_f32 costs
+// ~800 cycles per wave instruction (the 192 LDS float atomics per 32-point tile were 80 % of the SDF-branch backward),
+// a ds_read / v_add / ds_write triple a few tens.  PRIV = false keeps the shared accumulator + atomics (f32 test mode).
+template <bool PRIV = false>
 __device__ __forceinline__ void dw_flush(float* dst, int ld, int rows, int cols, int mo, int no, const f32x16& acc,
                                          float unscale) {
   const int lane = nsim_lane(), col = 32 * no + (lane & 31), hi = lane >> 5;
   if (col >= cols) return;
+  if constexpr (PRIV) {
+    float cur[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = 32 * mo + mfma_row(r, hi);
-    if (row < rows) atomicAdd(&dst[row * ld + col], acc[r] * unscale);
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * mo + mfma_row(r, hi);
+      cur[r] = row < rows ? dst[row * ld + col] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * mo + mfma_row(r, hi);
+      if (row < rows) dst[row * ld + col] = cur[r] + acc[r] * unscale;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * mo + mfma_row(r, hi);
+      if (row < rows) atomicAdd(&dst[row * ld + col], acc[r] * unscale);
+    }
   }
 }
 
 // dW[rows x cols] += A (NMA m-tiles) (x) B (NMB m-tiles) over the tile's points; db[rows] += rowsum(A)
-template <int PREC, int NMA, int NMB>
+template <int PREC, int NMA, int NMB, bool PRIV = false>
 __device__ __forceinline__ void dw_product(void* stA, void* stB, const float (&A)[NMA * 16], const float (&B)[NMB * 16],
                                            float* dW, int ld, int rows, int cols, float* db) {
   const float sa = dyn_scale<PREC, NMA * 16>(A), sb = dyn_scale<PREC, NMB * 16>(B);
@@ -181,7 +199,7 @@ __device__ __forceinline__ void dw_product(void* stA, void* stB, const float (&A
 #pragma unroll
     for (int no = 0; no < NMB; ++no) {
       const f32x16 acc = dw_tile<PREC>(stA, mo, stB, no);
-      dw_flush(dW, ld, rows, cols, mo, no, acc, un);
+      dw_flush<PRIV>(dW, ld, rows, cols, mo, no, acc, un);
     }
   if (db) {
     typedef typename StageT<PREC>::T T;
@@ -190,13 +208,14 @@ __device__ __forceinline__ void dw_product(void* stA, void* stB, const float (&A
     if (lane < NMA * 32 && lane < rows) {
       float s = 0.f;
       for (int j = 0; j < 32; ++j) s += (float)a[lane * StageT<PREC>::PITCH + j];
-      atomicAdd(&db[lane], s / sa);
+      if constexpr (PRIV) db[lane] = db[lane] + s / sa;
+      else atomicAdd(&db[lane], s / sa);
     }
   }
 }
 
 // row sums of an activation (for vector-shaped gradients such as the SDF head weights)
-template <int PREC, int NM>
+template <int PREC, int NM, bool PRIV = false>
 __device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16], float* dst, int rows) {
   const float sa = dyn_scale<PREC, NM * 16>(A);
   wave_sync_lds();
@@ -208,7 +227,8 @@ __device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16],
   if (lane < NM * 32 && lane < rows) {
     float s = 0.f;
     for (int j = 0; j < 32; ++j) s += (float)a[lane * StageT<PREC>::PITCH + j];
-    atomicAdd(&dst[lane], s / sa);
+    if constexpr (PRIV) dst[lane] = dst[lane] + s / sa;
+    else atomicAdd(&dst[lane], s / sa);
   }
 }
 
