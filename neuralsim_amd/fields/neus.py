@@ -46,10 +46,26 @@ class _FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, grid, sdf_w, sdf_b, rad_w, rad_b, h_appear, x, rays_o, rays_d, t, ridx, with_rgb,
-                goff=None):
-        """goff [R] int64 (batched model only): table offset of every ray's instance; needs ridx."""
-        S = x.shape[0] if x is not None else t.shape[0]
+                goff=None, extra_x=None):
+        """goff [R] int64 (batched model only): table offset of every ray's instance; needs ridx.
+        extra_x [M,3] (ray mode only): additional free points evaluated by the SAME launches (appended as M
+        zero-length rays); their sdf / nablas come back as two extra outputs.  The trainer uses it for the uniform
+        eikonal points (code_single/tools/train.py:602-613): a separate 4096-point launch chain costs ~0.2 ms of
+        fixed per-launch latency."""
         dev = grid.device
+        M = 0
+        if extra_x is not None:
+            assert x is None and goff is None, "extra points ride on a ray-mode query of a single-instance model"
+            R, M = rays_o.shape[0], extra_x.shape[0]
+            xe = extra_x.detach().float().reshape(-1, 3)
+            ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
+            ez[:, 2] = 1.0
+            rays_o, rays_d = torch.cat([rays_o, xe]), torch.cat([rays_d, ez])
+            t = torch.cat([t, ez[:, 0]])
+            ridx = torch.cat([ridx, torch.arange(R, R + M, device=dev)])
+            if h_appear is not None:
+                h_appear = torch.cat([h_appear.detach().float(), ez.new_zeros([M, h_appear.shape[1]])])
+        S = x.shape[0] if x is not None else t.shape[0]
         grid16, wpack = model._shadow()
         sdf = torch.empty([S], dtype=torch.float32, device=dev)
         nablas = torch.empty([S, 3], dtype=torch.float32, device=dev)
@@ -64,20 +80,38 @@ class _FieldFn(torch.autograd.Function):
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
-        ctx.model, ctx.S, ctx.with_rgb = model, S, with_rgb
+        ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
         ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
         ctx.goff = goff
-        ctx.ha_shape = h_appear.shape if h_appear is not None else None
-        if with_rgb:
-            return sdf, nablas, rgb
-        return sdf, nablas
+        ctx.ha_shape = ha.shape if ha is not None else None
+        if M == 0:
+            return (sdf, nablas, rgb) if with_rgb else (sdf, nablas)
+        Sm = S - M
+        outs = (sdf[:Sm], nablas[:Sm]) + ((rgb[:Sm],) if with_rgb else ()) + (sdf[Sm:], nablas[Sm:])
+        return outs
 
     @staticmethod
-    def backward(ctx, g_sdf, g_nab, g_rgb=None):
+    def backward(ctx, *grads):
         model = ctx.model
         x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd, h_pl, J_pl = ctx.geom
+        S, M = ctx.S, ctx.M
+        dev = nab_fwd.device
+        g_sdf, g_nab = grads[0], grads[1]
+        g_rgb = grads[2] if ctx.with_rgb else None
+        if M > 0:       # re-join the gradients of the main samples and of the extra points
+            Sm = S - M
+            ge_s, ge_n = grads[-2], grads[-1]
+
+            def join(a, b, tail):
+                if a is None and b is None:
+                    return None
+                a = a.float() if a is not None else torch.zeros([Sm, *tail], dtype=torch.float32, device=dev)
+                b = b.float() if b is not None else torch.zeros([M, *tail], dtype=torch.float32, device=dev)
+                return torch.cat([a, b])
+            g_sdf, g_nab = join(g_sdf, ge_s, ()), join(g_nab, ge_n, (3,))
+            if g_rgb is not None:
+                g_rgb = join(g_rgb, None, (3,))
         grid16, wpack = model._shadow()
-        dev = grid16.device
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
         need = ctx.needs_input_grad
         dgrid = torch.zeros([model.encoding.flattened_params.numel()], dtype=torch.float32, device=dev) if need[1] else None
@@ -88,7 +122,6 @@ class _FieldFn(torch.autograd.Function):
         gs = g_sdf.float().contiguous() if g_sdf is not None else None
         gn = g_nab.float().contiguous() if g_nab is not None else None
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
-        S = ctx.S
         fm = model.field_meta
         gn_total = gn
         if gr is not None:      # (1) radiance branch: weight grads + total gradient w.r.t. the normals
@@ -114,7 +147,9 @@ class _FieldFn(torch.autograd.Function):
         if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
             dsdf_w[-64:] /= model.sdf_scale
             dsdf_b[-1:] /= model.sdf_scale
-        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None, None)
+        if dha is not None and M > 0:
+            dha = dha[:dha.shape[0] - M]
+        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None, None, None)
 
 
 class _NeusAlphaFn(torch.autograd.Function):
@@ -666,10 +701,13 @@ class LoTDNeuSModel(nn.Module):
                 ret["details"] = dict(march_counts=march_counts)
             return ret
         h_appear = ray_tested.get("rays_h_appear", None)
+        extra_x = cfg.get("_extra_pts", None)              # trainer hook: free points riding on the same launches
         outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
-                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb), goff)
+                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb), goff, extra_x)
         sdf, nablas = outs[0], outs[1]
         rgb = outs[2] if with_rgb else None
+        if extra_x is not None:
+            ret["extra_pts"] = dict(sdf=outs[-2], nablas=outs[-1], net_x=extra_x)
         if not qp.get("nablas_has_grad", True):
             nablas = nablas.detach()
         alpha = _NeusAlphaFn.apply(sdf, self.ln_inv_s, pi, self.ln_inv_s_factor, fis)

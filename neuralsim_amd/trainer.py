@@ -61,14 +61,20 @@ class RenderTrainer:
         gt = torch.rand([N, 3], device=dev, generator=self.gen)
         return xy, fidx, gt
 
-    def render(self, xy, fidx, with_normal=True):
-        """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration)."""
+    def render(self, xy, fidx, with_normal=True, extra_pts=None):
+        """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration).
+        ``extra_pts`` [M,3]: free points evaluated by the same field launches (``_FieldFn`` extra_x)."""
         rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
         h_appear = embedding_lookup(self.appear, fidx)
         ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
                                    return_buffer=True, return_details=True, distant_model=self.distant_model,
-                                   sky_model=self.sky_model)
+                                   sky_model=self.sky_model,
+                                   bypass_ray_query_cfg=dict(_extra_pts=extra_pts) if extra_pts is not None else None)
         return ret
+
+    def sample_uniform_x(self) -> torch.Tensor:
+        lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
+        return lo + torch.rand([self.num_uniform, 3], device=self.model.device, generator=self.gen) * (hi - lo)
 
     def loss(self, ret, gt, uni=None):
         """photometric mse on all rays + eikonal on the close-range render samples and on uniform points."""
@@ -78,6 +84,8 @@ class RenderTrainer:
         if cr_vb["type"] != "empty":
             eik = eikonal_loss(cr_vb["nablas"])
         if self.num_uniform > 0:
+            if uni is None:
+                uni = ret["raw_per_obj_model"]["main"].get("extra_pts")      # rode on the render launches
             if uni is None:
                 uni = self.model.sample_pts_uniform(self.num_uniform, generator=self.gen)
             e2 = eikonal_loss(uni["nablas"])
@@ -95,10 +103,13 @@ class RenderTrainer:
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         xy, fidx, gt = self.sample_batch()
-        # the uniform-point branch has a static shape and no dependence on the rays: issued first, its launches hide
-        # behind the device draining the previous step (ray_test's compaction is the first host sync of the step)
-        uni = model.sample_pts_uniform(self.num_uniform, generator=self.gen) if self.num_uniform > 0 else None
-        ret = self.render(xy, fidx)
+        # the uniform eikonal points (train.py:602-613) ride on the render's field launches as zero-length rays: a
+        # separate 4096-point launch chain costs ~0.2 ms of fixed latency (fwd + two backward kernels + scatter)
+        x_uni = self.sample_uniform_x() if self.num_uniform > 0 else None
+        ret = self.render(xy, fidx, extra_pts=x_uni)
+        uni = None
+        if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
+            uni = model.forward_sdf_nablas(x_uni)
         loss, parts = self.loss(ret, gt, uni)
         self.optim.zero_grad()
         loss.backward()

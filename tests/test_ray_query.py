@@ -114,3 +114,40 @@ def test_ray_query_empty_and_no_perturb(backend):
     vb = ret["volume_buffer"]
     again = volume_integration(vb["opacity_alpha"], vb["t"], vb["rgb"], None, vb["pack_infos_hit"], True)
     assert torch.allclose(again["rgb_volume"], ret["rendered"]["rgb_volume"])
+
+
+def test_extra_points_ride_on_the_render_launches(backend):
+    """``_extra_pts`` (the trainer's uniform eikonal points appended as zero-length rays): identical samples, identical
+    values, and the gradient equals the sum of the two separate evaluations."""
+    p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "f32", N=32)
+    dv = lambda a: a.to(backend).contiguous()
+    x = (torch.rand(100, 3, generator=g) * 1.6 - 0.8)
+
+    def run(extra):
+        for prm in (model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w, model.rad_b, model.ln_inv_s):
+            prm.grad = None
+        ha = leaf(h_appear, backend)
+        tested = model.ray_test(dv(o), dv(d), near=0.01, far=None, rays_h_appear=ha)
+        ri = tested["rays_inds"].cpu()
+        cfg = dict(query_param=QP, with_rgb=True, with_normal=True, depth_use_normalized_vw=False, _render=True,
+                   _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]), query_mode="march_occ_multi_upsample")
+        if extra:
+            cfg["_extra_pts"] = dv(x)
+        ret = model.ray_query(ray_tested=tested, config=cfg)
+        uni = ret["extra_pts"] if extra else model.forward_sdf_nablas(dv(x))
+        loss = ret["rendered"]["rgb_volume"].sum() + 0.1 * ((ret["volume_buffer"]["nablas"].norm(dim=-1) - 1) ** 2).mean() \
+            + 0.3 * ((uni["nablas"].norm(dim=-1) - 1) ** 2).mean() + 0.05 * uni["sdf"].sum()
+        loss.backward()
+        grads = [prm.grad.detach().cpu().clone() for prm in (model.encoding.flattened_params, model.sdf_w, model.sdf_b,
+                                                             model.rad_w, model.rad_b, model.ln_inv_s)] + [ha.grad.cpu()]
+        return ret, uni, float(loss), grads
+
+    ret_a, uni_a, loss_a, g_a = run(False)
+    ret_b, uni_b, loss_b, g_b = run(True)
+    assert torch.equal(ret_a["volume_buffer"]["t"], ret_b["volume_buffer"]["t"])
+    assert torch.equal(ret_a["volume_buffer"]["sdf"], ret_b["volume_buffer"]["sdf"])
+    assert ret_b["volume_buffer"]["rgb"].shape == ret_a["volume_buffer"]["rgb"].shape
+    assert torch.allclose(uni_a["sdf"], uni_b["sdf"], atol=1e-6) and torch.allclose(uni_a["nablas"], uni_b["nablas"], atol=1e-5)
+    assert abs(loss_a - loss_b) < 1e-4 * abs(loss_a)
+    for ga, gb in zip(g_a, g_b):
+        assert rel_l2(gb, ga) < 1e-4
