@@ -57,8 +57,12 @@ const char* nsim_strerror(int code);
 int nsim_version(void);
 
 /* ---------------------------------------------------------------- pack ops (graphics.pack_ops) */
-/* get_pack_infos_from_n(n) ; total (device int64[1], may be NULL) receives sum(n). */
-int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, void* stream);
+/* get_pack_infos_from_n(n) ; total (device int64[1], may be NULL) receives sum(n).
+ * cap < 0: plain.  cap >= 0: the caller sized its sample buffers for cap elements WITHOUT knowing sum(n); a pack
+ * that would end beyond cap gets count 0 (its start is kept), so consumers stay in bounds; total still receives the
+ * true sum and the caller redoes the pass when it later reads total > cap. */
+int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
+                           void* stream);
 /* packed_sum(x [S,C], pack_infos) -> out [P,C]   (single_volume_renderer.py:84-101) */
 int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream);
 /* out[s,c] = x[s,c] (op) per_pack[p, c or 0]; op 0 mul, 1 div, 2 add, 3 sub; x may be NULL (treated as 1 for
@@ -190,16 +194,20 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
  * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]].
  * feat_planes == NULL: one fused point-major kernel (gather + decoder).
  * feat_planes != NULL: decoder only, on the level-major feature planes written by nsim_lotd_gather_lm for the same
- * points (x / rays / grid are then unused and may be NULL).  Same values either way. */
+ * points (x / rays / grid are then unused and may be NULL).  Same values either way.
+ * Speculatively sized buffers (level-major path): S is the CAPACITY (and the plane pitch); when n_dev != NULL the
+ * number of valid points is min(S, *n_dev + n_add), read on the device -- the host never learns the size of the
+ * marched sample set before launching its first query (one host sync less per step). */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const int64_t* ray_goff, int64_t S, float* sdf, const void* feat_planes, void* stream);
+                   const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
+                   const void* feat_planes, void* stream);
 /* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [16][S] of
  * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
  * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
-                        void* feat_planes, void* stream);
+                        const int64_t* n_dev, int64_t n_add, void* feat_planes, void* stream);
 /* Batched / multi-instance models (``batched_ray_query`` + ``set_condition``,
  * app/renderers/buffer_compose_renderer.py:222-265, app/models/shared/batched_neus.py:380-407): the tables of all
  * instances live in ONE flat tensor and ``ray_goff[r]`` (may be NULL) is the offset, in scalars (even), of ray r's

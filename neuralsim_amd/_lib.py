@@ -50,7 +50,7 @@ _F = C.c_float
 
 # name -> argtypes (every function additionally takes the trailing ``void* stream`` unless listed in _NOSTREAM)
 SIGNATURES = {
-    "nsim_pack_infos_from_n": [_P, _I64, _P, _P],
+    "nsim_pack_infos_from_n": [_P, _I64, _P, _P, _I64],
     "nsim_packed_sum": [_P, _I, _P, _I64, _P],
     "nsim_packed_binary": [_P, _I, _P, _I, _P, _I64, _I, _P],
     "nsim_packed_cmp": [_P, _P, _P, _I64, _I, _P],
@@ -79,8 +79,8 @@ SIGNATURES = {
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],
     "nsim_lotd_bwd": [_P, _P, _P, C.POINTER(LotdMeta), _I64, _P],
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
-    "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P],
-    "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P],
+    "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
@@ -151,27 +151,13 @@ def require_device(t: torch.Tensor, name: str = "tensor"):
         raise RuntimeError(f"neuralsim_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
 
 
-class TensorArg:
-    """A device pointer that keeps its tensor alive for as long as the argument tuple of the C call lives.
-    (A bare ``c_void_p(t.data_ptr())`` of a temporary such as ``g.contiguous()`` would let the caching allocator
-    hand the same block to the next temporary of the same argument list.)"""
-    __slots__ = ("_as_parameter_", "ref")
-
-    def __init__(self, t):
-        self.ref = t
-        self._as_parameter_ = C.c_void_p(t.data_ptr())
-
-
 def ptr(t, dtype=None, name="tensor"):
-    """Device pointer argument of a contiguous tensor (None -> NULL)."""
-    if t is None:
-        return None
-    require_device(t, name)
-    if dtype is not None and t.dtype != dtype:
+    """Marks a tensor argument of a C call (None -> NULL).  The tensor itself travels to ``call`` -- which turns it into
+    its device pointer -- so the argument tuple keeps every temporary (``g.contiguous()`` ...) alive for the duration of
+    the launch; a bare ``data_ptr()`` of a temporary would let the caching allocator hand the block to the next one."""
+    if t is not None and dtype is not None and t.dtype != dtype:
         raise TypeError(f"neuralsim_amd: {name} must be {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise ValueError(f"neuralsim_amd: {name} must be contiguous")
-    return TensorArg(t)
+    return t
 
 
 class KernelTimer:
@@ -198,17 +184,35 @@ class KernelTimer:
 TIMER = None   # set to a KernelTimer() to record events around the calls named in TIMER.only (all if None)
 
 
+_Tensor = torch.Tensor
+
+
+def _marshal(args):
+    out = []
+    for a in args:
+        if isinstance(a, _Tensor):
+            require_device(a)
+            if not a.is_contiguous():
+                raise ValueError("neuralsim_amd: tensor arguments must be contiguous")
+            out.append(a.data_ptr())
+        else:
+            out.append(a)
+    return out
+
+
 def call(name: str, *args):
-    """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code."""
+    """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code.  Tensor arguments are
+    passed as their device pointers (checked: device-resident, contiguous)."""
     lib = get_lib()
+    cargs = _marshal(args)
     if TIMER is not None and (TIMER.only is None or name in TIMER.only):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
+        rc = getattr(lib, name)(*cargs, stream_handle())
         e1.record()
         TIMER.events.setdefault(name, []).append((e0, e1))
     else:
-        rc = getattr(lib, name)(*args, C.c_void_p(stream_handle()))
+        rc = getattr(lib, name)(*cargs, stream_handle())
     if rc != 0:
         msg = lib.nsim_strerror(rc)
         raise RuntimeError(f"{name} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -207,6 +207,8 @@ struct FieldArgs {
   const int64_t* ray_goff;                         // batched model: table offset (in scalars, even) of ray r's instance
   const float* h_appear;
   int64_t S;
+  const int64_t* S_dev;                            // no-grad query with speculatively sized buffers: the number of valid
+  int64_t S_add;                                   // points is min(S, *S_dev + S_add); S stays the plane pitch
   float *sdf, *nablas, *rgb;                       // forward outputs
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
@@ -702,6 +704,11 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   const int lane = nsim_lane();
   const int xcd = (int)(blockIdx.x & 7u);
   const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * GLM_PTS) + lane;
+  int64_t Sv = a.S;                                 // valid points (<= capacity a.S)
+  if (a.S_dev) {
+    const int64_t sd = a.S_dev[0] + a.S_add;
+    Sv = sd < Sv ? sd : Sv;
+  }
   float xx[GLM_PTS][3];
   uint32_t goff[GLM_PTS];
 #pragma unroll
@@ -709,7 +716,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     const int64_t s = s0 + 64 * q;
     xx[q][0] = xx[q][1] = xx[q][2] = 0.f;
     goff[q] = 0u;
-    if (s < a.S) {
+    if (s < Sv) {
       if (a.ray_goff) goff[q] = (uint32_t)a.ray_goff[a.ridx[s]];
       if (a.x) {
         xx[q][0] = a.x[3 * s]; xx[q][1] = a.x[3 * s + 1]; xx[q][2] = a.x[3 * s + 2];
@@ -750,7 +757,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 #pragma unroll
     for (int q = 0; q < GLM_PTS; ++q) {
       const int64_t s = s0 + 64 * q;
-      if (s < a.S) {
+      if (s < Sv) {
         const int64_t e = (int64_t)l * a.S + s;
         if constexpr (PREC == 0) {
           union {
@@ -780,13 +787,18 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
   const char* W = stage_weights<PREC>(smem, a, 0, 2, L, wbytes);   // W1, W2 only
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
   const GridRef gref = grid_ref(a.grid);
-  const int64_t ntiles = (a.S + 31) / 32;
+  int64_t Sv = a.S;
+  if (a.S_dev) {
+    const int64_t sd = a.S_dev[0] + a.S_add;
+    Sv = sd < Sv ? sd : Sv;
+  }
+  const int64_t ntiles = (Sv + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
     TilePoint p;
     if constexpr (PLANES) {
       p.s = tile * 32 + j;
-      p.valid = p.s < a.S;
+      p.valid = p.s < Sv;
     } else {
       p = load_point(a, tile, j, false);
     }
@@ -1240,7 +1252,7 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
-                        void* feat_planes, void* stream) {
+                        const int64_t* n_dev, int64_t n_add, void* feat_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -1252,6 +1264,8 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.ray_goff = ray_goff;
   a.S = S;
+  a.S_dev = n_dev;
+  a.S_add = n_add;
   a.feat_pl = feat_planes;
   // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
   int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1277,7 +1291,8 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
 
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
-                   const int64_t* ray_goff, int64_t S, float* sdf, const void* feat_planes, void* stream) {
+                   const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
+                   const void* feat_planes, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -1289,6 +1304,8 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.ray_goff = ray_goff;
+  a.S_dev = feat_planes ? n_dev : nullptr;   // the speculative size applies to the level-major path only
+  a.S_add = n_add;
   a.S = S;
   a.sdf = sdf;
   a.feat_pl = feat_scratch;

@@ -18,7 +18,7 @@ static inline dim3 pack_grid(int64_t P) { return dim3(nsim_blocks(P, PACK_WAVES_
 // ------------------------------------------------------------------------------ pack_infos_from_n
 __global__ void __launch_bounds__(256) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
                                                              int64_t* __restrict__ pi,
-                                                             int64_t* __restrict__ total) {
+                                                             int64_t* __restrict__ total, int64_t cap) {
   __shared__ int64_t sums[256];
   const int tid = threadIdx.x;
   const int64_t chunk = (P + 255) / 256;
@@ -41,7 +41,9 @@ __global__ void __launch_bounds__(256) k_pack_infos_from_n(const int64_t* __rest
   for (int64_t i = b; i < e; ++i) {
     int64_t v = n[i];
     pi[2 * i] = run;
-    pi[2 * i + 1] = v;
+    // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied so that
+    // every consumer stays in bounds (the caller sees total > cap at its next sync and redoes the pass)
+    pi[2 * i + 1] = (cap >= 0 && run + v > cap) ? 0 : v;
     run += v;
   }
 }
@@ -469,9 +471,10 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
 // ================================================================================== C ABI
 extern "C" {
 
-int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, void* stream) {
+int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
+                           void* stream) {
   if (P < 0) return 2;
-  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(256), 0, (hipStream_t)stream, n, P, pack_infos, total);
+  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(256), 0, (hipStream_t)stream, n, P, pack_infos, total, cap);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_march_emit(
   if (r >= R) return;
   const int lane = nsim_lane();
   if (ray_word_off) bits += ray_word_off[r];
+  if (pi[2 * r + 1] == 0) return;      // nothing to emit (or a pack emptied by a speculative capacity, pack_ops.hip)
   const MarchRay m = march_load(rays_o, rays_d, near, far, jitter, r, step, max_steps);
   const int64_t st = pi[2 * r];
   int cnt = 0;

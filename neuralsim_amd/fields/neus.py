@@ -375,6 +375,8 @@ class LoTDNeuSModel(nn.Module):
         self.field_meta = fm
         self._wpack = None
         self._sdf_fused = os.environ.get("NSIM_SDF_FUSED", "0") == "1"
+        # size the sampling buffers from the previous step's density instead of reading the marched total back
+        self._speculate = os.environ.get("NSIM_SPECULATE", "1") == "1" and not self._sdf_fused
         self._wpack_versions = None
         if device is not None:
             self.to(device)
@@ -473,7 +475,8 @@ class LoTDNeuSModel(nn.Module):
         return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
 
     # ------------------------------------------------------------------ point queries
-    def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None) -> torch.Tensor:
+    def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None, n_dev=None,
+                   n_add: int = 0) -> torch.Tensor:
         """No-grad SDF of S points: level-major gather into feature planes [16][S] (f16x2 | f32x2), then the decoder
         on the planes (csrc/field.hip: k_lotd_gather_lm, k_field_sdf<.., true>).  NSIM_SDF_FUSED=1 selects the single
         fused point-major kernel instead (same values)."""
@@ -485,10 +488,11 @@ class LoTDNeuSModel(nn.Module):
         if not self._sdf_fused:
             planes = torch.empty([16 * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32, device=dev)
             _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(planes))
+                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
         _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(sdf), _lib.ptr(planes))
-        if _lib.TIMER is not None:
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add),
+                  _lib.ptr(sdf), _lib.ptr(planes))
+        if _lib.TIMER is not None and n_dev is None:       # speculative sizes are accounted once the true size is known
             _lib.TIMER.note_units("nsim_field_sdf", S)
             if planes is not None:
                 _lib.TIMER.note_units("nsim_lotd_gather_lm", S)
@@ -504,9 +508,10 @@ class LoTDNeuSModel(nn.Module):
         return sdf.reshape(shape)
 
     @torch.no_grad()
-    def _query_sdf_rays(self, rays_o, rays_d, t, ridx, goff=None):
+    def _query_sdf_rays(self, rays_o, rays_d, t, ridx, goff=None, n_dev=None, n_add=0):
         grid16, wpack = self._shadow()
-        return self._sdf_query(grid16, wpack, None, rays_o, rays_d, t, ridx, t.shape[0], t.device, goff=goff)
+        return self._sdf_query(grid16, wpack, None, rays_o, rays_d, t, ridx, t.shape[0], t.device, goff=goff,
+                               n_dev=n_dev, n_add=n_add)
 
     def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
         shape = x.shape[:-1]
@@ -594,8 +599,14 @@ class LoTDNeuSModel(nn.Module):
             c[key] = torch.arange(R, device=dev).repeat_interleave(n)
         return c[key]
 
-    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None):
-        """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling."""
+    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None, cap: Optional[int] = None):
+        """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling.
+
+        ``cap`` = None: the size M of the marched set is read back (host sync) before anything is allocated.
+        ``cap`` = int: buffers are sized for M <= cap WITHOUT reading M; every consumer is per-ray (through
+        ``pack_infos``) or takes the point count from device memory, rays that would overflow are emptied on the device
+        (nsim_pack_infos_from_n), and the caller compares the true M (returned as a device scalar) with cap at its next
+        sync -- one host round-trip less per step."""
         R = o.shape[0]
         dev = o.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -606,8 +617,12 @@ class LoTDNeuSModel(nn.Module):
         counts = torch.empty([R], dtype=torch.long, device=dev)
         _lib.call("nsim_march_count", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(counts))
-        pi_m, total = po.get_pack_infos_from_n(counts, return_total=True)
-        M = int(total.item())               # host sync #2: size of the marched set
+        pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
+        if cap is None:
+            M = int(total_m.item())             # host sync: size of the marched set
+            n_dev = None
+        else:
+            M, n_dev = int(cap), total_m
         t_m = torch.empty([max(M, 1)], **f32)
         _lib.call("nsim_march_emit", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
@@ -619,7 +634,7 @@ class LoTDNeuSModel(nn.Module):
         ridx = torch.empty([S], dtype=torch.long, device=dev)
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
                   _lib.ptr(pi), _lib.ptr(ridx))
-        sdf = self._query_sdf_rays(o, d, t, ridx, goff)
+        sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
@@ -639,24 +654,39 @@ class LoTDNeuSModel(nn.Module):
                       nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx))
             t, sdf, pi, S = t2, sdf2, pi2, S2
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
-        return t, sdf, pi, ridx, counts
+        return t, sdf, pi, ridx, counts, total_m
 
-    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float):
+    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None):
         """``march_occ_multi_upsample_compressed``: drop the samples whose visibility weight (from the no-grad SDFs
-        of the sampling pass) is negligible before the with-grad query.  Host sync #3 (size of the kept set)."""
+        of the sampling pass) is negligible before the with-grad query.  Host sync (size of the kept set; the same
+        round-trip also brings back the true marched total ``total_m`` of a speculatively sized sampling pass).
+        -> t_k, pack_infos_k, ridx_k, M_true (None when total_m is None); all None but M_true on overflow."""
         R = pi.shape[0]
         dev = t.device
         counts = torch.empty([R], dtype=torch.long, device=dev)
         _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
                   self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(counts))
         pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
-        Sk = int(total.item())
+        if total_m is None:
+            Sk, M_true = int(total.item()), None
+        else:
+            Sk, M_true = torch.cat([total, total_m]).tolist()
         t_k = torch.empty([Sk], dtype=torch.float32, device=dev)
         ridx_k = torch.empty([Sk], dtype=torch.long, device=dev)
         if Sk > 0:
             _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
                       self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
-        return t_k, pi_k, ridx_k
+        return t_k, pi_k, ridx_k, M_true
+
+    def _speculative_cap(self, R: int) -> Optional[int]:
+        """Capacity for the marched set of R rays from the last observed density (1.3x + slack), or None."""
+        st = getattr(self, "_march_stat", None)
+        if st is None or not self._speculate:
+            return None
+        R0, M0 = st
+        if R0 <= 0 or not (0.5 <= R / R0 <= 2.0):
+            return None
+        return int(1.3 * M0 * R / R0) + 8192
 
     def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,
                   return_details: bool = False, render_per_obj_individual: bool = False) -> Dict:
@@ -692,9 +722,27 @@ class LoTDNeuSModel(nn.Module):
         goff = ray_tested.get("rays_goff", None)           # batched model: per-ray instance offsets (table / occupancy)
         woff = ray_tested.get("rays_word_off", None)
         with torch.no_grad():
-            t, sdf_ng, pi, ridx, march_counts = self._sample(o, d, near, far, qp, jitter, jitter_c, goff, woff)
-            if mode.endswith("_compressed"):
-                t, pi, ridx = self._compress(t, sdf_ng, pi, fis, float(qp.get("compress_thre", 1e-4)))
+            compressed = mode.endswith("_compressed")
+            cap = self._speculative_cap(R) if compressed else None
+            t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c, goff, woff,
+                                                                      cap=cap)
+            if compressed:
+                thre = float(qp.get("compress_thre", 1e-4))
+                t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None)
+                if cap is not None and M_true > cap:          # the speculation failed: redo with the exact size
+                    t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c,
+                                                                              goff, woff, cap=None)
+                    t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre)
+                    M_true = int(total_m.item())
+                if M_true is None:
+                    M_true = int(sdf_ng.shape[0]) - R * (int(qp.get("num_coarse", 64)) + sum(int(n) for n in qp.get("num_fine", [8, 8, 32])))
+                self._march_stat = (R, M_true)
+                if _lib.TIMER is not None and cap is not None:    # the first query's true size, now that it is known
+                    S0 = M_true + R * int(qp.get("num_coarse", 64))
+                    _lib.TIMER.note_units("nsim_field_sdf", S0)
+                    if not self._sdf_fused:
+                        _lib.TIMER.note_units("nsim_lotd_gather_lm", S0)
+                t, pi, ridx = t_k, pi_k, ridx_k
         if t.shape[0] == 0:
             ret["volume_buffer"] = dict(type="empty")
             if return_details:

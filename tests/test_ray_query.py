@@ -151,3 +151,28 @@ def test_extra_points_ride_on_the_render_launches(backend):
     assert abs(loss_a - loss_b) < 1e-4 * abs(loss_a)
     for ga, gb in zip(g_a, g_b):
         assert rel_l2(gb, ga) < 1e-4
+
+
+def test_speculative_sample_buffers(backend):
+    """Compressed mode sizes its sampling buffers from the previous call's density (no read-back of the marched
+    total); the result must be identical to the exact path -- also when the guess was too small (redo) or when a
+    pack was emptied on the device."""
+    p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "f32", N=40)
+    dv = lambda a: a.to(backend).contiguous()
+    tested = model.ray_test(dv(o), dv(d), near=0.01, far=None, rays_h_appear=dv(h_appear))
+    ri = tested["rays_inds"].cpu()
+    cfg = dict(query_param=dict(QP, compress_thre=1e-3), with_rgb=True, with_normal=True, _render=True,
+               _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]), query_mode="march_occ_multi_upsample_compressed")
+    model._speculate = True
+    model._march_stat = None
+    ref = model.ray_query(ray_tested=tested, config=cfg, return_details=True)          # exact (no history)
+    R, M = model._march_stat
+    assert R == tested["num_rays"] and M == int(ref["details"]["march_counts"].sum())
+    for stat in ((R, M), (R, 3 * M), (R, max(1, M // 50)), None):       # good guess, loose guess, overflow -> redo, exact
+        model._march_stat = stat
+        out = model.ray_query(ray_tested=tested, config=cfg, return_details=True)
+        assert model._march_stat == (R, M)
+        for k in ("t", "sdf", "rgb", "opacity_alpha"):
+            assert torch.equal(out["volume_buffer"][k], ref["volume_buffer"][k]), (stat, k)
+        assert torch.equal(out["volume_buffer"]["pack_infos_hit"], ref["volume_buffer"]["pack_infos_hit"])
+        assert torch.equal(out["rendered"]["rgb_volume"], ref["rendered"]["rgb_volume"])
