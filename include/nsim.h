@@ -196,8 +196,9 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
  * feat_planes != NULL: decoder only, on the level-major feature planes written by nsim_lotd_gather_lm for the same
  * points (x / rays / grid are then unused and may be NULL).  Same values either way.
  * Speculatively sized buffers (level-major path): S is the CAPACITY (and the plane pitch); when n_dev != NULL the
- * number of valid points is min(S, *n_dev + n_add), read on the device -- the host never learns the size of the
- * marched sample set before launching its first query (one host sync less per step). */
+ * number of valid points is *n_dev + n_add, read on the device (0 if that exceeds S: the caller under-sized its
+ * buffers and redoes the pass) -- the host never learns the size of the marched sample set before launching its
+ * first query (one host sync less per step). */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,

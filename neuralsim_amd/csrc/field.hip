@@ -706,8 +706,10 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * GLM_PTS) + lane;
   int64_t Sv = a.S;                                 // valid points (<= capacity a.S)
   if (a.S_dev) {
+    // more points than the buffers were sized for: the packs are no longer contiguous (nsim_pack_infos_from_n
+    // emptied some), the caller will redo the pass -- touch nothing
     const int64_t sd = a.S_dev[0] + a.S_add;
-    Sv = sd < Sv ? sd : Sv;
+    Sv = sd <= Sv ? sd : 0;
   }
   float xx[GLM_PTS][3];
   uint32_t goff[GLM_PTS];
@@ -790,7 +792,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
   int64_t Sv = a.S;
   if (a.S_dev) {
     const int64_t sd = a.S_dev[0] + a.S_add;
-    Sv = sd < Sv ? sd : Sv;
+    Sv = sd <= Sv ? sd : 0;       // overflow of a speculative capacity: see k_lotd_gather_lm
   }
   const int64_t ntiles = (Sv + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;

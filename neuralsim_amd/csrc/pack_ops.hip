@@ -40,10 +40,12 @@ __global__ void __launch_bounds__(256) k_pack_infos_from_n(const int64_t* __rest
   int64_t run = sums[tid];
   for (int64_t i = b; i < e; ++i) {
     int64_t v = n[i];
-    pi[2 * i] = run;
-    // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied so that
-    // every consumer stays in bounds (the caller sees total > cap at its next sync and redoes the pass)
-    pi[2 * i + 1] = (cap >= 0 && run + v > cap) ? 0 : v;
+    // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied and every
+    // start stays <= cap, so that each consumer -- including those that append per-pack data at start + const * i --
+    // stays in bounds (the caller sees total > cap at its next sync and redoes the pass)
+    const bool over = cap >= 0 && run + v > cap;
+    pi[2 * i] = (cap >= 0 && run > cap) ? cap : run;
+    pi[2 * i + 1] = over ? 0 : v;
     run += v;
   }
 }
