@@ -24,8 +24,13 @@ class RenderTrainer:
     def __init__(self, model: LoTDNeuSModel, intr, c2w, WH, num_rays: int, lr: float = 1e-2, w_eikonal: float = 0.1,
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
-                 distant_model=None, sky_model=None, level_anneal: Optional[dict] = None):
+                 distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
+                 target_sphere_radius: Optional[float] = None):
         self.model = model
+        # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
+        # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
+        self.target_sphere_radius = target_sphere_radius
+        self._ray_cache = None
         # encoding_cfg.anneal_cfg{type: hardmask, start_it, stop_it, start_level} (dtu yaml:104-108)
         self.level_anneal = dict(level_anneal) if level_anneal else None
         self.intr, self.c2w, self.WH = intr, c2w, WH
@@ -58,13 +63,32 @@ class RenderTrainer:
         N = self.num_rays
         xy = torch.rand([N, 2], device=dev, generator=self.gen).clamp_(1e-6, 1 - 1e-6)   # cameras.py:247
         fidx = torch.randint(0, self.V, [N], device=dev, generator=self.gen)
-        gt = torch.rand([N, 3], device=dev, generator=self.gen)
+        if self.target_sphere_radius is None:
+            gt = torch.rand([N, 3], device=dev, generator=self.gen)
+        else:
+            o, d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
+            self._ray_cache = (xy, o, d)
+            gt = self.sphere_image(o, d, self.target_sphere_radius)
         return xy, fidx, gt
+
+    @staticmethod
+    def sphere_image(o, d, radius: float):
+        """Pixel colours of a sphere at the origin seen along unit rays (o, d): 0.5 + 0.5 n at the first hit, else 0."""
+        b = (o * d).sum(-1)
+        c = (o * o).sum(-1) - radius * radius
+        disc = b * b - c
+        t = -b - torch.sqrt(disc.clamp_min(0.0))
+        hit = (disc > 0) & (t > 0)
+        n = (o + t[:, None] * d) / radius
+        return torch.where(hit[:, None], 0.5 + 0.5 * n, torch.zeros_like(n))
 
     def render(self, xy, fidx, with_normal=True, extra_pts=None):
         """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration).
         ``extra_pts`` [M,3]: free points evaluated by the same field launches (``_FieldFn`` extra_x)."""
-        rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
+        if self._ray_cache is not None and self._ray_cache[0] is xy:
+            _, rays_o, rays_d = self._ray_cache
+        else:
+            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
         h_appear = embedding_lookup(self.appear, fidx)
         ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
                                    return_buffer=True, return_details=True, distant_model=self.distant_model,
