@@ -361,6 +361,7 @@ __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32]
   for (int k = 0; k < 32; ++k) r2[k] = fmaxf(r2[k] + vecf(W, L, V_RB2, hi, k), 0.f);
 }
 
+// MODE 3: MODE 1 on features / dh-dx planes already gathered level-major by k_lotd_gather_lm<., true> (training).
 // MODE 0: sdf only; MODE 1: sdf + nablas (+ rgb); MODE 2: backward of the SDF branch (gradient w.r.t. grid and
 // decoder weights given dL/dsdf and the TOTAL dL/dnablas, which already includes the radiance net's share).
 template <int PREC, int SDF_D, int MODE>
@@ -375,9 +376,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   // LDS float atomics cost ~800 cycles per instruction) and reads the weight fragments from L2 instead of LDS to
   // make room for the four copies; the f32 validation mode keeps one shared accumulator with atomics.
   constexpr bool PRIV = (MODE == 2 && PREC == 0);
+  constexpr bool FWD = (MODE == 1 || MODE == 3);          // forward with normals (+ radiance)
+  constexpr bool FROM_PLANES = (MODE == 2 || MODE == 3);  // h / dh-dx come from the level-major planes
   // W / L: per-lane vectors (always LDS in fp16 mode); WM / LM: matrix fragments (LDS, or L2 when PRIV)
   // MODE 0 / 2 touch only the SDF decoder (W1, W2, W2T, W1T); MODE 1 also the radiance matrices
-  const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (MODE == 1 ? M_COUNT : 4), L, wbytes);
+  const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (FWD ? M_COUNT : 4), L, wbytes);
   const char* WM = PRIV ? a.wpack : W;
   const FieldLayout LM = PRIV ? a.lay : L;
 
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
-    const TilePoint p = load_point(a, tile, j, MODE == 1);
+    const TilePoint p = load_point(a, tile, j, FWD);
     const bool valid = p.valid;
     const int64_t s = p.s;
     // ---------------------------------------------------------------- gather (8 of 16 levels per lane)
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // traffic instead of a second latency-bound random gather.
     float h[16];
     float J[16][3];
-    if constexpr (MODE == 2) {
+    if constexpr (FROM_PLANES) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -532,7 +535,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     }
     float g[16];
     dense<PREC, 1, 2>(g, WM + LM.mat[M_W1T], d1, false);
-    if constexpr (MODE == 1) {
+    if constexpr (FWD) {
       float nab[3];
 #pragma unroll
       for (int c3 = 0; c3 < 3; ++c3) {
@@ -698,8 +701,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // result does not depend on it): an XCD pulls only ITS levels' tables (~3 MB) through its L2 instead of all 24 MB.
 // Measured ceiling (tools/gather_bench.hip): a random 4-byte gather retires 267 G lines/s from an L2-resident 2 MB
 // table (= the 34 TB/s aggregate L2->L1 rate at 128 B per miss) but only 65-120 G/s from an 8-32 MB one.
+// WJ = true (with-grad forward of the training step): writes the f32 planes h [16][S][2] and dh/dx [16][S][2][3] that
+// the decoder kernels (k_field MODE 3 forward, MODE 2 backward) read -- the same split, so the 6.7 k-instruction
+// forward no longer carries the gather's address registers (it spilled 440 B per lane).
 #define GLM_PTS 4
-template <int PREC>
+template <int PREC, bool WJ>
 __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   const int lane = nsim_lane();
   const int xcd = (int)(blockIdx.x & 7u);
@@ -739,10 +745,15 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     const int type = a.lotd.type[l];
     const uint32_t T = a.lotd.size[l], off = (uint32_t)a.lotd.offset[l];
     float f0[GLM_PTS], f1[GLM_PTS];
+    float j0[WJ ? GLM_PTS : 1][3], j1[WJ ? GLM_PTS : 1][3];
 #pragma unroll
     for (int q = 0; q < GLM_PTS; ++q) {
       const LotdCell c = lotd_cell(xx[q], R);
       f0[q] = f1[q] = 0.f;
+      if constexpr (WJ) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) j0[q][c3] = j1[q][c3] = 0.f;
+      }
       if (l < a.lotd.n_active)
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
@@ -754,6 +765,20 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
         lotd_load2(gref, off + goff[q] + 2u * idx, g0, g1);
         f0[q] = f0[q] + w * g0;
         f1[q] = f1[q] + w * g1;
+        if constexpr (WJ) {
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            j0[q][c3] = j0[q][c3] + dw[c3] * g0;
+            j1[q][c3] = j1[q][c3] + dw[c3] * g1;
+          }
+        }
+      }
+      if constexpr (WJ) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+          j0[q][c3] = j0[q][c3] * c.dscale[c3];
+          j1[q][c3] = j1[q][c3] * c.dscale[c3];
+        }
       }
     }
 #pragma unroll
@@ -761,7 +786,17 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
       const int64_t s = s0 + 64 * q;
       if (s < Sv) {
         const int64_t e = (int64_t)l * a.S + s;
-        if constexpr (PREC == 0) {
+        if constexpr (WJ) {
+          float* hp = a.h_pl + e * 2;
+          float* jp = a.J_pl + e * 6;
+          hp[0] = f0[q];
+          hp[1] = f1[q];
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            jp[c3] = j0[q][c3];
+            jp[3 + c3] = j1[q][c3];
+          }
+        } else if constexpr (PREC == 0) {
           union {
             uint32_t u;
             f16 h[2];
@@ -1252,6 +1287,24 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   return 0;
 }
 
+// deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
+static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
+  int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool used[16] = {false};
+  for (int xc = 0; xc < 8; ++xc) a.glm_n[xc] = 0;
+  for (int it = 0; it < 16; ++it) {
+    int best = -1;
+    for (int l = 0; l < 16; ++l)
+      if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
+    used[best] = true;
+    int tx = 0;
+    for (int xc = 1; xc < 8; ++xc)
+      if (load[xc] < load[tx]) tx = xc;
+    a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
+    load[tx] += (int64_t)meta->lotd.size[best] + 65536;
+  }
+}
+
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
                         const int64_t* n_dev, int64_t n_add, void* feat_planes, void* stream) {
@@ -1269,24 +1322,10 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
   a.S_dev = n_dev;
   a.S_add = n_add;
   a.feat_pl = feat_planes;
-  // deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
-  int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool used[16] = {false};
-  for (int xc = 0; xc < 8; ++xc) a.glm_n[xc] = 0;
-  for (int it = 0; it < 16; ++it) {
-    int best = -1;
-    for (int l = 0; l < 16; ++l)
-      if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
-    used[best] = true;
-    int tx = 0;
-    for (int xc = 1; xc < 8; ++xc)
-      if (load[xc] < load[tx]) tx = xc;
-    a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
-    load[tx] += (int64_t)meta->lotd.size[best] + 65536;
-  }
+  deal_levels(meta, a);
   const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
-  if (meta->precision == 0) hipLaunchKernelGGL(k_lotd_gather_lm<0>, gg, dim3(64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_lotd_gather_lm<1>, gg, dim3(64), 0, (hipStream_t)stream, a);
+  if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_lotd_gather_lm<1, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -1354,6 +1393,14 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
   a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
+  static const bool fused = getenv("NSIM_FWD_FUSED") && atoi(getenv("NSIM_FWD_FUSED")) == 1;
+  if (h_planes && !fused) {      // training: level-major gather into the planes, then the decoders on the planes
+    deal_levels(meta, a);
+    const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+    if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+    return field_launch<3>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
+  }
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 

@@ -599,7 +599,8 @@ class LoTDNeuSModel(nn.Module):
             c[key] = torch.arange(R, device=dev).repeat_interleave(n)
         return c[key]
 
-    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None, cap: Optional[int] = None):
+    def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None, cap: Optional[int] = None,
+                pre_sync_hook=None):
         """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling.
 
         ``cap`` = None: the size M of the marched set is read back (host sync) before anything is allocated.
@@ -619,6 +620,8 @@ class LoTDNeuSModel(nn.Module):
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(counts))
         pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
         if cap is None:
+            if pre_sync_hook is not None:
+                pre_sync_hook()                 # independent host work queued ahead of the blocking read
             M = int(total_m.item())             # host sync: size of the marched set
             n_dev = None
         else:
@@ -656,7 +659,7 @@ class LoTDNeuSModel(nn.Module):
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts, total_m
 
-    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None):
+    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None):
         """``march_occ_multi_upsample_compressed``: drop the samples whose visibility weight (from the no-grad SDFs
         of the sampling pass) is negligible before the with-grad query.  Host sync (size of the kept set; the same
         round-trip also brings back the true marched total ``total_m`` of a speculatively sized sampling pass).
@@ -667,6 +670,8 @@ class LoTDNeuSModel(nn.Module):
         _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
                   self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(counts))
         pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
+        if pre_sync_hook is not None:
+            pre_sync_hook()                     # e.g. the trainer's prefetch of the next batch (its own sync lands here)
         if total_m is None:
             Sk, M_true = int(total.item()), None
         else:
@@ -724,11 +729,13 @@ class LoTDNeuSModel(nn.Module):
         with torch.no_grad():
             compressed = mode.endswith("_compressed")
             cap = self._speculative_cap(R) if compressed else None
+            hook = cfg.get("_pre_sync_hook", None)       # called once, right before the first blocking size read
             t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c, goff, woff,
-                                                                      cap=cap)
+                                                                      cap=cap, pre_sync_hook=hook if cap is None else None)
             if compressed:
                 thre = float(qp.get("compress_thre", 1e-4))
-                t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None)
+                t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None,
+                                                           pre_sync_hook=hook if cap is not None else None)
                 if cap is not None and M_true > cap:          # the speculation failed: redo with the exact size
                     t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c,
                                                                               goff, woff, cap=None)

@@ -68,7 +68,9 @@ class SingleVolumeRenderer(nn.Module):
                   rays_pix: torch.Tensor = None, *, model: LoTDNeuSModel, rays_h_appear: torch.Tensor = None,
                   near=None, far=None, with_rgb: bool = None, with_normal: bool = None, return_buffer=False,
                   return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-                  distant_model=None, sky_model=None, with_env: bool = None) -> Dict:
+                  distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None) -> Dict:
+        """``cr_ray_tested``: a ``model.ray_test`` result computed ahead of time for exactly these rays (the trainer
+        prefetches the next batch's AABB test while it waits on the current batch's sample count)."""
         assert rays_o.dim() == rays_d.dim() == 2, "rays_o and rays_d should have size of [N, 3]"
         config = self.config
         if with_rgb is None:
@@ -85,7 +87,8 @@ class SingleVolumeRenderer(nn.Module):
 
         cr_ray_input = dict(rays_o=rays_o, rays_d=rays_d, near=near, far=far, rays_ts=rays_ts, rays_pix=rays_pix,
                             rays_h_appear=rays_h_appear)
-        cr_ray_tested = model.ray_test(**cr_ray_input)
+        if cr_ray_tested is None:
+            cr_ray_tested = model.ray_test(**cr_ray_input)
         ray_query_config = dict(model.ray_query_cfg)
         ray_query_config.update({k: v for k, v in config.items()})
         ray_query_config.update(with_rgb=with_rgb, with_normal=with_normal)
@@ -198,7 +201,7 @@ class SingleVolumeRenderer(nn.Module):
     def render(self, model: LoTDNeuSModel, *, rays: List[torch.Tensor], rays_h_appear: torch.Tensor = None, near=None,
                far=None, rayschunk: int = None, with_rgb=None, with_normal=None, return_buffer=False,
                return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-               distant_model=None, sky_model=None, with_env: bool = None) -> Dict:
+               distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None) -> Dict:
         """rays = [rays_o, rays_d(, rays_ts, rays_pix)] with arbitrary prefix shape (reference :495-581)."""
         if rayschunk is None:
             rayschunk = self.config.get("rayschunk", 0)
@@ -209,7 +212,8 @@ class SingleVolumeRenderer(nn.Module):
             kwargs = dict(model=model, near=near, far=far, with_rgb=with_rgb, with_normal=with_normal,
                           return_buffer=return_buffer, return_details=return_details,
                           render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg,
-                          distant_model=distant_model, sky_model=sky_model, with_env=with_env)
+                          distant_model=distant_model, sky_model=sky_model, with_env=with_env,
+                          cr_ray_tested=cr_ray_tested)
             if self.training or (not rayschunk) or flat[0].shape[0] <= rayschunk:
                 ret = self(*flat[:2], rays_h_appear=ha, **kwargs)
             else:

@@ -25,12 +25,16 @@ class RenderTrainer:
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
                  distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
-                 target_sphere_radius: Optional[float] = None):
+                 target_sphere_radius: Optional[float] = None, pipeline: bool = True):
         self.model = model
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
         # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
         self.target_sphere_radius = target_sphere_radius
         self._ray_cache = None
+        # software pipelining of the data side: the next batch (rays, targets, AABB test + its compaction sync) is
+        # produced while the host waits for the current batch's sample count -- one blocking wait per step
+        self.pipeline = pipeline
+        self._prefetched = None
         # encoding_cfg.anneal_cfg{type: hardmask, start_it, stop_it, start_level} (dtu yaml:104-108)
         self.level_anneal = dict(level_anneal) if level_anneal else None
         self.intr, self.c2w, self.WH = intr, c2w, WH
@@ -82,19 +86,47 @@ class RenderTrainer:
         n = (o + t[:, None] * d) / radius
         return torch.where(hit[:, None], 0.5 + 0.5 * n, torch.zeros_like(n))
 
-    def render(self, xy, fidx, with_normal=True, extra_pts=None):
+    def render(self, xy, fidx, with_normal=True, extra_pts=None, batch: dict = None):
         """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration).
-        ``extra_pts`` [M,3]: free points evaluated by the same field launches (``_FieldFn`` extra_x)."""
+        ``extra_pts`` [M,3]: free points evaluated by the same field launches (``_FieldFn`` extra_x).
+        ``batch``: a prefetched batch (``_make_batch``): rays and AABB test are already there, and the prefetch of
+        the NEXT batch is queued right before this render's blocking sample-count read."""
+        bypass = dict(_extra_pts=extra_pts) if extra_pts is not None else {}
+        tested = None
+        if batch is not None:
+            rays_o, rays_d, tested = batch["rays_o"], batch["rays_d"], dict(batch["tested"])
+            if self.pipeline:
+                bypass["_pre_sync_hook"] = self._prefetch
+        elif self._ray_cache is not None and self._ray_cache[0] is xy:
+            _, rays_o, rays_d = self._ray_cache
+        else:
+            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
+        h_appear = None
+        if tested is None or self.distant_model is not None or self.sky_model is not None:
+            h_appear = embedding_lookup(self.appear, fidx)          # per-ray codes for every ray
+        if tested is not None:      # current appearance codes of the rays that hit (the test itself was geometry only)
+            tested["rays_h_appear"] = embedding_lookup(self.appear, batch["fidx_hit"]) if h_appear is None \
+                else embedding_lookup(h_appear, tested["rays_inds"])
+        ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
+                                   return_buffer=True, return_details=True, distant_model=self.distant_model,
+                                   sky_model=self.sky_model, bypass_ray_query_cfg=bypass or None, cr_ray_tested=tested)
+        return ret
+
+    def _make_batch(self) -> dict:
+        """sample_batch + ray generation + the AABB test (with its hit-ray compaction sync) of one batch."""
+        xy, fidx, gt = self.sample_batch()
         if self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
             rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
-        h_appear = embedding_lookup(self.appear, fidx)
-        ret = self.renderer.render(self.model, rays=[rays_o, rays_d], rays_h_appear=h_appear, with_normal=with_normal,
-                                   return_buffer=True, return_details=True, distant_model=self.distant_model,
-                                   sky_model=self.sky_model,
-                                   bypass_ray_query_cfg=dict(_extra_pts=extra_pts) if extra_pts is not None else None)
-        return ret
+        with torch.no_grad():
+            tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
+        return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested,
+                    fidx_hit=fidx[tested["rays_inds"]])
+
+    def _prefetch(self):
+        if self._prefetched is None:
+            self._prefetched = self._make_batch()
 
     def sample_uniform_x(self) -> torch.Tensor:
         lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
@@ -126,11 +158,16 @@ class RenderTrainer:
             model.anneal_levels(it, **self.level_anneal)
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
-        xy, fidx, gt = self.sample_batch()
+        batch = None
+        if self.pipeline:
+            batch, self._prefetched = (self._prefetched or self._make_batch()), None
+            xy, fidx, gt = batch["xy"], batch["fidx"], batch["gt"]
+        else:
+            xy, fidx, gt = self.sample_batch()
         # the uniform eikonal points (train.py:602-613) ride on the render's field launches as zero-length rays: a
         # separate 4096-point launch chain costs ~0.2 ms of fixed latency (fwd + two backward kernels + scatter)
         x_uni = self.sample_uniform_x() if self.num_uniform > 0 else None
-        ret = self.render(xy, fidx, extra_pts=x_uni)
+        ret = self.render(xy, fidx, extra_pts=x_uni, batch=batch)
         uni = None
         if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
             uni = model.forward_sdf_nablas(x_uni)
