@@ -174,8 +174,9 @@ class RenderTrainer:
         loss, parts = self.loss(ret, gt, uni)
         self.optim.zero_grad()
         loss.backward()
-        ndist.allreduce_grads(self.optim.params(), average=True)
-        self.optim.step()
+        # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
+        ndist.allreduce_grads(self.optim.params(), average=False)
+        self.optim.step(grad_scale=1.0 / self.world_size)
         vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
         self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
                           S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
