@@ -144,15 +144,19 @@ int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near,
 int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C,
                        float* out, void* stream);
 /* One NeuS up-sampling stage (num_fine[i], upsample_inv_s * factor[i], upsample_use_estimate_alpha).
- * scratch: float [S]. t_new: [R, n_fine] ascending. */
+ * scratch: float [S]. t_new: [R, n_fine] ascending.  x_new [R, n_fine, 3] (may be NULL; needs rays_o / rays_d [R,3]):
+ * positions o + t d of the new samples, so that the level-major query reads 12 B per point instead of re-deriving
+ * the point from (ridx, t, o, d) once per XCD. */
 int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
-                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, void* stream);
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
+                        const float* rays_d, float* x_new, void* stream);
 /* Sorted merge of packed (t_a, v_a) with batched (t_b, v_b) [R,nb]; packs must tile the arrays in order.
  * v_a / v_b / v_out may be NULL. pack_infos_out [R,2] is written; ridx_out [S_out] (may be NULL) receives the
- * ray (pack) index of every merged sample. */
+ * ray (pack) index of every merged sample; x_out [S_out, 3] (may be NULL; needs rays_o / rays_d) their positions. */
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
-                      int64_t* pack_infos_out, int64_t* ridx_out, void* stream);
+                      int64_t* pack_infos_out, int64_t* ridx_out, const float* rays_o, const float* rays_d,
+                      float* x_out, void* stream);
 
 /* ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): from the no-grad SDF of all
  * samples keep those that bound an interval with visibility weight > thre.  count -> counts [R]; emit (given

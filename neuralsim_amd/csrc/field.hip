@@ -214,7 +214,8 @@ struct FieldArgs {
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
   void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16][S] x (f16x2 | f32x2)
-  signed char glm_n[8], glm_lv[8][16];             // levels gathered by the blocks of XCD x (blockIdx % 8)
+  signed char glm_n[8], glm_lv[8][16];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
+  signed char glm_half[8][16];                     // ... for all points (0), the first (1) or the second (2) half of them
   float *h_pl, *J_pl;                              // level-major planes [16][S][2] / [16][S][2][3] saved by the forward
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16][S][2]
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
@@ -738,9 +739,12 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   }
   const GridRef gref = grid_ref(a.grid);
   const int nl = a.glm_n[xcd];
+  const bool second_half = (blockIdx.x >> 3) >= ((gridDim.x >> 3) + 1) / 2;
 #pragma unroll 1
   for (int k = 0; k < nl; ++k) {
     const int l = a.glm_lv[xcd][k];
+    const int half = a.glm_half[xcd][k];
+    if ((half == 1 && second_half) || (half == 2 && !second_half)) continue;
     const LotdRes R = a.lotd.res[l];
     const int type = a.lotd.type[l];
     const uint32_t T = a.lotd.size[l], off = (uint32_t)a.lotd.offset[l];
@@ -1287,21 +1291,43 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   return 0;
 }
 
-// deal the levels to the XCDs, largest table first onto the least loaded XCD (cost ~ table bytes)
+// Deal the levels to the XCDs so that every XCD streams few tables through its L2 AND the XCDs finish together:
+// a hashed level costs 1, a dense one ~0.35 (its lines mostly hit L1); levels go, most expensive first, onto the least
+// loaded XCD -- whole if that keeps the XCD within 8 % of the ideal load, otherwise split into two halves of the point
+// range on two XCDs (3 of the 11 hashed levels of the default pyramid end up split: max load 1.7 instead of 2.0).
 static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
-  int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float cost[16], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
   bool used[16] = {false};
+  for (int l = 0; l < 16; ++l) {
+    cost[l] = meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f;
+    total += cost[l];
+  }
+  const float limit = total / 8.0f * 1.08f;
   for (int xc = 0; xc < 8; ++xc) a.glm_n[xc] = 0;
-  for (int it = 0; it < 16; ++it) {
-    int best = -1;
-    for (int l = 0; l < 16; ++l)
-      if (!used[l] && (best < 0 || meta->lotd.size[l] > meta->lotd.size[best])) best = l;
-    used[best] = true;
+  auto least = [&]() {
     int tx = 0;
     for (int xc = 1; xc < 8; ++xc)
       if (load[xc] < load[tx]) tx = xc;
-    a.glm_lv[tx][(int)a.glm_n[tx]++] = (signed char)best;
-    load[tx] += (int64_t)meta->lotd.size[best] + 65536;
+    return tx;
+  };
+  auto put = [&](int xc, int l, int half, float c) {
+    a.glm_lv[xc][(int)a.glm_n[xc]] = (signed char)l;
+    a.glm_half[xc][(int)a.glm_n[xc]++] = (signed char)half;
+    load[xc] += c;
+  };
+  for (int it = 0; it < 16; ++it) {
+    int best = -1;
+    for (int l = 0; l < 16; ++l)
+      if (!used[l] && (best < 0 || cost[l] > cost[best] ||
+                       (cost[l] == cost[best] && meta->lotd.size[l] > meta->lotd.size[best]))) best = l;
+    used[best] = true;
+    const int x0 = least();
+    if (load[x0] + cost[best] <= limit || load[x0] == 0.f) {
+      put(x0, best, 0, cost[best]);
+    } else {
+      put(x0, best, 1, 0.5f * cost[best]);
+      put(least(), best, 2, 0.5f * cost[best]);
+    }
   }
 }
 

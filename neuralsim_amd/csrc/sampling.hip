@@ -258,7 +258,10 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
                                                                 const int64_t* __restrict__ pi, int64_t R,
                                                                 float inv_s, int n_fine, int use_est,
                                                                 float* __restrict__ csum,
-                                                                float* __restrict__ t_new) {
+                                                                float* __restrict__ t_new,
+                                                                const float* __restrict__ rays_o,
+                                                                const float* __restrict__ rays_d,
+                                                                float* __restrict__ x_new) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
@@ -305,9 +308,19 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
       float frac = (u - c_lo) / den;
       frac = fminf(fmaxf(frac, 0.f), 1.f);
       const float b_lo = tt[lo], b_hi = tt[lo + 1];
-      t_new[r * n_fine + k] = b_lo + frac * (b_hi - b_lo);
+      const float tn = b_lo + frac * (b_hi - b_lo);
+      t_new[r * n_fine + k] = tn;
+      if (x_new) {   // the sample's position, so that the level-major query loads 12 B instead of re-deriving it per XCD
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = rays_o[3 * r + c] + tn * rays_d[3 * r + c];
+      }
     } else if (k < n_fine) {
-      t_new[r * n_fine + k] = (n > 0) ? tt[0] : 0.f;
+      const float tn = (n > 0) ? tt[0] : 0.f;
+      t_new[r * n_fine + k] = tn;
+      if (x_new) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = rays_o[3 * r + c] + tn * rays_d[3 * r + c];
+      }
     }
   }
 }
@@ -336,11 +349,22 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
                                                               const float* __restrict__ t_b,
                                                               const float* __restrict__ v_b, int64_t R, int nb,
                                                               float* __restrict__ t_out, float* __restrict__ v_out,
-                                                              int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out) {
+                                                              int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
+                                                              const float* __restrict__ rays_o,
+                                                              const float* __restrict__ rays_d,
+                                                              float* __restrict__ x_out) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
   const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
+  float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
+  if (x_out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ro[c] = rays_o[3 * r + c];
+      rd[c] = rays_d[3 * r + c];
+    }
+  }
   const int64_t so = sa + r * (int64_t)nb;
   const float* a = t_a + sa;
   const float* b = t_b + r * (int64_t)nb;
@@ -354,6 +378,10 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
     t_out[so + pos] = v;
     if (v_out) v_out[so + pos] = v_a ? v_a[sa + i] : 0.f;
     if (ridx_out) ridx_out[so + pos] = r;
+    if (x_out) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
+    }
   }
   for (int64_t j = lane; j < nb; j += 64) {
     const float v = b[j];
@@ -361,6 +389,10 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
     t_out[so + pos] = v;
     if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
     if (ridx_out) ridx_out[so + pos] = r;
+    if (x_out) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
+    }
   }
 }
 
@@ -500,20 +532,23 @@ int nsim_coarse_depths(const float* near, const float* far, const float* jitter_
 }
 
 int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
-                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, void* stream) {
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
+                        const float* rays_d, float* x_new, void* stream) {
   if (R <= 0 || n_fine <= 0) return 0;
+  if (x_new && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_upsample_stage, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t, sdf, pack_infos, R, inv_s,
-                     n_fine, use_estimate_alpha, scratch, t_new);
+                     n_fine, use_estimate_alpha, scratch, t_new, rays_o, rays_d, x_new);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out,
-                      int64_t* ridx_out, void* stream) {
+                      int64_t* ridx_out, const float* rays_o, const float* rays_d, float* x_out, void* stream) {
   if (R <= 0) return 0;
+  if (x_out && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
-                     R, nb, t_out, v_out, pack_infos_out, ridx_out);
+                     R, nb, t_out, v_out, pack_infos_out, ridx_out, rays_o, rays_d, x_out);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

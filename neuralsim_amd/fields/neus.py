@@ -635,26 +635,39 @@ class LoTDNeuSModel(nn.Module):
         t = torch.empty([S], **f32)
         pi = torch.empty([R, 2], dtype=torch.long, device=dev)
         ridx = torch.empty([S], dtype=torch.long, device=dev)
+        # the level-major query visits every point once per XCD: hand it positions (12 B) instead of (ridx, t, o, d)
+        with_x = not self._sdf_fused
+        xq = torch.empty([S, 3], **f32) if with_x else None
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
-                  _lib.ptr(pi), _lib.ptr(ridx))
-        sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
+                  _lib.ptr(pi), _lib.ptr(ridx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(xq))
+        grid16, wpack = self._shadow()
+        if with_x:
+            sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if goff is not None else None, S, dev,
+                                  goff=goff, n_dev=n_dev, n_add=R * C)
+        else:
+            sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
             nf = int(nf)
             t_new = torch.empty([R, nf], **f32)
             scratch = torch.empty([S], **f32)
+            x_new = torch.empty([R * nf, 3], **f32) if with_x else None
             _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
-                      _lib.ptr(scratch), _lib.ptr(t_new))
+                      _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new))
             ridx_new = self._arange_repeat(R, nf, dev)
-            sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
+            if with_x:
+                sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if goff is not None else None,
+                                          R * nf, dev, goff=goff)
+            else:
+                sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
             S2 = S + R * nf
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
             pi2 = torch.empty([R, 2], dtype=torch.long, device=dev)
             ridx = torch.empty([S2], dtype=torch.long, device=dev)
             _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
-                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx))
+                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None)
             t, sdf, pi, S = t2, sdf2, pi2, S2
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts, total_m

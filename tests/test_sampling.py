@@ -128,9 +128,14 @@ def test_coarse_upsample_merge(backend):
             ref = orr.upsample_stage(t, sdf, pi, inv_s, nf, use_est)
             t_new = torch.zeros(R, nf, device=backend)
             scratch = torch.zeros(S, device=backend)
+            ro = torch.randn(R, 3, generator=torch.Generator().manual_seed(1))
+            rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=torch.Generator().manual_seed(2)), dim=-1)
+            x_new = torch.zeros(R, nf, 3, device=backend)
             _lib.call("nsim_upsample_stage", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, inv_s, nf,
-                      1 if use_est else 0, _lib.ptr(scratch), _lib.ptr(t_new))
+                      1 if use_est else 0, _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)),
+                      _lib.ptr(x_new))
             assert torch.allclose(t_new.cpu(), ref, atol=2e-5), (use_est, inv_s, nf, (t_new.cpu() - ref).abs().max())
+            assert torch.equal(x_new.cpu(), ro[:, None, :] + t_new.cpu()[..., None] * rd[:, None, :])   # bit-exact o + t d
             assert (t_new.cpu()[:, 1:] >= t_new.cpu()[:, :-1]).all()
     # merge
     nf = 8
@@ -143,8 +148,11 @@ def test_coarse_upsample_merge(backend):
     t_out = torch.zeros(S + R * nf, device=backend); v_out = torch.zeros_like(t_out)
     pi_out = torch.zeros(R, 2, dtype=torch.long, device=backend)
     ridx_out = torch.zeros(S + R * nf, dtype=torch.long, device=backend)
+    x_out = torch.zeros(S + R * nf, 3, device=backend)
     _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
-              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out))
+              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), _lib.ptr(dv(ro)),
+              _lib.ptr(dv(rd)), _lib.ptr(x_out))
+    assert torch.equal(x_out.cpu(), ro[ridx_out.cpu()] + t_out.cpu()[:, None] * rd[ridx_out.cpu()])
     assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
     assert torch.equal(ridx_out.cpu(), opo.pack_ridx(pi_ref, t_ref.shape[0]))
 
