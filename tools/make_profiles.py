@@ -9,9 +9,10 @@ G, P = ROOT / "gpurun_out", ROOT / "profiles"
 TAG = sys.argv[1] if len(sys.argv) > 1 else "round1"
 # C-ABI entry point -> kernel it launches (substring of the rocprofv3 kernel name)
 ABI = {
-    "nsim_lotd_gather_lm": "k_lotd_gather_lm<0>",
+    "nsim_lotd_gather_lm": "k_lotd_gather_lm<0, false>",
     "nsim_field_sdf": "k_field_sdf<0, 2, true>",
-    "nsim_field_fwd": "k_field<0, 2, 1>",
+    "nsim_field_fwd": "k_field<0, 2, 3>",            # decoder half; its gather half is k_lotd_gather_lm<0, true>
+    "nsim_field_fwd(gather)": "k_lotd_gather_lm<0, true>",
     "nsim_field_bwd_sdf": "k_field<0, 2, 2>",
     "nsim_field_bwd_rad": "k_rad_bwd<0>",
     "nsim_lotd_scatter": "k_lotd_scatter",
