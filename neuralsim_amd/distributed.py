@@ -50,18 +50,31 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, min(lo + per, n_total)
 
 
-def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_numel: int = 1 << 20):
-    """Sum (or average) ``p.grad`` over ranks: big tensors in place, everything else through one flat bucket.
-    Parameters whose grad is None on this rank (e.g. no ray hit) contribute zeros."""
+def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_numel: int = 1 << 20,
+                    wire_dtype: Optional[torch.dtype] = None):
+    """Sum (or average) ``p.grad`` over ranks: big tensors on their own (asynchronously), everything else through
+    one flat f32 bucket.  Parameters whose grad is None on this rank (e.g. no ray hit) contribute zeros.
+
+    ``wire_dtype`` (default: env NSIM_ALLREDUCE_DTYPE = bf16 | f32, bf16 if unset): the big tensors (the 12.2 M-entry
+    hash-table gradient, 48.8 MB in f32) travel in this type.  The reference trains fp16 parameters under DDP, i.e. it
+    all-reduces 2-byte gradients as well (code_single/tools/train.py:1401-1412); bf16 keeps the f32 exponent range, so
+    no loss scale is needed.  xGMI rings are per-link bound: halving the bytes halves the exposed time of the one
+    collective of the step."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
+    if wire_dtype is None:
+        wire_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp16": torch.float16}[
+            os.environ.get("NSIM_ALLREDUCE_DTYPE", "bf16")]
     world = dist.get_world_size()
     big, small = [], []
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p, dtype=torch.float32)
         (big if p.grad.numel() >= small_numel else small).append(p)
-    handles = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True) for p in big]
+    handles = []
+    for p in big:
+        buf = p.grad if wire_dtype == torch.float32 else p.grad.to(wire_dtype)
+        handles.append((p, buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)))
     if small:
         flat = torch.cat([p.grad.reshape(-1) for p in small])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -70,8 +83,10 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
-    for h in handles:
+    for p, buf, h in handles:
         h.wait()
+        if buf is not p.grad:
+            p.grad.copy_(buf)
     if average:
         for p in params:
             p.grad.div_(world)

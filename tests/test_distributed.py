@@ -63,14 +63,20 @@ def _worker(rank, world, port, out_dir):
     loss_on(lo, hi).backward()
     params = [t for t in p.tensors() if t.requires_grad]
     params[-1].grad = None                           # a parameter without a local gradient must still take part
-    nd.allreduce_grads(params, average=True, small_numel=1000)
-    shard_avg = [t.grad.clone() for t in params]
+    local = [t.grad.clone() if t.grad is not None else None for t in params]
+    results = {}
+    for wire in (torch.float32, torch.bfloat16):     # exact wire and the 2-byte default for the big tensors
+        for t, g0 in zip(params, local):
+            t.grad = g0.clone() if g0 is not None else None
+        nd.allreduce_grads(params, average=True, small_numel=1000, wire_dtype=wire)
+        results[wire] = [t.grad.clone() for t in params]
     for t in params:
         t.grad = None
     loss_on(0, N).backward()
-    for t, ga in zip(params[:-1], shard_avg[:-1]):
+    for t, ga, gb in zip(params[:-1], results[torch.float32][:-1], results[torch.bfloat16][:-1]):
         ref = t.grad if t.grad is not None else torch.zeros_like(t)
         assert torch.allclose(ga, ref, atol=1e-6, rtol=1e-4), (rank, float((ga - ref).abs().max()))
+        assert float((gb - ref).norm()) <= 8e-3 * float(ref.norm()) + 1e-9, (rank, "bf16 wire")
     dist.barrier()
     (Path(out_dir) / f"ok{rank}").write_text("ok")
     dist.destroy_process_group()
