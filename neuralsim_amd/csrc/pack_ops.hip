@@ -16,38 +16,50 @@ __device__ __forceinline__ int64_t pack_wave_id() {
 static inline dim3 pack_grid(int64_t P) { return dim3(nsim_blocks(P, PACK_WAVES_PER_BLOCK)); }
 
 // ------------------------------------------------------------------------------ pack_infos_from_n
-__global__ void __launch_bounds__(256) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
-                                                             int64_t* __restrict__ pi,
-                                                             int64_t* __restrict__ total, int64_t cap) {
-  __shared__ int64_t sums[256];
-  const int tid = threadIdx.x;
-  const int64_t chunk = (P + 255) / 256;
-  const int64_t b = tid * chunk, e = (b + chunk < P) ? b + chunk : P;
-  int64_t s = 0;
-  for (int64_t i = b; i < e; ++i) s += n[i];
-  sums[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t run = 0;
-    for (int i = 0; i < 256; ++i) {
-      int64_t v = sums[i];
-      sums[i] = run;
-      run += v;
+// One workgroup of 16 waves; a thread prefetches PI_PER elements (stride = block size, coalesced) so that a whole
+// super-chunk of 8192 counts costs ONE memory round trip, then PI_PER block scans (wave scan + 16 wave totals).
+#define PI_THREADS 1024
+#define PI_PER 8
+__global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
+                                                                    int64_t* __restrict__ pi,
+                                                                    int64_t* __restrict__ total, int64_t cap) {
+  __shared__ int64_t wtot[PI_THREADS / 64];
+  const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
+  int64_t carry = 0;
+  for (int64_t base = 0; base < P; base += (int64_t)PI_THREADS * PI_PER) {
+    int64_t v[PI_PER];
+#pragma unroll
+    for (int k = 0; k < PI_PER; ++k) {
+      const int64_t i = base + (int64_t)k * PI_THREADS + tid;
+      v[k] = i < P ? n[i] : 0;
     }
-    if (total) total[0] = run;
+#pragma unroll
+    for (int k = 0; k < PI_PER; ++k) {
+      const int64_t i = base + (int64_t)k * PI_THREADS + tid;
+      const int64_t incl = wave_incl_sum(v[k]);
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      int64_t before = 0, chunk = 0;
+#pragma unroll
+      for (int w = 0; w < PI_THREADS / 64; ++w) {
+        const int64_t x = wtot[w];
+        before += (w < wave) ? x : 0;
+        chunk += x;
+      }
+      const int64_t run = carry + before + incl - v[k];
+      if (i < P) {
+        // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied and every
+        // start stays <= cap, so that each consumer -- including those that append per-pack data at start + const * i
+        // -- stays in bounds (the caller sees total > cap at its next sync and redoes the pass)
+        const bool over = cap >= 0 && run + v[k] > cap;
+        pi[2 * i] = (cap >= 0 && run > cap) ? cap : run;
+        pi[2 * i + 1] = over ? 0 : v[k];
+      }
+      carry += chunk;
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  int64_t run = sums[tid];
-  for (int64_t i = b; i < e; ++i) {
-    int64_t v = n[i];
-    // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied and every
-    // start stays <= cap, so that each consumer -- including those that append per-pack data at start + const * i --
-    // stays in bounds (the caller sees total > cap at its next sync and redoes the pass)
-    const bool over = cap >= 0 && run + v > cap;
-    pi[2 * i] = (cap >= 0 && run > cap) ? cap : run;
-    pi[2 * i + 1] = over ? 0 : v;
-    run += v;
-  }
+  if (tid == 0 && total) total[0] = carry;
 }
 
 // ------------------------------------------------------------------------------------ packed_sum
@@ -476,7 +488,7 @@ extern "C" {
 int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
                            void* stream) {
   if (P < 0) return 2;
-  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(256), 0, (hipStream_t)stream, n, P, pack_infos, total, cap);
+  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, P, pack_infos, total, cap);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -58,13 +58,20 @@ class _FieldFn(torch.autograd.Function):
             assert x is None and goff is None, "extra points ride on a ray-mode query of a single-instance model"
             R, M = rays_o.shape[0], extra_x.shape[0]
             xe = extra_x.detach().float().reshape(-1, 3)
-            ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
-            ez[:, 2] = 1.0
+            ck = (M, str(dev))
+            cache = getattr(model, "_extra_cache", None)
+            if cache is None or cache[0] != ck:          # constants of the M zero-length rays: dir e_z, t 0, codes 0
+                ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
+                ez[:, 2] = 1.0
+                cache = model._extra_cache = (ck, ez, torch.zeros([M], dtype=torch.float32, device=dev),
+                                              torch.zeros([M, 4], dtype=torch.float32, device=dev))
+            _, ez, tz, hz = cache
             rays_o, rays_d = torch.cat([rays_o, xe]), torch.cat([rays_d, ez])
-            t = torch.cat([t, ez[:, 0]])
+            t = torch.cat([t, tz])
             ridx = torch.cat([ridx, torch.arange(R, R + M, device=dev)])
             if h_appear is not None:
-                h_appear = torch.cat([h_appear.detach().float(), ez.new_zeros([M, h_appear.shape[1]])])
+                hz = hz if h_appear.shape[1] == 4 else hz.new_zeros([M, h_appear.shape[1]])
+                h_appear = torch.cat([h_appear.detach().float(), hz])
         S = x.shape[0] if x is not None else t.shape[0]
         grid16, wpack = model._shadow()
         sdf = torch.empty([S], dtype=torch.float32, device=dev)
@@ -188,8 +195,9 @@ class _CompositeFn(torch.autograd.Function):
         trans = torch.empty_like(alpha)
         mask = torch.empty([P], dtype=torch.float32, device=dev)
         depth = torch.empty([P], dtype=torch.float32, device=dev)
-        rgb_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
-        nrm_o = torch.zeros([P, 3], dtype=torch.float32, device=dev)
+        # written for every pack when the corresponding input is present
+        rgb_o = (torch.empty if rgbc is not None else torch.zeros)([P, 3], dtype=torch.float32, device=dev)
+        nrm_o = (torch.empty if nrmc is not None else torch.zeros)([P, 3], dtype=torch.float32, device=dev)
         _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgbc), _lib.ptr(nrmc),
                   _lib.ptr(pack_infos), P, int(normalized_depth), _lib.ptr(vw), _lib.ptr(trans), _lib.ptr(mask),
                   _lib.ptr(depth), _lib.ptr(rgb_o), _lib.ptr(nrm_o))

@@ -26,7 +26,8 @@ def get_pack_infos_from_n(n: torch.Tensor, return_total: bool = False, cap: int 
     n = n.long().contiguous()
     P = n.shape[0]
     pi = torch.empty([P, 2], dtype=torch.long, device=n.device)
-    total = torch.zeros([1], dtype=torch.long, device=n.device)
+    total = torch.empty([1], dtype=torch.long, device=n.device) if P > 0 else \
+        torch.zeros([1], dtype=torch.long, device=n.device)          # the kernel always writes total[0]
     if P > 0:
         _lib.call("nsim_pack_infos_from_n", _lib.ptr(n), P, _lib.ptr(pi), _lib.ptr(total), int(cap))
     return (pi, total) if return_total else pi

@@ -44,13 +44,17 @@ def batchify_query(fn: Callable, *args: torch.Tensor, chunk: int, dim_batchify: 
 
 
 def prepare_empty_rendered(prefix, device, with_rgb=True, with_normal=True):
-    """app/renderers/utils.py:30-43"""
-    r = dict(mask_volume=torch.zeros(prefix, dtype=torch.float32, device=device),
-             depth_volume=torch.zeros(prefix, dtype=torch.float32, device=device))
-    if with_rgb:
-        r["rgb_volume"] = torch.zeros([*prefix, 3], dtype=torch.float32, device=device)
-    if with_normal:
-        r["normals_volume"] = torch.zeros([*prefix, 3], dtype=torch.float32, device=device)
+    """app/renderers/utils.py:30-43 -- zero images for every requested channel (two memsets: the scalar channels are
+    rows of one buffer, the vector channels column blocks of another)."""
+    sc = torch.zeros([2, *prefix], dtype=torch.float32, device=device)
+    r = dict(mask_volume=sc[0], depth_volume=sc[1])
+    nv = int(bool(with_rgb)) + int(bool(with_normal))
+    if nv:
+        vec = torch.zeros([*prefix, 3 * nv], dtype=torch.float32, device=device)
+        if with_rgb:
+            r["rgb_volume"] = vec[..., :3]
+        if with_normal:
+            r["normals_volume"] = vec[..., 3 * (nv - 1):]
     return r
 
 

@@ -190,3 +190,21 @@ def test_reference_fixture_collect_and_merge(backend):
     srt, indices = po.packed_sort(depths, total_pack_infos)
     assert torch.equal(srt, depths[indices])
     assert torch.allclose(srt.cpu(), torch.tensor(gold["sorted_depths"]), atol=0, rtol=0)
+
+
+def test_pack_infos_large_and_capped(backend):
+    """Block scan over several 1024-wide rounds and several 8192-wide super-chunks; speculative capacity semantics."""
+    from neuralsim_amd.graphics import pack_ops as po
+    g = torch.Generator().manual_seed(5)
+    for P in (1, 63, 1024, 1025, 8192, 20011):
+        n = torch.randint(0, 200, (P,), generator=g)
+        pi, tot = po.get_pack_infos_from_n(n.to(backend), return_total=True)
+        ref_start = torch.cumsum(n, 0) - n
+        assert torch.equal(pi.cpu()[:, 0], ref_start) and torch.equal(pi.cpu()[:, 1], n) and int(tot) == int(n.sum())
+        cap = int(n.sum()) // 2
+        pic, totc = po.get_pack_infos_from_n(n.to(backend), return_total=True, cap=cap)
+        pic = pic.cpu()
+        end = ref_start + n
+        assert int(totc) == int(n.sum())                                   # the true total, for the caller's check
+        assert torch.equal(pic[:, 1], torch.where(end <= cap, n, torch.zeros_like(n)))
+        assert torch.equal(pic[:, 0], ref_start.clamp_max(cap)) and int((pic[:, 0] + pic[:, 1]).max()) <= cap
