@@ -103,3 +103,99 @@ def test_backward_linearity_and_dedup_independence(setup):
     assert float((g_nd[0] - g_ab[0]).norm() / g_ab[0].norm()) < 1e-4
     # the table gradient only touches entries (its support is a small fraction of the 12.2 M parameters)
     assert 0.0 < float((g_ab[0] != 0).float().mean()) < 0.7
+
+
+def test_street_shaped_config_full_size():
+    """BASELINE configs[3]-shaped model (withmask_withlidar_joint.240219.yaml:146-226): cuboid LoTD with T = 2^20 (16
+    levels, 28 Mi parameters -- the config's 32 Mi needs ~18 levels, the fused kernels are specialised for 16), 1x64
+    decoder, sdf_scale 25, elongated AABB with a per-axis occupancy grid, sky MLP, 16384 rays per GPU.  Size-independent
+    properties: the three query kernels agree, the masked levels stay untouched, a few training steps run finite."""
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    from neuralsim_amd.grid_encodings.lotd import cuboid_ngp_res
+    from neuralsim_amd.env import SimpleSky
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    dev = torch.device("cuda", 0)
+    aspect = [2.0, 1.0, 0.3]
+    res = cuboid_ngp_res(aspect, 16, 1024, 16)
+    aabb = torch.tensor([[-1.0, -0.5, -0.15], [1.0, 0.5, 0.15]])
+    m = LoTDNeuSModel(lod_res=res, log2_hashmap_size=20, sdf_D=1, precision="fp16", ln_inv_s_init=0.3, sdf_scale=25.0,
+                      aabb=aabb, accel_cfg=dict(resolution=(64, 32, 10), update_from_net_cfg=dict(num_steps=2, num_pts=2 ** 18)),
+                      param_bound=2e-2, seed=4).to(dev)
+    cfg = m.encoding.cfg
+    assert cfg.num_levels == 16 and cfg.hashmap_size == 2 ** 20 and cfg.n_params > 24 * 2 ** 20
+    assert cfg.lod_res3[0][0] > cfg.lod_res3[0][1] > cfg.lod_res3[0][2]            # per-axis resolutions
+    m.geometric_init_sphere(0.12, noise_scale=0.5)                                   # a blob inside the flat box
+    m.accel.init(m.query_sdf, generator=torch.Generator(device=dev).manual_seed(1))
+    assert 0.0 < m.accel.frac_occupied() < 0.9
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = (torch.rand(200000, 3, device=dev, generator=g) * 2 - 1) * (aabb[1].to(dev) * 0.98)
+    out = m.forward_sdf_nablas(x)
+    s_lm = m.query_sdf(x)
+    m._sdf_fused = True
+    s_fu = m.query_sdf(x)
+    m._sdf_fused = False
+    assert float((s_lm - s_fu).abs().max()) < 1e-6                                   # level-major == fused
+    assert float((s_lm - out["sdf"].detach()).abs().max()) < 2e-3                    # == with-grad forward (fp16 paths)
+    assert bool(torch.isfinite(out["nablas"]).all())
+    # hardmask: masked levels get exactly no gradient
+    m.set_active_levels(10)
+    o2 = m.forward_sdf_nablas(x[:50000])
+    ((o2["nablas"].norm(dim=-1) - 1) ** 2).mean().backward()
+    gg = m.encoding.flattened_params.grad
+    off = cfg.lod_offsets[10]
+    assert float(gg[off:].abs().max()) == 0.0 and float(gg[:off].abs().max()) > 0.0
+    m.set_active_levels(None)
+    m.encoding.flattened_params.grad = None
+    # a few training steps at 16384 rays with the sky model
+    intr, c2w, WH = look_at_cameras(V=20, seed=3, device=dev, radius=1.6)
+    sky = SimpleSky(n_appear_embedding=4, precision="fp16", seed=5).to(dev)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=16384, lr=1e-3, num_uniform=4096, sky_model=sky, learn_inv_s=False)
+    losses = [float(tr.train_step(300 + i)) for i in range(6)]
+    assert all(l == l and l < 1e3 for l in losses), losses
+    assert tr.stats["R_hit"] > 0
+
+
+def test_indoor_shaped_config_full_size():
+    """BASELINE configs[2]-shaped step (lotd_neus.replica.230814.yaml): ``inside_out`` geometry seen from inside, an
+    image patch of 64x64 rays next to flat pixel rays (16384 in total), normals and depth rendered WITH gradient for the
+    monocular losses (scale-shift-invariant depth, normal L1 + cos -- plain torch on the outputs, as in the reference)."""
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    dev = torch.device("cuda", 0)
+    m = LoTDNeuSModel(sdf_D=2, precision="fp16", ln_inv_s_init=0.5, inside_out=True, seed=6).to(dev)
+    m.geometric_init_sphere(0.8)
+    m.accel.init(m.query_sdf, generator=torch.Generator(device=dev).manual_seed(1))
+    g = torch.Generator(device=dev).manual_seed(3)
+    rend = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=0.01, depth_use_normalized_vw=True,
+                                     perturb=True)).train()
+
+    def rays(shape):
+        d = torch.nn.functional.normalize(torch.randn(*shape, 3, device=dev, generator=g), dim=-1)
+        o = (torch.rand(*shape, 3, device=dev, generator=g) - 0.5) * 0.2          # cameras near the centre of the room
+        return o, d
+    o_p, d_p = rays((64, 64))                                                      # image patch
+    o_f, d_f = rays((12288,))                                                      # + 12288 pixel rays = 16384
+    out_p = rend.render(m, rays=[o_p, d_p], return_buffer=True)
+    out_f = rend.render(m, rays=[o_f, d_f], return_buffer=True)
+    rp, rf = out_p["rendered"], out_f["rendered"]
+    assert rp["depth_volume"].shape == (64, 64) and rp["normals_volume"].shape == (64, 64, 3)
+    assert rf["rgb_volume"].shape == (12288, 3)
+    assert float(rf["mask_volume"].detach().mean()) > 0.95                               # every ray ends on the wall
+    hitp = o_f + rf["depth_volume"].detach()[:, None] * d_f
+    assert float((hitp.norm(dim=-1) - 0.8).abs().median()) < 0.05                  # ... at the sphere of radius 0.8
+    nv = torch.nn.functional.normalize(rf["normals_volume"].detach(), dim=-1)
+    assert float((nv * torch.nn.functional.normalize(hitp, dim=-1)).sum(-1).median()) < -0.8   # normals face the camera
+    # monocular-style losses on the patch (depth up to scale/shift, normals) + photometric on the flat rays
+    dp = rp["depth_volume"].reshape(-1)
+    tgt = (dp.detach() * 1.7 + 0.3) + 0.01 * torch.randn_like(dp)
+    A = torch.stack([dp, torch.ones_like(dp)], dim=-1)
+    sol = torch.linalg.lstsq(A.detach(), tgt[:, None]).solution
+    loss = ((A @ sol).squeeze(-1) - tgt).abs().mean()
+    n_hat = torch.nn.functional.normalize(rp["normals_volume"].reshape(-1, 3), dim=-1)
+    n_gt = torch.nn.functional.normalize(-(o_p + rp["depth_volume"].detach()[..., None] * d_p).reshape(-1, 3), dim=-1)
+    loss = loss + (n_hat - n_gt).abs().sum(-1).mean() + (1 - (n_hat * n_gt).sum(-1)).mean()
+    loss = loss + (rf["rgb_volume"] ** 2).mean()
+    loss.backward()
+    for p in (m.encoding.flattened_params, m.sdf_w, m.rad_w):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
