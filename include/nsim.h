@@ -98,15 +98,20 @@ int nsim_alpha_to_vw_fwd(const float* alpha, const int64_t* pack_infos, int64_t 
 int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw, const float* dvw,
                          const int64_t* pack_infos, int64_t P, float* dalpha, void* stream);
 /* Fused SingleVolumeRenderer._volume_integration (single_volume_renderer.py:73-102): alpha -> vw -> mask,
- * depth (optionally normalised), rgb, normals per ray.  rgb / nrm (and their outputs) may be NULL. */
+ * depth (optionally normalised), rgb, normals per ray.  rgb / nrm (and their outputs) may be NULL.
+ * out_idx [P] (may be NULL): row of the per-ray outputs that pack p writes / reads -- the scatter of the hit rays into
+ * the all-rays images (``rendered[k][rays_inds_hit] = ...``, :88-101) fused into the same launch; the caller zeroes
+ * the images. */
 int nsim_composite_fwd(const float* alpha, const float* t, const float* rgb, const float* nrm,
                        const int64_t* pack_infos, int64_t P, int normalized_depth, float* vw, float* trans,
-                       float* mask, float* depth, float* rgb_out, float* nrm_out, void* stream);
+                       float* mask, float* depth, float* rgb_out, float* nrm_out, const int64_t* out_idx,
+                       void* stream);
 int nsim_composite_bwd(const float* alpha, const float* trans, const float* vw, const float* t,
                        const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
                        int normalized_depth, const float* mask, const float* depth, const float* dmask,
                        const float* ddepth, const float* drgb_out, const float* dnrm_out,
-                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, void* stream);
+                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, const int64_t* out_idx,
+                       void* stream);
 /* NeuS sdf -> opacity (NeusRendererMixin): alpha_i for interval (i,i+1), 0 at the
  * last sample of each pack.  inv_s = exp(ln_inv_s[0] * ln_inv_s_factor) unless forward_inv_s > 0. */
 int nsim_neus_alpha_fwd(const float* sdf, const int64_t* pack_infos, int64_t P, const float* ln_inv_s,
@@ -333,6 +338,13 @@ int nsim_eikonal_loss_bwd(const float* nablas, int64_t S, const float* gout, flo
 int nsim_mse_loss_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);
 int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float* gout, float* dpred, void* stream);
 int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, int64_t rows, float* out, void* stream);
+/* Compaction of the AABB-tested rays, (o, d, near, far)[idx] -> [R,...] in one launch
+ * (model.ray_test, app/renderers/single_volume_renderer.py:235-238). */
+int nsim_gather_rays(const float* rays_o, const float* rays_d, const float* near, const float* far, const int64_t* idx,
+                     int64_t R, float* o_out, float* d_out, float* near_out, float* far_out, void* stream);
+/* Synthetic supervision of bench.py (no dataset in this environment): analytic image of a sphere of ``radius`` at the
+ * origin along unit rays -- rgb = 0.5 + 0.5 normal at the first hit, 0 elsewhere. */
+int nsim_sphere_image(const float* rays_o, const float* rays_d, int64_t N, float radius, float* rgb, void* stream);
 
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;

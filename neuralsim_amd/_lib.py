@@ -60,8 +60,8 @@ SIGNATURES = {
     "nsim_merge_two_packs": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
     "nsim_alpha_to_vw_fwd": [_P, _P, _I64, _P, _P],
     "nsim_alpha_to_vw_bwd": [_P, _P, _P, _P, _P, _I64, _P],
-    "nsim_composite_fwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P],
-    "nsim_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_composite_fwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_neus_alpha_fwd": [_P, _P, _I64, _P, _F, _F, _P],
     "nsim_neus_alpha_bwd": [_P, _P, _P, _I64, _P, _F, _F, _P, _P],
     "nsim_raygen_pinhole": [_P, _P, _P, _P, _P, _I64, _I, _P, _P],
@@ -100,6 +100,8 @@ SIGNATURES = {
     "nsim_mse_loss_fwd": [_P, _P, _I64, _P],
     "nsim_mse_loss_bwd": [_P, _P, _I64, _P, _P],
     "nsim_rows_scatter_add": [_P, _P, _I64, _I, _I64, _P],
+    "nsim_gather_rays": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "nsim_sphere_image": [_P, _P, _I64, _F, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }

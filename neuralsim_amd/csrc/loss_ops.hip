@@ -94,6 +94,43 @@ __global__ void __launch_bounds__(LOSS_BLOCK) k_rows_scatter_add(const float* __
   }
 }
 
+// analytic image of a sphere at the origin along unit rays: 0.5 + 0.5 n at the first hit, black elsewhere
+// (synthetic multi-view-consistent supervision of bench.py; one launch instead of ~10 elementwise torch ops)
+__global__ void __launch_bounds__(LOSS_BLOCK) k_sphere_image(const float* __restrict__ o, const float* __restrict__ d,
+                                                             int64_t N, float radius, float* __restrict__ rgb) {
+  const int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+  if (i >= N) return;
+  const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2];
+  const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+  const float b = ox * dx + oy * dy + oz * dz;
+  const float c = ox * ox + oy * oy + oz * oz - radius * radius;
+  const float disc = b * b - c;
+  const float t = -b - sqrtf(fmaxf(disc, 0.f));
+  const bool hit = disc > 0.f && t > 0.f;
+  const float inv = 1.0f / radius;
+  rgb[3 * i] = hit ? 0.5f + 0.5f * (ox + t * dx) * inv : 0.f;
+  rgb[3 * i + 1] = hit ? 0.5f + 0.5f * (oy + t * dy) * inv : 0.f;
+  rgb[3 * i + 2] = hit ? 0.5f + 0.5f * (oz + t * dz) * inv : 0.f;
+}
+
+// compaction of the AABB-tested rays: (o, d, near, far)[idx] in one launch (model.ray_test)
+__global__ void __launch_bounds__(LOSS_BLOCK) k_gather_rays(const float* __restrict__ o, const float* __restrict__ d,
+                                                            const float* __restrict__ near, const float* __restrict__ far,
+                                                            const int64_t* __restrict__ idx, int64_t R,
+                                                            float* __restrict__ o_out, float* __restrict__ d_out,
+                                                            float* __restrict__ near_out, float* __restrict__ far_out) {
+  const int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+  if (i >= R) return;
+  const int64_t r = idx[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o_out[3 * i + c] = o[3 * r + c];
+    d_out[3 * i + c] = d[3 * r + c];
+  }
+  near_out[i] = near[r];
+  far_out[i] = far[r];
+}
+
 static inline dim3 loss_grid(int64_t n) {
   int64_t b = nsim_blocks(n, LOSS_BLOCK);
   return dim3((unsigned)(b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : b));
@@ -150,6 +187,27 @@ int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, 
   if (!out) return 4;
   hipLaunchKernelGGL(k_rows_scatter_add, loss_grid(n * C), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, g, idx, n, C, rows,
                      out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_sphere_image(const float* rays_o, const float* rays_d, int64_t N, float radius, float* rgb, void* stream) {
+  if (N < 0) return 2;
+  if (N == 0) return 0;
+  if (!rgb || !(radius > 0.f)) return 4;
+  hipLaunchKernelGGL(k_sphere_image, dim3(nsim_blocks(N, LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, rays_o,
+                     rays_d, N, radius, rgb);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_gather_rays(const float* rays_o, const float* rays_d, const float* near, const float* far, const int64_t* idx,
+                     int64_t R, float* o_out, float* d_out, float* near_out, float* far_out, void* stream) {
+  if (R < 0) return 2;
+  if (R == 0) return 0;
+  if (!o_out || !d_out || !near_out || !far_out) return 4;
+  hipLaunchKernelGGL(k_gather_rays, dim3(nsim_blocks(R, LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, rays_o,
+                     rays_d, near, far, idx, R, o_out, d_out, near_out, far_out);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -288,11 +288,12 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_fwd(
     const float* __restrict__ alpha, const float* __restrict__ t, const float* __restrict__ rgb,
     const float* __restrict__ nrm, const int64_t* __restrict__ pi, int64_t P, int normalized_depth,
     float* __restrict__ vw, float* __restrict__ trans, float* __restrict__ mask, float* __restrict__ depth,
-    float* __restrict__ rgb_out, float* __restrict__ nrm_out) {
+    float* __restrict__ rgb_out, float* __restrict__ nrm_out, const int64_t* __restrict__ out_idx) {
   const int64_t p = pack_wave_id();
   if (p >= P) return;
   const int lane = nsim_lane();
   const int64_t st = pi[2 * p], n = pi[2 * p + 1];
+  const int64_t q = out_idx ? out_idx[p] : p;      // row of the per-ray outputs (scatter to all-rays images)
   float carry = 1.0f;
   float am = 0.f, ad = 0.f, ar[3] = {0.f, 0.f, 0.f}, an[3] = {0.f, 0.f, 0.f};
   for (int64_t base = 0; base < n; base += 64) {
@@ -324,10 +325,10 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_fwd(
   if (rgb) for (int c = 0; c < 3; ++c) ar[c] = wave_sum(ar[c]);
   if (nrm) for (int c = 0; c < 3; ++c) an[c] = wave_sum(an[c]);
   if (lane == 0) {
-    mask[p] = am;
-    depth[p] = normalized_depth ? ad / (am + 1e-10f) : ad;
-    if (rgb) for (int c = 0; c < 3; ++c) rgb_out[p * 3 + c] = ar[c];
-    if (nrm) for (int c = 0; c < 3; ++c) nrm_out[p * 3 + c] = an[c];
+    mask[q] = am;
+    depth[q] = normalized_depth ? ad / (am + 1e-10f) : ad;
+    if (rgb) for (int c = 0; c < 3; ++c) rgb_out[q * 3 + c] = ar[c];
+    if (nrm) for (int c = 0; c < 3; ++c) nrm_out[q * 3 + c] = an[c];
   }
 }
 
@@ -338,22 +339,23 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_bwd(
     const float* __restrict__ depth, const float* __restrict__ dmask, const float* __restrict__ ddepth,
     const float* __restrict__ drgb_out, const float* __restrict__ dnrm_out,
     const float* __restrict__ dvw_ext, float* __restrict__ dalpha, float* __restrict__ drgb,
-    float* __restrict__ dnrm) {
+    float* __restrict__ dnrm, const int64_t* __restrict__ out_idx) {
   const int64_t p = pack_wave_id();
   if (p >= P) return;
   const int lane = nsim_lane();
   const int64_t st = pi[2 * p], n = pi[2 * p + 1];
-  float gm = dmask ? dmask[p] : 0.f;
-  float gd = ddepth ? ddepth[p] : 0.f;
+  const int64_t q = out_idx ? out_idx[p] : p;
+  float gm = dmask ? dmask[q] : 0.f;
+  float gd = ddepth ? ddepth[q] : 0.f;
   if (normalized_depth) {
     // depth = D / (m + eps): dD = gd / (m+eps) ; dm += -gd * depth / (m+eps)
-    const float den = mask[p] + 1e-10f;
-    gm += -gd * depth[p] / den;
+    const float den = mask[q] + 1e-10f;
+    gm += -gd * depth[q] / den;
     gd = gd / den;
   }
   float gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
-  if (rgb && drgb_out) for (int c = 0; c < 3; ++c) gr[c] = drgb_out[p * 3 + c];
-  if (nrm && dnrm_out) for (int c = 0; c < 3; ++c) gn[c] = dnrm_out[p * 3 + c];
+  if (rgb && drgb_out) for (int c = 0; c < 3; ++c) gr[c] = drgb_out[q * 3 + c];
+  if (nrm && dnrm_out) for (int c = 0; c < 3; ++c) gn[c] = dnrm_out[q * 3 + c];
   float carry = 0.f;
   const int64_t nchunks = (n + 63) / 64;
   for (int64_t c = nchunks - 1; c >= 0; --c) {
@@ -582,11 +584,12 @@ int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw
 
 int nsim_composite_fwd(const float* alpha, const float* t, const float* rgb, const float* nrm,
                        const int64_t* pack_infos, int64_t P, int normalized_depth, float* vw, float* trans,
-                       float* mask, float* depth, float* rgb_out, float* nrm_out, void* stream) {
+                       float* mask, float* depth, float* rgb_out, float* nrm_out, const int64_t* out_idx,
+                       void* stream) {
   if (P <= 0) return 0;
   if (!vw || !trans || !mask || !depth) return 4;
   hipLaunchKernelGGL(k_composite_fwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, t, rgb, nrm,
-                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out);
+                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out, out_idx);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -595,11 +598,12 @@ int nsim_composite_bwd(const float* alpha, const float* trans, const float* vw, 
                        const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
                        int normalized_depth, const float* mask, const float* depth, const float* dmask,
                        const float* ddepth, const float* drgb_out, const float* dnrm_out,
-                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, void* stream) {
+                       const float* dvw_ext, float* dalpha, float* drgb, float* dnrm, const int64_t* out_idx,
+                       void* stream) {
   if (P <= 0) return 0;
   hipLaunchKernelGGL(k_composite_bwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, trans, vw, t, rgb,
                      nrm, pack_infos, P, normalized_depth, mask, depth, dmask, ddepth, drgb_out, dnrm_out, dvw_ext,
-                     dalpha, drgb, dnrm);
+                     dalpha, drgb, dnrm, out_idx);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

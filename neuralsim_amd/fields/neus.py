@@ -181,10 +181,12 @@ class _NeusAlphaFn(torch.autograd.Function):
 
 
 class _CompositeFn(torch.autograd.Function):
-    """Fused ``SingleVolumeRenderer._volume_integration`` (single_volume_renderer.py:73-102)."""
+    """Fused ``SingleVolumeRenderer._volume_integration`` (single_volume_renderer.py:73-102); with ``out_idx`` / ``N`` the
+    per-ray results are written straight into zero-filled all-rays images (the reference's
+    ``rendered[k][rays_inds_hit] = ...``) by the same launch."""
 
     @staticmethod
-    def forward(ctx, alpha, t, rgb, nrm, pack_infos, normalized_depth):
+    def forward(ctx, alpha, t, rgb, nrm, pack_infos, normalized_depth, out_idx=None, N=None):
         alpha = alpha.float().contiguous()
         t = t.float().contiguous()
         rgbc = rgb.float().contiguous() if rgb is not None else None
@@ -193,22 +195,29 @@ class _CompositeFn(torch.autograd.Function):
         dev = alpha.device
         vw = torch.empty_like(alpha)
         trans = torch.empty_like(alpha)
-        mask = torch.empty([P], dtype=torch.float32, device=dev)
-        depth = torch.empty([P], dtype=torch.float32, device=dev)
-        # written for every pack when the corresponding input is present
-        rgb_o = (torch.empty if rgbc is not None else torch.zeros)([P, 3], dtype=torch.float32, device=dev)
-        nrm_o = (torch.empty if nrmc is not None else torch.zeros)([P, 3], dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if out_idx is None:
+            mask, depth = torch.empty([P], **f32), torch.empty([P], **f32)
+            # written for every pack when the corresponding input is present
+            rgb_o = (torch.empty if rgbc is not None else torch.zeros)([P, 3], **f32)
+            nrm_o = (torch.empty if nrmc is not None else torch.zeros)([P, 3], **f32)
+        else:
+            sc = torch.zeros([2, N], **f32)
+            mask, depth = sc[0], sc[1]
+            vec = torch.zeros([2, N, 3], **f32)
+            rgb_o, nrm_o = vec[0], vec[1]
+            out_idx = out_idx.contiguous()
         _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgbc), _lib.ptr(nrmc),
                   _lib.ptr(pack_infos), P, int(normalized_depth), _lib.ptr(vw), _lib.ptr(trans), _lib.ptr(mask),
-                  _lib.ptr(depth), _lib.ptr(rgb_o), _lib.ptr(nrm_o))
-        ctx.save_for_backward(alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth)
+                  _lib.ptr(depth), _lib.ptr(rgb_o), _lib.ptr(nrm_o), _lib.ptr(out_idx))
+        ctx.save_for_backward(alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth, out_idx)
         ctx.nd = int(normalized_depth)
         ctx.mark_non_differentiable(trans)
         return vw, mask, depth, rgb_o, nrm_o, trans
 
     @staticmethod
     def backward(ctx, g_vw, g_mask, g_depth, g_rgb, g_nrm, _g_trans):
-        alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth = ctx.saved_tensors
+        alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth, out_idx = ctx.saved_tensors
         P = pack_infos.shape[0]
 
         def c(g):
@@ -219,12 +228,15 @@ class _CompositeFn(torch.autograd.Function):
         _lib.call("nsim_composite_bwd", _lib.ptr(alpha), _lib.ptr(trans), _lib.ptr(vw), _lib.ptr(t), _lib.ptr(rgbc),
                   _lib.ptr(nrmc), _lib.ptr(pack_infos), P, ctx.nd, _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(c(g_mask)),
                   _lib.ptr(c(g_depth)), _lib.ptr(c(g_rgb)), _lib.ptr(c(g_nrm)), _lib.ptr(c(g_vw)), _lib.ptr(dalpha),
-                  _lib.ptr(drgb), _lib.ptr(dnrm))
-        return dalpha, None, drgb, dnrm, None, None
+                  _lib.ptr(drgb), _lib.ptr(dnrm), _lib.ptr(out_idx))
+        return dalpha, None, drgb, dnrm, None, None, None, None
 
 
-def volume_integration(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw=False) -> Dict[str, torch.Tensor]:
-    vw, mask, depth, rgb_o, nrm_o, _ = _CompositeFn.apply(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw)
+def volume_integration(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw=False, rays_inds=None,
+                       num_rays: int = None) -> Dict[str, torch.Tensor]:
+    """``rays_inds`` [P] + ``num_rays``: results as zero-filled [num_rays, ...] images with pack p at row rays_inds[p]."""
+    vw, mask, depth, rgb_o, nrm_o, _ = _CompositeFn.apply(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw,
+                                                         rays_inds, num_rays)
     out = dict(vw=vw, mask_volume=mask, depth_volume=depth)
     if rgb is not None:
         out["rgb_volume"] = rgb_o
@@ -581,9 +593,17 @@ class LoTDNeuSModel(nn.Module):
         _lib.call("nsim_aabb_ray_test", _lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), N, self.accel.meta,
                   float(near) if near is not None else 0.0, float(far) if far is not None else -1.0, _lib.ptr(near_t),
                   _lib.ptr(far_t), _lib.ptr(hit))
-        rays_inds = hit.nonzero()[:, 0]     # host sync #1 (the reference compacts here as well)
-        ret = dict(num_rays=int(rays_inds.shape[0]), rays_inds=rays_inds, rays_o=rays_o[rays_inds],
-                   rays_d=rays_d[rays_inds], near=near_t[rays_inds], far=far_t[rays_inds])
+        rays_inds = hit.nonzero()[:, 0]     # host sync (the reference compacts here as well)
+        R = int(rays_inds.shape[0])
+        if rays_o.requires_grad or rays_d.requires_grad:        # keep the graph for callers that differentiate rays
+            ret = dict(num_rays=R, rays_inds=rays_inds, rays_o=rays_o[rays_inds], rays_d=rays_d[rays_inds],
+                       near=near_t[rays_inds], far=far_t[rays_inds])
+        else:
+            o_h, d_h = torch.empty([R, 3], dtype=torch.float32, device=dev), torch.empty([R, 3], dtype=torch.float32, device=dev)
+            n_h, f_h = torch.empty([R], dtype=torch.float32, device=dev), torch.empty([R], dtype=torch.float32, device=dev)
+            _lib.call("nsim_gather_rays", _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(near_t), _lib.ptr(far_t),
+                      _lib.ptr(rays_inds), R, _lib.ptr(o_h), _lib.ptr(d_h), _lib.ptr(n_h), _lib.ptr(f_h))
+            ret = dict(num_rays=R, rays_inds=rays_inds, rays_o=o_h, rays_d=d_h, near=n_h, far=f_h)
         for k, v in extra.items():
             if isinstance(v, torch.Tensor) and v.shape[:1] == (N,):
                 if v.requires_grad and v.dim() == 2 and v.dtype == torch.float32:

@@ -87,7 +87,7 @@ class SingleVolumeRenderer(nn.Module):
             far = config.get("far", None)
         N, device = rays_o.shape[0], rays_o.device
         total_num_samples_per_ray = torch.zeros(N, dtype=torch.long, device=device)
-        total_rendered = prepare_empty_rendered([N], device, with_rgb=with_rgb, with_normal=with_normal)
+        total_rendered = None       # all-rays images: written by the fused compositing, zero images only if nothing hit
 
         cr_ray_input = dict(rays_o=rays_o, rays_d=rays_d, near=near, far=far, rays_ts=rays_ts, rays_pix=rays_pix,
                             rays_h_appear=rays_h_appear)
@@ -169,8 +169,10 @@ class SingleVolumeRenderer(nn.Module):
             nab = tvb.get("nablas_in_world") if with_normal else None
             if nab is not None and not self.training:
                 nab = F.normalize(nab.clamp(-1, 1), dim=-1)
+            every_ray = rih.shape[0] == N          # rays_inds are sorted & unique: R == N means identity
             out = volume_integration(tvb["opacity_alpha"], tvb["t"], tvb.get("rgb") if with_rgb else None, nab, pih,
-                                     config.get("depth_use_normalized_vw", True))
+                                     config.get("depth_use_normalized_vw", True),
+                                     rays_inds=None if every_ray else rih, num_rays=None if every_ray else N)
             tvb["vw"] = out["vw"]
             if pidx_cr is not None:
                 vb["vw_in_total"], dv_vb["vw_in_total"] = out["vw"][pidx_cr], out["vw"][pidx_dv]
@@ -178,10 +180,12 @@ class SingleVolumeRenderer(nn.Module):
                 vb["vw"] = vb["vw_in_total"] = out["vw"]
             else:
                 dv_vb["vw_in_total"] = out["vw"]
-            every_ray = rih.shape[0] == N          # rays_inds are sorted & unique: R == N means identity
-            for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
-                if k in out and k in total_rendered:
-                    total_rendered[k] = out[k] if every_ray else total_rendered[k].index_put((rih,), out[k])
+            # already all-rays images (the scatter of the hit rays is fused into the compositing launch)
+            total_rendered = {k: out[k] for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume") if k in out}
+            if with_normal and "normals_volume" not in total_rendered:
+                total_rendered["normals_volume"] = torch.zeros([N, 3], dtype=torch.float32, device=device)
+        if total_rendered is None:
+            total_rendered = prepare_empty_rendered([N], device, with_rgb=with_rgb, with_normal=with_normal)
         # ---- sky model (reference :449-457): one query per ray, blended with the residual transmittance
         if with_rgb:
             total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]

@@ -78,13 +78,10 @@ class RenderTrainer:
     @staticmethod
     def sphere_image(o, d, radius: float):
         """Pixel colours of a sphere at the origin seen along unit rays (o, d): 0.5 + 0.5 n at the first hit, else 0."""
-        b = (o * d).sum(-1)
-        c = (o * o).sum(-1) - radius * radius
-        disc = b * b - c
-        t = -b - torch.sqrt(disc.clamp_min(0.0))
-        hit = (disc > 0) & (t > 0)
-        n = (o + t[:, None] * d) / radius
-        return torch.where(hit[:, None], 0.5 + 0.5 * n, torch.zeros_like(n))
+        gt = torch.empty_like(o)
+        _lib.call("nsim_sphere_image", _lib.ptr(o.contiguous()), _lib.ptr(d.contiguous()), o.shape[0], float(radius),
+                  _lib.ptr(gt))
+        return gt
 
     def render(self, xy, fidx, with_normal=True, extra_pts=None, batch: dict = None):
         """rays -> SingleVolumeRenderer (ray_test, ray_query, [distant model + merge], volume integration).
