@@ -94,6 +94,9 @@ class RenderTrainer:
             rays_o, rays_d, tested = batch["rays_o"], batch["rays_d"], dict(batch["tested"])
             if self.pipeline:
                 bypass["_pre_sync_hook"] = self._prefetch
+            if self.perturb:        # the batch's pre-drawn uniforms (rows 0..R-1 for the R hit rays)
+                R = tested["num_rays"]
+                bypass["_jitter"], bypass["_jitter_c"] = batch["jitter"][:R], batch["jitter_c"][:R]
         elif self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
@@ -110,8 +113,16 @@ class RenderTrainer:
         return ret
 
     def _make_batch(self) -> dict:
-        """sample_batch + ray generation + the AABB test (with its hit-ray compaction sync) of one batch."""
+        """sample_batch + ray generation + the AABB test (with its hit-ray compaction sync) of one batch, plus -- in
+        ONE generator call -- the step's other uniforms: marching jitter [N], coarse-depth jitter [N, C] (the first R
+        rows serve the R hit rays) and the uniform eikonal points [M, 3]."""
         xy, fidx, gt = self.sample_batch()
+        dev, N, M = self.model.device, self.num_rays, self.num_uniform
+        C = int(self.model.ray_query_cfg.get("query_param", {}).get("num_coarse", 64))
+        rnd = torch.rand([N * (1 + C) + 3 * M], device=dev, generator=self.gen)
+        lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
+        extras = dict(jitter=rnd[:N], jitter_c=rnd[N:N * (1 + C)].view(N, C),
+                      x_uni=torch.addcmul(lo, rnd[N * (1 + C):].view(M, 3), hi - lo) if M > 0 else None)
         if self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
@@ -119,7 +130,7 @@ class RenderTrainer:
         with torch.no_grad():
             tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
         return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested,
-                    fidx_hit=fidx[tested["rays_inds"]])
+                    fidx_hit=fidx[tested["rays_inds"]], **extras)
 
     def _prefetch(self):
         if self._prefetched is None:
@@ -163,7 +174,10 @@ class RenderTrainer:
             xy, fidx, gt = self.sample_batch()
         # the uniform eikonal points (train.py:602-613) ride on the render's field launches as zero-length rays: a
         # separate 4096-point launch chain costs ~0.2 ms of fixed latency (fwd + two backward kernels + scatter)
-        x_uni = self.sample_uniform_x() if self.num_uniform > 0 else None
+        if batch is not None:
+            x_uni = batch["x_uni"]
+        else:
+            x_uni = self.sample_uniform_x() if self.num_uniform > 0 else None
         ret = self.render(xy, fidx, extra_pts=x_uni, batch=batch)
         uni = None
         if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
