@@ -35,7 +35,10 @@ def get_pack_infos_from_n(n: torch.Tensor, return_total: bool = False, cap: int 
 
 def _as2d(x):
     S = x.shape[0]
-    return x.reshape(S, -1), x.shape[1:]
+    C = 1
+    for v in x.shape[1:]:
+        C *= int(v)
+    return x.reshape(S, C), x.shape[1:]        # explicit C: reshape(0, -1) is ambiguous for an empty buffer
 
 
 def _binary(x2, per_pack2, pack_infos, op):
@@ -71,7 +74,7 @@ class _PackedSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (pack_infos,) = ctx.saved_tensors
-        g2 = _f32c(g).reshape(pack_infos.shape[0], -1)
+        g2 = _f32c(g).reshape(pack_infos.shape[0], max(1, g.numel() // max(1, pack_infos.shape[0])))
         dx = torch.zeros([ctx.S, g2.shape[1]], dtype=torch.float32, device=g.device)
         _lib.call("nsim_packed_binary", None, g2.shape[1], _lib.ptr(g2), g2.shape[1], _lib.ptr(pack_infos),
                   pack_infos.shape[0], 0, _lib.ptr(dx))
@@ -96,7 +99,7 @@ class _PackedBinary(torch.autograd.Function):
     def forward(ctx, x, per_pack, pack_infos, op):
         x2, tail = _as2d(_f32c(x))
         P = pack_infos.shape[0]
-        pp2 = _f32c(per_pack).reshape(P, -1)
+        pp2 = _f32c(per_pack).reshape(P, max(1, per_pack.numel() // max(1, P)))
         pack_infos = pack_infos.contiguous()
         out = torch.zeros_like(x2)
         _lib.call("nsim_packed_binary", _lib.ptr(x2), x2.shape[1], _lib.ptr(pp2), pp2.shape[1], _lib.ptr(pack_infos), P,
