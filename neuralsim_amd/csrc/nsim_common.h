@@ -96,8 +96,28 @@ __device__ __forceinline__ T wave_incl_prod(T v) {
   return v;
 }
 
+// Wave-wide reductions.  On the device the float versions stay in the VALU: four DPP steps reduce every row of 16
+// lanes (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror), four v_readlane + scalar-side combine finish across
+// rows -- ~10 issue slots, against six dependent ds_bpermute round trips (~100 cycles each) for the shuffle tree.
+#ifndef NSIM_HOST_EMU
+#define NSIM_DPP_F32(x, ctrl) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float nsim_readlane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+#endif
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
+#ifndef NSIM_HOST_EMU
+  if constexpr (__is_same(T, float)) {
+    v += NSIM_DPP_F32(v, 0xB1);
+    v += NSIM_DPP_F32(v, 0x4E);
+    v += NSIM_DPP_F32(v, 0x141);
+    v += NSIM_DPP_F32(v, 0x140);
+    return (nsim_readlane_f32(v, 0) + nsim_readlane_f32(v, 16)) + (nsim_readlane_f32(v, 32) + nsim_readlane_f32(v, 48));
+  }
+#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += wave_shfl_xor(v, o);
   return v;
@@ -105,6 +125,16 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 template <class T>
 __device__ __forceinline__ T wave_max(T v) {
+#ifndef NSIM_HOST_EMU
+  if constexpr (__is_same(T, float)) {
+    v = fmaxf(v, NSIM_DPP_F32(v, 0xB1));
+    v = fmaxf(v, NSIM_DPP_F32(v, 0x4E));
+    v = fmaxf(v, NSIM_DPP_F32(v, 0x141));
+    v = fmaxf(v, NSIM_DPP_F32(v, 0x140));
+    return fmaxf(fmaxf(nsim_readlane_f32(v, 0), nsim_readlane_f32(v, 16)),
+                 fmaxf(nsim_readlane_f32(v, 32), nsim_readlane_f32(v, 48)));
+  }
+#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     T u = wave_shfl_xor(v, o);
