@@ -73,9 +73,28 @@ __device__ __forceinline__ T quad_bcast(T v) {
 #endif
 }
 
-// inclusive scans across the 64 lanes (Hillis-Steele over shuffles)
+// inclusive scans across the 64 lanes.  Device, float: DPP row_shr 1/2/4/8 scans every row of 16, row_bcast15 /
+// row_bcast31 carry the row totals forward (lanes without a source keep the identity) -- six VALU steps, no LDS
+// crossbar.  Other types / the host emulator: Hillis-Steele over shuffles.
+#ifndef NSIM_HOST_EMU
+#define NSIM_DPP_OLD_F32(oldv, x, ctrl, rmask)                                                              \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(oldv)),             \
+                                                        __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+#endif
+
 template <class T>
 __device__ __forceinline__ T wave_incl_sum(T v) {
+#ifndef NSIM_HOST_EMU
+  if constexpr (__is_same(T, float)) {
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x111, 0xf);
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x112, 0xf);
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x114, 0xf);
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x118, 0xf);
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3
+    v += NSIM_DPP_OLD_F32(0.f, v, 0x143, 0xc);   // row_bcast31 into rows 2 and 3
+    return v;
+  }
+#endif
   const int lane = nsim_lane();
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -87,6 +106,17 @@ __device__ __forceinline__ T wave_incl_sum(T v) {
 
 template <class T>
 __device__ __forceinline__ T wave_incl_prod(T v) {
+#ifndef NSIM_HOST_EMU
+  if constexpr (__is_same(T, float)) {
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x111, 0xf);
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x112, 0xf);
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x114, 0xf);
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x118, 0xf);
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x142, 0xa);
+    v *= NSIM_DPP_OLD_F32(1.f, v, 0x143, 0xc);
+    return v;
+  }
+#endif
   const int lane = nsim_lane();
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
