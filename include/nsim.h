@@ -186,7 +186,7 @@ int nsim_lotd_bwd(const float* x, const float* dL_dout, const float* dL_ddydx, c
 /* Network description (host struct).  LoTDNeuSModel = LoTDSDF + RadianceNet
  * (app/models/single/neus.py:24-62; lotd_neus.dtu.230814.yaml:92-139). */
 typedef struct NsimFieldMeta {
-  NsimLotdMeta lotd;     /* must have 16 levels x 2 feats = 32 input features */
+  NsimLotdMeta lotd;     /* 1..16 levels x 2 feats (<= 32 input features; W1 is [64 x 2 num_levels]) */
   int32_t sdf_D;         /* hidden layers of the SDF decoder: 1 or 2 (width 64, softplus beta) */
   int32_t precision;     /* 0: fp16 MFMA (v_mfma_f32_32x32x16_f16), 1: exact f32 MFMA (32x32x2 f32) */
   float softplus_beta;   /* 100 */
@@ -195,7 +195,7 @@ typedef struct NsimFieldMeta {
 /* size in bytes of the packed-fragment weight buffer for a given meta */
 int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta);
 /* Re-pack f32 master weights into MFMA A-fragment order (once per optimizer step).
- * sdf_w: [W1 (64x32), (W2 (64x64)), Wout (1x64)] concatenated row-major; sdf_b likewise [64,(64),1];
+ * sdf_w: [W1 (64 x 2 num_levels), (W2 (64x64)), Wout (1x64)] concatenated row-major; sdf_b likewise [64,(64),1];
  * rad_w: [Wr1 (64x26), Wr2 (64x64), Wr3 (3x64)], rad_b [64,64,3]. */
 int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b,
                             const float* rad_w, const float* rad_b, void* wpack, void* stream);

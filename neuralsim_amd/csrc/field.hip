@@ -65,11 +65,12 @@ struct SrcOff {
   int r1, r2, r3, rb1, rb2, rb3;
   int n_sdf_w, n_sdf_b, n_rad_w, n_rad_b;
 };
-__host__ __device__ inline SrcOff src_off(int D) {
+// F1 = 2 * num_levels: width of the decoder input (<= 32; pyramids with fewer than 16 levels leave columns unused)
+__host__ __device__ inline SrcOff src_off(int D, int F1 = 32) {
   SrcOff o;
   o.w1 = 0;
-  o.w2 = 2048;
-  o.wh = (D == 2) ? 2048 + 4096 : 2048;
+  o.w2 = 64 * F1;
+  o.wh = (D == 2) ? 64 * F1 + 4096 : 64 * F1;
   o.n_sdf_w = o.wh + 64;
   o.b1 = 0;
   o.b2 = 64;
@@ -88,13 +89,14 @@ __host__ __device__ inline SrcOff src_off(int D) {
 
 
 // ------------------------------------------------------------------------------------ weight packing
-__device__ __forceinline__ float pack_src(int mat, int row, int col, int D, const float* sdf_w, const float* rad_w) {
-  const SrcOff o = src_off(D);
+__device__ __forceinline__ float pack_src(int mat, int row, int col, int D, int F1, const float* sdf_w,
+                                          const float* rad_w) {
+  const SrcOff o = src_off(D, F1);
   switch (mat) {
-    case M_W1: return sdf_w[o.w1 + row * 32 + col];
+    case M_W1: return col < F1 ? sdf_w[o.w1 + row * F1 + col] : 0.f;
     case M_W2: return D == 2 ? sdf_w[o.w2 + row * 64 + col] : 0.f;
     case M_W2T: return D == 2 ? sdf_w[o.w2 + col * 64 + row] : 0.f;
-    case M_W1T: return sdf_w[o.w1 + col * 32 + row];
+    case M_W1T: return row < F1 ? sdf_w[o.w1 + col * F1 + row] : 0.f;
     case M_R1: return col < 26 ? rad_w[o.r1 + row * 26 + col] : 0.f;
     case M_R2: return rad_w[o.r2 + row * 64 + col];
     case M_R3: return row < 3 ? rad_w[o.r3 + row * 64 + col] : 0.f;
@@ -109,7 +111,7 @@ struct PackDims {
   int uo[M_COUNT], ui[M_COUNT];
 };
 
-__global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims, int D, const float* __restrict__ sdf_w,
+__global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims, int D, int F1, const float* __restrict__ sdf_w,
                                                      const float* __restrict__ sdf_b, const float* __restrict__ rad_w,
                                                      const float* __restrict__ rad_b, char* __restrict__ wpack) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
         const int mo = fs / nS, s = fs % nS;
         row = 32 * mo + (lane & 31);
         col = 16 * s + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        ((f16*)(wpack + L.mat[m]))[k] = (f16)pack_src(m, row, col, D, sdf_w, rad_w);
+        ((f16*)(wpack + L.mat[m]))[k] = (f16)pack_src(m, row, col, D, F1, sdf_w, rad_w);
       } else {
         const int lane = (int)(k & 63);
         const int fr = (int)(k >> 6);
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
         const int mo = fm / nMi, mi = fm % nMi;
         row = 32 * mo + (lane & 31);
         col = unit_of(mi, r, lane >> 5);
-        ((float*)(wpack + L.mat[m]))[k] = pack_src(m, row, col, D, sdf_w, rad_w);
+        ((float*)(wpack + L.mat[m]))[k] = pack_src(m, row, col, D, F1, sdf_w, rad_w);
       }
       return;
     }
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
     const int v = (int)(vtid >> 6), k = (int)(vtid & 63);
     const int hi = k >> 5, m = (k >> 4) & 1, r = k & 15;
     const int u = unit_of(m, r, hi);
-    const SrcOff o = src_off(D);
+    const SrcOff o = src_off(D, F1);
     float val = 0.f;
     switch (v) {
       case V_B1: val = sdf_b[o.b1 + u]; break;
@@ -661,7 +663,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 
   if constexpr (MODE == 2) {
     __syncthreads();
-    const SrcOff so = src_off(SDF_D);
+    const int F1 = 2 * a.lotd.num_levels;
+    const SrcOff so = src_off(SDF_D, F1);
     for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
       float v;
       if constexpr (PRIV) {      // sum the four private copies
@@ -674,8 +677,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       }
       if (v == 0.f) continue;
       float* dst = nullptr;
-      if (i < AO.w2) dst = a.dsdf_w + so.w1 + (i - AO.w1);
-      else if (i < AO.wh) dst = (SDF_D == 2) ? a.dsdf_w + so.w2 + (i - AO.w2) : nullptr;
+      if (i < AO.w2) {           // accumulator rows are 32 wide, the parameter rows F1 (<= 32) wide
+        const int row = (i - AO.w1) >> 5, col = (i - AO.w1) & 31;
+        dst = col < F1 ? a.dsdf_w + so.w1 + row * F1 + col : nullptr;
+      } else if (i < AO.wh) dst = (SDF_D == 2) ? a.dsdf_w + so.w2 + (i - AO.w2) : nullptr;
       else if (i < AO.b1) dst = a.dsdf_w + so.wh + (i - AO.wh);
       else if (i < AO.b2) dst = a.dsdf_b + so.b1 + (i - AO.b1);
       else if (i < AO.bh) dst = (SDF_D == 2) ? a.dsdf_b + so.b2 + (i - AO.b2) : nullptr;
@@ -1214,7 +1219,7 @@ static int field_meta_check(const NsimFieldMeta* m) {
   if (!m) return 20;
   const int rc = lotd_meta_check(&m->lotd);
   if (rc) return rc;
-  if (m->lotd.num_levels != 16) return 21;
+  if (m->lotd.num_levels < 1 || m->lotd.num_levels > 16) return 21;
   if (m->sdf_D != 1 && m->sdf_D != 2) return 22;
   if (m->precision != 0 && m->precision != 1) return 23;
   return 0;
@@ -1286,7 +1291,7 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   }
   total += (int64_t)V_COUNT * 64;
   hipLaunchKernelGGL(k_field_pack, dim3(nsim_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, L, dims,
-                     meta->sdf_D, sdf_w, sdf_b, rad_w, rad_b, (char*)wpack);
+                     meta->sdf_D, 2 * meta->lotd.num_levels, sdf_w, sdf_b, rad_w, rad_b, (char*)wpack);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

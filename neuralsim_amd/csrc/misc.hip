@@ -27,7 +27,7 @@ const char* nsim_strerror(int code) {
     case 31: return "sky input width 3 + 6 n_frequencies + n_appear must be <= 96";
     case 32: return "sky model with n_appear > 0 needs h_appear";
     case 20: return "field meta is NULL";
-    case 21: return "fused field kernels need exactly 16 LoTD levels (32 features)";
+    case 21: return "fused field kernels take 1..16 LoTD levels (<= 32 input features)";
     case 22: return "sdf_D must be 1 or 2";
     case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";
     case 24: return "need either x or (rays_o, rays_d, t, ridx)";

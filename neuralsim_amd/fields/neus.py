@@ -30,8 +30,8 @@ DEFAULT_LOD_RES = [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 10
 RAD_IN = 26
 
 
-def _flat_sizes(D: int):
-    n_sdf_w = 64 * 32 + (64 * 64 if D == 2 else 0) + 64
+def _flat_sizes(D: int, L: int = 16):
+    n_sdf_w = 64 * 2 * L + (64 * 64 if D == 2 else 0) + 64
     n_sdf_b = 64 * D + 1
     n_rad_w = 64 * RAD_IN + 64 * 64 + 3 * 64
     n_rad_b = 131
@@ -119,7 +119,7 @@ class _FieldFn(torch.autograd.Function):
             if g_rgb is not None:
                 g_rgb = join(g_rgb, None, (3,))
         grid16, wpack = model._shadow()
-        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D)
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
         need = ctx.needs_input_grad
         dgrid = torch.zeros([model.encoding.flattened_params.numel()], dtype=torch.float32, device=dev) if need[1] else None
         # one memset for the four small accumulators
@@ -344,17 +344,17 @@ class LoTDNeuSModel(nn.Module):
         assert W == 64 and sdf_D in (1, 2), "gfx950 fused kernels: hidden width 64, 1 or 2 hidden SDF layers"
         self.sdf_scale, self.inside_out = float(sdf_scale), bool(inside_out)
         lod_res = list(lod_res) if lod_res is not None else list(DEFAULT_LOD_RES)
-        assert len(lod_res) == 16, "gfx950 fused kernels: 16 levels x 2 features"
+        assert 1 <= len(lod_res) <= 16, "gfx950 fused kernels: up to 16 levels x 2 features (32 decoder inputs)"
         self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
         self.encoding = LoTDEncoding(LoTDConfig(lod_res, 2, log2_hashmap_size), bound=param_bound, seed=seed)
-        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D)
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D, len(lod_res))
         g = torch.Generator().manual_seed(seed + 1)
 
         def lin(o, i, scale=1.0):
             b = 1.0 / math.sqrt(i)
             return ((torch.rand(o, i, generator=g) * 2 - 1) * b * scale, (torch.rand(o, generator=g) * 2 - 1) * b * scale)
         ws, bs = [], []
-        dims = [32] + [64] * sdf_D + [1]
+        dims = [2 * len(lod_res)] + [64] * sdf_D + [1]
         for li in range(len(dims) - 1):
             w, b = lin(dims[li + 1], dims[li])
             ws.append(w.reshape(-1))
@@ -470,14 +470,15 @@ class LoTDNeuSModel(nn.Module):
         lvl = self.encoding.flattened_params.data[cfg.lod_offsets[lv]: cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2].view(-1, 2)
         lvl[:, 0] = sdf.half().float().to(lvl.device)
         D = self.sdf_D
-        w1 = self.sdf_w.data[:2048].view(64, 32)
+        F1 = 2 * cfg.num_levels
+        w1 = self.sdf_w.data[:64 * F1].view(64, F1)
         w1.mul_(noise_scale)
         w1[0].zero_()
         w1[0, 2 * lv] = 1.0
         self.sdf_b.data[:64].mul_(noise_scale)
         self.sdf_b.data[0] = 2.0 * self.sdf_scale      # keeps the pass-through unit in softplus' linear region
         if D == 2:
-            w2 = self.sdf_w.data[2048:2048 + 4096].view(64, 64)
+            w2 = self.sdf_w.data[64 * F1:64 * F1 + 4096].view(64, 64)
             w2.mul_(noise_scale)
             w2[0].zero_()
             w2[0, 0] = 1.0

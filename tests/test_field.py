@@ -239,3 +239,49 @@ def test_anneal_schedule():
     assert m.anneal_levels(0, 0, 1000, 2) == 3 and m.field_meta.lotd.n_active_levels == 3
     assert m.anneal_levels(500, 0, 1000, 2) == 9
     assert m.anneal_levels(1000, 0, 1000, 2) == 16 and m.field_meta.lotd.n_active_levels == 0    # 0 = all
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_field_fewer_than_16_levels(backend, precision):
+    """Pyramids with fewer than 16 levels (decoder input 2 L < 32): values, normals, colours and all gradients."""
+    from oracle import lotd as olotd
+    lod_res = list(SMALL_RES_T[:11])
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=2, seed=7, sphere_init=False,
+                                 grid_bound=0.3, noise_scale=1.0)
+    p.grid = p.grid.float()
+    for t in p.tensors():
+        t.requires_grad_(True)
+    assert p.sdf_w[0].shape == (64, 22)
+    model = model_from_params(p, backend, precision=precision)
+    assert model.sdf_w.numel() == 64 * 22 + 4096 + 64
+    g = torch.Generator().manual_seed(2)
+    R, S = 6, 100
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    dv = lambda a: a.to(backend).contiguous()
+    ha_d = leaf(h_appear, backend)
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    tol = dict(f32=(2e-5, 2e-4, 2e-5, 2e-4), fp16=(4e-3, 5e-2, 4e-3, 3e-2))[precision]
+    assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < tol[1] * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < tol[2]
+    for fused in (False, True):
+        model._sdf_fused = fused
+        assert torch.allclose(model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu(), sdf.cpu().detach(),
+                              atol=2e-6)
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < tol[3], (k, e)
