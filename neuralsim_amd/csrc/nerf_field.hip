@@ -278,24 +278,30 @@ struct NerfArgs {
 
 #define NERF_WAVES 4
 
-template <int PREC>
-__device__ __forceinline__ const char* nerf_stage_weights(char* smem, const NerfArgs& a, int& used) {
+// Stage the pack into LDS (fp16 mode): everything, or -- VEC_ONLY -- just the per-lane vectors (the matrices are then
+// read from L2, which frees LDS for private weight-gradient accumulators).  Returns the base the VECTORS are addressed
+// from: nvec() uses offsets relative to lay.vec[0].
+template <int PREC, bool VEC_ONLY>
+__device__ __forceinline__ const char* nerf_stage_weights(char* smem, const NerfArgs& a, int& used, const char*& WM) {
   if constexpr (PREC == 0) {
-    const int n16 = (int)(a.lay.total >> 4);
-    const f16x8* src = reinterpret_cast<const f16x8*>(a.wpack);
+    const int64_t first = VEC_ONLY ? a.lay.vec[0] : 0;
+    const int n16 = (int)((a.lay.total - first + 15) >> 4);
+    const f16x8* src = reinterpret_cast<const f16x8*>(a.wpack + first);
     f16x8* dst = reinterpret_cast<f16x8*>(smem);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-    used = (int)((a.lay.total + 15) & ~15);
+    used = n16 << 4;
     __syncthreads();
-    return smem;
+    WM = VEC_ONLY ? a.wpack : smem;
+    return VEC_ONLY ? smem : smem + a.lay.vec[0];
   } else {
     used = 0;
-    return a.wpack;
+    WM = a.wpack;
+    return a.wpack + a.lay.vec[0];
   }
 }
 
-__device__ __forceinline__ float nvec(const char* W, const NerfLayout& L, int v, int hi, int k) {
-  return reinterpret_cast<const float*>(W + L.vec[v])[hi * 32 + k];
+__device__ __forceinline__ float nvec(const char* WV, const NerfLayout& L, int v, int hi, int k) {
+  return reinterpret_cast<const float*>(WV + (L.vec[v] - L.vec[0]))[hi * 32 + k];
 }
 
 // radiance input, second M-tile (slots 32..63): SH-4 of the view direction, appearance code, zero padding
@@ -357,14 +363,20 @@ __device__ __forceinline__ NerfPoint nerf_point(const NerfArgs& a, int64_t tile,
 
 __device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// fp16 backward: three waves per workgroup, each with a PRIVATE copy of the weight-gradient accumulators in LDS
+// (plain read-add-write -- LDS float atomics cost ~800 cycles per instruction, mfma_mlp.h:dw_flush), matrices from L2.
+#define NERF_WAVES_PRIV 3
 template <int PREC, int BWD>
-__global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
+__global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : NERF_WAVES)) k_nerf(NerfArgs a) {
   NSIM_DYN_SMEM(smem);
+  constexpr bool PRIV = (PREC == 0 && BWD);
+  constexpr int NW = PRIV ? NERF_WAVES_PRIV : NERF_WAVES;
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
   const NerfLayout& L = a.lay;
   int wbytes;
-  const char* W = nerf_stage_weights<PREC>(smem, a, wbytes);
+  const char* WM;
+  const char* W = nerf_stage_weights<PREC, PRIV>(smem, a, wbytes, WM);
   // LDS accumulators (backward): D1 [64x32], DWH [64], DB1 [64], bd [4], Q1 [64x64], Q2 [64x64], Q3 [3x64], RB1, RB2, RB3
   constexpr int A_D1 = 0, A_DWH = 2048, A_DB1 = 2112, A_BD = 2176, A_Q1 = 2180, A_Q2 = A_Q1 + 4096, A_Q3 = A_Q2 + 4096,
                 A_RB1 = A_Q3 + 192, A_RB2 = A_RB1 + 64, A_RB3 = A_RB2 + 64, A_TOTAL = A_RB3 + 4;
@@ -372,17 +384,22 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
   char* stA = nullptr;
   char* stB = nullptr;
   if constexpr (BWD) {
-    accum = reinterpret_cast<float*>(smem + wbytes);
-    char* stbase = smem + wbytes + ((A_TOTAL * 4 + 15) & ~15) + wave * stage_bytes_per_wave<PREC>();
+    constexpr int ACC_BYTES = (A_TOTAL * 4 + 15) & ~15;
+    accum = reinterpret_cast<float*>(smem + wbytes + (PRIV ? wave * ACC_BYTES : 0));
+    char* stbase = smem + wbytes + (PRIV ? NW : 1) * ACC_BYTES + wave * stage_bytes_per_wave<PREC>();
     stA = stbase;
     stB = stbase + stage_bytes_per_wave<PREC>() / 2;
-    for (int i = threadIdx.x; i < A_TOTAL; i += blockDim.x) accum[i] = 0.f;
+    if constexpr (PRIV) {
+      for (int i = lane; i < A_TOTAL; i += 64) accum[i] = 0.f;
+    } else {
+      for (int i = threadIdx.x; i < A_TOTAL; i += blockDim.x) accum[i] = 0.f;
+    }
     __syncthreads();
   }
-  const float b_d = reinterpret_cast<const float*>(W + L.vec[NV_SCAL])[0];
+  const float b_d = reinterpret_cast<const float*>(W + (L.vec[NV_SCAL] - L.vec[0]))[0];
   const int64_t ntiles = (a.S + 31) / 32;
-  const int64_t wstride = (int64_t)gridDim.x * NERF_WAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * NERF_WAVES + wave; tile < ntiles; tile += wstride) {
+  const int64_t wstride = (int64_t)gridDim.x * NW;
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += wstride) {
     const NerfPoint p = nerf_point(a, tile, j);
     const int64_t s = p.s;
     // -------------------------------------------------------------- features: gather (forward) or planes (backward)
@@ -446,14 +463,14 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
     nerf_rin_tail(rin, p.vd, p.ha, hi);
     // -------------------------------------------------------------- density + radiance forward
     float a1[32];
-    dense<PREC, 2, 1>(a1, W + L.mat[N_D1], h, true);
+    dense<PREC, 2, 1>(a1, WM + L.mat[N_D1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = fmaxf(a1[k] + nvec(W, L, NV_DB1, hi, k), 0.f);
     float r1[32], r2[32];
-    dense<PREC, 2, 2>(r1, W + L.mat[N_Q1], rin, true);
+    dense<PREC, 2, 2>(r1, WM + L.mat[N_Q1], rin, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) r1[k] = fmaxf(r1[k] + nvec(W, L, NV_RB1, hi, k), 0.f);
-    dense<PREC, 2, 2>(r2, W + L.mat[N_Q2], r1, false);
+    dense<PREC, 2, 2>(r2, WM + L.mat[N_Q2], r1, false);
 #pragma unroll
     for (int k = 0; k < 32; ++k) r2[k] = fmaxf(r2[k] + nvec(W, L, NV_RB2, hi, k), 0.f);
     if constexpr (!BWD) {
@@ -462,7 +479,7 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
       for (int k = 0; k < 32; ++k) raw = raw + nvec(W, L, NV_DWH, hi, k) * a1[k];
       raw = raw + wave_shfl_xor(raw, 32) + b_d;
       float o3[16];
-      dense<PREC, 1, 2>(o3, W + L.mat[N_Q3], r2, false);
+      dense<PREC, 1, 2>(o3, WM + L.mat[N_Q3], r2, false);
       if (p.valid && hi == 0) {
         a.sigma[s] = softplus1(raw);
 #pragma unroll
@@ -489,19 +506,19 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
       }
-      dw_product<PREC, 1, 2>(stA, stB, dout, r2, accum + A_Q3, 64, 3, 64, accum + A_RB3);
+      dw_product<PREC, 1, 2, PRIV>(stA, stB, dout, r2, accum + A_Q3, 64, 3, 64, accum + A_RB3);
       float dr2[32];
-      dense<PREC, 2, 1>(dr2, W + L.mat[N_Q3T], dout, true);
+      dense<PREC, 2, 1>(dr2, WM + L.mat[N_Q3T], dout, true);
 #pragma unroll
       for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
-      dw_product<PREC, 2, 2>(stA, stB, dr2, r1, accum + A_Q2, 64, 64, 64, accum + A_RB2);
+      dw_product<PREC, 2, 2, PRIV>(stA, stB, dr2, r1, accum + A_Q2, 64, 64, 64, accum + A_RB2);
       float dr1[32];
-      dense<PREC, 2, 2>(dr1, W + L.mat[N_Q2T], dr2, true);
+      dense<PREC, 2, 2>(dr1, WM + L.mat[N_Q2T], dr2, true);
 #pragma unroll
       for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
-      dw_product<PREC, 2, 2>(stA, stB, dr1, rin, accum + A_Q1, 64, 64, 64, accum + A_RB1);
+      dw_product<PREC, 2, 2, PRIV>(stA, stB, dr1, rin, accum + A_Q1, 64, 64, 64, accum + A_RB1);
       float din[32];
-      dense<PREC, 2, 2>(din, W + L.mat[N_Q1T], dr1, true);
+      dense<PREC, 2, 2>(din, WM + L.mat[N_Q1T], dr1, true);
       // appearance slots 48..51 = second M-tile local 16..19: (hi0: r8..11 -> 16..19)
       if (a.dh_appear && p.valid && hi == 0) {
 #pragma unroll
@@ -515,15 +532,18 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
         whv[k] = draw * a1[k];
         da[k] = a1[k] > 0.f ? draw * nvec(W, L, NV_DWH, hi, k) : 0.f;
       }
-      rowsum_acc<PREC, 2>(stA, whv, accum + A_DWH, 64);
+      rowsum_acc<PREC, 2, PRIV>(stA, whv, accum + A_DWH, 64);
       {
         float v = (hi == 0) ? draw : 0.f;
         v = wave_sum(v);
-        if (lane == 0 && v != 0.f) atomicAdd(&accum[A_BD], v);
+        if (lane == 0 && v != 0.f) {
+          if constexpr (PRIV) accum[A_BD] = accum[A_BD] + v;
+          else atomicAdd(&accum[A_BD], v);
+        }
       }
-      dw_product<PREC, 2, 1>(stA, stB, da, h, accum + A_D1, 32, 64, 32, accum + A_DB1);
+      dw_product<PREC, 2, 1, PRIV>(stA, stB, da, h, accum + A_D1, 32, 64, 32, accum + A_DB1);
       float dh[16];
-      dense<PREC, 1, 2>(dh, W + L.mat[N_D1T], da, true);
+      dense<PREC, 1, 2>(dh, WM + L.mat[N_D1T], da, true);
       if (p.valid && a.dh_pl) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -542,7 +562,16 @@ __global__ void __launch_bounds__(64 * NERF_WAVES) k_nerf(NerfArgs a) {
     __syncthreads();
     const int F = a.F, K1 = a.F + 20;
     for (int i = threadIdx.x; i < A_TOTAL; i += blockDim.x) {
-      const float v = accum[i];
+      float v;
+      if constexpr (PRIV) {
+        constexpr int ACC_FLOATS = ((A_TOTAL * 4 + 15) & ~15) / 4;
+        const float* a0 = reinterpret_cast<const float*>(smem + wbytes);
+        v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += a0[w * ACC_FLOATS + i];
+      } else {
+        v = accum[i];
+      }
       if (v == 0.f) continue;
       float* dst = nullptr;
       if (i < A_DWH) {
@@ -574,12 +603,18 @@ struct Scatter4Args {
   int64_t S;
   const float* dh_pl;
   float* dgrid;
+  int dedup_max_rw;
 };
 
 __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
   const int lane = nsim_lane();
   const int l = blockIdx.y;
   const int Rx = a.lotd.res_xyz[l], Rw = a.lotd.res_w[l];
+  // K = 64 shells per ray: a wave holds consecutive shells of (mostly) ONE ray.  Far shells converge to a fixed
+  // (x/r) direction and step through few 1/r cells on the coarser levels, so runs of lanes hit the same vertex:
+  // collapse them (run heads by ballot, segmented shuffle scan) before the atomics -- the kernel is bound by the
+  // atomic request rate, the extra shuffles are free.
+  const bool dedup = Rw <= a.dedup_max_rw;
   const int rq = lane & 3;
   float* base = a.dgrid + a.lotd.offset[l];
   const int64_t nchunks = (a.S + 63) / 64;
@@ -600,6 +635,7 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
     for (int yzw = 0; yzw < 8; ++yzw) {
       uint32_t idx[2];
       float v0[2], v1[2];
+      int emit[2];
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         const int corner = dx | (yzw << 1);
@@ -608,15 +644,33 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
                               a.lotd.type[l], a.lotd.size[l]);
         v0[dx] = w * dh0;
         v1[dx] = w * dh1;
+        emit[dx] = valid;
+        if (dedup) {
+          const uint32_t key = valid ? idx[dx] : 0xffffffffu;
+          const uint32_t pk = wave_shfl(key, lane - 1);
+          const unsigned long long heads = wave_ballot(lane == 0 || pk != key);
+          const unsigned long long below = heads & ((2ull << lane) - 1ull);
+          const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
+            if (lane - d >= run_start) {
+              v0[dx] += o0;
+              v1[dx] += o1;
+            }
+          }
+          emit[dx] = valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));   // last lane of the run
+        }
       }
 #define NSIM_QUAD4(I)                                                                                      \
   {                                                                                                        \
     const uint32_t i0 = quad_bcast<I>(idx[0]), i1 = quad_bcast<I>(idx[1]);                                 \
     const float a0 = quad_bcast<I>(v0[0]), a1 = quad_bcast<I>(v1[0]);                                      \
     const float b0 = quad_bcast<I>(v0[1]), b1 = quad_bcast<I>(v1[1]);                                      \
-    const int ee = quad_bcast<I>((int)valid);                                                              \
+    const int e0 = quad_bcast<I>(emit[0]), e1 = quad_bcast<I>(emit[1]);                                    \
     const uint32_t ii = rq < 2 ? i0 : i1;                                                                  \
     const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));                                  \
+    const int ee = rq < 2 ? e0 : e1;                                                                       \
     if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                              \
   }
       NSIM_QUAD4(0)
@@ -748,10 +802,16 @@ int nsim_distant_bwd(const NsimDistantMeta* meta, const void* wpack, const float
   a.dsigma = dsigma; a.drgb = drgb;
   a.dh_pl = dh_planes;
   a.dden_w = dden_w; a.dden_b = dden_b; a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
-  const size_t wl = meta->precision == 0 ? (size_t)((a.lay.total + 15) & ~15) : 0;
   const size_t st = meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
-  const size_t shmem = wl + ((10700 * 4 + 15) & ~15) + NERF_WAVES * st;
-  const dim3 grid(nerf_grid(S, 512)), block(64 * NERF_WAVES);
+  const size_t acc = (10700 * 4 + 15) & ~15;
+  const bool priv = meta->precision == 0;
+  const int nw = priv ? NERF_WAVES_PRIV : NERF_WAVES;
+  const size_t vec_bytes = (size_t)((a.lay.total - a.lay.vec[0] + 15) & ~15);
+  const size_t shmem = priv ? vec_bytes + nw * acc + nw * st : acc + nw * st;
+  const int64_t tiles = (S + 31) / 32;
+  int64_t nb = (tiles + nw - 1) / nw;
+  nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
+  const dim3 grid((unsigned)nb), block(64 * nw);
   if (meta->precision == 0) hipLaunchKernelGGL((k_nerf<0, 1>), grid, block, shmem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_nerf<1, 1>), grid, block, shmem, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
@@ -767,6 +827,8 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   Scatter4Args sa;
   sa.lotd = lotd4_dev(meta);
   sa.u4 = u4; sa.valid = valid; sa.S = S; sa.dh_pl = dh_planes; sa.dgrid = dgrid;
+  sa.dedup_max_rw = 64;
+  if (const char* e = getenv("NSIM_DEDUP4_MAX_RW")) sa.dedup_max_rw = atoi(e);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
   hipLaunchKernelGGL(k_lotd4_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
   NSIM_CHECK_LAUNCH();
