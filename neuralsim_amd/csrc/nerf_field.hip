@@ -827,7 +827,7 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   Scatter4Args sa;
   sa.lotd = lotd4_dev(meta);
   sa.u4 = u4; sa.valid = valid; sa.S = S; sa.dh_pl = dh_planes; sa.dgrid = dgrid;
-  sa.dedup_max_rw = 64;
+  sa.dedup_max_rw = 1 << 30;      // every level: 3.62 -> 1.73 ms per 0.52 M shell points (levels with Rw <= 16 / 64 only: 2.07 / 1.76)
   if (const char* e = getenv("NSIM_DEDUP4_MAX_RW")) sa.dedup_max_rw = atoi(e);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
   hipLaunchKernelGGL(k_lotd4_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
