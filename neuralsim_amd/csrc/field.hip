@@ -1517,7 +1517,7 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   sa.dh_pl = dh_planes; sa.g_pl = g_planes; sa.gn = gn;
   sa.ray_goff = ray_goff;
   sa.dgrid = dgrid;
-  sa.dedup_max_res = 600;
+  sa.dedup_max_res = 1 << 30;   // every level (compressed query mode keeps neighbouring fine samples: 0.345 -> 0.319 ms; it was 600 for the un-compressed mode)
   const char* e = getenv("NSIM_DEDUP_MAX_RES");
   if (e) sa.dedup_max_res = atoi(e);
   const int64_t chunks = (S + 63) / 64;
