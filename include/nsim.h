@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NSIM_MAX_LEVELS 24
+#define NSIM_MAX_LEVELS 32
 #define NSIM_LOTD_DENSE 0
 #define NSIM_LOTD_HASH 1
 

@@ -9,7 +9,7 @@ from pathlib import Path
 
 import torch
 
-NSIM_MAX_LEVELS = 24
+NSIM_MAX_LEVELS = 32
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libnsim_hip.so"
 

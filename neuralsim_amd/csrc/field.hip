@@ -43,13 +43,19 @@ struct FieldLayout {
 static const int kMatUo[M_COUNT] = {64, 64, 64, 32, 64, 64, 32, 64, 64, 32};
 static const int kMatUi[M_COUNT] = {32, 64, 64, 64, 32, 64, 64, 32, 64, 64};
 
-static inline FieldLayout field_layout(int precision) {
+// nc = number of 16-level feature chunks of the decoder input (1: <= 16 levels, 2: 17..32 levels).  Only the first
+// layer's matrices grow: W1 is [64 x 32 nc], W1T [32 nc x 64].
+static inline int mat_uo(int m, int nc) { return m == M_W1T ? 32 * nc : kMatUo[m]; }
+static inline int mat_ui(int m, int nc) { return m == M_W1 ? 32 * nc : kMatUi[m]; }
+static inline int field_nc(int num_levels) { return num_levels > 16 ? 2 : 1; }
+
+static inline FieldLayout field_layout(int precision, int nc = 1) {
   FieldLayout L;
   L.elt = precision == 0 ? 2 : 4;
   int64_t off = 0;
   for (int m = 0; m < M_COUNT; ++m) {
     L.mat[m] = off;
-    off += (int64_t)kMatUo[m] * kMatUi[m] * L.elt;
+    off += (int64_t)mat_uo(m, nc) * mat_ui(m, nc) * L.elt;
   }
   for (int v = 0; v < V_COUNT; ++v) {
     L.vec[v] = off;
@@ -65,7 +71,7 @@ struct SrcOff {
   int r1, r2, r3, rb1, rb2, rb3;
   int n_sdf_w, n_sdf_b, n_rad_w, n_rad_b;
 };
-// F1 = 2 * num_levels: width of the decoder input (<= 32; pyramids with fewer than 16 levels leave columns unused)
+// F1 = 2 * num_levels: width of the decoder input (<= 32 nc; the columns up to 32 nc are zero padding in the pack)
 __host__ __device__ inline SrcOff src_off(int D, int F1 = 32) {
   SrcOff o;
   o.w1 = 0;
@@ -215,11 +221,11 @@ struct FieldArgs {
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
-  void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16][S] x (f16x2 | f32x2)
-  signed char glm_n[8], glm_lv[8][16];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
-  signed char glm_half[8][16];                     // ... for all points (0), the first (1) or the second (2) half of them
-  float *h_pl, *J_pl;                              // level-major planes [16][S][2] / [16][S][2][3] saved by the forward
-  float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16][S][2]
+  void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16 nc][S] x (f16x2 | f32x2)
+  signed char glm_n[8], glm_lv[8][32];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
+  signed char glm_half[8][32];                     // ... for all points (0), the first (1) or the second (2) half of them
+  float *h_pl, *J_pl;                              // level-major planes [16 nc][S][2] / [16 nc][S][2][3] saved by the forward
+  float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16 nc][S][2]
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
@@ -229,10 +235,10 @@ struct FieldArgs {
 struct AccOff {
   int w1, w2, wh, b1, b2, bh, total;
 };
-__host__ __device__ inline AccOff acc_off() {
+__host__ __device__ inline AccOff acc_off(int nc = 1) {
   AccOff a;
   int o = 0;
-  a.w1 = o; o += 64 * 32;
+  a.w1 = o; o += 64 * 32 * nc;
   a.w2 = o; o += 64 * 64;
   a.wh = o; o += 64;
   a.b1 = o; o += 64;
@@ -367,7 +373,9 @@ __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32]
 // MODE 3: MODE 1 on features / dh-dx planes already gathered level-major by k_lotd_gather_lm<., true> (training).
 // MODE 0: sdf only; MODE 1: sdf + nablas (+ rgb); MODE 2: backward of the SDF branch (gradient w.r.t. grid and
 // decoder weights given dL/dsdf and the TOTAL dL/dnablas, which already includes the radiance net's share).
-template <int PREC, int SDF_D, int MODE>
+// NC: 16-level feature chunks of the decoder input (2 for pyramids of 17..32 levels -- the first layer contracts over
+// 64 features; only on the level-major planes, MODE 2 / 3).
+template <int PREC, int SDF_D, int MODE, int NC = 1>
 __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -381,6 +389,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   constexpr bool PRIV = (MODE == 2 && PREC == 0);
   constexpr bool FWD = (MODE == 1 || MODE == 3);          // forward with normals (+ radiance)
   constexpr bool FROM_PLANES = (MODE == 2 || MODE == 3);  // h / dh-dx come from the level-major planes
+  static_assert(NC == 1 || FROM_PLANES, "more than 16 levels: level-major planes only");
+  // NC == 2: a private accumulator copy is 34 KB -> three waves per workgroup fit the 160 KB of LDS
+  constexpr int NW = (PRIV && NC == 2) ? 3 : FIELD_WAVES;
   // W / L: per-lane vectors (always LDS in fp16 mode); WM / LM: matrix fragments (LDS, or L2 when PRIV)
   // MODE 0 / 2 touch only the SDF decoder (W1, W2, W2T, W1T); MODE 1 also the radiance matrices
   const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (FWD ? M_COUNT : 4), L, wbytes);
@@ -390,10 +401,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   float* accum = nullptr;
   char* stA = nullptr;
   char* stB = nullptr;
-  const AccOff AO = acc_off();
-  constexpr int ACC_BYTES = ((6400 * 4 + 15) & ~15);      // >= AO.total floats, one copy
+  const AccOff AO = acc_off(NC);
+  constexpr int ACC_BYTES = (((6400 + 2048 * (NC - 1)) * 4 + 15) & ~15);      // >= AO.total floats, one copy
   if constexpr (MODE == 2) {
-    const int ncopies = PRIV ? FIELD_WAVES : 1;
+    const int ncopies = PRIV ? NW : 1;
     accum = reinterpret_cast<float*>(smem + wbytes + (PRIV ? wave * ACC_BYTES : 0));
     char* stbase = smem + wbytes + ncopies * ACC_BYTES + wave * stage_bytes_per_wave<PREC>();
     stA = stbase;
@@ -409,8 +420,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const GridRef gref = grid_ref(a.grid);
 
   const int64_t ntiles = (a.S + 31) / 32;
-  const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
+  const int64_t wstride = (int64_t)gridDim.x * NW;
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += wstride) {
     const TilePoint p = load_point(a, tile, j, FWD);
     const bool valid = p.valid;
     const int64_t s = p.s;
@@ -418,33 +429,40 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // The backward does NOT gather again: the forward saved h and dh/dx as level-major planes
     // ([level][sample][..], coalesced across the 32 samples of a tile) -- 512 B per sample of sequential HBM
     // traffic instead of a second latency-bound random gather.
-    float h[16];
-    float J[16][3];
+    float h[16 * NC];
+    float J[NC == 1 ? 16 : 1][3];     // NC == 2 re-reads dh/dx from the planes where it is consumed
     if constexpr (FROM_PLANES) {
+#pragma unroll
+      for (int m = 0; m < NC; ++m) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int l = 4 * q + 2 * hi + b;
-          const int r0 = 4 * q + 2 * b;
+          const int l = 16 * m + 4 * q + 2 * hi + b;
+          const int r0 = 16 * m + 4 * q + 2 * b;
           if (valid) {
             const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
-            const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
             h[r0] = hp[0];
             h[r0 + 1] = hp[1];
+            if constexpr (NC == 1) {
+              const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
 #pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) {
-              J[r0][c3] = jp[c3];
-              J[r0 + 1][c3] = jp[3 + c3];
+              for (int c3 = 0; c3 < 3; ++c3) {
+                J[r0][c3] = jp[c3];
+                J[r0 + 1][c3] = jp[3 + c3];
+              }
             }
           } else {
             h[r0] = h[r0 + 1] = 0.f;
+            if constexpr (NC == 1) {
 #pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
+              for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
+            }
           }
         }
       }
-    } else {
+      }
+    } else if constexpr (NC == 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -498,7 +516,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     }
     // ---------------------------------------------------------------- SDF decoder forward
     float a1[32];
-    dense<PREC, 2, 1>(a1, WM + LM.mat[M_W1], h, true);
+    dense<PREC, 2, NC>(a1, WM + LM.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(W, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];  // last hidden activation (== a1 when SDF_D == 1)
@@ -536,16 +554,36 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
       }
     }
-    float g[16];
-    dense<PREC, 1, 2>(g, WM + LM.mat[M_W1T], d1, false);
+    float g[16 * NC];
+    dense<PREC, NC, 2>(g, WM + LM.mat[M_W1T], d1, false);
     if constexpr (FWD) {
       float nab[3];
+      if constexpr (NC == 1) {
 #pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3) {
-        float acc = 0.f;
+        for (int c3 = 0; c3 < 3; ++c3) {
+          float acc = 0.f;
 #pragma unroll
-        for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
-        nab[c3] = acc + wave_shfl_xor(acc, 32);
+          for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
+          nab[c3] = acc + wave_shfl_xor(acc, 32);
+        }
+      } else {
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+          for (int m = 0; m < NC; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const int l = 16 * m + 4 * q + 2 * hi + b;
+                const int r0 = 16 * m + 4 * q + 2 * b;
+                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + g[r0] * jp[c3] + g[r0 + 1] * jp[3 + c3];
+              }
+        }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) nab[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
       }
       float rgbv[3] = {0.f, 0.f, 0.f};
       if (a.has_rgb) {
@@ -582,13 +620,31 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
       }
       // ------------------------------------------------------------ second-order path through the normals
-      float gh[16];  // dL / dg
+      float gh[16 * NC];  // dL / dg
+      if constexpr (NC == 1) {
 #pragma unroll
-      for (int f = 0; f < 16; ++f) gh[f] = J[f][0] * gn[0] + J[f][1] * gn[1] + J[f][2] * gn[2];
+        for (int f = 0; f < 16; ++f) gh[f] = J[f][0] * gn[0] + J[f][1] * gn[1] + J[f][2] * gn[2];
+      } else {
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int l = 16 * m + 4 * q + 2 * hi + b;
+              const int r0 = 16 * m + 4 * q + 2 * b;
+              gh[r0] = gh[r0 + 1] = 0.f;
+              if (valid) {
+                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+                gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
+                gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+              }
+            }
+      }
       float dh1[32];  // dL / d d1  = W1 . gh
-      dense<PREC, 2, 1>(dh1, WM + LM.mat[M_W1], gh, true);
+      dense<PREC, 2, NC>(dh1, WM + LM.mat[M_W1], gh, true);
       const bool do_dw = !(a.ablate & 4);
-      if (do_dw) dw_product<PREC, 2, 1, PRIV>(stA, stB, d1, gh, accum + AO.w1, 32, 64, 32, nullptr);
+      if (do_dw) dw_product<PREC, 2, NC, PRIV>(stA, stB, d1, gh, accum + AO.w1, 32 * NC, 64, 32 * NC, nullptr);
       float dz1[32];
       float whv[32];  // vector-shaped gradient of the SDF head weights
       if constexpr (SDF_D == 2) {
@@ -636,19 +692,21 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           else atomicAdd(&accum[AO.bh], v);
         }
       }
-      if (do_dw) dw_product<PREC, 2, 1, PRIV>(stA, stB, dz1, h, accum + AO.w1, 32, 64, 32, accum + AO.b1);
-      float dh[16];
-      dense<PREC, 1, 2>(dh, WM + LM.mat[M_W1T], dz1, true);
+      if (do_dw) dw_product<PREC, 2, NC, PRIV>(stA, stB, dz1, h, accum + AO.w1, 32 * NC, 64, 32 * NC, accum + AO.b1);
+      float dh[16 * NC];
+      dense<PREC, NC, 2>(dh, WM + LM.mat[M_W1T], dz1, true);
       // ------------------------------------------------------------ hand-off to the scatter kernel
       // dL/dh and g = d sdf/d h as level-major planes + the total dL/dnablas per sample; k_lotd_scatter turns
       // them into grid gradients at full occupancy (it is bound by the atomic unit, not by this kernel's MFMA chain)
       if (valid && a.dh_pl) {
 #pragma unroll
+        for (int m = 0; m < NC; ++m)
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const int l = 4 * q + 2 * hi + b;
-            const int r0 = 4 * q + 2 * b;
+            const int l = 16 * m + 4 * q + 2 * hi + b;
+            const int r0 = 16 * m + 4 * q + 2 * b;
             float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
             float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
             dp[0] = dh[r0];
@@ -671,14 +729,14 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         const float* a0 = reinterpret_cast<const float*>(smem + wbytes);
         v = 0.f;
 #pragma unroll
-        for (int w = 0; w < FIELD_WAVES; ++w) v += a0[w * (ACC_BYTES / 4) + i];
+        for (int w = 0; w < NW; ++w) v += a0[w * (ACC_BYTES / 4) + i];
       } else {
         v = accum[i];
       }
       if (v == 0.f) continue;
       float* dst = nullptr;
-      if (i < AO.w2) {           // accumulator rows are 32 wide, the parameter rows F1 (<= 32) wide
-        const int row = (i - AO.w1) >> 5, col = (i - AO.w1) & 31;
+      if (i < AO.w2) {           // accumulator rows are 32 NC wide, the parameter rows F1 (<= 32 NC) wide
+        const int row = (i - AO.w1) / (32 * NC), col = (i - AO.w1) % (32 * NC);
         dst = col < F1 ? a.dsdf_w + so.w1 + row * F1 + col : nullptr;
       } else if (i < AO.wh) dst = (SDF_D == 2) ? a.dsdf_w + so.w2 + (i - AO.w2) : nullptr;
       else if (i < AO.b1) dst = a.dsdf_w + so.wh + (i - AO.wh);
@@ -822,7 +880,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   }
 }
 
-template <int PREC, int SDF_D, bool PLANES>
+template <int PREC, int SDF_D, bool PLANES, int NC = 1>
 __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_sdf(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -850,7 +908,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
     }
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll 1
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < 2 * NC; ++rb) {      // one K-step of 8 features per lane-half: levels 16 (rb/2) + 8 (rb%2) + ..
+      const int lb = 16 * (rb >> 1) + 8 * (rb & 1);
       float f8[8];
       f16x8 bvp;
       if constexpr (PLANES) {
@@ -859,7 +918,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const int l = 4 * (2 * rb + qq) + 2 * hi + b;
+            const int l = lb + 4 * qq + 2 * hi + b;
             const int64_t e = (int64_t)l * a.S + (p.valid ? p.s : 0);
             if constexpr (PREC == 0) {
               union {
@@ -879,7 +938,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int l = 4 * (2 * rb + qq) + 2 * hi + b;
+          const int l = lb + 4 * qq + 2 * hi + b;
           const LotdRes R = a.lotd.res[l];
           const LotdCell c = lotd_cell(p.xx, R);
           float f0 = 0.f, f1 = 0.f;
@@ -910,14 +969,14 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
         }
         const f16x8* A = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
 #pragma unroll
-        for (int mo = 0; mo < 2; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 + rb) * 64 + lane], bv, acc[mo]);
+        for (int mo = 0; mo < 2; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 * NC + rb) * 64 + lane], bv, acc[mo]);
       } else {
         const float* A = reinterpret_cast<const float*>(W + L.mat[M_W1]);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
           for (int mo = 0; mo < 2; ++mo)
-            acc[mo] = mfma_32x32x2_f32(A[(mo * 16 + 8 * rb + e) * 64 + lane], f8[e], acc[mo]);
+            acc[mo] = mfma_32x32x2_f32(A[(mo * 16 * NC + 8 * rb + e) * 64 + lane], f8[e], acc[mo]);
       }
     }
     const float inv_h = PREC == 0 ? 1.0f / SDF_H_SCALE : 1.0f;
@@ -1219,7 +1278,7 @@ static int field_meta_check(const NsimFieldMeta* m) {
   if (!m) return 20;
   const int rc = lotd_meta_check(&m->lotd);
   if (rc) return rc;
-  if (m->lotd.num_levels < 1 || m->lotd.num_levels > 16) return 21;
+  if (m->lotd.num_levels < 1 || m->lotd.num_levels > 32) return 21;
   if (m->sdf_D != 1 && m->sdf_D != 2) return 22;
   if (m->precision != 0 && m->precision != 1) return 23;
   return 0;
@@ -1228,14 +1287,14 @@ static int field_meta_check(const NsimFieldMeta* m) {
 static FieldArgs field_args(const NsimFieldMeta* meta) {
   FieldArgs a = FieldArgs();
   a.lotd = lotd_dev(&meta->lotd);
-  a.lay = field_layout(meta->precision);
+  a.lay = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
   a.beta = meta->softplus_beta;
   return a;
 }
 
-static unsigned field_grid(int64_t S, int64_t max_blocks) {
+static unsigned field_grid(int64_t S, int64_t max_blocks, int waves = FIELD_WAVES) {
   const int64_t tiles = (S + 31) / 32;
-  int64_t b = (tiles + FIELD_WAVES - 1) / FIELD_WAVES;
+  int64_t b = (tiles + waves - 1) / waves;
   if (b > max_blocks) b = max_blocks;
   if (b < 1) b = 1;
   return (unsigned)b;
@@ -1243,7 +1302,7 @@ static unsigned field_grid(int64_t S, int64_t max_blocks) {
 
 static size_t weights_lds_bytes(const NsimFieldMeta* meta, int first = 0, int count = M_COUNT) {
   if (meta->precision != 0) return 0;
-  const FieldLayout L = field_layout(0);
+  const FieldLayout L = field_layout(0, field_nc(meta->lotd.num_levels));
   const int64_t m1 = (first + count < M_COUNT) ? L.mat[first + count] : L.vec[0];
   return (size_t)(((m1 - L.mat[first]) + (L.total - L.vec[0]) + 15) & ~15);
 }
@@ -1251,11 +1310,31 @@ static size_t stage_bytes(const NsimFieldMeta* meta) {
   return meta->precision == 0 ? stage_bytes_per_wave<0>() : stage_bytes_per_wave<1>();
 }
 
+// waves per workgroup of k_field<., ., MODE, NC> (see NW in the kernel)
+static int field_waves(const NsimFieldMeta* meta, int mode) {
+  return (mode == 2 && meta->precision == 0 && field_nc(meta->lotd.num_levels) == 2) ? 3 : FIELD_WAVES;
+}
+
 template <int MODE>
 static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t shmem, int64_t max_blocks,
                         hipStream_t stream) {
-  const dim3 grid(field_grid(a.S, max_blocks)), block(64 * FIELD_WAVES);
+  const int nw = field_waves(meta, MODE);
+  const dim3 grid(field_grid(a.S, max_blocks, nw)), block(64 * nw);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
+  if (field_nc(meta->lotd.num_levels) == 2) {
+    if constexpr (MODE == 2 || MODE == 3) {
+      switch (key) {
+        case 0: hipLaunchKernelGGL((k_field<0, 1, MODE, 2>), grid, block, shmem, stream, a); break;
+        case 1: hipLaunchKernelGGL((k_field<0, 2, MODE, 2>), grid, block, shmem, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_field<1, 1, MODE, 2>), grid, block, shmem, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_field<1, 2, MODE, 2>), grid, block, shmem, stream, a); break;
+      }
+      NSIM_CHECK_LAUNCH();
+      return 0;
+    } else {
+      return 30;      // more than 16 levels: only the level-major (planes) path exists
+    }
+  }
   switch (key) {
     case 0: hipLaunchKernelGGL((k_field<0, 1, MODE>), grid, block, shmem, stream, a); break;
     case 1: hipLaunchKernelGGL((k_field<0, 2, MODE>), grid, block, shmem, stream, a); break;
@@ -1274,20 +1353,21 @@ extern "C" {
 
 int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta) {
   if (field_meta_check(meta)) return -1;
-  return field_layout(meta->precision).total;
+  return field_layout(meta->precision, field_nc(meta->lotd.num_levels)).total;
 }
 
 int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b, const float* rad_w,
                             const float* rad_b, void* wpack, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
-  const FieldLayout L = field_layout(meta->precision);
+  const int nc = field_nc(meta->lotd.num_levels);
+  const FieldLayout L = field_layout(meta->precision, nc);
   PackDims dims;
   int64_t total = 0;
   for (int m = 0; m < M_COUNT; ++m) {
-    dims.uo[m] = kMatUo[m];
-    dims.ui[m] = kMatUi[m];
-    total += (int64_t)kMatUo[m] * kMatUi[m];
+    dims.uo[m] = mat_uo(m, nc);
+    dims.ui[m] = mat_ui(m, nc);
+    total += (int64_t)dims.uo[m] * dims.ui[m];
   }
   total += (int64_t)V_COUNT * 64;
   hipLaunchKernelGGL(k_field_pack, dim3(nsim_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, L, dims,
@@ -1301,10 +1381,12 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 // loaded XCD -- whole if that keeps the XCD within 8 % of the ideal load, otherwise split into two halves of the point
 // range on two XCDs (3 of the 11 hashed levels of the default pyramid end up split: max load 1.7 instead of 2.0).
 static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
-  float cost[16], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
-  bool used[16] = {false};
-  for (int l = 0; l < 16; ++l) {
-    cost[l] = meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f;
+  // the planes hold 16 nc levels; the ones past num_levels only get zeros written (cheap)
+  const int NL = 16 * field_nc(meta->lotd.num_levels);
+  float cost[32], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
+  bool used[32] = {false};
+  for (int l = 0; l < NL; ++l) {
+    cost[l] = l >= meta->lotd.num_levels ? (NL > 16 ? 0.05f : 0.35f) : (meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f);
     total += cost[l];
   }
   const float limit = total / 8.0f * 1.08f;
@@ -1320,11 +1402,11 @@ static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
     a.glm_half[xc][(int)a.glm_n[xc]++] = (signed char)half;
     load[xc] += c;
   };
-  for (int it = 0; it < 16; ++it) {
+  auto tsize = [&](int l) { return l < meta->lotd.num_levels ? meta->lotd.size[l] : 0u; };
+  for (int it = 0; it < NL; ++it) {
     int best = -1;
-    for (int l = 0; l < 16; ++l)
-      if (!used[l] && (best < 0 || cost[l] > cost[best] ||
-                       (cost[l] == cost[best] && meta->lotd.size[l] > meta->lotd.size[best]))) best = l;
+    for (int l = 0; l < NL; ++l)
+      if (!used[l] && (best < 0 || cost[l] > cost[best] || (cost[l] == cost[best] && tsize(l) > tsize(best)))) best = l;
     used[best] = true;
     const int x0 = least();
     if (load[x0] + cost[best] <= limit || load[x0] == 0.f) {
@@ -1384,7 +1466,15 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
-  if (feat_scratch) {   // decoder on the planes gathered by nsim_lotd_gather_lm
+  if (field_nc(meta->lotd.num_levels) == 2) {
+    if (!feat_scratch) return 30;     // more than 16 levels: level-major path only
+    switch (key) {
+      case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+    }
+  } else if (feat_scratch) {   // decoder on the planes gathered by nsim_lotd_gather_lm
     switch (key) {
       case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
@@ -1425,7 +1515,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
   static const bool fused = getenv("NSIM_FWD_FUSED") && atoi(getenv("NSIM_FWD_FUSED")) == 1;
-  if (h_planes && !fused) {      // training: level-major gather into the planes, then the decoders on the planes
+  if (h_planes && (!fused || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
     deal_levels(meta, a);
     const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
     if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
@@ -1492,10 +1582,10 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dh_pl = dh_planes; a.g_pl = g_planes;
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
   a.ablate = bwd_ablate();
-  const AccOff AO = acc_off();
-  // fp16: four private accumulator copies + staging, weights from L2; f32: staged weights + one shared accumulator
-  const size_t acc_bytes = (6400 * 4 + 15) & ~15;
-  const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + FIELD_WAVES * acc_bytes + FIELD_WAVES * stage_bytes(meta)
+  // fp16: one private accumulator copy per wave + staging, weights from L2; f32: staged weights + one shared accumulator
+  const int nc = field_nc(meta->lotd.num_levels), nw = field_waves(meta, 2);
+  const size_t acc_bytes = ((6400 + 2048 * (nc - 1)) * 4 + 15) & ~15;
+  const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + nw * acc_bytes + nw * stage_bytes(meta)
                                             : weights_lds_bytes(meta, 0, 4) + acc_bytes + FIELD_WAVES * stage_bytes(meta);
   return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
 }

@@ -80,8 +80,11 @@ class _FieldFn(torch.autograd.Function):
         ha = h_appear.detach().float().contiguous() if h_appear is not None else None
         need_bwd = any(ctx.needs_input_grad)
         # level-major planes of the gathered features / their x-derivative, saved so the backward never re-gathers
-        h_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if need_bwd else None
-        J_pl = torch.empty([16, S, 2, 3], dtype=torch.float32, device=dev) if need_bwd else None
+        # (pyramids with more than 16 levels exist on the level-major path only: planes in evaluation as well)
+        NLP = model.plane_levels
+        need_pl = need_bwd or NLP > 16
+        h_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
+        J_pl = torch.empty([NLP, S, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
         _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
@@ -136,8 +139,9 @@ class _FieldFn(torch.autograd.Function):
             _lib.call("nsim_field_bwd_rad", fm, _lib.ptr(wpack), _lib.ptr(nab_fwd.detach()), _lib.ptr(rgb_fwd.detach()),
                       _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S,
                       _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(gn_total), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
-        dh_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
-        g_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        NLP = model.plane_levels
+        dh_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
         # (2) SDF-decoder branch on the saved planes
         _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
                   _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b))
@@ -344,7 +348,9 @@ class LoTDNeuSModel(nn.Module):
         assert W == 64 and sdf_D in (1, 2), "gfx950 fused kernels: hidden width 64, 1 or 2 hidden SDF layers"
         self.sdf_scale, self.inside_out = float(sdf_scale), bool(inside_out)
         lod_res = list(lod_res) if lod_res is not None else list(DEFAULT_LOD_RES)
-        assert 1 <= len(lod_res) <= 16, "gfx950 fused kernels: up to 16 levels x 2 features (32 decoder inputs)"
+        assert 1 <= len(lod_res) <= 32, "gfx950 decoder kernels: up to 32 levels x 2 features (64 decoder inputs)"
+        # the level-major planes hold 16 levels per feature chunk of the decoder's first layer (csrc/field.hip: NC)
+        self.plane_levels = 16 if len(lod_res) <= 16 else 32
         self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
         self.encoding = LoTDEncoding(LoTDConfig(lod_res, 2, log2_hashmap_size), bound=param_bound, seed=seed)
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D, len(lod_res))
@@ -394,7 +400,7 @@ class LoTDNeuSModel(nn.Module):
         fm.softplus_beta = float(softplus_beta)
         self.field_meta = fm
         self._wpack = None
-        self._sdf_fused = os.environ.get("NSIM_SDF_FUSED", "0") == "1"
+        self._sdf_fused = os.environ.get("NSIM_SDF_FUSED", "0") == "1" and self.plane_levels == 16
         # size the sampling buffers from the previous step's density instead of reading the marched total back
         self._speculate = os.environ.get("NSIM_SPECULATE", "1") == "1" and not self._sdf_fused
         self._wpack_versions = None
@@ -507,7 +513,8 @@ class LoTDNeuSModel(nn.Module):
         fm = self.field_meta
         planes = None
         if not self._sdf_fused:
-            planes = torch.empty([16 * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32, device=dev)
+            planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,
+                                 device=dev)
             _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
         _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),

@@ -285,3 +285,54 @@ def test_field_fewer_than_16_levels(backend, precision):
     for k, v in got.items():
         e = rel_l2(v.cpu(), ref[k])
         assert e < tol[3], (k, e)
+
+
+@pytest.mark.parametrize("levels,sdf_D,precision", [(19, 2, "f32"), (19, 2, "fp16"), (24, 1, "f32"), (32, 2, "fp16")])
+def test_field_more_than_16_levels(backend, levels, sdf_D, precision):
+    """Pyramids with 17..32 levels (the street configs' auto pyramids have ~18-20): the decoder's first layer contracts
+    over two 16-level feature chunks (csrc/field.hip: NC = 2) -- values, normals, colours, the no-grad SDF query and all
+    gradients against the oracle."""
+    lod_res = [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(levels)]
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=sdf_D, seed=11, sphere_init=False,
+                                 grid_bound=0.3, noise_scale=1.0)
+    p.grid = p.grid.float()
+    for t in p.tensors():
+        t.requires_grad_(True)
+    assert p.sdf_w[0].shape == (64, 2 * levels)
+    model = model_from_params(p, backend, precision=precision)
+    assert model.plane_levels == 32
+    g = torch.Generator().manual_seed(3)
+    R, S = 7, 150
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    dv = lambda a: a.to(backend).contiguous()
+    ha_d = leaf(h_appear, backend)
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    tol = dict(f32=(2e-5, 2e-4, 2e-5, 2e-4), fp16=(4e-3, 5e-2, 4e-3, 3e-2))[precision]
+    assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < tol[1] * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < tol[2]
+    # no-grad paths: the sampling query and the evaluation forward (planes are used there too)
+    q = model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu()
+    assert (q - sdf_r.detach()).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    with torch.no_grad():
+        sdf_e, nab_e = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                      model.rad_b, None, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), False)
+    assert torch.allclose(sdf_e.cpu(), sdf.detach().cpu(), atol=1e-6)
+    assert torch.allclose(nab_e.cpu(), nab.detach().cpu(), atol=1e-5)
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < tol[3], (k, e)
