@@ -186,7 +186,8 @@ int nsim_lotd_bwd(const float* x, const float* dL_dout, const float* dL_ddydx, c
 /* Network description (host struct).  LoTDNeuSModel = LoTDSDF + RadianceNet
  * (app/models/single/neus.py:24-62; lotd_neus.dtu.230814.yaml:92-139). */
 typedef struct NsimFieldMeta {
-  NsimLotdMeta lotd;     /* 1..16 levels x 2 feats (<= 32 input features; W1 is [64 x 2 num_levels]) */
+  NsimLotdMeta lotd;     /* 1..32 levels x 2 feats (<= 64 input features; W1 is [64 x 2 num_levels]); more than 16
+                          * levels: level-major planes of 32 levels, the planes arguments are then mandatory */
   int32_t sdf_D;         /* hidden layers of the SDF decoder: 1 or 2 (width 64, softplus beta) */
   int32_t precision;     /* 0: fp16 MFMA (v_mfma_f32_32x32x16_f16), 1: exact f32 MFMA (32x32x2 f32) */
   float softplus_beta;   /* 100 */
@@ -212,7 +213,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
                    const void* feat_planes, void* stream);
-/* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [16][S] of
+/* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [NLP][S] (NLP = 16 for <= 16 levels, 32 above) of
  * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
  * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
@@ -226,7 +227,7 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
  * With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
- * h_planes [16,S,2] / J_planes [16,S,2,3] (both or neither): when given, the gathered features and their
+ * h_planes [NLP,S,2] / J_planes [NLP,S,2,3] (both or neither; NLP = 16 for <= 16 levels, 32 above): when given, the gathered features and their
  * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again). */
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
@@ -244,7 +245,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 /* (2) SDF-decoder branch on the saved h / J planes: given dL/dsdf [S] and the total dL/dnablas gn [S,3] (either may
  *     be NULL) accumulates dsdf_w / dsdf_b -- including the double-backward terms of nablas w.r.t. the decoder
  *     weights (app/loss/eikonal.py:216-251) -- and writes the hand-off planes dh_planes = dL/dh and
- *     g_planes = d sdf/d h, both [16,S,2] (both or neither). */
+ *     g_planes = d sdf/d h, both [NLP,S,2] (both or neither). */
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
                        float* dsdf_w, float* dsdf_b, void* stream);

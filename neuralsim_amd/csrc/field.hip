@@ -1332,7 +1332,7 @@ static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t sh
       NSIM_CHECK_LAUNCH();
       return 0;
     } else {
-      return 30;      // more than 16 levels: only the level-major (planes) path exists
+      return 33;      // more than 16 levels: only the level-major (planes) path exists
     }
   }
   switch (key) {
@@ -1467,7 +1467,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
   if (field_nc(meta->lotd.num_levels) == 2) {
-    if (!feat_scratch) return 30;     // more than 16 levels: level-major path only
+    if (!feat_scratch) return 33;     // more than 16 levels: level-major path only
     switch (key) {
       case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;

@@ -27,7 +27,8 @@ const char* nsim_strerror(int code) {
     case 31: return "sky input width 3 + 6 n_frequencies + n_appear must be <= 96";
     case 32: return "sky model with n_appear > 0 needs h_appear";
     case 20: return "field meta is NULL";
-    case 21: return "fused field kernels take 1..16 LoTD levels (<= 32 input features)";
+    case 21: return "field kernels take 1..32 LoTD levels (<= 64 input features)";
+    case 33: return "pyramids with more than 16 levels exist on the level-major path only: the planes arguments are required";
     case 22: return "sdf_D must be 1 or 2";
     case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";
     case 24: return "need either x or (rays_o, rays_d, t, ridx)";
