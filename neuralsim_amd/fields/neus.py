@@ -498,8 +498,38 @@ class LoTDNeuSModel(nn.Module):
         self.sdf_w.add_(0)
         return self
 
+    # ------------------------------------------------------------------ inv_s control (var_ctrl_cfg)
+    def set_var_ctrl(self, ctrl_type: Optional[str] = "mix_linear", start_it: int = 0, stop_it: int = 1,
+                     final_inv_s: float = 2000.0):
+        """``var_ctrl_cfg{ctrl_type: mix_linear, start_it, stop_it, final_inv_s}`` (lotd_neus.dtu.230814.yaml:83-89):
+        from ``start_it`` to ``stop_it`` the effective inv_s moves linearly from the learned ``exp(ln_inv_s * factor)``
+        to ``final_inv_s``:  inv_s(it) = (1 - a) exp(ln_inv_s factor) + a final_inv_s,  a = clip((it - start) / (stop -
+        start), 0, 1).  The controller lives in the absent nr3d_lib -- this blend is the semantics fixed here (parity
+        unpinned).  The learned parameter keeps receiving (1 - a) of the gradient; no kernel knows about the schedule:
+        the blend is a 1-element torch expression handed to the kernels in place of ``ln_inv_s``."""
+        assert ctrl_type in (None, "mix_linear")
+        self._var_ctrl = None if ctrl_type is None else dict(start_it=int(start_it), stop_it=int(stop_it),
+                                                             final_inv_s=float(final_inv_s))
+        self._ctrl_mix = 0.0
+
+    def training_before_per_step(self, it: int, logger=None):
+        """Per-iteration hook of the reference's trainer (app/resources/asset_bank.py:291-298): inv_s control here; the
+        occupancy refresh (``accel.cur_batch__step``) and the level annealing are driven by the trainer."""
+        vc = getattr(self, "_var_ctrl", None)
+        if vc is not None:
+            span = max(vc["stop_it"] - vc["start_it"], 1)
+            self._ctrl_mix = min(max((int(it) - vc["start_it"]) / span, 0.0), 1.0)
+
+    def _ln_inv_s_eff(self) -> torch.Tensor:
+        """The 1-element tensor the alpha / compress kernels read as ln_inv_s (autograd-transparent)."""
+        a = getattr(self, "_ctrl_mix", 0.0)
+        if a <= 0.0 or getattr(self, "_var_ctrl", None) is None:
+            return self.ln_inv_s
+        inv_s = (1.0 - a) * torch.exp(self.ln_inv_s * self.ln_inv_s_factor) + a * self._var_ctrl["final_inv_s"]
+        return torch.log(inv_s) / self.ln_inv_s_factor
+
     def forward_inv_s(self) -> torch.Tensor:
-        return torch.exp(self.ln_inv_s * self.ln_inv_s_factor)
+        return torch.exp(self._ln_inv_s_eff() * self.ln_inv_s_factor)
 
     # ------------------------------------------------------------------ point queries
     def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None, n_dev=None,
@@ -716,7 +746,8 @@ class LoTDNeuSModel(nn.Module):
         R = pi.shape[0]
         dev = t.device
         counts = torch.empty([R], dtype=torch.long, device=dev)
-        _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
+        ln_eff = self._ln_inv_s_eff().detach()
+        _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(ln_eff),
                   self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(counts))
         pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
         if pre_sync_hook is not None:
@@ -728,7 +759,7 @@ class LoTDNeuSModel(nn.Module):
         t_k = torch.empty([Sk], dtype=torch.float32, device=dev)
         ridx_k = torch.empty([Sk], dtype=torch.long, device=dev)
         if Sk > 0:
-            _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(self.ln_inv_s.detach()),
+            _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(ln_eff),
                       self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
         return t_k, pi_k, ridx_k, M_true
 
@@ -814,7 +845,7 @@ class LoTDNeuSModel(nn.Module):
             ret["extra_pts"] = dict(sdf=outs[-2], nablas=outs[-1], net_x=extra_x)
         if not qp.get("nablas_has_grad", True):
             nablas = nablas.detach()
-        alpha = _NeusAlphaFn.apply(sdf, self.ln_inv_s, pi, self.ln_inv_s_factor, fis)
+        alpha = _NeusAlphaFn.apply(sdf, self._ln_inv_s_eff(), pi, self.ln_inv_s_factor, fis)
         vb = dict(type="packed", rays_inds_hit=ray_tested["rays_inds"], pack_infos_hit=pi, t=t, opacity_alpha=alpha,
                   nablas=nablas, sdf=sdf)
         if with_rgb:

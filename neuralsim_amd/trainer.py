@@ -164,6 +164,7 @@ class RenderTrainer:
         acc = model.accel
         if self.level_anneal is not None:
             model.anneal_levels(it, **self.level_anneal)
+        model.training_before_per_step(it)          # inv_s control (var_ctrl_cfg); a no-op unless set_var_ctrl() was called
         if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         batch = None

@@ -176,3 +176,44 @@ def test_speculative_sample_buffers(backend):
             assert torch.equal(out["volume_buffer"][k], ref["volume_buffer"][k]), (stat, k)
         assert torch.equal(out["volume_buffer"]["pack_infos_hit"], ref["volume_buffer"]["pack_infos_hit"])
         assert torch.equal(out["rendered"]["rgb_volume"], ref["rendered"]["rgb_volume"])
+
+
+def test_var_ctrl_mix_linear(backend):
+    """``var_ctrl_cfg{ctrl_type: mix_linear}``: the scheduled inv_s renders exactly like a model whose ln_inv_s holds
+    the blended value, the learned parameter receives (1 - a) exp(ln f) / inv_s of that model's gradient, and the
+    schedule end points are the learned value (a = 0) and ``final_inv_s`` (a = 1)."""
+    import math
+    p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "f32")
+    dv = lambda a: a.to(backend).contiguous()
+    tested = model.ray_test(dv(o), dv(d), near=0.01, far=None, rays_h_appear=dv(h_appear))
+    ri = tested["rays_inds"].cpu()
+    cfg = dict(query_param=dict(QP, compress_thre=1e-3), with_rgb=True, with_normal=True, _render=True,
+               _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]), query_mode="march_occ_multi_upsample_compressed")
+    f, ln0 = model.ln_inv_s_factor, float(model.ln_inv_s)
+    model.set_var_ctrl("mix_linear", start_it=100, stop_it=300, final_inv_s=400.0)
+    model.training_before_per_step(50)
+    assert model._ctrl_mix == 0.0 and abs(float(model.forward_inv_s()) - math.exp(ln0 * f)) < 1e-3
+    model.training_before_per_step(1000)
+    assert model._ctrl_mix == 1.0 and abs(float(model.forward_inv_s()) - 400.0) < 1e-2
+    model.training_before_per_step(150)
+    a = 0.25
+    inv_eff = (1 - a) * math.exp(ln0 * f) + a * 400.0
+    assert model._ctrl_mix == a and abs(float(model.forward_inv_s()) - inv_eff) < 1e-2
+
+    def run():
+        model.zero_grad()
+        ret = model.ray_query(ray_tested=tested, config=cfg)
+        (ret["rendered"]["rgb_volume"].square().sum() + ret["rendered"]["mask_volume"].sum()).backward()
+        return ret, float(model.ln_inv_s.grad), model.sdf_w.grad.clone()
+    ret_c, g_c, gw_c = run()
+    # the same model without a controller, ln_inv_s set to the blended value
+    model.set_var_ctrl(None)
+    with torch.no_grad():
+        model.ln_inv_s.fill_(math.log(inv_eff) / f)
+    ret_r, g_r, gw_r = run()
+    for k in ("rgb_volume", "mask_volume", "depth_volume"):
+        assert torch.allclose(ret_c["rendered"][k], ret_r["rendered"][k], atol=2e-6), k
+    assert torch.equal(ret_c["volume_buffer"]["pack_infos_hit"], ret_r["volume_buffer"]["pack_infos_hit"])
+    assert rel_l2(gw_c.cpu(), gw_r.cpu()) < 1e-5
+    chain = (1 - a) * math.exp(ln0 * f) / inv_eff
+    assert abs(g_c - chain * g_r) < 1e-4 * (1 + abs(g_r)), (g_c, chain * g_r)
