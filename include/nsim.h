@@ -125,6 +125,12 @@ int nsim_neus_alpha_bwd(const float* sdf, const float* dalpha, const int64_t* pa
 int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr /*[V,3,3]*/,
                         const float* c2w /*[V,4,4]*/, const int64_t* WH /*[V,2]*/, int64_t N, int snap,
                         float* rays_o, float* rays_d, void* stream);
+/* Its backward w.r.t. the poses (pose refinement, LearnableParams -> refined c2w,
+ * withmask_withlidar_joint.240219.yaml:338-352): d_c2w [V,4,4] (initialised by the caller) += the gradients of
+ * rays_o = T and rays_d = R l / |R l|; d_rays_o / d_rays_d [N,3] may each be NULL. */
+int nsim_raygen_pinhole_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* c2w,
+                            const int64_t* WH, int64_t N, int snap, const float* d_rays_o, const float* d_rays_d,
+                            float* d_c2w, void* stream);
 /* AABBSpace.ray_test (call site single_volume_renderer.py:235-238): far < 0 means "no far". */
 int nsim_aabb_ray_test(const float* rays_o, const float* rays_d, int64_t N, const NsimOccMeta* meta,
                        float near, float far, float* near_out, float* far_out, uint8_t* hit, void* stream);
@@ -237,23 +243,37 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
  *
  * (1) radiance branch: given dL/drgb [S,3], the saved forward nablas_fwd / rgb_fwd [S,3] and the upstream
  *     dL/dnablas (may be NULL): accumulates drad_w / drad_b (layouts of nsim_field_pack_weights), dh_appear [R,4]
- *     (may be NULL) and writes gn_out [S,3] = dL/dnablas + d(radiance)/d nablas. */
+ *     (may be NULL) and writes gn_out [S,3] = dL/dnablas + d(radiance)/d nablas.
+ *     Pose refinement (LearnableParams, withmask_withlidar_joint.240219.yaml:338-352 -- the rays carry gradients):
+ *     dx [S,3] (may be NULL) is SET to the radiance net's gradient w.r.t. the sample position, dv [S,3] (may be
+ *     NULL) to its gradient w.r.t. the view direction (through SH-4). */
 int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
                        const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                        const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
-                       float* drad_w, float* drad_b, float* dh_appear, void* stream);
+                       float* drad_w, float* drad_b, float* dh_appear, float* dx, float* dv, void* stream);
 /* (2) SDF-decoder branch on the saved h / J planes: given dL/dsdf [S] and the total dL/dnablas gn [S,3] (either may
  *     be NULL) accumulates dsdf_w / dsdf_b -- including the double-backward terms of nablas w.r.t. the decoder
  *     weights (app/loss/eikonal.py:216-251) -- and writes the hand-off planes dh_planes = dL/dh and
- *     g_planes = d sdf/d h, both [NLP,S,2] (both or neither). */
+ *     g_planes = d sdf/d h, both [NLP,S,2] (both or neither).  dx [S,3] (may be NULL; initialised by the caller or
+ *     by (1)) += (dh/dx)^T dL/dh, the first-order position gradient (LoTD ``dL/dx``). */
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
-                       float* dsdf_w, float* dsdf_b, void* stream);
+                       float* dsdf_w, float* dsdf_b, float* dx, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term). */
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d,
                       const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
                       const float* dh_planes, const float* g_planes, const float* gn, float* dgrid, void* stream);
+/* (4, pose refinement only) position gradient of the normals' own dependence on x: nablas = (d sdf/d h) . dh/dx(x), and
+ *     inside a cell the trilinear interpolant has mixed second derivatives:
+ *     dx[s][c] += sum_{l,f} g[l][s][f] sum_{c' != c} gn[s][c'] d2 h_{l,f} / dx_c' dx_c.   g_planes from (2), gn from (1). */
+int nsim_lotd_hess_dx(const NsimLotdMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                      const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
+                      const float* g_planes, const float* gn, float* dx, void* stream);
+/* (5, pose refinement only) x_s = o_r + t_s d_r, v_s = d_r  =>  d_rays_o[r] += dx_s, d_rays_d[r] += t_s dx_s + dv_s
+ *     (dv, d_rays_o, d_rays_d may each be NULL); the outputs [R,3] are initialised by the caller. */
+int nsim_ray_grad_reduce(const float* dx, const float* dv, const float* t, const int64_t* ridx, int64_t S,
+                         float* d_rays_o, float* d_rays_d, void* stream);
 
 /* ------------------------------------------------ NeRF++ distant-view model (LoTDNeRFDistant) */
 /* 4-D LoTD level table of ``lotd_auto_compute_cfg{type: ngp4d}`` (lotd_neus.dtu.230814.yaml:193-200): level l has

@@ -65,6 +65,7 @@ SIGNATURES = {
     "nsim_neus_alpha_fwd": [_P, _P, _I64, _P, _F, _F, _P],
     "nsim_neus_alpha_bwd": [_P, _P, _P, _I64, _P, _F, _F, _P, _P],
     "nsim_raygen_pinhole": [_P, _P, _P, _P, _P, _I64, _I, _P, _P],
+    "nsim_raygen_pinhole_bwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_aabb_ray_test": [_P, _P, _I64, C.POINTER(OccMeta), _F, _F, _P, _P, _P],
     "nsim_occ_decay": [_P, _I64, _F],
     "nsim_occ_update": [_P, _P, _P, _I64, C.POINTER(OccMeta), _F],
@@ -82,8 +83,10 @@ SIGNATURES = {
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P],
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
-    "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
-    "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "nsim_ray_grad_reduce": [_P, _P, _P, _P, _I64, _P, _P],
     "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_distant_pack_weights": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P],
     "nsim_distant_shells": [_P, _P, _P, _P, _I64, _I, C.POINTER(C.c_float * 6), _F, _F, _P, _P, _P],

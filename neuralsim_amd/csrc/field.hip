@@ -203,6 +203,21 @@ __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// out[c] = sum_k g[k] * d sh4_k / d d_c   (pose refinement: gradient w.r.t. the view direction)
+__device__ __forceinline__ void sh4_grad(const float d[3], const float (&g)[16], float (&out)[3]) {
+  const float x = d[0], y = d[1], z = d[2];
+  const float x2 = x * x, y2 = y * y, z2 = z * z;
+  const float a1 = 0.48860251190291987f, b = 1.0925484305920792f, c1 = 0.94617469575755997f;
+  const float e = 0.54627421529603959f, f = 0.59004358992664352f, gg = 2.8906114426405538f;
+  const float h = 0.45704579946446572f, i3 = 0.3731763325901154f, jj = 1.4453057213202769f;
+  out[0] = -a1 * g[3] + b * y * g[4] - b * z * g[7] + 2.0f * e * x * g[8] - 6.0f * f * x * y * g[9] + gg * y * z * g[10] +
+           h * (1.0f - 5.0f * z2) * g[13] + 2.0f * jj * z * x * g[14] + f * (-3.0f * x2 + 3.0f * y2) * g[15];
+  out[1] = -a1 * g[1] + b * x * g[4] - b * z * g[5] - 2.0f * e * y * g[8] + f * (-3.0f * x2 + 3.0f * y2) * g[9] +
+           gg * x * z * g[10] + h * (1.0f - 5.0f * z2) * g[11] - 2.0f * jj * z * y * g[14] + 6.0f * f * x * y * g[15];
+  out[2] = a1 * g[2] - b * y * g[5] + 2.0f * c1 * z * g[6] - b * x * g[7] + gg * x * y * g[10] - 10.0f * h * y * z * g[11] +
+           i3 * (15.0f * z2 - 3.0f) * g[12] - 10.0f * h * x * z * g[13] + jj * (x2 - y2) * g[14];
+}
+
 // ------------------------------------------------------------------------------------------ kernels
 struct FieldArgs {
   LotdDev lotd;
@@ -221,6 +236,7 @@ struct FieldArgs {
   const float *nablas_fwd, *rgb_fwd;               // saved forward outputs (radiance backward)
   const float *dsdf, *dnablas, *drgb;              // upstream gradients
   float* dnab_total;                               // [S,3] scratch: dnablas + d(radiance)/d nablas
+  float *dx, *dv;                                  // pose refinement: dL/d(sample position) / dL/d(view dir) [S,3], or NULL
   void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16 nc][S] x (f16x2 | f32x2)
   signed char glm_n[8], glm_lv[8][32];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
   signed char glm_half[8][32];                     // ... for all points (0), the first (1) or the second (2) half of them
@@ -695,6 +711,29 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       if (do_dw) dw_product<PREC, 2, NC, PRIV>(stA, stB, dz1, h, accum + AO.w1, 32 * NC, 64, 32 * NC, accum + AO.b1);
       float dh[16 * NC];
       dense<PREC, NC, 2>(dh, WM + LM.mat[M_W1T], dz1, true);
+      if (a.dx) {   // pose refinement: dL/dx += (dh/dx)^T dL/dh  (dh/dx re-read from the planes: this path is rare)
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+          for (int m = 0; m < NC; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const int l = 16 * m + 4 * q + 2 * hi + b;
+                const int r0 = 16 * m + 4 * q + 2 * b;
+                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
+              }
+        }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
+        if (valid && hi == 0) {
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) a.dx[3 * s + c3] = a.dx[3 * s + c3] + acc[c3];
+        }
+      }
       // ------------------------------------------------------------ hand-off to the scatter kernel
       // dL/dh and g = d sdf/d h as level-major planes + the total dL/dnablas per sample; k_lotd_scatter turns
       // them into grid gradients at full occupancy (it is bound by the atomic unit, not by this kernel's MFMA chain)
@@ -1101,6 +1140,27 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) a.dnab_total[3 * s + c] = gn[c];
     }
+    if (a.dx) {   // pose refinement: the radiance net's position input (slots 0-2: hi 0, r 0..2) ...
+      if (p.valid && hi == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dx[3 * s + c] = din[c];
+      }
+    }
+    if (a.dv) {   // ... and its view direction through SH4 (slots 3-18)
+      float gsh[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int slot = k + 3, ohi = (slot >> 2) & 1, r = (slot & 3) + 4 * (slot >> 3);
+        const float v = (hi == ohi) ? din[r] : 0.f;
+        gsh[k] = v + wave_shfl_xor(v, 32);
+      }
+      float gv[3];
+      sh4_grad(p.vd, gsh, gv);
+      if (p.valid && hi == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dv[3 * s + c] = gv[c];
+      }
+    }
     // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
     if (a.dh_appear && p.valid) {
       if (hi == 1) {
@@ -1244,6 +1304,88 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
       NSIM_QUAD_ISSUE(3)
 #undef NSIM_QUAD_ISSUE
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------- pose refinement
+// dL/dx of the normals' own position dependence: nablas_c' = sum_f g_f J_f,c'(x), and inside a cell the trilinear
+// interpolant has mixed second derivatives only:  H_f[c'][c] = dscale_c' dscale_c sum_corner s_c' s_c w_third grid_f
+// (c != c').  dx[c] += sum_f g_f sum_{c' != c} gn_c' H_f[c'][c].  One lane per sample over all levels (point-major:
+// this launch exists only when the rays carry gradients, e.g. StreetSurf's pose refinement,
+// withmask_withlidar_joint.240219.yaml:338-352), g from the hand-off planes of the SDF-branch backward.
+struct HessArgs {
+  LotdDev lotd;
+  const f16* grid;
+  const float *x, *rays_o, *rays_d, *t;
+  const int64_t* ridx;
+  const int64_t* ray_goff;
+  int64_t S;
+  const float *g_pl, *gn;
+  float* dx;
+};
+
+__global__ void __launch_bounds__(256) k_lotd_hess_dx(HessArgs a) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.S) return;
+  float xx[3];
+  uint32_t goff = 0u;
+  if (a.x) {
+    xx[0] = a.x[3 * s]; xx[1] = a.x[3 * s + 1]; xx[2] = a.x[3 * s + 2];
+    if (a.ray_goff) goff = (uint32_t)a.ray_goff[a.ridx[s]];
+  } else {
+    const int64_t ray = a.ridx[s];
+    const float tt = a.t[s];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xx[c] = a.rays_o[3 * ray + c] + tt * a.rays_d[3 * ray + c];
+    if (a.ray_goff) goff = (uint32_t)a.ray_goff[ray];
+  }
+  const float gn[3] = {a.gn[3 * s], a.gn[3 * s + 1], a.gn[3 * s + 2]};
+  const GridRef gref = grid_ref(a.grid);
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int l = 0; l < a.lotd.n_active; ++l) {
+    const LotdRes R = a.lotd.res[l];
+    const LotdCell c = lotd_cell(xx, R);
+    const float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
+    const float g0 = gp[0], g1 = gp[1];
+    float hxy = 0.f, hxz = 0.f, hyz = 0.f;      // already contracted with g over the two features
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int bx = corner & 1, by = (corner >> 1) & 1, bz = (corner >> 2) & 1;
+      const uint32_t idx = lotd_index(c.c0[0] + bx, c.c0[1] + by, c.c0[2] + bz, R, a.lotd.type[l], a.lotd.size[l]);
+      float f0, f1;
+      lotd_load2(gref, (uint32_t)a.lotd.offset[l] + goff + 2u * idx, f0, f1);
+      const float v = g0 * f0 + g1 * f1;
+      const float sx = bx ? 1.0f : -1.0f, sy = by ? 1.0f : -1.0f, sz = bz ? 1.0f : -1.0f;
+      const float wx = bx ? c.w[0] : 1.0f - c.w[0], wy = by ? c.w[1] : 1.0f - c.w[1], wz = bz ? c.w[2] : 1.0f - c.w[2];
+      hxy = hxy + sx * sy * wz * v;
+      hxz = hxz + sx * sz * wy * v;
+      hyz = hyz + sy * sz * wx * v;
+    }
+    hxy = hxy * (c.dscale[0] * c.dscale[1]);
+    hxz = hxz * (c.dscale[0] * c.dscale[2]);
+    hyz = hyz * (c.dscale[1] * c.dscale[2]);
+    acc[0] = acc[0] + gn[1] * hxy + gn[2] * hxz;
+    acc[1] = acc[1] + gn[0] * hxy + gn[2] * hyz;
+    acc[2] = acc[2] + gn[0] * hxz + gn[1] * hyz;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.dx[3 * s + c] = a.dx[3 * s + c] + acc[c];
+}
+
+// x_s = o_r + t_s d_r, v_s = d_r:  d o_r += dx_s,  d d_r += t_s dx_s + dv_s   (samples of a ray are neighbours: the
+// atomics of one wave hit a handful of addresses)
+__global__ void __launch_bounds__(256) k_ray_grad_reduce(const float* __restrict__ dx, const float* __restrict__ dv,
+                                                         const float* __restrict__ t, const int64_t* __restrict__ ridx,
+                                                         int64_t S, float* __restrict__ d_o, float* __restrict__ d_d) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t r = ridx[s];
+  const float tt = t[s];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float g = dx[3 * s + c];
+    if (d_o) atomicAdd(&d_o[3 * r + c], g);
+    if (d_d) atomicAdd(&d_d[3 * r + c], tt * g + (dv ? dv[3 * s + c] : 0.f));
   }
 }
 
@@ -1533,7 +1675,7 @@ static int bwd_ablate() {
 int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
                        const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                        const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
-                       float* drad_w, float* drad_b, float* dh_appear, void* stream) {
+                       float* drad_w, float* drad_b, float* dh_appear, float* dx, float* dv, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -1549,6 +1691,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.dnablas = dnablas; a.drgb = drgb;
   a.nablas_fwd = nablas_fwd; a.rgb_fwd = rgb_fwd; a.dnab_total = gn_out;
   a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
+  a.dx = dx; a.dv = dv;
   a.has_rgb = 1;
   const RadAccOff RO = rad_acc_off();
   const size_t racc = (6144 * 4 + 15) & ~15;
@@ -1567,7 +1710,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
-                       float* dsdf_b, void* stream) {
+                       float* dsdf_b, float* dx, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -1581,6 +1724,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
   a.dh_pl = dh_planes; a.g_pl = g_planes;
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
+  a.dx = dx;
   a.ablate = bwd_ablate();
   // fp16: one private accumulator copy per wave + staging, weights from L2; f32: staged weights + one shared accumulator
   const int nc = field_nc(meta->lotd.num_levels), nw = field_waves(meta, 2);
@@ -1613,6 +1757,38 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   const int64_t chunks = (S + 63) / 64;
   const dim3 grid(nsim_blocks(chunks, 4, 4096), meta->num_levels);
   hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_lotd_hess_dx(const NsimLotdMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                      const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
+                      const float* g_planes, const float* gn, float* dx, void* stream) {
+  const int rc = lotd_meta_check(meta);
+  if (rc) return rc;
+  if (S <= 0) return 0;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (ray_goff && !ridx) return 29;
+  if (!grid_f16 || !g_planes || !gn || !dx) return 4;
+  HessArgs ha;
+  ha.lotd = lotd_dev(meta);
+  ha.grid = (const f16*)grid_f16;
+  ha.x = x; ha.rays_o = rays_o; ha.rays_d = rays_d; ha.t = t; ha.ridx = ridx;
+  ha.ray_goff = ray_goff;
+  ha.S = S;
+  ha.g_pl = g_planes; ha.gn = gn; ha.dx = dx;
+  hipLaunchKernelGGL(k_lotd_hess_dx, dim3(nsim_blocks(S, 256)), dim3(256), 0, (hipStream_t)stream, ha);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_ray_grad_reduce(const float* dx, const float* dv, const float* t, const int64_t* ridx, int64_t S,
+                         float* d_rays_o, float* d_rays_d, void* stream) {
+  if (S < 0) return 2;
+  if (S == 0) return 0;
+  if (!dx || !t || !ridx) return 4;
+  hipLaunchKernelGGL(k_ray_grad_reduce, dim3(nsim_blocks(S, 256)), dim3(256), 0, (hipStream_t)stream, dx, dv, t, ridx, S,
+                     d_rays_o, d_rays_d);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

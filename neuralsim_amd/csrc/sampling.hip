@@ -71,6 +71,55 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict_
   rays_o[3 * i + 2] = M[11];
 }
 
+// Backward of the ray generation w.r.t. the camera poses (pose refinement: the reference's LearnableParams feed refined
+// c2w matrices into Camera.get_selected_rays, withmask_withlidar_joint.240219.yaml:338-352):
+//   rays_o = T,  rays_d = R l / |R l|   =>   dT[f] += d_o,  dR[f] += ((I - d d^T) d_d / |R l|) (x) l
+// d_c2w [V,4,4] is accumulated with atomics (a few thousand rays onto a few hundred poses; the bottom row stays zero).
+__global__ void __launch_bounds__(256) k_raygen_pinhole_bwd(const float* __restrict__ xy,
+                                                             const int64_t* __restrict__ fidx,
+                                                             const float* __restrict__ intr,
+                                                             const float* __restrict__ c2w,
+                                                             const int64_t* __restrict__ WH, int64_t N, int snap,
+                                                             const float* __restrict__ d_o,
+                                                             const float* __restrict__ d_d,
+                                                             float* __restrict__ d_c2w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t f = fidx[i];
+  const float W = (float)WH[2 * f], H = (float)WH[2 * f + 1];
+  float w = xy[2 * i] * W, h = xy[2 * i + 1] * H;
+  if (snap) {
+    float wi = truncf(w), hi = truncf(h);
+    wi = fminf(fmaxf(wi, 0.f), W - 1.f);
+    hi = fminf(fmaxf(hi, 0.f), H - 1.f);
+    w = wi + 0.5f;
+    h = hi + 0.5f;
+  }
+  const float* K = intr + f * 9;
+  const float l[3] = {(w - K[2]) / K[0], (h - K[5]) / K[4], 1.0f};
+  const float* M = c2w + f * 16;
+  float dw[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) dw[r] = M[4 * r] * l[0] + M[4 * r + 1] * l[1] + M[4 * r + 2] * l[2];
+  const float nrm = fmaxf(sqrtf(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]), 1e-12f);
+  float* G = d_c2w + f * 16;
+  if (d_d) {
+    const float u[3] = {dw[0] / nrm, dw[1] / nrm, dw[2] / nrm};
+    const float g[3] = {d_d[3 * i], d_d[3 * i + 1], d_d[3 * i + 2]};
+    const float dot = g[0] * u[0] + g[1] * u[1] + g[2] * u[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gr = (g[r] - dot * u[r]) / nrm;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) atomicAdd(&G[4 * r + c], gr * l[c]);
+    }
+  }
+  if (d_o) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) atomicAdd(&G[4 * r + 3], d_o[3 * i + r]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ AABB ray test
 __global__ void __launch_bounds__(256) k_aabb_ray_test(const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d, int64_t N, OccDev m,
@@ -460,6 +509,17 @@ int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr,
   if (N <= 0) return 0;
   hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
                      WH, N, snap, rays_o, rays_d);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_raygen_pinhole_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* c2w,
+                            const int64_t* WH, int64_t N, int snap, const float* d_rays_o, const float* d_rays_d,
+                            float* d_c2w, void* stream) {
+  if (N <= 0) return 0;
+  if (!d_c2w) return 4;
+  hipLaunchKernelGGL(k_raygen_pinhole_bwd, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr,
+                     c2w, WH, N, snap, d_rays_o, d_rays_d, d_c2w);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

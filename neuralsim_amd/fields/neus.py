@@ -91,6 +91,7 @@ class _FieldFn(torch.autograd.Function):
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
+        ctx.x_shape = x.shape if x is not None else None
         ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
         ctx.goff = goff
         ctx.ha_shape = ha.shape if ha is not None else None
@@ -134,17 +135,44 @@ class _FieldFn(torch.autograd.Function):
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
         fm = model.field_meta
         gn_total = gn
+        # pose refinement (the rays / points carry gradients, e.g. LearnableParams of the street config): per-sample
+        # dL/dx and dL/d(view dir), reduced per ray at the end
+        need_x, need_o, need_d = need[7] and x is not None, need[8] and x is None, need[9] and x is None
+        need_dx = need_x or need_o or need_d
+        dx = dv = None
+        if need_dx:
+            dx = (torch.empty if gr is not None else torch.zeros)([S, 3], dtype=torch.float32, device=dev)
+            dv = torch.empty([S, 3], dtype=torch.float32, device=dev) if (gr is not None and need_d) else None
         if gr is not None:      # (1) radiance branch: weight grads + total gradient w.r.t. the normals
             gn_total = torch.empty([S, 3], dtype=torch.float32, device=dev)
             _lib.call("nsim_field_bwd_rad", fm, _lib.ptr(wpack), _lib.ptr(nab_fwd.detach()), _lib.ptr(rgb_fwd.detach()),
                       _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S,
-                      _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(gn_total), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha))
+                      _lib.ptr(gn), _lib.ptr(gr), _lib.ptr(gn_total), _lib.ptr(drad_w), _lib.ptr(drad_b), _lib.ptr(dha),
+                      _lib.ptr(dx), _lib.ptr(dv))
         NLP = model.plane_levels
-        dh_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
-        g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
+        need_pl = dgrid is not None or (need_dx and gn_total is not None)
+        dh_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
+        g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
         # (2) SDF-decoder branch on the saved planes
         _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
-                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b))
+                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx))
+        d_x = d_o = d_d = None
+        if need_dx:
+            if gn_total is not None:    # the normals' own dependence on x (mixed second derivatives of the interpolant)
+                _lib.call("nsim_lotd_hess_dx", model.encoding.cfg.meta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
+                          _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(g_pl),
+                          _lib.ptr(gn_total), _lib.ptr(dx))
+            if need_x:
+                d_x = dx.reshape(ctx.x_shape)
+            else:
+                Rt = rays_o.shape[0]
+                d_o = torch.zeros([Rt, 3], dtype=torch.float32, device=dev) if need_o else None
+                d_d = torch.zeros([Rt, 3], dtype=torch.float32, device=dev) if need_d else None
+                _lib.call("nsim_ray_grad_reduce", _lib.ptr(dx), _lib.ptr(dv), _lib.ptr(t), _lib.ptr(ridx), S,
+                          _lib.ptr(d_o), _lib.ptr(d_d))
+                if M > 0:       # the appended zero-length rays of the extra points are not the caller's
+                    d_o = d_o[:Rt - M] if d_o is not None else None
+                    d_d = d_d[:Rt - M] if d_d is not None else None
         if dgrid is not None:   # (3) scatter to the hash grid
             _lib.call("nsim_lotd_scatter", model.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
@@ -160,7 +188,7 @@ class _FieldFn(torch.autograd.Function):
             dsdf_b[-1:] /= model.sdf_scale
         if dha is not None and M > 0:
             dha = dha[:dha.shape[0] - M]
-        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, None, None, None, None, None, None, None, None)
+        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_x, d_o, d_d, None, None, None, None, None)
 
 
 class _NeusAlphaFn(torch.autograd.Function):
@@ -573,7 +601,7 @@ class LoTDNeuSModel(nn.Module):
 
     def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
         shape = x.shape[:-1]
-        xf = x.detach().float().reshape(-1, 3).contiguous()
+        xf = (x if x.requires_grad else x.detach()).float().reshape(-1, 3).contiguous()   # dL/dx flows when asked for
         sdf, nablas = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w,
                                      self.rad_b, None, xf, None, None, None, None, False)
         if not nablas_has_grad:
@@ -837,8 +865,13 @@ class LoTDNeuSModel(nn.Module):
             return ret
         h_appear = ray_tested.get("rays_h_appear", None)
         extra_x = cfg.get("_extra_pts", None)              # trainer hook: free points riding on the same launches
+        # rays that carry gradients (pose refinement) stay attached for the with-grad query only; the sampling above
+        # is no-grad by construction (t is a constant of the differentiable step, as in the reference)
+        o_g, d_g = ray_tested["rays_o"], ray_tested["rays_d"]
+        o_in = o_g.float().contiguous() if o_g.requires_grad else o
+        d_in = d_g.float().contiguous() if d_g.requires_grad else d
         outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
-                              h_appear if with_rgb else None, None, o, d, t, ridx, bool(with_rgb), goff, extra_x)
+                              h_appear if with_rgb else None, None, o_in, d_in, t, ridx, bool(with_rgb), goff, extra_x)
         sdf, nablas = outs[0], outs[1]
         rgb = outs[2] if with_rgb else None
         if extra_x is not None:

@@ -5,16 +5,40 @@ import torch
 from .. import _lib
 
 
+class _RaygenFn(torch.autograd.Function):
+    """Ray generation with a backward w.r.t. the camera poses (pose refinement: the reference's LearnableParams hand
+    refined c2w matrices to ``Camera.get_selected_rays``; pixels and intrinsics are constants)."""
+
+    @staticmethod
+    def forward(ctx, c2w, xy, fidx, intr, WH, snap):
+        N = xy.shape[0]
+        o = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
+        d = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
+        c2w = c2w.float().contiguous()
+        _lib.call("nsim_raygen_pinhole", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH), N,
+                  snap, _lib.ptr(o), _lib.ptr(d))
+        ctx.save_for_backward(c2w, xy, fidx, intr, WH)
+        ctx.snap = snap
+        return o, d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        c2w, xy, fidx, intr, WH = ctx.saved_tensors
+        d_c2w = torch.zeros_like(c2w)
+        g_o = g_o.float().contiguous() if g_o is not None else None
+        g_d = g_d.float().contiguous() if g_d is not None else None
+        _lib.call("nsim_raygen_pinhole_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH),
+                  xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
+        return d_c2w, None, None, None, None, None
+
+
 def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
                           WH: torch.Tensor, snap_to_pixel_centers: bool = True):
-    """xy [N,2] in [0,1], fidx [N] int64, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] int64 -> rays_o, rays_d [N,3]."""
-    N = xy.shape[0]
-    o = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
-    d = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
-    _lib.call("nsim_raygen_pinhole", _lib.ptr(xy.float().contiguous()), _lib.ptr(fidx.long().contiguous()),
-              _lib.ptr(intr.float().contiguous()), _lib.ptr(c2w.float().contiguous()), _lib.ptr(WH.long().contiguous()),
-              N, 1 if snap_to_pixel_centers else 0, _lib.ptr(o), _lib.ptr(d))
-    return o, d
+    """xy [N,2] in [0,1], fidx [N] int64, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] int64 -> rays_o, rays_d [N,3].
+    Differentiable w.r.t. ``c2w`` (pose refinement); everything else is a constant of the step."""
+    return _RaygenFn.apply(c2w, xy.detach().float().contiguous(), fidx.long().contiguous(),
+                           intr.detach().float().contiguous(), WH.long().contiguous(),
+                           1 if snap_to_pixel_centers else 0)
 
 
 def look_at_cameras(V=100, radius=3.0, H=800, W=800, f=1111.1, seed=42, device=None):

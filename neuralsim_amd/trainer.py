@@ -25,7 +25,13 @@ class RenderTrainer:
                  num_uniform: int = 4096, near: float = 0.01, far: Optional[float] = None, n_appear: int = 4,
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
                  distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
-                 target_sphere_radius: Optional[float] = None, pipeline: bool = True):
+                 target_sphere_radius: Optional[float] = None, pipeline: bool = True,
+                 pose_refine: Optional[dict] = None, c2w_true=None):
+        """pose_refine: ``dict(lr=1e-4, start_it=500)`` -- per-frame pose corrections (an axis-angle rotation and a
+        translation, ``c2w' = [R Exp(w) | T + dT]``) trained through the rays from ``start_it`` on, standing in for the
+        reference's ``LearnableParams`` (withmask_withlidar_joint.240219.yaml:338-352; the parametrisation of the
+        absent nr3d_lib is not known -- semantics fixed here).  ``c2w_true``: the poses the synthetic targets are
+        rendered from when they differ from the (noisy) ``c2w`` the training starts with."""
         self.model = model
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
         # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
@@ -38,7 +44,13 @@ class RenderTrainer:
         # encoding_cfg.anneal_cfg{type: hardmask, start_it, stop_it, start_level} (dtu yaml:104-108)
         self.level_anneal = dict(level_anneal) if level_anneal else None
         self.intr, self.c2w, self.WH = intr, c2w, WH
+        self.c2w_true = c2w if c2w_true is None else c2w_true
         self.V = intr.shape[0]
+        self.pose_refine = dict(pose_refine) if pose_refine else None
+        self.pose_delta, self.pose_optim, self._it = None, None, 0
+        if self.pose_refine is not None:
+            self.pose_delta = nn.Parameter(torch.zeros([self.V, 6], device=model.device))
+            self.pose_optim = torch.optim.Adam([self.pose_delta], lr=float(self.pose_refine.get("lr", 1e-4)))
         self.num_rays = num_rays             # rays per rank per iteration (weak scaling, as the reference's DDP)
         self.w_eikonal, self.num_uniform = w_eikonal, num_uniform
         self.near, self.far, self.perturb = near, far, perturb
@@ -62,6 +74,27 @@ class RenderTrainer:
                                                   depth_use_normalized_vw=False)).train()
         self.stats: Dict[str, float] = {}
 
+    def pose_refine_active(self) -> bool:
+        return self.pose_refine is not None and self._it >= int(self.pose_refine.get("start_it", 500))
+
+    def current_c2w(self) -> torch.Tensor:
+        """The poses rays are generated from: ``c2w`` or, once the refinement is active, [R Exp(w) | T + dT] (Rodrigues,
+        broadcast-multiply-sum as the reference insists for pose composition, nodes.py:79-84)."""
+        if not self.pose_refine_active():
+            return self.c2w
+        w, dT = self.pose_delta[:, :3], self.pose_delta[:, 3:]
+        th = w.norm(dim=-1, keepdim=True).clamp_min(1e-12)[..., None]              # [V,1,1]
+        K = torch.zeros([self.V, 3, 3], device=w.device, dtype=w.dtype)
+        K = K.index_put((torch.arange(self.V, device=w.device)[:, None], torch.tensor([[2, 0, 1]], device=w.device),
+                         torch.tensor([[1, 2, 0]], device=w.device)), w)              # K[2,1]=wx K[0,2]=wy K[1,0]=wz
+        K = K - K.transpose(1, 2)
+        K2 = (K[:, :, :, None] * K[:, None, :, :]).sum(-2)                             # K @ K
+        E = torch.eye(3, device=w.device) + torch.sin(th) / th * K + (1.0 - torch.cos(th)) / (th * th) * K2
+        R = self.c2w[:, :3, :3]
+        Rn = (R[:, :, :, None] * E[:, None, :, :]).sum(-2)                             # R @ E
+        top = torch.cat([Rn, (self.c2w[:, :3, 3] + dT)[..., None]], dim=-1)
+        return torch.cat([top, self.c2w[:, 3:4, :]], dim=1)
+
     def sample_batch(self):
         dev = self.model.device
         N = self.num_rays
@@ -70,8 +103,12 @@ class RenderTrainer:
         if self.target_sphere_radius is None:
             gt = torch.rand([N, 3], device=dev, generator=self.gen)
         else:
-            o, d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
-            self._ray_cache = (xy, o, d)
+            with torch.no_grad():           # the targets are pixels of the TRUE cameras
+                o, d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w_true, self.WH)
+            if self.c2w_true is self.c2w and not self.pose_refine_active():
+                self._ray_cache = (xy, o, d)
+            else:
+                self._ray_cache = None
             gt = self.sphere_image(o, d, self.target_sphere_radius)
         return xy, fidx, gt
 
@@ -92,7 +129,9 @@ class RenderTrainer:
         tested = None
         if batch is not None:
             rays_o, rays_d, tested = batch["rays_o"], batch["rays_d"], dict(batch["tested"])
-            if self.pipeline:
+            # no prefetch under pose refinement: it would build the next batch's graph on pose parameters that this
+            # step's optimizer then updates in place
+            if self.pipeline and not self.pose_refine_active():
                 bypass["_pre_sync_hook"] = self._prefetch
             if self.perturb:        # the batch's pre-drawn uniforms (rows 0..R-1 for the R hit rays)
                 R = tested["num_rays"]
@@ -100,7 +139,7 @@ class RenderTrainer:
         elif self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
-            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
+            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH)
         h_appear = None
         if tested is None or self.distant_model is not None or self.sky_model is not None:
             h_appear = embedding_lookup(self.appear, fidx)          # per-ray codes for every ray
@@ -126,9 +165,12 @@ class RenderTrainer:
         if self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
-            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w, self.WH)
-        with torch.no_grad():
+            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH)
+        if rays_o.requires_grad:        # pose refinement: the compaction of the hit rays stays in the graph
             tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
+        else:
+            with torch.no_grad():
+                tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
         return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested,
                     fidx_hit=fidx[tested["rays_inds"]], **extras)
 
@@ -160,6 +202,10 @@ class RenderTrainer:
 
     def train_step(self, it: int) -> torch.Tensor:
         model = self.model
+        self._it = int(it)
+        refine = self.pose_refine_active()
+        if refine and self._prefetched is not None:      # a batch drawn before the refinement started: re-draw with grad
+            self._prefetched = None
         # training_before_per_step: occupancy refresh with a rank-shared seed keeps replicas consistent
         acc = model.accel
         if self.level_anneal is not None:
@@ -185,10 +231,16 @@ class RenderTrainer:
             uni = model.forward_sdf_nablas(x_uni)
         loss, parts = self.loss(ret, gt, uni)
         self.optim.zero_grad()
+        if refine:
+            self.pose_optim.zero_grad(set_to_none=True)
         loss.backward()
         # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
         ndist.allreduce_grads(self.optim.params(), average=False)
         self.optim.step(grad_scale=1.0 / self.world_size)
+        if refine and self.pose_delta.grad is not None:
+            if self.world_size > 1:
+                ndist.allreduce_grads([self.pose_delta], average=True, wire_dtype=torch.float32)
+            self.pose_optim.step()
         vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
         self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
                           S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)

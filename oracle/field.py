@@ -139,13 +139,15 @@ def forward_sdf(x: torch.Tensor, p: FieldParams) -> torch.Tensor:
     return sdf_decoder(lotd_forward(x, p.grid, p.spec), p)
 
 
-def forward_sdf_nablas(x: torch.Tensor, p: FieldParams, nablas_has_grad: bool = True):
-    """-> (sdf [S], nablas [S,3]).  docs/exps/exp_permuto_3d_modulated.py:63-76."""
+def forward_sdf_nablas(x: torch.Tensor, p: FieldParams, nablas_has_grad: bool = True, x_has_grad: bool = False):
+    """-> (sdf [S], nablas [S,3]).  docs/exps/exp_permuto_3d_modulated.py:63-76.
+    x_has_grad: keep x in the graph (pose refinement: sdf and nablas are then differentiable w.r.t. the sample
+    positions, the latter through the mixed second derivatives of the piecewise-trilinear interpolant)."""
     outer_grad = torch.is_grad_enabled()
     with torch.enable_grad():
-        xg = x.detach().clone().requires_grad_(True)
+        xg = x if (x_has_grad and x.requires_grad) else x.detach().clone().requires_grad_(True)
         sdf = forward_sdf(xg, p)
-        create = outer_grad and nablas_has_grad and any(t.requires_grad for t in p.tensors())
+        create = outer_grad and nablas_has_grad and (any(t.requires_grad for t in p.tensors()) or xg is x)
         nablas = torch.autograd.grad(sdf, xg, torch.ones_like(sdf), create_graph=create,
                                      retain_graph=True)[0]
     if not create:
@@ -162,8 +164,8 @@ def radiance(x, v, nablas, h_appear, p: FieldParams) -> torch.Tensor:
     return torch.sigmoid(F.linear(a, p.rad_w[2], p.rad_b[2]))
 
 
-def forward_field(x, v, h_appear, p: FieldParams):
+def forward_field(x, v, h_appear, p: FieldParams, x_has_grad: bool = False):
     """The with-grad query of the render step: -> sdf [S], nablas [S,3], rgb [S,3]."""
-    sdf, nablas = forward_sdf_nablas(x, p, nablas_has_grad=True)
-    rgb = radiance(x.detach(), v, nablas, h_appear, p)
+    sdf, nablas = forward_sdf_nablas(x, p, nablas_has_grad=True, x_has_grad=x_has_grad)
+    rgb = radiance(x if x_has_grad else x.detach(), v, nablas, h_appear, p)
     return sdf, nablas, rgb

@@ -278,7 +278,7 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
     x = o[ridx] + t[:, None] * d[ridx]
     v = d[ridx]
     ha = h_appear[rays_inds][ridx] if h_appear is not None else torch.zeros(x.shape[0], 4)
-    sdf_g, nablas, rgb = forward_field(x, v, ha, p)
+    sdf_g, nablas, rgb = forward_field(x, v, ha, p, x_has_grad=x.requires_grad)   # rays with grad: pose refinement
     inv_s = p.inv_s() if forward_inv_s is None else torch.as_tensor(float(forward_inv_s))
     alpha = neus_alpha_packed(sdf_g, pi, inv_s)
     ret['volume_buffer'] = dict(type='packed', rays_inds_hit=rays_inds, pack_infos_hit=pi, t=t,

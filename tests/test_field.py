@@ -336,3 +336,59 @@ def test_field_more_than_16_levels(backend, levels, sdf_D, precision):
     for k, v in got.items():
         e = rel_l2(v.cpu(), ref[k])
         assert e < tol[3], (k, e)
+
+
+@pytest.mark.parametrize("levels,precision", [(16, "f32"), (16, "fp16"), (19, "f32")])
+def test_pose_gradients(backend, levels, precision):
+    """Pose refinement (LearnableParams, withmask_withlidar_joint.240219.yaml:338-352): gradients w.r.t. rays_o / rays_d
+    of the with-grad query -- through the features (dh/dx), the normals' own position dependence (mixed second
+    derivatives of the interpolant), the radiance net's position input and its view direction (SH-4) -- and
+    ``forward_sdf_nablas(x)`` w.r.t. x, against torch autograd on the oracle."""
+    lod_res = list(SMALL_RES_T) if levels == 16 else [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(levels)]
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=2, seed=5, sphere_init=False,
+                                 grid_bound=0.3, noise_scale=1.0)
+    p.grid = p.grid.float()
+    model = model_from_params(p, backend, precision=precision)
+    g = torch.Generator().manual_seed(4)
+    R, S = 9, 160
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    # oracle
+    o_r, d_r = leaf(rays_o), leaf(rays_d)
+    x = o_r[ridx] + t[:, None] * d_r[ridx]
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, d_r[ridx], h_appear[ridx], p, x_has_grad=True)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    # device
+    dv = lambda a: a.to(backend).contiguous()
+    o_d, d_d = leaf(rays_o, backend), leaf(rays_d, backend)
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, dv(h_appear), None, o_d, d_d, dv(t), dv(ridx), True)
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    tol = dict(f32=3e-4, fp16=4e-2)[precision]
+    assert rel_l2(o_d.grad.cpu(), o_r.grad) < tol, rel_l2(o_d.grad.cpu(), o_r.grad)
+    assert rel_l2(d_d.grad.cpu(), d_r.grad) < tol, rel_l2(d_d.grad.cpu(), d_r.grad)
+    # each rgb-free piece on its own: sdf only (first order), nablas only (second order)
+    for w_s, w_n in ((1.0, 0.0), (0.0, 1.0)):
+        o_r.grad = d_r.grad = None
+        x = o_r[ridx] + t[:, None] * d_r[ridx]
+        s_r, n_r = ofield.forward_sdf_nablas(x, p, x_has_grad=True)
+        ((s_r * ws).sum() * w_s + (n_r * wn).sum() * w_n).backward()
+        o_d.grad = d_d.grad = None
+        s_d, n_d = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                  model.rad_b, None, None, o_d, d_d, dv(t), dv(ridx), False)
+        ((s_d * dv(ws)).sum() * w_s + (n_d * dv(wn)).sum() * w_n).backward()
+        assert rel_l2(o_d.grad.cpu(), o_r.grad) < tol, (w_s, w_n, rel_l2(o_d.grad.cpu(), o_r.grad))
+        assert rel_l2(d_d.grad.cpu(), d_r.grad) < tol, (w_s, w_n)
+    # point mode: forward_sdf_nablas(x) with x.requires_grad
+    xp = (torch.rand(100, 3, generator=g) * 2 - 1) * 0.9
+    x_r = leaf(xp)
+    s_r, n_r = ofield.forward_sdf_nablas(x_r, p, x_has_grad=True)
+    ((s_r * ws[:100]).sum() + (n_r * wn[:100]).sum()).backward()
+    x_d = leaf(xp, backend)
+    out = model.forward_sdf_nablas(x_d)
+    ((out["sdf"] * dv(ws[:100])).sum() + (out["nablas"] * dv(wn[:100])).sum()).backward()
+    assert rel_l2(x_d.grad.cpu(), x_r.grad) < tol

@@ -217,3 +217,35 @@ def test_var_ctrl_mix_linear(backend):
     assert rel_l2(gw_c.cpu(), gw_r.cpu()) < 1e-5
     chain = (1 - a) * math.exp(ln0 * f) / inv_eff
     assert abs(g_c - chain * g_r) < 1e-4 * (1 + abs(g_r)), (g_c, chain * g_r)
+
+
+def test_ray_query_pose_gradients(backend):
+    """Rays that carry gradients (pose refinement) through ray_test -> ray_query -> rendered pixels: d loss / d rays_o,
+    d rays_d equal the oracle's autograd result; rays that miss the box get exactly zero."""
+    p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "f32")
+    N = o.shape[0]
+    o_r, d_r = leaf(o), leaf(d)
+    ret_o = orr.ray_query(p, o_r, d_r, h_appear, occ, AABB[0], AABB[1], RES, near=0.01, far=None, num_coarse=16,
+                          num_fine=(4, 4, 8), step_size=0.02, max_steps=512, jitter=jit, jitter_c=jit_c,
+                          depth_use_normalized_vw=False)
+    gt = torch.rand(ret_o["num_rays"], 3, generator=g)
+    wn = torch.randn(ret_o["num_rays"], 3, generator=g) * 0.1
+    lo = ((ret_o["rendered"]["rgb_volume"] - gt) ** 2).sum() + (ret_o["rendered"]["normals_volume"] * wn).sum() \
+        + ret_o["rendered"]["depth_volume"].sum()
+    lo.backward()
+    dv = lambda a: a.to(backend).contiguous()
+    o_d, d_d = leaf(o, backend), leaf(d, backend)
+    tested = model.ray_test(o_d, d_d, near=0.01, far=None, rays_h_appear=dv(h_appear))
+    ri = tested["rays_inds"].cpu()
+    cfg = dict(query_param=dict(QP), with_rgb=True, with_normal=True, depth_use_normalized_vw=False, _render=True,
+               _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]), query_mode="march_occ_multi_upsample")
+    ret = model.ray_query(ray_tested=tested, config=cfg)
+    l = ((ret["rendered"]["rgb_volume"] - dv(gt)) ** 2).sum() + (ret["rendered"]["normals_volume"] * dv(wn)).sum() \
+        + ret["rendered"]["depth_volume"].sum()
+    assert abs(float(l) - float(lo)) < 1e-4 * (1 + abs(float(lo)))
+    l.backward()
+    assert rel_l2(o_d.grad.cpu(), o_r.grad) < 2e-3, rel_l2(o_d.grad.cpu(), o_r.grad)
+    assert rel_l2(d_d.grad.cpu(), d_r.grad) < 2e-3, rel_l2(d_d.grad.cpu(), d_r.grad)
+    miss = torch.ones(N, dtype=torch.bool)
+    miss[ri] = False
+    assert miss.any() and float(o_d.grad.cpu()[miss].abs().max()) == 0.0

@@ -40,6 +40,25 @@ def test_raygen_and_aabb(backend):
     assert torch.allclose(nt.cpu()[hit_ref], n_ref[hit_ref], atol=1e-6) and torch.allclose(ft.cpu()[hit_ref], f_ref[hit_ref], atol=1e-6)
 
 
+def test_raygen_pose_gradient(backend):
+    """Pose refinement: d loss / d c2w through the ray generation (rays_o = T, rays_d = R l / |R l|) vs autograd on
+    the oracle; the bottom row of every pose gets no gradient, untouched frames none at all."""
+    from neuralsim_amd.graphics.cameras import pinhole_selected_rays
+    xy, fidx, intr, c2w, WH = _rays(N=257)
+    fidx[fidx == 3] = 2                                   # frame 3 is never sampled
+    g = torch.Generator().manual_seed(9)
+    wo, wd = torch.randn(257, 3, generator=g), torch.randn(257, 3, generator=g)
+    c_r = leaf(c2w)
+    o_r, d_r = orr.pinhole_rays(xy, fidx, intr, c_r, WH)
+    ((o_r * wo).sum() + (d_r * wd).sum()).backward()
+    c_d = leaf(c2w, backend)
+    o, d = pinhole_selected_rays(xy.to(backend), fidx.to(backend), intr.to(backend), c_d, WH.to(backend))
+    assert torch.allclose(o.detach().cpu(), o_r.detach(), atol=0) and torch.allclose(d.detach().cpu(), d_r.detach(), atol=2e-7)
+    ((o * wo.to(backend)).sum() + (d * wd.to(backend)).sum()).backward()
+    assert torch.allclose(c_d.grad.cpu(), c_r.grad, rtol=2e-4, atol=2e-5)
+    assert float(c_d.grad[:, 3].abs().max()) == 0.0 and float(c_d.grad[3].abs().max()) == 0.0
+
+
 def _sphere_occ(res=(64, 64, 64), shell=0.03):
     ax = [(torch.arange(r) + 0.5) / r * 2 - 1 for r in res]
     zz, yy, xx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")

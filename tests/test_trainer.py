@@ -31,3 +31,28 @@ def test_train_steps_reduce_loss(backend):
     assert all(l == l for l in losses)           # no NaN
     assert losses[-1] < losses[0], losses
     assert tr.stats["R_hit"] > 0 and tr.stats["S_f"] >= tr.stats["R_hit"] * 16
+
+
+def test_pose_refinement_steps(backend):
+    """Pose refinement wired through the step: before ``start_it`` the poses are constants (no gradient, pipelined
+    batches), afterwards the per-frame corrections receive finite non-zero gradients through ray generation ->
+    ray_test -> ray_query and move; the refined poses stay rigid (orthonormal rotation, bottom row untouched)."""
+    m = _tiny(backend)
+    intr, c2w_true, WH = look_at_cameras(V=4, seed=1, device=backend)
+    c2w = c2w_true.clone()
+    c2w[:, :3, 3] += 0.02 * torch.randn(4, 3, generator=torch.Generator().manual_seed(3)).to(backend)   # noisy start
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=32, lr=1e-3, num_uniform=16, perturb=True, target_sphere_radius=0.5,
+                       pose_refine=dict(lr=1e-3, start_it=2), c2w_true=c2w_true)
+    losses = [float(tr.train_step(it)) for it in range(2)]
+    assert tr.pose_delta.grad is None and float(tr.pose_delta.abs().max()) == 0.0
+    assert torch.equal(tr.current_c2w(), c2w)
+    losses += [float(tr.train_step(it)) for it in range(2, 6)]
+    assert all(l == l for l in losses)
+    g = tr.pose_delta.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0.0
+    assert float(tr.pose_delta.abs().max()) > 0.0
+    cur = tr.current_c2w().detach()
+    R = cur[:, :3, :3]
+    eye = torch.eye(3, device=R.device).expand(4, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5)
+    assert torch.equal(cur[:, 3], c2w[:, 3])
