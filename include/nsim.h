@@ -303,11 +303,13 @@ int nsim_distant_pack_weights(const NsimDistantMeta* meta, const float* den_w, c
 int nsim_distant_shells(const float* rays_o, const float* rays_d, const float* near, const float* jitter, int64_t N,
                         int K, const float* aabb, float r_min, float r_max, float* t, float* u4, uint8_t* valid,
                         void* stream);
-/* alpha = 1 - exp(-sigma * delta), delta = t[k+1]-t[k] (1e10 for the last shell: include_inf_distance); 0 if !valid */
-int nsim_density_alpha_fwd(const float* sigma, const float* t, const uint8_t* valid, int64_t N, int K, float* alpha,
-                           void* stream);
+/* alpha = 1 - exp(-sigma * delta), delta = t[k+1]-t[k]; last shell: 1e10 when include_inf_distance (object-centric
+ * configs, lotd_neus.dtu.230814.yaml:236) else the previous interval repeated (street config with a sky model,
+ * withmask_withlidar_joint.240219.yaml:294); 0 if !valid */
+int nsim_density_alpha_fwd(const float* sigma, const float* t, const uint8_t* valid, int64_t N, int K,
+                           int include_inf_distance, float* alpha, void* stream);
 int nsim_density_alpha_bwd(const float* sigma, const float* t, const uint8_t* valid, const float* dalpha, int64_t N,
-                           int K, float* dsigma, void* stream);
+                           int K, int include_inf_distance, float* dsigma, void* stream);
 /* fused 4-D gather + density MLP + radiance MLP on S = N*K points (ray = s / K): sigma [S], rgb [S,3];
  * h_planes [16,S,2] (may be NULL) saves the features for the backward. */
 int nsim_distant_fwd(const NsimDistantMeta* meta, const void* grid_f16, const void* wpack, const float* u4,

@@ -90,8 +90,8 @@ SIGNATURES = {
     "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_distant_pack_weights": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P],
     "nsim_distant_shells": [_P, _P, _P, _P, _I64, _I, C.POINTER(C.c_float * 6), _F, _F, _P, _P, _P],
-    "nsim_density_alpha_fwd": [_P, _P, _P, _I64, _I, _P],
-    "nsim_density_alpha_bwd": [_P, _P, _P, _P, _I64, _I, _P],
+    "nsim_density_alpha_fwd": [_P, _P, _P, _I64, _I, _I, _P],
+    "nsim_density_alpha_bwd": [_P, _P, _P, _P, _I64, _I, _I, _P],
     "nsim_distant_fwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_distant_bwd": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_lotd4_scatter": [C.POINTER(Lotd4Meta), _P, _P, _I64, _P, _P],

@@ -138,25 +138,33 @@ __global__ void __launch_bounds__(256) k_distant_shells(const float* __restrict_
   u4_out[4 * s + 3] = fminf(fmaxf(inv_r, 0.f), 1.f);
 }
 
-// alpha_k = 1 - exp(-sigma_k * delta_k), delta = t_{k+1} - t_k (1e10 for the last shell); 0 on invalid shells
+// alpha_k = 1 - exp(-sigma_k * delta_k), delta = t_{k+1} - t_k; the last shell reaches to infinity (1e10,
+// ``include_inf_distance: true``, object-centric configs) or repeats the previous interval (``false``: the street
+// config, whose sky model takes the remaining transmittance); 0 on invalid shells
+__device__ __forceinline__ float shell_delta(const float* t, const uint8_t* valid, int64_t s, int k, int K, int include_inf) {
+  if (k + 1 < K) return t[s + 1] - t[s];
+  if (include_inf) return 1e10f;
+  return (k > 0 && valid[s - 1]) ? t[s] - t[s - 1] : 0.f;
+}
+
 __global__ void __launch_bounds__(256) k_density_alpha_fwd(const float* __restrict__ sigma, const float* __restrict__ t,
                                                             const uint8_t* __restrict__ valid, int64_t N, int K,
-                                                            float* __restrict__ alpha) {
+                                                            int include_inf, float* __restrict__ alpha) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= N * K) return;
   const int k = (int)(s % K);
-  const float delta = (k + 1 < K) ? (t[s + 1] - t[s]) : 1e10f;
+  const float delta = shell_delta(t, valid, s, k, K, include_inf);
   alpha[s] = valid[s] ? 1.0f - expf(-sigma[s] * delta) : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_density_alpha_bwd(const float* __restrict__ sigma, const float* __restrict__ t,
                                                             const uint8_t* __restrict__ valid,
                                                             const float* __restrict__ dalpha, int64_t N, int K,
-                                                            float* __restrict__ dsigma) {
+                                                            int include_inf, float* __restrict__ dsigma) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= N * K) return;
   const int k = (int)(s % K);
-  const float delta = (k + 1 < K) ? (t[s + 1] - t[s]) : 1e10f;
+  const float delta = shell_delta(t, valid, s, k, K, include_inf);
   dsigma[s] = valid[s] ? dalpha[s] * delta * expf(-sigma[s] * delta) : 0.f;
 }
 
@@ -745,20 +753,20 @@ int nsim_distant_shells(const float* rays_o, const float* rays_d, const float* n
   return 0;
 }
 
-int nsim_density_alpha_fwd(const float* sigma, const float* t, const uint8_t* valid, int64_t N, int K, float* alpha,
-                           void* stream) {
+int nsim_density_alpha_fwd(const float* sigma, const float* t, const uint8_t* valid, int64_t N, int K,
+                           int include_inf_distance, float* alpha, void* stream) {
   if (N <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(k_density_alpha_fwd, dim3(nsim_blocks(N * K, 256)), dim3(256), 0, (hipStream_t)stream, sigma, t,
-                     valid, N, K, alpha);
+                     valid, N, K, include_inf_distance, alpha);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_density_alpha_bwd(const float* sigma, const float* t, const uint8_t* valid, const float* dalpha, int64_t N,
-                           int K, float* dsigma, void* stream) {
+                           int K, int include_inf_distance, float* dsigma, void* stream) {
   if (N <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(k_density_alpha_bwd, dim3(nsim_blocks(N * K, 256)), dim3(256), 0, (hipStream_t)stream, sigma, t,
-                     valid, dalpha, N, K, dsigma);
+                     valid, dalpha, N, K, include_inf_distance, dsigma);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

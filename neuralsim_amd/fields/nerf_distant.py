@@ -59,6 +59,8 @@ class _DistantFn(torch.autograd.Function):
         sigma = torch.empty([S], dtype=torch.float32, device=dev)
         rgb = torch.empty([S, 3], dtype=torch.float32, device=dev)
         need_bwd = any(ctx.needs_input_grad)
+        if not model.use_view_dirs:       # the SH columns of the first radiance layer are zero: any direction will do
+            rays_d = rays_d.detach()
         h_pl = torch.empty([16, S, 2], dtype=torch.float32, device=dev) if need_bwd else None
         ha = h_appear.detach().float().contiguous() if h_appear is not None else None
         _lib.call("nsim_distant_fwd", model.meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(u4), _lib.ptr(rays_d),
@@ -94,17 +96,18 @@ class _DistantFn(torch.autograd.Function):
         if dgrid is not None:
             _lib.call("nsim_lotd4_scatter", model.cfg.meta, _lib.ptr(u4), _lib.ptr(valid), ctx.S, _lib.ptr(dh_pl),
                       _lib.ptr(dgrid))
-        return (None, dgrid, dden_w, dden_b, drad_w, drad_b, dha, None, None, None, None)
+        return (None, dgrid, dden_w, dden_b, model._contract_rad_w(drad_w), drad_b, dha, None, None, None, None)
 
 
 class _DensityAlphaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sigma, t, valid, N, K):
+    def forward(ctx, sigma, t, valid, N, K, include_inf=True):
         sigma = sigma.float().contiguous()
         alpha = torch.empty_like(sigma)
-        _lib.call("nsim_density_alpha_fwd", _lib.ptr(sigma), _lib.ptr(t), _lib.ptr(valid), N, K, _lib.ptr(alpha))
+        _lib.call("nsim_density_alpha_fwd", _lib.ptr(sigma), _lib.ptr(t), _lib.ptr(valid), N, K, int(include_inf),
+                  _lib.ptr(alpha))
         ctx.save_for_backward(sigma, t, valid)
-        ctx.N, ctx.K = N, K
+        ctx.N, ctx.K, ctx.inf = N, K, int(include_inf)
         return alpha
 
     @staticmethod
@@ -112,8 +115,8 @@ class _DensityAlphaFn(torch.autograd.Function):
         sigma, t, valid = ctx.saved_tensors
         dsigma = torch.empty_like(sigma)
         _lib.call("nsim_density_alpha_bwd", _lib.ptr(sigma), _lib.ptr(t), _lib.ptr(valid), _lib.ptr(g.float().contiguous()),
-                  ctx.N, ctx.K, _lib.ptr(dsigma))
-        return dsigma, None, None, None, None
+                  ctx.N, ctx.K, ctx.inf, _lib.ptr(dsigma))
+        return dsigma, None, None, None, None, None
 
 
 class LoTDNeRFDistantModel(nn.Module):
@@ -121,9 +124,15 @@ class LoTDNeRFDistantModel(nn.Module):
 
     def __init__(self, aabb: torch.Tensor = None, precision: str = "fp16", radius_scale_min: float = 1.0,
                  radius_scale_max: float = 1000.0, max_steps: int = 64, include_inf_distance: bool = True,
-                 lotd_auto_compute_cfg: dict = None, param_bound: float = 1e-4, seed: int = 7, device=None):
+                 use_view_dirs: bool = True, lotd_auto_compute_cfg: dict = None, param_bound: float = 1e-4,
+                 seed: int = 7, device=None):
+        """``include_inf_distance`` / ``radiance_decoder_cfg.use_view_dirs``: true / true in the object-centric configs
+        (lotd_neus.dtu.230814.yaml:221-236), false / false in the street config, which has a sky model and feeds the
+        radiance net features + appearance only (withmask_withlidar_joint.240219.yaml:281-294).  The street config's
+        ``sample_mode: fixed_cuboid_shells`` + ``interval_type: inverse_proportional`` is what the shells kernel does:
+        cuboid shells = the AABB scaled about its centre, uniform in 1/r."""
         super().__init__()
-        assert include_inf_distance, "only include_inf_distance=True (the reference's object-centric configs) is built"
+        self.include_inf, self.use_view_dirs = bool(include_inf_distance), bool(use_view_dirs)
         c = dict(lotd_auto_compute_cfg or {})
         self.cfg = LoTD4Config(c.get("target_num_params", 8 * 2 ** 20), c.get("min_res_xyz", 8), c.get("min_res_w", 4),
                                c.get("log2_hashmap_size", 19), c.get("per_level_scale", 1.382))
@@ -139,7 +148,7 @@ class LoTDNeRFDistantModel(nn.Module):
             return (torch.rand(o, i, generator=g) * 2 - 1) * b, (torch.rand(o, generator=g) * 2 - 1) * b
         dw1, db1 = lin(64, F)
         dw2, db2 = lin(1, 64)
-        rw1, rb1 = lin(64, F + 20)
+        rw1, rb1 = lin(64, F + (20 if self.use_view_dirs else 4))
         rw2, rb2 = lin(64, 64)
         rw3, rb3 = lin(3, 64)
         self.den_w = nn.Parameter(torch.cat([dw1.reshape(-1), dw2.reshape(-1)]))
@@ -171,9 +180,29 @@ class LoTDNeRFDistantModel(nn.Module):
             if self._wpack is None or self._wpack.numel() != nbytes or self._wpack.device != self.den_w.device:
                 self._wpack = torch.zeros([nbytes], dtype=torch.uint8, device=self.den_w.device)
             _lib.call("nsim_distant_pack_weights", self.meta, _lib.ptr(self.den_w.detach()), _lib.ptr(self.den_b.detach()),
-                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(self._wpack))
+                      _lib.ptr(self._expand_rad_w(self.rad_w.detach())), _lib.ptr(self.rad_b.detach()),
+                      _lib.ptr(self._wpack))
             self._wpack_versions = vers
         return self.params16, self._wpack
+
+    # The kernels' first radiance layer is [64 x (F + 16 SH + 4 appearance)]; without view directions the parameter is
+    # [64 x (F + 4)] (the reference's shape) and the SH columns of the packed matrix are zeros.
+    def _expand_rad_w(self, rad_w: torch.Tensor) -> torch.Tensor:
+        if self.use_view_dirs:
+            return rad_w
+        F = self.cfg.out_features
+        q1 = rad_w[:64 * (F + 4)].view(64, F + 4)
+        full = torch.zeros([64, F + 20], dtype=rad_w.dtype, device=rad_w.device)
+        full[:, :F] = q1[:, :F]
+        full[:, F + 16:] = q1[:, F:]
+        return torch.cat([full.reshape(-1), rad_w[64 * (F + 4):]]).contiguous()
+
+    def _contract_rad_w(self, d_full: torch.Tensor) -> torch.Tensor:
+        if self.use_view_dirs:
+            return d_full
+        F = self.cfg.out_features
+        q1 = d_full[:64 * (F + 20)].view(64, F + 20)
+        return torch.cat([torch.cat([q1[:, :F], q1[:, F + 16:]], dim=1).reshape(-1), d_full[64 * (F + 20):]])
 
     def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config=None, return_buffer=True,
                   return_details=False, render_per_obj_individual=False) -> Dict:
@@ -198,7 +227,7 @@ class LoTDNeRFDistantModel(nn.Module):
         h_appear = ray_tested.get("rays_h_appear", None)
         sigma, rgb = _DistantFn.apply(self, self.flattened_params, self.den_w, self.den_b, self.rad_w, self.rad_b,
                                       h_appear, u4, d, valid, K)
-        alpha = _DensityAlphaFn.apply(sigma, t.reshape(-1), valid, N, K)
+        alpha = _DensityAlphaFn.apply(sigma, t.reshape(-1), valid, N, K, self.include_inf)
         vb = dict(type="batched", rays_inds_hit=torch.arange(N, device=dev), num_per_hit=K, t=t,
                   opacity_alpha=alpha.view(N, K), rgb=rgb.view(N, K, 3), sigma=sigma.view(N, K), valid=valid.view(N, K))
         ret = dict(volume_buffer=vb)

@@ -118,7 +118,7 @@ class DistantParams:
         return self
 
 
-def make_distant_params(spec: LoTD4Spec = None, seed=7, grid_bound=1e-4, W=64) -> DistantParams:
+def make_distant_params(spec: LoTD4Spec = None, seed=7, grid_bound=1e-4, W=64, use_view_dirs=True) -> DistantParams:
     spec = spec or make_ngp4d_spec()
     g = torch.Generator().manual_seed(seed)
     grid = (((torch.rand(spec.n_params, generator=g) * 2 - 1) * grid_bound).half()).float()
@@ -129,7 +129,7 @@ def make_distant_params(spec: LoTD4Spec = None, seed=7, grid_bound=1e-4, W=64) -
         return (torch.rand(o, i, generator=g) * 2 - 1) * b, (torch.rand(o, generator=g) * 2 - 1) * b
     dw1, db1 = lin(W, Fdim)
     dw2, db2 = lin(1, W)
-    rw1, rb1 = lin(W, Fdim + 20)
+    rw1, rb1 = lin(W, Fdim + (20 if use_view_dirs else 4))     # radiance_decoder_cfg.use_view_dirs (street: false)
     rw2, rb2 = lin(W, W)
     rw3, rb3 = lin(3, W)
     return DistantParams(spec, grid, [dw1, dw2], [db1, db2], [rw1, rw2, rw3], [rb1, rb2, rb3])
@@ -140,7 +140,8 @@ def distant_forward(u4, v, h_appear, p: DistantParams):
     h = lotd4_forward(u4, p.grid, p.spec)
     a = F.relu(F.linear(h, p.den_w[0], p.den_b[0]))
     sigma = F.softplus(F.linear(a, p.den_w[1], p.den_b[1]).squeeze(-1))
-    rin = torch.cat([h, sh4(v), h_appear], dim=-1)
+    use_view_dirs = p.rad_w[0].shape[1] == h.shape[1] + 20
+    rin = torch.cat([h, sh4(v), h_appear], dim=-1) if use_view_dirs else torch.cat([h, h_appear], dim=-1)
     r = F.relu(F.linear(rin, p.rad_w[0], p.rad_b[0]))
     r = F.relu(F.linear(r, p.rad_w[1], p.rad_b[1]))
     rgb = torch.sigmoid(F.linear(r, p.rad_w[2], p.rad_b[2]))
@@ -180,20 +181,27 @@ def shell_points_u4(rays_o, rays_d, t, inv_r, aabb_min, aabb_max):
     return u.clamp(0.0, 1.0)
 
 
-def density_alpha(sigma, t, valid):
-    """alpha_k = 1 - exp(-sigma_k delta_k) over valid shells; the last valid shell reaches to infinity."""
+def density_alpha(sigma, t, valid, include_inf=True):
+    """alpha_k = 1 - exp(-sigma_k delta_k) over valid shells; the last valid shell reaches to infinity
+    (``include_inf_distance``) or repeats the interval before it (0 if it has no valid predecessor)."""
     N, K = t.shape
     big = torch.full_like(t, float('inf'))
     tv = torch.where(valid, t, big)
     # next valid depth: suffix minimum of later valid depths
     nxt = torch.flip(torch.cummin(torch.flip(torch.cat([tv[:, 1:], big[:, :1]], dim=1), [1]), dim=1).values, [1])
-    delta = torch.where(torch.isinf(nxt), torch.full_like(t, 1e10), nxt - t)
+    if include_inf:
+        last = torch.full_like(t, 1e10)
+    else:
+        prev_t = torch.cat([t[:, :1], t[:, :-1]], dim=1)
+        prev_ok = torch.cat([valid[:, :1] & False, valid[:, :-1]], dim=1)
+        last = torch.where(prev_ok, t - prev_t, torch.zeros_like(t))
+    delta = torch.where(torch.isinf(nxt), last, nxt - t)
     alpha = 1.0 - torch.exp(-sigma * delta)
     return torch.where(valid, alpha, torch.zeros_like(alpha))
 
 
 def distant_ray_query(p: DistantParams, rays_o, rays_d, near, h_appear, aabb_min, aabb_max, K=64, r_min=1.0,
-                      r_max=1000.0, jitter=None):
+                      r_max=1000.0, jitter=None, include_inf=True):
     """``query_mode: march`` of the distant model on ALL rays -> batched volume buffer [N,K]."""
     N = rays_o.shape[0]
     with torch.no_grad():
@@ -203,6 +211,6 @@ def distant_ray_query(p: DistantParams, rays_o, rays_d, near, h_appear, aabb_min
     ha = h_appear[:, None, :].expand(N, K, 4) if h_appear is not None else torch.zeros(N, K, 4)
     sigma, rgb = distant_forward(u4.reshape(-1, 4), v.reshape(-1, 3), ha.reshape(-1, 4), p)
     sigma, rgb = sigma.view(N, K), rgb.view(N, K, 3)
-    alpha = density_alpha(sigma, t, valid)
+    alpha = density_alpha(sigma, t, valid, include_inf)
     return dict(type='batched', rays_inds_hit=torch.arange(N), num_per_hit=K, t=t, opacity_alpha=alpha, rgb=rgb,
                 sigma=sigma, valid=valid, u4=u4)

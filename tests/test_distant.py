@@ -9,9 +9,10 @@ from util import leaf, look_at_cameras, rel_l2
 AABB = torch.tensor([[-1.0, -1, -1], [1.0, 1, 1]])
 
 
-def _model_from(p, backend, precision):
+def _model_from(p, backend, precision, street=False):
     from neuralsim_amd.fields.nerf_distant import LoTDNeRFDistantModel
-    m = LoTDNeRFDistantModel(aabb=AABB, precision=precision, max_steps=16,
+    m = LoTDNeRFDistantModel(aabb=AABB, precision=precision, max_steps=16, include_inf_distance=not street,
+                             use_view_dirs=not street,
                              lotd_auto_compute_cfg=dict(target_num_params=2 ** 14, min_res_xyz=3, min_res_w=2,
                                                         log2_hashmap_size=10, per_level_scale=1.382))
     assert m.cfg.n_params == p.spec.n_params and m.cfg.res_xyz == p.spec.res_xyz
@@ -24,11 +25,14 @@ def _model_from(p, backend, precision):
     return m.to(backend)
 
 
-@pytest.mark.parametrize("precision", ["f32", "fp16"])
-def test_distant_model_parity(backend, precision):
+@pytest.mark.parametrize("precision,street", [("f32", False), ("fp16", False), ("f32", True)])
+def test_distant_model_parity(backend, precision, street):
+    """street = the street config's variant (withmask_withlidar_joint.240219.yaml:281-294): no view directions in the
+    radiance net (first layer [64 x (F + 4)]), ``include_inf_distance: false``."""
     spec = od.make_ngp4d_spec(target_num_params=2 ** 14, min_res_xyz=3, min_res_w=2, log2_hashmap_size=10)
     assert "Hash" in spec.types and "Dense" in spec.types and spec.num_levels < 16
-    p = od.make_distant_params(spec, grid_bound=0.5)
+    p = od.make_distant_params(spec, grid_bound=0.5, use_view_dirs=not street)
+    assert p.rad_w[0].shape[1] == 2 * spec.num_levels + (4 if street else 20)
     p.requires_grad_(True)
     g = torch.Generator().manual_seed(1)
     N, K = 21, 16
@@ -41,8 +45,10 @@ def test_distant_model_parity(backend, precision):
     ha = torch.randn(N, 4, generator=g) * 0.3
     jit = torch.rand(N, K, generator=g)
     ha_o = leaf(ha)
-    vbo = od.distant_ray_query(p, o, d, near, ha_o, AABB[0], AABB[1], K=K, jitter=jit)
-    m = _model_from(p, backend, precision)
+    vbo = od.distant_ray_query(p, o, d, near, ha_o, AABB[0], AABB[1], K=K, jitter=jit, include_inf=not street)
+    m = _model_from(p, backend, precision, street)
+    if street:      # the last shell no longer absorbs everything
+        assert float(vbo["opacity_alpha"][:, -1].min()) < 1.0
     dv = lambda t: t.to(backend).contiguous()
     ha_d = leaf(ha, backend)
     ret = m.ray_query(ray_tested=dict(rays_o=dv(o), rays_d=dv(d), near=dv(near), rays_h_appear=ha_d),
