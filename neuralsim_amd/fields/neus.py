@@ -38,6 +38,29 @@ def _flat_sizes(D: int, L: int = 16):
     return n_sdf_w, n_sdf_b, n_rad_w, n_rad_b
 
 
+def append_extra_points(model, rays_o, rays_d, t, ridx, h_appear, extra_x):
+    """Free points appended to a ray-mode query as M zero-length rays (origin = the point, direction e_z, depth 0,
+    appearance code 0): ray arrays grow to [R+M], sample arrays to [S+M]."""
+    dev = rays_o.device
+    R, M = rays_o.shape[0], extra_x.shape[0]
+    xe = extra_x.detach().float().reshape(-1, 3)
+    ck = (M, str(dev))
+    cache = getattr(model, "_extra_cache", None)
+    if cache is None or cache[0] != ck:          # constants of the M zero-length rays: dir e_z, t 0, codes 0
+        ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
+        ez[:, 2] = 1.0
+        cache = model._extra_cache = (ck, ez, torch.zeros([M], dtype=torch.float32, device=dev),
+                                      torch.zeros([M, 4], dtype=torch.float32, device=dev))
+    _, ez, tz, hz = cache
+    rays_o, rays_d = torch.cat([rays_o, xe]), torch.cat([rays_d, ez])
+    t = torch.cat([t, tz])
+    ridx = torch.cat([ridx, torch.arange(R, R + M, device=dev)])
+    if h_appear is not None:
+        hz = hz if h_appear.shape[1] == 4 else hz.new_zeros([M, h_appear.shape[1]])
+        h_appear = torch.cat([h_appear.detach().float(), hz])
+    return rays_o, rays_d, t, ridx, h_appear
+
+
 # --------------------------------------------------------------------------------------------- autograd
 class _FieldFn(torch.autograd.Function):
     """(grid, sdf_w, sdf_b, rad_w, rad_b, h_appear) -> (sdf [S], nablas [S,3], rgb [S,3]).
@@ -56,22 +79,8 @@ class _FieldFn(torch.autograd.Function):
         M = 0
         if extra_x is not None:
             assert x is None and goff is None, "extra points ride on a ray-mode query of a single-instance model"
-            R, M = rays_o.shape[0], extra_x.shape[0]
-            xe = extra_x.detach().float().reshape(-1, 3)
-            ck = (M, str(dev))
-            cache = getattr(model, "_extra_cache", None)
-            if cache is None or cache[0] != ck:          # constants of the M zero-length rays: dir e_z, t 0, codes 0
-                ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
-                ez[:, 2] = 1.0
-                cache = model._extra_cache = (ck, ez, torch.zeros([M], dtype=torch.float32, device=dev),
-                                              torch.zeros([M, 4], dtype=torch.float32, device=dev))
-            _, ez, tz, hz = cache
-            rays_o, rays_d = torch.cat([rays_o, xe]), torch.cat([rays_d, ez])
-            t = torch.cat([t, tz])
-            ridx = torch.cat([ridx, torch.arange(R, R + M, device=dev)])
-            if h_appear is not None:
-                hz = hz if h_appear.shape[1] == 4 else hz.new_zeros([M, h_appear.shape[1]])
-                h_appear = torch.cat([h_appear.detach().float(), hz])
+            M = extra_x.shape[0]
+            rays_o, rays_d, t, ridx, h_appear = append_extra_points(model, rays_o, rays_d, t, ridx, h_appear, extra_x)
         S = x.shape[0] if x is not None else t.shape[0]
         grid16, wpack = model._shadow()
         sdf = torch.empty([S], dtype=torch.float32, device=dev)
@@ -801,20 +810,11 @@ class LoTDNeuSModel(nn.Module):
             return None
         return int(1.3 * M0 * R / R0) + 8192
 
-    def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,
-                  return_details: bool = False, render_per_obj_individual: bool = False) -> Dict:
-        """``query_mode = march_occ_multi_upsample`` (single_volume_renderer.py:244-246)."""
-        cfg = dict(config)
-        qp = dict(cfg.get("query_param", self.ray_query_cfg.get("query_param", {})))
-        with_rgb = cfg.get("with_rgb", True)
-        with_normal = cfg.get("with_normal", False)
-        ret = dict()
+    def _query_samples(self, ray_tested: dict, cfg: dict, qp: dict):
+        """The no-grad half of ``ray_query``: occupancy marching + coarse depths + NeuS up-sampling (+ compression) of the
+        R tested rays.  -> (o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis): depths t [S] packed by pi [R,2] with
+        ray indices ridx [S] -- constants of the differentiable part that follows."""
         R = ray_tested["num_rays"]
-        if R == 0:
-            ret["volume_buffer"] = dict(type="empty")
-            if return_details:
-                ret["details"] = dict()
-            return ret
         o = ray_tested["rays_o"].detach().float().contiguous()
         d = ray_tested["rays_d"].detach().float().contiguous()
         near, far = ray_tested["near"].contiguous(), ray_tested["far"].contiguous()
@@ -858,6 +858,23 @@ class LoTDNeuSModel(nn.Module):
                     if not self._sdf_fused:
                         _lib.TIMER.note_units("nsim_lotd_gather_lm", S0)
                 t, pi, ridx = t_k, pi_k, ridx_k
+        return o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis
+
+    def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,
+                  return_details: bool = False, render_per_obj_individual: bool = False) -> Dict:
+        """``query_mode = march_occ_multi_upsample`` (single_volume_renderer.py:244-246)."""
+        cfg = dict(config)
+        qp = dict(cfg.get("query_param", self.ray_query_cfg.get("query_param", {})))
+        with_rgb = cfg.get("with_rgb", True)
+        with_normal = cfg.get("with_normal", False)
+        ret = dict()
+        R = ray_tested["num_rays"]
+        if R == 0:
+            ret["volume_buffer"] = dict(type="empty")
+            if return_details:
+                ret["details"] = dict()
+            return ret
+        o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis = self._query_samples(ray_tested, cfg, qp)
         if t.shape[0] == 0:
             ret["volume_buffer"] = dict(type="empty")
             if return_details:

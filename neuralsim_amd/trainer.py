@@ -14,7 +14,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, distributed as ndist
-from .fields.neus import LoTDNeuSModel, volume_integration
+import os
+
+from .fields.neus import LoTDNeuSModel, volume_integration, append_extra_points, _flat_sizes
 from .graphics.cameras import pinhole_selected_rays
 from .optim import FusedAdam
 from .losses import eikonal_loss, mse_loss, embedding_lookup
@@ -26,13 +28,17 @@ class RenderTrainer:
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
                  distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
                  target_sphere_radius: Optional[float] = None, pipeline: bool = True,
-                 pose_refine: Optional[dict] = None, c2w_true=None):
+                 pose_refine: Optional[dict] = None, c2w_true=None, fused_step: Optional[bool] = None):
         """pose_refine: ``dict(lr=1e-4, start_it=500)`` -- per-frame pose corrections (an axis-angle rotation and a
         translation, ``c2w' = [R Exp(w) | T + dT]``) trained through the rays from ``start_it`` on, standing in for the
         reference's ``LearnableParams`` (withmask_withlidar_joint.240219.yaml:338-352; the parametrisation of the
         absent nr3d_lib is not known -- semantics fixed here).  ``c2w_true``: the poses the synthetic targets are
         rendered from when they differ from the (noisy) ``c2w`` the training starts with."""
         self.model = model
+        # fused_step (default on, env NSIM_FUSED_STEP=0 turns it off): the differentiable part of the iteration -- field
+        # forward, sdf->alpha, compositing, losses and their whole backward -- is issued as one straight chain of
+        # launches without the autograd engine in between (``_train_render_fused``); same kernels, same numbers
+        self.fused_step = (os.environ.get("NSIM_FUSED_STEP", "1") == "1") if fused_step is None else bool(fused_step)
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
         # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
         self.target_sphere_radius = target_sphere_radius
@@ -151,6 +157,123 @@ class RenderTrainer:
                                    sky_model=self.sky_model, bypass_ray_query_cfg=bypass or None, cr_ray_tested=tested)
         return ret
 
+    # ------------------------------------------------------------------ the differentiable part as one launch chain
+    def _fused_ok(self) -> bool:
+        m = self.model
+        return (self.fused_step and type(m) is LoTDNeuSModel and self.distant_model is None and self.sky_model is None
+                and not self.pose_refine_active() and getattr(m, "_ctrl_mix", 0.0) == 0.0)
+
+    def _train_render_fused(self, batch: dict) -> Optional[torch.Tensor]:
+        """render + loss + backward of one prefetched batch WITHOUT the autograd engine: the launches the autograd path
+        issues (``_FieldFn`` / ``_NeusAlphaFn`` / ``_CompositeFn`` / the fused losses and their backwards), back to
+        back, gradients assigned to ``.grad``.  Between the sample-count sync and the first large backward kernel the
+        GPU has ~0.2 ms of work queued; the autograd path spends ~0.6 ms of host time there (graph nodes, small
+        elementwise kernels, engine hops) and the chip idles -- here the same stretch is ~20 plain launches.
+        Covers the object-centric training configuration (one NeuS model, photometric mse + eikonal on render samples and
+        uniform points, appearance codes); returns None when no ray produced samples (caller falls back)."""
+        model = self.model
+        tested = batch["tested"]
+        R, N = tested["num_rays"], self.num_rays
+        if R == 0:
+            return None
+        dev = model.device
+        cfg = dict(model.ray_query_cfg)
+        cfg.update(self.renderer.config)
+        cfg.update(with_rgb=True, with_normal=True)
+        if self.pipeline:
+            cfg["_pre_sync_hook"] = self._prefetch
+        if self.perturb:
+            cfg["_jitter"], cfg["_jitter_c"] = batch["jitter"][:R], batch["jitter_c"][:R]
+        qp = dict(cfg.get("query_param", model.ray_query_cfg.get("query_param", {})))
+        o, d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
+        S = int(t.shape[0])
+        if S == 0:
+            return None
+        call, ptr = _lib.call, _lib.ptr
+        f32 = dict(dtype=torch.float32, device=dev)
+        ha = self.appear.detach()[batch["fidx_hit"]]
+        x_uni = batch["x_uni"] if self.num_uniform > 0 else None
+        M = int(x_uni.shape[0]) if x_uni is not None else 0
+        if M:
+            o, d, t_a, ridx_a, ha = append_extra_points(model, o, d, t, ridx, ha, x_uni)
+        else:
+            t_a, ridx_a = t, ridx
+        St = S + M
+        grid16, wpack = model._shadow()
+        fm, NLP = model.field_meta, model.plane_levels
+        # ---------------------------------------------------------------- forward
+        sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
+        h_pl, J_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2, 3], **f32)
+        call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha), St,
+             ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl))
+        ln_inv_s = model.ln_inv_s.detach()
+        alpha = torch.empty([S], **f32)
+        call("nsim_neus_alpha_fwd", ptr(sdf), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(alpha))
+        vw, trans = torch.empty([S], **f32), torch.empty([S], **f32)
+        nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
+        every_ray = R == N                      # rays_inds sorted & unique: identity
+        if every_ray:
+            sc, vec, out_idx = torch.empty([2, N], **f32), torch.empty([2, N, 3], **f32), None
+        else:
+            sc, vec, out_idx = torch.zeros([2, N], **f32), torch.zeros([2, N, 3], **f32), tested["rays_inds"]
+        call("nsim_composite_fwd", ptr(alpha), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(vw), ptr(trans), ptr(sc[0]),
+             ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
+        gt = batch["gt"]
+        acc = torch.zeros([3], **f32)           # mse, eikonal(render samples), eikonal(uniform points)
+        call("nsim_mse_loss_fwd", ptr(vec[0]), ptr(gt), N * 3, ptr(acc))
+        call("nsim_eikonal_loss_fwd", ptr(nab), S, ptr(acc[1:]))
+        if M:
+            call("nsim_eikonal_loss_fwd", ptr(nab[S:]), M, ptr(acc[2:]))
+        cst = getattr(self, "_fused_consts", None)
+        if cst is None or cst[0].device != dev:
+            cst = self._fused_consts = (torch.ones([], **f32), torch.full([], float(self.w_eikonal), **f32),
+                                        torch.tensor([1.0, self.w_eikonal, self.w_eikonal], **f32))
+        one, w_eik, w_vec = cst
+        # ---------------------------------------------------------------- backward of loss = mse + w (eik + eik)
+        d_img = torch.empty([N, 3], **f32)
+        call("nsim_mse_loss_bwd", ptr(vec[0]), ptr(gt), N * 3, ptr(one), ptr(d_img))
+        dalpha, drgb, dsdf, dnab = (torch.empty([S], **f32), torch.empty([St, 3], **f32), torch.empty([St], **f32),
+                                    torch.empty([St, 3], **f32))
+        if M:                                   # the free points have no colour / alpha consumers
+            drgb[S:].zero_()
+            dsdf[S:].zero_()
+        call("nsim_composite_bwd", ptr(alpha), ptr(trans), ptr(vw), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(sc[0]),
+             ptr(sc[1]), None, None, ptr(d_img), None, None, ptr(dalpha), ptr(drgb), None, ptr(out_idx))
+        dln = torch.zeros([1], **f32)
+        call("nsim_neus_alpha_bwd", ptr(sdf), ptr(dalpha), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(dsdf),
+             ptr(dln))
+        call("nsim_eikonal_loss_bwd", ptr(nab), S, ptr(w_eik), ptr(dnab))
+        if M:
+            call("nsim_eikonal_loss_bwd", ptr(nab[S:]), M, ptr(w_eik), ptr(dnab[S:]))
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
+        dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
+        dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], **f32).split(
+            [n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
+        dha = torch.zeros([R + M, ha.shape[1]], **f32)
+        gn_total = torch.empty([St, 3], **f32)
+        call("nsim_field_bwd_rad", fm, ptr(wpack), ptr(nab), ptr(rgb), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), ptr(ha),
+             St, ptr(dnab), ptr(drgb), ptr(gn_total), ptr(drad_w), ptr(drad_b), ptr(dha), None, None)
+        dh_pl, g_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2], **f32)
+        call("nsim_field_bwd_sdf", fm, ptr(wpack), ptr(h_pl), ptr(J_pl), St, ptr(dsdf), ptr(gn_total), ptr(dh_pl),
+             ptr(g_pl), ptr(dsdf_w), ptr(dsdf_b), None)
+        call("nsim_lotd_scatter", model.encoding.cfg.meta, None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, St,
+             ptr(dh_pl), ptr(g_pl), ptr(gn_total), ptr(dgrid))
+        if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
+            dsdf_w[-64:] /= model.sdf_scale
+            dsdf_b[-1:] /= model.sdf_scale
+        d_app = torch.zeros_like(self.appear)
+        call("nsim_rows_scatter_add", ptr(dha), ptr(batch["fidx_hit"]), R, int(ha.shape[1]), self.V, ptr(d_app))
+        if _lib.TIMER is not None:
+            for k in ("nsim_field_fwd", "nsim_field_bwd_sdf", "nsim_lotd_scatter", "nsim_field_bwd_rad"):
+                _lib.TIMER.note_units(k, St)
+        model.encoding.flattened_params.grad = dgrid
+        model.sdf_w.grad, model.sdf_b.grad, model.rad_w.grad, model.rad_b.grad = dsdf_w, dsdf_b, drad_w, drad_b
+        if model.ln_inv_s.requires_grad:
+            model.ln_inv_s.grad = dln
+        self.appear.grad = d_app
+        self.stats = dict(R_hit=R, S_f=S)
+        return torch.dot(acc, w_vec)
+
     def _make_batch(self) -> dict:
         """sample_batch + ray generation + the AABB test (with its hit-ray compaction sync) of one batch, plus -- in
         ONE generator call -- the step's other uniforms: marching jitter [N], coarse-depth jitter [N, C] (the first R
@@ -225,15 +348,23 @@ class RenderTrainer:
             x_uni = batch["x_uni"]
         else:
             x_uni = self.sample_uniform_x() if self.num_uniform > 0 else None
-        ret = self.render(xy, fidx, extra_pts=x_uni, batch=batch)
-        uni = None
-        if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
-            uni = model.forward_sdf_nablas(x_uni)
-        loss, parts = self.loss(ret, gt, uni)
-        self.optim.zero_grad()
-        if refine:
-            self.pose_optim.zero_grad(set_to_none=True)
-        loss.backward()
+        loss = None
+        if batch is not None and self._fused_ok():
+            self.optim.zero_grad()
+            loss = self._train_render_fused(batch)
+        if loss is None:
+            ret = self.render(xy, fidx, extra_pts=x_uni, batch=batch)
+            uni = None
+            if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
+                uni = model.forward_sdf_nablas(x_uni)
+            loss, parts = self.loss(ret, gt, uni)
+            self.optim.zero_grad()
+            if refine:
+                self.pose_optim.zero_grad(set_to_none=True)
+            loss.backward()
+            vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
+            self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
+                              S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
         # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
         ndist.allreduce_grads(self.optim.params(), average=False)
         self.optim.step(grad_scale=1.0 / self.world_size)
@@ -241,7 +372,4 @@ class RenderTrainer:
             if self.world_size > 1:
                 ndist.allreduce_grads([self.pose_delta], average=True, wire_dtype=torch.float32)
             self.pose_optim.step()
-        vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
-        self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
-                          S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
         return loss.detach()

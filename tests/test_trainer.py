@@ -56,3 +56,25 @@ def test_pose_refinement_steps(backend):
     eye = torch.eye(3, device=R.device).expand(4, 3, 3)
     assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5)
     assert torch.equal(cur[:, 3], c2w[:, 3])
+
+
+def test_fused_step_equals_autograd_step(backend):
+    """The straight launch chain of ``_train_render_fused`` is the autograd step with the engine removed: same loss,
+    same parameters after a few iterations (identical kernels; only the order of float atomics may differ)."""
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(0)                    # the occupancy initialisation draws from the global generator
+        m = _tiny(backend)
+        intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, num_uniform=24, perturb=True,
+                           target_sphere_radius=0.5, fused_step=fused)
+        assert tr._fused_ok() == fused
+        losses = [float(tr.train_step(it)) for it in range(5)]
+        outs.append((losses, m.encoding.flattened_params.detach().clone(), m.sdf_w.detach().clone(),
+                     m.rad_w.detach().clone(), m.ln_inv_s.detach().clone(), tr.appear.detach().clone(), dict(tr.stats)))
+    (la, *pa, sa), (lb, *pb, sb) = outs
+    assert sa == sb and sa["S_f"] > 0
+    assert all(abs(x - y) < 1e-5 * (1 + abs(x)) for x, y in zip(la, lb)), (la, lb)
+    for a, b in zip(pa, pb):
+        # float atomics commute only approximately and Adam normalises tiny gradients: a few 1e-6 after five steps
+        assert torch.allclose(a, b, rtol=1e-4, atol=5e-5), float((a - b).abs().max())
