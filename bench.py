@@ -168,6 +168,7 @@ def main():
     if rank == 0:
         out["config"]["distant_model"] = bool(args.distant)
         out["config"]["sky_model"] = bool(args.sky)
+        out["config"]["launch_chain"] = "fused (no autograd engine)" if tr._fused_ok() else "autograd"
         if world == 1 and not args.no_cpu_baseline and not args.distant and not args.sky:
             out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
         print(json.dumps(out), flush=True)
