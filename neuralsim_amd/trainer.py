@@ -201,6 +201,21 @@ class RenderTrainer:
         St = S + M
         grid16, wpack = model._shadow()
         fm, NLP = model.field_meta, model.plane_levels
+        # every buffer that must start at zero comes out of ONE arena (one memset instead of nine small ones)
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
+        every_ray = R == N                      # rays_inds sorted & unique: identity
+        A = ha.shape[1]
+        sizes = [4, 4, n_sdf_w, n_sdf_b, n_rad_w, n_rad_b, (R + M) * A, self.V * A, St * 3, St,
+                 0 if every_ray else 2 * N, 0 if every_ray else 6 * N]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) & ~3
+        arena = torch.zeros([tot], **f32)
+        acc, dln, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_app, drgb, dsdf, sc0, vec0 = [
+            arena[o_:o_ + n] for o_, n in zip(offs, sizes)]
+        acc, dln = acc[:3], dln[:1]
+        dha, d_app, drgb = dha.view(R + M, A), d_app.view(self.V, A), drgb.view(St, 3)
         # ---------------------------------------------------------------- forward
         sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
         h_pl, J_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2, 3], **f32)
@@ -211,15 +226,14 @@ class RenderTrainer:
         call("nsim_neus_alpha_fwd", ptr(sdf), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(alpha))
         vw, trans = torch.empty([S], **f32), torch.empty([S], **f32)
         nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
-        every_ray = R == N                      # rays_inds sorted & unique: identity
         if every_ray:
             sc, vec, out_idx = torch.empty([2, N], **f32), torch.empty([2, N, 3], **f32), None
         else:
-            sc, vec, out_idx = torch.zeros([2, N], **f32), torch.zeros([2, N, 3], **f32), tested["rays_inds"]
+            sc, vec, out_idx = sc0.view(2, N), vec0.view(2, N, 3), tested["rays_inds"]
         call("nsim_composite_fwd", ptr(alpha), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(vw), ptr(trans), ptr(sc[0]),
              ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
         gt = batch["gt"]
-        acc = torch.zeros([3], **f32)           # mse, eikonal(render samples), eikonal(uniform points)
+        # acc: mse, eikonal(render samples), eikonal(uniform points)
         call("nsim_mse_loss_fwd", ptr(vec[0]), ptr(gt), N * 3, ptr(acc))
         call("nsim_eikonal_loss_fwd", ptr(nab), S, ptr(acc[1:]))
         if M:
@@ -232,24 +246,16 @@ class RenderTrainer:
         # ---------------------------------------------------------------- backward of loss = mse + w (eik + eik)
         d_img = torch.empty([N, 3], **f32)
         call("nsim_mse_loss_bwd", ptr(vec[0]), ptr(gt), N * 3, ptr(one), ptr(d_img))
-        dalpha, drgb, dsdf, dnab = (torch.empty([S], **f32), torch.empty([St, 3], **f32), torch.empty([St], **f32),
-                                    torch.empty([St, 3], **f32))
-        if M:                                   # the free points have no colour / alpha consumers
-            drgb[S:].zero_()
-            dsdf[S:].zero_()
+        dalpha, dnab = torch.empty([S], **f32), torch.empty([St, 3], **f32)
+        # (drgb / dsdf come zeroed from the arena: the free points have no colour / alpha consumers)
         call("nsim_composite_bwd", ptr(alpha), ptr(trans), ptr(vw), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(sc[0]),
              ptr(sc[1]), None, None, ptr(d_img), None, None, ptr(dalpha), ptr(drgb), None, ptr(out_idx))
-        dln = torch.zeros([1], **f32)
         call("nsim_neus_alpha_bwd", ptr(sdf), ptr(dalpha), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(dsdf),
              ptr(dln))
         call("nsim_eikonal_loss_bwd", ptr(nab), S, ptr(w_eik), ptr(dnab))
         if M:
             call("nsim_eikonal_loss_bwd", ptr(nab[S:]), M, ptr(w_eik), ptr(dnab[S:]))
-        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
         dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
-        dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], **f32).split(
-            [n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
-        dha = torch.zeros([R + M, ha.shape[1]], **f32)
         gn_total = torch.empty([St, 3], **f32)
         call("nsim_field_bwd_rad", fm, ptr(wpack), ptr(nab), ptr(rgb), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), ptr(ha),
              St, ptr(dnab), ptr(drgb), ptr(gn_total), ptr(drad_w), ptr(drad_b), ptr(dha), None, None)
@@ -261,8 +267,7 @@ class RenderTrainer:
         if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
             dsdf_w[-64:] /= model.sdf_scale
             dsdf_b[-1:] /= model.sdf_scale
-        d_app = torch.zeros_like(self.appear)
-        call("nsim_rows_scatter_add", ptr(dha), ptr(batch["fidx_hit"]), R, int(ha.shape[1]), self.V, ptr(d_app))
+        call("nsim_rows_scatter_add", ptr(dha), ptr(batch["fidx_hit"]), R, A, self.V, ptr(d_app))
         if _lib.TIMER is not None:
             for k in ("nsim_field_fwd", "nsim_field_bwd_sdf", "nsim_lotd_scatter", "nsim_field_bwd_rad"):
                 _lib.TIMER.note_units(k, St)
