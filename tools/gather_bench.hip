@@ -39,6 +39,28 @@ __global__ void __launch_bounds__(256) k_gather(const unsigned* __restrict__ tab
   if (acc == 0x12345678u) out[tid] = acc;
 }
 
+// random dword gather through a buffer resource with cache-policy bits AUX (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX, int ILP>
+__global__ void __launch_bounds__(256) k_gather_buf(const unsigned* __restrict__ tab, unsigned n_entries, int iters,
+                                                     unsigned seed, unsigned* out) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(tab), 0, 0xffffffff, 0x00020000);
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned x = tid * 2654435761u + seed;
+  unsigned acc = 0;
+  for (int i = 0; i < iters; ++i) {
+    unsigned v[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+      x = x * 1664525u + 1013904223u;
+      const unsigned idx = (x >> 8) & (n_entries - 1);
+      v[k] = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4u), 0, AUX);
+    }
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) acc += v[k];
+  }
+  if (acc == 0x12345678u) out[tid] = acc;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_cell(const unsigned* __restrict__ tab, int R, int iters, unsigned seed, unsigned* out) {
   unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +102,9 @@ static unsigned* g_tab; static unsigned* g_out; static unsigned g_n; static int 
 template <int MODE, int ILP> void launch_g(int r) {
   hipLaunchKernelGGL((k_gather<MODE, ILP>), dim3(g_blocks), dim3(256), 0, 0, g_tab, g_n, 64, 7u + r, g_out, g_R);
 }
+template <int AUX> void launch_b(int r) {
+  hipLaunchKernelGGL((k_gather_buf<AUX, 8>), dim3(g_blocks), dim3(256), 0, 0, g_tab, g_n, 64, 7u + r, g_out);
+}
 template <int MODE> void launch_c(int r) {
   hipLaunchKernelGGL((k_cell<MODE>), dim3(g_blocks), dim3(256), 0, 0, g_tab, g_R, 64, 7u + r, g_out);
 }
@@ -97,6 +122,12 @@ int main() {
       t = timeit(launch_g<0, 8>, 3);  printf("blocks %d table %6.1f MB  random dword        ILP8 : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
       t = timeit(launch_g<1, 4>, 3);  printf("blocks %d table %6.1f MB  pair 2x dword       ILP4 : %7.1f G dwords/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
       t = timeit(launch_g<2, 4>, 3);  printf("blocks %d table %6.1f MB  pair dwordx2        ILP4 : %7.1f G dwords/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<0>, 3);   printf("blocks %d table %6.1f MB  buffer dword aux 0 (default)  : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<1>, 3);   printf("blocks %d table %6.1f MB  buffer dword aux 1 (sc0)      : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<2>, 3);   printf("blocks %d table %6.1f MB  buffer dword aux 2 (nt)       : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<3>, 3);   printf("blocks %d table %6.1f MB  buffer dword aux 3 (sc0 nt)   : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<16>, 3);  printf("blocks %d table %6.1f MB  buffer dword aux 16 (sc1)     : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
+      t = timeit(launch_b<17>, 3);  printf("blocks %d table %6.1f MB  buffer dword aux 17 (sc0 sc1) : %7.1f G loads/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
       g_R = (int)floor(cbrt((double)g_n));
       t = timeit(launch_c<3>, 3);     printf("blocks %d table %6.1f MB  dense cell 8x dword (R=%d): %7.1f G dwords/s\n", blocks, g_n * 4 / 1048576.0, g_R, threads * it * 8 / t / 1e6);
       t = timeit(launch_c<4>, 3);     printf("blocks %d table %6.1f MB  dense cell 4x dwordx2     : %7.1f G dwords/s\n", blocks, g_n * 4 / 1048576.0, threads * it * 8 / t / 1e6);
