@@ -260,10 +260,13 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
                        float* dsdf_w, float* dsdf_b, float* dx, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
- *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term). */
+ *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term).
+ *     Levels [level_begin, level_begin + level_count) only (level_count <= 0: all) -- a data-parallel caller scatters
+ *     the pyramid in two halves and starts the all-reduce of the first half's gradient while the second is computed. */
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d,
                       const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,
-                      const float* dh_planes, const float* g_planes, const float* gn, float* dgrid, void* stream);
+                      const float* dh_planes, const float* g_planes, const float* gn, float* dgrid, int level_begin,
+                      int level_count, void* stream);
 /* (4, pose refinement only) position gradient of the normals' own dependence on x: nablas = (d sdf/d h) . dh/dx(x), and
  *     inside a cell the trilinear interpolant has mixed second derivatives:
  *     dx[s][c] += sum_{l,f} g[l][s][f] sum_{c' != c} gn[s][c'] d2 h_{l,f} / dx_c' dx_c.   g_planes from (2), gn from (1). */

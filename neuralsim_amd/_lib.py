@@ -87,7 +87,7 @@ SIGNATURES = {
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P],
     "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
     "nsim_ray_grad_reduce": [_P, _P, _P, _P, _I64, _P, _P],
-    "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _I, _I],
     "nsim_distant_pack_weights": [C.POINTER(DistantMeta), _P, _P, _P, _P, _P],
     "nsim_distant_shells": [_P, _P, _P, _P, _I64, _I, C.POINTER(C.c_float * 6), _F, _F, _P, _P, _P],
     "nsim_density_alpha_fwd": [_P, _P, _P, _I64, _I, _I, _P],

@@ -1215,11 +1215,12 @@ struct ScatterArgs {
   const int64_t* ray_goff;
   float* dgrid;
   int dedup_max_res;
+  int level_begin;      // this launch covers levels [level_begin, level_begin + gridDim.y)
 };
 
 __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
-  const int l = blockIdx.y;
+  const int l = a.level_begin + (int)blockIdx.y;
   const LotdRes R = a.lotd.res[l];
   if (l >= a.lotd.n_active) return;     // masked level: no gradient
   const bool dedup = R.max() <= a.dedup_max_res;
@@ -1736,10 +1737,16 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
 
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d, const float* t,
                       const int64_t* ridx, const int64_t* ray_goff, int64_t S, const float* dh_planes,
-                      const float* g_planes, const float* gn, float* dgrid, void* stream) {
+                      const float* g_planes, const float* gn, float* dgrid, int level_begin, int level_count,
+                      void* stream) {
   const int rc = lotd_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
+  if (level_count <= 0) {       // all levels
+    level_begin = 0;
+    level_count = meta->num_levels;
+  }
+  if (level_begin < 0 || level_begin + level_count > meta->num_levels) return 12;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (!dh_planes || !g_planes || !dgrid) return 28;
   if (ray_goff && !ridx) return 29;
@@ -1755,7 +1762,8 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   const char* e = getenv("NSIM_DEDUP_MAX_RES");
   if (e) sa.dedup_max_res = atoi(e);
   const int64_t chunks = (S + 63) / 64;
-  const dim3 grid(nsim_blocks(chunks, 4, 4096), meta->num_levels);
+  sa.level_begin = level_begin;
+  const dim3 grid(nsim_blocks(chunks, 4, 4096), level_count);
   hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
   NSIM_CHECK_LAUNCH();
   return 0;

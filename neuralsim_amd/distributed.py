@@ -92,6 +92,29 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
             p.grad.div_(world)
 
 
+def wire_dtype_default() -> torch.dtype:
+    return {"bf16": torch.bfloat16, "f32": torch.float32, "fp16": torch.float16}[
+        os.environ.get("NSIM_ALLREDUCE_DTYPE", "bf16")]
+
+
+def allreduce_start(t: torch.Tensor, wire_dtype: Optional[torch.dtype] = None):
+    """Begin an asynchronous sum-all-reduce of ``t`` (travelling as ``wire_dtype``); collectives complete in issue
+    order, so a caller interleaves them with the kernels that produce the next tensor.  -> token for
+    ``allreduce_finish``."""
+    wire_dtype = torch.float32 if wire_dtype is None else wire_dtype
+    buf = t if (wire_dtype == t.dtype and t.is_contiguous()) else t.to(wire_dtype).contiguous()
+    return t, buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_finish(token):
+    """Wait for ``allreduce_start`` and write the sum back into the original tensor."""
+    t, buf, h = token
+    h.wait()
+    if buf is not t:
+        t.copy_(buf)
+    return t
+
+
 def broadcast_module(module: torch.nn.Module, src: int = 0):
     """Make replicas bit-identical (parameters AND buffers such as the occupancy grid) -- what DDP does at
     construction / every forward for buffers (code_single/tools/train.py:1401-1406)."""

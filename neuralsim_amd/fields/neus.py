@@ -185,7 +185,7 @@ class _FieldFn(torch.autograd.Function):
         if dgrid is not None:   # (3) scatter to the hash grid
             _lib.call("nsim_lotd_scatter", model.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
-                      _lib.ptr(gn_total), _lib.ptr(dgrid))
+                      _lib.ptr(gn_total), _lib.ptr(dgrid), 0, 0)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd_sdf", S)
             if dgrid is not None:

@@ -49,12 +49,14 @@ class FusedAdam:
         return [g["p"] for g in self.groups]
 
     @torch.no_grad()
-    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0, skip=()):
+        """``skip``: parameters the caller updates itself in this iteration through ``step_range`` (AFTER this call:
+        the step counter of the bias corrections advances here)."""
         self.t += 1
         lr = self.lr if lr is None else lr
         for g in self.groups:
             p = g["p"]
-            if p.grad is None:
+            if p.grad is None or any(p is q for q in skip):
                 continue
             b1, b2 = g["betas"]
             p16 = g["p16"]() if g["p16"] is not None else None
@@ -63,6 +65,21 @@ class FusedAdam:
                       1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(grad_scale), 0)
         for m in self._dirty:
             m._wpack_versions = None           # MLP weights changed in place: re-pack the MFMA fragments lazily
+
+    @torch.no_grad()
+    def step_range(self, p: torch.Tensor, lo: int, hi: int, grad: torch.Tensor, lr: Optional[float] = None,
+                   grad_scale: float = 1.0):
+        """Adam on the flat slice p[lo:hi] with gradient ``grad`` [hi-lo] (f32), using the bias corrections of the
+        iteration ``step`` has just opened -- lets a data-parallel caller update one half of the hash table while the
+        all-reduce of the other half is still in flight."""
+        lr = self.lr if lr is None else lr
+        g = next(g for g in self.groups if g["p"] is p)
+        b1, b2 = g["betas"]
+        p16 = g["p16"]() if g["p16"] is not None else None
+        _lib.call("nsim_adam_step", _lib.ptr(p.data.view(-1)[lo:hi]), _lib.ptr(p16.view(-1)[lo:hi] if p16 is not None else None),
+                  _lib.ptr(grad.contiguous()), _lib.ptr(g["m"].view(-1)[lo:hi]), _lib.ptr(g["v"].view(-1)[lo:hi]), hi - lo,
+                  float(lr), float(b1), float(b2), float(self.eps), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                  float(grad_scale), 0)
 
     def zero_grad(self):
         for g in self.groups:

@@ -39,6 +39,9 @@ class RenderTrainer:
         # forward, sdf->alpha, compositing, losses and their whole backward -- is issued as one straight chain of
         # launches without the autograd engine in between (``_train_render_fused``); same kernels, same numbers
         self.fused_step = (os.environ.get("NSIM_FUSED_STEP", "1") == "1") if fused_step is None else bool(fused_step)
+        # N > 1: overlap the table-gradient all-reduce with the second half of the scatter (NSIM_OVERLAP_ALLREDUCE=0: off)
+        self.overlap_allreduce = os.environ.get("NSIM_OVERLAP_ALLREDUCE", "1") == "1"
+        self._step_done = False
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
         # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
         self.target_sphere_radius = target_sphere_radius
@@ -262,22 +265,71 @@ class RenderTrainer:
         dh_pl, g_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2], **f32)
         call("nsim_field_bwd_sdf", fm, ptr(wpack), ptr(h_pl), ptr(J_pl), St, ptr(dsdf), ptr(gn_total), ptr(dh_pl),
              ptr(g_pl), ptr(dsdf_w), ptr(dsdf_b), None)
-        call("nsim_lotd_scatter", model.encoding.cfg.meta, None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, St,
-             ptr(dh_pl), ptr(g_pl), ptr(gn_total), ptr(dgrid))
         if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
             dsdf_w[-64:] /= model.sdf_scale
             dsdf_b[-1:] /= model.sdf_scale
         call("nsim_rows_scatter_add", ptr(dha), ptr(batch["fidx_hit"]), R, A, self.V, ptr(d_app))
-        if _lib.TIMER is not None:
-            for k in ("nsim_field_fwd", "nsim_field_bwd_sdf", "nsim_lotd_scatter", "nsim_field_bwd_rad"):
-                _lib.TIMER.note_units(k, St)
-        model.encoding.flattened_params.grad = dgrid
+        grid_p = model.encoding.flattened_params
         model.sdf_w.grad, model.sdf_b.grad, model.rad_w.grad, model.rad_b.grad = dsdf_w, dsdf_b, drad_w, drad_b
         if model.ln_inv_s.requires_grad:
             model.ln_inv_s.grad = dln
         self.appear.grad = d_app
+        scatter_args = (model.encoding.cfg.meta, None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, St, ptr(dh_pl),
+                        ptr(g_pl), ptr(gn_total), ptr(dgrid))
+        if self.world_size > 1 and self.overlap_allreduce:
+            self._dp_reduce_step(dgrid, lambda l0, n: call("nsim_lotd_scatter", *scatter_args, l0, n))
+        else:
+            call("nsim_lotd_scatter", *scatter_args, 0, 0)
+        grid_p.grad = dgrid
+        if _lib.TIMER is not None:
+            for k in ("nsim_field_fwd", "nsim_field_bwd_sdf", "nsim_lotd_scatter", "nsim_field_bwd_rad"):
+                _lib.TIMER.note_units(k, St)
         self.stats = dict(R_hit=R, S_f=S)
         return torch.dot(acc, w_vec)
+
+    def _dp_reduce_step(self, dgrid: torch.Tensor, scatter=None):
+        """Data-parallel reduction + optimizer step with the hash-table gradient leaving in two halves: the all-reduce of
+        the coarse half runs while the fine half is still being scattered (``scatter(level_begin, level_count)``), and
+        Adam on the first half runs under the second all-reduce.  Collectives complete in issue order, so the small
+        bucket (MLP weights, inv_s, appearance codes: ready before the scatter) goes first.  Every rank issues exactly
+        this sequence whichever path produced its gradients (``scatter`` None: ``dgrid`` is complete already)."""
+        grid_p = self.model.encoding.flattened_params
+        small = [q for q in self.optim.params() if q is not grid_p]
+        flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1).float() for q in small])
+        tok_small = ndist.allreduce_start(flat)
+        wire, toks = ndist.wire_dtype_default(), []
+        for l0, l1, o0, o1 in self._grid_halves():
+            if scatter is not None:
+                scatter(l0, l1 - l0)
+            toks.append((ndist.allreduce_start(dgrid[o0:o1], wire), o0, o1))
+        ndist.allreduce_finish(tok_small)
+        off = 0
+        for q in small:
+            n = q.numel()
+            q.grad = flat[off:off + n].view_as(q)
+            off += n
+        gs = 1.0 / self.world_size
+        self.optim.step(grad_scale=gs, skip=(grid_p,))
+        for tok, o0, o1 in toks:
+            self.optim.step_range(grid_p, o0, o1, ndist.allreduce_finish(tok), grad_scale=gs)
+        self._step_done = True
+
+    def _grid_halves(self):
+        """Two contiguous level ranges of about equal scatter cost (a hashed level ~1, a dense one ~0.35 -- the
+        weights of the gather's level dealing): [(level_begin, level_end, param_begin, param_end)] * 2."""
+        cfg = self.model.encoding.cfg
+        cost = [1.0 if t == "Hash" else 0.35 for t in cfg.lod_types]
+        L, tot = cfg.num_levels, sum(cost)
+        if L < 2:
+            return [(0, L, 0, cfg.n_params)]
+        run, k = 0.0, 1
+        for i in range(L - 1):
+            run += cost[i]
+            k = i + 1
+            if run >= 0.5 * tot:
+                break
+        offs = list(cfg.lod_offsets) + [cfg.n_params]
+        return [(0, k, 0, offs[k]), (k, L, offs[k], cfg.n_params)]
 
     def _make_batch(self) -> dict:
         """sample_batch + ray generation + the AABB test (with its hit-ray compaction sync) of one batch, plus -- in
@@ -370,9 +422,16 @@ class RenderTrainer:
             vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
             self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
                               S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
-        # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
-        ndist.allreduce_grads(self.optim.params(), average=False)
-        self.optim.step(grad_scale=1.0 / self.world_size)
+        if not self._step_done and self.world_size > 1 and self.overlap_allreduce and self._fused_ok():
+            # this rank fell back to the autograd path (nothing hit): same collective sequence as its peers
+            gp = model.encoding.flattened_params
+            self._dp_reduce_step(gp.grad if gp.grad is not None else torch.zeros_like(gp))
+        if self._step_done:         # the overlapped data-parallel path reduced and stepped already
+            self._step_done = False
+        else:
+            # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
+            ndist.allreduce_grads(self.optim.params(), average=False)
+            self.optim.step(grad_scale=1.0 / self.world_size)
         if refine and self.pose_delta.grad is not None:
             if self.world_size > 1:
                 ndist.allreduce_grads([self.pose_delta], average=True, wire_dtype=torch.float32)

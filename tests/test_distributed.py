@@ -96,7 +96,7 @@ def test_shard_range_covers_batch():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
-def _bench_worker(rank, world, port, out_dir):
+def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32"):
     """bench.timed_run under two gloo ranks, with the kernel emulator standing in for the GPU (control flow of the
     N>1 path: sharded rays, gradient all-reduce inside train_step, barrier + max-over-ranks timing, rank-0 JSON)."""
     import ctypes
@@ -104,8 +104,11 @@ def _bench_worker(rank, world, port, out_dir):
     sys.path.insert(0, str(ROOT / "tests"))
     sys.path.insert(0, str(ROOT / "tests" / "emu"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), NSIM_OVERLAP_ALLREDUCE=overlap, NSIM_ALLREDUCE_DTYPE=wire)   # f32 = exact wire:
+    # the two schedules must then agree to rounding (with the 2-byte wire, a + b of nearly cancelling rank gradients
+    # may change sign, which Adam turns into a full step)
     torch.set_num_threads(2)
+    torch.manual_seed(0)
     import build_emu
     from neuralsim_amd import _lib, distributed as nd
     lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
@@ -122,6 +125,12 @@ def _bench_worker(rank, world, port, out_dir):
     nd.broadcast_module(m)
     intr, c2w, WH = look_at_cameras(V=4, seed=1, device=dev)
     tr = RenderTrainer(m, intr, c2w, WH, num_rays=16, lr=1e-3, num_uniform=16, rank=rank, world_size=world)
+    assert tr._fused_ok() and tr.overlap_allreduce == (overlap == "1")
+    if overlap == "1":      # two contiguous level ranges covering the pyramid and its parameters
+        h = tr._grid_halves()
+        cfg = m.encoding.cfg
+        assert h[0][0] == 0 and h[0][1] == h[1][0] and h[1][1] == cfg.num_levels
+        assert h[0][2] == 0 and h[0][3] == h[1][2] == cfg.lod_offsets[h[0][1]] and h[1][3] == cfg.n_params
     out = bench.timed_run(tr, steps=2, warmup=1, rank=rank, world=world, dev=dev, rays_per_gpu=16)
     # replicas must still agree after the all-reduced updates
     w = m.sdf_w.detach().clone()
@@ -129,6 +138,8 @@ def _bench_worker(rank, world, port, out_dir):
     dist.all_gather(ws, w)
     assert torch.equal(ws[0], ws[1])
     if rank == 0:
+        torch.save(dict(grid=m.encoding.flattened_params.detach().clone(), sdf_w=w, rad_w=m.rad_w.detach().clone(),
+                        appear=tr.appear.detach().clone()), str(Path(out_dir) / f"params_overlap{overlap}{wire}.pt"))
         assert out["n_gpus"] == world and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
         assert abs(out["value"] - 16 * world * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2
     else:
@@ -139,6 +150,59 @@ def _bench_worker(rank, world, port, out_dir):
 
 
 def test_bench_control_flow_two_ranks(tmp_path):
+    """... with the table-gradient all-reduce overlapped in two halves (default) and as one collective after the
+    backward: both leave the replicas in sync, and both arrive at the same parameters."""
     world = 2
-    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    assert all((tmp_path / f"bench_ok{r}").exists() for r in range(world))
+    for overlap, wire in (("1", "f32"), ("0", "f32"), ("1", "bf16")):        # bf16 = the production wire format
+        mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), overlap, wire), nprocs=world, join=True)
+        assert all((tmp_path / f"bench_ok{r}").exists() for r in range(world))
+        for r in range(world):
+            (tmp_path / f"bench_ok{r}").unlink()
+    a, b = (torch.load(str(tmp_path / f"params_overlap{o}f32.pt")) for o in ("1", "0"))
+    for k in a:
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, float((a[k] - b[k]).abs().max()))
+
+
+def _gpu_dp_worker(rank, world, port, out_dir, overlap):
+    """Two data-parallel ranks sharing ONE GPU (gloo moves the CUDA tensors; RCCL refuses two ranks per device): the real
+    HIP kernels, real streams and the asynchronous collectives of the overlapped schedule."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), NSIM_OVERLAP_ALLREDUCE=overlap, NSIM_ALLREDUCE_DTYPE="f32")
+    torch.manual_seed(0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from neuralsim_amd import distributed as nd
+    from test_trainer import _tiny
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    dev = torch.device("cuda", 0)
+    m = _tiny(dev, seed=42)
+    nd.broadcast_module(m)
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=dev)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=256, lr=1e-3, num_uniform=64, rank=rank, world_size=world,
+                       target_sphere_radius=0.5)
+    assert tr._fused_ok() and tr.overlap_allreduce == (overlap == "1")
+    losses = [float(tr.train_step(it)) for it in range(4)]
+    assert all(l == l for l in losses)
+    g = m.encoding.flattened_params.detach().clone()
+    gs = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(gs, g)
+    assert torch.equal(gs[0], gs[1])                  # replicas in sync
+    if rank == 0:
+        torch.save(dict(grid=g.cpu(), sdf_w=m.sdf_w.detach().cpu(), losses=torch.tensor(losses)),
+                   str(Path(out_dir) / f"gpu_overlap{overlap}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_overlapped_schedule_on_gpu(tmp_path):
+    world = 2
+    for overlap in ("1", "0"):
+        mp.spawn(_gpu_dp_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+    a, b = (torch.load(str(tmp_path / f"gpu_overlap{o}.pt")) for o in ("1", "0"))
+    assert torch.allclose(a["losses"], b["losses"], rtol=1e-4, atol=1e-6)
+    for k in ("grid", "sdf_w"):     # float atomics commute only approximately (+ Adam on tiny gradients)
+        assert torch.allclose(a[k], b[k], rtol=1e-3, atol=2e-4), (k, float((a[k] - b[k]).abs().max()))
