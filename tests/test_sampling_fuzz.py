@@ -1,0 +1,113 @@
+"""Property-based fuzzing of the per-ray sampling kernels: sorted merge, NeuS up-sampling and the
+keep-set of the compressed query mode on random ragged packs -- single-sample rays, packs shorter / longer than a wave
+(64), exact depth ties -- against the oracle.  Index / membership results must be bit-exact."""
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import pack_ops as opo, render as orr
+from neuralsim_amd import _lib
+from neuralsim_amd.graphics import pack_ops as po
+
+SET = dict(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+counts = st.lists(st.sampled_from([1, 2, 3, 5, 17, 63, 64, 65, 129, 200]), min_size=1, max_size=14)
+
+
+def _packs(n, g):
+    n = torch.tensor(n)
+    pi = opo.get_pack_infos_from_n(n)
+    S = int(n.sum())
+    ridx = opo.pack_ridx(pi, S)
+    near = torch.rand(n.shape[0], generator=g) + 0.5
+    t = near[ridx] + torch.randint(0, 400, (S,), generator=g).float() * (1.0 / 256)      # exact ties are common
+    t, _ = opo.packed_sort(t, pi)
+    return n, pi, S, ridx, t, near
+
+
+@settings(**SET)
+@given(n=counts, nf=st.sampled_from([1, 4, 8, 32, 70]), seed=st.integers(0, 10 ** 6))
+def test_fuzz_merge_sorted(backend, n, nf, seed):
+    g = torch.Generator().manual_seed(seed)
+    n, pi, S, ridx, t, near = _packs(n, g)
+    R = n.shape[0]
+    sdf = torch.randn(S, generator=g)
+    t_b = (near[:, None] + torch.randint(0, 400, (R, nf), generator=g).float() * (1.0 / 256)).sort(dim=1).values
+    v_b = torch.randn(R, nf, generator=g)
+    t_ref, pi_ref, pa, pb = orr.merge_sorted(t, pi, t_b)
+    v_ref = torch.empty_like(t_ref)
+    v_ref[pa] = sdf
+    v_ref[pb.reshape(-1)] = v_b.reshape(-1)
+    dv = lambda a: a.to(backend).contiguous()
+    ro, rd = torch.randn(R, 3, generator=g), torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    T = S + R * nf
+    t_out, v_out = torch.zeros(T, device=backend), torch.zeros(T, device=backend)
+    pi_out = torch.zeros(R, 2, dtype=torch.long, device=backend)
+    ridx_out = torch.zeros(T, dtype=torch.long, device=backend)
+    x_out = torch.zeros(T, 3, device=backend)
+    _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
+              R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), _lib.ptr(dv(ro)),
+              _lib.ptr(dv(rd)), _lib.ptr(x_out))
+    assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
+    assert torch.equal(ridx_out.cpu(), opo.pack_ridx(pi_ref, T))
+    assert torch.equal(x_out.cpu(), ro[ridx_out.cpu()] + t_out.cpu()[:, None] * rd[ridx_out.cpu()])
+
+
+@settings(**SET)
+@given(n=st.lists(st.sampled_from([2, 3, 5, 17, 63, 64, 65, 129, 200]), min_size=1, max_size=14),
+       nf=st.sampled_from([1, 8, 32, 70]), inv_s=st.sampled_from([16.0, 64.0, 1024.0]), use_est=st.booleans(),
+       seed=st.integers(0, 10 ** 6))
+def test_fuzz_upsample_stage(backend, n, nf, inv_s, use_est, seed):
+    g = torch.Generator().manual_seed(seed)
+    n, pi, S, ridx, t, near = _packs(n, g)
+    # strictly increasing depths (the up-sampler divides by interval lengths), an SDF crossing zero somewhere
+    t = t + torch.arange(S).float() * 1e-4
+    R = n.shape[0]
+    sdf = (near[ridx] + 0.3 + 0.5 * torch.rand(R, generator=g)[ridx] - t) * 0.6 + 0.01 * torch.randn(S, generator=g)
+    ref = orr.upsample_stage(t, sdf, pi, inv_s, nf, use_est)
+    dv = lambda a: a.to(backend).contiguous()
+    ro, rd = torch.randn(R, 3, generator=g), torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    t_new, scratch = torch.zeros(R, nf, device=backend), torch.zeros(S, device=backend)
+    x_new = torch.zeros(R, nf, 3, device=backend)
+    _lib.call("nsim_upsample_stage", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, inv_s, nf, int(use_est),
+              _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)), _lib.ptr(x_new))
+    tn = t_new.cpu()
+    assert torch.isfinite(tn).all() and (tn[:, 1:] >= tn[:, :-1]).all()
+    lo = t[pi[:, 0]][:, None]
+    hi = t[pi[:, 0] + pi[:, 1] - 1][:, None]
+    assert ((tn >= lo - 1e-5) & (tn <= hi + 1e-5)).all()                        # new depths stay inside the ray's span
+    assert torch.allclose(tn, ref, atol=5e-5), float((tn - ref).abs().max())
+    assert torch.equal(x_new.cpu(), ro[:, None, :] + tn[..., None] * rd[:, None, :])
+
+
+@settings(**SET)
+@given(n=counts, inv_s=st.sampled_from([8.0, 64.0, 400.0]), thre=st.sampled_from([1e-4, 1e-2, 0.2]),
+       seed=st.integers(0, 10 ** 6))
+def test_fuzz_compress(backend, n, inv_s, thre, seed):
+    """Keep-set of ``march_occ_multi_upsample_compressed``: samples bounding an interval whose visibility weight exceeds
+    ``thre`` (oracle/render.py ray_query, compress branch)."""
+    g = torch.Generator().manual_seed(seed)
+    n, pi, S, ridx, t, near = _packs(n, g)
+    R = n.shape[0]
+    sdf = (near[ridx] + 0.2 + torch.rand(R, generator=g)[ridx] - t) * 0.5 + 0.02 * torch.randn(S, generator=g)
+    vw = opo.packed_alpha_to_vw(orr.neus_alpha_packed(sdf, pi, torch.tensor(inv_s)), pi)
+    margin = (vw - thre).abs().min() if S else torch.tensor(1.0)
+    if float(margin) < 1e-6:        # a weight within float noise of the threshold: the keep decision is not defined
+        return
+    sig = vw > thre
+    first = torch.zeros_like(sig)
+    first[pi[:, 0][pi[:, 1] > 0]] = True
+    prev_sig = torch.cat([sig[:1] & False, sig[:-1]]) & ~first
+    keep = sig | prev_sig
+    cnt_ref = torch.zeros(R, dtype=torch.long).index_add_(0, ridx[keep], torch.ones(int(keep.sum()), dtype=torch.long))
+    dv = lambda a: a.to(backend).contiguous()
+    ln = torch.zeros(1, device=backend)
+    counts_d = torch.zeros(R, dtype=torch.long, device=backend)
+    _lib.call("nsim_compress_count", _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, _lib.ptr(ln), 1.0, float(inv_s), float(thre),
+              _lib.ptr(counts_d))
+    assert torch.equal(counts_d.cpu(), cnt_ref)
+    pi_k = po.get_pack_infos_from_n(counts_d)
+    K = int(cnt_ref.sum())
+    t_k = torch.zeros(K, device=backend)
+    ridx_k = torch.zeros(K, dtype=torch.long, device=backend)
+    _lib.call("nsim_compress_emit", _lib.ptr(dv(sdf)), _lib.ptr(dv(t)), _lib.ptr(dv(pi)), R, _lib.ptr(ln), 1.0, float(inv_s),
+              float(thre), _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
+    assert torch.equal(t_k.cpu(), t[keep]) and torch.equal(ridx_k.cpu(), ridx[keep])
