@@ -1,4 +1,5 @@
 """The whole training step (ray gen .. Adam) on a tiny configuration: loss goes down, replicas stay in sync."""
+import pytest
 import torch
 
 from neuralsim_amd.fields.neus import LoTDNeuSModel
@@ -58,22 +59,29 @@ def test_pose_refinement_steps(backend):
     assert torch.equal(cur[:, 3], c2w[:, 3])
 
 
-def test_fused_step_equals_autograd_step(backend):
+@pytest.mark.parametrize("variant", ["default", "all_rays_hit_no_uniform_no_perturb"])
+def test_fused_step_equals_autograd_step(backend, variant):
     """The straight launch chain of ``_train_render_fused`` is the autograd step with the engine removed: same loss,
-    same parameters after a few iterations (identical kernels; only the order of float atomics may differ)."""
+    same parameters after a few iterations (identical kernels; only the order of float atomics may differ).
+    Second variant: a long lens (every ray hits the box -> images written without the scatter index), no uniform
+    eikonal points, no perturbation."""
     outs = []
     for fused in (False, True):
         torch.manual_seed(0)                    # the occupancy initialisation draws from the global generator
         m = _tiny(backend)
-        intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
-        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, num_uniform=24, perturb=True,
-                           target_sphere_radius=0.5, fused_step=fused)
+        if variant == "default":
+            intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+            kw = dict(num_uniform=24, perturb=True)
+        else:
+            intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend, f=4000.0)
+            kw = dict(num_uniform=0, perturb=False)
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=fused, **kw)
         assert tr._fused_ok() == fused
         losses = [float(tr.train_step(it)) for it in range(5)]
         outs.append((losses, m.encoding.flattened_params.detach().clone(), m.sdf_w.detach().clone(),
                      m.rad_w.detach().clone(), m.ln_inv_s.detach().clone(), tr.appear.detach().clone(), dict(tr.stats)))
     (la, *pa, sa), (lb, *pb, sb) = outs
-    assert sa == sb and sa["S_f"] > 0
+    assert sa == sb and sa["S_f"] > 0 and (variant == "default" or sa["R_hit"] == 40)
     assert all(abs(x - y) < 1e-5 * (1 + abs(x)) for x, y in zip(la, lb)), (la, lb)
     for a, b in zip(pa, pb):
         # float atomics commute only approximately and Adam normalises tiny gradients: a few 1e-6 after five steps
