@@ -188,17 +188,25 @@ class RenderTrainer:
         if self.perturb:
             cfg["_jitter"], cfg["_jitter_c"] = batch["jitter"][:R], batch["jitter_c"][:R]
         qp = dict(cfg.get("query_param", model.ray_query_cfg.get("query_param", {})))
-        o, d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
+        # the per-RAY arrays of the with-grad query (hit rays + the uniform eikonal points as zero-length rays) do not
+        # depend on the sample count: they are queued BEFORE the sampling pass and its blocking size read
+        ha = self.appear.detach()[batch["fidx_hit"]]
+        x_uni = batch["x_uni"] if self.num_uniform > 0 else None
+        M = int(x_uni.shape[0]) if x_uni is not None else 0
+        o_r, d_r = tested["rays_o"].detach().float().contiguous(), tested["rays_d"].detach().float().contiguous()
+        if M:
+            e = torch.empty([0], dtype=torch.float32, device=dev)
+            o, d, tz, rz, ha = append_extra_points(model, o_r, d_r, e, e.long(), ha, x_uni)
+        else:
+            o, d = o_r, d_r
+        _o, _d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
         S = int(t.shape[0])
         if S == 0:
             return None
         call, ptr = _lib.call, _lib.ptr
         f32 = dict(dtype=torch.float32, device=dev)
-        ha = self.appear.detach()[batch["fidx_hit"]]
-        x_uni = batch["x_uni"] if self.num_uniform > 0 else None
-        M = int(x_uni.shape[0]) if x_uni is not None else 0
-        if M:
-            o, d, t_a, ridx_a, ha = append_extra_points(model, o, d, t, ridx, ha, x_uni)
+        if M:       # per-SAMPLE arrays: depth 0 on ray R + i for the i-th free point
+            t_a, ridx_a = torch.cat([t, tz]), torch.cat([ridx, rz])
         else:
             t_a, ridx_a = t, ridx
         St = S + M
