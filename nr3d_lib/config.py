@@ -1,0 +1,77 @@
+"""``nr3d_lib.config.ConfigDict`` -- the attribute-access dict the renderers build their per-query configs from
+(``ConfigDict(**model.ray_query_cfg, **config)``, app/renderers/single_volume_renderer.py:241) -- and
+``parse_device_ids``.  The YAML front end of nr3d_lib.config (``${...}`` / ``${eval:...}`` resolution, CLI merging) is
+harness, out of scope."""
+from typing import List, Union
+
+import torch
+
+
+class ConfigDict(dict):
+    """dict with attribute access; nested plain dicts are wrapped on construction / assignment."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    @staticmethod
+    def _wrap(v):
+        if isinstance(v, dict) and not isinstance(v, ConfigDict):
+            return ConfigDict(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(ConfigDict._wrap(x) for x in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, self._wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __delattr__(self, k):
+        try:
+            del self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def update(self, *args, **kwargs):
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    def setdefault(self, k, default=None):
+        if k not in self:
+            self[k] = default
+        return self[k]
+
+    def copy(self):
+        return ConfigDict(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        return ConfigDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+    def to_dict(self):
+        def un(v):
+            if isinstance(v, ConfigDict):
+                return {k: un(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return type(v)(un(x) for x in v)
+            return v
+        return un(self)
+
+
+def parse_device_ids(device_ids: Union[str, int, List[int]] = -1, to_torch: bool = False):
+    """-1 / 'all' -> every visible device; an int, a list or a comma-separated string -> that list."""
+    if isinstance(device_ids, str):
+        device_ids = -1 if device_ids in ("all", "-1") else [int(x) for x in device_ids.split(",") if x != ""]
+    if isinstance(device_ids, int):
+        device_ids = list(range(torch.cuda.device_count())) if device_ids == -1 else [device_ids]
+    device_ids = list(device_ids)
+    return [torch.device("cuda", i) for i in device_ids] if to_torch else device_ids

@@ -1,0 +1,116 @@
+"""The reference's own ``SingleVolumeRenderer`` source (app/renderers/single_volume_renderer.py, loaded unchanged from
+/root/reference by tests/ref_glue.py) driving THIS repository's models through the nr3d_lib shim, compared with the
+renderer mirror (``neuralsim_amd.renderers.SingleVolumeRenderer``) on identical rays and weights.
+
+Two uses:
+  * in the authoring container (reference present) the reference renderer and the mirror run side by side on the
+    emulator backend and must agree -- every output image, the merged volume buffer, ``vw_in_total``, gradients;
+  * the same scenario's reference-side outputs are frozen in ``tests/golden/renderer_fixture.pt``
+    (``tests/golden/make_renderer_fixture.py``); ``test_mirror_matches_reference_fixture`` replays the mirror against
+    them on the GPU box, where /root/reference does not exist.
+"""
+from pathlib import Path
+
+import pytest
+import torch
+
+import ref_glue
+from renderer_scenario import SCENARIOS, build_scenario, run_mirror, run_reference
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "renderer_fixture.pt"
+needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="/root/reference is not present")
+
+
+def _cmp(a, b, tol, what):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype in (torch.long, torch.int32, torch.bool, torch.uint8):
+        assert torch.equal(a, b), what
+    else:
+        e = float((a.float() - b.float()).abs().max()) if a.numel() else 0.0
+        assert e <= tol, (what, e)
+
+
+@needs_reference
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_reference_renderer_runs_on_the_mirror(backend, name):
+    """Same process, same models: reference glue vs mirror.  Both sides call the same kernels, so the agreement is
+    tight (f32 sums in a different order only)."""
+    sc = build_scenario(name, backend)
+    with ref_glue.reference_renderer_modules() as mods:
+        ref = run_reference(mods, sc, backward=True)
+    got = run_mirror(sc, backward=True)
+    for k in ref["rendered"]:
+        _cmp(got["rendered"][k], ref["rendered"][k], 2e-5, f"rendered.{k}")
+    assert set(got["rendered"]) >= set(ref["rendered"])
+    _cmp(got["samples_cnt"], ref["samples_cnt"], 0, "samples_cnt")
+    for k in ("pack_infos_hit", "t", "opacity_alpha", "rgb", "vw"):
+        if k in ref["volume_buffer"]:
+            _cmp(got["volume_buffer"][k], ref["volume_buffer"][k], 2e-5, f"volume_buffer.{k}")
+    for k in ref["vw_in_total"]:
+        _cmp(got["vw_in_total"][k], ref["vw_in_total"][k], 2e-5, f"vw_in_total.{k}")
+    for k, g in ref["grads"].items():
+        denom = float(g.norm()) + 1e-12
+        e = float((got["grads"][k] - g).norm()) / denom
+        assert e < 1e-3, (k, e)
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_mirror_matches_reference_fixture(backend, name):
+    """The mirror against the frozen outputs of the reference's renderer (generated on the emulator backend in f32
+    MFMA mode; the device differs from it by f32 rounding of the field kernels only)."""
+    assert GOLDEN.exists(), "run tests/golden/make_renderer_fixture.py in the authoring container"
+    fx = torch.load(GOLDEN)[name]
+    sc = build_scenario(name, backend)
+    got = run_mirror(sc, backward=True)
+    _cmp(got["samples_cnt"], fx["samples_cnt"], 0, "samples_cnt")
+    assert set(got["volume_buffer"]) == set(fx["volume_buffer"])
+    if "pack_infos_hit" in fx["volume_buffer"]:
+        _cmp(got["volume_buffer"]["pack_infos_hit"], fx["volume_buffer"]["pack_infos_hit"], 0, "pack_infos_hit")
+    for k in fx["rendered"]:
+        _cmp(got["rendered"][k], fx["rendered"][k], 2e-2 if k == "depth_volume" else 5e-4, f"rendered.{k}")
+    for k in ("t", "opacity_alpha", "rgb", "vw"):
+        if k in fx["volume_buffer"]:
+            _cmp(got["volume_buffer"][k], fx["volume_buffer"][k], 1e-3, f"volume_buffer.{k}")
+    for k, g in fx["grads"].items():
+        e = float((got["grads"][k] - g).norm()) / (float(g.norm()) + 1e-12)
+        assert e < 5e-3, (k, e)
+
+
+@needs_reference
+def test_reference_volume_integration_pins_the_oracle():
+    """``SingleVolumeRenderer._volume_integration`` of the reference (single_volume_renderer.py:73-102) fed with the
+    ORACLE's pack ops (pure torch, CPU) against ``oracle.render.volume_integration`` -- pins the oracle's restatement
+    of the integration (vw, mask, depth with and without normalisation, rgb, normals in train and eval mode)."""
+    from oracle import pack_ops as opo, render as orr
+    import sys
+    g = torch.Generator().manual_seed(3)
+    n = torch.tensor([5, 1, 0, 9, 3])
+    pi = opo.get_pack_infos_from_n(n)
+    S = int(n.sum())
+    alpha, t = torch.rand(S, generator=g) * 0.7, torch.rand(S, generator=g).cumsum(0)
+    rgb, nab = torch.rand(S, 3, generator=g), torch.randn(S, 3, generator=g) * 1.5
+    keep = n > 0
+    pi_hit, rih = pi[keep], keep.nonzero()[:, 0]
+    with ref_glue.reference_renderer_modules() as mods:
+        m = mods["app.renderers.single_volume_renderer"]
+        saved = (m.packed_alpha_to_vw, m.packed_sum, m.packed_div)
+        m.packed_alpha_to_vw = lambda a, pack_infos: opo.packed_alpha_to_vw(a, pack_infos)
+        m.packed_sum = opo.packed_sum
+        m.packed_div = opo.packed_div
+        try:
+            for training in (True, False):
+                for norm_depth in (True, False):
+                    r = ref_glue.make_reference_renderer(mods, dict(depth_use_normalized_vw=norm_depth), training=training)
+                    rendered = mods["app.renderers.utils"].prepare_empty_rendered([5], with_rgb=True, with_normal=True)
+                    vb = dict(type="packed", rays_inds_hit=rih, pack_infos_hit=pi_hit, opacity_alpha=alpha.clone(),
+                              t=t, rgb=rgb, nablas_in_world=nab.clone())
+                    r._volume_integration(vb, rendered)
+                    nn_ = nab if training else torch.nn.functional.normalize(nab.clamp(-1, 1), dim=-1)
+                    o = orr.volume_integration(alpha, t, rgb, nn_, pi_hit, norm_depth)
+                    assert torch.allclose(vb["vw"], o["vw"], atol=1e-6)
+                    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+                        assert torch.allclose(rendered[k][rih], o[k], atol=1e-5), (k, training, norm_depth)
+                        assert float(rendered[k][~keep].abs().sum()) == 0.0
+        finally:
+            m.packed_alpha_to_vw, m.packed_sum, m.packed_div = saved
+    assert "app" not in sys.modules

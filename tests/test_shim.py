@@ -9,6 +9,15 @@ def test_reference_import_lines_resolve():
     # app/renderers/buffer_compose_renderer.py:33 ; app/renderers/utils.py:15 ; app/loss/lidar.py:17
     from nr3d_lib.graphics.pack_ops import interleave_linstep, packed_geq, packed_leq, packed_lt, packed_matmul, packed_sort  # noqa: F401
     from nr3d_lib.models.utils import batchify_query  # noqa: F401
+    from nr3d_lib.graphics.pack_ops.pack_ops import packed_sum as ps2          # app/loss/eikonal.py:22
+    from nr3d_lib.profile import profile                                       # single_volume_renderer.py:15
+    from nr3d_lib.config import ConfigDict, parse_device_ids                   # single_volume_renderer.py:17
+    assert ps2 is packed_sum and parse_device_ids("0,1") == [0, 1]
+    c = ConfigDict(a=dict(b=1), **dict(with_rgb=True))
+    assert c.a.b == 1 and c.get("missing", 5) == 5 and c.copy().a.b == 1
+    with profile("phase"):
+        pass
+    assert profile(lambda x: x + 1)(1) == 2
     from nr3d_lib.models.fields.neus import LoTDNeuSModel
     from nr3d_lib.models.accelerations import OccGridAccel, OccGridEma  # noqa: F401
     from nr3d_lib.models.grid_encodings.lotd import LoTDEncoding  # noqa: F401
