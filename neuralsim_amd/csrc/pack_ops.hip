@@ -269,12 +269,17 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_alpha_to_vw_bwd(
   float carry = 0.f;  // sum of g over all later chunks
   const int64_t nchunks = (n + 63) / 64;
   for (int64_t c = nchunks - 1; c >= 0; --c) {
-    const int64_t i = c * 64 + lane;
+    // lanes hold the chunk BACK TO FRONT, so the inclusive scan over lanes is a true suffix sum: the sum over the later
+    // samples is accumulated from small terms upwards.  (total - prefix cancels catastrophically behind an opaque
+    // sample, and the result is divided by 1 - alpha + 1e-10.)
+    const int64_t i = c * 64 + (63 - lane);
     const bool valid = i < n;
     const float g = valid ? dvw[st + i] * vw[st + i] : 0.f;
     const float incl = wave_incl_sum(g);
     const float tot = wave_shfl(incl, 63);
-    const float suffix = carry + (tot - incl);
+    float excl = wave_shfl(incl, lane - 1);
+    if (lane == 0) excl = 0.f;
+    const float suffix = carry + excl;
     if (valid) {
       const float a = alpha[st + i];
       dalpha[st + i] = dvw[st + i] * trans[st + i] - suffix / (1.0f - a + 1e-10f);
@@ -359,7 +364,7 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_bwd(
   float carry = 0.f;
   const int64_t nchunks = (n + 63) / 64;
   for (int64_t c = nchunks - 1; c >= 0; --c) {
-    const int64_t i = c * 64 + lane;
+    const int64_t i = c * 64 + (63 - lane);      // back to front: see k_alpha_to_vw_bwd
     const bool valid = i < n;
     float gvw = 0.f, w = 0.f;
     if (valid) {
@@ -388,7 +393,9 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_bwd(
     const float g = gvw * w;
     const float incl = wave_incl_sum(g);
     const float tot = wave_shfl(incl, 63);
-    const float suffix = carry + (tot - incl);
+    float excl = wave_shfl(incl, lane - 1);
+    if (lane == 0) excl = 0.f;
+    const float suffix = carry + excl;
     if (valid) {
       const float a = alpha[st + i];
       dalpha[st + i] = gvw * trans[st + i] - suffix / (1.0f - a + 1e-10f);

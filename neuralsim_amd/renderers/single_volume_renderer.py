@@ -72,9 +72,15 @@ class SingleVolumeRenderer(nn.Module):
                   rays_pix: torch.Tensor = None, *, model: LoTDNeuSModel, rays_h_appear: torch.Tensor = None,
                   near=None, far=None, with_rgb: bool = None, with_normal: bool = None, return_buffer=False,
                   return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-                  distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None) -> Dict:
+                  distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None,
+                  world_transform=None) -> Dict:
         """``cr_ray_tested``: a ``model.ray_test`` result computed ahead of time for exactly these rays (the trainer
-        prefetches the next batch's AABB test while it waits on the current batch's sample count)."""
+        prefetches the next batch's AABB test while it waits on the current batch's sample count).
+        ``world_transform`` = (rotation [3,3] or per-ray [N,3,3], translation [3] / [N,3], scale): the object -> world
+        pose of the main object's scene node; rays are brought into the object frame before the queries
+        (``scene.convert_rays_in_node``, reference :225) -- the distant model sees the same object-frame rays (:284-286),
+        the sky the world directions (:455) -- and the sample normals are rotated back with the DETACHED rotation
+        (:262-265).  None = identity (the single-object configs)."""
         assert rays_o.dim() == rays_d.dim() == 2, "rays_o and rays_d should have size of [N, 3]"
         config = self.config
         if with_rgb is None:
@@ -88,6 +94,11 @@ class SingleVolumeRenderer(nn.Module):
         N, device = rays_o.shape[0], rays_o.device
         total_num_samples_per_ray = torch.zeros(N, dtype=torch.long, device=device)
         total_rendered = None       # all-rays images: written by the fused compositing, zero images only if nothing hit
+        rays_d_world = rays_d
+        if world_transform is not None:
+            assert cr_ray_tested is None, "a precomputed ray test is in the object frame already"
+            rot, trans, scale = world_transform
+            rays_o, rays_d = model.convert_rays_in_node(rays_o, rays_d, rot, trans, scale)
 
         cr_ray_input = dict(rays_o=rays_o, rays_d=rays_d, near=near, far=far, rays_ts=rays_ts, rays_pix=rays_pix,
                             rays_h_appear=rays_h_appear)
@@ -107,7 +118,14 @@ class SingleVolumeRenderer(nn.Module):
             total_num_samples_per_ray[rih] += pih[:, 1]
             vb.update(rays_inds_collect=rih, pack_infos_collect=pih)
             if "nablas" in vb:
-                vb["nablas_in_world"] = vb["nablas"]          # identity object->world rotation (single object)
+                if world_transform is None:
+                    vb["nablas_in_world"] = vb["nablas"]      # identity object->world rotation
+                else:
+                    o2w = world_transform[0].detach()
+                    if o2w.dim() == 2:
+                        vb["nablas_in_world"] = (o2w * vb["nablas"].unsqueeze(-2)).sum(-1)
+                    else:                                     # per-ray rotation (object frozen at several frames)
+                        vb["nablas_in_world"] = po.packed_matmul(vb["nablas"], o2w[rih], pih)
         # ---- distant-view model on ALL rays (reference :281-335)
         dv_vb = None
         if distant_model is not None:
@@ -192,7 +210,7 @@ class SingleVolumeRenderer(nn.Module):
             if with_env is None:
                 with_env = config.get("with_env", True)
             if with_env and sky_model is not None:
-                env_rgb = sky_model(v=F.normalize(rays_d, dim=-1), h_appear=rays_h_appear)
+                env_rgb = sky_model(v=F.normalize(rays_d_world, dim=-1), h_appear=rays_h_appear)
                 total_rendered["rgb_sky"] = env_rgb
                 total_rendered["rgb_volume_non_occupied"] = env_blend = \
                     (1.0 - total_rendered["mask_volume"][..., None]) * env_rgb
@@ -209,7 +227,8 @@ class SingleVolumeRenderer(nn.Module):
     def render(self, model: LoTDNeuSModel, *, rays: List[torch.Tensor], rays_h_appear: torch.Tensor = None, near=None,
                far=None, rayschunk: int = None, with_rgb=None, with_normal=None, return_buffer=False,
                return_details=False, render_per_obj_individual=False, bypass_ray_query_cfg: dict = None,
-               distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None) -> Dict:
+               distant_model=None, sky_model=None, with_env: bool = None, cr_ray_tested: dict = None,
+               world_transform=None) -> Dict:
         """rays = [rays_o, rays_d(, rays_ts, rays_pix)] with arbitrary prefix shape (reference :495-581)."""
         if rayschunk is None:
             rayschunk = self.config.get("rayschunk", 0)
@@ -221,7 +240,7 @@ class SingleVolumeRenderer(nn.Module):
                           return_buffer=return_buffer, return_details=return_details,
                           render_per_obj_individual=render_per_obj_individual, bypass_ray_query_cfg=bypass_ray_query_cfg,
                           distant_model=distant_model, sky_model=sky_model, with_env=with_env,
-                          cr_ray_tested=cr_ray_tested)
+                          cr_ray_tested=cr_ray_tested, world_transform=world_transform)
             if self.training or (not rayschunk) or flat[0].shape[0] <= rayschunk:
                 ret = self(*flat[:2], rays_h_appear=ha, **kwargs)
             else:

@@ -86,11 +86,133 @@ def reference_renderer_modules():
             spec.loader.exec_module(mod)
             mods[name] = mod
         mods["classes"] = classes
+        if (REF_ROOT / "app/resources/scenes.py").exists():
+            with reference_scene_class() as Scene:       # the reference's own world -> object ray conversion
+                mods["convert_rays_in_node"] = Scene.convert_rays_in_node
+                mods["convert_rays_in_nodes_list"] = Scene.convert_rays_in_nodes_list
+            sys.modules["app"], sys.modules["app.resources"] = app, sys.modules.get("app.resources") or app
         yield mods
     finally:
         for k in [k for k in sys.modules if k == "app" or k.startswith("app.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+@contextlib.contextmanager
+def reference_camera_class():
+    """-> the reference's ``Camera`` class (app/resources/observers/cameras.py, loaded unchanged).  Its ray methods are
+    called UNBOUND on a ``FakeCamera``: the snapping / clamping / normalisation / origin logic is the reference's,
+    ``intr.lift`` and ``world_transform.rotate`` (nr3d_lib.models.attributes, absent) are the stand-ins below."""
+    assert (REF_ROOT / "app/resources/observers/cameras.py").exists()
+    names = ["nr3d_lib.utils", "nr3d_lib.models.attributes", "nr3d_lib.graphics.cameras", "app", "app.resources",
+             "app.resources.nodes", "app.resources.observers", "app.resources.observers.cameras"]
+    saved = {k: sys.modules.get(k) for k in names}
+    attrs = _stub_module("nr3d_lib.models.attributes")
+    attrs.__all__ = []
+    app, res, obs = _stub_module("app"), _stub_module("app.resources"), _stub_module("app.resources.observers")
+    app.__path__, res.__path__, obs.__path__ = [], [], []
+    sys.modules.update({
+        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", is_scalar=lambda x: not hasattr(x, "__len__")),
+        "nr3d_lib.models.attributes": attrs,
+        "nr3d_lib.graphics.cameras": _stub_module("nr3d_lib.graphics.cameras", pinhole_lift=None, sphere_inside_frustum=None),
+        "app": app, "app.resources": res, "app.resources.observers": obs,
+        "app.resources.nodes": _stub_module("app.resources.nodes", SceneNode=type("SceneNode", (), {})),
+    })
+    try:
+        spec = importlib.util.spec_from_file_location("app.resources.observers.cameras",
+                                                      str(REF_ROOT / "app/resources/observers/cameras.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        yield mod.Camera
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+@contextlib.contextmanager
+def reference_scene_class():
+    """-> the reference's ``Scene`` class (app/resources/scenes.py, loaded unchanged) for its static ray conversions
+    ``convert_rays_in_node`` / ``convert_rays_in_nodes_list`` (:629-708)."""
+    assert (REF_ROOT / "app/resources/scenes.py").exists()
+    names = ["nr3d_lib.utils", "nr3d_lib.models.attributes", "nr3d_lib.models.accelerations.occgrid_accel", "app",
+             "app.resources", "app.resources.observers", "app.resources.scenes"]
+    saved = {k: sys.modules.get(k) for k in names}
+    attrs = _stub_module("nr3d_lib.models.attributes")
+    attrs.__all__ = []
+    app = _stub_module("app")
+    app.__path__ = []
+    res = _stub_module("app.resources", SceneNode=type("SceneNode", (), {}))
+    res.__path__ = []
+    obs = _stub_module("app.resources.observers", OBSERVER_CLASS_NAMES=[], OBSERVER_TYPE=object,
+                       Camera=type("Camera", (), {}), Lidar=type("Lidar", (), {}), RaysLidar=type("RaysLidar", (), {}))
+    import nr3d_lib.models.accelerations as acc
+    sys.modules.update({
+        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", IDListedDict=dict, get_shape=None, import_str=None,
+                                       check_to_torch=None),
+        "nr3d_lib.models.attributes": attrs,
+        "nr3d_lib.models.accelerations.occgrid_accel": _stub_module("nr3d_lib.models.accelerations.occgrid_accel",
+                                                                    OccGridAccel=acc.OccGridAccel),
+        "app": app, "app.resources": res, "app.resources.observers": obs,
+    })
+    try:
+        spec = importlib.util.spec_from_file_location("app.resources.scenes", str(REF_ROOT / "app/resources/scenes.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        yield mod.Scene
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+class FakePinhole:
+    """Stand-in for nr3d_lib's PinholeCameraMatKHW attribute: mat [...,3,3], W/H (scalars or [...]); ``lift`` is the
+    textbook pinhole back-projection ((u - cx) / fx * d, (v - cy) / fy * d, d)."""
+    def __init__(self, mat, WH):
+        self.mat, self._wh = mat, WH
+        self.W, self.H = int(WH.reshape(-1, 2)[0, 0]), int(WH.reshape(-1, 2)[0, 1])
+
+    def __getitem__(self, i):
+        return FakePinhole(self.mat[i], self._wh[i])
+
+    def wh(self):
+        return self._wh
+
+    def lift(self, u, v, d):
+        m = self.mat
+        fx, fy, cx, cy = m[..., 0, 0], m[..., 1, 1], m[..., 0, 2], m[..., 1, 2]
+        return torch.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], dim=-1)
+
+
+class FakePose:
+    """Stand-in for nr3d_lib's TransformMat4x4: ``rotate`` is broadcast-multiply-sum (cameras.py:355-359 forbids mm)."""
+    def __init__(self, mat):
+        self.mat = mat
+
+    def __getitem__(self, i):
+        return FakePose(self.mat[i])
+
+    def rotate(self, v):
+        R = self.mat[..., :3, :3]
+        if R.dim() == 2:
+            return (R * v.unsqueeze(-2)).sum(-1)
+        return (R.view(*R.shape[:-2], *[1] * (v.dim() - R.dim() + 1), 3, 3) * v.unsqueeze(-2)).sum(-1)
+
+    def translation(self):
+        return self.mat[..., :3, 3]
+
+
+class FakeCamera:
+    def __init__(self, intr, c2w, WH, i_prefix=()):
+        self.intr, self.world_transform = FakePinhole(intr, WH), FakePose(c2w)
+        self.i_prefix, self.device, self.dtype = tuple(i_prefix), intr.device, intr.dtype
 
 
 class FakeTransform:
@@ -103,14 +225,21 @@ class FakeTransform:
     def rotation(self):
         return self.R
 
+    def translation(self):
+        return self.t
+
     def rotate(self, v):
         return (self.R * v.unsqueeze(-2)).sum(-1)
+
+    def vec_3(self):          # node.scale.vec_3()
+        return torch.full([3], float(self.s), device=self.R.device) if not torch.is_tensor(self.s) else self.s
 
 
 class FakeNode:
     def __init__(self, model, class_name, id, world_transform=None):
         self.model, self.class_name, self.id = model, class_name, id
         self.world_transform = world_transform or FakeTransform()
+        self.scale = self.world_transform
         if not hasattr(model, "id"):
             model.id = f"{class_name}#model"
 
@@ -119,8 +248,12 @@ class FakeScene:
     """The part of ``app.resources.Scene`` that ``SingleVolumeRenderer.ray_query`` touches
     (single_volume_renderer.py:157-263): drawable groups by class name, the device, the image embeddings and
     ``convert_rays_in_node`` (scenes.py:686-708 -- world -> object by the node's rotation / translation / scale)."""
-    def __init__(self, device, main_class_name="Main", image_embeddings=None):
+    def __init__(self, device, main_class_name="Main", image_embeddings=None, convert_rays_in_node=None):
+        """``convert_rays_in_node``: the reference's own static method (``reference_scene_class``) when the caller
+        loaded it; the restatement below otherwise."""
         self.device = device
+        if convert_rays_in_node is not None:
+            self.convert_rays_in_node = convert_rays_in_node
         self.main_class_name = main_class_name
         self.image_embeddings = image_embeddings
         self.drawable_groups_by_class_name = {}

@@ -16,6 +16,9 @@ SCENARIOS = {
     "main_train": dict(distant=False, sky=False, training=True, with_normal=True, norm_depth=False),
     "main_distant_sky_train": dict(distant=True, sky=True, training=True, with_normal=True, norm_depth=False),
     "main_distant_eval": dict(distant=True, sky=False, training=False, with_normal=True, norm_depth=True),
+    # the main object posed in the world (rotation, translation, scale): rays converted by the REFERENCE's
+    # Scene.convert_rays_in_node, normals rotated back (single_volume_renderer.py:225, 262-265)
+    "posed_main_distant_sky_train": dict(distant=True, sky=True, training=True, with_normal=True, norm_depth=True, posed=True),
     "main_sky_all_miss": dict(distant=False, sky=True, training=True, with_normal=False, norm_depth=True, all_miss=True),
 }
 
@@ -36,6 +39,16 @@ def build_scenario(name, device, precision="f32"):
     else:
         o[::6] += torch.tensor([0.0, 4.0, 0.0])          # rays that miss the close-range box
     ha = torch.randn(N, 4, generator=g) * 0.3
+    s["world_transform"] = None
+    if s.get("posed"):
+        ax = torch.tensor([0.3, -0.5, 0.81])
+        ax = ax / ax.norm()
+        K = torch.tensor([[0.0, -ax[2], ax[1]], [ax[2], 0.0, -ax[0]], [-ax[1], ax[0], 0.0]])
+        R = torch.eye(3) + 0.61 * K + (1 - (1 - 0.61 ** 2) ** 0.5) * (K @ K)          # Rodrigues, sin = 0.61
+        tr, sc = torch.tensor([0.3, -0.2, 0.15]), 1.25
+        # the rays were drawn in the object frame: move them into the world so that the same samples come back
+        o, d = (R * (o * sc).unsqueeze(-2)).sum(-1) + tr, (R * (d * sc).unsqueeze(-2)).sum(-1)
+        s["world_transform"] = (R.to(device), tr.to(device), sc)
     val, _ = orr.build_occ_grid(p, AABB[0], AABB[1], RES, n_pts=2 ** 13, n_steps=2)
     model = model_from_params(p, device, precision=precision)
     model.accel = OccGridAccel(AABB, resolution=RES, device=device)
@@ -110,8 +123,10 @@ def run_reference(mods, s, backward=False):
     """The reference's SingleVolumeRenderer.ray_query (single_volume_renderer.py:136-492) over a FakeScene."""
     import ref_glue
     dev = s["device"]
-    scene = ref_glue.FakeScene(dev, main_class_name="Main", image_embeddings=ref_glue.FixedEmbeddings(s["h_appear"]))
-    scene.add(ref_glue.FakeNode(s["model"], "Main", "main"))
+    scene = ref_glue.FakeScene(dev, main_class_name="Main", image_embeddings=ref_glue.FixedEmbeddings(s["h_appear"]),
+                               convert_rays_in_node=mods.get("convert_rays_in_node"))
+    wt = ref_glue.FakeTransform(*s["world_transform"], device=dev) if s["world_transform"] is not None else None
+    scene.add(ref_glue.FakeNode(s["model"], "Main", "main", wt))
     if s["distant_model"] is not None:
         scene.add(ref_glue.FakeNode(s["distant_model"], "Distant", "distant"))
     if s["sky_model"] is not None:
@@ -130,5 +145,5 @@ def run_mirror(s, backward=False):
     with torch.set_grad_enabled(s["training"]):
         ret = r.ray_query(s["rays_o"], s["rays_d"], model=s["model"], rays_h_appear=s["h_appear"],
                           distant_model=s["distant_model"], sky_model=s["sky_model"], return_buffer=True,
-                          return_details=True)
+                          return_details=True, world_transform=s["world_transform"])
     return _finish(s, ret, ret["raw_per_obj_model"], backward)

@@ -51,7 +51,7 @@ def test_reference_renderer_runs_on_the_mirror(backend, name):
     for k, g in ref["grads"].items():
         denom = float(g.norm()) + 1e-12
         e = float((got["grads"][k] - g).norm()) / denom
-        assert e < 1e-3, (k, e)
+        assert e < 2e-4, (k, e)
 
 
 @pytest.mark.parametrize("name", list(SCENARIOS))
@@ -72,7 +72,11 @@ def test_mirror_matches_reference_fixture(backend, name):
         if k in fx["volume_buffer"]:
             _cmp(got["volume_buffer"][k], fx["volume_buffer"][k], 1e-3, f"volume_buffer.{k}")
     for k, g in fx["grads"].items():
-        e = float((got["grads"][k] - g).norm()) / (float(g.norm()) + 1e-12)
+        mine = got["grads"][k]
+        if isinstance(g, dict):                 # strided sample + norm of a large gradient
+            assert abs(float(mine.norm()) - g["norm"]) <= 5e-3 * g["norm"], k
+            mine, g = mine[::g["stride"]], g["sample"]
+        e = float((mine - g).norm()) / (float(g.norm()) + 1e-12)
         assert e < 5e-3, (k, e)
 
 
@@ -114,3 +118,38 @@ def test_reference_volume_integration_pins_the_oracle():
         finally:
             m.packed_alpha_to_vw, m.packed_sum, m.packed_div = saved
     assert "app" not in sys.modules
+
+
+@needs_reference
+def test_reference_camera_rays_pin_the_oracle_and_the_kernel(backend):
+    """Row a1: ``Camera._get_selected_rays_from_ixy`` and ``get_all_rays`` of the reference (cameras.py:281-310,
+    332-360; pixel-centre snapping, clamping, normalisation are the reference's code, the pinhole lift and the
+    broadcast rotation are stand-ins for the absent nr3d_lib attributes) against the oracle's ``pinhole_rays`` and
+    the ray-generation kernel."""
+    from oracle import render as orr
+    from neuralsim_amd.eval import all_pixel_xy
+    from neuralsim_amd.graphics.cameras import pinhole_selected_rays
+    from util import look_at_cameras
+    intr, c2w, WH = look_at_cameras(V=5, seed=9, H=40, W=56, f=61.3)
+    intr[:, 0, 2] += 0.37                                 # principal point off the pixel grid
+    intr[:, 1, 1] *= 1.03
+    g = torch.Generator().manual_seed(2)
+    N = 1000
+    xy = torch.rand(N, 2, generator=g).clamp(1e-6, 1 - 1e-6)
+    xy[:4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [1.0, 0.0], [0.999999, 0.5]])      # the clamp at the image border
+    fidx = torch.randint(0, 5, (N,), generator=g)
+    with ref_glue.reference_camera_class() as Camera:
+        cam = ref_glue.FakeCamera(intr, c2w, WH.float())
+        for snap in (True, False):
+            o_ref, d_ref = Camera._get_selected_rays_from_ixy(cam, fidx, xy, snap_to_pixel_centers=snap)
+            o_o, d_o = orr.pinhole_rays(xy, fidx, intr, c2w, WH, snap_to_pixel_centers=snap)
+            assert torch.equal(o_ref, o_o) and float((d_ref - d_o).abs().max()) <= 2e-7
+            if snap:
+                dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+                o_k, d_k = pinhole_selected_rays(dv(xy), dv(fidx), dv(intr), dv(c2w), dv(WH))
+                assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 3e-7
+        one = ref_glue.FakeCamera(intr[2], c2w[2], WH[2].float())
+        o_all, d_all = Camera.get_all_rays(one)
+    xy_all = all_pixel_xy(56, 40, torch.device("cpu"))
+    o_o, d_o = orr.pinhole_rays(xy_all, torch.full([56 * 40], 2), intr, c2w, WH)
+    assert o_all.shape == (56 * 40, 3) and torch.equal(o_all, o_o) and float((d_all - d_o).abs().max()) <= 2e-7
