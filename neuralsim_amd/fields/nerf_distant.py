@@ -125,12 +125,20 @@ class LoTDNeRFDistantModel(nn.Module):
     def __init__(self, aabb: torch.Tensor = None, precision: str = "fp16", radius_scale_min: float = 1.0,
                  radius_scale_max: float = 1000.0, max_steps: int = 64, include_inf_distance: bool = True,
                  use_view_dirs: bool = True, lotd_auto_compute_cfg: dict = None, param_bound: float = 1e-4,
-                 seed: int = 7, device=None):
+                 seed: int = 7, device=None, ray_query_cfg: dict = None, **reference_params):
         """``include_inf_distance`` / ``radiance_decoder_cfg.use_view_dirs``: true / true in the object-centric configs
         (lotd_neus.dtu.230814.yaml:221-236), false / false in the street config, which has a sky model and feeds the
         radiance net features + appearance only (withmask_withlidar_joint.240219.yaml:281-294).  The street config's
         ``sample_mode: fixed_cuboid_shells`` + ``interval_type: inverse_proportional`` is what the shells kernel does:
         cuboid shells = the AABB scaled about its centre, uniform in 1/r."""
+        if reference_params:        # the reference's model_params block verbatim (fields/ref_config.py)
+            from . import ref_config
+            kw = ref_config.distant_native_kwargs(dict(
+                reference_params, include_inf_distance=include_inf_distance, radius_scale_min=radius_scale_min,
+                radius_scale_max=radius_scale_max, ray_query_cfg=ray_query_cfg))
+            kw.setdefault("max_steps", max_steps)
+            LoTDNeRFDistantModel.__init__(self, aabb=aabb, seed=seed, device=device, **kw)
+            return
         super().__init__()
         self.include_inf, self.use_view_dirs = bool(include_inf_distance), bool(use_view_dirs)
         c = dict(lotd_auto_compute_cfg or {})
@@ -167,6 +175,24 @@ class LoTDNeRFDistantModel(nn.Module):
         self.ray_query_cfg = dict(query_mode="march", query_param=dict(march_cfg=dict(sample_mode="box", max_steps=self.K)))
         if device is not None:
             self.to(device)
+
+    def populate(self, aabb: torch.Tensor = None, device=None, **unused):
+        """The reference hands the close-range object's AABB over at populate time (``populate_cfg.cr_obj_classname``,
+        lotd_neus.dtu.230814.yaml:239-241; app/models/single/nerf.py:145-196)."""
+        if aabb is not None:
+            self.aabb.copy_(torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3))
+        if device is not None:
+            self.to(device)
+        return self
+
+    def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
+        return False
+
+    def training_before_per_step(self, it: int, logger=None):
+        pass
+
+    def training_after_per_step(self, it: int, logger=None):
+        pass
 
     def _shadow(self):
         p = self.flattened_params

@@ -364,6 +364,9 @@ class OccGridAccel(nn.Module):
 
     def cur_batch__step(self, it: int, query_sdf):
         """``training_before_per_step`` hook (app/resources/asset_bank.py:291-298)."""
+        if getattr(self, "_last_step_it", None) == it:      # trainer and model hook may both call in: once per iteration
+            return
+        self._last_step_it = it
         if it >= self.n_steps_warmup and it % self.n_steps_between_update == 0:
             self.update_from_net(query_sdf)
 
@@ -376,12 +379,34 @@ class LoTDNeuSModel(nn.Module):
                  precision: str = "fp16", softplus_beta: float = 100.0, ln_inv_s_init: float = 0.1,
                  ln_inv_s_factor: float = 10.0, bounding_size: float = 2.0, aabb: torch.Tensor = None,
                  accel_cfg: dict = None, ray_query_cfg: dict = None, param_bound: float = 1e-4, seed: int = 42,
-                 sdf_scale: float = 1.0, inside_out: bool = False, device=None):
+                 sdf_scale: float = 1.0, inside_out: bool = False, device=None, **reference_params):
         """``sdf_scale``: the decoder output is divided by it (street config ``sdf_scale: 25``,
         withmask_withlidar_joint.240219.yaml:158); ``inside_out``: sign of the geometric initialisation (indoor config
         ``inside_out: true``, lotd_neus.replica.230814.yaml:95).  Both live in the absent nr3d_lib -- semantics fixed
-        here: sdf = head(h) / sdf_scale (folded into the packed head weights), inside_out => initial sdf = r - |x|."""
+        here: sdf = head(h) / sdf_scale (folded into the packed head weights), inside_out => initial sdf = r - |x|.
+
+        ``reference_params``: the reference's ``model_params`` block passed verbatim, as
+        ``import_str(model_class)(**model_params, device=device)`` does (app/resources/asset_bank.py:129-138) --
+        ``dtype, var_ctrl_cfg, cos_anneal_cfg, use_tcnn_backend, surface_cfg, radiance_cfg`` next to ``accel_cfg`` /
+        ``ray_query_cfg`` (fields/ref_config.py).  Blocks that size themselves from the AABB (``lotd_use_cuboid``,
+        ``accel_cfg.vox_size``: the street model) are built by ``populate(aabb=...)``, as in the reference
+        (app/models/single/neus.py:152-196)."""
+        if reference_params:
+            from . import ref_config
+            params = dict(reference_params, accel_cfg=accel_cfg, ray_query_cfg=ray_query_cfg)
+            if aabb is None and ref_config.neus_needs_aabb(params):
+                nn.Module.__init__(self)
+                self._deferred_params, self._deferred_seed = params, seed
+                self._pending_device = device
+                return
+            kw, post = ref_config.neus_native_kwargs(params, aabb=aabb)
+            LoTDNeuSModel.__init__(self, seed=seed, device=device, **kw)
+            self._reference_post = post
+            if "var_ctrl" in post:
+                self.set_var_ctrl(**post["var_ctrl"])
+            return
         super().__init__()
+        self._deferred_params = None
         assert W == 64 and sdf_D in (1, 2), "gfx950 fused kernels: hidden width 64, 1 or 2 hidden SDF layers"
         self.sdf_scale, self.inside_out = float(sdf_scale), bool(inside_out)
         lod_res = list(lod_res) if lod_res is not None else list(DEFAULT_LOD_RES)
@@ -443,6 +468,51 @@ class LoTDNeuSModel(nn.Module):
         self._wpack_versions = None
         if device is not None:
             self.to(device)
+
+    # ------------------------------------------------------------------ reference life cycle
+    def populate(self, aabb: torch.Tensor = None, device=None, **unused):
+        """``model.populate(...)`` of the reference's asset mixin (app/models/single/neus.py:55-59 ``populate(device=)``,
+        :152-196 ``populate(aabb=, device=)`` for the street model): builds a model whose ``model_params`` needed the
+        AABB, moves it to the device."""
+        if getattr(self, "_deferred_params", None) is not None:
+            assert aabb is not None, "this model_params block sizes itself from the AABB: populate(aabb=...)"
+            params, seed = self._deferred_params, self._deferred_seed
+            device = device if device is not None else self._pending_device
+            acc, rq = params.pop("accel_cfg", None), params.pop("ray_query_cfg", None)
+            LoTDNeuSModel.__init__(self, aabb=torch.as_tensor(aabb, dtype=torch.float32).cpu(), seed=seed, accel_cfg=acc,
+                                   ray_query_cfg=rq, **params)
+        elif aabb is not None:
+            assert torch.allclose(torch.as_tensor(aabb, dtype=torch.float32).cpu(), self.accel.aabb.cpu()), \
+                "populate(aabb=...) differs from the AABB the model was built with"
+        if device is not None:
+            self.to(device)
+        return self
+
+    @torch.no_grad()
+    def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
+        """``asset_training_initialize`` -> ``training_initialize`` (app/models/single/neus.py:61-64, :198-236): the
+        geometric initialisation named by ``surface_cfg.geo_init_method`` / ``radius_init`` (here the deterministic
+        sphere of ``geometric_init_sphere`` instead of ``initialize_cfg.num_iters`` pre-training steps) followed by
+        ``accel.init(self.query_sdf)``.  Returns True when the weights were (re-)initialised."""
+        post = getattr(self, "_reference_post", {})
+        updated = False
+        method = post.get("geo_init_method", "pretrain_after_zero_out")
+        if ("pretrain" in method) and not getattr(self, "is_pretrained", False):
+            cfg = self.encoding.cfg
+            if "zero_out" in method:
+                self.encoding.flattened_params.zero_()
+            ext = (self.accel.aabb[1] - self.accel.aabb[0]).cpu()
+            # radius_init is in object units; the sphere is written in the [-1, 1] coordinates of the shortest axis
+            r = float(post.get("radius_init", 0.5)) / (float(ext.min()) / 2.0)
+            self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
+            self.is_pretrained = updated = True
+            del cfg
+        if self.accel is not None:
+            self.accel.init(self.query_sdf, logger=logger)
+        an = post.get("anneal")
+        if an is not None:
+            self.anneal_levels(0, **an)
+        return updated
 
     # ------------------------------------------------------------------ bookkeeping
     @property
@@ -556,6 +626,22 @@ class LoTDNeuSModel(nn.Module):
         if vc is not None:
             span = max(vc["stop_it"] - vc["start_it"], 1)
             self._ctrl_mix = min(max((int(it) - vc["start_it"]) / span, 0.0), 1.0)
+        post = getattr(self, "_reference_post", None)
+        if post is not None:        # built from the reference's model_params: the model drives its own schedules
+            if post.get("anneal") is not None:
+                self.anneal_levels(int(it), **post["anneal"])
+            self.accel.cur_batch__step(int(it), self.query_sdf)
+
+    def training_after_per_step(self, it: int, logger=None):
+        """After ``optimizer.step`` (app/resources/asset_bank.py:300-308): nothing to do -- the fp16 table shadow and
+        the packed MFMA weight fragments refresh lazily from the parameter versions."""
+
+    def rendering_before_per_view(self, renderer=None, observer=None, per_frame_info: dict = None):
+        """app/resources/asset_bank.py:310-318: no per-view state."""
+
+    def model_setup(self):
+        """app/resources/asset_bank.py:269-277: make the derived buffers current once (shadow + weight pack)."""
+        self._shadow()
 
     def _ln_inv_s_eff(self) -> torch.Tensor:
         """The 1-element tensor the alpha / compress kernels read as ln_inv_s (autograd-transparent)."""

@@ -75,3 +75,56 @@ def parse_device_ids(device_ids: Union[str, int, List[int]] = -1, to_torch: bool
         device_ids = list(range(torch.cuda.device_count())) if device_ids == -1 else [device_ids]
     device_ids = list(device_ids)
     return [torch.device("cuda", i) for i in device_ids] if to_torch else device_ids
+
+
+# ------------------------------------------------------------------------------------------------ YAML front end
+def _lookup(root: dict, path: str):
+    cur = root
+    for k in path.split("."):
+        cur = cur[k]
+    return cur
+
+
+def _resolve_str(s: str, root: dict, depth: int = 0):
+    """``${a.b}`` -> the value at that path of the ROOT config (typed when the string is nothing but the reference),
+    ``${eval:"expr"}`` / ``${eval:expr}`` -> Python arithmetic -- the two interpolation forms the reference's configs
+    use on the model blocks (lotd_neus.dtu.230814.yaml:82-166)."""
+    import re
+    assert depth < 16, f"circular interpolation in {s!r}"
+    pat = re.compile(r"\$\{([^{}]+)\}")
+    m = pat.fullmatch(s.strip())
+
+    def value(body):
+        if body.startswith("eval:"):
+            expr = body[5:].strip()
+            if len(expr) >= 2 and expr[0] == expr[-1] and expr[0] in "\"'":
+                expr = expr[1:-1]
+            expr = _resolve_str(expr, root, depth + 1) if "${" in expr else expr
+            return eval(str(expr), {"__builtins__": {}}, {"min": min, "max": max, "int": int, "float": float})
+        v = _lookup(root, body)
+        return _resolve_str(v, root, depth + 1) if isinstance(v, str) and "${" in v else v
+    if m:
+        return value(m.group(1))
+    return pat.sub(lambda mm: str(value(mm.group(1))), s)
+
+
+def resolve_config(cfg: dict) -> ConfigDict:
+    """Resolve every interpolation of a loaded YAML tree against its own root."""
+    def walk(v):
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [walk(x) for x in v]
+        if isinstance(v, str) and "${" in v:
+            try:
+                return walk(_resolve_str(v, cfg))
+            except (KeyError, TypeError):
+                return v            # references into parts of the harness config that are not present stay verbatim
+        return v
+    return ConfigDict(walk(cfg))
+
+
+def load_config(path: str) -> ConfigDict:
+    import yaml
+    with open(path) as f:
+        return resolve_config(yaml.safe_load(f))
