@@ -172,6 +172,47 @@ def reference_scene_class():
                 sys.modules[k] = v
 
 
+@contextlib.contextmanager
+def reference_lidar_loss_module():
+    """-> the reference's app/loss/lidar.py (LineOfSightLoss, DepthLoss), loaded unchanged.  ``packed_sum`` & co come
+    from the shim; the harness pieces it imports (logger, annealers, the elementwise recon losses of nr3d_lib) get
+    minimal stand-ins."""
+    assert (REF_ROOT / "app/loss/lidar.py").exists()
+    names = ["nr3d_lib.logger", "nr3d_lib.models.annealers", "nr3d_lib.models.loss", "nr3d_lib.models.loss.recon", "app",
+             "app.resources", "app.loss", "app.loss.lidar"]
+    saved = {k: sys.modules.get(k) for k in names}
+
+    def masked_mean(x, mask):
+        return x.mean() if mask is None else (x * mask).sum() / mask.sum().clamp_min(1)
+    recon = _stub_module(
+        "nr3d_lib.models.loss.recon",
+        l1_loss=lambda p, g, mask=None, reduction="mean": masked_mean((p - g).abs(), mask),
+        l2_loss=lambda p, g, mask=None, reduction="mean": masked_mean((p - g) ** 2, mask),
+        relative_l2_loss=lambda p, g, mask=None, reduction="mean": masked_mean((p - g) ** 2 / (g ** 2 + 1e-2), mask),
+        huber_loss=lambda p, g, mask=None, reduction="mean", alpha=1.0: masked_mean(
+            torch.nn.functional.huber_loss(p, g, reduction="none", delta=alpha), mask))
+    app, lossp = _stub_module("app"), _stub_module("app.loss")
+    app.__path__, lossp.__path__ = [], []
+    sys.modules.update({
+        "nr3d_lib.logger": _stub_module("nr3d_lib.logger", Logger=object),
+        "nr3d_lib.models.annealers": _stub_module("nr3d_lib.models.annealers", get_annealer=None, get_anneal_val=None),
+        "nr3d_lib.models.loss": _stub_module("nr3d_lib.models.loss"), "nr3d_lib.models.loss.recon": recon,
+        "app": app, "app.loss": lossp, "app.resources": _stub_module("app.resources", Scene=object),
+    })
+    try:
+        spec = importlib.util.spec_from_file_location("app.loss.lidar", str(REF_ROOT / "app/loss/lidar.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        yield mod
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 class FakePinhole:
     """Stand-in for nr3d_lib's PinholeCameraMatKHW attribute: mat [...,3,3], W/H (scalars or [...]); ``lift`` is the
     textbook pinhole back-projection ((u - cx) / fx * d, (v - cy) / fy * d, d)."""

@@ -73,6 +73,10 @@ def test_mirror_matches_reference_fixture(backend, name):
             _cmp(got["volume_buffer"][k], fx["volume_buffer"][k], 1e-3, f"volume_buffer.{k}")
     for k, g in fx["grads"].items():
         mine = got["grads"][k]
+        if (g["norm"] if isinstance(g, dict) else float(g.norm())) < 1e-4:
+            # rounding noise only (the sky behind an opaque far shell: 1 - mask = 0 up to f32 rounding)
+            assert float(mine.norm()) < 1e-4, k
+            continue
         if isinstance(g, dict):                 # strided sample + norm of a large gradient
             assert abs(float(mine.norm()) - g["norm"]) <= 5e-3 * g["norm"], k
             mine, g = mine[::g["stride"]], g["sample"]
@@ -153,3 +157,55 @@ def test_reference_camera_rays_pin_the_oracle_and_the_kernel(backend):
     xy_all = all_pixel_xy(56, 40, torch.device("cpu"))
     o_o, d_o = orr.pinhole_rays(xy_all, torch.full([56 * 40], 2), intr, c2w, WH)
     assert o_all.shape == (56 * 40, 3) and torch.equal(o_all, o_o) and float((d_all - d_o).abs().max()) <= 2e-7
+
+
+@needs_reference
+def test_reference_line_of_sight_loss_on_a_lidar_step(backend):
+    """The street config's second batch per iteration (withmask_withlidar_joint.240219.yaml:7-8, train.py:896-902):
+    rays rendered with ``with_rgb=False`` (radiance net skipped), then the reference's ``LineOfSightLoss``
+    (app/loss/lidar.py:57-206, loaded unchanged) reads ``volume_buffer['vw']`` / ``['t']`` / ``pack_infos_hit`` and
+    ``rendered['depth_volume']`` of the mirror's return value.  Loss values and the gradient that reaches the table
+    are compared with the same formulas evaluated with the oracle's pack ops on the detached buffers."""
+    from oracle import pack_ops as opo
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    sc = build_scenario("main_train", backend)
+    r = SingleVolumeRenderer(dict(with_rgb=False, with_normal=False, near=0.01, depth_use_normalized_vw=True,
+                                  perturb=False)).train()
+    ret = r.ray_query(sc["rays_o"], sc["rays_d"], model=sc["model"], return_buffer=True)
+    assert "rgb_volume" not in ret["rendered"] and "rgb" not in ret["volume_buffer"]
+    vb = ret["volume_buffer"]
+    N = sc["N"]
+    g = torch.Generator().manual_seed(8)
+    ranges = (ret["rendered"]["depth_volume"].detach().cpu() + torch.randn(N, generator=g) * 0.05).clamp_min(0.1)
+    mask = (torch.rand(N, generator=g) < 0.8)
+    gt = dict(ranges=ranges.to(backend))
+    with ref_glue.reference_lidar_loss_module() as lidar:
+        losses = {}
+        for fn_type, param in (("nerf", dict(sigma=0.1)), ("neus_urban", dict(sigma=0.1)), ("neus_unisim", dict(epsilon=0.1))):
+            los = lidar.LineOfSightLoss(w=0.5, fn_type=fn_type, fn_param=param)
+            for k, v in los(None, ret, None, gt, it=0, mask=mask.to(backend)).items():
+                losses[f"{fn_type}.{k}"] = v
+    assert len(losses) == 5
+    total = sum(losses.values())
+    sc["model"].encoding.flattened_params.grad = None
+    total.backward()
+    g_table = sc["model"].encoding.flattened_params.grad.detach().cpu().clone()
+    rg = sc["model"].rad_w.grad
+    assert float(g_table.abs().sum()) > 0 and (rg is None or float(rg.abs().sum()) == 0.0)   # no radiance query happened
+    # the same formulas on the oracle's pack ops (f64), vw as the leaf
+    pi, t = vb["pack_infos_hit"].cpu(), vb["t"].detach().cpu().double()
+    rih = vb["rays_inds_hit"].cpu()
+    vw = vb["vw"].detach().cpu().double().requires_grad_(True)
+    gt_ex = torch.repeat_interleave(ranges[rih].double(), pi[:, 1])
+    mh = mask[rih].double()
+    sig = 0.1
+    tgt = torch.exp(torch.distributions.normal.Normal(0.0, sig / 3.0).log_prob(t - gt_ex))
+    nb = opo.packed_sum(((t <= gt_ex + sig) & (t >= gt_ex - sig)) * (vw - tgt) ** 2, pi)
+    em = opo.packed_sum((t < gt_ex - sig) * vw ** 2, pi)
+    eu = opo.packed_sum(((t - gt_ex).abs() > 0.1) * vw ** 2, pi)
+    want = {"nerf.lidar_loss.los.neighbor": 0.5 * (nb * mh).mean(), "nerf.lidar_loss.los.empty": 0.5 * (em * mh).mean(),
+            "neus_unisim.lidar_loss.los.empty": 0.5 * (eu * mh).mean()}
+    want["neus_urban.lidar_loss.los.neighbor"], want["neus_urban.lidar_loss.los.empty"] = \
+        want["nerf.lidar_loss.los.neighbor"], want["nerf.lidar_loss.los.empty"]
+    for k, v in want.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-5 * (1 + abs(float(v))), k
