@@ -200,7 +200,19 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         pair and carries ``rays_bidx_hit`` / ``rays_full_bidx_hit`` next to ``rays_inds_hit``."""
         assert self.ins_inds_per_batch is not None, "set_condition() first"
         bt = batched_ray_tested
-        ins = self.ins_inds_per_batch[bt["rays_full_bidx"]] if bt["num_rays"] > 0 else bt["rays_full_bidx"]
+        # The reference conditions the model on the COMPACTED batch -- ``set_condition({'ins_id': [ids of the items
+        # that were hit at all]})`` after ``batched_ray_test(compact_batch=True)`` (buffer_compose_renderer.py:247-258)
+        # -- so the condition is indexed by ``rays_bidx``; a condition given over the full batch by ``rays_full_bidx``
+        # (when every item was hit the two coincide).
+        n_cond = int(self.ins_inds_per_batch.shape[0])
+        if "full_bidx_map" in bt and n_cond == int(bt["full_bidx_map"].shape[0]):
+            which = bt["rays_bidx"]
+        else:
+            which = bt["rays_full_bidx"]
+            if batched_ray_input is not None and batched_ray_input.get("rays_o") is not None:
+                assert n_cond == int(batched_ray_input["rays_o"].shape[0]), \
+                    "set_condition() covers neither the compacted nor the full batch of batched_ray_tested"
+        ins = self.ins_inds_per_batch[which] if bt["num_rays"] > 0 else which
         goff, woff = self._offsets(ins)
         tested = dict(bt)
         tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())

@@ -39,6 +39,13 @@ def main():
             r["grads"] = {k: (g if g.numel() <= 8192 else dict(stride=8, sample=g[::8].clone(), norm=float(g.norm())))
                           for k, g in r["grads"].items()}
             print(name, {k: tuple(v.shape) for k, v in r["rendered"].items()}, "grads:", len(r["grads"]))
+    import compose_scenario as cs
+    with ref_glue.reference_compose_renderer_modules() as mods:      # code_multi: the reference's BufferComposeRenderer
+        out["compose"] = cs.run_reference(mods, cs.build(torch.device("cpu")))
+    for r in out.values():
+        r["grads"] = {k: (g if (isinstance(g, dict) or g.numel() <= 8192) else
+                          dict(stride=8, sample=g[::8].clone(), norm=float(g.norm()))) for k, g in r["grads"].items()}
+
     def own(v):         # torch.save writes whole storages: detach views from the buffers they were sliced out of
         if torch.is_tensor(v):
             return v.clone().contiguous()

@@ -99,6 +99,98 @@ def reference_renderer_modules():
 
 
 @contextlib.contextmanager
+def reference_compose_renderer_modules():
+    """-> the reference's ``app/renderers/buffer_compose_renderer.py`` (multi-object renderer of code_multi), loaded
+    unchanged, plus the grouping / ray-conversion statics of its ``Scene``.  Stand-ins: ``torch_scatter`` and
+    ``matplotlib`` (imported at module level, used by the segmentation z-buffer / debug plots only),
+    ``nr3d_lib.utils.IDListedDict``, ``app.models.asset_base`` (the ``AssetAssignment`` enum, same members)."""
+    import enum
+    assert (REF_ROOT / "app/renderers/buffer_compose_renderer.py").exists()
+    with reference_renderer_modules() as mods:          # installs app / app.renderers / utils / resources stubs
+        with reference_scene_class() as Scene:
+            pass
+        names = ["torch_scatter", "matplotlib", "matplotlib.pyplot", "nr3d_lib.utils", "app.models", "app.models.asset_base",
+                 "app.renderers.buffer_compose_renderer"]
+        saved = {k: sys.modules.get(k) for k in names}
+
+        class AssetAssignment(enum.Enum):
+            OBJECT = 0
+            SCENE = 1
+            MULTI_OBJ_ONE_SCENE = 2
+            MULTI_OBJ_MULTI_SCENE = 3
+            MULTI_OBJ = 3
+            MULTI_SCENE = 4
+            MISC = 5
+        import nr3d_lib.config  # noqa: F401
+        scenes_mod = sys.modules.get("app.resources.scenes")
+        res = sys.modules["app.resources"]
+        res.namedtuple_ind_id_obj = Scene.group_drawables_by_class_name.__globals__["namedtuple_ind_id_obj"]
+        mpl = _stub_module("matplotlib")
+        mpl.__path__ = []
+        am = _stub_module("app.models")
+        am.__path__ = []
+        sys.modules.update({
+            "torch_scatter": _stub_module("torch_scatter", scatter_min=None),
+            "matplotlib": mpl, "matplotlib.pyplot": _stub_module("matplotlib.pyplot"),
+            "nr3d_lib.utils": _stub_module("nr3d_lib.utils", IDListedDict=dict),
+            "app.models": am,
+            "app.models.asset_base": _stub_module("app.models.asset_base", AssetAssignment=AssetAssignment,
+                                                  AssetModelMixin=object),
+        })
+        try:
+            spec = importlib.util.spec_from_file_location("app.renderers.buffer_compose_renderer",
+                                                          str(REF_ROOT / "app/renderers/buffer_compose_renderer.py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[spec.name] = mod
+            spec.loader.exec_module(mod)
+            mods = dict(mods, compose=mod, Scene=Scene, AssetAssignment=AssetAssignment)
+            del scenes_mod
+            yield mods
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+
+
+class FakeComposeScene:
+    """What ``BufferComposeRenderer.ray_query`` touches of the Scene (buffer_compose_renderer.py:133-168, 198):
+    drawables in a fixed order, grouping by class name and the batched ray conversion (both the REFERENCE's static
+    methods), class / instance index maps, image embeddings."""
+    def __init__(self, device, Scene, image_embeddings=None):
+        self.device, self._Scene, self.image_embeddings = device, Scene, image_embeddings
+        self.nodes = []
+        self.drawable_groups_by_class_name = {}
+        self.convert_rays_in_nodes_list = Scene.convert_rays_in_nodes_list
+        self.group_drawables_by_class_name = Scene.group_drawables_by_class_name
+
+    def add(self, node):
+        self.nodes.append(node)
+        self.drawable_groups_by_class_name.setdefault(node.class_name, []).append(node)
+        node.full_unique_id = node.id
+        node.i_valid_flags = torch.tensor(True, device=self.device)
+        return node
+
+    def get_drawables(self):
+        return [n for n in self.nodes if n.class_name != "Sky"]
+
+    def get_drawable_groups_by_class_name(self, class_name):
+        return self.drawable_groups_by_class_name.get(class_name, [])
+
+    def get_drawable_class_ind_map(self):
+        return {c: i for i, c in enumerate(self.drawable_groups_by_class_name)}
+
+    def get_drawable_instance_ind_map(self):
+        return {n.id: i for i, n in enumerate(self.nodes)}
+
+
+class FakeObserver(_Named):
+    def filter_drawable_groups(self, drawables):
+        return drawables
+
+
+@contextlib.contextmanager
 def reference_camera_class():
     """-> the reference's ``Camera`` class (app/resources/observers/cameras.py, loaded unchanged).  Its ray methods are
     called UNBOUND on a ``FakeCamera``: the snapping / clamping / normalisation / origin logic is the reference's,

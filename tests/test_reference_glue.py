@@ -209,3 +209,48 @@ def test_reference_line_of_sight_loss_on_a_lidar_step(backend):
         want["nerf.lidar_loss.los.neighbor"], want["nerf.lidar_loss.los.empty"]
     for k, v in want.items():
         assert abs(float(losses[k]) - float(v)) <= 1e-5 * (1 + abs(float(v))), k
+
+
+@needs_reference
+def test_reference_compose_renderer_runs_on_the_mirror(backend):
+    """code_multi: the reference's ``BufferComposeRenderer.ray_query`` (buffer_compose_renderer.py:110-850, loaded
+    unchanged) over a fake scene -- a single-object background model, a shared batched model with posed instances (one
+    of them outside the view, so the batch is compacted), a sky -- against the mirror on the same models and rays."""
+    import compose_scenario as cs
+    sc = cs.build(backend)
+    with ref_glue.reference_compose_renderer_modules() as mods:
+        ref = cs.run_reference(mods, sc)
+    got = cs.run_mirror(sc)
+    _compare_compose(got, ref, 3e-5, 3e-4)
+
+
+def _compare_compose(got, ref, tol, gtol):
+    assert torch.equal(got["samples_cnt"], ref["samples_cnt"]) and int((ref["samples_cnt"] > 0).sum()) > 20
+    assert ref["vehicle_ids"] == ["car2", "car0"]                         # car1 is never hit: compacted away
+    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume", "rgb_volume_occupied", "rgb_sky",
+              "rgb_volume_non_occupied"):
+        _cmp(got["rendered"][k], ref["rendered"][k], tol, k)
+    _cmp(got["volume_buffer"]["pack_infos_hit"], ref["volume_buffer"]["pack_infos_hit"], 0, "pack_infos_hit")
+    for k in ("t", "opacity_alpha", "rgb", "vw"):
+        _cmp(got["volume_buffer"][k], ref["volume_buffer"][k], tol, f"volume_buffer.{k}")
+    for key in ("main", "Vehicle"):
+        _cmp(got["vw_in_total"][key], ref["vw_in_total"][key], tol, f"vw_in_total.{key}")
+    assert set(got["grads"]) >= set(ref["grads"])
+    for k, gr in ref["grads"].items():
+        mine = got["grads"][k]
+        norm = gr["norm"] if isinstance(gr, dict) else float(gr.norm())
+        if norm < 1e-6:
+            continue
+        if isinstance(gr, dict):
+            assert abs(float(mine.norm()) - norm) <= gtol * norm, k
+            mine, gr = mine[::gr["stride"]], gr["sample"]
+        e = float((mine - gr).norm()) / (float(gr.norm()) + 1e-12)
+        assert e < gtol, (k, e)
+
+
+def test_compose_mirror_matches_reference_fixture(backend):
+    """The compose mirror against the frozen outputs of the reference's BufferComposeRenderer (``-m gpu`` on the box)."""
+    import compose_scenario as cs
+    fx = torch.load(GOLDEN)["compose"]
+    got = cs.run_mirror(cs.build(backend))
+    _compare_compose(got, fx, 1e-3, 5e-3)
