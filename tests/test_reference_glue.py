@@ -224,7 +224,7 @@ def test_reference_compose_renderer_runs_on_the_mirror(backend):
     _compare_compose(got, ref, 3e-5, 3e-4)
 
 
-def _compare_compose(got, ref, tol, gtol):
+def _compare_compose(got, ref, tol, gtol, btol=None):
     assert torch.equal(got["samples_cnt"], ref["samples_cnt"]) and int((ref["samples_cnt"] > 0).sum()) > 20
     assert ref["vehicle_ids"] == ["car2", "car0"]                         # car1 is never hit: compacted away
     for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume", "rgb_volume_occupied", "rgb_sky",
@@ -232,9 +232,9 @@ def _compare_compose(got, ref, tol, gtol):
         _cmp(got["rendered"][k], ref["rendered"][k], tol, k)
     _cmp(got["volume_buffer"]["pack_infos_hit"], ref["volume_buffer"]["pack_infos_hit"], 0, "pack_infos_hit")
     for k in ("t", "opacity_alpha", "rgb", "vw"):
-        _cmp(got["volume_buffer"][k], ref["volume_buffer"][k], tol, f"volume_buffer.{k}")
+        _cmp(got["volume_buffer"][k], ref["volume_buffer"][k], btol or tol, f"volume_buffer.{k}")
     for key in ("main", "Vehicle"):
-        _cmp(got["vw_in_total"][key], ref["vw_in_total"][key], tol, f"vw_in_total.{key}")
+        _cmp(got["vw_in_total"][key], ref["vw_in_total"][key], btol or tol, f"vw_in_total.{key}")
     assert set(got["grads"]) >= set(ref["grads"])
     for k, gr in ref["grads"].items():
         mine = got["grads"][k]
@@ -253,4 +253,5 @@ def test_compose_mirror_matches_reference_fixture(backend):
     import compose_scenario as cs
     fx = torch.load(GOLDEN)["compose"]
     got = cs.run_mirror(cs.build(backend))
-    _compare_compose(got, fx, 1e-3, 5e-3)
+    # per-sample alphas amplify the f32 rounding differences between the device and the emulator by inv_s (~90 here)
+    _compare_compose(got, fx, 1e-3, 5e-3, btol=4e-3)
