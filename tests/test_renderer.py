@@ -86,3 +86,56 @@ def test_sky_blend_in_renderer(backend):
     r["rgb_volume"].sum().backward()
     assert sky.w.grad is not None and float(sky.w.grad.abs().sum()) > 0
     assert model.encoding.flattened_params.grad is not None                 # (1 - mask) carries gradient to the SDF
+
+
+def test_ssim_and_masked_psnr():
+    """SSIM against a direct (loop-free but unfused) evaluation with scipy's Gaussian filter; PSNR mask variants."""
+    import numpy as np
+    from scipy.ndimage import correlate1d
+    from neuralsim_amd.eval import ssim
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(40, 52, 3, generator=g)
+    b = (a + 0.1 * torch.randn(40, 52, 3, generator=g)).clamp(0, 1)
+    assert abs(ssim(a, a) - 1.0) < 1e-6 and ssim(a, b) < 0.99
+    w = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2))
+    w /= w.sum()
+
+    def blur(x):
+        return correlate1d(correlate1d(x, w, axis=0, mode="constant"), w, axis=1, mode="constant")
+    x, y = a.numpy().astype(np.float64), b.numpy().astype(np.float64)
+    tot = 0.0
+    for c in range(3):
+        mx, my = blur(x[..., c]), blur(y[..., c])
+        sxx, syy, sxy = blur(x[..., c] ** 2) - mx ** 2, blur(y[..., c] ** 2) - my ** 2, blur(x[..., c] * y[..., c]) - mx * my
+        tot += (((2 * mx * my + 1e-4) * (2 * sxy + 9e-4)) / ((mx ** 2 + my ** 2 + 1e-4) * (sxx + syy + 9e-4))).mean()
+    assert abs(ssim(a, b) - tot / 3) < 1e-5
+    m = torch.zeros(40, 52, 1)
+    m[10:30, 5:40] = 1
+    full = psnr(a * m, b * m)
+    assert abs(psnr(a, b, m, only_in_mask=False) - full) < 1e-4
+    assert psnr(a, b, m, only_in_mask=True) < full                       # same error over fewer pixels
+    assert 0.0 < ssim(a * m, b * m, m, only_in_mask=True) < ssim(a * m, b * m, m, only_in_mask=False)
+
+
+def test_evaluate_views(backend):
+    """eval.py:241-316 on the hot path: chunked full-image renders scored with PSNR / SSIM (full and foreground)."""
+    from neuralsim_amd.eval import evaluate_views
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=3, ln_inv_s=0.6, grid_bound=2e-2, noise_scale=1.0)
+    intr, c2w, WH = look_at_cameras(V=2, seed=5, H=16, W=16, f=14.0)
+    model = model_from_params(p, backend, precision="f32")
+    model.ray_query_cfg = dict(query_mode="march_occ_multi_upsample", query_param=QP)
+    model.accel = OccGridAccel(AABB, resolution=RES, device=backend)
+    val, _ = orr.build_occ_grid(p, AABB[0], AABB[1], RES, n_pts=2 ** 14, n_steps=2)
+    model.accel.occ_val.copy_(val.to(backend))
+    model.accel.pack_bits()
+    renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=False, near=0.01, depth_use_normalized_vw=True))
+    dv = lambda t: t.to(backend)          # noqa: E731
+    ha = torch.tensor([[0.1, -0.2, 0.3, 0.05]])
+    first = evaluate_views(renderer, model, dv(intr), dv(c2w), dv(WH), [0, 1], [torch.zeros(16, 16, 3)] * 2,
+                           rays_h_appear=dv(ha), rayschunk=100)
+    from neuralsim_amd.eval import render_image
+    imgs = [render_image(renderer, model, dv(intr), dv(c2w), dv(WH), frame=f, rays_h_appear=dv(ha)) for f in (0, 1)]
+    res = evaluate_views(renderer, model, dv(intr), dv(c2w), dv(WH), [0, 1], [i["rgb_volume"].cpu() for i in imgs],
+                         gt_masks=[(i["mask_volume"] > 0.5).cpu() for i in imgs], rays_h_appear=dv(ha), rayschunk=100)
+    assert all(v > 60 for v in res["full_psnr"]) and all(v > 0.999 for v in res["full_ssim"])      # scored against itself
+    assert all(a < 40 for a in first["full_psnr"]) and len(res["fg_ssim_only_in_mask"]) == 2
