@@ -112,6 +112,8 @@ class SingleVolumeRenderer(nn.Module):
         cr_ret = model.ray_query(ray_input=cr_ray_input, ray_tested=cr_ray_tested, config=ray_query_config,
                                  return_buffer=True, return_details=return_details,
                                  render_per_obj_individual=render_per_obj_individual)
+        # what the loss modules look up in raw_per_obj_model (reference :247; app/loss/eikonal.py:197-202)
+        cr_ret.update(class_name=config.get("main_class_name", "Main"), model_id=getattr(model, "id", "main"), obj_id="main")
         vb = cr_ret["volume_buffer"]
         if vb["type"] != "empty":
             rih, pih = vb["rays_inds_hit"], vb["pack_infos_hit"]
@@ -140,6 +142,7 @@ class SingleVolumeRenderer(nn.Module):
                 dv_cfg[k] = v
             dv_ret = distant_model.ray_query(ray_tested=dv_tested, config=dv_cfg, return_buffer=True,
                                              return_details=return_details)
+            dv_ret.update(class_name="Distant", model_id=getattr(distant_model, "id", "distant"), obj_id="distant")
             dv_vb = dv_ret["volume_buffer"]
             K = dv_vb["num_per_hit"]
             total_num_samples_per_ray += K

@@ -305,6 +305,39 @@ def reference_lidar_loss_module():
                 sys.modules[k] = v
 
 
+@contextlib.contextmanager
+def reference_eikonal_loss_module():
+    """-> the reference's app/loss/eikonal.py (EikonalLoss), loaded unchanged.  ``packed_sum`` comes from the shim
+    (``nr3d_lib.graphics.pack_ops.pack_ops``); ``safe_mse_loss`` (absent nr3d_lib) is a stand-in that is only reached
+    with ``safe_mse=True`` -- the tests construct the loss with ``safe_mse=False`` (plain ``F.mse_loss``)."""
+    assert (REF_ROOT / "app/loss/eikonal.py").exists()
+    names = ["nr3d_lib.logger", "nr3d_lib.models.annealers", "nr3d_lib.models.loss", "nr3d_lib.models.loss.safe",
+             "nr3d_lib.utils", "app", "app.resources", "app.loss", "app.loss.eikonal"]
+    saved = {k: sys.modules.get(k) for k in names}
+    app, lossp = _stub_module("app"), _stub_module("app.loss")
+    app.__path__, lossp.__path__ = [], []
+    sys.modules.update({
+        "nr3d_lib.logger": _stub_module("nr3d_lib.logger", Logger=object),
+        "nr3d_lib.models.annealers": _stub_module("nr3d_lib.models.annealers", get_annealer=None, get_anneal_val=None),
+        "nr3d_lib.models.loss": _stub_module("nr3d_lib.models.loss"),
+        "nr3d_lib.models.loss.safe": _stub_module("nr3d_lib.models.loss.safe", safe_mse_loss=None),
+        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", tensor_statistics=None),
+        "app": app, "app.loss": lossp, "app.resources": _stub_module("app.resources", Scene=object, SceneNode=object),
+    })
+    try:
+        spec = importlib.util.spec_from_file_location("app.loss.eikonal", str(REF_ROOT / "app/loss/eikonal.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        yield mod
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 class FakePinhole:
     """Stand-in for nr3d_lib's PinholeCameraMatKHW attribute: mat [...,3,3], W/H (scalars or [...]); ``lift`` is the
     textbook pinhole back-projection ((u - cx) / fx * d, (v - cy) / fy * d, d)."""

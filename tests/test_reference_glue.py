@@ -255,3 +255,45 @@ def test_compose_mirror_matches_reference_fixture(backend):
     got = cs.run_mirror(cs.build(backend))
     # per-sample alphas amplify the f32 rounding differences between the device and the emulator by inv_s (~90 here)
     _compare_compose(got, fx, 1e-3, 5e-3, btol=4e-3)
+
+
+@needs_reference
+def test_reference_eikonal_loss_on_the_mirror(backend):
+    """The reference's ``EikonalLoss`` (app/loss/eikonal.py:23-251, loaded unchanged; dtu config:
+    ``on_uniform_samples``, ``on_occ_ratio 1``, ``on_render_type both``, ``on_render_ratio .1``) driven by the mirror's
+    return value: it looks up ``raw_per_obj_model[*]['class_name' | 'model_id' | 'volume_buffer']``, calls
+    ``model.sample_pts_in_occupied`` and reads ``nablas``, ``vw_in_total``, ``pack_infos_collect``.  With the noise off
+    the three terms equal the plain formulas, and the gradient reaches the table through the second-order path."""
+    from oracle import pack_ops as opo
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    sc = build_scenario("main_train", backend)
+    model = sc["model"]
+    model.id = "LoTDNeuSObj#Main"
+    r = SingleVolumeRenderer(sc["common"]).train()
+    ret = r.ray_query(sc["rays_o"], sc["rays_d"], model=model, rays_h_appear=sc["h_appear"], return_buffer=True,
+                      return_details=True)
+    raw = ret["raw_per_obj_model"]["main"]
+    assert raw["class_name"] == "Main" and raw["model_id"] == model.id
+    uni = model.sample_pts_uniform(64, generator=torch.Generator(device=backend).manual_seed(1))
+
+    class Bank(dict):
+        pass
+    scene = type("S", (), {})()
+    scene.asset_bank = Bank({model.id: model})
+    with ref_glue.reference_eikonal_loss_module() as eik:
+        loss_mod = eik.EikonalLoss(1.0e-3, ["Main"], on_uniform_samples=True, on_occ_ratio=1.0, on_render_type="both",
+                                   on_render_ratio=0.1, with_noise=0.0, safe_mse=False)
+        torch.manual_seed(0)
+        losses = loss_mod(scene, ret, {"Main": uni}, None, None, it=0, mode="pixel")
+    assert set(losses) == {"loss_eikonal.Main.uniform", "loss_eikonal.Main.occ", "loss_eikonal.Main.render"}
+    vb = raw["volume_buffer"]
+    fn = lambda n: (n.norm(dim=-1) - 1.0) ** 2          # noqa: E731
+    nab = vb["nablas"].detach().cpu().double()
+    want_render = fn(nab).mean() + opo.packed_sum(fn(nab) * vb["vw_in_total"].detach().cpu().double(),
+                                                  vb["pack_infos_collect"].cpu()).mean()
+    assert abs(float(losses["loss_eikonal.Main.render"]) - 1e-3 * 0.1 * float(want_render)) < 1e-7
+    assert abs(float(losses["loss_eikonal.Main.uniform"]) - 1e-3 * float(fn(uni["nablas"].detach().cpu().double()).mean())) < 1e-7
+    assert float(losses["loss_eikonal.Main.occ"]) > 0
+    model.encoding.flattened_params.grad = None
+    sum(losses.values()).backward()
+    assert float(model.encoding.flattened_params.grad.abs().sum()) > 0
