@@ -48,12 +48,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
 
-def build_trainer(device, rank, world, seed=42, distant=False, sky=False):
+def build_trainer(device, rank, world, seed=42, distant=False, sky=False, sdf_D=2):
     from neuralsim_amd.fields.neus import LoTDNeuSModel
     from neuralsim_amd.graphics.cameras import look_at_cameras
     from neuralsim_amd.trainer import RenderTrainer
     from neuralsim_amd import distributed as ndist
-    model = LoTDNeuSModel(sdf_D=2, precision="fp16", ln_inv_s_init=0.5, seed=seed).to(device)
+    model = LoTDNeuSModel(sdf_D=sdf_D, precision="fp16", ln_inv_s_init=0.5, seed=seed).to(device)
     # DTU-scan-like pixel coverage: a sphere of radius 0.75 covers ~40 % of the 800x800 views of the camera rig
     # (radius_init 0.5 of the reference config would cover 16 %); see DESIGN.md sec. 7
     model.geometric_init_sphere(SPHERE_RADIUS)
@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--distant", action="store_true",
                     help="add the NeRF++ distant-view model (64 shells on every ray), as in the reference's full config")
     ap.add_argument("--sky", action="store_true", help="add the sky MLP (SimpleSky, street configs) blended per ray")
+    ap.add_argument("--sdf-depth", type=int, default=2, choices=(1, 2),
+                    help="hidden layers of the SDF decoder: 2 = BASELINE configs[1] (2x64, the default), 1 = the reference "
+                         "yaml's own decoder_cfg D: 1 (lotd_neus.dtu.230814.yaml:120)")
     args = ap.parse_args()
 
     from neuralsim_amd import _lib, distributed as ndist
@@ -163,11 +166,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.get_lib()
-    tr = build_trainer(dev, rank, world, distant=args.distant, sky=args.sky)
+    tr = build_trainer(dev, rank, world, distant=args.distant, sky=args.sky, sdf_D=args.sdf_depth)
     out = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=RAYS_PER_GPU)
     if rank == 0:
         out["config"]["distant_model"] = bool(args.distant)
         out["config"]["sky_model"] = bool(args.sky)
+        out["config"]["sdf_mlp"] = f"{args.sdf_depth}x64"
         out["config"]["launch_chain"] = "fused (no autograd engine)" if tr._fused_ok() else "autograd"
         if world == 1 and not args.no_cpu_baseline and not args.distant and not args.sky:
             out["cpu_baseline"], out["parity"] = cpu_baseline(tr, n_rays=args.cpu_rays)
@@ -270,7 +274,7 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
                    unit="rays/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
                    config=dict(workload="BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
-                                        "8192 rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + 2x64 SDF MLP + 2x64 radiance "
+                                        f"8192 rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + {tr.model.sdf_D}x64 SDF MLP + 2x64 radiance "
                                         "MLP (SH4, appear 4), synthetic sphere r=0.75 (~40% coverage) supervised by its analytic image, occ grid 64^3, num_coarse 64, "
                                         "num_fine [8,8,32], "
                                         "step .005, query_mode march_occ_multi_upsample_compressed (reference default), inv_s=e^5, eikonal on "
