@@ -111,3 +111,40 @@ def test_fuzz_compress(backend, n, inv_s, thre, seed):
     _lib.call("nsim_compress_emit", _lib.ptr(dv(sdf)), _lib.ptr(dv(t)), _lib.ptr(dv(pi)), R, _lib.ptr(ln), 1.0, float(inv_s),
               float(thre), _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
     assert torch.equal(t_k.cpu(), t[keep]) and torch.equal(ridx_k.cpu(), ridx[keep])
+
+
+@settings(**SET)
+@given(n=counts, p_one=st.sampled_from([0.0, 0.02, 0.2]), p_zero=st.sampled_from([0.0, 0.1]), scale=st.sampled_from([0.05, 0.5, 1.0]),
+       norm_depth=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_fuzz_compositing_forward_backward(backend, n, p_one, p_zero, scale, norm_depth, seed):
+    """Fused compositing and the stand-alone alpha -> vw op on random ragged packs with exactly-opaque (alpha = 1) and
+    exactly-empty (alpha = 0) samples sprinkled in: values and EVERY per-sample gradient against the f64 oracle (the
+    backward's 1 / (1 - alpha + 1e-10) factor makes the sums over the later samples cancellation-critical)."""
+    from neuralsim_amd.fields.neus import volume_integration
+    g = torch.Generator().manual_seed(seed)
+    n, pi, S, ridx, t, near = _packs(n, g)
+    R = n.shape[0]
+    alpha = torch.rand(S, generator=g) * scale
+    u = torch.rand(S, generator=g)
+    alpha[u < p_one] = 1.0
+    alpha[(u >= p_one) & (u < p_one + p_zero)] = 0.0
+    rgb, nrm = torch.rand(S, 3, generator=g), torch.randn(S, 3, generator=g)
+    wm, wd = torch.randn(R, generator=g), torch.randn(R, generator=g) * 0.3
+    wr, wn = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+    dv = lambda a: a.to(backend).contiguous()         # noqa: E731
+    a_d = alpha.clone().to(backend).requires_grad_(True)
+    a_o = alpha.double().requires_grad_(True)
+    r_d, r_o = rgb.clone().to(backend).requires_grad_(True), rgb.double().requires_grad_(True)
+    out = volume_integration(a_d, dv(t), r_d, dv(nrm), dv(pi), norm_depth)
+    ref = orr.volume_integration(a_o, t.double(), r_o, nrm.double(), pi, norm_depth)
+    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+        assert torch.allclose(out[k].detach().cpu().double(), ref[k].detach(), atol=2e-5, rtol=1e-5), k
+    (out["mask_volume"] * dv(wm) + out["depth_volume"] * dv(wd) + (out["rgb_volume"] * dv(wr)).sum(-1)
+     + (out["normals_volume"] * dv(wn)).sum(-1)).sum().backward()
+    (ref["mask_volume"] * wm + ref["depth_volume"] * wd + (ref["rgb_volume"] * wr).sum(-1)
+     + (ref["normals_volume"] * wn).sum(-1)).sum().backward()
+    err = (a_d.grad.cpu().double() - a_o.grad).abs() / a_o.grad.abs().clamp_min(1.0)
+    assert float(err.max()) < 2e-4, (float(err.max()), int(err.argmax()), float(alpha[int(err.argmax())]))
+    assert torch.allclose(r_d.grad.cpu().double(), r_o.grad, atol=1e-5)
+    vw = po.packed_alpha_to_vw(dv(alpha), dv(pi))
+    assert torch.allclose(vw.cpu().double(), opo.packed_alpha_to_vw(alpha.double(), pi), atol=1e-6)
