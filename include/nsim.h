@@ -280,7 +280,9 @@ int nsim_ray_grad_reduce(const float* dx, const float* dv, const float* t, const
 
 /* ------------------------------------------------ NeRF++ distant-view model (LoTDNeRFDistant) */
 /* 4-D LoTD level table of ``lotd_auto_compute_cfg{type: ngp4d}`` (lotd_neus.dtu.230814.yaml:193-200): level l has
- * res_xyz^3 * res_w vertices (Dense) or a 2^k-entry hash table; 2 features per level; <= 16 levels. */
+ * res_xyz^3 * res_w vertices (Dense) or a 2^k-entry hash table; 2 features per level; <= 16 levels.
+ * ``lotd_use_cuboid: true`` (withmask_withlidar_joint.240219.yaml:256): per-axis vertex counts -- res_xyz is the x
+ * count, res_y / res_z the other two; 0 in res_y / res_z means "same as res_xyz" (cubic level). */
 typedef struct NsimLotd4Meta {
   int32_t num_levels;
   int32_t res_xyz[16];
@@ -288,6 +290,8 @@ typedef struct NsimLotd4Meta {
   int32_t type[16];
   uint32_t size[16];
   int64_t offset[16];
+  int32_t res_y[16];
+  int32_t res_z[16];
 } NsimLotd4Meta;
 
 typedef struct NsimDistantMeta {

@@ -28,7 +28,8 @@ class OccMeta(C.Structure):
 
 class Lotd4Meta(C.Structure):
     _fields_ = [("num_levels", C.c_int32), ("res_xyz", C.c_int32 * 16), ("res_w", C.c_int32 * 16),
-                ("type", C.c_int32 * 16), ("size", C.c_uint32 * 16), ("offset", C.c_int64 * 16)]
+                ("type", C.c_int32 * 16), ("size", C.c_uint32 * 16), ("offset", C.c_int64 * 16),
+                ("res_y", C.c_int32 * 16), ("res_z", C.c_int32 * 16)]
 
 
 class DistantMeta(C.Structure):

@@ -15,7 +15,7 @@
 
 struct Lotd4Dev {
   int num_levels;
-  int res_xyz[D4_MAX_LEVELS], res_w[D4_MAX_LEVELS], type[D4_MAX_LEVELS];
+  int res_xyz[D4_MAX_LEVELS], res_y[D4_MAX_LEVELS], res_z[D4_MAX_LEVELS], res_w[D4_MAX_LEVELS], type[D4_MAX_LEVELS];
   uint32_t size[D4_MAX_LEVELS];
   int64_t offset[D4_MAX_LEVELS];
 };
@@ -26,6 +26,8 @@ static inline Lotd4Dev lotd4_dev(const NsimLotd4Meta* m) {
   for (int l = 0; l < D4_MAX_LEVELS; ++l) {
     const bool ok = l < m->num_levels;
     d.res_xyz[l] = ok ? m->res_xyz[l] : 2;
+    d.res_y[l] = ok ? (m->res_y[l] > 0 ? m->res_y[l] : m->res_xyz[l]) : 2;      // 0: cubic level
+    d.res_z[l] = ok ? (m->res_z[l] > 0 ? m->res_z[l] : m->res_xyz[l]) : 2;
     d.res_w[l] = ok ? m->res_w[l] : 2;
     d.type[l] = ok ? m->type[l] : 0;
     d.size[l] = ok ? m->size[l] : 16;
@@ -39,8 +41,10 @@ static int lotd4_meta_check(const NsimLotd4Meta* m) {
   if (m->num_levels < 1 || m->num_levels > D4_MAX_LEVELS) return 12;
   for (int l = 0; l < m->num_levels; ++l) {
     if (m->res_xyz[l] < 2 || m->res_w[l] < 2) return 13;
+    if (m->res_y[l] == 1 || m->res_z[l] == 1 || m->res_y[l] < 0 || m->res_z[l] < 0) return 13;
+    const uint64_t ry = m->res_y[l] > 0 ? m->res_y[l] : m->res_xyz[l], rz = m->res_z[l] > 0 ? m->res_z[l] : m->res_xyz[l];
     if (m->type[l] == NSIM_LOTD_DENSE) {
-      if ((uint64_t)m->res_xyz[l] * m->res_xyz[l] * m->res_xyz[l] * m->res_w[l] != (uint64_t)m->size[l]) return 14;
+      if ((uint64_t)m->res_xyz[l] * ry * rz * m->res_w[l] != (uint64_t)m->size[l]) return 14;
     } else if (m->type[l] == NSIM_LOTD_HASH) {
       if (m->size[l] == 0 || (m->size[l] & (m->size[l] - 1)) != 0) return 17;
     } else {
@@ -56,11 +60,11 @@ struct Cell4 {
   float w[4];
 };
 
-__device__ __forceinline__ Cell4 lotd4_cell(const float u[4], int Rx, int Rw) {
+__device__ __forceinline__ Cell4 lotd4_cell(const float u[4], int Rx, int Ry, int Rz, int Rw) {
   Cell4 c;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int R = a < 3 ? Rx : Rw;
+    const int R = a == 0 ? Rx : (a == 1 ? Ry : (a == 2 ? Rz : Rw));
     const float pos = u[a] * (float)(R - 1);
     float f = floorf(pos);
     f = fminf(fmaxf(f, 0.f), (float)(R - 2));
@@ -70,9 +74,10 @@ __device__ __forceinline__ Cell4 lotd4_cell(const float u[4], int Rx, int Rw) {
   return c;
 }
 
-__device__ __forceinline__ uint32_t lotd4_index(int cx, int cy, int cz, int cw, int Rx, int type, uint32_t T) {
+__device__ __forceinline__ uint32_t lotd4_index(int cx, int cy, int cz, int cw, int Rx, int Ry, int Rz, int type,
+                                                uint32_t T) {
   if (type == NSIM_LOTD_DENSE)
-    return (uint32_t)cx + (uint32_t)Rx * ((uint32_t)cy + (uint32_t)Rx * ((uint32_t)cz + (uint32_t)Rx * (uint32_t)cw));
+    return (uint32_t)cx + (uint32_t)Rx * ((uint32_t)cy + (uint32_t)Ry * ((uint32_t)cz + (uint32_t)Rz * (uint32_t)cw));
   const uint32_t h = (uint32_t)cx ^ ((uint32_t)cy * 2654435761u) ^ ((uint32_t)cz * 805459861u) ^
                      ((uint32_t)cw * 3674653429u);
   return h & (T - 1u);
@@ -425,13 +430,13 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
           const int l = 4 * q + 2 * hi + b;   // level slot; slots >= num_levels are padding
           float f0 = 0.f, f1 = 0.f;
           if (l < a.lotd.num_levels) {
-            const int Rx = a.lotd.res_xyz[l], Rw = a.lotd.res_w[l];
-            const Cell4 c = lotd4_cell(u, Rx, Rw);
+            const int Rx = a.lotd.res_xyz[l], Ry = a.lotd.res_y[l], Rz = a.lotd.res_z[l], Rw = a.lotd.res_w[l];
+            const Cell4 c = lotd4_cell(u, Rx, Ry, Rz, Rw);
 #pragma unroll
             for (int corner = 0; corner < 16; ++corner) {
               const float w = lotd4_weight(c, corner);
               const uint32_t idx = lotd4_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
-                                               c.c0[2] + ((corner >> 2) & 1), c.c0[3] + ((corner >> 3) & 1), Rx,
+                                               c.c0[2] + ((corner >> 2) & 1), c.c0[3] + ((corner >> 3) & 1), Rx, Ry, Rz,
                                                a.lotd.type[l], a.lotd.size[l]);
               float g0, g1;
               lotd4_load2(a.grid, a.lotd.offset[l], idx, g0, g1);
@@ -617,7 +622,7 @@ struct Scatter4Args {
 __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
   const int lane = nsim_lane();
   const int l = blockIdx.y;
-  const int Rx = a.lotd.res_xyz[l], Rw = a.lotd.res_w[l];
+  const int Rx = a.lotd.res_xyz[l], Ry = a.lotd.res_y[l], Rz = a.lotd.res_z[l], Rw = a.lotd.res_w[l];
   // K = 64 shells per ray: a wave holds consecutive shells of (mostly) ONE ray.  Far shells converge to a fixed
   // (x/r) direction and step through few 1/r cells on the coarser levels, so runs of lanes hit the same vertex:
   // collapse them (run heads by ballot, segmented shuffle scan) before the atomics -- the kernel is bound by the
@@ -638,7 +643,7 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
       dh0 = dp[0];
       dh1 = dp[1];
     }
-    const Cell4 c = lotd4_cell(u, Rx, Rw);
+    const Cell4 c = lotd4_cell(u, Rx, Ry, Rz, Rw);
 #pragma unroll
     for (int yzw = 0; yzw < 8; ++yzw) {
       uint32_t idx[2];
@@ -649,7 +654,7 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
         const int corner = dx | (yzw << 1);
         const float w = lotd4_weight(c, corner);
         idx[dx] = lotd4_index(c.c0[0] + dx, c.c0[1] + (yzw & 1), c.c0[2] + ((yzw >> 1) & 1), c.c0[3] + (yzw >> 2), Rx,
-                              a.lotd.type[l], a.lotd.size[l]);
+                              Ry, Rz, a.lotd.type[l], a.lotd.size[l]);
         v0[dx] = w * dh0;
         v1[dx] = w * dh1;
         emit[dx] = valid;

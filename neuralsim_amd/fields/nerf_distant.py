@@ -22,16 +22,24 @@ class LoTD4Config:
     per_level_scale}`` (yaml :193-200)."""
 
     def __init__(self, target_num_params=8 * 2 ** 20, min_res_xyz=8, min_res_w=4, log2_hashmap_size=19,
-                 per_level_scale=1.382, max_levels=16):
+                 per_level_scale=1.382, max_levels=16, aspect=None):
+        """``aspect``: the AABB's (x, y, z) extents when ``lotd_use_cuboid: true``
+        (withmask_withlidar_joint.240219.yaml:256) -- the shortest axis follows the ``min_res_xyz`` progression, the
+        other two are stretched by their extent ratio (the 3-D pyramid's convention, grid_encodings/lotd.py); None =
+        cubic levels."""
         T = 2 ** log2_hashmap_size
-        self.res_xyz, self.res_w, self.types, self.sizes, self.offsets = [], [], [], [], []
+        self.res_xyz, self.res_w, self.types, self.sizes, self.offsets, self.res3 = [], [], [], [], [], []
+        asp = [1.0, 1.0, 1.0] if aspect is None else [float(a) / min(float(b) for b in aspect) for a in aspect]
+        self.cuboid = aspect is not None
         off = 0
         for l in range(max_levels):
             Rx = int(math.ceil(min_res_xyz * per_level_scale ** l - 1e-6))
             Rw = int(math.ceil(min_res_w * per_level_scale ** l - 1e-6))
-            n = Rx ** 3 * Rw
+            R3 = [int(math.ceil(min_res_xyz * per_level_scale ** l * a - 1e-6)) for a in asp]
+            n = R3[0] * R3[1] * R3[2] * Rw
             dense = n <= T
             self.res_xyz.append(Rx)
+            self.res3.append(R3)
             self.res_w.append(Rw)
             self.types.append("Dense" if dense else "Hash")
             self.sizes.append(n if dense else T)
@@ -44,7 +52,7 @@ class LoTD4Config:
         m = _lib.Lotd4Meta()
         m.num_levels = self.num_levels
         for l in range(self.num_levels):
-            m.res_xyz[l], m.res_w[l] = self.res_xyz[l], self.res_w[l]
+            m.res_xyz[l], m.res_y[l], m.res_z[l], m.res_w[l] = self.res3[l][0], self.res3[l][1], self.res3[l][2], self.res_w[l]
             m.type[l] = 0 if self.types[l] == "Dense" else 1
             m.size[l], m.offset[l] = self.sizes[l], self.offsets[l]
         self.meta = m
@@ -125,7 +133,8 @@ class LoTDNeRFDistantModel(nn.Module):
     def __init__(self, aabb: torch.Tensor = None, precision: str = "fp16", radius_scale_min: float = 1.0,
                  radius_scale_max: float = 1000.0, max_steps: int = 64, include_inf_distance: bool = True,
                  use_view_dirs: bool = True, lotd_auto_compute_cfg: dict = None, param_bound: float = 1e-4,
-                 seed: int = 7, device=None, ray_query_cfg: dict = None, **reference_params):
+                 seed: int = 7, device=None, ray_query_cfg: dict = None, lotd_use_cuboid: bool = False,
+                 **reference_params):
         """``include_inf_distance`` / ``radiance_decoder_cfg.use_view_dirs``: true / true in the object-centric configs
         (lotd_neus.dtu.230814.yaml:221-236), false / false in the street config, which has a sky model and feeds the
         radiance net features + appearance only (withmask_withlidar_joint.240219.yaml:281-294).  The street config's
@@ -140,10 +149,21 @@ class LoTDNeRFDistantModel(nn.Module):
             LoTDNeRFDistantModel.__init__(self, aabb=aabb, seed=seed, device=device, **kw)
             return
         super().__init__()
+        self._ctor = dict(precision=precision, radius_scale_min=radius_scale_min, radius_scale_max=radius_scale_max,
+                          max_steps=max_steps, include_inf_distance=include_inf_distance, use_view_dirs=use_view_dirs,
+                          lotd_auto_compute_cfg=lotd_auto_compute_cfg, param_bound=param_bound, seed=seed,
+                          ray_query_cfg=ray_query_cfg, lotd_use_cuboid=lotd_use_cuboid)
+        self.lotd_use_cuboid = bool(lotd_use_cuboid)
         self.include_inf, self.use_view_dirs = bool(include_inf_distance), bool(use_view_dirs)
         c = dict(lotd_auto_compute_cfg or {})
+        aspect = None
+        if self.lotd_use_cuboid and aabb is not None:
+            ext = (torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3)[1]
+                   - torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3)[0]).tolist()
+            if max(ext) / min(ext) > 1.0 + 1e-6:
+                aspect = ext
         self.cfg = LoTD4Config(c.get("target_num_params", 8 * 2 ** 20), c.get("min_res_xyz", 8), c.get("min_res_w", 4),
-                               c.get("log2_hashmap_size", 19), c.get("per_level_scale", 1.382))
+                               c.get("log2_hashmap_size", 19), c.get("per_level_scale", 1.382), aspect=aspect)
         F = self.cfg.out_features
         g = torch.Generator().manual_seed(seed)
         p = ((torch.rand(self.cfg.n_params, generator=g) * 2 - 1) * param_bound).half().float()
@@ -180,7 +200,17 @@ class LoTDNeRFDistantModel(nn.Module):
         """The reference hands the close-range object's AABB over at populate time (``populate_cfg.cr_obj_classname``,
         lotd_neus.dtu.230814.yaml:239-241; app/models/single/nerf.py:145-196)."""
         if aabb is not None:
-            self.aabb.copy_(torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3))
+            a = torch.as_tensor(aabb, dtype=torch.float32).reshape(2, 3).cpu()
+            ext = (a[1] - a[0]).tolist()
+            cur = (self.aabb[1] - self.aabb[0]).cpu().tolist()
+            same_shape = all(abs(e / min(ext) - c / min(cur)) < 1e-6 for e, c in zip(ext, cur))
+            if self.lotd_use_cuboid and not same_shape:
+                # per-axis pyramid: the table is sized from the AABB's aspect, which is only known now
+                dev = device if device is not None else self.den_w.device
+                LoTDNeRFDistantModel.__init__(self, aabb=a, **self._ctor)
+                device = dev
+            else:
+                self.aabb.copy_(a.to(self.aabb.device))
         if device is not None:
             self.to(device)
         return self

@@ -218,6 +218,7 @@ def distant_native_kwargs(params: dict) -> Dict:
     kw["lotd_auto_compute_cfg"] = {k: ac[k] for k in ("target_num_params", "min_res_xyz", "min_res_w", "log2_hashmap_size",
                                                       "per_level_scale") if k in ac}
     kw["param_bound"] = float((enc.get("param_init_cfg") or {}).get("bound", 1e-4))
+    kw["lotd_use_cuboid"] = bool(enc.get("lotd_use_cuboid", False))
     if (p.get("extra_pos_embed_cfg") or {}).get("type", "identity") != "identity":
         _unsupported("extra_pos_embed_cfg.type", p["extra_pos_embed_cfg"]["type"], "identity")
     dd = dict(p.get("density_decoder_cfg") or {})

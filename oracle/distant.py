@@ -43,31 +43,43 @@ class LoTD4Spec:
     n_params: int
     hashmap_size: int
     n_feats: int = 2
+    res3: List[List[int]] = None        # per-axis (x, y, z) vertex counts (``lotd_use_cuboid``); None = cubic res_xyz
 
     @property
     def num_levels(self):
         return len(self.res_xyz)
 
+    def res_of(self, l: int):
+        """(Rx, Ry, Rz, Rw) of level l."""
+        r3 = self.res3[l] if self.res3 is not None else [self.res_xyz[l]] * 3
+        return [*r3, self.res_w[l]]
+
 
 def make_ngp4d_spec(target_num_params=8 * 2 ** 20, min_res_xyz=8, min_res_w=4, n_feats=2, log2_hashmap_size=19,
-                    per_level_scale=1.382, max_levels=16) -> LoTD4Spec:
+                    per_level_scale=1.382, max_levels=16, aspect=None) -> LoTD4Spec:
+    """``aspect`` = the AABB's (x, y, z) extents for ``lotd_use_cuboid: true``
+    (withmask_withlidar_joint.240219.yaml:256): the shortest axis gets the ``min_res_xyz`` progression, the others are
+    stretched by their extent ratio (same convention as the 3-D pyramid, oracle/lotd.py cuboid_ngp_res)."""
     T = 2 ** log2_hashmap_size
-    rx, rw, types, sizes, offs = [], [], [], [], []
+    rx, rw, types, sizes, offs, r3 = [], [], [], [], [], []
     off = 0
+    asp = [1.0, 1.0, 1.0] if aspect is None else [float(a) / min(float(b) for b in aspect) for a in aspect]
     for l in range(max_levels):
         Rx = int(math.ceil(min_res_xyz * per_level_scale ** l - 1e-6))
         Rw = int(math.ceil(min_res_w * per_level_scale ** l - 1e-6))
-        n = Rx ** 3 * Rw
+        R3 = [int(math.ceil(min_res_xyz * per_level_scale ** l * a - 1e-6)) for a in asp]
+        n = R3[0] * R3[1] * R3[2] * Rw
         dense = n <= T
         rx.append(Rx)
         rw.append(Rw)
+        r3.append(R3)
         types.append('Dense' if dense else 'Hash')
         sizes.append(n if dense else T)
         offs.append(off)
         off += sizes[-1] * n_feats
         if off >= target_num_params:
             break
-    return LoTD4Spec(rx, rw, types, sizes, offs, off, T, n_feats)
+    return LoTD4Spec(rx, rw, types, sizes, offs, off, T, n_feats, None if aspect is None else r3)
 
 
 def lotd4_forward(u: torch.Tensor, params: torch.Tensor, spec: LoTD4Spec) -> torch.Tensor:
@@ -77,13 +89,14 @@ def lotd4_forward(u: torch.Tensor, params: torch.Tensor, spec: LoTD4Spec) -> tor
     outs = []
     m = 0xFFFFFFFF
     for l in range(spec.num_levels):
-        R = torch.tensor([spec.res_xyz[l]] * 3 + [spec.res_w[l]], dtype=torch.float32)
+        R4 = spec.res_of(l)
+        R = torch.tensor(R4, dtype=torch.float32)
         pos = u * (R - 1.0)
         c0 = torch.minimum(torch.floor(pos.detach()).clamp_min(0), R - 2.0).long()
         w = pos - c0.to(pos.dtype)
         table = p32[spec.offsets[l]: spec.offsets[l] + spec.sizes[l] * 2].view(-1, 2)
         feat = u.new_zeros([S, 2])
-        Rx = spec.res_xyz[l]
+        Rx, Ry, Rz = R4[0], R4[1], R4[2]
         for corner in range(16):
             d = [(corner >> a) & 1 for a in range(4)]
             wt = torch.ones(S)
@@ -91,7 +104,7 @@ def lotd4_forward(u: torch.Tensor, params: torch.Tensor, spec: LoTD4Spec) -> tor
                 wt = wt * (w[:, a] if d[a] else 1.0 - w[:, a])
             c = [c0[:, a] + d[a] for a in range(4)]
             if spec.types[l] == 'Dense':
-                idx = c[0] + Rx * (c[1] + Rx * (c[2] + Rx * c[3]))
+                idx = c[0] + Rx * (c[1] + Ry * (c[2] + Rz * c[3]))
             else:
                 idx = ((c[0] * PRIMES4[0]) & m) ^ ((c[1] * PRIMES4[1]) & m) ^ ((c[2] * PRIMES4[2]) & m) ^ ((c[3] * PRIMES4[3]) & m)
                 idx = idx % spec.hashmap_size

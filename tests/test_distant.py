@@ -77,6 +77,53 @@ def test_distant_model_parity(backend, precision, street):
     assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < gtol
 
 
+def test_distant_cuboid_pyramid_parity(backend):
+    """``lotd_use_cuboid: true`` on an elongated AABB (street config, withmask_withlidar_joint.240219.yaml:256): per-axis
+    vertex counts of the 4-D pyramid -- values and table gradient against the oracle; a cubic AABB keeps cubic levels."""
+    from neuralsim_amd.fields.nerf_distant import LoTDNeRFDistantModel
+    aabb = torch.tensor([[-2.0, -1.0, -0.5], [2.0, 1.0, 0.5]])
+    auto = dict(target_num_params=2 ** 15, min_res_xyz=3, min_res_w=2, log2_hashmap_size=11, per_level_scale=1.382)
+    spec = od.make_ngp4d_spec(target_num_params=2 ** 15, min_res_xyz=3, min_res_w=2, log2_hashmap_size=11,
+                              aspect=[4.0, 2.0, 1.0])
+    assert spec.res3[0] == [12, 6, 3] and "Dense" in spec.types and "Hash" in spec.types
+    p = od.make_distant_params(spec, grid_bound=0.5, use_view_dirs=False)
+    p.requires_grad_(True)
+    m = LoTDNeRFDistantModel(aabb=aabb, precision="f32", max_steps=8, include_inf_distance=False, use_view_dirs=False,
+                             lotd_auto_compute_cfg=auto, lotd_use_cuboid=True)
+    assert m.cfg.res3 == spec.res3 and m.cfg.n_params == spec.n_params and m.cfg.types == spec.types
+    cube = LoTDNeRFDistantModel(aabb=AABB, precision="f32", max_steps=8, lotd_auto_compute_cfg=auto, lotd_use_cuboid=True)
+    assert not cube.cfg.cuboid and cube.cfg.res3[0] == [3, 3, 3]
+    # the reference hands the AABB over at populate time: the table is re-sized there
+    late = LoTDNeRFDistantModel(precision="f32", max_steps=8, include_inf_distance=False, use_view_dirs=False,
+                                lotd_auto_compute_cfg=auto, lotd_use_cuboid=True).populate(aabb=aabb)
+    assert late.cfg.res3 == spec.res3 and torch.equal(late.aabb, aabb)
+    with torch.no_grad():
+        m.flattened_params.copy_(p.grid)
+        m.den_w.copy_(torch.cat([w.reshape(-1) for w in p.den_w]))
+        m.den_b.copy_(torch.cat([b.reshape(-1) for b in p.den_b]))
+        m.rad_w.copy_(torch.cat([w.reshape(-1) for w in p.rad_w]))
+        m.rad_b.copy_(torch.cat([b.reshape(-1) for b in p.rad_b]))
+    m = m.to(backend)
+    g = torch.Generator().manual_seed(4)
+    N, K = 19, 8
+    o = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([3.0, 1.5, 0.8])
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    near = torch.full([N], 0.01)
+    ha = torch.randn(N, 4, generator=g) * 0.3
+    vbo = od.distant_ray_query(p, o, d, near, ha, aabb[0], aabb[1], K=K, include_inf=False)
+    dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+    ret = m.ray_query(ray_tested=dict(rays_o=dv(o), rays_d=dv(d), near=dv(near), rays_h_appear=dv(ha)), config={})
+    vb = ret["volume_buffer"]
+    v = vbo["valid"]
+    assert torch.equal(vb["valid"].cpu().bool(), v) and float(v.float().mean()) > 0.5
+    assert (vb["sigma"].cpu() - vbo["sigma"])[v].abs().max() < 3e-5 * (1 + float(vbo["sigma"].detach().max()))
+    assert (vb["rgb"].cpu() - vbo["rgb"])[v].abs().max() < 3e-5
+    w = torch.randn(N, K, generator=g)
+    (vbo["sigma"] * w * v).sum().backward()
+    (vb["sigma"] * dv(w) * dv(v)).sum().backward()
+    assert rel_l2(m.flattened_params.grad.cpu(), p.grid.grad) < 3e-4
+
+
 def test_ngp4d_levels_match_config():
     """lotd_neus.dtu.230814.yaml:193-200: 8 Mi target -> 12 levels (5 dense + 7 hashed), 24 features."""
     from neuralsim_amd.fields.nerf_distant import LoTD4Config

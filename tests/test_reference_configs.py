@@ -105,6 +105,7 @@ def test_street_block_is_built_at_populate(backend):
     d = LoTDNeRFDistantModel(**dp, device=backend).populate(aabb=aabb, device=backend)
     assert d.include_inf is False and d.use_view_dirs is False and d.K == c.distant_nsample
     assert torch.equal(d.aabb.cpu(), aabb)
+    assert d.cfg.cuboid and d.cfg.res3[0] == [23, 8, 3]                   # lotd_use_cuboid: per-axis 4-D pyramid (120:40:16)
     sky = SimpleSky(**c.assetbank_cfg.Sky.model_params.to_dict(), device=backend)
     assert sky.n_frequencies == 10 and sky.n_appear == 4
 
