@@ -170,10 +170,14 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         ``rays_bidx [R]`` (index into the compacted list of items that were hit at all), ``full_bidx_map [B'']``
         (compact -> full), ``num_rays``, ``near``, ``far`` and the filtered inputs."""
         Bq, N = rays_o.shape[0], rays_o.shape[1]
-        flat = super().ray_test(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), near=near, far=far)
-        pair = flat["rays_inds"]
-        full_bidx = torch.div(pair, N, rounding_mode="floor")
-        rinds = pair - full_bidx * N
+        # RAY-major pair order (ray index ascending, the items of one ray consecutive): the renderer regroups the packs
+        # of a ray that crosses several items with ``unique_consecutive`` and relies on exactly this order
+        # (buffer_compose_renderer.py:347-368, "[!!!] Requires ridx to be consecutive and monotonically increasing").
+        flat = super().ray_test(rays_o.transpose(0, 1).reshape(-1, 3), rays_d.transpose(0, 1).reshape(-1, 3), near=near,
+                                far=far)
+        pair = flat["rays_inds"]                                     # = ray * Bq + item
+        rinds = torch.div(pair, Bq, rounding_mode="floor")
+        full_bidx = pair - rinds * Bq
         if compact_batch:
             full_bidx_map, bidx = torch.unique(full_bidx, return_inverse=True)      # sorted: order of items kept
         else:
@@ -183,7 +187,7 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
                    far=flat["far"])
         for k, v in extra.items():
             if isinstance(v, torch.Tensor) and v.shape[:2] == (Bq, N):
-                vf = v.reshape(Bq * N, *v.shape[2:])
+                vf = v.transpose(0, 1).reshape(N * Bq, *v.shape[2:])
                 if vf.requires_grad and vf.dim() == 2 and vf.dtype == torch.float32:
                     from ..losses import embedding_lookup
                     ret[k] = embedding_lookup(vf, pair)

@@ -12,8 +12,8 @@ path:
 
 There is no Scene graph in this repository (harness, out of scope): drawables are passed explicitly as
 ``Drawable(id, class_name, model, rotation [3,3], translation [3], scale)`` -- the object-to-world transform of the
-frame being rendered.  Not mirrored: per-object / per-class re-renderings and the segmentation z-buffer (:276-311,
-:729-806), which are evaluation outputs, not part of the training step.
+frame being rendered.  ``render_per_class_in_scene`` / ``render_per_obj_in_scene`` (:729-806) are mirrored; not
+mirrored: ``render_per_obj_individual`` and its segmentation z-buffer (:276-311), which are evaluation outputs.
 """
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -61,7 +61,11 @@ class BufferComposeRenderer(nn.Module):
     def ray_query(self, rays_o: torch.Tensor, rays_d: torch.Tensor, *, drawables: List[Drawable],
                   rays_h_appear: torch.Tensor = None, near=None, far=None, with_rgb: bool = None,
                   with_normal: bool = None, sky_model=None, return_buffer=False, return_details=False,
-                  bypass_ray_query_cfg: Dict[str, dict] = None) -> Dict:
+                  bypass_ray_query_cfg: Dict[str, dict] = None, render_per_obj_in_scene: bool = False,
+                  render_per_class_in_scene: bool = False) -> Dict:
+        """``render_per_class_in_scene`` / ``render_per_obj_in_scene``: every class's / object's share of the JOINT
+        rendering -- its samples weighted by ``vw_in_total`` (reference :729-806; the per-class masks feed the
+        importance sampler of code_multi/tools/train.py:589-592, the per-object images the mono / manhattan losses)."""
         assert rays_o.dim() == rays_d.dim() == 2
         cfgd = self.config
         with_rgb = cfgd.get("with_rgb", True) if with_rgb is None else with_rgb
@@ -120,8 +124,16 @@ class BufferComposeRenderer(nn.Module):
             vb = raw["volume_buffer"]
             if vb["type"] == "empty":
                 continue
-            vb["rays_inds_collect"], vb["pack_infos_collect"] = vb["rays_inds_hit"], vb["pack_infos_hit"]
-            ray_visible_samples.index_add_(0, vb["rays_inds_hit"], vb["pack_infos_hit"][:, 1])
+            rih, n_hit = vb["rays_inds_hit"], vb["pack_infos_hit"][:, 1]
+            # a ray that crosses several items of a batched model owns several consecutive packs: regroup them into
+            # ONE pack per ray for the collect step (reference :347-368)
+            ric, dup = torch.unique_consecutive(rih, return_counts=True)
+            if ric.shape[0] != rih.shape[0]:
+                n_col = torch.zeros([N], dtype=torch.long, device=dev).index_add_(0, rih, n_hit)[ric]
+                vb["rays_inds_collect"], vb["pack_infos_collect"] = ric, po.get_pack_infos_from_n(n_col)
+            else:
+                vb["rays_inds_collect"], vb["pack_infos_collect"] = rih, vb["pack_infos_hit"]
+            ray_visible_samples.index_add_(0, rih, n_hit)
 
         total_volume_buffer = dict(type="empty")
         total_rays_inds_hit = ray_visible_samples.nonzero()[:, 0]
@@ -173,6 +185,58 @@ class BufferComposeRenderer(nn.Module):
                 vb = raw["volume_buffer"]
                 if vb["type"] != "empty":
                     vb["vw_in_total"] = out["vw"][ranks[vb["pidx_in_total"]]]
+        norm_depth = cfgd.get("depth_use_normalized_vw", True)
+
+        def share(vb, pack_infos):
+            """Per-pack sums of one object buffer weighted by its vw_in_total -> dict of [P(,3)]."""
+            vw = vb["vw_in_total"].reshape(-1)
+            out_ = dict(mask_volume=po.packed_sum(vw, pack_infos), depth_volume=po.packed_sum(vw * vb["t"].flatten(), pack_infos))
+            if with_rgb:
+                out_["rgb_volume"] = po.packed_sum(vw[:, None] * vb["rgb"].flatten(0, -2), pack_infos)
+            if with_normal and "nablas_in_world" in vb:
+                out_["normals_volume"] = po.packed_sum(vw[:, None] * vb["nablas_in_world"].flatten(0, -2), pack_infos)
+            return out_
+        rendered_per_class, rendered_per_obj = {}, {}
+        if render_per_class_in_scene:
+            for dr in drawables:
+                rendered_per_class.setdefault(dr.class_name, prepare_empty_rendered([N], dev, with_rgb=with_rgb,
+                                                                                    with_normal=with_normal))
+            if sky_model is not None:
+                rendered_per_class["Sky"] = prepare_empty_rendered([N], dev, with_rgb=with_rgb, with_normal=with_normal)
+            for raw in raw_per_obj_model.values():
+                vb = raw["volume_buffer"]
+                if vb["type"] == "empty" or "vw_in_total" not in vb:
+                    continue
+                tgt = rendered_per_class[raw["class_name"]]
+                for k, v in share(vb, vb["pack_infos_collect"]).items():      # index_add: several objects per class
+                    tgt[k] = tgt[k].index_add(0, vb["rays_inds_collect"], v)
+            if norm_depth:
+                for v in rendered_per_class.values():
+                    v["depth_volume"] = v["depth_volume"] / (v["mask_volume"] + 1e-10)
+        if render_per_obj_in_scene:
+            for dr in drawables:
+                rendered_per_obj[dr.id] = prepare_empty_rendered([N], dev, with_rgb=with_rgb, with_normal=with_normal)
+            for raw in raw_per_obj_model.values():
+                vb = raw["volume_buffer"]
+                if vb["type"] == "empty" or "vw_in_total" not in vb:
+                    continue
+                sh = share(vb, vb["pack_infos_hit"])
+                if isinstance(raw["obj_id"], list):             # batched model: one image per item of the batch
+                    ids = raw["obj_id"]
+                    cur = prepare_empty_rendered([len(ids), N], dev, with_rgb=with_rgb, with_normal=with_normal)
+                    where = (vb["rays_full_bidx_hit"], vb["rays_inds_hit"])
+                    for k, v in sh.items():
+                        cur[k] = cur[k].index_put(where, v)
+                    if norm_depth:
+                        cur["depth_volume"] = cur["depth_volume"] / (cur["mask_volume"] + 1e-10)
+                    for i, oid in enumerate(ids):
+                        rendered_per_obj[oid] = {k: v[i] for k, v in cur.items()}
+                else:
+                    cur = rendered_per_obj[raw["obj_id"]]
+                    for k, v in sh.items():
+                        cur[k] = cur[k].index_put((vb["rays_inds_hit"],), v)
+                    if norm_depth:
+                        cur["depth_volume"] = cur["depth_volume"] / (cur["mask_volume"] + 1e-10)
         if with_rgb:
             total_rendered["rgb_volume_occupied"] = total_rendered["rgb_volume"]
             if sky_model is not None and cfgd.get("with_env", True):
@@ -180,7 +244,14 @@ class BufferComposeRenderer(nn.Module):
                 total_rendered["rgb_sky"] = env
                 total_rendered["rgb_volume_non_occupied"] = blend = (1.0 - total_rendered["mask_volume"][..., None]) * env
                 total_rendered["rgb_volume"] = total_rendered["rgb_volume"] + blend
+                if render_per_class_in_scene:                   # reference :821-823
+                    rendered_per_class["Sky"]["rgb_volume"] = blend
+                    rendered_per_class["Sky"]["mask_volume"] = 1 - total_rendered["mask_volume"]
         ret = dict(rendered=total_rendered, ray_intersections=dict(samples_cnt=ray_visible_samples))
+        if render_per_class_in_scene:
+            ret["rendered_per_class_in_scene"] = rendered_per_class
+        if render_per_obj_in_scene:
+            ret["rendered_per_obj_in_scene"] = rendered_per_obj
         if return_buffer:
             ret["volume_buffer"] = total_volume_buffer
         if return_details:

@@ -34,11 +34,14 @@ def build(device):
         sky.w.copy_(torch.cat([w.reshape(-1) for w in ws]).to(device))
         sky.b.copy_(torch.cat(bs).to(device))
     dv = lambda a: a.to(device).contiguous()         # noqa: E731
-    poses = {"car2": (_rot_y(0.6), torch.tensor([0.9, 0.1, 0.3]), 0.45),
-             "car1": (_rot_y(0.2), torch.tensor([0.0, 40.0, 0.0]), 0.4),          # far outside every ray: never hit
-             "car0": (_rot_y(-0.9), torch.tensor([-0.8, -0.1, 0.5]), 0.4)}
-    poses = {k: (dv(R), dv(t), s) for k, (R, t, s) in poses.items()}
     intr, c2w, WH = look_at_cameras(V=2, seed=4, H=14, W=14, f=9.0)
+    eye, fwd = c2w[0, :3, 3], c2w[0, :3, 2]
+    # car2 and car0 sit one behind the other on the optical axis of camera 0: the central rays cross BOTH items, i.e.
+    # the batched buffer holds two consecutive packs for those rays
+    poses = {"car2": (_rot_y(0.6), eye + 2.0 * fwd, 0.3),
+             "car1": (_rot_y(0.2), torch.tensor([0.0, 40.0, 0.0]), 0.4),          # far outside every ray: never hit
+             "car0": (_rot_y(-0.9), eye + 3.2 * fwd, 0.45)}
+    poses = {k: (dv(R), dv(t), s) for k, (R, t, s) in poses.items()}
     o, d = orr.pinhole_rays(all_pixel_xy(14, 14, torch.device("cpu")), torch.zeros(196, dtype=torch.long), intr, c2w, WH)
     N = o.shape[0]
     g = torch.Generator().manual_seed(3)
@@ -57,14 +60,18 @@ def _finish(sc, ret, vehicle_ids):
             p.grad = None
     ((r["rgb_volume"] * sc["w_rgb"]).sum() + (r["normals_volume"] * sc["w_nrm"]).sum()
      + (r["depth_volume"] * sc["w_depth"]).sum()).backward()
-    c = lambda t: t.detach().cpu().clone()          # noqa: E731
+    c = c_ = lambda t: t.detach().cpu().clone()          # noqa: E731
     vb = ret["volume_buffer"]
     return dict(rendered={k: c(v) for k, v in r.items()}, samples_cnt=c(ret["ray_intersections"]["samples_cnt"]),
                 volume_buffer={k: c(vb[k]) for k in ("pack_infos_hit", "t", "opacity_alpha", "rgb", "vw")},
                 vw_in_total={k: c(ret["raw_per_obj_model"][k]["volume_buffer"]["vw_in_total"]).flatten()
                              for k in ("main", "Vehicle")},
                 grads={f"{n}.{k}": c(p.grad) for n, m in models for k, p in m.named_parameters() if p.grad is not None},
-                vehicle_ids=list(vehicle_ids))
+                per_class={c: {k: c_(v) for k, v in r_.items()} for c, r_ in ret.get("rendered_per_class_in_scene", {}).items()},
+                per_obj={o: {k: c_(v) for k, v in r_.items()} for o, r_ in ret.get("rendered_per_obj_in_scene", {}).items()},
+                vehicle_ids=list(vehicle_ids),
+                rays_crossing_two_items=int((torch.unique_consecutive(
+                    ret["raw_per_obj_model"]["Vehicle"]["volume_buffer"]["rays_inds_hit"], return_counts=True)[1] > 1).sum()))
 
 
 def run_reference(mods, sc):
@@ -86,7 +93,8 @@ def run_reference(mods, sc):
     rr.train()
     obs = type("Camera", (mods["classes"]["Camera"], ref_glue.FakeObserver), {})("cam0")
     ret = rr.ray_query(sc["rays_o"], sc["rays_d"], rays_ts=torch.zeros(sc["N"], device=dev), scene=scene, observer=obs,
-                       return_buffer=True, return_details=True)
+                       return_buffer=True, return_details=True, render_per_class_in_scene=True,
+                       render_per_obj_in_scene=True)
     return _finish(sc, ret, ret["raw_per_obj_model"]["Vehicle"]["obj_id"])
 
 
@@ -96,7 +104,7 @@ def run_mirror(sc):
         [Drawable(k, "Vehicle", sc["vehicle"], rotation=R, translation=t, scale=s) for k, (R, t, s) in sc["poses"].items()]
     mine = BufferComposeRenderer(sc["common"]).train()
     ret = mine(sc["rays_o"], sc["rays_d"], drawables=drawables, rays_h_appear=sc["h_appear"], sky_model=sc["sky"],
-               return_buffer=True, return_details=True)
+               return_buffer=True, return_details=True, render_per_class_in_scene=True, render_per_obj_in_scene=True)
     vb = ret["raw_per_obj_model"]["Vehicle"]["volume_buffer"]
     ids = list(sc["poses"])
     hit = sorted(set(vb["rays_full_bidx_hit"].tolist()))

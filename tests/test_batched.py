@@ -86,21 +86,28 @@ def test_batched_query_matches_per_instance_oracle(backend, compressed):
         outs.append(r)
         n_hit.append(r["num_rays"])
     assert bt["num_rays"] == sum(n_hit)
-    assert torch.equal(bt["rays_inds"].cpu(), torch.cat([r["rays_inds"] for r in outs]))
-    assert torch.equal(bt["rays_full_bidx"].cpu(), torch.cat([torch.full([n], k) for k, n in enumerate(n_hit)]))
+    # the pairs come RAY-major (ray ascending, the items of a ray consecutive: what the compose renderer's
+    # unique_consecutive regrouping needs); ``perm`` takes the oracle's item-major concatenation there
+    ray_cat = torch.cat([r["rays_inds"] for r in outs])
+    item_cat = torch.cat([torch.full([n], k) for k, n in enumerate(n_hit)])
+    perm = torch.argsort(ray_cat * len(cond) + item_cat)
+    assert torch.equal(bt["rays_inds"].cpu(), ray_cat[perm]) and torch.equal(bt["rays_full_bidx"].cpu(), item_cat[perm])
+    assert bool((bt["rays_inds"][1:] >= bt["rays_inds"][:-1]).all())
     assert torch.equal(bt["full_bidx_map"].cpu(), torch.arange(len(cond))) and torch.equal(bt["rays_bidx"], bt["rays_full_bidx"])
-    assert torch.equal(ret["details"]["march_counts"].cpu(), torch.cat([r["debug"]["march_counts"] for r in outs]))
+    assert torch.equal(ret["details"]["march_counts"].cpu(), torch.cat([r["debug"]["march_counts"] for r in outs])[perm])
     n_o = torch.cat([r["volume_buffer"]["pack_infos_hit"][:, 1] for r in outs])
-    assert torch.equal(vb["pack_infos_hit"][:, 1].cpu(), n_o)
-    assert (vb["t"].cpu() - torch.cat([r["volume_buffer"]["t"] for r in outs])).abs().max() < 3e-4   # f32 up-sampler noise (1e-7 sdf x inv_s 1024)
+    assert torch.equal(vb["pack_infos_hit"][:, 1].cpu(), n_o[perm])
+    pi_o = opo_get(n_o)
+    samp = torch.cat([torch.arange(int(pi_o[k, 0]), int(pi_o[k, 0] + pi_o[k, 1])) for k in perm.tolist()])   # sample permutation
+    assert (vb["t"].cpu() - torch.cat([r["volume_buffer"]["t"] for r in outs])[samp]).abs().max() < 3e-4   # f32 up-sampler noise (1e-7 sdf x inv_s 1024)
     for key in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
-        ref = torch.cat([r["rendered"][key] for r in outs])
+        ref = torch.cat([r["rendered"][key] for r in outs])[perm]
         assert (ret["rendered"][key].detach().cpu() - ref.detach()).abs().max() < 6e-4, key
     # the two items really differ (different instances, different radii)
     assert (outs[0]["rendered"]["depth_volume"].mean() - outs[1]["rendered"]["depth_volume"].mean()).abs() > 1e-2
     # loss + backward: per-instance table gradients land in that instance's slice, decoder gradients add up
-    wgt = torch.rand(bt["num_rays"], 3, generator=g)
-    loss = (ret["rendered"]["rgb_volume"] * dv(wgt)).sum() + 0.1 * ((vb["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
+    wgt = torch.rand(bt["num_rays"], 3, generator=g)            # indexed in the oracle's item-major order
+    loss = (ret["rendered"]["rgb_volume"] * dv(wgt[perm])).sum() + 0.1 * ((vb["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
     loss.backward()
     off = 0
     for r in outs:
@@ -121,6 +128,11 @@ def test_batched_query_matches_per_instance_oracle(backend, compressed):
     assert rel_l2(m.rad_w.grad.cpu(), torch.cat([w.grad.reshape(-1) for w in p0.rad_w])) < 5e-3
     m.clean_condition()
     assert m.ins_inds_per_batch is None
+
+
+def opo_get(n):
+    from oracle import pack_ops as opo
+    return opo.get_pack_infos_from_n(n)
 
 
 def test_batched_point_queries_and_occupancy(backend):

@@ -227,6 +227,7 @@ def test_reference_compose_renderer_runs_on_the_mirror(backend):
 def _compare_compose(got, ref, tol, gtol, btol=None):
     assert torch.equal(got["samples_cnt"], ref["samples_cnt"]) and int((ref["samples_cnt"] > 0).sum()) > 20
     assert ref["vehicle_ids"] == ["car2", "car0"]                         # car1 is never hit: compacted away
+    assert ref["rays_crossing_two_items"] > 3                             # several rays own two consecutive vehicle packs
     for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume", "rgb_volume_occupied", "rgb_sky",
               "rgb_volume_non_occupied"):
         _cmp(got["rendered"][k], ref["rendered"][k], tol, k)
@@ -235,6 +236,14 @@ def _compare_compose(got, ref, tol, gtol, btol=None):
         _cmp(got["volume_buffer"][k], ref["volume_buffer"][k], btol or tol, f"volume_buffer.{k}")
     for key in ("main", "Vehicle"):
         _cmp(got["vw_in_total"][key], ref["vw_in_total"][key], btol or tol, f"vw_in_total.{key}")
+    # every class's / object's share of the joint rendering (reference :729-806, :821-823)
+    assert set(ref["per_class"]) == set(got["per_class"]) == {"Main", "Vehicle", "Sky"}
+    assert set(ref["per_obj"]) <= set(got["per_obj"]) and {"main", "car0", "car1", "car2"} <= set(ref["per_obj"])
+    for grp in ("per_class", "per_obj"):
+        for name, imgs in ref[grp].items():
+            for k, v in imgs.items():
+                _cmp(got[grp][name][k], v, btol or tol, f"{grp}.{name}.{k}")
+    assert float(ref["per_obj"]["car2"]["mask_volume"].max()) > 0.05 and float(ref["per_obj"]["car1"]["mask_volume"].max()) == 0.0
     assert set(got["grads"]) >= set(ref["grads"])
     for k, gr in ref["grads"].items():
         mine = got["grads"][k]
