@@ -306,3 +306,42 @@ def test_reference_eikonal_loss_on_the_mirror(backend):
     model.encoding.flattened_params.grad = None
     sum(losses.values()).backward()
     assert float(model.encoding.flattened_params.grad.abs().sum()) > 0
+
+
+@needs_reference
+def test_reference_render_chunked_through_the_shim_batchify_query(backend):
+    """The reference's top-level ``SingleVolumeRenderer.render`` (:495-581) in eval mode with a ``rayschunk`` smaller
+    than the batch: it splits the rays with ``nr3d_lib.models.utils.batchify_query`` -- the SHIM's implementation --
+    and concatenates the nested result dicts; compared with one un-chunked query and with the mirror's chunked
+    ``render`` ([H, W] prefix shape restored)."""
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    sc = build_scenario("main_distant_eval", backend)
+    H, W = 4, 9
+    o, d = sc["rays_o"].view(H, W, 3), sc["rays_d"].view(H, W, 3)
+    ts = torch.zeros(H, W, device=backend)
+    with ref_glue.reference_renderer_modules() as mods:
+        scene = ref_glue.FakeScene(backend, image_embeddings=ref_glue.FixedEmbeddings(None),
+                                   convert_rays_in_node=mods.get("convert_rays_in_node"))
+        # per-chunk appearance rows: the embedding is looked up from the chunk's rays_ts
+        scene.image_embeddings = type("E", (), {"__getitem__": lambda self, k: (
+            lambda rays_ts, mode="interp": sc["h_appear"][:1].expand(rays_ts.shape[0], -1))})()
+        scene.add(ref_glue.FakeNode(sc["model"], "Main", "main"))
+        scene.add(ref_glue.FakeNode(sc["distant_model"], "Distant", "distant"))
+        r = ref_glue.make_reference_renderer(mods, sc["common"], val=dict(rayschunk=10), training=False)
+        cam = mods["classes"]["Camera"]("cam0")
+        cam.near = cam.far = None
+        scene.id, scene.observers = "scene0", {"cam0": cam}
+        scene.asset_bank = type("Bank", (), {"rendering_before_per_view": lambda self, **kw: [
+            m.rendering_before_per_view(kw["renderer"], kw["observer"]) for m in (sc["model"], )]})()
+        chunked = r.render(scene, rays=[o, d, ts], observer=cam, rayschunk=10)
+        whole = r.render(scene, rays=[o, d, ts], observer=cam, rayschunk=0)
+    for k in ("rgb_volume", "depth_volume", "mask_volume", "normals_volume"):
+        assert chunked["rendered"][k].shape[:2] == (H, W)
+        _cmp(chunked["rendered"][k].cpu(), whole["rendered"][k].cpu(), 1e-6, k)
+    _cmp(chunked["ray_intersections"]["samples_cnt"].cpu(), whole["ray_intersections"]["samples_cnt"].cpu(), 0, "samples_cnt")
+    mine = SingleVolumeRenderer(dict(sc["common"], rayschunk=10)).eval()
+    ha = sc["h_appear"][:1].expand(H * W, -1).contiguous().view(H, W, -1)
+    got = mine.render(sc["model"], rays=[o, d], rays_h_appear=ha, distant_model=sc["distant_model"])
+    for k in ("rgb_volume", "depth_volume", "mask_volume", "normals_volume"):
+        _cmp(got["rendered"][k].cpu(), chunked["rendered"][k].cpu(), 2e-5, f"mirror.{k}")
+    del cam
