@@ -16,10 +16,12 @@ __device__ __forceinline__ int64_t pack_wave_id() {
 static inline dim3 pack_grid(int64_t P) { return dim3(nsim_blocks(P, PACK_WAVES_PER_BLOCK)); }
 
 // ------------------------------------------------------------------------------ pack_infos_from_n
-// One workgroup of 16 waves; a thread prefetches PI_PER elements (stride = block size, coalesced) so that a whole
-// super-chunk of 8192 counts costs ONE memory round trip, then PI_PER block scans (wave scan + 16 wave totals).
+// One workgroup of 16 waves walks the counts in super-chunks of PI_THREADS * PI_PER = 8192.
 #define PI_THREADS 1024
 #define PI_PER 8
+// Blocked arrangement: thread t owns PI_PER CONSECUTIVE counts of the super-chunk, so a super-chunk of 8192 counts
+// needs one serial 8-element prefix per thread and ONE block scan (wave scan + 16 wave totals) instead of PI_PER of
+// them -- the 8192-ray batch of the training step is exactly one super-chunk.
 __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
                                                                     int64_t* __restrict__ pi,
                                                                     int64_t* __restrict__ total, int64_t cap) {
@@ -27,26 +29,28 @@ __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t*
   const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
   int64_t carry = 0;
   for (int64_t base = 0; base < P; base += (int64_t)PI_THREADS * PI_PER) {
+    const int64_t i0 = base + (int64_t)tid * PI_PER;
     int64_t v[PI_PER];
+    int64_t mine = 0;
 #pragma unroll
     for (int k = 0; k < PI_PER; ++k) {
-      const int64_t i = base + (int64_t)k * PI_THREADS + tid;
-      v[k] = i < P ? n[i] : 0;
+      v[k] = (i0 + k) < P ? n[i0 + k] : 0;
+      mine += v[k];
     }
+    const int64_t incl = wave_incl_sum(mine);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int64_t before = 0, chunk = 0;
+#pragma unroll
+    for (int w = 0; w < PI_THREADS / 64; ++w) {
+      const int64_t x = wtot[w];
+      before += (w < wave) ? x : 0;
+      chunk += x;
+    }
+    int64_t run = carry + before + incl - mine;
 #pragma unroll
     for (int k = 0; k < PI_PER; ++k) {
-      const int64_t i = base + (int64_t)k * PI_THREADS + tid;
-      const int64_t incl = wave_incl_sum(v[k]);
-      if (lane == 63) wtot[wave] = incl;
-      __syncthreads();
-      int64_t before = 0, chunk = 0;
-#pragma unroll
-      for (int w = 0; w < PI_THREADS / 64; ++w) {
-        const int64_t x = wtot[w];
-        before += (w < wave) ? x : 0;
-        chunk += x;
-      }
-      const int64_t run = carry + before + incl - v[k];
+      const int64_t i = i0 + k;
       if (i < P) {
         // cap >= 0: the caller sized its buffers speculatively; a pack that would end beyond cap is emptied and every
         // start stays <= cap, so that each consumer -- including those that append per-pack data at start + const * i
@@ -55,9 +59,10 @@ __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t*
         pi[2 * i] = (cap >= 0 && run > cap) ? cap : run;
         pi[2 * i + 1] = over ? 0 : v[k];
       }
-      carry += chunk;
-      __syncthreads();
+      run += v[k];
     }
+    carry += chunk;
+    __syncthreads();
   }
   if (tid == 0 && total) total[0] = carry;
 }
