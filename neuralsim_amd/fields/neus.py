@@ -362,13 +362,14 @@ class OccGridAccel(nn.Module):
         self.occ_val.zero_()
         self.update_from_net(query_sdf, **kw)
 
-    def cur_batch__step(self, it: int, query_sdf):
-        """``training_before_per_step`` hook (app/resources/asset_bank.py:291-298)."""
+    def cur_batch__step(self, it: int, query_sdf, generator=None):
+        """``training_before_per_step`` hook (app/resources/asset_bank.py:291-298).  ``generator``: a rank-shared
+        generator keeps data-parallel replicas of the grid identical."""
         if getattr(self, "_last_step_it", None) == it:      # trainer and model hook may both call in: once per iteration
             return
         self._last_step_it = it
         if it >= self.n_steps_warmup and it % self.n_steps_between_update == 0:
-            self.update_from_net(query_sdf)
+            self.update_from_net(query_sdf, generator=generator)
 
 
 # ---------------------------------------------------------------------------------------------- model
@@ -630,7 +631,7 @@ class LoTDNeuSModel(nn.Module):
         if post is not None:        # built from the reference's model_params: the model drives its own schedules
             if post.get("anneal") is not None:
                 self.anneal_levels(int(it), **post["anneal"])
-            self.accel.cur_batch__step(int(it), self.query_sdf)
+            self.accel.cur_batch__step(int(it), self.query_sdf, generator=getattr(self, "refresh_generator", None))
 
     def training_after_per_step(self, it: int, logger=None):
         """After ``optimizer.step`` (app/resources/asset_bank.py:300-308): nothing to do -- the fp16 table shadow and

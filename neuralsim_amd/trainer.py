@@ -398,8 +398,13 @@ class RenderTrainer:
         acc = model.accel
         if self.level_anneal is not None:
             model.anneal_levels(it, **self.level_anneal)
+        # a model built from the reference's model_params drives its own schedules in the hook (level annealing,
+        # occupancy refresh); it gets the rank-shared generator so that replicas refresh identically
+        self_driven = getattr(model, "_reference_post", None) is not None
+        if self_driven:
+            model.refresh_generator = self.gen_shared
         model.training_before_per_step(it)          # inv_s control (var_ctrl_cfg); a no-op unless set_var_ctrl() was called
-        if it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
+        if not self_driven and it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
         batch = None
         if self.pipeline:

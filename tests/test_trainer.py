@@ -86,3 +86,51 @@ def test_fused_step_equals_autograd_step(backend, variant):
     for a, b in zip(pa, pb):
         # float atomics commute only approximately and Adam normalises tiny gradients: a few 1e-6 after five steps
         assert torch.allclose(a, b, rtol=1e-4, atol=5e-5), float((a - b).abs().max())
+
+
+def test_model_built_from_reference_model_params_trains(backend):
+    """A model constructed from a reference-style ``model_params`` block (the dtu yaml's keys, a small pyramid) inside
+    the trainer: the model's own ``training_before_per_step`` drives level annealing, inv_s control and the occupancy
+    refresh (once per scheduled iteration, with the trainer's rank-shared generator), the fused step trains it."""
+    mp = dict(
+        dtype="half",
+        var_ctrl_cfg=dict(ln_inv_s_init=0.3, ln_inv_s_factor=10.0, ctrl_type="mix_linear", start_it=2, stop_it=6,
+                          final_inv_s=400.0),
+        cos_anneal_cfg=None, use_tcnn_backend=False,
+        surface_cfg=dict(bounding_size=2.0, clip_level_grad_ema_factor=0,
+                         encoding_cfg=dict(lotd_auto_compute_cfg=dict(type="gen_ngp", min_res=4, n_feats=2, log2_hashmap_size=10,
+                                                                      per_level_scale=1.382, num_levels=8, max_res=64),
+                                           anneal_cfg=dict(type="hardmask", start_it=0, start_level=2, stop_it=4),
+                                           param_init_cfg=dict(type="uniform_to_type", bound=1.0e-4)),
+                         decoder_cfg=dict(type="mlp", D=1, W=64, activation=dict(type="softplus", beta=100.0)),
+                         n_extra_feat_from_output=0, radius_init=0.5, geo_init_method="pretrain_after_zero_out"),
+        radiance_cfg=dict(use_pos=True, use_nablas=True, use_view_dirs=True, dir_embed_cfg=dict(type="spherical", degree=4),
+                          D=2, W=64, n_appear_embedding=4),
+        accel_cfg=dict(type="occ_grid", resolution=[16, 16, 16], occ_val_fn_cfg=dict(type="sdf", inv_s=256.0), occ_thre=0.3,
+                       ema_decay=0.95, init_cfg=dict(mode="from_net", num_steps=1, num_pts=4096),
+                       update_from_net_cfg=dict(num_steps=1, num_pts=2048), update_from_samples_cfg={},
+                       n_steps_between_update=2, n_steps_warmup=2),
+        ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed",
+                           query_param=dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4],
+                                            coarse_step_cfg=dict(step_mode="linear"),
+                                            march_cfg=dict(step_size=0.05, max_steps=128), upsample_inv_s=64.0,
+                                            upsample_inv_s_factors=[1, 4], upsample_use_estimate_alpha=True)))
+    m = LoTDNeuSModel(**mp, device=backend)
+    m.populate(device=backend)
+    assert m.training_initialize(dict(lr=1e-3, num_iters=500)) is True
+    assert 0.0 < m.accel.frac_occupied() < 0.8 and m.sdf_D == 1
+    refreshes = []
+    real = m.accel.update_from_net
+    m.accel.update_from_net = lambda *a, **k: (refreshes.append(k.get("generator") is not None), real(*a, **k))[1]
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, learn_inv_s=False)
+    xy, fidx, gt = tr.sample_batch()
+    tr.sample_batch = lambda: (xy, fidx, gt)
+    losses, active = [], []
+    for it in range(6):
+        losses.append(float(tr.train_step(it)))
+        active.append(m.encoding.cfg.meta.n_active_levels)
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert active[0] == 3 and active[-1] == 0                    # hardmask: levels 0..2 at it 0, all from stop_it on
+    assert refreshes == [True, True]                             # it = 2 and 4, each once, with the shared generator
+    assert abs(m._ctrl_mix - 0.75) < 1e-6                        # var_ctrl at it 5: (5 - 2) / (6 - 2)
