@@ -287,6 +287,14 @@ class LoTDNeRFDistantModel(nn.Module):
         vb = dict(type="batched", rays_inds_hit=torch.arange(N, device=dev), num_per_hit=K, t=t,
                   opacity_alpha=alpha.view(N, K), rgb=rgb.view(N, K, 3), sigma=sigma.view(N, K), valid=valid.view(N, K))
         ret = dict(volume_buffer=vb)
+        if render_per_obj_individual:       # this model alone (single_volume_renderer.py:313-317): all rays are "hit"
+            from ..graphics.nerf import ray_alpha_to_vw
+            vw = ray_alpha_to_vw(alpha.view(N, K))
+            msk = vw.sum(-1)
+            dw = vw / (msk[..., None] + 1e-10) if cfg.get("depth_use_normalized_vw", True) else vw
+            ret["rendered"] = dict(mask_volume=msk, depth_volume=(dw * t).sum(-1))
+            if cfg.get("with_rgb", True):
+                ret["rendered"]["rgb_volume"] = (vw[..., None] * rgb.view(N, K, 3)).sum(-2)
         if return_details:
             ret["details"] = dict(u4=u4)
         return ret

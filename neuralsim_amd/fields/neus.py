@@ -956,14 +956,34 @@ class LoTDNeuSModel(nn.Module):
         with_normal = cfg.get("with_normal", False)
         ret = dict()
         R = ray_tested["num_rays"]
+        # ``render_per_obj_individual``: this object alone, as images over ALL the rays of ``ray_input`` (the renderers
+        # index them with rays_inds / reshape them to the view: buffer_compose_renderer.py:576-577,
+        # code_single/tools/train.py:1037-1040); without ray_input the hit rays only
+        n_all = None
+        if render_per_obj_individual and ray_input is not None and ray_input.get("rays_o") is not None:
+            n_all = int(ray_input["rays_o"].shape[0])
+
+        def empty_rendered():
+            dev = ray_tested["rays_inds"].device
+            z = lambda *sh: torch.zeros([n_all or 0, *sh], dtype=torch.float32, device=dev)      # noqa: E731
+            r_ = dict(mask_volume=z(), depth_volume=z())
+            if with_rgb:
+                r_["rgb_volume"] = z(3)
+            if with_normal:
+                r_["normals_volume"] = z(3)
+            return r_
         if R == 0:
             ret["volume_buffer"] = dict(type="empty")
+            if render_per_obj_individual:
+                ret["rendered"] = empty_rendered()
             if return_details:
                 ret["details"] = dict()
             return ret
         o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis = self._query_samples(ray_tested, cfg, qp)
         if t.shape[0] == 0:
             ret["volume_buffer"] = dict(type="empty")
+            if render_per_obj_individual:
+                ret["rendered"] = empty_rendered()
             if return_details:
                 ret["details"] = dict(march_counts=march_counts)
             return ret
@@ -990,7 +1010,10 @@ class LoTDNeuSModel(nn.Module):
         ret["volume_buffer"] = vb
         if render_per_obj_individual or cfg.get("_render", False):
             ret["rendered"] = volume_integration(alpha, t, rgb, nablas if (with_normal or cfg.get("_render", False)) else None,
-                                                 pi, cfg.get("depth_use_normalized_vw", True))
+                                                 pi, cfg.get("depth_use_normalized_vw", True),
+                                                 rays_inds=ray_tested["rays_inds"] if n_all is not None else None,
+                                                 num_rays=n_all)
+            ret["rendered"].pop("vw", None)
         if return_details:
             ret["details"] = dict(march_counts=march_counts, sdf_nograd=sdf_ng, ridx=ridx)
         return ret

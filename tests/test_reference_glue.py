@@ -345,3 +345,37 @@ def test_reference_render_chunked_through_the_shim_batchify_query(backend):
     for k in ("rgb_volume", "depth_volume", "mask_volume", "normals_volume"):
         _cmp(got["rendered"][k].cpu(), chunked["rendered"][k].cpu(), 2e-5, f"mirror.{k}")
     del cam
+
+
+@needs_reference
+def test_reference_renderer_per_object_renderings(backend):
+    """``render_per_obj_individual`` / ``render_per_obj_in_scene`` of the reference's SingleVolumeRenderer (:250-256,
+    :313-320, :412-442) on the mirror's models: every model returns its own all-rays ``rendered`` dict, and the
+    in-scene shares of the close-range and the distant model add up to the joint image."""
+    sc = build_scenario("main_distant_sky_train", backend)
+    with ref_glue.reference_renderer_modules() as mods:
+        scene = ref_glue.FakeScene(backend, image_embeddings=ref_glue.FixedEmbeddings(sc["h_appear"]),
+                                   convert_rays_in_node=mods.get("convert_rays_in_node"))
+        scene.add(ref_glue.FakeNode(sc["model"], "Main", "main"))
+        scene.add(ref_glue.FakeNode(sc["distant_model"], "Distant", "distant"))
+        scene.add(ref_glue.FakeNode(sc["sky_model"], "Sky", "sky"))
+        r = ref_glue.make_reference_renderer(mods, dict(sc["common"], depth_use_normalized_vw=False), training=True)
+        cam = mods["classes"]["Camera"]("cam0")
+        ret = r.ray_query(sc["rays_o"], sc["rays_d"], rays_ts=torch.zeros(sc["N"], device=backend), scene=scene,
+                          observer=cam, return_buffer=True, return_details=True, render_per_obj_individual=True,
+                          render_per_obj_in_scene=True)
+    N = sc["N"]
+    ind, ins = ret["rendered_per_obj"], ret["rendered_per_obj_in_scene"]
+    assert set(ind) == set(ins) == {"main", "distant"}
+    for oid in ind:
+        assert ind[oid]["mask_volume"].shape == (N,) and ind[oid]["rgb_volume"].shape == (N, 3)
+    assert ind["main"]["normals_volume_in_world"].shape == (N, 3)
+    hit = ret["raw_per_obj_model"]["main"]["volume_buffer"]["rays_inds_hit"]
+    miss = torch.ones(N, dtype=torch.bool, device=backend)
+    miss[hit] = False
+    assert float(ind["main"]["mask_volume"][miss].abs().sum()) == 0.0 and float(ind["main"]["mask_volume"][hit].min()) > 0
+    assert float(ind["distant"]["mask_volume"].min()) > 0.99                  # include_inf_distance: opaque on its own
+    tot = ret["rendered"]
+    for k in ("mask_volume", "depth_volume", "rgb_volume_occupied"):
+        kk = "rgb_volume" if k == "rgb_volume_occupied" else k
+        _cmp((ins["main"][kk] + ins["distant"][kk]).detach().cpu(), tot[k].detach().cpu(), 2e-5, f"in-scene sum {k}")
