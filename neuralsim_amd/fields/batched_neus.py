@@ -220,9 +220,29 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         goff, woff = self._offsets(ins)
         tested = dict(bt)
         tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
-        ret = super().ray_query(ray_input=batched_ray_input, ray_tested=tested, config=config,
-                                return_buffer=return_buffer, return_details=return_details,
-                                render_per_obj_individual=render_per_obj_individual)
+        want_pairs = bool(dict(config).get("_render", False))
+        cfg = dict(config, _render=True) if render_per_obj_individual else config
+        ret = super().ray_query(ray_input=None, ray_tested=tested, config=cfg, return_buffer=return_buffer,
+                                return_details=return_details, render_per_obj_individual=False)
+        if render_per_obj_individual:
+            # every batch item alone, as [B', N(, 3)] images over all the rays (buffer_compose_renderer.py:268-275 slices
+            # them per object and indexes them with (rays_full_bidx, rays_inds))
+            assert batched_ray_input is not None and batched_ray_input.get("rays_o") is not None, \
+                "render_per_obj_individual needs batched_ray_input (the [B', N, 3] rays)"
+            Bq, N = batched_ray_input["rays_o"].shape[:2]
+            pairs = ret.pop("rendered", None)
+            dev = bt["rays_inds"].device
+            keys = ["mask_volume", "depth_volume"] + (["rgb_volume"] if dict(config).get("with_rgb", True) else []) + \
+                (["normals_volume"] if dict(config).get("with_normal", False) else [])
+            where = (bt["rays_full_bidx"], bt["rays_inds"])
+            full = {}
+            for k in keys:
+                tail = (3,) if k in ("rgb_volume", "normals_volume") else ()
+                z = torch.zeros([Bq, N, *tail], dtype=torch.float32, device=dev)
+                full[k] = z.index_put(where, pairs[k]) if pairs is not None and k in pairs else z
+            ret["rendered"] = full
+            if want_pairs and pairs is not None:
+                ret["rendered_pairs"] = pairs
         vb = ret["volume_buffer"]
         if vb["type"] != "empty":
             vb["rays_bidx_hit"] = bt["rays_bidx"]

@@ -130,7 +130,7 @@ def reference_compose_renderer_modules():
         am = _stub_module("app.models")
         am.__path__ = []
         sys.modules.update({
-            "torch_scatter": _stub_module("torch_scatter", scatter_min=None),
+            "torch_scatter": _stub_module("torch_scatter", scatter_min=_scatter_min),
             "matplotlib": mpl, "matplotlib.pyplot": _stub_module("matplotlib.pyplot"),
             "nr3d_lib.utils": _stub_module("nr3d_lib.utils", IDListedDict=dict),
             "app.models": am,
@@ -152,6 +152,17 @@ def reference_compose_renderer_modules():
                     sys.modules.pop(k, None)
                 else:
                     sys.modules[k] = v
+
+
+def _scatter_min(src, index, dim=0):
+    """torch_scatter.scatter_min for 1-D inputs (the segmentation z-buffer of buffer_compose_renderer.py:296-301)."""
+    n = int(index.max()) + 1
+    out = torch.full([n], float("inf"), dtype=src.dtype, device=src.device).scatter_reduce(0, index, src, reduce="amin")
+    is_min = src == out[index]
+    pos = torch.arange(src.numel(), device=src.device)
+    arg = torch.full([n], src.numel(), dtype=torch.long, device=src.device).scatter_reduce(
+        0, index[is_min], pos[is_min], reduce="amin")
+    return out, arg
 
 
 class FakeComposeScene:

@@ -379,3 +379,50 @@ def test_reference_renderer_per_object_renderings(backend):
     for k in ("mask_volume", "depth_volume", "rgb_volume_occupied"):
         kk = "rgb_volume" if k == "rgb_volume_occupied" else k
         _cmp((ins["main"][kk] + ins["distant"][kk]).detach().cpu(), tot[k].detach().cpu(), 2e-5, f"in-scene sum {k}")
+
+
+@needs_reference
+def test_reference_compose_renderer_individual_renderings_and_segmentation(backend):
+    """``render_per_obj_individual`` of the reference's BufferComposeRenderer (:268-311, :548-577): the batched model
+    hands back one all-rays image per batch item, the single model its own; the reference builds its instance / class
+    segmentation z-buffer from them (two vehicles overlap on the central pixels: the nearer one wins)."""
+    import compose_scenario as cs
+    sc = cs.build(backend)
+    with ref_glue.reference_compose_renderer_modules() as mods:
+        from nr3d_lib.config import ConfigDict
+        AA = mods["AssetAssignment"]
+        main, mb, sky = sc["main"], sc["vehicle"], sc["sky"]
+        main.assigned_to, main.is_ray_query_supported, main.is_batched_query_supported = AA.OBJECT, True, False
+        mb.assigned_to, mb.is_ray_query_supported = AA.MULTI_OBJ, True
+        sky.assigned_to, sky.is_ray_query_supported = AA.SCENE, False
+        scene = ref_glue.FakeComposeScene(backend, mods["Scene"], image_embeddings=ref_glue.FixedEmbeddings(sc["h_appear"]))
+        scene.add(ref_glue.FakeNode(main, "Main", "main", ref_glue.FakeTransform(device=backend)))
+        for k, (R, t, s) in sc["poses"].items():
+            scene.add(ref_glue.FakeNode(mb, "Vehicle", k, ref_glue.FakeTransform(R, t, s, device=backend)))
+        scene.add(ref_glue.FakeNode(sky, "Sky", "sky", ref_glue.FakeTransform(device=backend)))
+        rr = mods["compose"].BufferComposeRenderer(ConfigDict(common=ConfigDict(dict(sc["common"], segmentation_threshold=0.002)),
+                                                              train=ConfigDict(), val=ConfigDict()))
+        rr.image_postprocessor = None
+        rr.eval()
+        obs = type("Camera", (mods["classes"]["Camera"], ref_glue.FakeObserver), {})("cam0")
+        with torch.no_grad():
+            ret = rr.ray_query(sc["rays_o"], sc["rays_d"], rays_ts=torch.zeros(sc["N"], device=backend), scene=scene,
+                               observer=obs, render_per_obj_individual=True)
+    N = sc["N"]
+    per = ret["rendered_per_obj"]
+    assert set(per) == {"main", "car0", "car1", "car2"}
+    for oid, r in per.items():
+        assert r["mask_volume"].shape == (N,) and r["rgb_volume"].shape == (N, 3) and r["normals_volume_in_world"].shape == (N, 3)
+    # (the 14 x 14 view is very wide: the far vehicle is grazed by the four central rays only)
+    assert float(per["car1"]["mask_volume"].abs().sum()) == 0.0 and float(per["car0"]["mask_volume"].max()) > 0.002
+    ins_map = scene.get_drawable_instance_ind_map()
+    seg = ret["ins_seg_mask_buffer"].cpu()
+    both = ((per["car0"]["mask_volume"] > 0.002) & (per["car2"]["mask_volume"] > 0.002)).cpu()
+    assert int(both.sum()) > 0                                               # pixels where the two vehicles overlap
+    nearer = torch.where(per["car2"]["depth_volume"] < per["car0"]["depth_volume"], ins_map["car2"], ins_map["car0"]).cpu()
+    d_main = torch.where(per["main"]["mask_volume"] > 0.002, per["main"]["depth_volume"],
+                         torch.full_like(per["main"]["depth_volume"], float("inf"))).cpu()
+    d_veh = torch.minimum(per["car2"]["depth_volume"], per["car0"]["depth_volume"]).cpu()
+    sel = both & (d_veh < d_main)                                            # ... and in front of the background object
+    assert int(sel.sum()) > 0 and torch.equal(seg[sel], nearer[sel])
+    assert set(ret["class_seg_mask_buffer"].unique().tolist()) <= {-1, 0, 1}
