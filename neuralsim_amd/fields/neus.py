@@ -499,7 +499,6 @@ class LoTDNeuSModel(nn.Module):
         updated = False
         method = post.get("geo_init_method", "pretrain_after_zero_out")
         if ("pretrain" in method) and not getattr(self, "is_pretrained", False):
-            cfg = self.encoding.cfg
             if "zero_out" in method:
                 self.encoding.flattened_params.zero_()
             ext = (self.accel.aabb[1] - self.accel.aabb[0]).cpu()
@@ -507,7 +506,6 @@ class LoTDNeuSModel(nn.Module):
             r = float(post.get("radius_init", 0.5)) / (float(ext.min()) / 2.0)
             self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
             self.is_pretrained = updated = True
-            del cfg
         if self.accel is not None:
             self.accel.init(self.query_sdf, logger=logger)
         an = post.get("anneal")
