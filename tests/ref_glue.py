@@ -349,6 +349,35 @@ def reference_eikonal_loss_module():
                 sys.modules[k] = v
 
 
+@contextlib.contextmanager
+def reference_loss_module(name: str):
+    """-> the reference's ``app/loss/<name>.py`` loaded unchanged, for the loss modules that only need the shim's pack
+    ops plus harness stand-ins (``get_annealer`` is only reached with an ``anneal`` config, which the tests leave None)."""
+    path = REF_ROOT / "app" / "loss" / f"{name}.py"
+    assert path.exists()
+    names = ["nr3d_lib.logger", "nr3d_lib.models.annealers", "app", "app.resources", "app.loss", f"app.loss.{name}"]
+    saved = {k: sys.modules.get(k) for k in names}
+    app, lossp = _stub_module("app"), _stub_module("app.loss")
+    app.__path__, lossp.__path__ = [], []
+    sys.modules.update({
+        "nr3d_lib.logger": _stub_module("nr3d_lib.logger", Logger=object),
+        "nr3d_lib.models.annealers": _stub_module("nr3d_lib.models.annealers", get_annealer=None, get_anneal_val=None),
+        "app": app, "app.loss": lossp, "app.resources": _stub_module("app.resources", Scene=object, SceneNode=object),
+    })
+    try:
+        spec = importlib.util.spec_from_file_location(f"app.loss.{name}", str(path))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        yield mod
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 class FakePinhole:
     """Stand-in for nr3d_lib's PinholeCameraMatKHW attribute: mat [...,3,3], W/H (scalars or [...]); ``lift`` is the
     textbook pinhole back-projection ((u - cx) / fx * d, (v - cy) / fy * d, d)."""

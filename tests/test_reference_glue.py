@@ -426,3 +426,44 @@ def test_reference_compose_renderer_individual_renderings_and_segmentation(backe
     sel = both & (d_veh < d_main)                                            # ... and in front of the background object
     assert int(sel.sum()) > 0 and torch.equal(seg[sel], nearer[sel])
     assert set(ret["class_seg_mask_buffer"].unique().tolist()) <= {-1, 0, 1}
+
+
+@needs_reference
+def test_reference_mask_entropy_loss(backend):
+    """``MaskEntropyRegLoss.forward_code_single`` (app/loss/mask_entropy.py:45-160; dtu config ``mask_entropy_mode:
+    crisp_cr``) on the return value of the reference renderer running on the mirror's models: the close-range /
+    distant masks it rebuilds from ``vw_in_total`` + ``pack_infos_collect`` add up to the joint mask, and its value
+    equals the formula on the oracle's pack ops."""
+    from oracle import pack_ops as opo
+    sc = build_scenario("main_distant_sky_train", backend)
+    N = sc["N"]
+    with ref_glue.reference_renderer_modules() as mods:
+        scene = ref_glue.FakeScene(backend, image_embeddings=ref_glue.FixedEmbeddings(sc["h_appear"]),
+                                   convert_rays_in_node=mods.get("convert_rays_in_node"))
+        scene.add(ref_glue.FakeNode(sc["model"], "Main", "main"))
+        scene.add(ref_glue.FakeNode(sc["distant_model"], "Distant", "distant"))
+        scene.add(ref_glue.FakeNode(sc["sky_model"], "Sky", "sky"))
+        r = ref_glue.make_reference_renderer(mods, sc["common"], training=True)
+        ret = r.ray_query(sc["rays_o"], sc["rays_d"], rays_ts=torch.zeros(N, device=backend), scene=scene,
+                          observer=mods["classes"]["Camera"]("cam0"), return_buffer=True, return_details=True)
+    with ref_glue.reference_loss_module("mask_entropy") as me:
+        crisp = me.MaskEntropyRegLoss(3.0e-3, mode="crisp_cr").forward_code_single(scene, ret, [N], it=0)
+        cross = me.MaskEntropyRegLoss(1.0, mode="cross_crdv").forward_code_single(scene, ret, [N], it=0)
+    raw = ret["raw_per_obj_model"]
+
+    def mask_of(key):
+        vb = raw[key]["volume_buffer"]
+        m = torch.zeros(N, dtype=torch.float64)
+        m[vb["rays_inds_collect"].cpu()] = opo.packed_sum(vb["vw_in_total"].detach().cpu().double().flatten(),
+                                                          vb["pack_infos_collect"].cpu())
+        return m
+    m_cr, m_dv = mask_of("main"), mask_of("distant")
+    assert float((m_cr + m_dv - ret["rendered"]["mask_volume"].detach().cpu().double()).abs().max()) < 2e-5
+    eps = 1e-5
+    want = -(m_cr * torch.log(m_cr.clamp_min(eps)) + (1 - m_cr) * torch.log((1 - m_cr).clamp_min(eps))).mean()
+    assert abs(float(crisp["loss_mask_entropy.crisp_cr"]) - 3.0e-3 * float(want)) < 1e-7
+    want1 = (m_cr * torch.log(m_dv.clamp_min(eps))).mean()
+    assert abs(float(cross["loss_mask_entropy.cross_cr_on_dv"]) - float(want1)) < 1e-5
+    sc["model"].encoding.flattened_params.grad = None
+    (crisp["loss_mask_entropy.crisp_cr"] + cross["loss_mask_entropy.cross_dv_on_cr"]).backward()
+    assert float(sc["model"].encoding.flattened_params.grad.abs().sum()) > 0
