@@ -41,6 +41,9 @@ typedef struct NsimLotdMeta {
   int32_t type[NSIM_MAX_LEVELS];       /* NSIM_LOTD_DENSE | NSIM_LOTD_HASH */
   uint32_t size[NSIM_MAX_LEVELS];      /* entries (vertices or hash slots) */
   int64_t offset[NSIM_MAX_LEVELS];     /* offset of the level in the flat param tensor, in scalars */
+  float x_scale[3];                    /* position -> unit coordinate of the pyramid, per axis: u = x * x_scale + x_shift */
+  float x_shift[3];                    /* = the model's AABB normalisation (nr3d_lib AABBSpace: lo -> 0, hi -> 1);
+                                        * x_scale all zero = the [-1,1]^3 cube (0.5, 0.5) */
 } NsimLotdMeta;
 
 /* Occupancy-grid / AABB description (host struct). nr3d_lib.models.accelerations.OccGridAccel +

@@ -18,7 +18,7 @@ class LotdMeta(C.Structure):
     _fields_ = [("num_levels", C.c_int32), ("n_feats", C.c_int32), ("n_active_levels", C.c_int32),
                 ("res", (C.c_int32 * 3) * NSIM_MAX_LEVELS),
                 ("type", C.c_int32 * NSIM_MAX_LEVELS), ("size", C.c_uint32 * NSIM_MAX_LEVELS),
-                ("offset", C.c_int64 * NSIM_MAX_LEVELS)]
+                ("offset", C.c_int64 * NSIM_MAX_LEVELS), ("x_scale", C.c_float * 3), ("x_shift", C.c_float * 3)]
 
 
 class OccMeta(C.Structure):

@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b;
           const LotdRes R = a.lotd.res[l];
-          const LotdCell c = lotd_cell(p.xx, R);
+          const LotdCell c = lotd_cell(p.xx, R, a.lotd);
           float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
           if (l < a.lotd.n_active)      // hardmask annealing: masked levels are never read
 #pragma unroll
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     float j0[WJ ? GLM_PTS : 1][3], j1[WJ ? GLM_PTS : 1][3];
 #pragma unroll
     for (int q = 0; q < GLM_PTS; ++q) {
-      const LotdCell c = lotd_cell(xx[q], R);
+      const LotdCell c = lotd_cell(xx[q], R, a.lotd);
       f0[q] = f1[q] = 0.f;
       if constexpr (WJ) {
 #pragma unroll
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
         for (int b = 0; b < 2; ++b) {
           const int l = lb + 4 * qq + 2 * hi + b;
           const LotdRes R = a.lotd.res[l];
-          const LotdCell c = lotd_cell(p.xx, R);
+          const LotdCell c = lotd_cell(p.xx, R, a.lotd);
           float f0 = 0.f, f1 = 0.f;
           if (l < a.lotd.n_active)
 #pragma unroll
@@ -1252,7 +1252,7 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
         for (int c = 0; c < 3; ++c) gn[c] = a.gn[3 * s + c];
       }
     }
-    const LotdCell c = lotd_cell(xx, R);
+    const LotdCell c = lotd_cell(xx, R, a.lotd);
     const float q0[3] = {g0 * gn[0] * c.dscale[0], g0 * gn[1] * c.dscale[1], g0 * gn[2] * c.dscale[2]};
     const float q1[3] = {g1 * gn[0] * c.dscale[0], g1 * gn[1] * c.dscale[1], g1 * gn[2] * c.dscale[2]};
 #pragma unroll
@@ -1345,7 +1345,7 @@ __global__ void __launch_bounds__(256) k_lotd_hess_dx(HessArgs a) {
   float acc[3] = {0.f, 0.f, 0.f};
   for (int l = 0; l < a.lotd.n_active; ++l) {
     const LotdRes R = a.lotd.res[l];
-    const LotdCell c = lotd_cell(xx, R);
+    const LotdCell c = lotd_cell(xx, R, a.lotd);
     const float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
     const float g0 = gp[0], g1 = gp[1];
     float hxy = 0.f, hxz = 0.f, hyz = 0.f;      // already contracted with g over the two features

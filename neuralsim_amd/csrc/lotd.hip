@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) k_lotd_fwd(const float* __restrict__ x, c
   const int l = (int)(tid % L);
   const float xx[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
   const LotdRes R = m.res[l];
-  const LotdCell c = lotd_cell(xx, R);
+  const LotdCell c = lotd_cell(xx, R, m);
   float f0 = 0.f, f1 = 0.f;
   float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
   if (l < m.n_active)
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_lotd_bwd(const float* __restrict__ x, c
   if (l >= m.n_active) return;   // masked level: no gradient
   const float xx[3] = {x[3 * s], x[3 * s + 1], x[3 * s + 2]};
   const LotdRes R = m.res[l];
-  const LotdCell c = lotd_cell(xx, R);
+  const LotdCell c = lotd_cell(xx, R, m);
   const int64_t o = s * (2 * L) + 2 * l;
   const float d0 = dout ? dout[o] : 0.f, d1 = dout ? dout[o + 1] : 0.f;
   float q0[3] = {0.f, 0.f, 0.f}, q1[3] = {0.f, 0.f, 0.f};

@@ -21,6 +21,7 @@ struct LotdDev {
   int type[NSIM_MAX_LEVELS];
   uint32_t size[NSIM_MAX_LEVELS];
   int64_t offset[NSIM_MAX_LEVELS];
+  float xs[3], xb[3];                  // u_a = x_a * xs[a] + xb[a]  (AABB -> [0,1] per axis; (0.5, 0.5) for [-1,1]^3)
 };
 
 static inline LotdDev lotd_dev(const NsimLotdMeta* m) {
@@ -32,6 +33,11 @@ static inline LotdDev lotd_dev(const NsimLotdMeta* m) {
     d.type[l] = l < m->num_levels ? m->type[l] : 0;
     d.size[l] = l < m->num_levels ? m->size[l] : 8;
     d.offset[l] = l < m->num_levels ? m->offset[l] : 0;
+  }
+  const bool unit = m->x_scale[0] == 0.f && m->x_scale[1] == 0.f && m->x_scale[2] == 0.f;
+  for (int a = 0; a < 3; ++a) {
+    d.xs[a] = unit ? 0.5f : m->x_scale[a];
+    d.xb[a] = unit ? 0.5f : m->x_shift[a];
   }
   return d;
 }
@@ -57,21 +63,21 @@ static inline int lotd_meta_check(const NsimLotdMeta* m) {
 struct LotdCell {
   int c0[3];
   float w[3];
-  float dscale[3];  // d pos_a / d x_a = 0.5 * (R_a - 1)
+  float dscale[3];  // d pos_a / d x_a = x_scale_a * (R_a - 1)
 };
 
-__device__ __forceinline__ LotdCell lotd_cell(const float x[3], const LotdRes& R) {
+__device__ __forceinline__ LotdCell lotd_cell(const float x[3], const LotdRes& R, const LotdDev& L) {
   LotdCell c;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float rm1 = (float)(R.r[a] - 1);
-    const float u = x[a] * 0.5f + 0.5f;
+    const float u = x[a] * L.xs[a] + L.xb[a];
     const float pos = u * rm1;
     float f = floorf(pos);
     f = fminf(fmaxf(f, 0.f), (float)(R.r[a] - 2));
     c.c0[a] = (int)f;
     c.w[a] = pos - f;
-    c.dscale[a] = 0.5f * rm1;
+    c.dscale[a] = L.xs[a] * rm1;
   }
   return c;
 }

@@ -403,6 +403,7 @@ class LoTDNeuSModel(nn.Module):
             kw, post = ref_config.neus_native_kwargs(params, aabb=aabb)
             LoTDNeuSModel.__init__(self, seed=seed, device=device, **kw)
             self._reference_post = post
+            self.geo_init_method = post.get("geo_init_method", self.geo_init_method)
             if "var_ctrl" in post:
                 self.set_var_ctrl(**post["var_ctrl"])
             return
@@ -439,10 +440,15 @@ class LoTDNeuSModel(nn.Module):
         self.rad_w = nn.Parameter(torch.cat(ws))
         self.rad_b = nn.Parameter(torch.cat(bs))
         self.ln_inv_s = nn.Parameter(torch.tensor([float(ln_inv_s_init)]))
+        # ``implicit_surface.is_pretrained`` / ``.geo_init_method`` as the reference's asset classes read them
+        # (app/models/single/neus.py:203-206, 229)
+        self.register_buffer("is_pretrained", torch.tensor([False]), persistent=True)
+        self.geo_init_method = "pretrain_after_zero_out"
         assert self.sdf_w.numel() == n_sdf_w and self.rad_w.numel() == n_rad_w
         if aabb is None:
             h = bounding_size / 2.0
             aabb = torch.tensor([[-h, -h, -h], [h, h, h]])
+        self.encoding.cfg.set_aabb(aabb)           # the pyramid spans the AABB (per axis); must precede fm.lotd = meta below
         accel_cfg = dict(accel_cfg or {})
         self.accel = OccGridAccel(aabb, resolution=accel_cfg.get("resolution", (64, 64, 64)),
                                   occ_thre=accel_cfg.get("occ_thre", 0.3), ema_decay=accel_cfg.get("ema_decay", 0.95),
@@ -498,14 +504,15 @@ class LoTDNeuSModel(nn.Module):
         post = getattr(self, "_reference_post", {})
         updated = False
         method = post.get("geo_init_method", "pretrain_after_zero_out")
-        if ("pretrain" in method) and not getattr(self, "is_pretrained", False):
+        if ("pretrain" in method) and not bool(self.is_pretrained):
             if "zero_out" in method:
                 self.encoding.flattened_params.zero_()
             ext = (self.accel.aabb[1] - self.accel.aabb[0]).cpu()
             # radius_init is in object units; the sphere is written in the [-1, 1] coordinates of the shortest axis
             r = float(post.get("radius_init", 0.5)) / (float(ext.min()) / 2.0)
             self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
-            self.is_pretrained = updated = True
+            self.is_pretrained.fill_(True)
+            updated = True
         if self.accel is not None:
             self.accel.init(self.query_sdf, logger=logger)
         an = post.get("anneal")
@@ -602,6 +609,31 @@ class LoTDNeuSModel(nn.Module):
         self.sdf_b.data[-1] = -2.0 * self.sdf_scale
         self.encoding.flattened_params.add_(0)      # bump versions: refresh fp16 shadow / weight pack lazily
         self.sdf_w.add_(0)
+        return self
+
+    @property
+    def implicit_surface(self):
+        """The reference's models keep the SDF network in ``self.implicit_surface``; here the model is its own."""
+        return self
+
+    @torch.no_grad()
+    def geometric_init_fn(self, sdf_fn, noise_scale: float = 0.25, level: int = None):
+        """Like ``geometric_init_sphere`` for an arbitrary target: ``sdf_fn(x [V,3] in OBJECT coordinates) -> [V]`` signed
+        distance in object units, sampled at the vertices of the finest dense level (the road-surface / capsule targets
+        of the street model's pre-training, app/models/single/neus.py:198-236)."""
+        self.geometric_init_sphere(0.5, noise_scale=noise_scale, inside_out=False, level=level)   # decoder pass-through
+        cfg = self.encoding.cfg
+        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense") if level is None else int(level)
+        Rx, Ry, Rz = cfg.lod_res3[lv]
+        zz, yy, xx = torch.meshgrid(torch.linspace(-1.0, 1.0, Rz), torch.linspace(-1.0, 1.0, Ry),
+                                    torch.linspace(-1.0, 1.0, Rx), indexing="ij")
+        a = self.accel.aabb.detach().cpu()
+        xn = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+        x_obj = a[0] + (xn + 1.0) * 0.5 * (a[1] - a[0])
+        sdf = sdf_fn(x_obj).reshape(-1).float() * self.sdf_scale
+        lvl = self.encoding.flattened_params.data[cfg.lod_offsets[lv]: cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2].view(-1, 2)
+        lvl[:, 0] = sdf.half().float().to(lvl.device)
+        self.encoding.flattened_params.add_(0)
         return self
 
     # ------------------------------------------------------------------ inv_s control (var_ctrl_cfg)

@@ -64,6 +64,20 @@ class LoTDConfig:
             m.offset[l] = self.lod_offsets[l]
         self.meta = m
 
+    def set_aabb(self, aabb):
+        """The pyramid spans the model's AABB: position x (object coordinates) -> unit coordinate u = (x - lo) / (hi - lo)
+        per axis (nr3d_lib's AABBSpace normalisation, app/models/single/neus.py:152-196 ``populate(aabb=...)``) -- with
+        ``lotd_use_cuboid`` vertex counts the cells are then isotropic in object space.  The [-1,1]^3 cube gives
+        (x_scale, x_shift) = (0.5, 0.5): u = x / 2 + 1 / 2, the arithmetic of the cubic configs bit for bit."""
+        import torch
+        a = torch.as_tensor(aabb, dtype=torch.float64).reshape(2, 3)
+        self.aabb = a.float()
+        for i in range(3):
+            inv = 1.0 / float(a[1, i] - a[0, i])
+            self.meta.x_scale[i] = inv
+            self.meta.x_shift[i] = -float(a[0, i]) * inv
+        return self
+
     def set_active_levels(self, n: int):
         """Hardmask level annealing (``anneal_cfg{type: hardmask, start_level, start_it, stop_it}``,
         lotd_neus.dtu.230814.yaml:104-108): levels >= n yield zero features and get no gradient."""

@@ -36,10 +36,19 @@ class LoTDSpec:
     lod_sizes: List[int]      # number of entries (vertices or hash slots) per level
     lod_offsets: List[int]    # offset (in scalars) of each level in the flat param tensor
     n_params: int
+    aabb: object = None       # [2,3] the pyramid spans this box (u = (x - lo) / (hi - lo) per axis); None = [-1,1]^3
 
     @property
     def num_levels(self):
         return len(self.lod_res)
+
+    def unit_coords(self, x: torch.Tensor) -> torch.Tensor:
+        """position -> [0,1]^3 coordinate of the pyramid, as x * scale + shift (the kernels' arithmetic)."""
+        if self.aabb is None:
+            return x * 0.5 + 0.5
+        a = torch.as_tensor(self.aabb, dtype=torch.float64).reshape(2, 3)
+        inv = (1.0 / (a[1] - a[0]))
+        return x * inv.to(x.dtype) + (-a[0] * inv).to(x.dtype)
 
     @property
     def out_features(self):
@@ -100,7 +109,7 @@ def lotd_forward(x: torch.Tensor, params: torch.Tensor, spec: LoTDSpec, n_active
     ``nablas = d sdf / d x`` and its double-backward come for free in the oracle."""
     S = x.shape[0]
     F = spec.n_feats
-    u = x * 0.5 + 0.5
+    u = spec.unit_coords(x)
     p32 = params.float()
     outs = []
     n_active = getattr(spec, 'n_active', None) if n_active is None else n_active

@@ -78,7 +78,12 @@ def test_field_fwd_bwd(backend, sdf_D, precision):
     ridx = torch.randint(0, R, (S,), generator=g).sort().values
     t = torch.rand(S, generator=g) * 0.8
     h_appear = torch.randn(R, 4, generator=g) * 0.5
+    if box is not None:
+        rays_o = (box[0] + box[1]) / 2 + rays_o * (box[1] - box[0]) / 2
+        t = t * float((box[1] - box[0]).min()) / 2
     x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    if box is not None:
+        assert bool(((x > box[0]) & (x < box[1])).all())
     ha_o = leaf(h_appear)
     sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
     ha_d = leaf(h_appear, backend)
@@ -174,7 +179,7 @@ def test_sdf_scale_and_inside_out(backend):
         assert float((sd - want).abs().max()) < 0.08, (inside_out, sd)
 
 
-@pytest.mark.parametrize("case", ["cuboid", "anneal", "cuboid+anneal"])
+@pytest.mark.parametrize("case", ["cuboid", "anneal", "cuboid+anneal", "cuboid+aabb"])
 def test_field_cuboid_levels_and_hardmask(backend, case):
     """Per-axis level resolutions (``lotd_use_cuboid``, street config :160) and hardmask level annealing
     (``anneal_cfg{type: hardmask}``, dtu config :104-108): values, normals and every gradient vs the oracle; the masked
@@ -187,10 +192,18 @@ def test_field_cuboid_levels_and_hardmask(backend, case):
                                  grid_bound=0.3, noise_scale=1.0)
     p.grid = p.grid.float()
     p.spec.n_active = n_active
+    box = None
+    if "aabb" in case:
+        # an elongated, off-centre AABB in object units (the street model after populate(aabb=...)): the pyramid spans
+        # the box per axis, positions / normals / gradients are in object coordinates
+        box = torch.tensor([[-3.0, -2.5, -0.75], [5.0, 1.5, 1.25]])
+        p.spec.aabb = box
     for t in p.tensors():
         t.requires_grad_(True)
     model = model_from_params(p, backend, precision="f32")
     model.set_active_levels(n_active)
+    if box is not None:
+        assert torch.equal(model.accel.aabb.cpu(), box) and abs(model.encoding.cfg.meta.x_scale[0] - 0.125) < 1e-7
     assert ("Hash" in p.spec.lod_types) and ("Dense" in p.spec.lod_types)
     g = torch.Generator().manual_seed(2)
     R, S = 5, 90
@@ -199,7 +212,12 @@ def test_field_cuboid_levels_and_hardmask(backend, case):
     ridx = torch.randint(0, R, (S,), generator=g).sort().values
     t = torch.rand(S, generator=g) * 0.8
     h_appear = torch.randn(R, 4, generator=g) * 0.5
+    if box is not None:
+        rays_o = (box[0] + box[1]) / 2 + rays_o * (box[1] - box[0]) / 2
+        t = t * float((box[1] - box[0]).min()) / 2
     x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    if box is not None:
+        assert bool(((x > box[0]) & (x < box[1])).all())
     ha_o = leaf(h_appear)
     sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
     dv = lambda a: a.to(backend).contiguous()
@@ -261,7 +279,12 @@ def test_field_fewer_than_16_levels(backend, precision):
     ridx = torch.randint(0, R, (S,), generator=g).sort().values
     t = torch.rand(S, generator=g) * 0.8
     h_appear = torch.randn(R, 4, generator=g) * 0.5
+    if box is not None:
+        rays_o = (box[0] + box[1]) / 2 + rays_o * (box[1] - box[0]) / 2
+        t = t * float((box[1] - box[0]).min()) / 2
     x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    if box is not None:
+        assert bool(((x > box[0]) & (x < box[1])).all())
     ha_o = leaf(h_appear)
     sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
     dv = lambda a: a.to(backend).contiguous()
@@ -308,7 +331,12 @@ def test_field_more_than_16_levels(backend, levels, sdf_D, precision):
     ridx = torch.randint(0, R, (S,), generator=g).sort().values
     t = torch.rand(S, generator=g) * 0.8
     h_appear = torch.randn(R, 4, generator=g) * 0.5
+    if box is not None:
+        rays_o = (box[0] + box[1]) / 2 + rays_o * (box[1] - box[0]) / 2
+        t = t * float((box[1] - box[0]).min()) / 2
     x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    if box is not None:
+        assert bool(((x > box[0]) & (x < box[1])).all())
     ha_o = leaf(h_appear)
     sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
     dv = lambda a: a.to(backend).contiguous()

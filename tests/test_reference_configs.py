@@ -134,3 +134,33 @@ def test_unsupported_options_fail_loudly():
         LoTDNeuSModel(**wide)
     with pytest.raises(TypeError, match="unexpected"):
         LoTDNeuSModel(**dict(base, not_a_key=1))
+
+
+def test_street_pretrain_targets(backend):
+    """``pretrain_sdf_road_surface`` / ``pretrain_sdf_capsule`` (shim of nr3d_lib.models.fields.sdf) through the
+    reference's ``LoTDNeuSStreet.asset_training_initialize`` flow (app/models/single/neus.py:198-236): the table
+    starts as the road surface ``ego_height`` below the track, ``is_pretrained`` flips, the occupancy grid is built."""
+    from nr3d_lib.models.fields.neus import LoTDNeuSModel
+    from nr3d_lib.models.fields.sdf import pretrain_sdf_capsule, pretrain_sdf_road_surface
+    aabb = torch.tensor([[-8.0, -4.0, -2.0], [8.0, 4.0, 2.0]])
+    m = LoTDNeuSModel(lod_res=[[9, 5, 3], [17, 9, 5], [33, 17, 9]], log2_hashmap_size=13, sdf_D=1, precision="f32",
+                      aabb=aabb, sdf_scale=25.0, accel_cfg=dict(resolution=(16, 8, 4), update_from_net_cfg=dict(num_steps=2, num_pts=2 ** 13)))
+    m = m.to(backend)
+    m.geo_init_method = "pretrain"
+    tracks = torch.stack([torch.linspace(-7, 7, 29), torch.zeros(29), torch.full([29], 0.5)], dim=-1)   # camera 0.5 above z = 0 ...
+    # --- what asset_training_initialize does
+    assert not m.implicit_surface.is_pretrained
+    pretrain_sdf_road_surface(m.implicit_surface, tracks, lr=1e-3, num_iters=1000, num_points=262144, w_eikonal=3e-3,
+                              floor_dim="z", floor_up_sign=1, ego_height=2.0, logger=None, log_prefix="street")
+    m.implicit_surface.is_pretrained = ~m.implicit_surface.is_pretrained
+    m.accel.init(m.query_sdf)
+    assert bool(m.is_pretrained)
+    x = torch.tensor([[0.0, 0.0, 0.5], [3.0, 1.0, -1.5], [-5.0, -2.0, -1.9], [2.0, 0.5, 1.5]], device=backend)
+    sdf = m.query_sdf(x).cpu()
+    want = x.cpu()[:, 2] - (0.5 - 2.0)                                    # ... so the road is at z = -1.5
+    assert (sdf - want).abs().max() < 0.05
+    occ = m.accel.occ_grid.cpu()                                          # [X, Y, Z]: only the slab around z = -1.5
+    assert bool(occ[:, :, 0].any()) and not bool(occ[:, :, 2:].any())
+    pretrain_sdf_capsule(m.implicit_surface, tracks, surface_distance=1.0)
+    s2 = m.query_sdf(torch.tensor([[0.0, 0.0, 0.5], [0.0, 3.0, 0.5]], device=backend)).cpu()
+    assert s2[0] > 0.9 and s2[1] < -1.5                                    # free on the track, solid 3 m beside it

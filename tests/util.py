@@ -38,7 +38,8 @@ def model_from_params(p, device, precision="f32", log2_hashmap_size=None):
     from neuralsim_amd.fields.neus import LoTDNeuSModel
     l2 = int(math.log2(p.spec.hashmap_size))
     m = LoTDNeuSModel(lod_res=p.spec.lod_res, log2_hashmap_size=l2, sdf_D=len(p.sdf_w) - 1, precision=precision,
-                      ln_inv_s_init=float(p.ln_inv_s), ln_inv_s_factor=p.ln_inv_s_factor)
+                      ln_inv_s_init=float(p.ln_inv_s), ln_inv_s_factor=p.ln_inv_s_factor,
+                      aabb=torch.as_tensor(p.spec.aabb, dtype=torch.float32) if getattr(p.spec, "aabb", None) is not None else None)
     with torch.no_grad():
         m.encoding.flattened_params.copy_(p.grid.detach().float())
         m.sdf_w.copy_(torch.cat([w.detach().reshape(-1) for w in p.sdf_w]))
