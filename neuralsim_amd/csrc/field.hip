@@ -807,7 +807,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // WJ = true (with-grad forward of the training step): writes the f32 planes h [16][S][2] and dh/dx [16][S][2][3] that
 // the decoder kernels (k_field MODE 3 forward, MODE 2 backward) read -- the same split, so the 6.7 k-instruction
 // forward no longer carries the gather's address registers (it spilled 440 B per lane).
+#ifndef GLM_PTS
 #define GLM_PTS 4
+#endif
 template <int PREC, bool WJ>
 __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   const int lane = nsim_lane();
