@@ -15,18 +15,24 @@ def all_pixel_xy(W: int, H: int, device):
 
 @torch.no_grad()
 def render_image(renderer, model, intr, c2w, WH, frame: int, rays_h_appear=None, rayschunk: int = 65536, **kw):
-    """-> dict of [H, W(,3)] images of camera ``frame`` (eval mode: perturb off, normalised depth weights)."""
+    """-> dict of [H, W(,3)] images of camera ``frame``, rendered with the reference's VALIDATION renderer settings
+    whatever the renderer was built with: eval mode, ``perturb: false``, ``depth_use_normalized_vw: true``
+    (lotd_neus.dtu.230814.yaml:272-278 ``renderer.train`` / ``renderer.val``: the reference keeps two renderer configs) --
+    so evaluating with a trainer's own (perturbing) renderer is deterministic."""
     W, H = int(WH[frame, 0]), int(WH[frame, 1])
     xy = all_pixel_xy(W, H, intr.device)
     fidx = torch.full([xy.shape[0]], frame, dtype=torch.long, device=intr.device)
     rays_o, rays_d = pinhole_selected_rays(xy, fidx, intr, c2w, WH)
-    was_training = renderer.training
+    was_training, cfg_saved = renderer.training, dict(renderer.config)
     renderer.eval()
+    renderer.config.update(perturb=False, depth_use_normalized_vw=True)
     try:
         ha = rays_h_appear.expand(xy.shape[0], -1).contiguous() if rays_h_appear is not None else None
         ret = renderer.render(model, rays=[rays_o, rays_d], rays_h_appear=ha, rayschunk=rayschunk, **kw)
     finally:
         renderer.train(was_training)
+        renderer.config.clear()
+        renderer.config.update(cfg_saved)
     return {k: v.reshape(H, W, *v.shape[1:]) for k, v in ret["rendered"].items()}
 
 

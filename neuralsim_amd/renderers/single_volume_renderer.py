@@ -12,7 +12,9 @@ close-range ("cr") object, which is the part of that file that sits on the hot p
   rays that hit the AABB, pose gradients detached, its batched buffer merged with the close-range packed buffer by
   ``merge_two_packs_sorted`` and scattered into the total buffers.
 
-Not mirrored yet ("next"): the sky blend (:447-457).  There is no Scene graph here: the model is passed directly (the reference looks it up through
+* the sky blend (reference :447-457): ``rgb_volume + (1 - mask_volume) * sky(v, h_appear)``.
+
+There is no Scene graph here: the model is passed directly (the reference looks it up through
 ``scene.get_drawable_groups_by_class_name``), rays are expected in the model's object space.
 """
 from typing import Callable, Dict, List, Optional

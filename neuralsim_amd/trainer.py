@@ -6,7 +6,7 @@ Follows ``Trainer.train_step_pixel`` and the main loop of the reference
 (app/loss/photometric.py:88-146), eikonal on the render samples and on uniformly sampled points
 (app/loss/eikonal.py:216-251; ``num_uniform`` code_single/tools/train.py:602-613), per-frame appearance
 embeddings (app/models/scene/image_embeddings.py:23-80).  Data is synthetic (posed pinhole cameras of
-SURVEY.md sec. 8d, random target colours).
+SURVEY.md sec. 8d; targets = the analytic image of the synthetic sphere, or random colours).
 """
 from typing import Dict, Optional
 
@@ -42,6 +42,8 @@ class RenderTrainer:
         # N > 1: overlap the table-gradient all-reduce with the second half of the scatter (NSIM_OVERLAP_ALLREDUCE=0: off)
         self.overlap_allreduce = os.environ.get("NSIM_OVERLAP_ALLREDUCE", "1") == "1"
         self._step_done = False
+        # measurement aid (bench.py ``exposed_allreduce_ms``): every rank keeps its local gradients, no collective is issued
+        self.skip_allreduce = False
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
         # (colour = 0.5 + 0.5 normal on the sphere, black elsewhere) -- multi-view consistent, keeps the geometry put
         self.target_sphere_radius = target_sphere_radius
@@ -250,10 +252,11 @@ class RenderTrainer:
         if M:
             call("nsim_eikonal_loss_fwd", ptr(nab[S:]), M, ptr(acc[2:]))
         cst = getattr(self, "_fused_consts", None)
-        if cst is None or cst[0].device != dev:
-            cst = self._fused_consts = (torch.ones([], **f32), torch.full([], float(self.w_eikonal), **f32),
+        if cst is None or cst[0] != (dev, float(self.w_eikonal)):
+            cst = self._fused_consts = ((dev, float(self.w_eikonal)), torch.ones([], **f32),
+                                        torch.full([], float(self.w_eikonal), **f32),
                                         torch.tensor([1.0, self.w_eikonal, self.w_eikonal], **f32))
-        one, w_eik, w_vec = cst
+        _, one, w_eik, w_vec = cst
         # ---------------------------------------------------------------- backward of loss = mse + w (eik + eik)
         d_img = torch.empty([N, 3], **f32)
         call("nsim_mse_loss_bwd", ptr(vec[0]), ptr(gt), N * 3, ptr(one), ptr(d_img))
@@ -302,6 +305,13 @@ class RenderTrainer:
         bucket (MLP weights, inv_s, appearance codes: ready before the scatter) goes first.  Every rank issues exactly
         this sequence whichever path produced its gradients (``scatter`` None: ``dgrid`` is complete already)."""
         grid_p = self.model.encoding.flattened_params
+        if self.skip_allreduce:
+            if scatter is not None:
+                scatter(0, 0)
+            grid_p.grad = dgrid
+            self.optim.step(grad_scale=1.0)
+            self._step_done = True
+            return
         small = [q for q in self.optim.params() if q is not grid_p]
         flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1).float() for q in small])
         tok_small = ndist.allreduce_start(flat)
@@ -443,10 +453,14 @@ class RenderTrainer:
             self._step_done = False
         else:
             # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
-            ndist.allreduce_grads(self.optim.params(), average=False)
-            self.optim.step(grad_scale=1.0 / self.world_size)
-        if refine and self.pose_delta.grad is not None:
-            if self.world_size > 1:
+            if not self.skip_allreduce:
+                ndist.allreduce_grads(self.optim.params(), average=False)
+            self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
+        if refine:
+            # every rank takes part in the collective, also one whose batch hit nothing (no graph to the poses)
+            if self.pose_delta.grad is None:
+                self.pose_delta.grad = torch.zeros_like(self.pose_delta)
+            if self.world_size > 1 and not self.skip_allreduce:
                 ndist.allreduce_grads([self.pose_delta], average=True, wire_dtype=torch.float32)
             self.pose_optim.step()
         return loss.detach()

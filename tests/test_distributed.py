@@ -131,7 +131,8 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32"):
         cfg = m.encoding.cfg
         assert h[0][0] == 0 and h[0][1] == h[1][0] and h[1][1] == cfg.num_levels
         assert h[0][2] == 0 and h[0][3] == h[1][2] == cfg.lod_offsets[h[0][1]] and h[1][3] == cfg.n_params
-    out = bench.timed_run(tr, steps=2, warmup=1, rank=rank, world=world, dev=dev, rays_per_gpu=16)
+    out, it_next = bench.timed_run(tr, steps=2, warmup=1, rank=rank, world=world, dev=dev, rays_per_gpu=16)
+    assert it_next == 257 + 2
     # replicas must still agree after the all-reduced updates
     w = m.sdf_w.detach().clone()
     ws = [torch.zeros_like(w) for _ in range(world)]

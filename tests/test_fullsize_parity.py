@@ -1,0 +1,278 @@
+"""Oracle parity AT the BASELINE configuration (configs[1]: L = 16 / T = 2^19 table with resolutions 16..2048, 2x64 SDF
+decoder, 2x64 radiance net, occupancy 64^3, num_coarse 64 + num_fine [8, 8, 32], step .005, the 100-camera 800x800
+rig; model / hyper-parameters of code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:94-190).
+
+The model is ``bench.build_trainer``'s, its weights are copied verbatim into ``oracle.field.FieldParams`` and both sides
+get identical rays, appearance codes and perturbation randoms:
+
+* ``test_api_path_*``  -- ``ray_test`` + ``ray_query`` + autograd (the drop-in path a reference renderer drives) on 2048
+  rays, both query modes.  precision f32 (exact-f32 MFMA): discrete decisions bit-exact (hit rays, march counts, merged /
+  compressed sample counts), depths / sdf / colours / images and every gradient tight.  precision fp16 (the product
+  default): images within the stated fp16 tolerance; gradients are compared on the ORACLE's sample set (the up-sampler
+  multiplies the ~1e-3 fp16 error of an SDF by inv_s = 1024, so individual fine samples move -- the sample set is
+  a continuous function of the SDFs, the arithmetic on a given set is what fp16 parity can pin).
+* ``test_fused_step_*`` -- the bench's own launch chain (``RenderTrainer._train_render_fused``: 8192 rays + 4096 uniform
+  eikonal points, compressed mode) against the oracle's loss and gradients of the same batch.
+
+GPU only (``-m gpu``): the host emulator needs hours at this size; the same comparisons at emulator size are
+tests/test_ray_query.py and tests/test_trainer.py.
+"""
+import json
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import field as ofield, render as orr
+from util import leaf, oracle_flat_grads, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+N_API = 2048
+W_EIK = 0.1
+REPORT_DIR = Path(__file__).resolve().parent.parent / "gpurun_out"
+
+# ---- tolerances.  f32 = exact-f32 MFMA validation mode; fp16 = product default.
+TOL = dict(
+    f32=dict(t=1e-4, sdf=2e-5, rgb=2e-5, nablas=2e-4, img=dict(mask_volume=2e-5, rgb_volume=2e-5, depth_volume=1e-4,
+                                                               normals_volume=2e-4),
+             grad=2e-4, loss=1e-5, flips=2),
+    fp16=dict(img=dict(mask_volume=3e-2, rgb_volume=3e-2, depth_volume=9e-2, normals_volume=3e-2),
+              sdf=4e-3, rgb=4e-3, nablas=6e-2, grad=3e-2, loss=2e-3),
+)
+
+
+def _report(name, rec):
+    try:
+        REPORT_DIR.mkdir(exist_ok=True)
+        (REPORT_DIR / f"parity_fullsize_{name}.json").write_text(json.dumps(rec, indent=1, sort_keys=True))
+    except OSError:
+        pass
+    print(f"[parity {name}] " + json.dumps(rec, sort_keys=True))
+
+
+_RIGS = {}
+
+
+def _rig(precision):
+    """bench.build_trainer (BASELINE configs[1]) + the oracle carrying the same weights and occupancy grid."""
+    if precision in _RIGS:
+        return _RIGS[precision]
+    import bench
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    tr = bench.build_trainer(dev, 0, 1, precision=precision)
+    m = tr.model
+    cfg = m.encoding.cfg
+    assert tr.num_rays == 8192 and cfg.n_params == 12196216 and list(cfg.lod_res)[-1] == 2048 and m.sdf_D == 2
+    p = ofield.params_from_flat(cfg.lod_res, 19, m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b,
+                                m.ln_inv_s, sdf_D=2, ln_inv_s_factor=m.ln_inv_s_factor)
+    occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
+    _RIGS[precision] = (tr, p, occ, dev)
+    return _RIGS[precision]
+
+
+def _fresh(p):
+    for t in p.tensors():
+        t.grad = None
+        t.requires_grad_(True)
+    return p
+
+
+def _zero_grads(tr):
+    m = tr.model
+    for q in (m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s, tr.appear):
+        q.grad = None
+
+
+def _product_grads(tr):
+    m = tr.model
+    return dict(grid=m.encoding.flattened_params.grad, sdf_w=m.sdf_w.grad, sdf_b=m.sdf_b.grad, rad_w=m.rad_w.grad,
+                rad_b=m.rad_b.grad, ln_inv_s=m.ln_inv_s.grad)
+
+
+def _batch(tr, N, seed):
+    """N rays of the rig (+ targets = the analytic sphere image, per-ray appearance codes, perturbation randoms)."""
+    g = torch.Generator().manual_seed(seed)
+    V = tr.intr.shape[0]
+    xy = torch.rand(N, 2, generator=g).clamp(1e-6, 1 - 1e-6)
+    fidx = torch.randint(0, V, (N,), generator=g)
+    o, d = orr.pinhole_rays(xy, fidx, tr.intr.cpu(), tr.c2w.cpu(), tr.WH.cpu())
+    jit, jit_c = torch.rand(N, generator=g), torch.rand(N, 64, generator=g)
+    ha = tr.appear.detach().cpu()[fidx].clone()
+    dev = tr.model.device
+    gt = tr.sphere_image(o.to(dev), d.to(dev), 0.75).cpu()
+    return o, d, fidx, ha, jit, jit_c, gt
+
+
+def _oracle_query(p, occ, tr, o, d, ha, jit, jit_c, compressed, **kw):
+    a = tr.model.accel.aabb.detach().cpu()
+    return orr.ray_query(p, o, d, ha, occ, a[0], a[1], tr.model.accel.resolution, near=0.01, far=None, jitter=jit,
+                         jitter_c=jit_c, depth_use_normalized_vw=False, compress=compressed, compress_thre=1e-4, **kw)
+
+
+@pytest.mark.parametrize("compressed", [True, False])
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
+    tr, p, occ, dev = _rig(precision)
+    m = tr.model
+    tol = TOL[precision]
+    N = N_API
+    o, d, fidx, ha, jit, jit_c, gt = _batch(tr, N, seed=11)
+    _fresh(p)
+    ha_o = leaf(ha)
+    ret_o = _oracle_query(p, occ, tr, o, d, ha_o, jit, jit_c, compressed)
+    loss_o, _ = orr.render_loss(ret_o, gt, N, w_eikonal=W_EIK)
+    loss_o.backward()
+    ref = oracle_flat_grads(p)
+    vbo = ret_o["volume_buffer"]
+    ri = ret_o["rays_inds"]
+    dv = lambda a: a.to(dev).contiguous()        # noqa: E731
+    mode = "march_occ_multi_upsample" + ("_compressed" if compressed else "")
+    rec = dict(precision=precision, mode=mode, rays=N, hit=int(ri.shape[0]), samples_oracle=int(vbo["t"].shape[0]))
+
+    # ---------------------------------------------------------------- end to end through the model's API
+    _zero_grads(tr)
+    ha_p = leaf(ha, dev)
+    tested = m.ray_test(dv(o), dv(d), near=0.01, far=None, rays_h_appear=ha_p)
+    assert tested["num_rays"] == ret_o["num_rays"] and torch.equal(tested["rays_inds"].cpu(), ri)
+    cfg = dict(m.ray_query_cfg)
+    cfg.update(query_mode=mode, with_rgb=True, with_normal=True, depth_use_normalized_vw=False, _render=True,
+               _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]))
+    ret = m.ray_query(ray_tested=tested, config=cfg, return_details=True)
+    vb = ret["volume_buffer"]
+    assert torch.equal(ret["details"]["march_counts"].cpu(), ret_o["debug"]["march_counts"])     # bit-exact, any precision
+    rec["samples"] = int(vb["t"].shape[0])
+    n_p, n_o = vb["pack_infos_hit"][:, 1].cpu(), vbo["pack_infos_hit"][:, 1]
+    rec["rays_with_other_count"] = int((n_p != n_o).sum())
+    # the no-grad SDFs of the sampling pass (un-compressed set): same points in f32 mode
+    sdf_ng, sdf_ng_o = ret["details"]["sdf_nograd"].cpu(), ret_o["debug"]["sdf_nograd"]
+    assert sdf_ng.shape == sdf_ng_o.shape            # march + 64 coarse + 48 fine per ray on both sides
+    rec["sdf_nograd_max"] = float((sdf_ng - sdf_ng_o).abs().max())
+    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+        rec["img_" + k] = float((ret["rendered"][k].cpu() - ret_o["rendered"][k]).abs().max())
+    mse = float(((ret["rendered"]["rgb_volume"].cpu() - ret_o["rendered"]["rgb_volume"]) ** 2).mean())
+    rec["psnr_rgb_db"] = round(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2)
+    same = None
+    if precision == "f32":
+        # compress keep decisions (vw > 1e-4) sit on a threshold: a 1e-6 SDF difference may flip one of ~4e5
+        assert rec["rays_with_other_count"] <= tol["flips"], rec
+        same_ray = (n_p == n_o)
+        same = torch.repeat_interleave(same_ray, n_o)               # oracle samples of rays with identical counts
+        same_p = torch.repeat_interleave(same_ray, n_p)
+        for k in ("t", "sdf", "rgb", "nablas"):
+            a, b = vb[k].detach().cpu()[same_p], vbo[k].detach()[same]
+            rec["smp_" + k] = float((a - b).abs().max())
+    rgb_full = torch.zeros(N, 3, device=dev).index_put((tested["rays_inds"],), ret["rendered"]["rgb_volume"])
+    loss = ((rgb_full - dv(gt)) ** 2).mean() + W_EIK * ((vb["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+    loss.backward()
+    rec["loss"], rec["loss_oracle"] = float(loss), float(loss_o)
+    got = _product_grads(tr)
+    got["h_appear"] = ha_p.grad
+    ref["h_appear"] = ha_o.grad
+    for k, v in got.items():
+        rec["e2e_grad_" + k] = rel_l2(v.cpu(), ref[k])
+
+    # ---------------------------------------------------------------- the differentiable part on the ORACLE's sample set
+    from neuralsim_amd.fields.neus import _FieldFn, _NeusAlphaFn, volume_integration
+    _zero_grads(tr)
+    ha_p2 = leaf(ha[ri], dev)
+    o_h, d_h = dv(o[ri]), dv(d[ri])
+    t_o, pi_o = dv(vbo["t"]), dv(vbo["pack_infos_hit"])
+    ridx_o = torch.repeat_interleave(torch.arange(ri.shape[0]), vbo["pack_infos_hit"][:, 1]).to(dev)
+    sdf, nab, rgb = _FieldFn.apply(m, m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, ha_p2, None, o_h,
+                                   d_h, t_o, ridx_o, True)
+    alpha = _NeusAlphaFn.apply(sdf, m.ln_inv_s, pi_o, m.ln_inv_s_factor, 0.0)
+    rend = volume_integration(alpha, t_o, rgb, nab, pi_o, False)
+    for k, a, b in (("sdf", sdf, vbo["sdf"]), ("rgb", rgb, vbo["rgb"]), ("nablas", nab, vbo["nablas"]),
+                    ("alpha", alpha, vbo["opacity_alpha"])):
+        rec["fix_" + k] = float((a.detach().cpu() - b.detach()).abs().max())
+    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+        rec["fix_img_" + k] = float((rend[k].detach().cpu() - ret_o["rendered"][k].detach()).abs().max())
+    rgb_full = torch.zeros(N, 3, device=dev).index_put((dv(ri),), rend["rgb_volume"])
+    loss2 = ((rgb_full - dv(gt)) ** 2).mean() + W_EIK * ((nab.norm(dim=-1) - 1.0) ** 2).mean()
+    loss2.backward()
+    rec["fix_loss"] = float(loss2)
+    got = _product_grads(tr)
+    got["h_appear"] = torch.zeros(N, 4, device=dev).index_put((dv(ri),), ha_p2.grad)
+    for k, v in got.items():
+        rec["fix_grad_" + k] = rel_l2(v.cpu(), ref[k])
+    _report(f"api_{precision}_{'compressed' if compressed else 'full'}", rec)
+
+    # ---------------------------------------------------------------- assertions
+    for k, lim in tol["img"].items():
+        assert rec["img_" + k] < lim, (k, rec["img_" + k])
+        assert rec["fix_img_" + k] < lim, ("fix", k, rec["fix_img_" + k])
+    for k in ("sdf", "rgb", "nablas"):
+        assert rec["fix_" + k] < tol[k], (k, rec["fix_" + k])
+    assert abs(rec["fix_loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
+    for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
+        assert rec["fix_grad_" + k] < tol["grad"], (k, rec["fix_grad_" + k])
+    if precision == "f32":
+        assert rec["sdf_nograd_max"] < tol["sdf"]
+        for k in ("t", "sdf", "rgb", "nablas"):
+            assert rec["smp_" + k] < tol[k], (k, rec["smp_" + k])
+        assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        if rec["rays_with_other_count"] == 0:
+            for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
+                assert rec["e2e_grad_" + k] < tol["grad"], (k, rec["e2e_grad_" + k])
+    else:
+        assert abs(rec["loss"] - rec["loss_oracle"]) < 10 * tol["loss"] * (1 + abs(rec["loss_oracle"]))
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_fused_step_matches_oracle_at_baseline_config(precision):
+    """The bench's launch chain (no autograd engine) on one full batch: 8192 rays + 4096 uniform eikonal points."""
+    tr, p, occ, dev = _rig(precision)
+    m = tr.model
+    tol = TOL[precision]
+    assert tr._fused_ok()
+    tr._prefetched = None
+    batch = tr._make_batch()
+    N = tr.num_rays
+    o, d = batch["rays_o"].cpu(), batch["rays_d"].cpu()
+    ri = batch["tested"]["rays_inds"].cpu()
+    R = int(ri.shape[0])
+    jit, jit_c = torch.zeros(N), torch.zeros(N, 64)
+    jit[ri], jit_c[ri] = batch["jitter"][:R].cpu(), batch["jitter_c"][:R].cpu()      # rows 0..R-1 serve the R hit rays
+    ha = leaf(tr.appear.detach().cpu()[batch["fidx"].cpu()])
+    gt, x_uni = batch["gt"].cpu(), batch["x_uni"].cpu()
+    _fresh(p)
+    ret_o = _oracle_query(p, occ, tr, o, d, ha, jit, jit_c, True)
+    assert torch.equal(ret_o["rays_inds"], ri)
+    loss_o, _ = orr.render_loss(ret_o, gt, N, w_eikonal=W_EIK)
+    _, nab_u = ofield.forward_sdf_nablas(x_uni, p)
+    loss_o = loss_o + W_EIK * ((nab_u.norm(dim=-1) - 1.0) ** 2).mean()
+    loss_o.backward()
+    ref = oracle_flat_grads(p)
+    ref["appear"] = torch.zeros_like(tr.appear.detach().cpu()).index_add_(0, batch["fidx"].cpu(), ha.grad)
+    # the fused chain (its prefetch hook would only draw the next batch: off for the comparison)
+    pipe, tr.pipeline = tr.pipeline, False
+    try:
+        tr.optim.zero_grad()
+        _zero_grads(tr)
+        loss = tr._train_render_fused(batch)
+    finally:
+        tr.pipeline = pipe
+    torch.cuda.synchronize()
+    got = _product_grads(tr)
+    got["appear"] = tr.appear.grad
+    rec = dict(precision=precision, rays=N, hit=R, samples=int(tr.stats["S_f"]),
+               samples_oracle=int(ret_o["volume_buffer"]["t"].shape[0]), loss=float(loss), loss_oracle=float(loss_o))
+    for k, v in got.items():
+        rec["grad_" + k] = rel_l2(v.cpu(), ref[k])
+    _report(f"fused_{precision}", rec)
+    if precision == "f32":
+        assert abs(rec["samples"] - rec["samples_oracle"]) <= 2 * tol["flips"]
+        assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        for k in got:
+            assert rec["grad_" + k] < (tol["grad"] if rec["samples"] == rec["samples_oracle"] else 5e-3), (k, rec["grad_" + k])
+    else:
+        assert abs(rec["samples"] - rec["samples_oracle"]) < 0.02 * rec["samples_oracle"]
+        assert abs(rec["loss"] - rec["loss_oracle"]) < 10 * tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        # sample membership differs (see the module docstring): the gradient of the SAME loss on a slightly different
+        # quadrature -- bounded, not tight; the tight fp16 gradient check is the fixed-sample-set leg of the API test
+        for k in got:
+            assert rec["grad_" + k] < 0.15, (k, rec["grad_" + k])

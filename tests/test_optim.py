@@ -1,0 +1,77 @@
+"""``nsim_adam_step`` (csrc/optim.hip, ``neuralsim_amd.optim.FusedAdam``) against ``torch.optim.Adam`` configured as the
+reference's ``training_cfg`` does: ``eps 1e-15, betas [0.9, 0.99]`` (lotd_neus.dtu.230814.yaml:178-184), step site
+code_single/tools/train.py:1494-1502."""
+import pytest
+import torch
+
+from neuralsim_amd import _lib
+
+
+def _torch_adam_trace(p0, grads, lr, betas, eps):
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=lr, betas=betas, eps=eps)
+    out = []
+    for g in grads:
+        p.grad = g.clone()
+        opt.step()
+        out.append(p.detach().clone())
+    return out
+
+
+@pytest.mark.parametrize("grad_scale", [1.0, 0.5])
+def test_adam_step_matches_torch_adam(backend, grad_scale):
+    dev = backend
+    g = torch.Generator().manual_seed(5)
+    n = 70001                                  # not a multiple of the block / wave size
+    p0 = (torch.rand(n, generator=g) * 2 - 1) * 1e-2
+    # gradients over many decades, some exactly zero (untouched hash entries), some tiny (eps 1e-15 matters there)
+    mag = 10.0 ** (torch.rand(5, n, generator=g) * 12 - 10)
+    grads = torch.randn(5, n, generator=g) * mag
+    grads[:, ::7] = 0.0
+    lr, betas, eps = 1e-2, (0.9, 0.99), 1e-15
+    ref = _torch_adam_trace(p0, [gr * grad_scale for gr in grads], lr, betas, eps)
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p16 = torch.zeros(n, dtype=torch.float16, device=dev)
+    for t in range(1, 6):
+        gd = grads[t - 1].to(dev).contiguous()
+        _lib.call("nsim_adam_step", _lib.ptr(p), _lib.ptr(p16), _lib.ptr(gd), _lib.ptr(m), _lib.ptr(v), n, lr, betas[0],
+                  betas[1], eps, 1.0 - betas[0] ** t, 1.0 - betas[1] ** t, float(grad_scale), 0)
+        got, want = p.cpu(), ref[t - 1]
+        # <= 1e-6 relative (a few f32 ulps of the parameter: the kernel rounds lr / bias1 * (m / denom) in another order)
+        assert float((got - want).abs().max()) < 1e-6 * (lr + float(want.abs().max())), t
+        assert torch.equal(p16.cpu(), p.cpu().half())            # the fp16 shadow the gather kernels read
+        assert torch.equal(gd.cpu(), grads[t - 1])               # zero_grad = 0 leaves the gradient alone
+    # entries that never saw a gradient do not move (untouched hash entries stay put under dense Adam)
+    assert torch.equal(p.cpu()[::7], p0[::7])
+    # zero_grad = 1 clears the gradient in the same pass
+    gd = grads[0].to(dev).contiguous()
+    _lib.call("nsim_adam_step", _lib.ptr(p), None, _lib.ptr(gd), _lib.ptr(m), _lib.ptr(v), n, lr, betas[0], betas[1], eps,
+              1.0 - betas[0] ** 6, 1.0 - betas[1] ** 6, 1.0, 1)
+    assert float(gd.abs().max()) == 0.0
+
+
+def test_fused_adam_step_range_equals_full_step(backend):
+    """``FusedAdam.step_range`` on two halves == one ``step`` (the overlapped data-parallel schedule relies on it)."""
+    from neuralsim_amd.optim import FusedAdam
+    from test_trainer import _tiny
+    outs = []
+    for split in (False, True):
+        torch.manual_seed(0)
+        m = _tiny(backend)
+        opt = FusedAdam(m, lr=1e-2)
+        gp = m.encoding.flattened_params
+        g = torch.Generator().manual_seed(1)
+        for it in range(3):
+            for q in opt.params():
+                q.grad = (torch.randn(q.shape, generator=g) * 1e-3).to(backend)
+            if split:
+                k = gp.numel() // 3
+                full = gp.grad
+                opt.step(grad_scale=0.5, skip=(gp,))
+                opt.step_range(gp, 0, k, full[:k].contiguous(), grad_scale=0.5)
+                opt.step_range(gp, k, gp.numel(), full[k:].contiguous(), grad_scale=0.5)
+            else:
+                opt.step(grad_scale=0.5)
+        outs.append([q.detach().clone().cpu() for q in opt.params()] + [m.encoding.shadow().clone().cpu()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

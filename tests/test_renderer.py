@@ -139,3 +139,26 @@ def test_evaluate_views(backend):
                          gt_masks=[(i["mask_volume"] > 0.5).cpu() for i in imgs], rays_h_appear=dv(ha), rayschunk=100)
     assert all(v > 60 for v in res["full_psnr"]) and all(v > 0.999 for v in res["full_ssim"])      # scored against itself
     assert all(a < 40 for a in first["full_psnr"]) and len(res["fg_ssim_only_in_mask"]) == 2
+
+
+def test_eval_render_is_deterministic_with_a_training_renderer(backend):
+    """``render_image`` with the TRAINER's renderer (``perturb: true``, un-normalised depth weights): evaluation applies
+    the validation settings (dtu yaml:275-278) itself -- two renders are identical and equal the val-configured one."""
+    from neuralsim_amd.eval import render_image
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=3, ln_inv_s=0.6, grid_bound=2e-2, noise_scale=1.0)
+    intr, c2w, WH = look_at_cameras(V=1, seed=5, H=12, W=12, f=11.0)
+    model = model_from_params(p, backend, precision="f32")
+    model.ray_query_cfg = dict(query_mode="march_occ_multi_upsample", query_param=QP)
+    model.accel = OccGridAccel(AABB, resolution=RES, device=backend)
+    val, _ = orr.build_occ_grid(p, AABB[0], AABB[1], RES, n_pts=2 ** 14, n_steps=2)
+    model.accel.occ_val.copy_(val.to(backend))
+    model.accel.pack_bits()
+    dv = lambda t: t.to(backend)          # noqa: E731
+    train_r = SingleVolumeRenderer(dict(with_rgb=True, near=0.01, depth_use_normalized_vw=False, perturb=True)).train()
+    val_r = SingleVolumeRenderer(dict(with_rgb=True, near=0.01, depth_use_normalized_vw=True, perturb=False)).eval()
+    a = render_image(train_r, model, dv(intr), dv(c2w), dv(WH), frame=0)
+    b = render_image(train_r, model, dv(intr), dv(c2w), dv(WH), frame=0)
+    c = render_image(val_r, model, dv(intr), dv(c2w), dv(WH), frame=0)
+    assert train_r.training and train_r.config["perturb"] is True and train_r.config["depth_use_normalized_vw"] is False
+    for k in ("rgb_volume", "depth_volume", "mask_volume"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
