@@ -573,8 +573,8 @@ class LoTDNeuSModel(nn.Module):
                               level: int = None):
         """Deterministic stand-in for the reference's SDF pre-training (``geo_init_method: pretrain_after_zero_out``,
         ``radius_init`` -- lotd_neus.dtu.230814.yaml:125-126; app/models/single/neus.py:198-236): feature 0 of the
-        finest dense level holds |x_vertex| - radius and unit 0 of every hidden layer passes it through the linear
-        region of softplus(beta) (bias +2), so the initial SDF is a (trilinearly sampled) sphere; the remaining
+        finest dense level holds |x_vertex| - radius and units 0 / 1 of every hidden layer pass +-it through
+        (softplus(s) - softplus(-s) == s), so the initial SDF is a (trilinearly sampled) sphere; the remaining
         weights keep a small random part so every gradient path is exercised."""
         cfg = self.encoding.cfg
         lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense") if level is None else int(level)
@@ -590,23 +590,28 @@ class LoTDNeuSModel(nn.Module):
         lvl[:, 0] = sdf.half().float().to(lvl.device)
         D = self.sdf_D
         F1 = 2 * cfg.num_levels
+        # units 0 / 1 of every hidden layer carry +s / -s (s = the stored SDF): softplus(s) - softplus(-s) == s exactly, and
+        # the activations are small near the surface, where the fp16 MFMA operands need their resolution (one unit
+        # carrying s + 2 through softplus' linear region has an fp16 spacing of 2e-3: a staircase SDF)
         w1 = self.sdf_w.data[:64 * F1].view(64, F1)
         w1.mul_(noise_scale)
         w1[0].zero_()
-        w1[0, 2 * lv] = 1.0
+        w1[1].zero_()
+        w1[0, 2 * lv], w1[1, 2 * lv] = 1.0, -1.0
         self.sdf_b.data[:64].mul_(noise_scale)
-        self.sdf_b.data[0] = 2.0 * self.sdf_scale      # keeps the pass-through unit in softplus' linear region
+        self.sdf_b.data[0:2] = 0.0
         if D == 2:
             w2 = self.sdf_w.data[64 * F1:64 * F1 + 4096].view(64, 64)
             w2.mul_(noise_scale)
             w2[0].zero_()
-            w2[0, 0] = 1.0
+            w2[1].zero_()
+            w2[0, 0], w2[0, 1], w2[1, 0], w2[1, 1] = 1.0, -1.0, -1.0, 1.0
             self.sdf_b.data[64:128].mul_(noise_scale)
-            self.sdf_b.data[64] = 0.0
+            self.sdf_b.data[64:66] = 0.0
         wh = self.sdf_w.data[-64:]
         wh.mul_(noise_scale * 0.05)
-        wh[0] = 1.0
-        self.sdf_b.data[-1] = -2.0 * self.sdf_scale
+        wh[0], wh[1] = 1.0, -1.0
+        self.sdf_b.data[-1] = 0.0
         self.encoding.flattened_params.add_(0)      # bump versions: refresh fp16 shadow / weight pack lazily
         self.sdf_w.add_(0)
         return self

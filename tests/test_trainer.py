@@ -130,7 +130,8 @@ def test_model_built_from_reference_model_params_trains(backend):
     for it in range(6):
         losses.append(float(tr.train_step(it)))
         active.append(m.encoding.cfg.meta.n_active_levels)
-    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    # the loss falls between two level activations (a freshly unmasked level perturbs it: hardmask annealing)
+    assert all(l == l for l in losses) and losses[2] < losses[0] and losses[-1] < losses[3], losses
     assert active[0] == 3 and active[-1] == 0                    # hardmask: levels 0..2 at it 0, all from stop_it on
     assert refreshes == [True, True]                             # it = 2 and 4, each once, with the shared generator
     assert abs(m._ctrl_mix - 0.75) < 1e-6                        # var_ctrl at it 5: (5 - 2) / (6 - 2)
