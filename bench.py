@@ -167,7 +167,7 @@ def cpu_baseline(tr, budget_s=20.0, max_iters=3):
 # fp16-MFMA rendering vs the f32 oracle on identical rays / weights (eval mode, no perturbation): asserted.
 # tests/test_fullsize_parity.py holds the same comparison (plus f32 mode, samples and gradients) under pytest.
 PARITY_RAYS = 2048
-PARITY_TOL = dict(max_abs_rgb=3e-2, min_psnr_db=45.0)
+PARITY_TOL = dict(max_abs_rgb=5e-3, min_psnr_db=60.0)      # measured: 1.4e-3 / 88 dB
 
 
 def parity_check(tr):

@@ -1198,6 +1198,135 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
   }
 }
 
+// Backward of the radiance branch, workgroup-joint weight gradients (mfma_mlp.h: "workgroup-joint weight-gradient
+// products"): the four waves of a workgroup stage their 32 points side by side (K = 128 per product), every wave owns
+// two of the eight output tiles -- dR2 tile (wave >> 1, wave & 1) and either a dR3 tile (waves 0, 1) or a dR1 tile
+// (waves 2, 3) -- in MFMA accumulator registers for the whole launch, the bias sums live in one register of the wave
+// that idles during the product.  LDS: the six weight matrices (34.5 KB) + one staging area (34.8 KB) = 69 KB -> two
+// workgroups per CU, two waves per SIMD (k_rad_bwd: 141 KB, one).  Same inputs / outputs as k_rad_bwd.
+template <int PREC>
+__global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd_j(FieldArgs a) {
+  NSIM_DYN_SMEM(smem);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  const int wave = (int)(threadIdx.x >> 6);
+  FieldLayout L;
+  int wbytes;
+  const char* W = stage_weights<PREC>(smem, a, M_R1, 6, L, wbytes);
+  char* stA = smem + wbytes;
+  char* stB = stA + 64 * jstage_row_bytes<PREC>();
+  f32x16 accR2 = zero16(), accX = zero16();
+  float bsum = 0.f;      // wave 0: d rb1[lane], wave 1: d rb2[lane], wave 2: d rb3[lane < 3]
+
+  const int64_t ntiles = (a.S + 31) / 32;
+  const int64_t ngroups = (ntiles + JOINT_WAVES - 1) / JOINT_WAVES;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t tile = grp * JOINT_WAVES + wave;          // may lie past the end: all its points are invalid (zeros)
+    const TilePoint p = load_point(a, tile, j, true);
+    const int64_t s = p.s;
+    float nab[3] = {0.f, 0.f, 0.f}, rgbv[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+    if (p.valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        nab[c] = a.nablas_fwd[3 * s + c];
+        rgbv[c] = a.rgb_fwd[3 * s + c];
+        gr[c] = a.drgb[3 * s + c];
+        if (a.dnablas) gn[c] = a.dnablas[3 * s + c];
+      }
+    }
+    float rin[16], r1[32], r2[32];
+    make_rin(rin, p, nab, a.h_appear, hi);
+    radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
+    float dout[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dout[r] = 0.f;
+    if (hi == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
+    }
+    // ---- dR3 += dout (x) r2, d rb3 += rowsum(dout)
+    __syncthreads();                              // the previous group's readers of the staging area are done
+    jstage<PREC, 1>(stA, dout, wave);
+    jstage<PREC, 2>(stB, r2, wave);
+    __syncthreads();
+    if (wave < 2) accX = jdw_tile<PREC>(stA, 0, stB, wave, accX);
+    if (wave == 2) bsum += jrow_sum<PREC>(stA, 3);
+    float dr2[32];
+    dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
+    // ---- dR2 += dr2 (x) r1, d rb2 += rowsum(dr2)
+    __syncthreads();
+    jstage<PREC, 2>(stA, dr2, wave);
+    jstage<PREC, 2>(stB, r1, wave);
+    __syncthreads();
+    accR2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accR2);
+    if (wave == 1) bsum += jrow_sum<PREC>(stA, 64);
+    float dr1[32];
+    dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
+    // ---- dR1 += dr1 (x) rin, d rb1 += rowsum(dr1)
+    __syncthreads();
+    jstage<PREC, 2>(stA, dr1, wave);
+    jstage<PREC, 1>(stB, rin, wave);
+    __syncthreads();
+    if (wave >= 2) accX = jdw_tile<PREC>(stA, wave - 2, stB, 0, accX);
+    if (wave == 0) bsum += jrow_sum<PREC>(stA, 64);
+    float din[16];
+    dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
+    // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
+    const float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
+    gn[0] += v0 + wave_shfl_xor(v0, 32);
+    gn[1] += v1 + wave_shfl_xor(v1, 32);
+    gn[2] += v2 + wave_shfl_xor(v2, 32);
+    if (p.valid && hi == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.dnab_total[3 * s + c] = gn[c];
+    }
+    if (a.dx) {   // pose refinement: the radiance net's position input (slots 0-2: hi 0, r 0..2) ...
+      if (p.valid && hi == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dx[3 * s + c] = din[c];
+      }
+    }
+    if (a.dv) {   // ... and its view direction through SH4 (slots 3-18)
+      float gsh[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int slot = k + 3, ohi = (slot >> 2) & 1, r = (slot & 3) + 4 * (slot >> 3);
+        const float v = (hi == ohi) ? din[r] : 0.f;
+        gsh[k] = v + wave_shfl_xor(v, 32);
+      }
+      float gv[3];
+      sh4_grad(p.vd, gsh, gv);
+      if (p.valid && hi == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dv[3 * s + c] = gv[c];
+      }
+    }
+    // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
+    if (a.dh_appear && p.valid) {
+      if (hi == 1) {
+        atomicAdd(&a.dh_appear[4 * p.ray + 0], din[10]);
+        atomicAdd(&a.dh_appear[4 * p.ray + 1], din[11]);
+      } else {
+        atomicAdd(&a.dh_appear[4 * p.ray + 2], din[12]);
+        atomicAdd(&a.dh_appear[4 * p.ray + 3], din[13]);
+      }
+    }
+  }
+  // ---- one flush per wave
+  const SrcOff so = src_off(1);
+  jflush_tile(a.drad_w + so.r2, 64, 64, 64, wave >> 1, wave & 1, accR2);
+  if (wave < 2) jflush_tile(a.drad_w + so.r3, 64, 3, 64, 0, wave, accX);
+  else jflush_tile(a.drad_w + so.r1, 26, 64, 26, wave - 2, 0, accX);
+  if (bsum != 0.f) {
+    if (wave == 0) atomicAdd(&a.drad_b[so.rb1 + lane], bsum);
+    else if (wave == 1) atomicAdd(&a.drad_b[so.rb2 + lane], bsum);
+    else if (wave == 2 && lane < 3) atomicAdd(&a.drad_b[so.rb3 + lane], bsum);
+  }
+}
+
 // ------------------------------------------------------------------------------------ grid scatter
 // dgrid[level][vertex][f] += w_c * dh[f] + g[f] * dscale * (dw_c . gn)      (first + second order terms)
 //
@@ -1696,12 +1825,25 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
   a.dx = dx; a.dv = dv;
   a.has_rgb = 1;
-  const RadAccOff RO = rad_acc_off();
+  const int64_t tiles = (S + 31) / 32;
+  const char* oldp = getenv("NSIM_RAD_BWD_OLD");      // A/B aid: the per-wave LDS-accumulator kernel of round 1
+  const bool old_path = oldp && atoi(oldp) == 1;
+  if (!old_path) {
+    // workgroup-joint weight gradients: weights + one staging area in LDS, two workgroups per CU
+    const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
+    const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + 128 * row;
+    int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
+    nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+    const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
+    if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd_j<0>), grid, block, shmem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_rad_bwd_j<1>), grid, block, shmem, (hipStream_t)stream, a);
+    NSIM_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t racc = (6144 * 4 + 15) & ~15;
   const size_t shmem = meta->precision == 0
                            ? weights_lds_bytes(meta, M_R1, 0) + RAD_WAVES * racc + RAD_WAVES * stage_bytes(meta)
                            : weights_lds_bytes(meta, M_R1, 6) + racc + RAD_WAVES * stage_bytes(meta);
-  const int64_t tiles = (S + 31) / 32;
   int64_t nb = (tiles + RAD_WAVES - 1) / RAD_WAVES;
   nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
   const dim3 grid((unsigned)nb), block(64 * RAD_WAVES);

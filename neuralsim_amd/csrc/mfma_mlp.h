@@ -232,3 +232,103 @@ __device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16],
   }
 }
 
+
+// ===================================================================== workgroup-joint weight-gradient products
+// The weight gradients contract over POINTS.  Instead of one 32-point product per wave and tile (with its accumulator
+// read-add-written in LDS after every tile: 16 ds_read + 16 ds_write per lane and output tile, four private 25 KB
+// accumulator copies -> one workgroup per CU), the NW waves of a workgroup stage their activations side by side
+// ([unit][32 NW points]) and every wave owns a FIXED subset of the output tiles, which it keeps in MFMA accumulator
+// registers for the whole launch: no read-modify-write at all, no accumulators in LDS, one flush per wave at the end.
+// fp16 mode stages bf16 (v_mfma_f32_32x32x16_bf16, same rate as f16 on gfx950): the f32 exponent range makes the
+// per-tile power-of-two re-scaling of the f16 operands unnecessary, which is what allows the accumulation to run
+// ACROSS tiles; the operands keep 8 significant bits, the sum is f32.  f32 mode stages f32 (exact, validation).
+#define JOINT_WAVES 4
+#define JOINT_PTS (32 * JOINT_WAVES)
+
+template <int PREC>
+struct JStageT {
+  typedef bf16 T;
+  static constexpr int PITCH = JOINT_PTS + 8;     // 272 B rows: 16-byte aligned, conflict-free ds_read_b128
+};
+template <>
+struct JStageT<1> {
+  typedef float T;
+  static constexpr int PITCH = JOINT_PTS + 1;
+};
+
+template <int PREC>
+__host__ __device__ constexpr int jstage_row_bytes() {
+  return JStageT<PREC>::PITCH * (int)sizeof(typename JStageT<PREC>::T);
+}
+
+// write this wave's 32 points of an activation (NM m-tiles in activation-register order) into rows [0, 32 NM) of ``st``
+template <int PREC, int NM>
+__device__ __forceinline__ void jstage(void* st, const float (&v)[NM * 16], int wave) {
+  typedef typename JStageT<PREC>::T T;
+  T* p = reinterpret_cast<T*>(st);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = (T)v[m * 16 + r];
+}
+
+// acc += A[32 mo + row][:] . B[32 no + col][:]^T over the JOINT_PTS staged points
+template <int PREC>
+__device__ __forceinline__ f32x16 jdw_tile(const void* stA, int mo, const void* stB, int no, f32x16 acc) {
+  typedef typename JStageT<PREC>::T T;
+  constexpr int P = JStageT<PREC>::PITCH;
+  const T* a = reinterpret_cast<const T*>(stA);
+  const T* b = reinterpret_cast<const T*>(stB);
+  const int lane = nsim_lane(), i = lane & 31, hi = lane >> 5;
+  if constexpr (PREC == 0) {
+#pragma unroll
+    for (int s = 0; s < JOINT_PTS / 16; ++s) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + (32 * mo + i) * P + 16 * s + 8 * hi);
+      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + (32 * no + i) * P + 16 * s + 8 * hi);
+      acc = mfma_32x32x16_bf16(av, bv, acc);
+    }
+  } else {
+#pragma unroll 8
+    for (int q = 0; q < JOINT_PTS / 2; ++q) {
+      const float av = a[(32 * mo + i) * P + 2 * q + hi];
+      const float bv = b[(32 * no + i) * P + 2 * q + hi];
+      acc = mfma_32x32x2_f32(av, bv, acc);
+    }
+  }
+  return acc;
+}
+
+// sum over the staged points of row ``lane`` (bias gradients): valid for lane < rows
+template <int PREC>
+__device__ __forceinline__ float jrow_sum(const void* stA, int rows) {
+  typedef typename JStageT<PREC>::T T;
+  constexpr int P = JStageT<PREC>::PITCH;
+  const T* a = reinterpret_cast<const T*>(stA);
+  const int lane = nsim_lane();
+  float s = 0.f;
+  if (lane < rows) {
+    if constexpr (PREC == 0) {
+#pragma unroll
+      for (int q = 0; q < JOINT_PTS / 8; ++q) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + lane * P + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e];
+      }
+    } else {
+      for (int q = 0; q < JOINT_PTS; ++q) s += a[lane * P + q];
+    }
+  }
+  return s;
+}
+
+// flush an accumulator tile with global atomics: dst[(32 mo + row) * ld + 32 no + col], rows < rows, cols < cols
+__device__ __forceinline__ void jflush_tile(float* dst, int ld, int rows, int cols, int mo, int no, const f32x16& acc) {
+  const int lane = nsim_lane(), col = 32 * no + (lane & 31), hi = lane >> 5;
+  if (col >= cols) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * mo + mfma_row(r, hi);
+    if (row < rows && acc[r] != 0.f) atomicAdd(&dst[row * ld + col], acc[r]);
+  }
+}

@@ -25,6 +25,8 @@
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ cross-lane
 __device__ __forceinline__ int nsim_lane() {
@@ -205,6 +207,22 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) 
   return d;
 #else
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_32x32x16_bf16: same fragment layout and rate as the f16 form, operands with the f32 exponent range.
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef NSIM_HOST_EMU
+  bf16 aa[8], bb[8];
+  float cc[16], dd[16];
+  for (int e = 0; e < 8; ++e) { aa[e] = a[e]; bb[e] = b[e]; }
+  for (int r = 0; r < 16; ++r) cc[r] = c[r];
+  emu::mfma32<bf16, 8>(aa, bb, cc, dd);
+  f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = dd[r];
+  return d;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #endif
 }
 

@@ -9,7 +9,7 @@ get identical rays, appearance codes and perturbation randoms:
   rays, both query modes.  precision f32 (exact-f32 MFMA): discrete decisions bit-exact (hit rays, march counts, merged /
   compressed sample counts), depths / sdf / colours / images and every gradient tight.  precision fp16 (the product
   default): images within the stated fp16 tolerance; gradients are compared on the ORACLE's sample set (the up-sampler
-  multiplies the ~1e-3 fp16 error of an SDF by inv_s = 1024, so individual fine samples move -- the sample set is
+  multiplies the ~1e-4 fp16 error of an SDF by inv_s = 1024, so individual fine samples move -- the sample set is
   a continuous function of the SDFs, the arithmetic on a given set is what fp16 parity can pin).
 * ``test_fused_step_*`` -- the bench's own launch chain (``RenderTrainer._train_render_fused``: 8192 rays + 4096 uniform
   eikonal points, compressed mode) against the oracle's loss and gradients of the same batch.
@@ -38,11 +38,17 @@ TOL = dict(
     # sample-level values (t, and sdf / nablas / rgb AT those t) carry the up-sampler's sensitivity: the inverse-CDF step
     # divides by CDF increments down to 1e-5, so 1e-6 differences of the no-grad SDFs move a fine sample by up to ~1e-3
     # -- the images and the fixed-sample-set values are the tight checks
-    f32=dict(t=3e-3, sdf=2e-3, rgb=1e-4, nablas=2e-3, fix=dict(sdf=2e-5, rgb=2e-5, nablas=2e-4),
+    # (nablas: a sample that moves by 2e-4 crosses cells of the res-2048 level, whose features are hash noise)
+    f32=dict(t=3e-3, sdf=2e-3, rgb=1e-4, nablas=3e-2, fix=dict(sdf=2e-5, rgb=2e-5, nablas=2e-4),
              img=dict(mask_volume=1e-4, rgb_volume=1e-4, depth_volume=2e-4, normals_volume=1e-4),
              grad=5e-4, loss=1e-5, flips=2),
-    fp16=dict(img=dict(mask_volume=3e-2, rgb_volume=3e-2, depth_volume=9e-2, normals_volume=3e-2),
-              fix=dict(sdf=4e-3, rgb=4e-3, nablas=6e-2), grad=3e-2, loss=2e-3),
+    # fp16 MFMA operands (measured at this config: images <= 2.3e-3, sdf 2.4e-4 / 5e-5 near the surface, nablas 5.5e-4).
+    # Gradients on the oracle's sample set: 3e-2 on the compressed set (samples near the surface; measured 5e-3); the
+    # un-compressed set is dominated by samples far from the surface where the eikonal residual |n| - 1 ~ 1e-3 is a
+    # difference of cancelling terms -- the 5e-4 fp16 error of n is half of it (measured 6e-2 on the table gradient; the
+    # f32 kernels give 1.5e-6 on the same set, i.e. the same conditioning x the f32 / fp16 epsilon ratio)
+    fp16=dict(img=dict(mask_volume=5e-3, rgb_volume=5e-3, depth_volume=1e-2, normals_volume=1e-2),
+              fix=dict(sdf=1e-3, rgb=1e-3, nablas=5e-3), grad=3e-2, grad_full=1e-1, loss=2e-3),
 )
 
 
@@ -219,8 +225,9 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
     for k in ("sdf", "rgb", "nablas"):
         assert rec["fix_" + k] < tol["fix"][k], (k, rec["fix_" + k])
     assert abs(rec["fix_loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
+    gtol = tol["grad"] if (compressed or precision == "f32") else tol["grad_full"]
     for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
-        assert rec["fix_grad_" + k] < tol["grad"], (k, rec["fix_grad_" + k])
+        assert rec["fix_grad_" + k] < gtol, (k, rec["fix_grad_" + k])
     if precision == "f32":
         assert rec["sdf_nograd_max"] < tol["sdf"]
         assert rec["march_coarse_sdf_max"] < tol["fix"]["sdf"]
@@ -231,7 +238,12 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
             for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
                 assert rec["e2e_grad_" + k] < tol["grad"], (k, rec["e2e_grad_" + k])
     else:
-        assert abs(rec["loss"] - rec["loss_oracle"]) < 10 * tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        assert rec["psnr_rgb_db"] > 60.0
+        # end to end the fp16 sampler places a few fine samples elsewhere (59 of 2038 rays kept another count): the table
+        # gradient is entry-specific at the res-2048 level (cell 1e-3), so its rel-L2 is bounded, not tight
+        for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
+            assert rec["e2e_grad_" + k] < 0.15, (k, rec["e2e_grad_" + k])
 
 
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
@@ -282,8 +294,8 @@ def test_fused_step_matches_oracle_at_baseline_config(precision):
         for k in got:
             assert rec["grad_" + k] < (tol["grad"] if rec["samples"] == rec["samples_oracle"] else 5e-3), (k, rec["grad_" + k])
     else:
-        assert abs(rec["samples"] - rec["samples_oracle"]) < 0.02 * rec["samples_oracle"]
-        assert abs(rec["loss"] - rec["loss_oracle"]) < 10 * tol["loss"] * (1 + abs(rec["loss_oracle"]))
+        assert abs(rec["samples"] - rec["samples_oracle"]) < 0.005 * rec["samples_oracle"]
+        assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
         # sample membership differs (see the module docstring): the gradient of the SAME loss on a slightly different
         # quadrature -- bounded, not tight; the tight fp16 gradient check is the fixed-sample-set leg of the API test
         for k in got:
