@@ -282,6 +282,20 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 
 #define FIELD_WAVES 4
 
+// Development aid (-DNSIM_KTIME, never in the product build): s_memtime stamps of wave 0 of the first 64 workgroups at
+// phase boundaries of their SECOND group iteration, read back by tools/ktime.py through nsim_debug_ktime.
+#ifdef NSIM_KTIME
+__device__ long long g_ktime[2][64 * 24];
+#define KT(K, i)                                                                                          \
+  if (blockIdx.x < 64 && wave == 0 && lane == 0 && (grp == (int64_t)blockIdx.x + gridDim.x || (i) >= 20)) \
+  g_ktime[K][blockIdx.x * 24 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+extern "C" int nsim_debug_ktime(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktime), sizeof(g_ktime));
+}
+#else
+#define KT(K, i)
+#endif
+
 // Copy the MFMA fragments a kernel needs into LDS (fp16 mode) and return a layout whose offsets are relative to the
 // LDS copy: matrices [first, first+count) are contiguous in the pack, the per-lane vectors follow.  The f32
 // validation mode reads fragments from global/L2.
@@ -359,15 +373,19 @@ __device__ __forceinline__ void make_rin(float (&rin)[16], const TilePoint& p, c
 #pragma unroll
     for (int c = 0; c < 4; ++c) ha[c] = h_appear[4 * p.ray + c];
   }
+  // register r holds slot U(0,r,0) on the hi == 0 lanes and U(0,r,1) = U(0,r,0) + 4 on the others: both candidates are
+  // compile-time selections, one v_cndmask per register (a slot computed from the lane would cost a compare chain each)
+  auto slot_val = [&](int slot) -> float {
+    if (slot < 3) return p.xx[slot];
+    if (slot < 19) return sh[slot - 3];
+    if (slot < 22) return nab[slot - 19];
+    if (slot < 26) return ha[slot - 22];
+    return 0.f;
+  };
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int slot = unit_of(0, r, hi);
-    float v = 0.f;
-    if (slot < 3) v = p.xx[slot];
-    else if (slot < 19) v = sh[slot - 3];
-    else if (slot < 22) v = nab[slot - 19];
-    else if (slot < 26) v = ha[slot - 22];
-    rin[r] = v;
+    const float v0 = slot_val(unit_of(0, r, 0)), v1 = slot_val(unit_of(0, r, 1));
+    rin[r] = hi ? v1 : v0;
   }
 }
 
@@ -785,6 +803,252 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       if (dst) atomicAdd(dst, v);
     }
   }
+}
+
+// Backward of the SDF branch (the work of k_field<., ., 2>) with workgroup-joint weight gradients (mfma_mlp.h): per group of
+// 4 x 32 points the waves stage the operands of the four weight-gradient products side by side; wave w owns the dW2 tile
+// (w >> 1, w & 1) and the dW1 tile w & 1 over the point half w >> 1, both in MFMA accumulator registers for the whole
+// launch; bias / head-weight sums are one register each.  LDS: W1, W2, W2T, W1T + vectors (26 KB) + staging 192 rows
+// (51 KB) = 77 KB -> two workgroups per CU.  J (dh/dx, 48 registers in k_field) is consumed straight from its loads
+// into dL/dg, h is re-read for the last product, g leaves for the scatter as soon as it exists: the live set fits
+// 256 registers = two waves per SIMD (k_field<0,2,2>: 468 registers, 145 KB LDS -> one wave per SIMD).
+// 16-level pyramids (NC = 1); more levels keep k_field<., ., 2, 2>.
+template <int PREC, int SDF_D>
+__global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_bwd_j(FieldArgs a) {
+  NSIM_DYN_SMEM(smem);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  const int wave = (int)(threadIdx.x >> 6);
+  const float beta = a.beta, inv_beta = 1.0f / a.beta;
+  FieldLayout L;
+  int wbytes = 0;
+  const char* W = stage_weights<PREC>(smem, a, 0, 4, L, wbytes);
+  char* stA = smem + wbytes;
+  char* stB = stA + 64 * jstage_row_bytes<PREC>();
+  char* stC = stB + 64 * jstage_row_bytes<PREC>();
+  f32x16 accW1 = zero16(), accW2 = zero16();
+  float bs1 = 0.f, bs2 = 0.f, bsh = 0.f, bh = 0.f;      // this wave's share of d b1[lane], d b2[lane], d wh[lane], d b_head
+  const bool do_dw = !(a.ablate & 4);
+
+  const int64_t ntiles = (a.S + 31) / 32;
+  const int64_t ngroups = (ntiles + JOINT_WAVES - 1) / JOINT_WAVES;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t s = (grp * JOINT_WAVES + wave) * 32 + j;      // past the end: an invalid point contributes zeros
+    const bool valid = s < a.S;
+    // the per-lane bias / head vectors are re-read from LDS where they are used: an address the compiler cannot prove
+    // loop-invariant keeps it from hoisting 96 of them into registers for the whole launch
+    int vo = 0;
+#ifndef NSIM_HOST_EMU
+    asm volatile("" : "+v"(vo));
+#endif
+    const char* Wv = W + vo;
+    float gs = 0.f, gn[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      if (a.dsdf) gs = a.dsdf[s];
+      if (a.dnablas) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gn[c] = a.dnablas[3 * s + c];
+      }
+    }
+    // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
+    float gh[16];
+    auto load_h = [&](float (&h)[16]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          h[r0] = h[r0 + 1] = 0.f;
+          if (valid) {
+            const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+            h[r0] = hp[0];
+            h[r0 + 1] = hp[1];
+          }
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+        gh[r0] = gh[r0 + 1] = 0.f;
+        if (valid) {
+          const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+          gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
+          gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+        }
+      }
+    // ---- decoder forward (recomputed) and d sdf / d h
+    float a1[32];
+    {
+      float h[16];
+      load_h(h);
+      dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(Wv, L, V_B1, hi, k), beta, inv_beta);
+    float a2[32];
+    float d1[32];      // d sdf / d z1 = sigma(beta z1) . e1, e1 = d sdf / d a1 (not kept: e1 sigma1 == d1 wherever it is needed)
+    if constexpr (SDF_D == 2) {
+      dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a2[k] = softplus_b(a2[k] + vecf(Wv, L, V_B2, hi, k), beta, inv_beta);
+      float d2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(Wv, L, V_WH, hi, k);
+      dense<PREC, 2, 2>(d1, W + L.mat[M_W2T], d2, false);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d1[k] = sig_from_softplus(a1[k], beta) * d1[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        a2[k] = a1[k];
+        d1[k] = sig_from_softplus(a1[k], beta) * vecf(Wv, L, V_WH, hi, k);
+      }
+    }
+    {
+      float g[16];
+      dense<PREC, 1, 2>(g, W + L.mat[M_W1T], d1, false);
+      if (valid && a.g_pl) {      // hand-off to the scatter kernel: g = d sdf / d h
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+            float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
+            gp[0] = g[r0];
+            gp[1] = g[r0 + 1];
+          }
+      }
+    }
+    // ======================================================================================= backward
+    // ---- dW1 += d1 (x) gh
+    __syncthreads();                              // the previous group's readers of the staging areas are done
+    jstage<PREC, 2>(stA, d1, wave);
+    jstage<PREC, 1>(stB, gh, wave);
+    __syncthreads();
+    if (do_dw) {
+      if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
+      else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
+    }
+    float dh1[32];  // dL / d d1 = W1 . gh
+    dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
+    float dz1[32], whv[32];
+    if constexpr (SDF_D == 2) {
+      float eh1[32];  // dL / d e1
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float s1 = sig_from_softplus(a1[k], beta);
+        dz1[k] = dh1[k] * d1[k] * (beta * (1.0f - s1));      // dh1 e1 beta s1 (1 - s1), e1 s1 = d1
+        eh1[k] = dh1[k] * s1;
+      }
+      float d2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(Wv, L, V_WH, hi, k);
+      // ---- dW2 += d2 (x) eh1
+      __syncthreads();
+      jstage<PREC, 2>(stA, d2, wave);
+      jstage<PREC, 2>(stB, eh1, wave);
+      __syncthreads();
+      if (do_dw) accW2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW2);
+      float dh2[32];  // dL / d d2 = W2 . eh1
+      dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
+      float dz2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float s2 = sig_from_softplus(a2[k], beta);
+        const float wh = vecf(Wv, L, V_WH, hi, k);
+        whv[k] = dh2[k] * s2 + gs * a2[k];
+        dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
+      }
+      // ---- dW2 += dz2 (x) a1, d b2 += rowsum(dz2), d wh += rowsum(whv)
+      __syncthreads();
+      jstage<PREC, 2>(stA, dz2, wave);
+      jstage<PREC, 2>(stB, a1, wave);
+      jstage<PREC, 2>(stC, whv, wave);
+      __syncthreads();
+      if (do_dw) {
+        accW2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW2);
+        bs2 += jrow_sum<PREC>(stA, 64, wave);
+        bsh += jrow_sum<PREC>(stC, 64, wave);
+      }
+      float da1[32];
+      dense<PREC, 2, 2>(da1, W + L.mat[M_W2T], dz2, true);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) dz1[k] = dz1[k] + da1[k] * sig_from_softplus(a1[k], beta);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float s1 = sig_from_softplus(a1[k], beta);
+        const float wh = vecf(Wv, L, V_WH, hi, k);
+        whv[k] = dh1[k] * s1 + gs * a1[k];
+        dz1[k] = gs * wh * s1 + dh1[k] * wh * (beta * s1 * (1.0f - s1));
+      }
+    }
+    {
+      float v = (hi == 0) ? gs : 0.f;
+      bh += wave_sum(v);
+    }
+    // ---- dW1 += dz1 (x) h, d b1 += rowsum(dz1)  (+ d wh when there is one hidden layer)
+    __syncthreads();
+    jstage<PREC, 2>(stA, dz1, wave);
+    {
+      float h[16];      // re-read (L2-warm) rather than kept in 16 registers across the whole tile
+      load_h(h);
+      jstage<PREC, 1>(stB, h, wave);
+    }
+    if constexpr (SDF_D == 1) jstage<PREC, 2>(stC, whv, wave);
+    __syncthreads();
+    if (do_dw) {
+      if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
+      else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
+      bs1 += jrow_sum<PREC>(stA, 64, wave);
+      if constexpr (SDF_D == 1) bsh += jrow_sum<PREC>(stC, 64, wave);
+    }
+    float dh[16];
+    dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
+    if (a.dx) {   // pose refinement: dL/dx += (dh/dx)^T dL/dh  (dh/dx re-read from the planes: this path is rare)
+      float acc[3] = {0.f, 0.f, 0.f};
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+            const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
+          }
+      }
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
+      if (valid && hi == 0) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) a.dx[3 * s + c3] = a.dx[3 * s + c3] + acc[c3];
+      }
+    }
+    if (valid && a.dh_pl) {      // hand-off to the scatter kernel: dL/dh
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
+          dp[0] = dh[r0];
+          dp[1] = dh[r0 + 1];
+        }
+    }
+  }
+  // ---- one flush per wave
+  const int F1 = 2 * a.lotd.num_levels;
+  const SrcOff so = src_off(SDF_D, F1);
+  jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave & 1, 0, accW1);
+  if constexpr (SDF_D == 2) {
+    jflush_tile(a.dsdf_w + so.w2, 64, 64, 64, wave >> 1, wave & 1, accW2);
+    if (bs2 != 0.f) atomicAdd(&a.dsdf_b[so.b2 + lane], bs2);
+  }
+  if (bs1 != 0.f) atomicAdd(&a.dsdf_b[so.b1 + lane], bs1);
+  if (bsh != 0.f) atomicAdd(&a.dsdf_w[so.wh + lane], bsh);
+  if (lane == 0 && bh != 0.f) atomicAdd(&a.dsdf_b[so.bh], bh);
 }
 
 // No-grad SDF query (all sampling / occupancy-refresh traffic goes through here).  Lean variant of the forward:
@@ -1211,15 +1475,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
   const int wave = (int)(threadIdx.x >> 6);
   FieldLayout L;
   int wbytes;
+  { const int64_t grp = -1; KT(0, 23); }
   const char* W = stage_weights<PREC>(smem, a, M_R1, 6, L, wbytes);
   char* stA = smem + wbytes;
   char* stB = stA + 64 * jstage_row_bytes<PREC>();
   f32x16 accR2 = zero16(), accX = zero16();
-  float bsum = 0.f;      // wave 0: d rb1[lane], wave 1: d rb2[lane], wave 2: d rb3[lane < 3]
+  float bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;      // this wave's share of d rb1[lane], d rb2[lane], d rb3[lane < 3]
 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t ngroups = (ntiles + JOINT_WAVES - 1) / JOINT_WAVES;
+  { const int64_t grp = -1; KT(0, 20); }
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    KT(0, 0);
     const int64_t tile = grp * JOINT_WAVES + wave;          // may lie past the end: all its points are invalid (zeros)
     const TilePoint p = load_point(a, tile, j, true);
     const int64_t s = p.s;
@@ -1235,7 +1502,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
     }
     float rin[16], r1[32], r2[32];
     make_rin(rin, p, nab, a.h_appear, hi);
+    KT(0, 1);
     radiance_hidden<PREC>(r1, r2, rin, W, L, hi);
+    KT(0, 2);
     float dout[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dout[r] = 0.f;
@@ -1243,37 +1512,66 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
 #pragma unroll
       for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
     }
+    // ONE exact power-of-two scale per tile for the whole backward chain (fp16 operands): the chain only multiplies by
+    // weight matrices (|W| <~ 1, width 64) and relu masks, so every later value stays within ~2^-13 .. 2^6 of the
+    // scaled input -- well inside fp16's range; it is carried scaled (``*s``) and unscaled where it leaves the chain
+    const float sc = dyn_scale<PREC, 16>(dout), inv_sc = 1.0f / sc;
+    float douts[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) douts[r] = dout[r] * sc;
     // ---- dR3 += dout (x) r2, d rb3 += rowsum(dout)
+    KT(0, 3);
     __syncthreads();                              // the previous group's readers of the staging area are done
+    KT(0, 4);
     jstage<PREC, 1>(stA, dout, wave);
     jstage<PREC, 2>(stB, r2, wave);
+    KT(0, 5);
     __syncthreads();
+    KT(0, 6);
     if (wave < 2) accX = jdw_tile<PREC>(stA, 0, stB, wave, accX);
-    if (wave == 2) bsum += jrow_sum<PREC>(stA, 3);
-    float dr2[32];
-    dense<PREC, 2, 1>(dr2, W + L.mat[M_R3T], dout, true);
+    bs3 += jrow_sum<PREC>(stA, 3, wave);
+    KT(0, 7);
+    float dr2s[32], dr2[32];
+    dense<PREC, 2, 1>(dr2s, W + L.mat[M_R3T], douts, false);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
+    for (int k = 0; k < 32; ++k) {
+      dr2s[k] = r2[k] > 0.f ? dr2s[k] : 0.f;
+      dr2[k] = dr2s[k] * inv_sc;
+    }
     // ---- dR2 += dr2 (x) r1, d rb2 += rowsum(dr2)
+    KT(0, 8);
     __syncthreads();
+    KT(0, 9);
     jstage<PREC, 2>(stA, dr2, wave);
     jstage<PREC, 2>(stB, r1, wave);
+    KT(0, 10);
     __syncthreads();
+    KT(0, 11);
     accR2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accR2);
-    if (wave == 1) bsum += jrow_sum<PREC>(stA, 64);
-    float dr1[32];
-    dense<PREC, 2, 2>(dr1, W + L.mat[M_R2T], dr2, true);
+    bs2 += jrow_sum<PREC>(stA, 64, wave);
+    KT(0, 12);
+    float dr1s[32], dr1[32];
+    dense<PREC, 2, 2>(dr1s, W + L.mat[M_R2T], dr2s, false);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
+    for (int k = 0; k < 32; ++k) {
+      dr1s[k] = r1[k] > 0.f ? dr1s[k] : 0.f;
+      dr1[k] = dr1s[k] * inv_sc;
+    }
     // ---- dR1 += dr1 (x) rin, d rb1 += rowsum(dr1)
+    KT(0, 13);
     __syncthreads();
+    KT(0, 14);
     jstage<PREC, 2>(stA, dr1, wave);
     jstage<PREC, 1>(stB, rin, wave);
     __syncthreads();
+    KT(0, 15);
     if (wave >= 2) accX = jdw_tile<PREC>(stA, wave - 2, stB, 0, accX);
-    if (wave == 0) bsum += jrow_sum<PREC>(stA, 64);
+    bs1 += jrow_sum<PREC>(stA, 64, wave);
+    KT(0, 16);
     float din[16];
-    dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1, true);
+    dense<PREC, 1, 2>(din, W + L.mat[M_R1T], dr1s, false);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) din[r] = din[r] * inv_sc;
     // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
     const float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
     gn[0] += v0 + wave_shfl_xor(v0, 32);
@@ -1314,17 +1612,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
         atomicAdd(&a.dh_appear[4 * p.ray + 3], din[13]);
       }
     }
+    KT(0, 17);
   }
+  { const int64_t grp = -1; KT(0, 21); }
   // ---- one flush per wave
   const SrcOff so = src_off(1);
   jflush_tile(a.drad_w + so.r2, 64, 64, 64, wave >> 1, wave & 1, accR2);
   if (wave < 2) jflush_tile(a.drad_w + so.r3, 64, 3, 64, 0, wave, accX);
   else jflush_tile(a.drad_w + so.r1, 26, 64, 26, wave - 2, 0, accX);
-  if (bsum != 0.f) {
-    if (wave == 0) atomicAdd(&a.drad_b[so.rb1 + lane], bsum);
-    else if (wave == 1) atomicAdd(&a.drad_b[so.rb2 + lane], bsum);
-    else if (wave == 2 && lane < 3) atomicAdd(&a.drad_b[so.rb3 + lane], bsum);
-  }
+  if (bs1 != 0.f) atomicAdd(&a.drad_b[so.rb1 + lane], bs1);
+  if (bs2 != 0.f) atomicAdd(&a.drad_b[so.rb2 + lane], bs2);
+  if (lane < 3 && bs3 != 0.f) atomicAdd(&a.drad_b[so.rb3 + lane], bs3);
+  { const int64_t grp = -1; KT(0, 22); }
 }
 
 // ------------------------------------------------------------------------------------ grid scatter
@@ -1833,7 +2132,9 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + 128 * row;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
-    nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);
+    const char* gcap = getenv("NSIM_RAD_BWD_GRID");
+    const int64_t cap = gcap ? atoi(gcap) : 512;          // two resident workgroups per CU
+    nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
     if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd_j<0>), grid, block, shmem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_rad_bwd_j<1>), grid, block, shmem, (hipStream_t)stream, a);
@@ -1871,8 +2172,29 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
   a.dx = dx;
   a.ablate = bwd_ablate();
-  // fp16: one private accumulator copy per wave + staging, weights from L2; f32: staged weights + one shared accumulator
   const int nc = field_nc(meta->lotd.num_levels), nw = field_waves(meta, 2);
+  const char* oldp = getenv("NSIM_SDF_BWD_OLD");      // A/B aid: the per-wave LDS-accumulator kernel of round 1
+  if (nc == 1 && !(oldp && atoi(oldp) == 1)) {
+    // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
+    const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
+    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row;
+    const int64_t tiles = (S + 31) / 32;
+    int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
+    const char* gcap = getenv("NSIM_SDF_BWD_GRID");
+    const int64_t cap = gcap ? atoi(gcap) : 512;          // two resident workgroups per CU
+    nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
+    const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
+    switch (meta->precision * 2 + (meta->sdf_D - 1)) {
+      case 0: hipLaunchKernelGGL((k_field_bwd_j<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 1: hipLaunchKernelGGL((k_field_bwd_j<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 2: hipLaunchKernelGGL((k_field_bwd_j<1, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 3: hipLaunchKernelGGL((k_field_bwd_j<1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+    }
+    NSIM_CHECK_LAUNCH();
+    return 0;
+  }
+  // more than 16 levels: fp16: one private accumulator copy per wave + staging, weights from L2; f32: staged weights +
+  // one shared accumulator
   const size_t acc_bytes = ((6400 + 2048 * (nc - 1)) * 4 + 15) & ~15;
   const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + nw * acc_bytes + nw * stage_bytes(meta)
                                             : weights_lds_bytes(meta, 0, 4) + acc_bytes + FIELD_WAVES * stage_bytes(meta);

@@ -273,8 +273,8 @@ __device__ __forceinline__ void jstage(void* st, const float (&v)[NM * 16], int 
     for (int r = 0; r < 16; ++r) p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = (T)v[m * 16 + r];
 }
 
-// acc += A[32 mo + row][:] . B[32 no + col][:]^T over the JOINT_PTS staged points
-template <int PREC>
+// acc += A[32 mo + row][:] . B[32 no + col][:]^T over the staged points [16 S0, 16 S1)  (default: all JOINT_PTS)
+template <int PREC, int S0 = 0, int S1 = JOINT_PTS / 16>
 __device__ __forceinline__ f32x16 jdw_tile(const void* stA, int mo, const void* stB, int no, f32x16 acc) {
   typedef typename JStageT<PREC>::T T;
   constexpr int P = JStageT<PREC>::PITCH;
@@ -283,14 +283,14 @@ __device__ __forceinline__ f32x16 jdw_tile(const void* stA, int mo, const void* 
   const int lane = nsim_lane(), i = lane & 31, hi = lane >> 5;
   if constexpr (PREC == 0) {
 #pragma unroll
-    for (int s = 0; s < JOINT_PTS / 16; ++s) {
+    for (int s = S0; s < S1; ++s) {
       const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + (32 * mo + i) * P + 16 * s + 8 * hi);
       const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + (32 * no + i) * P + 16 * s + 8 * hi);
       acc = mfma_32x32x16_bf16(av, bv, acc);
     }
   } else {
 #pragma unroll 8
-    for (int q = 0; q < JOINT_PTS / 2; ++q) {
+    for (int q = 8 * S0; q < 8 * S1; ++q) {
       const float av = a[(32 * mo + i) * P + 2 * q + hi];
       const float bv = b[(32 * no + i) * P + 2 * q + hi];
       acc = mfma_32x32x2_f32(av, bv, acc);
@@ -299,9 +299,10 @@ __device__ __forceinline__ f32x16 jdw_tile(const void* stA, int mo, const void* 
   return acc;
 }
 
-// sum over the staged points of row ``lane`` (bias gradients): valid for lane < rows
+// sum of row ``lane`` over THIS wave's 32 staged points (bias gradients; every wave keeps its own partial sum, so no
+// wave becomes the straggler of the next barrier).  bf16: v_dot2c_f32_bf16 against (1, 1) adds two points per issue.
 template <int PREC>
-__device__ __forceinline__ float jrow_sum(const void* stA, int rows) {
+__device__ __forceinline__ float jrow_sum(const void* stA, int rows, int wave) {
   typedef typename JStageT<PREC>::T T;
   constexpr int P = JStageT<PREC>::PITCH;
   const T* a = reinterpret_cast<const T*>(stA);
@@ -310,13 +311,23 @@ __device__ __forceinline__ float jrow_sum(const void* stA, int rows) {
   if (lane < rows) {
     if constexpr (PREC == 0) {
 #pragma unroll
-      for (int q = 0; q < JOINT_PTS / 8; ++q) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + lane * P + 8 * q);
+      for (int q = 0; q < 4; ++q) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + lane * P + 32 * wave + 8 * q);
+#ifdef NSIM_HOST_EMU
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)v[e];
+#else
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 one = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2 pr = {v[2 * e], v[2 * e + 1]};
+          s = __builtin_amdgcn_fdot2_f32_bf16(pr, one, s, false);
+        }
+#endif
       }
     } else {
-      for (int q = 0; q < JOINT_PTS; ++q) s += a[lane * P + q];
+      for (int q = 0; q < 32; ++q) s += a[lane * P + 32 * wave + q];
     }
   }
   return s;
