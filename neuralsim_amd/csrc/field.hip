@@ -242,7 +242,7 @@ struct FieldArgs {
   signed char glm_half[8][32];                     // ... for all points (0), the first (1) or the second (2) half of them
   float *h_pl, *J_pl;                              // level-major planes [16 nc][S][2] / [16 nc][S][2][3] saved by the forward
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16 nc][S][2]
-  int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products
+  int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products, 8 no dh_appear atomics
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
 };
@@ -821,6 +821,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
   const float beta = a.beta, inv_beta = 1.0f / a.beta;
   FieldLayout L;
   int wbytes = 0;
+  { const int64_t grp = -1; KT(1, 23); }
   const char* W = stage_weights<PREC>(smem, a, 0, 4, L, wbytes);
   char* stA = smem + wbytes;
   char* stB = stA + 64 * jstage_row_bytes<PREC>();
@@ -831,7 +832,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t ngroups = (ntiles + JOINT_WAVES - 1) / JOINT_WAVES;
+  { const int64_t grp = -1; KT(1, 20); }
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    KT(1, 0);
     const int64_t s = (grp * JOINT_WAVES + wave) * 32 + j;      // past the end: an invalid point contributes zeros
     const bool valid = s < a.S;
     // the per-lane bias / head vectors are re-read from LDS where they are used: an address the compiler cannot prove
@@ -877,6 +880,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
           gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
         }
       }
+    KT(1, 1);
     // ---- decoder forward (recomputed) and d sdf / d h
     float a1[32];
     {
@@ -922,7 +926,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
     }
     // ======================================================================================= backward
     // ---- dW1 += d1 (x) gh
-    __syncthreads();                              // the previous group's readers of the staging areas are done
+    KT(1, 2);
+    __syncthreads();
+    KT(1, 3);                              // the previous group's readers of the staging areas are done
     jstage<PREC, 2>(stA, d1, wave);
     jstage<PREC, 1>(stB, gh, wave);
     __syncthreads();
@@ -930,8 +936,10 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
       if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
       else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
     }
+    KT(1, 4);
     float dh1[32];  // dL / d d1 = W1 . gh
     dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
+    KT(1, 5);
     float dz1[32], whv[32];
     if constexpr (SDF_D == 2) {
       float eh1[32];  // dL / d e1
@@ -945,11 +953,14 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
 #pragma unroll
       for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(Wv, L, V_WH, hi, k);
       // ---- dW2 += d2 (x) eh1
+      KT(1, 6);
       __syncthreads();
+      KT(1, 7);
       jstage<PREC, 2>(stA, d2, wave);
       jstage<PREC, 2>(stB, eh1, wave);
       __syncthreads();
       if (do_dw) accW2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW2);
+      KT(1, 8);
       float dh2[32];  // dL / d d2 = W2 . eh1
       dense<PREC, 2, 2>(dh2, W + L.mat[M_W2], eh1, true);
       float dz2[32];
@@ -961,7 +972,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
         dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
       }
       // ---- dW2 += dz2 (x) a1, d b2 += rowsum(dz2), d wh += rowsum(whv)
+      KT(1, 9);
       __syncthreads();
+      KT(1, 10);
       jstage<PREC, 2>(stA, dz2, wave);
       jstage<PREC, 2>(stB, a1, wave);
       jstage<PREC, 2>(stC, whv, wave);
@@ -971,6 +984,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
         bs2 += jrow_sum<PREC>(stA, 64, wave);
         bsh += jrow_sum<PREC>(stC, 64, wave);
       }
+      KT(1, 11);
       float da1[32];
       dense<PREC, 2, 2>(da1, W + L.mat[M_W2T], dz2, true);
 #pragma unroll
@@ -989,7 +1003,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
       bh += wave_sum(v);
     }
     // ---- dW1 += dz1 (x) h, d b1 += rowsum(dz1)  (+ d wh when there is one hidden layer)
+    KT(1, 12);
     __syncthreads();
+    KT(1, 13);
     jstage<PREC, 2>(stA, dz1, wave);
     {
       float h[16];      // re-read (L2-warm) rather than kept in 16 registers across the whole tile
@@ -1004,8 +1020,10 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
       bs1 += jrow_sum<PREC>(stA, 64, wave);
       if constexpr (SDF_D == 1) bsh += jrow_sum<PREC>(stC, 64, wave);
     }
+    KT(1, 14);
     float dh[16];
     dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
+    KT(1, 15);
     if (a.dx) {   // pose refinement: dL/dx += (dh/dx)^T dL/dh  (dh/dx re-read from the planes: this path is rare)
       float acc[3] = {0.f, 0.f, 0.f};
       if (valid) {
@@ -1037,7 +1055,10 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
           dp[1] = dh[r0 + 1];
         }
     }
+    KT(1, 16);
+    KT(1, 17);
   }
+  { const int64_t grp = -1; KT(1, 21); }
   // ---- one flush per wave
   const int F1 = 2 * a.lotd.num_levels;
   const SrcOff so = src_off(SDF_D, F1);
@@ -1049,6 +1070,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_b
   if (bs1 != 0.f) atomicAdd(&a.dsdf_b[so.b1 + lane], bs1);
   if (bsh != 0.f) atomicAdd(&a.dsdf_w[so.wh + lane], bsh);
   if (lane == 0 && bh != 0.f) atomicAdd(&a.dsdf_b[so.bh], bh);
+  { const int64_t grp = -1; KT(1, 22); }
 }
 
 // No-grad SDF query (all sampling / occupancy-refresh traffic goes through here).  Lean variant of the forward:
@@ -1428,13 +1450,13 @@ __global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
       }
     }
     // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
-    if (a.dh_appear && p.valid) {
-      if (hi == 1) {
-        atomicAdd(&a.dh_appear[4 * p.ray + 0], din[10]);
-        atomicAdd(&a.dh_appear[4 * p.ray + 1], din[11]);
-      } else {
-        atomicAdd(&a.dh_appear[4 * p.ray + 2], din[12]);
-        atomicAdd(&a.dh_appear[4 * p.ray + 3], din[13]);
+    // (summed over the samples of a ray inside the wave: one atomic per ray, channel and wave, not one per sample)
+    if (a.dh_appear && !(a.ablate & 8)) {
+      float c0 = hi == 1 ? din[10] : din[12], c1 = hi == 1 ? din[11] : din[13];
+      if (halfwave_run_sum2(p.ray, p.valid, c0, c1)) {
+        float* dst = a.dh_appear + 4 * p.ray + (hi == 1 ? 0 : 2);
+        atomicAdd(dst, c0);
+        atomicAdd(dst + 1, c1);
       }
     }
   }
@@ -1603,13 +1625,13 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
       }
     }
     // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
-    if (a.dh_appear && p.valid) {
-      if (hi == 1) {
-        atomicAdd(&a.dh_appear[4 * p.ray + 0], din[10]);
-        atomicAdd(&a.dh_appear[4 * p.ray + 1], din[11]);
-      } else {
-        atomicAdd(&a.dh_appear[4 * p.ray + 2], din[12]);
-        atomicAdd(&a.dh_appear[4 * p.ray + 3], din[13]);
+    // (summed over the samples of a ray inside the wave: one atomic per ray, channel and wave, not one per sample)
+    if (a.dh_appear && !(a.ablate & 8)) {
+      float c0 = hi == 1 ? din[10] : din[12], c1 = hi == 1 ? din[11] : din[13];
+      if (halfwave_run_sum2(p.ray, p.valid, c0, c1)) {
+        float* dst = a.dh_appear + 4 * p.ray + (hi == 1 ? 0 : 2);
+        atomicAdd(dst, c0);
+        atomicAdd(dst + 1, c1);
       }
     }
     KT(0, 17);
@@ -1918,6 +1940,11 @@ static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t sh
   return 0;
 }
 
+static int bwd_ablate() {
+  const char* ab = getenv("NSIM_ABLATE");
+  return ab ? atoi(ab) : 0;
+}
+
 // persistent grids: the packed weights (58 KB) are staged into LDS once per workgroup
 #define FIELD_GRID_FWD 1024
 #define FIELD_GRID_BWD 256      // one resident workgroup per CU (LDS-limited): persistent waves amortise the accumulator flush
@@ -2098,11 +2125,6 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
-static int bwd_ablate() {
-  const char* ab = getenv("NSIM_ABLATE");
-  return ab ? atoi(ab) : 0;
-}
-
 int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
                        const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                        const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
@@ -2124,6 +2146,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.drad_w = drad_w; a.drad_b = drad_b; a.dh_appear = dh_appear;
   a.dx = dx; a.dv = dv;
   a.has_rgb = 1;
+  a.ablate = bwd_ablate();
   const int64_t tiles = (S + 31) / 32;
   const char* oldp = getenv("NSIM_RAD_BWD_OLD");      // A/B aid: the per-wave LDS-accumulator kernel of round 1
   const bool old_path = oldp && atoi(oldp) == 1;

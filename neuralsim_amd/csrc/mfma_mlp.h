@@ -343,3 +343,25 @@ __device__ __forceinline__ void jflush_tile(float* dst, int ld, int rows, int co
     if (row < rows && acc[r] != 0.f) atomicAdd(&dst[row * ld + col], acc[r]);
   }
 }
+
+// Sum v0 / v1 over the runs of equal ``key`` among the 32 lanes of each wave half (keys arrive grouped: consecutive
+// samples of a ray are neighbouring lanes); the run total is valid on the LAST lane of the run, for which the function
+// returns true.  Used to issue ONE atomic per (ray, channel) and wave instead of one per sample: same-address atomics of
+// one instruction are separate requests to the atomic unit (21 G requests/s chip-wide) and serialise in L2.
+__device__ __forceinline__ bool halfwave_run_sum2(int64_t key, bool valid, float& v0, float& v1) {
+  const int lane = nsim_lane();
+  const int64_t k = valid ? key : (int64_t)-1 - lane;          // invalid lanes: runs of their own
+  const int64_t pk = wave_shfl(k, lane - 1);
+  const unsigned long long heads = wave_ballot((lane & 31) == 0 || pk != k);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const float o0 = wave_shfl(v0, lane - d), o1 = wave_shfl(v1, lane - d);
+    if (lane - d >= run_start) {
+      v0 += o0;
+      v1 += o1;
+    }
+  }
+  return valid && ((lane & 31) == 31 || ((heads >> (lane + 1)) & 1ull));
+}

@@ -533,9 +533,19 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
       float din[32];
       dense<PREC, 2, 2>(din, WM + L.mat[N_Q1T], dr1, true);
       // appearance slots 48..51 = second M-tile local 16..19: (hi0: r8..11 -> 16..19)
-      if (a.dh_appear && p.valid && hi == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&a.dh_appear[4 * p.ray + c], din[16 + 8 + c]);
+      // (summed over the shells of a ray inside the wave first: one atomic per ray and channel, not one per sample)
+      if (a.dh_appear) {
+        float c0 = din[16 + 8], c1 = din[16 + 9], c2 = din[16 + 10], c3 = din[16 + 11];
+        const bool v = p.valid && hi == 0;
+        const bool last = halfwave_run_sum2(p.ray, v, c0, c1);
+        halfwave_run_sum2(p.ray, v, c2, c3);
+        if (last) {
+          float* dst = a.dh_appear + 4 * p.ray;
+          atomicAdd(dst, c0);
+          atomicAdd(dst + 1, c1);
+          atomicAdd(dst + 2, c2);
+          atomicAdd(dst + 3, c3);
+        }
       }
       // ---- density branch: sigma = softplus(raw) -> d raw = d sigma * (1 - exp(-sigma))
       const float draw = gs * (1.0f - nsim_fast_exp(-sg));

@@ -14,7 +14,11 @@ from neuralsim_amd import _lib  # noqa: E402
 
 LABELS = {0: ["loop top", "loads+rin", "rad fwd (2 dense)", "dout/scale", "barrier A3", "stage P3", "barrier B3", "dW3+rowsum",
               "dense R3T", "barrier A2", "stage P2", "barrier B2", "dW2+rowsum", "dense R2T", "barrier A1", "stage P1+barrier",
-              "dW1+rowsum", "dense R1T + outputs"]}
+              "dW1+rowsum", "dense R1T + outputs"],
+          1: ["loop top", "loads gs/gn/J -> gh", "fwd recompute + g store", "barrier A(d1,gh)", "stage+barrier+dW1a", "dense dh1",
+              "dz1/eh1/d2", "barrier A(d2,eh1)", "stage+barrier+dW2a", "dense dh2, whv/dz2", "barrier A(dz2,a1)",
+              "stage+barrier+dW2b+rowsums", "dense da1, dz1", "barrier A(dz1,h)", "stage+barrier+dW1b+rowsum", "dense dh",
+              "dh store", "-"]}
 
 
 def main():
