@@ -1353,143 +1353,17 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
   }
 }
 
-// Backward of the radiance branch: given dL/drgb, the saved forward nablas / rgb -> gradients of the radiance
-// weights, of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].
-// No grid access at all: per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
-#define RAD_WAVES 4
-template <int PREC>
-__global__ void __launch_bounds__(64 * RAD_WAVES) k_rad_bwd(FieldArgs a) {
-  NSIM_DYN_SMEM(smem);
-  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
-  const int wave = (int)(threadIdx.x >> 6);
-  FieldLayout L;
-  int wbytes;
-  // fp16: private per-wave accumulators (plain LDS read-add-write, see mfma_mlp.h:dw_flush), matrices from L2
-  constexpr bool PRIV = (PREC == 0);
-  constexpr int ACC_BYTES = ((6144 * 4 + 15) & ~15);      // >= RadAccOff.total floats
-  const char* W = stage_weights<PREC>(smem, a, M_R1, PRIV ? 0 : 6, L, wbytes);
-  const char* WM = PRIV ? a.wpack : W;
-  const FieldLayout LM = PRIV ? a.lay : L;
-  const RadAccOff AO = rad_acc_off();
-  float* accum = reinterpret_cast<float*>(smem + wbytes + (PRIV ? wave * ACC_BYTES : 0));
-  char* stA = smem + wbytes + (PRIV ? RAD_WAVES : 1) * ACC_BYTES + wave * stage_bytes_per_wave<PREC>();
-  char* stB = stA + stage_bytes_per_wave<PREC>() / 2;
-  if constexpr (PRIV) {
-    for (int i = lane; i < AO.total; i += 64) accum[i] = 0.f;
-  } else {
-    for (int i = threadIdx.x; i < AO.total; i += blockDim.x) accum[i] = 0.f;
-  }
-  __syncthreads();
-
-  const int64_t ntiles = (a.S + 31) / 32;
-  const int64_t wstride = (int64_t)gridDim.x * RAD_WAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * RAD_WAVES + wave; tile < ntiles; tile += wstride) {
-    const TilePoint p = load_point(a, tile, j, true);
-    const int64_t s = p.s;
-    float nab[3] = {0.f, 0.f, 0.f}, rgbv[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
-    if (p.valid) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        nab[c] = a.nablas_fwd[3 * s + c];
-        rgbv[c] = a.rgb_fwd[3 * s + c];
-        gr[c] = a.drgb[3 * s + c];
-        if (a.dnablas) gn[c] = a.dnablas[3 * s + c];
-      }
-    }
-    float rin[16], r1[32], r2[32];
-    make_rin(rin, p, nab, a.h_appear, hi);
-    radiance_hidden<PREC>(r1, r2, rin, W, L, hi, WM, &LM);
-    float dout[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dout[r] = 0.f;
-    if (hi == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dout[c] = gr[c] * rgbv[c] * (1.0f - rgbv[c]);
-    }
-    dw_product<PREC, 1, 2, PRIV>(stA, stB, dout, r2, accum + AO.r3, 64, 3, 64, accum + AO.rb3);
-    float dr2[32];
-    dense<PREC, 2, 1>(dr2, WM + LM.mat[M_R3T], dout, true);
-#pragma unroll
-    for (int k = 0; k < 32; ++k) dr2[k] = r2[k] > 0.f ? dr2[k] : 0.f;
-    dw_product<PREC, 2, 2, PRIV>(stA, stB, dr2, r1, accum + AO.r2, 64, 64, 64, accum + AO.rb2);
-    float dr1[32];
-    dense<PREC, 2, 2>(dr1, WM + LM.mat[M_R2T], dr2, true);
-#pragma unroll
-    for (int k = 0; k < 32; ++k) dr1[k] = r1[k] > 0.f ? dr1[k] : 0.f;
-    dw_product<PREC, 2, 1, PRIV>(stA, stB, dr1, rin, accum + AO.r1, 26, 64, 26, accum + AO.rb1);
-    float din[16];
-    dense<PREC, 1, 2>(din, WM + LM.mat[M_R1T], dr1, true);
-    // slots 19 (hi0,r11) 20,21 (hi1,r8,r9): gradient w.r.t. the normals fed to the radiance net
-    const float v0 = hi == 0 ? din[11] : 0.f, v1 = hi == 1 ? din[8] : 0.f, v2 = hi == 1 ? din[9] : 0.f;
-    gn[0] += v0 + wave_shfl_xor(v0, 32);
-    gn[1] += v1 + wave_shfl_xor(v1, 32);
-    gn[2] += v2 + wave_shfl_xor(v2, 32);
-    if (p.valid && hi == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a.dnab_total[3 * s + c] = gn[c];
-    }
-    if (a.dx) {   // pose refinement: the radiance net's position input (slots 0-2: hi 0, r 0..2) ...
-      if (p.valid && hi == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a.dx[3 * s + c] = din[c];
-      }
-    }
-    if (a.dv) {   // ... and its view direction through SH4 (slots 3-18)
-      float gsh[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int slot = k + 3, ohi = (slot >> 2) & 1, r = (slot & 3) + 4 * (slot >> 3);
-        const float v = (hi == ohi) ? din[r] : 0.f;
-        gsh[k] = v + wave_shfl_xor(v, 32);
-      }
-      float gv[3];
-      sh4_grad(p.vd, gsh, gv);
-      if (p.valid && hi == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a.dv[3 * s + c] = gv[c];
-      }
-    }
-    // slots 22,23 (hi1,r10,r11) 24,25 (hi0,r12,r13): appearance embedding gradient
-    // (summed over the samples of a ray inside the wave: one atomic per ray, channel and wave, not one per sample)
-    if (a.dh_appear && !(a.ablate & 8)) {
-      float c0 = hi == 1 ? din[10] : din[12], c1 = hi == 1 ? din[11] : din[13];
-      if (halfwave_run_sum2(p.ray, p.valid, c0, c1)) {
-        float* dst = a.dh_appear + 4 * p.ray + (hi == 1 ? 0 : 2);
-        atomicAdd(dst, c0);
-        atomicAdd(dst + 1, c1);
-      }
-    }
-  }
-  __syncthreads();
-  const SrcOff so = src_off(1);
-  for (int i = threadIdx.x; i < AO.total; i += blockDim.x) {
-    float v;
-    if constexpr (PRIV) {
-      const float* a0 = reinterpret_cast<const float*>(smem + wbytes);
-      v = 0.f;
-#pragma unroll
-      for (int w = 0; w < RAD_WAVES; ++w) v += a0[w * (ACC_BYTES / 4) + i];
-    } else {
-      v = accum[i];
-    }
-    if (v == 0.f) continue;
-    float* dst = nullptr;
-    if (i < AO.r2) dst = a.drad_w + so.r1 + (i - AO.r1);
-    else if (i < AO.r3) dst = a.drad_w + so.r2 + (i - AO.r2);
-    else if (i < AO.rb1) dst = a.drad_w + so.r3 + (i - AO.r3);
-    else if (i < AO.rb2) dst = a.drad_b + so.rb1 + (i - AO.rb1);
-    else if (i < AO.rb3) dst = a.drad_b + so.rb2 + (i - AO.rb2);
-    else dst = (i - AO.rb3 < 3) ? a.drad_b + so.rb3 + (i - AO.rb3) : nullptr;
-    if (dst) atomicAdd(dst, v);
-  }
-}
-
-// Backward of the radiance branch, workgroup-joint weight gradients (mfma_mlp.h: "workgroup-joint weight-gradient
-// products"): the four waves of a workgroup stage their 32 points side by side (K = 128 per product), every wave owns
+// Backward of the radiance branch: given dL/drgb and the saved forward nablas / rgb -> gradients of the radiance weights,
+// of the appearance codes, and dnab_total[s] = dL/dnablas[s] (upstream) + d(radiance path)/d nablas[s].  No grid access:
+// per point 12 B (x) + 12 B (nablas) + 12 B (rgb) + 12 B (drgb) in, 12 B out.
+// Workgroup-joint weight gradients (mfma_mlp.h: "workgroup-joint weight-gradient products"): the four waves of a workgroup stage their 32 points side by side (K = 128 per product), every wave owns
 // two of the eight output tiles -- dR2 tile (wave >> 1, wave & 1) and either a dR3 tile (waves 0, 1) or a dR1 tile
 // (waves 2, 3) -- in MFMA accumulator registers for the whole launch, the bias sums live in one register of the wave
 // that idles during the product.  LDS: the six weight matrices (34.5 KB) + one staging area (34.8 KB) = 69 KB -> two
-// workgroups per CU, two waves per SIMD (k_rad_bwd: 141 KB, one).  Same inputs / outputs as k_rad_bwd.
+// workgroups per CU, two waves per SIMD (round 1's per-wave LDS accumulators: 141 KB, one).
+// Measured (MI355X, 274 k points): 0.208 ms in round 1 -> 0.162 ms with this structure -> 0.104 ms once the per-sample
+// appearance-code atomics were summed per ray inside the wave (they had been 80 % of a group's time: s_memtime stamps,
+// tools/ktime.py); the round-1 structure with the same atomics fix measured 0.100 ms -- the atomics were the bound.
 template <int PREC>
 __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd_j(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
@@ -2148,31 +2022,14 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   a.has_rgb = 1;
   a.ablate = bwd_ablate();
   const int64_t tiles = (S + 31) / 32;
-  const char* oldp = getenv("NSIM_RAD_BWD_OLD");      // A/B aid: the per-wave LDS-accumulator kernel of round 1
-  const bool old_path = oldp && atoi(oldp) == 1;
-  if (!old_path) {
-    // workgroup-joint weight gradients: weights + one staging area in LDS, two workgroups per CU
-    const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
-    const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + 128 * row;
-    int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
-    const char* gcap = getenv("NSIM_RAD_BWD_GRID");
-    const int64_t cap = gcap ? atoi(gcap) : 512;          // two resident workgroups per CU
-    nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
-    const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
-    if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd_j<0>), grid, block, shmem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_rad_bwd_j<1>), grid, block, shmem, (hipStream_t)stream, a);
-    NSIM_CHECK_LAUNCH();
-    return 0;
-  }
-  const size_t racc = (6144 * 4 + 15) & ~15;
-  const size_t shmem = meta->precision == 0
-                           ? weights_lds_bytes(meta, M_R1, 0) + RAD_WAVES * racc + RAD_WAVES * stage_bytes(meta)
-                           : weights_lds_bytes(meta, M_R1, 6) + racc + RAD_WAVES * stage_bytes(meta);
-  int64_t nb = (tiles + RAD_WAVES - 1) / RAD_WAVES;
-  nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
-  const dim3 grid((unsigned)nb), block(64 * RAD_WAVES);
-  if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd<0>), grid, block, shmem, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_rad_bwd<1>), grid, block, shmem, (hipStream_t)stream, a);
+  // workgroup-joint weight gradients: weights + one staging area in LDS, two workgroups per CU
+  const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
+  const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + 128 * row;
+  int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
+  nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);          // two resident workgroups per CU
+  const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
+  if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd_j<0>), grid, block, shmem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_rad_bwd_j<1>), grid, block, shmem, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -2196,8 +2053,11 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dx = dx;
   a.ablate = bwd_ablate();
   const int nc = field_nc(meta->lotd.num_levels), nw = field_waves(meta, 2);
-  const char* oldp = getenv("NSIM_SDF_BWD_OLD");      // A/B aid: the per-wave LDS-accumulator kernel of round 1
-  if (nc == 1 && !(oldp && atoi(oldp) == 1)) {
+  // The workgroup-joint variant of this backward (k_field_bwd_j) is opt-in (NSIM_SDF_BWD_JOINT=1): with two hidden layers
+  // its live set does not fit the 256 registers of two waves per SIMD (177 spilled) and it measured 0.275 ms against
+  // 0.230 ms for k_field<., ., 2> on 278 k points.
+  const char* jp = getenv("NSIM_SDF_BWD_JOINT");
+  if (nc == 1 && jp && atoi(jp) == 1) {
     // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row;

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..model_base import ModelMixin
 
 
 class _SkyFn(torch.autograd.Function):
@@ -46,7 +47,7 @@ class _SkyFn(torch.autograd.Function):
         return None, dw, db, None, dha
 
 
-class SimpleSky(nn.Module):
+class SimpleSky(ModelMixin, nn.Module):
     def __init__(self, dir_embed_cfg: Optional[dict] = None, D: int = 2, W: int = 256, n_appear_embedding: int = 4,
                  activation: str = "relu", output_activation: str = "sigmoid", precision: str = "fp16", seed: int = 42,
                  device=None, **unused):
@@ -80,6 +81,16 @@ class SimpleSky(nn.Module):
     @property
     def device(self):
         return self.w.device
+
+    def _param_groups(self, cfg: dict):
+        """``training_cfg{lr: skylr, ...}`` (withmask_withlidar_joint.240219.yaml:322-325)."""
+        return [dict(name="decoder", params=[self.w, self.b])]
+
+    def _after_optimizer_step(self):
+        self._wpack_versions = None
+
+    def _weight_reg_tensors(self):
+        return [self.w]
 
     def set_precision(self, precision: str):
         self.meta.precision = {"fp16": 0, "f32": 1}[precision]

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..model_base import ModelMixin
 
 
 class LoTD4Config:
@@ -127,7 +128,7 @@ class _DensityAlphaFn(torch.autograd.Function):
         return dsigma, None, None, None, None, None
 
 
-class LoTDNeRFDistantModel(nn.Module):
+class LoTDNeRFDistantModel(ModelMixin, nn.Module):
     is_ray_query_supported = True
 
     def __init__(self, aabb: torch.Tensor = None, precision: str = "fp16", radius_scale_min: float = 1.0,
@@ -217,6 +218,31 @@ class LoTDNeRFDistantModel(nn.Module):
 
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
         return False
+
+    # ------------------------------------------------------------------ optimizer (model_base.ModelMixin)
+    def _param_groups(self, cfg: dict):
+        """``training_cfg{lr: bglr, eps, betas}`` (lotd_neus.dtu.230814.yaml:249-254)."""
+        self._shadow()
+        return [dict(name="encoding", params=[self.flattened_params], shadow16=lambda: self._shadow()[0]),
+                dict(name="density_decoder", params=[self.den_w, self.den_b]),
+                dict(name="radiance_decoder", params=[self.rad_w, self.rad_b])]
+
+    def _after_optimizer_step(self):
+        self._wpack_versions = None
+
+    def _weight_reg_tensors(self):
+        return [self.den_w, self.rad_w]
+
+    @property
+    def space(self):
+        """The close-range object's box this model surrounds (``populate(aabb=cr_obj.model.space.aabb)``,
+        app/models/single/nerf.py:170-177)."""
+        from ..spatial import AABBSpace
+        sp = getattr(self, "_space", None)
+        if sp is None or sp.aabb.device != self.aabb.device or not torch.equal(sp.aabb, self.aabb):
+            sp = AABBSpace(aabb=self.aabb.detach().clone(), device=self.aabb.device)
+            object.__setattr__(self, "_space", sp)
+        return sp
 
     def training_before_per_step(self, it: int, logger=None):
         pass

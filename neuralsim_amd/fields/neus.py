@@ -25,6 +25,8 @@ import torch.nn as nn
 from .. import _lib
 from ..grid_encodings.lotd import LoTDConfig, LoTDEncoding
 from ..graphics import pack_ops as po
+from ..model_base import ModelMixin
+from ..spatial import AABBSpace, aabb_ray_test
 
 DEFAULT_LOD_RES = [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
 RAD_IN = 26
@@ -373,7 +375,7 @@ class OccGridAccel(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------- model
-class LoTDNeuSModel(nn.Module):
+class LoTDNeuSModel(ModelMixin, nn.Module):
     is_ray_query_supported = True
 
     def __init__(self, lod_res: Sequence[int] = None, log2_hashmap_size: int = 19, sdf_D: int = 2, W: int = 64,
@@ -528,6 +530,33 @@ class LoTDNeuSModel(nn.Module):
     @property
     def space_aabb(self):
         return self.accel.aabb
+
+    @property
+    def space(self) -> AABBSpace:
+        """``model.space`` (``.aabb``, ``.get_bounding_volume()``, ``.ray_test``): app/resources/nodes.py:92-103,
+        app/models/single/nerf.py:175."""
+        sp = getattr(self, "_space", None)
+        if sp is None or sp.aabb.device != self.accel.aabb.device or not torch.equal(sp.aabb, self.accel.aabb):
+            sp = AABBSpace(aabb=self.accel.aabb.detach().clone(), device=self.accel.aabb.device)
+            object.__setattr__(self, "_space", sp)          # a view of the model's box, not a registered sub-module
+        return sp
+
+    # ------------------------------------------------------------------ optimizer (model_base.ModelMixin)
+    def _param_groups(self, cfg: dict):
+        """``training_cfg{lr, eps, betas, invs_betas}`` (lotd_neus.dtu.230814.yaml:178-185): the table (with its fp16
+        shadow written by the same Adam pass), the two decoders, and ``ln_inv_s`` with its own betas."""
+        enc = self.encoding
+        enc.shadow()
+        return [dict(name="implicit_surface.encoding", params=[enc.flattened_params], shadow16=lambda: enc.shadow()),
+                dict(name="implicit_surface.decoder", params=[self.sdf_w, self.sdf_b]),
+                dict(name="radiance_net", params=[self.rad_w, self.rad_b]),
+                dict(name="ln_inv_s", params=[self.ln_inv_s], betas=tuple(cfg.get("invs_betas", (0.9, 0.999))))]
+
+    def _after_optimizer_step(self):
+        self._wpack_versions = None         # MLP weights changed in place: re-pack the MFMA fragments lazily
+
+    def _weight_reg_tensors(self):
+        return [self.sdf_w, self.rad_w]
 
     def set_precision(self, precision: str):
         self.field_meta.precision = {"fp16": 0, "f32": 1}[precision]
@@ -779,38 +808,9 @@ class LoTDNeuSModel(nn.Module):
         return o, d
 
     def ray_test(self, rays_o, rays_d, near=None, far=None, **extra) -> Dict:
-        """AABB slab test + compaction of the hit rays (single_volume_renderer.py:235-238)."""
-        rays_o = rays_o.float().contiguous()
-        rays_d = rays_d.float().contiguous()
-        N = rays_o.shape[0]
-        dev = rays_o.device
-        near_t = torch.empty([N], dtype=torch.float32, device=dev)
-        far_t = torch.empty([N], dtype=torch.float32, device=dev)
-        hit = torch.empty([N], dtype=torch.uint8, device=dev)
-        _lib.call("nsim_aabb_ray_test", _lib.ptr(rays_o.detach()), _lib.ptr(rays_d.detach()), N, self.accel.meta,
-                  float(near) if near is not None else 0.0, float(far) if far is not None else -1.0, _lib.ptr(near_t),
-                  _lib.ptr(far_t), _lib.ptr(hit))
-        rays_inds = hit.nonzero()[:, 0]     # host sync (the reference compacts here as well)
-        R = int(rays_inds.shape[0])
-        if rays_o.requires_grad or rays_d.requires_grad:        # keep the graph for callers that differentiate rays
-            ret = dict(num_rays=R, rays_inds=rays_inds, rays_o=rays_o[rays_inds], rays_d=rays_d[rays_inds],
-                       near=near_t[rays_inds], far=far_t[rays_inds])
-        else:
-            o_h, d_h = torch.empty([R, 3], dtype=torch.float32, device=dev), torch.empty([R, 3], dtype=torch.float32, device=dev)
-            n_h, f_h = torch.empty([R], dtype=torch.float32, device=dev), torch.empty([R], dtype=torch.float32, device=dev)
-            _lib.call("nsim_gather_rays", _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(near_t), _lib.ptr(far_t),
-                      _lib.ptr(rays_inds), R, _lib.ptr(o_h), _lib.ptr(d_h), _lib.ptr(n_h), _lib.ptr(f_h))
-            ret = dict(num_rays=R, rays_inds=rays_inds, rays_o=o_h, rays_d=d_h, near=n_h, far=f_h)
-        for k, v in extra.items():
-            if isinstance(v, torch.Tensor) and v.shape[:1] == (N,):
-                if v.requires_grad and v.dim() == 2 and v.dtype == torch.float32:
-                    from ..losses import embedding_lookup      # row gather with a one-launch backward
-                    ret[k] = embedding_lookup(v, rays_inds)
-                else:
-                    ret[k] = v[rays_inds]
-            else:
-                ret[k] = v
-        return ret
+        """AABB slab test + compaction of the hit rays (single_volume_renderer.py:235-238); the same call as
+        ``model.space.ray_test(**ray_input)`` (app/visualizer/gui_runner_single_cuboid.py:135-138)."""
+        return aabb_ray_test(self.accel.aabb, self.accel.meta, rays_o, rays_d, near=near, far=far, **extra)
 
     def _arange_repeat(self, R: int, n: int, dev):
         """arange(R).repeat_interleave(n), cached (ray index of the batched up-sampling points)."""
@@ -989,6 +989,8 @@ class LoTDNeuSModel(nn.Module):
         qp = dict(cfg.get("query_param", self.ray_query_cfg.get("query_param", {})))
         with_rgb = cfg.get("with_rgb", True)
         with_normal = cfg.get("with_normal", False)
+        if cfg.get("with_feature_dim", 0):          # ``n_extra_feat_from_output`` is 0 in every config of the hot path
+            raise NotImplementedError("with_feature_dim > 0: the decoders of this model emit no extra feature channels")
         ret = dict()
         R = ray_tested["num_rays"]
         # ``render_per_obj_individual``: this object alone, as images over ALL the rays of ``ray_input`` (the renderers
@@ -1051,4 +1053,10 @@ class LoTDNeuSModel(nn.Module):
             ret["rendered"].pop("vw", None)
         if return_details:
             ret["details"] = dict(march_counts=march_counts, sdf_nograd=sdf_ng, ridx=ridx)
+        if cfg.get("with_near_sdf", False):
+            # ``renderer._config_train.with_near_sdf = True`` (code_single/tools/train.py:245) -> ``details['near_sdf']``
+            # read by ClearanceLoss (app/loss/clearance.py:85-87): the SDF, with gradient, where each tested ray enters
+            # the model's space (x = o + near d).  (Implementation in the absent nr3d_lib: semantics fixed here.)
+            x_near = (o + ray_tested["near"].float()[:, None] * d).detach()
+            ret.setdefault("details", {})["near_sdf"] = self.forward_sdf_nablas(x_near, nablas_has_grad=False)["sdf"]
         return ret
