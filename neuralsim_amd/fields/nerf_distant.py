@@ -155,7 +155,10 @@ class LoTDNeRFDistantModel(ModelMixin, nn.Module):
                           lotd_auto_compute_cfg=lotd_auto_compute_cfg, param_bound=param_bound, seed=seed,
                           ray_query_cfg=ray_query_cfg, lotd_use_cuboid=lotd_use_cuboid)
         self.lotd_use_cuboid = bool(lotd_use_cuboid)
-        self.include_inf, self.use_view_dirs = bool(include_inf_distance), bool(use_view_dirs)
+        # ``include_inf_distance: None`` = decided at populate time from the scene (no Sky node -> the last shell reaches
+        # infinity; app/models/single/nerf.py:180-182 assigns the attribute)
+        self.include_inf_distance = include_inf_distance
+        self.use_view_dirs = bool(use_view_dirs)
         c = dict(lotd_auto_compute_cfg or {})
         aspect = None
         if self.lotd_use_cuboid and aabb is not None:
@@ -218,6 +221,10 @@ class LoTDNeRFDistantModel(ModelMixin, nn.Module):
 
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
         return False
+
+    @property
+    def include_inf(self) -> bool:
+        return True if self.include_inf_distance is None else bool(self.include_inf_distance)
 
     # ------------------------------------------------------------------ optimizer (model_base.ModelMixin)
     def _param_groups(self, cfg: dict):

@@ -1,0 +1,42 @@
+"""``nr3d_lib.models.loss.recon`` -- the elementwise reconstruction losses the reference's loss modules star-import
+(app/loss/photometric.py:67-84, app/loss/weight_reg.py:15): plain torch formulas on renderer outputs, restated from
+their names (implementation absent).  ``mask`` weights the elements; ``reduction`` 'mean' | 'none'."""
+import torch
+import torch.nn.functional as F
+
+__all__ = ["l1_loss", "l2_loss", "mse_loss", "huber_loss", "smooth_l1_loss", "relative_l1_loss", "relative_l2_loss"]
+
+
+def _reduce(x, mask, reduction):
+    if mask is not None:
+        x = x * mask
+        if reduction == "mean":
+            return x.sum() / (mask.expand_as(x).sum().clamp_min(1))
+    return x.mean() if reduction == "mean" else x
+
+
+def l1_loss(pred, gt, mask=None, reduction="mean"):
+    return _reduce((pred - gt).abs(), mask, reduction)
+
+
+def l2_loss(pred, gt, mask=None, reduction="mean"):
+    return _reduce((pred - gt) ** 2, mask, reduction)
+
+
+mse_loss = l2_loss
+
+
+def huber_loss(pred, gt, mask=None, reduction="mean", alpha: float = 1.0):
+    return _reduce(F.huber_loss(pred, gt, reduction="none", delta=alpha), mask, reduction)
+
+
+def smooth_l1_loss(pred, gt, mask=None, reduction="mean", beta: float = 1.0):
+    return _reduce(F.smooth_l1_loss(pred, gt, reduction="none", beta=beta), mask, reduction)
+
+
+def relative_l1_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
+    return _reduce((pred - gt).abs() / (gt.abs() + eps), mask, reduction)
+
+
+def relative_l2_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
+    return _reduce((pred - gt) ** 2 / (gt ** 2 + eps), mask, reduction)

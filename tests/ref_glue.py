@@ -495,3 +495,65 @@ def make_reference_renderer(mods, common: dict, train: dict = None, val: dict = 
     r.populate(None)
     r.train(training)
     return r
+
+
+@contextlib.contextmanager
+def reference_model_wrapper_modules():
+    """-> the reference's asset wrappers and the two model-side losses, loaded UNCHANGED from /root/reference:
+    ``app/models/asset_base.py`` (AssetMixin / AssetModelMixin / AssetAssignment), ``app/models/single/neus.py``
+    (LoTDNeuSObj, LoTDNeuSStreet), ``app/models/single/nerf.py`` (LoTDNeRFDistant), ``app/loss/clearance.py``,
+    ``app/loss/weight_reg.py``.  Everything they import from nr3d_lib resolves in this repository's shim
+    (``nr3d_lib.{logger, config, models.{model_base, spatial, autodecoder, annealers, loss.recon, fields.{neus, nerf, sdf},
+    fields_distant.nerf}}``); stand-ins only for the scene graph (``app.resources.{Scene, SceneNode}``, the observers) and
+    for three harness names ``nerf.py`` imports for its MLP-NeRF classes (``check_to_torch``, ``get_embedder``,
+    ``TransformMat4x4``), which the hot path never touches."""
+    assert (REF_ROOT / "app/models/single/neus.py").exists()
+    root = str(Path(__file__).resolve().parent.parent)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    names = ["nr3d_lib.utils", "nr3d_lib.models.embedders", "nr3d_lib.models.attributes"]
+    saved = {k: sys.modules.get(k) for k in names}
+    saved_app = {k: v for k, v in sys.modules.items() if k == "app" or k.startswith("app.")}
+    for k in saved_app:
+        del sys.modules[k]
+    classes = {n: type(n, (_Named,), {}) for n in ("Scene", "SceneNode", "Camera")}
+    pk = {}
+    for n in ("app", "app.models", "app.models.single", "app.loss"):
+        pk[n] = _stub_module(n)
+        pk[n].__path__ = []
+    sys.modules.update(pk)
+    sys.modules.update({
+        "app.resources": _stub_module("app.resources", Scene=classes["Scene"], SceneNode=classes["SceneNode"]),
+        "app.resources.observers": _stub_module("app.resources.observers", Camera=classes["Camera"]),
+        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", check_to_torch=lambda x, **k: torch.as_tensor(x)),
+        "nr3d_lib.models.embedders": _stub_module("nr3d_lib.models.embedders", get_embedder=None),
+        "nr3d_lib.models.attributes": _stub_module("nr3d_lib.models.attributes", TransformMat4x4=None),
+    })
+    try:
+        mods = {}
+        for name, rel in (("app.models.asset_base", "app/models/asset_base.py"),
+                          ("app.models.single.neus", "app/models/single/neus.py"),
+                          ("app.models.single.nerf", "app/models/single/nerf.py"),
+                          ("app.loss.clearance", "app/loss/clearance.py"),
+                          ("app.loss.weight_reg", "app/loss/weight_reg.py")):
+            spec = importlib.util.spec_from_file_location(name, str(REF_ROOT / rel))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            mods[name] = mod
+        # ``model_class: app.models.single.LoTDNeuSObj`` (the package star-imports its modules, app/models/single/__init__.py)
+        for m in ("app.models.single.neus", "app.models.single.nerf"):
+            for n in mods[m].__all__:
+                if hasattr(mods[m], n):
+                    setattr(pk["app.models.single"], n, getattr(mods[m], n))
+        mods["classes"] = classes
+        yield mods
+    finally:
+        for k in [k for k in sys.modules if k == "app" or k.startswith("app.")]:
+            del sys.modules[k]
+        sys.modules.update(saved_app)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
