@@ -144,6 +144,11 @@ int nsim_occ_decay(float* val, int64_t nvox, float decay, void* stream);
 int nsim_occ_update(float* val, const float* pts, const float* sdf, int64_t n, const NsimOccMeta* meta,
                     float inv_s, void* stream);
 int nsim_occ_pack_bits(const float* val, int64_t nvox, float thre, uint32_t* bits, void* stream);
+/* ``accel_cfg.update_from_samples_cfg: {}`` (lotd_neus.dtu.230814.yaml:158; hook app/resources/asset_bank.py:291-298): the
+ * SDFs the sampling pass of a training step computes anyway are max-folded into the value grid (no decay: the periodic
+ * refresh decays and re-thresholds).  n_dev (may be NULL): valid points = min(n, *n_dev + n_add), 0 if that exceeds n. */
+int nsim_occ_collect(float* val, const float* pts, const float* sdf, int64_t n, const int64_t* n_dev, int64_t n_add,
+                     const NsimOccMeta* meta, float inv_s, void* stream);
 /* OccGridAccel.ray_march (march_cfg{step_size,max_steps}): lattice t_k = near + (k + jitter) * step.
  * ray_word_off (may be NULL): batched occupancy grid (``accel_cfg{type: occ_grid_batched}``,
  * code_multi/.../no_fg_occ.221218.yaml:369-377) -- offset in 32-bit words of ray r's instance inside ``bits``. */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "nsim_occ_decay": [_P, _I64, _F],
     "nsim_occ_update": [_P, _P, _P, _I64, C.POINTER(OccMeta), _F],
     "nsim_occ_pack_bits": [_P, _I64, _F, _P],
+    "nsim_occ_collect": [_P, _P, _P, _I64, _P, _I64, C.POINTER(OccMeta), _F],
     "nsim_march_count": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P],
     "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
     "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],

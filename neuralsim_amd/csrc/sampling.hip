@@ -162,10 +162,16 @@ __global__ void __launch_bounds__(256) k_occ_decay(float* __restrict__ val, int6
 }
 
 // scatter-max of f(sdf) = 4 sig(s x)(1 - sig(s x)) >= 0: integer atomicMax on the bit pattern is exact
+// n_dev (may be NULL): the number of valid points is min(n, *n_dev + n_add) -- 0 when that exceeds n (a speculatively
+// sized sampling pass that overflowed: the caller redoes it, see k_lotd_gather_lm)
 __global__ void __launch_bounds__(256) k_occ_update(float* __restrict__ val, const float* __restrict__ pts,
                                                      const float* __restrict__ sdf, int64_t n, OccDev m,
-                                                     float inv_s) {
+                                                     float inv_s, const int64_t* __restrict__ n_dev, int64_t n_add) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) {
+    const int64_t nd = n_dev[0] + n_add;
+    n = nd <= n ? nd : 0;
+  }
   if (i >= n) return;
   int64_t flat;
   if (!occ_voxel(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], flat)) return;
@@ -546,7 +552,17 @@ int nsim_occ_update(float* val, const float* pts, const float* sdf, int64_t n, c
   if (n <= 0) return 0;
   if (!meta) return 5;
   hipLaunchKernelGGL(k_occ_update, dim3(nsim_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, val, pts, sdf, n,
-                     occ_dev(meta), inv_s);
+                     occ_dev(meta), inv_s, (const int64_t*)nullptr, (int64_t)0);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_occ_collect(float* val, const float* pts, const float* sdf, int64_t n, const int64_t* n_dev, int64_t n_add,
+                     const NsimOccMeta* meta, float inv_s, void* stream) {
+  if (n <= 0) return 0;
+  if (!meta) return 5;
+  hipLaunchKernelGGL(k_occ_update, dim3(nsim_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, val, pts, sdf, n,
+                     occ_dev(meta), inv_s, n_dev, n_add);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

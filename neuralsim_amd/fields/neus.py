@@ -295,8 +295,20 @@ class OccGridAccel(nn.Module):
     (lotd_neus.dtu.230814.yaml:140-155; nr3d_lib.models.accelerations.OccGridAccel / OccGridEma)."""
 
     def __init__(self, aabb: torch.Tensor, resolution=(64, 64, 64), occ_thre=0.3, ema_decay=0.95, inv_s=256.0,
-                 num_steps=4, num_pts=2 ** 20, n_steps_between_update=16, n_steps_warmup=256, device=None):
+                 num_steps=4, num_pts=2 ** 20, n_steps_between_update=16, n_steps_warmup=256, device=None,
+                 update_from_samples_cfg: Optional[dict] = None, init_cfg: Optional[dict] = None):
         super().__init__()
+        self.init_cfg = dict(init_cfg or {})         # ``init_cfg{mode: from_net, num_steps, num_pts}``: sizes of ``init``
+        # ``update_from_samples_cfg: {}`` (dtu yaml:158): the SDFs of a training step's sampling pass are max-folded into
+        # the value grid as they are computed (``collect``); the periodic refresh then decays, adds its random queries
+        # and re-thresholds.  None = off.  (Implementation in the absent nr3d_lib: semantics fixed here, oracle/render.py
+        # ``occ_collect``.)  ``collect_armed`` is set by the model's ``training_before_per_step`` for ONE sampling pass.
+        self.update_from_samples_cfg = None if update_from_samples_cfg is None else dict(update_from_samples_cfg)
+        self.collect_armed = False
+        # data parallel: ranks render different rays, so their collected values differ -- a trainer sets ``sync_values``
+        # (all-reduce MAX of the 1 MB value grid) and every refresh starts from the union (SURVEY.md sec. 8e; the
+        # reference's DDP re-broadcasts rank 0's buffers instead)
+        self.sync_values = None
         self.resolution = [int(r) for r in resolution]
         self.occ_thre, self.ema_decay, self.inv_s = float(occ_thre), float(ema_decay), float(inv_s)
         self.num_steps, self.num_pts = int(num_steps), int(num_pts)
@@ -344,6 +356,8 @@ class OccGridAccel(nn.Module):
         """EMA-max refresh from random SDF queries (``init_cfg`` / ``update_from_net_cfg``)."""
         dev = self.occ_val.device
         lo, hi = self.aabb[0], self.aabb[1]
+        if self.update_from_samples_cfg is not None and self.sync_values is not None:
+            self.sync_values(self.occ_val)
         for _ in range(num_steps or self.num_steps):
             pts = lo + torch.rand([num_pts or self.num_pts, 3], device=dev, generator=generator) * (hi - lo)
             self.update_from_samples(pts, query_sdf(pts), pack=False)
@@ -360,8 +374,16 @@ class OccGridAccel(nn.Module):
         if pack:
             self.pack_bits()
 
+    @torch.no_grad()
+    def collect(self, pts: torch.Tensor, sdf: torch.Tensor, n_dev: torch.Tensor = None, n_add: int = 0):
+        """Fold the (pts [n,3], sdf [n]) of a sampling-pass query into the value grid (max, no decay, bits untouched)."""
+        _lib.call("nsim_occ_collect", _lib.ptr(self.occ_val), _lib.ptr(pts), _lib.ptr(sdf), sdf.shape[0], _lib.ptr(n_dev),
+                  int(n_add), self.meta, self.inv_s)
+
     def init(self, query_sdf, logger=None, **kw):
         self.occ_val.zero_()
+        kw.setdefault("num_steps", self.init_cfg.get("num_steps"))
+        kw.setdefault("num_pts", self.init_cfg.get("num_pts"))
         self.update_from_net(query_sdf, **kw)
 
     def cur_batch__step(self, it: int, query_sdf, generator=None):
@@ -451,14 +473,16 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             h = bounding_size / 2.0
             aabb = torch.tensor([[-h, -h, -h], [h, h, h]])
         self.encoding.cfg.set_aabb(aabb)           # the pyramid spans the AABB (per axis); must precede fm.lotd = meta below
-        accel_cfg = dict(accel_cfg or {})
+        accel_cfg = dict(accel_cfg) if accel_cfg is not None else dict(update_from_samples_cfg={})     # dtu yaml:140-160
         self.accel = OccGridAccel(aabb, resolution=accel_cfg.get("resolution", (64, 64, 64)),
                                   occ_thre=accel_cfg.get("occ_thre", 0.3), ema_decay=accel_cfg.get("ema_decay", 0.95),
                                   inv_s=accel_cfg.get("occ_val_fn_cfg", {}).get("inv_s", 256.0),
                                   num_steps=accel_cfg.get("update_from_net_cfg", {}).get("num_steps", 4),
                                   num_pts=accel_cfg.get("update_from_net_cfg", {}).get("num_pts", 2 ** 20),
                                   n_steps_between_update=accel_cfg.get("n_steps_between_update", 16),
-                                  n_steps_warmup=accel_cfg.get("n_steps_warmup", 256))
+                                  n_steps_warmup=accel_cfg.get("n_steps_warmup", 256),
+                                  update_from_samples_cfg=accel_cfg.get("update_from_samples_cfg", None),
+                                  init_cfg=accel_cfg.get("init_cfg", None))
         self.ray_query_cfg = dict(ray_query_cfg or dict(
             query_mode="march_occ_multi_upsample_compressed",     # the reference's default (dtu yaml:157)
             query_param=dict(nablas_has_grad=True, num_coarse=64, num_fine=[8, 8, 32], upsample_inv_s=64.0,
@@ -687,6 +711,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def training_before_per_step(self, it: int, logger=None):
         """Per-iteration hook of the reference's trainer (app/resources/asset_bank.py:291-298): inv_s control here; the
         occupancy refresh (``accel.cur_batch__step``) and the level annealing are driven by the trainer."""
+        if self.accel is not None and self.accel.update_from_samples_cfg is not None:
+            self.accel.collect_armed = True          # the coming step's sampling pass feeds the occupancy values
         vc = getattr(self, "_var_ctrl", None)
         if vc is not None:
             span = max(vc["stop_it"] - vc["start_it"], 1)
@@ -871,6 +897,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                   goff=goff, n_dev=n_dev, n_add=R * C)
         else:
             sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
+        collect = with_x and goff is None and self.accel.collect_armed
+        if collect:
+            self.accel.collect(xq, sdf, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
@@ -886,6 +915,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                           R * nf, dev, goff=goff)
             else:
                 sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
+            if collect:
+                self.accel.collect(x_new, sdf_new)
             S2 = S + R * nf
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
@@ -980,6 +1011,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                     if not self._sdf_fused:
                         _lib.TIMER.note_units("nsim_lotd_gather_lm", S0)
                 t, pi, ridx = t_k, pi_k, ridx_k
+        self.accel.collect_armed = False         # one sampling pass per arming (evaluation renders never collect)
         return o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis
 
     def ray_query(self, *, ray_input: dict = None, ray_tested: dict, config, return_buffer: bool = True,

@@ -169,6 +169,8 @@ def neus_native_kwargs(params: dict, aabb=None) -> Tuple[Dict, Dict]:
     de = dict(rc.get("dir_embed_cfg") or dict(type="spherical", degree=4))
     if not rc.get("use_view_dirs", True) or de.get("type") != "spherical" or int(de.get("degree", 4)) != 4:
         _unsupported("radiance_cfg.dir_embed_cfg", de, "view directions enter through spherical harmonics of degree 4")
+    if not rc.get("use_nablas", True):
+        _unsupported("radiance_cfg.use_nablas", False, "the radiance kernel reads the sample normal")
     if not rc.get("use_pos", True):
         _unsupported("radiance_cfg.use_pos", False, "the radiance kernel reads the sample position")
     if int(rc.get("n_appear_embedding", 4)) != 4:
@@ -178,6 +180,11 @@ def neus_native_kwargs(params: dict, aabb=None) -> Tuple[Dict, Dict]:
         _unsupported("accel_cfg.type", acc.get("type"), "occ_grid (and occ_grid_batched on the batched model)")
     if (acc.get("occ_val_fn_cfg") or {}).get("type", "sdf") != "sdf":
         _unsupported("accel_cfg.occ_val_fn_cfg.type", acc["occ_val_fn_cfg"]["type"], "sdf")
+    ic = acc.get("init_cfg")
+    if ic is not None and ic.get("mode", "from_net") != "from_net":
+        _unsupported("accel_cfg.init_cfg.mode", ic.get("mode"), "from_net")
+    if acc.get("update_from_samples_cfg"):
+        _unsupported("accel_cfg.update_from_samples_cfg", acc["update_from_samples_cfg"], "{} (every sampling-pass sample is used)")
     if "vox_size" in acc and "resolution" not in acc:
         assert aabb is not None, "accel_cfg.vox_size needs the AABB (populate(aabb=...))"
         # the AABB is in object units; a street node's scale makes one unit several metres -- the caller's populate
@@ -187,6 +194,9 @@ def neus_native_kwargs(params: dict, aabb=None) -> Tuple[Dict, Dict]:
     kw["accel_cfg"] = acc
     if p.get("ray_query_cfg") is not None:
         kw["ray_query_cfg"] = _plain(p["ray_query_cfg"])
+        cs = (kw["ray_query_cfg"].get("query_param") or {}).get("coarse_step_cfg")
+        if cs is not None and cs.get("step_mode", "linear") != "linear":
+            _unsupported("ray_query_cfg.query_param.coarse_step_cfg.step_mode", cs.get("step_mode"), "linear")
     if aabb is not None:
         kw["aabb"] = aabb
     return kw, post

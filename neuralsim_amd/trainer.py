@@ -84,6 +84,13 @@ class RenderTrainer:
         self.renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=near, far=far, perturb=perturb,
                                                   depth_use_normalized_vw=False)).train()
         self.stats: Dict[str, float] = {}
+        if world_size > 1 and getattr(model, "accel", None) is not None:
+            import torch.distributed as dist
+
+            def _sync_occ(v):        # union of the ranks' render-time occupancy values before every refresh
+                if dist.is_initialized() and not self.skip_allreduce:
+                    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            model.accel.sync_values = _sync_occ
 
     def pose_refine_active(self) -> bool:
         return self.pose_refine is not None and self._it >= int(self.pose_refine.get("start_it", 500))

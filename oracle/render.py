@@ -95,6 +95,13 @@ def occ_update(occ_val: torch.Tensor, pts, sdf, aabb_min, scale, res, decay=0.95
     return out
 
 
+def occ_collect(occ_val: torch.Tensor, pts, sdf, aabb_min, scale, res, inv_s=256.0):
+    """``update_from_samples_cfg: {}`` (lotd_neus.dtu.230814.yaml:158): the samples of a training step's sampling pass
+    folded into the value grid -- ``occ_update`` without the decay (the periodic refresh decays).  Semantics fixed here
+    (nr3d_lib absent): PARITY UNPINNED."""
+    return occ_update(occ_val, pts, sdf, aabb_min, scale, res, decay=1.0, inv_s=inv_s)
+
+
 def build_occ_grid(p: FieldParams, aabb_min, aabb_max, res, n_pts=2 ** 18, n_steps=4, thre=0.3,
                    inv_s=256.0, seed=0):
     """``init_cfg{mode: from_net}``: EMA grid from random SDF queries -> (val f32 [res^3], occ bool)."""
@@ -261,7 +268,7 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
             sdf[pa] = sdf_old
             sdf[pb.reshape(-1)] = sdf_new
             ridx = po.pack_ridx(pi, t.shape[0])
-    ret['debug'] = dict(t=t, sdf_nograd=sdf, pack_infos=pi, march_counts=cnt_m)
+    ret['debug'] = dict(t=t, sdf_nograd=sdf, pack_infos=pi, march_counts=cnt_m, ridx=ridx, x_nograd=o[ridx] + t[:, None] * d[ridx])
     if compress:
         # ``march_occ_multi_upsample_compressed``: keep the samples that bound an interval with vw > thre
         with torch.no_grad():

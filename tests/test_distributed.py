@@ -185,12 +185,17 @@ def _gpu_dp_worker(rank, world, port, out_dir, overlap):
     tr = RenderTrainer(m, intr, c2w, WH, num_rays=256, lr=1e-3, num_uniform=64, rank=rank, world_size=world,
                        target_sphere_radius=0.5)
     assert tr._fused_ok() and tr.overlap_allreduce == (overlap == "1")
-    losses = [float(tr.train_step(it)) for it in range(4)]
+    # 34 iterations = eight occupancy refreshes (every 4 from iteration 2): render-time values are collected per rank
+    # (update_from_samples_cfg) and united by the MAX all-reduce before each refresh
+    assert m.accel.update_from_samples_cfg is not None and m.accel.sync_values is not None
+    losses = [float(tr.train_step(it)) for it in range(34)]
     assert all(l == l for l in losses)
+    for t in (m.encoding.flattened_params, m.sdf_w, m.rad_w, tr.appear, m.accel.occ_val, m.accel.occ_bits):
+        g = t.detach().clone()
+        gs = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        assert torch.equal(gs[0], gs[1])              # replicas bit-identical: parameters AND occupancy
     g = m.encoding.flattened_params.detach().clone()
-    gs = [torch.zeros_like(g) for _ in range(world)]
-    dist.all_gather(gs, g)
-    assert torch.equal(gs[0], gs[1])                  # replicas in sync
     if rank == 0:
         torch.save(dict(grid=g.cpu(), sdf_w=m.sdf_w.detach().cpu(), losses=torch.tensor(losses)),
                    str(Path(out_dir) / f"gpu_overlap{overlap}.pt"))
@@ -204,6 +209,7 @@ def test_two_rank_overlapped_schedule_on_gpu(tmp_path):
     for overlap in ("1", "0"):
         mp.spawn(_gpu_dp_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
     a, b = (torch.load(str(tmp_path / f"gpu_overlap{o}.pt")) for o in ("1", "0"))
-    assert torch.allclose(a["losses"], b["losses"], rtol=1e-4, atol=1e-6)
-    for k in ("grid", "sdf_w"):     # float atomics commute only approximately (+ Adam on tiny gradients)
-        assert torch.allclose(a[k], b[k], rtol=1e-3, atol=2e-4), (k, float((a[k] - b[k]).abs().max()))
+    # the two schedules see the same batches for the first iterations; float atomics commute only approximately, Adam
+    # amplifies that, and after the first refresh the occupancy (hence the sample sets) may differ: compare the start
+    assert torch.allclose(a["losses"][:4], b["losses"][:4], rtol=1e-4, atol=1e-6)
+    assert float(a["losses"][-1]) < float(a["losses"][0]) and float(b["losses"][-1]) < float(b["losses"][0])

@@ -211,3 +211,49 @@ def test_neus_alpha_and_composite(backend):
                 assert err < 2e-4, (nm, fis, nd, float(err))
             if fis == 0.0:
                 assert abs(float(l_d.grad.cpu()) - float(l_o.grad)) / max(1e-9, abs(float(l_o.grad))) < 2e-3
+
+
+def test_occupancy_collects_the_sampling_pass(backend):
+    """``accel_cfg.update_from_samples_cfg: {}`` (dtu yaml:158): one armed training-step sampling pass max-folds the SDF of
+    every sample it queries into the value grid (no decay, bits untouched until the next refresh) == the oracle's
+    ``occ_collect`` on the oracle's own samples; evaluation passes (not armed) leave the grid alone."""
+    from oracle import render as orr
+    from util import look_at_cameras, make_params, model_from_params
+    from neuralsim_amd.fields.neus import OccGridAccel
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=3, ln_inv_s=0.45, grid_bound=2e-2, noise_scale=1.0)
+    g = torch.Generator().manual_seed(1)
+    intr, c2w, WH = look_at_cameras(V=3, seed=3)
+    N = 40
+    o, d = orr.pinhole_rays(torch.rand(N, 2, generator=g) * 0.5 + 0.25, torch.randint(0, 3, (N,), generator=g), intr, c2w, WH)
+    aabb = torch.tensor([[-1.0, -1, -1], [1.0, 1, 1]])
+    res = [16, 16, 16]
+    model = model_from_params(p, backend, precision="f32")
+    model.accel = OccGridAccel(aabb, resolution=res, device=backend, update_from_samples_cfg={})
+    val0, occ = orr.build_occ_grid(p, aabb[0], aabb[1], res, n_pts=2 ** 12, n_steps=2)
+    val0 = val0 * 0.5                                           # so that fresh samples can raise values
+    model.accel.occ_val.copy_(val0.to(backend))
+    model.accel.pack_bits()
+    bits0 = model.accel.occ_bits.clone()
+    qp = dict(nablas_has_grad=True, num_coarse=16, num_fine=[4, 4, 8], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4, 16],
+              upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.02, max_steps=512))
+    cfg = dict(query_param=qp, with_rgb=True, query_mode="march_occ_multi_upsample")
+    dv = lambda a: a.to(backend).contiguous()        # noqa: E731
+    tested = model.ray_test(dv(o), dv(d), near=0.01)
+    model.ray_query(ray_tested=tested, config=cfg)               # not armed: an evaluation render
+    assert torch.equal(model.accel.occ_val.cpu(), val0)
+    model.training_before_per_step(0)                            # arms ONE pass
+    assert model.accel.collect_armed
+    model.ray_query(ray_tested=tested, config=cfg)
+    assert not model.accel.collect_armed
+    ret_o = orr.ray_query(p, o, d, None, val0 > 0.3, aabb[0], aabb[1], res, near=0.01, num_coarse=16, num_fine=(4, 4, 8),
+                          step_size=0.02, max_steps=512)
+    res_t = torch.tensor(res)
+    want = orr.occ_collect(val0, ret_o["debug"]["x_nograd"], ret_o["debug"]["sdf_nograd"], aabb[0],
+                           res_t.float() / (aabb[1] - aabb[0]), res_t)
+    got = model.accel.occ_val.cpu()
+    assert float((want > val0).float().mean()) > 0.02           # the pass did raise values
+    # identical up to fine samples that sit within rounding of a voxel face (their positions differ by ~1e-6)
+    assert float(((got - want).abs() > 1e-4).float().mean()) < 2e-3
+    assert torch.equal(model.accel.occ_bits, bits0)              # thresholded only by the next refresh
+    model.ray_query(ray_tested=tested, config=cfg)               # a second, un-armed pass: unchanged
+    assert torch.equal(model.accel.occ_val.cpu(), got)

@@ -13,7 +13,7 @@ def _tiny(backend, seed=42):
               upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
     m = LoTDNeuSModel(lod_res=SMALL_RES, log2_hashmap_size=10, sdf_D=2, precision="fp16", ln_inv_s_init=0.3,
                       accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
-                                     n_steps_between_update=4, n_steps_warmup=2),
+                                     update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
                       ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp), seed=seed).to(backend)
     m.geometric_init_sphere(0.5)
     m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
