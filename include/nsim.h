@@ -391,6 +391,21 @@ int nsim_adam_step(float* p, void* p16, float* grad, float* m, float* v, int64_t
                    float beta2, float eps, float bias1, float bias2, float grad_scale, int zero_grad,
                    void* stream);
 
+/* The same update for up to NSIM_ADAM_MULTI_MAX small tensors in one launch (the decoder weights / biases, inv_s and
+ * appearance codes of a step); per tensor: its own betas / bias corrections and a learning-rate factor. */
+#define NSIM_ADAM_MULTI_MAX 12
+typedef struct {
+  float* p;
+  void* p16;        /* may be NULL */
+  float* grad;
+  float* m;
+  float* v;
+  int64_t n;
+  float beta1, beta2, bias1, bias2, lr_scale;
+} NsimAdamTensor;
+int nsim_adam_multi(const NsimAdamTensor* tensors, int n_tensors, float lr, float eps, float grad_scale, int zero_grad,
+                    void* stream);
+
 /* MFMA layout self-test (tests only): writes D = A(32x16 f16) * B(16x32 f16) with the wrappers used by the
  * field kernels; a, b given in plain row-major. d is 32x32 f32 row-major. */
 int nsim_selftest_mfma(const float* a, const float* b, float* d, int use_f32, void* stream);

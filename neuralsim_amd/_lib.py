@@ -40,6 +40,15 @@ class SkyMeta(C.Structure):
     _fields_ = [("n_frequencies", C.c_int32), ("n_appear", C.c_int32), ("precision", C.c_int32)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("p16", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("n", C.c_int64), ("beta1", C.c_float), ("beta2", C.c_float), ("bias1", C.c_float), ("bias2", C.c_float),
+                ("lr_scale", C.c_float)]
+
+
+ADAM_MULTI_MAX = 12
+
+
 class FieldMeta(C.Structure):
     _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
 
@@ -108,6 +117,7 @@ SIGNATURES = {
     "nsim_gather_rays": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_sphere_image": [_P, _P, _I64, _F, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],
+    "nsim_adam_multi": [C.POINTER(AdamTensor), _I, _F, _F, _F, _I],
     "nsim_selftest_mfma": [_P, _P, _P, _I],
 }
 NOSTREAM = {

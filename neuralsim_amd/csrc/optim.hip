@@ -25,6 +25,49 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, f16* __rest
   }
 }
 
+// The small parameter tensors of a step (decoder weights and biases, inv_s, appearance codes: seven launches of a few
+// thousand elements each) in ONE launch: blockIdx.y selects the tensor.
+struct AdamMulti {
+  NsimAdamTensor t[NSIM_ADAM_MULTI_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti a, float lr, float eps, float grad_scale, int zero_grad) {
+  const NsimAdamTensor t = a.t[blockIdx.y];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  f16* p16 = (f16*)t.p16;
+  for (; i < t.n; i += stride) {
+    const float g = t.grad[i] * grad_scale;
+    const float mi = t.beta1 * t.m[i] + (1.0f - t.beta1) * g;
+    const float vi = t.beta2 * t.v[i] + (1.0f - t.beta2) * g * g;
+    t.m[i] = mi;
+    t.v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(t.bias2) + eps;
+    const float pi = t.p[i] - (lr * t.lr_scale / t.bias1) * (mi / denom);
+    t.p[i] = pi;
+    if (p16) p16[i] = (f16)pi;
+    if (zero_grad) t.grad[i] = 0.f;
+  }
+}
+
+extern "C" int nsim_adam_multi(const NsimAdamTensor* tensors, int n_tensors, float lr, float eps, float grad_scale,
+                               int zero_grad, void* stream) {
+  if (n_tensors <= 0) return 0;
+  if (!tensors || n_tensors > NSIM_ADAM_MULTI_MAX) return 2;
+  AdamMulti a;
+  int64_t nmax = 0;
+  for (int k = 0; k < n_tensors; ++k) {
+    a.t[k] = tensors[k];
+    if (!a.t[k].p || !a.t[k].grad || !a.t[k].m || !a.t[k].v) return 4;
+    nmax = a.t[k].n > nmax ? a.t[k].n : nmax;
+  }
+  if (nmax <= 0) return 0;
+  hipLaunchKernelGGL(k_adam_multi, dim3(nsim_blocks(nmax, 256, 1024), n_tensors), dim3(256), 0, (hipStream_t)stream, a, lr,
+                     eps, grad_scale, zero_grad);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int nsim_adam_step(float* p, void* p16, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float bias1, float bias2, float grad_scale, int zero_grad,
                               void* stream) {

@@ -172,11 +172,35 @@ __global__ void __launch_bounds__(256) k_occ_update(float* __restrict__ val, con
     const int64_t nd = n_dev[0] + n_add;
     n = nd <= n ? nd : 0;
   }
-  if (i >= n) return;
-  int64_t flat;
-  if (!occ_voxel(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], flat)) return;
-  const float s = 1.0f / (1.0f + expf(-sdf[i] * inv_s));
-  const float v = 4.0f * s * (1.0f - s);
+  // Consecutive samples of a ray share voxels (64^3 grid: ~6 marching steps per voxel) and most values do not exceed
+  // what the grid already holds: same-address atomics are separate requests that serialise in L2, so (1) equal voxels
+  // of neighbouring lanes are max-reduced inside the wave and only the last lane of a run goes on, (2) it skips the
+  // atomic when a plain read already shows a value >= its own (the grid only grows between refreshes).
+  const int lane = nsim_lane();
+  int64_t flat = -1 - lane;
+  float v = 0.f;
+  bool ok = i < n;
+  if (ok) {
+    int64_t f;
+    ok = occ_voxel(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], f);
+    if (ok) {
+      flat = f;
+      const float s = 1.0f / (1.0f + expf(-sdf[i] * inv_s));
+      v = 4.0f * s * (1.0f - s);
+    }
+  }
+  const int64_t pk = wave_shfl(flat, lane - 1);
+  const unsigned long long heads = wave_ballot(lane == 0 || pk != flat);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = wave_shfl(v, lane - d);
+    if (lane - d >= run_start) v = fmaxf(v, o);
+  }
+  const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+  if (!ok || !last) return;
+  if (val[flat] >= v) return;
   int iv;
   memcpy(&iv, &v, 4);
   atomicMax((int*)val + flat, iv);

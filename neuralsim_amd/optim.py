@@ -54,15 +54,27 @@ class FusedAdam:
         the step counter of the bias corrections advances here)."""
         self.t += 1
         lr = self.lr if lr is None else lr
+        small = []
         for g in self.groups:
             p = g["p"]
             if p.grad is None or any(p is q for q in skip):
                 continue
             b1, b2 = g["betas"]
             p16 = g["p16"]() if g["p16"] is not None else None
+            if p.numel() < (1 << 18) and p16 is None:     # batched below: one launch for all of them
+                small.append((g, p.grad.contiguous()))
+                continue
             _lib.call("nsim_adam_step", _lib.ptr(p.data), _lib.ptr(p16), _lib.ptr(p.grad.contiguous()), _lib.ptr(g["m"]),
                       _lib.ptr(g["v"]), p.numel(), float(lr), float(b1), float(b2), float(self.eps),
                       1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(grad_scale), 0)
+        for k in range(0, len(small), _lib.ADAM_MULTI_MAX):
+            chunk = small[k:k + _lib.ADAM_MULTI_MAX]
+            arr = (_lib.AdamTensor * len(chunk))()
+            for i, (g, grad) in enumerate(chunk):
+                b1, b2 = g["betas"]
+                arr[i] = _lib.AdamTensor(g["p"].data_ptr(), None, grad.data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
+                                         g["p"].numel(), b1, b2, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0)
+            _lib.call("nsim_adam_multi", arr, len(chunk), float(lr), float(self.eps), float(grad_scale), 0)
         for m in self._dirty:
             m._wpack_versions = None           # MLP weights changed in place: re-pack the MFMA fragments lazily
 

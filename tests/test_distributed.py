@@ -190,11 +190,13 @@ def _gpu_dp_worker(rank, world, port, out_dir, overlap):
     assert m.accel.update_from_samples_cfg is not None and m.accel.sync_values is not None
     losses = [float(tr.train_step(it)) for it in range(34)]
     assert all(l == l for l in losses)
-    for t in (m.encoding.flattened_params, m.sdf_w, m.rad_w, tr.appear, m.accel.occ_val, m.accel.occ_bits):
+    m.accel.sync_values(m.accel.occ_val)              # the values collected since the last refresh are per rank: unite them
+    for name, t in (("grid", m.encoding.flattened_params), ("sdf_w", m.sdf_w), ("rad_w", m.rad_w), ("appear", tr.appear),
+                    ("occ_bits", m.accel.occ_bits), ("occ_val", m.accel.occ_val)):
         g = t.detach().clone()
         gs = [torch.zeros_like(g) for _ in range(world)]
         dist.all_gather(gs, g)
-        assert torch.equal(gs[0], gs[1])              # replicas bit-identical: parameters AND occupancy
+        assert torch.equal(gs[0], gs[1]), name        # replicas bit-identical: parameters AND occupancy
     g = m.encoding.flattened_params.detach().clone()
     if rank == 0:
         torch.save(dict(grid=g.cpu(), sdf_w=m.sdf_w.detach().cpu(), losses=torch.tensor(losses)),

@@ -75,3 +75,31 @@ def test_fused_adam_step_range_equals_full_step(backend):
         outs.append([q.detach().clone().cpu() for q in opt.params()] + [m.encoding.shadow().clone().cpu()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_adam_multi_equals_single_tensor_steps(backend):
+    """``nsim_adam_multi`` (all small tensors of a step in one launch) == one ``nsim_adam_step`` per tensor, bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    sizes = [6208, 129, 5952, 131, 400, 1]
+    betas = [(0.9, 0.99)] * 5 + [(0.9, 0.999)]
+    P = [torch.randn(n, generator=g) * 0.1 for n in sizes]
+    G = [torch.randn(n, generator=g) * 1e-3 for n in sizes]
+    lr, eps, t, gs = 3e-3, 1e-15, 4, 0.5
+
+    def state():
+        return ([p.clone().to(backend) for p in P], [x.clone().to(backend) for x in G],
+                [torch.full((n,), 1e-4, device=backend) for n in sizes], [torch.full((n,), 1e-7, device=backend) for n in sizes])
+    p1, g1, m1, v1 = state()
+    for k in range(len(sizes)):
+        b1, b2 = betas[k]
+        _lib.call("nsim_adam_step", _lib.ptr(p1[k]), None, _lib.ptr(g1[k]), _lib.ptr(m1[k]), _lib.ptr(v1[k]), sizes[k], lr, b1, b2,
+                  eps, 1.0 - b1 ** t, 1.0 - b2 ** t, gs, 0)
+    p2, g2, m2, v2 = state()
+    arr = (_lib.AdamTensor * len(sizes))()
+    for k in range(len(sizes)):
+        b1, b2 = betas[k]
+        arr[k] = _lib.AdamTensor(p2[k].data_ptr(), None, g2[k].data_ptr(), m2[k].data_ptr(), v2[k].data_ptr(), sizes[k], b1, b2,
+                                 1.0 - b1 ** t, 1.0 - b2 ** t, 1.0)
+    _lib.call("nsim_adam_multi", arr, len(sizes), lr, eps, gs, 0)
+    for a, b in zip(p1 + m1 + v1, p2 + m2 + v2):
+        assert torch.equal(a.cpu(), b.cpu())
