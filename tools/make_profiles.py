@@ -14,7 +14,7 @@ ABI = {
     "nsim_field_fwd": "k_field<0, 2, 3>",            # decoder half; its gather half is k_lotd_gather_lm<0, true>
     "nsim_field_fwd(gather)": "k_lotd_gather_lm<0, true>",
     "nsim_field_bwd_sdf": "k_field<0, 2, 2>",
-    "nsim_field_bwd_rad": "k_rad_bwd<0>",
+    "nsim_field_bwd_rad": "k_rad_bwd_j<0>",
     "nsim_lotd_scatter": "k_lotd_scatter",
 }
 
@@ -23,14 +23,14 @@ def main():
     bench = json.loads((G / "prof_bench.json").read_text().strip().splitlines()[-1])
     (P / f"{TAG}_bench_n1.json").write_text(json.dumps(bench, indent=1))
     st = json.loads((G / "prof_stats.json").read_text())
-    steps = 48
-    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline   (MI355X, {TAG})",
+    steps = 48          # 16 warm-up + 32 timed
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants   (MI355X, {TAG})",
              f"{'kernel':72s} {'calls':>7s} {'us/step':>9s} {'avg us':>9s} {'%':>6s}"]
     for k in st["kernels"][:40]:
         lines.append(f"{k['name'][:72]:72s} {k['calls']:7d} {k['total_us'] / steps:9.1f} {k['avg_us']:9.2f} {k['pct']:6.2f}")
     (P / f"{TAG}_rocprofv3_kernel_stats.txt").write_text("\n".join(lines) + "\n")
     (P / f"{TAG}_rocprofv3_kernel_stats.json").write_text(json.dumps(dict(
-        command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline",
+        command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants",
         kernels=st["kernels"][:40], dispatch=st.get("dispatch", [])), indent=1))
     fe = json.loads((G / "prof_pmc_fetch.json").read_text()).get("pmc", {})
     wr = json.loads((G / "prof_pmc_write.json").read_text()).get("pmc", {})
@@ -51,6 +51,40 @@ def main():
             "access widths of these kernels are uncalibrated. Counters are memory-side (Infinity-Cache hits included).")
     (P / f"{TAG}_rocprofv3_pmc_hbm.json").write_text(json.dumps(dict(note=note, kernels=out), indent=1))
     (P / "traffic.json").write_text(json.dumps(traffic, indent=1))
+    gp = G / "prof_gaps.json"
+    if gp.exists():
+        (P / f"{TAG}_gap_profile.json").write_text(gp.read_text())
+    sq = G / "prof_pmc_sq.json"
+    if sq.exists():
+        q = json.loads(sq.read_text())
+        disp = {d["name"]: d for d in q.get("dispatch", [])}
+        ks = {}
+        for name, c in q.get("pmc", {}).items():
+            if "k_field" not in name and "k_rad" not in name and "k_lotd" not in name:
+                continue
+            v = {k: x["avg"] for k, x in c.items()}
+            rec = dict(counters=v, launches=int(next(iter(c.values()))["n"]))
+            if v.get("GRBM_GUI_ACTIVE"):
+                rec["mfma_util_pct"] = round(100.0 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 2)
+            if v.get("SQ_WAVE_CYCLES"):
+                w = v["SQ_WAVE_CYCLES"]
+                rec["valu_active_per_wave_cycle"] = round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / w, 3)
+                rec["wait_any_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / w, 3)
+                rec["wait_inst_any_frac"] = round(v.get("SQ_WAIT_INST_ANY", 0.0) / w, 3)
+                if v.get("SQ_BUSY_CU_CYCLES"):
+                    rec["waves_per_cu_cycle"] = round(w / v["SQ_BUSY_CU_CYCLES"], 2)
+            d = disp.get(name)
+            if d:
+                rec.update(vgpr=d["vgpr"], agpr=d["agpr"], lds=d["lds"], scratch=d["scratch"], avg_us=round(d["avg_ns"] / 1e3, 1))
+            ks[name] = rec
+        (P / f"{TAG}_rocprofv3_pmc_mfma.json").write_text(json.dumps(dict(
+            command="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
+                    "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --steps 32 --warmup 16 "
+                    "--no-cpu-baseline --no-variants",
+            note="per-launch averages. mfma_util_pct = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) "
+                 "(gfx94x derived-metric formula); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; "
+                 "waves_per_cu_cycle = SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES = resident waves per busy CU (4 SIMDs).",
+            kernels=ks), indent=1))
     print(json.dumps(traffic, indent=1))
     print(bench["value"], bench["ms_per_step"], bench["roofline"])
 

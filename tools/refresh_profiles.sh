@@ -1,18 +1,22 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): bench line + rocprofv3 kernel stats + the two HBM PMC passes of the same command.
-# Small JSON summaries land in gpurun_out/ (the raw databases stay in /tmp); tools/make_profiles.py turns them into
-# the tracked files under profiles/.
+# Runs ON THE GPU BOX (via gpurun): bench line + rocprofv3 kernel stats + gap profile + the HBM and SQ/MFMA PMC passes of
+# the same command (counters in their own runs, --kernel-trace only).  Small JSON summaries land in gpurun_out/ (the raw
+# databases stay in /tmp); tools/make_profiles.py turns them into the tracked files under profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline"
-timeout 600 python $R/bench.py > $O/prof_bench.json 2> $O/prof_bench.err
+CMD="python $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants"
+timeout 900 python $R/bench.py > $O/prof_bench.json 2> $O/prof_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o s -- $CMD > $O/prof_stats_bench.json 2>/tmp/e1.log
-python $R/tools/prof_summary.py $(find /tmp/p_stats -name "*.db" | head -1) $O/prof_stats.json
+DB=$(find /tmp/p_stats -name "*.db" | head -1)
+python $R/tools/prof_summary.py $DB $O/prof_stats.json
+python $R/tools/gap_profile.py $DB $O/prof_gaps.json
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o f -- $CMD > /dev/null 2>/tmp/e2.log
 python $R/tools/prof_summary.py $(find /tmp/p_fetch -name "*.db" | head -1) $O/prof_pmc_fetch.json
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o w -- $CMD > /dev/null 2>/tmp/e3.log
 python $R/tools/prof_summary.py $(find /tmp/p_write -name "*.db" | head -1) $O/prof_pmc_write.json
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/p_sq -o q -- $CMD > /dev/null 2>/tmp/e4.log
+python $R/tools/prof_summary.py $(find /tmp/p_sq -name "*.db" | head -1) $O/prof_pmc_sq.json
 tail -1 $O/prof_bench.json | cut -c1-300
