@@ -456,6 +456,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * NW;
   for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += wstride) {
+    const int64_t grp = tile / NW;      // (stamps of -DNSIM_KTIME builds: the wave-0 tile sequence of this workgroup)
+    (void)grp;
+    if constexpr (MODE == 2) { KT(1, 0); }
     const TilePoint p = load_point(a, tile, j, FWD);
     const bool valid = p.valid;
     const int64_t s = p.s;
@@ -548,6 +551,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
       }
     }
+    if constexpr (MODE == 2) { KT(1, 1); }
     // ---------------------------------------------------------------- SDF decoder forward
     float a1[32];
     dense<PREC, 2, NC>(a1, WM + LM.mat[M_W1], h, true);
@@ -645,6 +649,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     }
     // ======================================================================================= backward
     if constexpr (MODE == 2) {
+      KT(1, 2);
       float gs = 0.f, gn[3] = {0.f, 0.f, 0.f};
       if (valid) {
         if (a.dsdf) gs = a.dsdf[s];
@@ -675,10 +680,13 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               }
             }
       }
+      KT(1, 3);
       float dh1[32];  // dL / d d1  = W1 . gh
       dense<PREC, 2, NC>(dh1, WM + LM.mat[M_W1], gh, true);
+      KT(1, 4);
       const bool do_dw = !(a.ablate & 4);
       if (do_dw) dw_product<PREC, 2, NC, PRIV>(stA, stB, d1, gh, accum + AO.w1, 32 * NC, 64, 32 * NC, nullptr);
+      KT(1, 5);
       float dz1[32];
       float whv[32];  // vector-shaped gradient of the SDF head weights
       if constexpr (SDF_D == 2) {
@@ -692,7 +700,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         float d2[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(W, L, V_WH, hi, k);
+        KT(1, 6);
         if (do_dw) dw_product<PREC, 2, 2, PRIV>(stA, stB, d2, eh1, accum + AO.w2, 64, 64, 64, nullptr);
+        KT(1, 7);
         float dh2[32];  // dL / d d2 = W2 . eh1
         dense<PREC, 2, 2>(dh2, WM + LM.mat[M_W2], eh1, true);
         float dz2[32];
@@ -703,9 +713,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           whv[k] = dh2[k] * s2 + gs * a2[k];
           dz2[k] = gs * wh * s2 + dh2[k] * wh * (beta * s2 * (1.0f - s2));
         }
+        KT(1, 8);
         if (do_dw) dw_product<PREC, 2, 2, PRIV>(stA, stB, dz2, a1, accum + AO.w2, 64, 64, 64, accum + AO.b2);
+        KT(1, 9);
         float da1[32];
         dense<PREC, 2, 2>(da1, WM + LM.mat[M_W2T], dz2, true);
+        KT(1, 10);
 #pragma unroll
         for (int k = 0; k < 32; ++k) dz1[k] = dz1[k] + da1[k] * sig_from_softplus(a1[k], beta);
       } else {
@@ -717,7 +730,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           dz1[k] = gs * wh * s1 + dh1[k] * wh * (beta * s1 * (1.0f - s1));
         }
       }
+      KT(1, 11);
       if (do_dw) rowsum_acc<PREC, 2, PRIV>(stA, whv, accum + AO.wh, 64);
+      KT(1, 12);
       {
         float v = (hi == 0) ? gs : 0.f;
         v = wave_sum(v);
@@ -727,8 +742,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
       }
       if (do_dw) dw_product<PREC, 2, NC, PRIV>(stA, stB, dz1, h, accum + AO.w1, 32 * NC, 64, 32 * NC, accum + AO.b1);
+      KT(1, 13);
       float dh[16 * NC];
       dense<PREC, NC, 2>(dh, WM + LM.mat[M_W1T], dz1, true);
+      KT(1, 14);
       if (a.dx) {   // pose refinement: dL/dx += (dh/dx)^T dL/dh  (dh/dx re-read from the planes: this path is rare)
         float acc[3] = {0.f, 0.f, 0.f};
         if (valid) {
@@ -773,6 +790,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           }
         }
       }
+      KT(1, 15);
+      KT(1, 16);
+      KT(1, 17);
     }
   }
 

@@ -15,10 +15,9 @@ from neuralsim_amd import _lib  # noqa: E402
 LABELS = {0: ["loop top", "loads+rin", "rad fwd (2 dense)", "dout/scale", "barrier A3", "stage P3", "barrier B3", "dW3+rowsum",
               "dense R3T", "barrier A2", "stage P2", "barrier B2", "dW2+rowsum", "dense R2T", "barrier A1", "stage P1+barrier",
               "dW1+rowsum", "dense R1T + outputs"],
-          1: ["loop top", "loads gs/gn/J -> gh", "fwd recompute + g store", "barrier A(d1,gh)", "stage+barrier+dW1a", "dense dh1",
-              "dz1/eh1/d2", "barrier A(d2,eh1)", "stage+barrier+dW2a", "dense dh2, whv/dz2", "barrier A(dz2,a1)",
-              "stage+barrier+dW2b+rowsums", "dense da1, dz1", "barrier A(dz1,h)", "stage+barrier+dW1b+rowsum", "dense dh",
-              "dh store", "-"]}
+          1: ["loop top", "loads h, J (planes)", "fwd recompute (a1 a2 d2 e1 d1 g)", "gs/gn loads, gh", "dense dh1", "dW(d1,gh)",
+              "dz1/eh1/d2", "dW(d2,eh1)", "dense dh2, whv/dz2", "dW(dz2,a1)", "dense da1", "dz1 +=", "rowsum whv",
+              "dW(dz1,h)", "dense dh", "dh/g stores", "-", "-"]}
 
 
 def main():

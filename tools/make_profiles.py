@@ -24,13 +24,13 @@ def main():
     (P / f"{TAG}_bench_n1.json").write_text(json.dumps(bench, indent=1))
     st = json.loads((G / "prof_stats.json").read_text())
     steps = 48          # 16 warm-up + 32 timed
-    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants   (MI355X, {TAG})",
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity   (MI355X, {TAG})",
              f"{'kernel':72s} {'calls':>7s} {'us/step':>9s} {'avg us':>9s} {'%':>6s}"]
     for k in st["kernels"][:40]:
         lines.append(f"{k['name'][:72]:72s} {k['calls']:7d} {k['total_us'] / steps:9.1f} {k['avg_us']:9.2f} {k['pct']:6.2f}")
     (P / f"{TAG}_rocprofv3_kernel_stats.txt").write_text("\n".join(lines) + "\n")
     (P / f"{TAG}_rocprofv3_kernel_stats.json").write_text(json.dumps(dict(
-        command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants",
+        command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity",
         kernels=st["kernels"][:40], dispatch=st.get("dispatch", [])), indent=1))
     fe = json.loads((G / "prof_pmc_fetch.json").read_text()).get("pmc", {})
     wr = json.loads((G / "prof_pmc_write.json").read_text()).get("pmc", {})
@@ -80,7 +80,7 @@ def main():
         (P / f"{TAG}_rocprofv3_pmc_mfma.json").write_text(json.dumps(dict(
             command="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
                     "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --steps 32 --warmup 16 "
-                    "--no-cpu-baseline --no-variants",
+                    "--no-cpu-baseline --no-variants --no-parity",
             note="per-launch averages. mfma_util_pct = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) "
                  "(gfx94x derived-metric formula); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; "
                  "waves_per_cu_cycle = SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES = resident waves per busy CU (4 SIMDs).",

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants"
+CMD="python $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity"
 timeout 900 python $R/bench.py > $O/prof_bench.json 2> $O/prof_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o s -- $CMD > $O/prof_stats_bench.json 2>/tmp/e1.log
 DB=$(find /tmp/p_stats -name "*.db" | head -1)
