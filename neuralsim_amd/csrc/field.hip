@@ -285,7 +285,7 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 // Development aid (-DNSIM_KTIME, never in the product build): s_memtime stamps of wave 0 of the first 64 workgroups at
 // phase boundaries of their SECOND group iteration, read back by tools/ktime.py through nsim_debug_ktime.
 #ifdef NSIM_KTIME
-__device__ long long g_ktime[2][64 * 24];
+__device__ long long g_ktime[3][64 * 24];
 #define KT(K, i)                                                                                          \
   if (blockIdx.x < 64 && wave == 0 && lane == 0 && (grp == (int64_t)blockIdx.x + gridDim.x || (i) >= 20)) \
   g_ktime[K][blockIdx.x * 24 + (i)] = (long long)__builtin_amdgcn_s_memtime()
@@ -459,6 +459,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     const int64_t grp = tile / NW;      // (stamps of -DNSIM_KTIME builds: the wave-0 tile sequence of this workgroup)
     (void)grp;
     if constexpr (MODE == 2) { KT(1, 0); }
+    if constexpr (MODE == 3) { KT(2, 0); }
     const TilePoint p = load_point(a, tile, j, FWD);
     const bool valid = p.valid;
     const int64_t s = p.s;
@@ -552,6 +553,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       }
     }
     if constexpr (MODE == 2) { KT(1, 1); }
+    if constexpr (MODE == 3) { KT(2, 1); }
     // ---------------------------------------------------------------- SDF decoder forward
     float a1[32];
     dense<PREC, 2, NC>(a1, WM + LM.mat[M_W1], h, true);
@@ -575,6 +577,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
       if (valid && hi == 0) a.sdf[s] = sdf;
       continue;
     }
+    if constexpr (MODE == 3) { KT(2, 2); }
     // ---------------------------------------------------------------- d sdf / d h  (the "g chain")
     float e1[32];  // d sdf / d a1  (only SDF_D == 2)
     float d1[32];  // d sdf / d z1
@@ -595,6 +598,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     float g[16 * NC];
     dense<PREC, NC, 2>(g, WM + LM.mat[M_W1T], d1, false);
     if constexpr (FWD) {
+      if constexpr (MODE == 3) { KT(2, 3); }
       float nab[3];
       if constexpr (NC == 1) {
 #pragma unroll
@@ -623,6 +627,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) nab[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
       }
+      if constexpr (MODE == 3) { KT(2, 4); }
       float rgbv[3] = {0.f, 0.f, 0.f};
       if (a.has_rgb) {
         float rin[16], r1[32], r2[32];
@@ -636,6 +641,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           rgbv[c] = 1.0f / (1.0f + nsim_fast_exp(-v));
         }
       }
+      if constexpr (MODE == 3) { KT(2, 5); }
       if (valid && hi == 0) {
         a.sdf[s] = sdf;
 #pragma unroll
@@ -645,6 +651,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           for (int c = 0; c < 3; ++c) a.rgb[3 * s + c] = rgbv[c];
         }
       }
+      if constexpr (MODE == 3) { KT(2, 6); KT(2, 17); }
       continue;
     }
     // ======================================================================================= backward
@@ -834,7 +841,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // 256 registers = two waves per SIMD (k_field<0,2,2>: 468 registers, 145 KB LDS -> one wave per SIMD).
 // 16-level pyramids (NC = 1); more levels keep k_field<., ., 2, 2>.
 template <int PREC, int SDF_D>
-__global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_field_bwd_j(FieldArgs a) {
+__global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 2 : 1) k_field_bwd_j(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -2073,18 +2080,20 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   a.dx = dx;
   a.ablate = bwd_ablate();
   const int nc = field_nc(meta->lotd.num_levels), nw = field_waves(meta, 2);
-  // The workgroup-joint variant of this backward (k_field_bwd_j) is opt-in (NSIM_SDF_BWD_JOINT=1): with two hidden layers
-  // its live set does not fit the 256 registers of two waves per SIMD (177 spilled) and it measured 0.275 ms against
-  // 0.230 ms for k_field<., ., 2> on 278 k points.
-  const char* jp = getenv("NSIM_SDF_BWD_JOINT");
-  if (nc == 1 && jp && atoi(jp) == 1) {
+  // 16-level pyramids: the workgroup-joint kernel (k_field_bwd_j).  Measured on 278 k points (MI355X): k_field<0,2,2>
+  // 0.232 ms -> 0.176 ms (weights in LDS instead of L2 reads -- the recomputed forward alone was 35 % of a tile --
+  // and no accumulator read-modify-write); forced into 256 registers (two waves per SIMD) it spills 177 and takes 0.275 ms,
+  // so the two-hidden-layer instantiation runs one wave per SIMD.  NSIM_SDF_BWD_OLD=1: the round-1 kernel (A/B aid).
+  const char* oldp = getenv("NSIM_SDF_BWD_OLD");
+  if (nc == 1 && !(oldp && atoi(oldp) == 1)) {
     // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row;
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");
-    const int64_t cap = gcap ? atoi(gcap) : 512;          // two resident workgroups per CU
+    // one hidden layer: 226 registers -> two resident workgroups per CU; two hidden layers: one (see the kernel)
+    const int64_t cap = gcap ? atoi(gcap) : (meta->sdf_D == 1 && meta->precision == 0 ? 512 : 256);
     nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
     switch (meta->precision * 2 + (meta->sdf_D - 1)) {

@@ -17,7 +17,8 @@ LABELS = {0: ["loop top", "loads+rin", "rad fwd (2 dense)", "dout/scale", "barri
               "dW1+rowsum", "dense R1T + outputs"],
           1: ["loop top", "loads h, J (planes)", "fwd recompute (a1 a2 d2 e1 d1 g)", "gs/gn loads, gh", "dense dh1", "dW(d1,gh)",
               "dz1/eh1/d2", "dW(d2,eh1)", "dense dh2, whv/dz2", "dW(dz2,a1)", "dense da1", "dz1 +=", "rowsum whv",
-              "dW(dz1,h)", "dense dh", "dh/g stores", "-", "-"]}
+              "dW(dz1,h)", "dense dh", "dh/g stores", "-", "-"],
+          2: ["loop top", "loads h, J (planes)", "sdf fwd (a1 a2 sdf)", "g chain (d2 e1 d1 g)", "nablas", "radiance net", "stores"] + ["-"] * 11}
 
 
 def main():
@@ -29,12 +30,12 @@ def main():
         it += 1
     torch.cuda.synchronize()
     lib = _lib.get_lib()
-    buf = (ctypes.c_longlong * (2 * 64 * 24))()
+    buf = (ctypes.c_longlong * (3 * 64 * 24))()
     rc = lib.nsim_debug_ktime(buf)
     assert rc == 0, rc
-    t = torch.tensor(list(buf), dtype=torch.float64).view(2, 64, 24)
+    t = torch.tensor(list(buf), dtype=torch.float64).view(3, 64, 24)
     out = {}
-    for K in (0, 1):
+    for K in (0, 1, 2):
         x = t[K]
         if float(x.abs().sum()) == 0:
             continue
