@@ -173,14 +173,19 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
 }
 
 // ------------------------------------------------------------------------------------ activations
-// softplus(z; beta) with torch's threshold (beta z > 20 -> z), on the native exp2/log2 pipes.
+// softplus(z; beta) = max(z, 0) + log(1 + exp(-beta |z|)) / beta on the raw base-2 pipes: two quarter-rate
+// transcendentals + five full-rate ops per value (the libm-style __expf / __logf forms and torch's explicit threshold
+// select cost twelve).  torch's ``threshold`` (beta z > 20 -> z) is implied: there the log term is < 2.1e-9 / beta,
+// below half an ulp of z >= 0.2, so the sum rounds to z.  This is THE VALU cost of the decoder kernels (64 per point
+// and pass against 12 MFMAs per 32 points).
+#define NSIM_LOG2E 1.4426950408889634f
+#define NSIM_LN2 0.6931471805599453f
 __device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) {
-  const float bz = z * beta;
-  const float soft = fmaxf(z, 0.f) + nsim_fast_log(1.0f + nsim_fast_exp(-fabsf(bz))) * inv_beta;
-  return bz > 20.f ? z : soft;
+  const float t = nsim_exp2(-fabsf(z) * (beta * NSIM_LOG2E));
+  return fmaxf(z, 0.f) + nsim_log2(1.0f + t) * (inv_beta * NSIM_LN2);
 }
 // sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)   (abs. error <= 6e-8)
-__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_fast_exp(-beta * a); }
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E)); }
 
 __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
   const float x = d[0], y = d[1], z = d[2];
@@ -470,19 +475,33 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     float h[16 * NC];
     float J[NC == 1 ? 16 : 1][3];     // NC == 2 re-reads dh/dx from the planes where it is consumed
     if constexpr (FROM_PLANES) {
+      // all feature reads first, then dh/dx: the first layer needs h only, so the 384 B / point of dh/dx are still in
+      // flight (vmcnt is in order) while the decoder starts
 #pragma unroll
-      for (int m = 0; m < NC; ++m) {
+      for (int m = 0; m < NC; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int l = 16 * m + 4 * q + 2 * hi + b;
-          const int r0 = 16 * m + 4 * q + 2 * b;
-          if (valid) {
-            const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
-            h[r0] = hp[0];
-            h[r0 + 1] = hp[1];
-            if constexpr (NC == 1) {
+          for (int b = 0; b < 2; ++b) {
+            const int l = 16 * m + 4 * q + 2 * hi + b;
+            const int r0 = 16 * m + 4 * q + 2 * b;
+            h[r0] = h[r0 + 1] = 0.f;
+            if (valid) {
+              const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+              h[r0] = hp[0];
+              h[r0 + 1] = hp[1];
+            }
+          }
+      if constexpr (NC == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 4 * q + 2 * hi + b;
+            const int r0 = 4 * q + 2 * b;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
+            if (valid) {
               const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
 #pragma unroll
               for (int c3 = 0; c3 < 3; ++c3) {
@@ -490,15 +509,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
                 J[r0 + 1][c3] = jp[3 + c3];
               }
             }
-          } else {
-            h[r0] = h[r0 + 1] = 0.f;
-            if constexpr (NC == 1) {
-#pragma unroll
-              for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
-            }
           }
-        }
-      }
       }
     } else if constexpr (NC == 1) {
 #pragma unroll
@@ -841,7 +852,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // 256 registers = two waves per SIMD (k_field<0,2,2>: 468 registers, 145 KB LDS -> one wave per SIMD).
 // 16-level pyramids (NC = 1); more levels keep k_field<., ., 2, 2>.
 template <int PREC, int SDF_D>
-__global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 2 : 1) k_field_bwd_j(FieldArgs a) {
+__global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -860,6 +871,26 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t ngroups = (ntiles + JOINT_WAVES - 1) / JOINT_WAVES;
   { const int64_t grp = -1; KT(1, 20); }
+  // Software pipeline over the plane reads (512 B per point, the only bulk HBM traffic of this kernel): the features of
+  // the NEXT group are requested while this group computes, and dh/dx -- needed only after the recomputed forward -- is
+  // requested before it, so that the bursts of all workgroups no longer alternate with their compute phases.
+  auto load_h_at = [&](float (&h)[16], int64_t sp) {
+    const bool v = sp < a.S;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+        h[r0] = h[r0 + 1] = 0.f;
+        if (v) {
+          const float* hp = a.h_pl + ((int64_t)l * a.S + sp) * 2;
+          h[r0] = hp[0];
+          h[r0 + 1] = hp[1];
+        }
+      }
+  };
+  float hn[16];
+  load_h_at(hn, ((int64_t)blockIdx.x * JOINT_WAVES + wave) * 32 + j);
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     KT(1, 0);
     const int64_t s = (grp * JOINT_WAVES + wave) * 32 + j;      // past the end: an invalid point contributes zeros
@@ -880,41 +911,31 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 
       }
     }
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
-    float gh[16];
-    auto load_h = [&](float (&h)[16]) {
+    float h[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-          h[r0] = h[r0 + 1] = 0.f;
-          if (valid) {
-            const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
-            h[r0] = hp[0];
-            h[r0 + 1] = hp[1];
-          }
-        }
-    };
+    for (int r = 0; r < 16; ++r) h[r] = hn[r];
+    float Jr[16][3];      // dh/dx of this group: in flight during the recomputed forward
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-        gh[r0] = gh[r0 + 1] = 0.f;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
         if (valid) {
           const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
-          gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
-          gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            Jr[r0][c3] = jp[c3];
+            Jr[r0 + 1][c3] = jp[3 + c3];
+          }
         }
       }
+    load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
     KT(1, 1);
     // ---- decoder forward (recomputed) and d sdf / d h
     float a1[32];
-    {
-      float h[16];
-      load_h(h);
-      dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
-    }
+    dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(Wv, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];
@@ -952,6 +973,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 
       }
     }
     // ======================================================================================= backward
+    float gh[16];  // dL / dg = J . gn
+#pragma unroll
+    for (int f = 0; f < 16; ++f) gh[f] = Jr[f][0] * gn[0] + Jr[f][1] * gn[1] + Jr[f][2] * gn[2];
     // ---- dW1 += d1 (x) gh
     KT(1, 2);
     __syncthreads();
@@ -1034,11 +1058,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, (PREC == 0 && SDF_D == 1) ? 
     __syncthreads();
     KT(1, 13);
     jstage<PREC, 2>(stA, dz1, wave);
-    {
-      float h[16];      // re-read (L2-warm) rather than kept in 16 registers across the whole tile
-      load_h(h);
-      jstage<PREC, 1>(stB, h, wave);
-    }
+    jstage<PREC, 1>(stB, h, wave);
     if constexpr (SDF_D == 1) jstage<PREC, 2>(stC, whv, wave);
     __syncthreads();
     if (do_dw) {
@@ -2092,8 +2112,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");
-    // one hidden layer: 226 registers -> two resident workgroups per CU; two hidden layers: one (see the kernel)
-    const int64_t cap = gcap ? atoi(gcap) : (meta->sdf_D == 1 && meta->precision == 0 ? 512 : 256);
+    const int64_t cap = gcap ? atoi(gcap) : 256;          // one resident workgroup per CU (register-limited)
     nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
     switch (meta->precision * 2 + (meta->sdf_D - 1)) {

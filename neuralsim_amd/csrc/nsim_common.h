@@ -191,6 +191,22 @@ __device__ __forceinline__ float nsim_fast_log(float x) {
 #endif
 }
 
+// raw base-2 pipes: v_exp_f32 / v_log_f32 (the ranges used here never reach their denormal corner cases)
+__device__ __forceinline__ float nsim_exp2(float x) {
+#ifdef NSIM_HOST_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ __forceinline__ float nsim_log2(float x) {
+#ifdef NSIM_HOST_EMU
+  return log2f(x);
+#else
+  return __builtin_amdgcn_logf(x);
+#endif
+}
+
 // ------------------------------------------------------------------------ MFMA
 // v_mfma_f32_32x32x16_f16: A lane l -> row (l&31), B lane l -> col (l&31),
 // 8 K-slots per lane indexed by (l>>5, e); C/D: col = l&31,
