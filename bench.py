@@ -275,7 +275,26 @@ def main():
             var["distant_ms"], _ = time_steps(trd, 16, 8, 257)
             del trd
             torch.cuda.empty_cache()
+            # a full 800 x 800 evaluation view (code_single/tools/eval.py:241-316: rayschunk pieces, validation renderer
+            # settings), timed, and its PSNR against the analytic image the model is being trained on
+            from neuralsim_amd.eval import psnr, render_image
+            from neuralsim_amd.graphics.cameras import pinhole_selected_rays
+            from neuralsim_amd.eval import all_pixel_xy
+            ha = tr.appear.detach()[0:1]
+            render_image(tr.renderer, tr.model, tr.intr, tr.c2w, tr.WH, frame=0, rays_h_appear=ha)       # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = render_image(tr.renderer, tr.model, tr.intr, tr.c2w, tr.WH, frame=0, rays_h_appear=ha)
+            torch.cuda.synchronize()
+            var["eval_800x800_ms"] = (time.perf_counter() - t0) * 1e3
+            W_, H_ = int(tr.WH[0, 0]), int(tr.WH[0, 1])
+            xy = all_pixel_xy(W_, H_, dev)
+            o_, d_ = pinhole_selected_rays(xy, torch.zeros(xy.shape[0], dtype=torch.long, device=dev), tr.intr, tr.c2w, tr.WH)
+            gt_img = tr.sphere_image(o_, d_, SPHERE_RADIUS).view(H_, W_, 3)
+            eval_psnr = psnr(img["rgb_volume"], gt_img)
             var = {k: round(v, 3) for k, v in var.items()}
+            var["eval_800x800_rays_per_s"] = round(W_ * H_ / var["eval_800x800_ms"] * 1e3, 1)
+            var["eval_psnr_vs_target_db"] = round(eval_psnr, 2)
             var["api_path_rays_per_s"] = round(args.rays_per_gpu / var["api_path_ms"] * 1e3, 1)
             var["distant_rays_per_s"] = round(args.rays_per_gpu / var["distant_ms"] * 1e3, 1)
             out["variants"] = var

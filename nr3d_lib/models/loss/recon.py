@@ -4,7 +4,8 @@ their names (implementation absent).  ``mask`` weights the elements; ``reduction
 import torch
 import torch.nn.functional as F
 
-__all__ = ["l1_loss", "l2_loss", "mse_loss", "huber_loss", "smooth_l1_loss", "relative_l1_loss", "relative_l2_loss"]
+__all__ = ["l1_loss", "l2_loss", "mse_loss", "huber_loss", "smooth_l1_loss", "relative_l1_loss", "relative_l2_loss",
+           "mape_loss", "smape_loss"]
 
 
 def _reduce(x, mask, reduction):
@@ -40,3 +41,11 @@ def relative_l1_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
 
 def relative_l2_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
     return _reduce((pred - gt) ** 2 / (gt ** 2 + eps), mask, reduction)
+
+
+def mape_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
+    return _reduce((pred - gt).abs() / (gt.abs() + eps), mask, reduction)
+
+
+def smape_loss(pred, gt, mask=None, reduction="mean", eps: float = 1e-2):
+    return _reduce((pred - gt).abs() / (0.5 * (pred.abs() + gt.abs()) + eps), mask, reduction)

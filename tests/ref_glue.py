@@ -557,3 +557,42 @@ def reference_model_wrapper_modules():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+@contextlib.contextmanager
+def reference_mono_loss_module():
+    """-> the reference's app/loss/mono.py (MonoDepthLoss / MonoSDFDepthLoss / MonoNormalLoss: the monocular-cue losses of
+    BASELINE configs[2], lotd_neus.replica.230814.yaml:272-293), loaded unchanged.  Shim: ``nr3d_lib.{logger, config,
+    models.loss.{recon, utils}, models.annealers, graphics.pack_ops}``; stand-ins: the scene graph, ``kornia`` (mask
+    erosion: unused with ``mask_erode 0``) and ``torchmetrics`` (Pearson variant of the depth loss: a torch restatement)."""
+    assert (REF_ROOT / "app/loss/mono.py").exists()
+    with reference_renderer_modules():          # app / app.renderers.utils (rotate_volume_buffer_nablas) / app.resources
+        names = ["kornia", "torchmetrics", "torchmetrics.functional", "torchmetrics.functional.regression", "app.loss",
+                 "app.loss.mono"]
+        saved = {k: sys.modules.get(k) for k in names}
+
+        def pearson_corrcoef(a, b):
+            a, b = a - a.mean(), b - b.mean()
+            return (a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-12)
+        tm, tmf = _stub_module("torchmetrics", PearsonCorrCoef=object), _stub_module("torchmetrics.functional")
+        tm.__path__, tmf.__path__ = [], []
+        lossp = _stub_module("app.loss")
+        lossp.__path__ = []
+        sys.modules.update({
+            "kornia": _stub_module("kornia", morphology=None), "torchmetrics": tm, "torchmetrics.functional": tmf,
+            "torchmetrics.functional.regression": _stub_module("torchmetrics.functional.regression",
+                                                               pearson_corrcoef=pearson_corrcoef),
+            "app.loss": lossp,
+        })
+        try:
+            spec = importlib.util.spec_from_file_location("app.loss.mono", str(REF_ROOT / "app/loss/mono.py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[spec.name] = mod
+            spec.loader.exec_module(mod)
+            yield mod
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v

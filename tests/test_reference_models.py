@@ -200,3 +200,61 @@ def test_fused_adam_torch_optimizer_matches_torch_adam(backend):
     assert lr_factor(0, None) == 1.0 and abs(lr_factor(50, dict(type="warmup_cosine", num_iters=100, min_factor=0.1,
                                                                 warmup_steps=0)) - 0.55) < 1e-9
     assert lr_factor(25, dict(type="multistep", milestones=[10, 20, 30], gamma=0.5)) == 0.25
+
+
+@needs_reference
+def test_reference_monocular_losses_on_an_image_patch(backend):
+    """BASELINE configs[2] (indoor, lotd_neus.replica.230814.yaml: ``inside_out``, image-patch step, ``mono_depth`` +
+    ``mono_normals``): the reference's MonoDepthLoss (scale-and-shift invariant, with its multi-scale gradient term) and
+    MonoNormalLoss (L1 + cosine), loaded unchanged, on a 16 x 16 patch rendered WITH gradient by the mirror renderer --
+    depth and normals images carry gradients back to the table and both decoders."""
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    from util import SMALL_RES
+    dev = backend
+    qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+              upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
+    m = LoTDNeuSModel(lod_res=SMALL_RES, log2_hashmap_size=10, sdf_D=2, precision="f32", ln_inv_s_init=0.4, inside_out=True,
+                      accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048)),
+                      ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp), seed=6).to(dev)
+    m.geometric_init_sphere(0.8)
+    m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
+    g = torch.Generator().manual_seed(3)
+    H = W = 16
+    d = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1).to(dev)
+    o = torch.zeros(H, W, 3, device=dev)                                   # a camera at the centre of the room
+    rend = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=0.01, depth_use_normalized_vw=True,
+                                     perturb=False)).train()
+    ret = rend.render(m, rays=[o, d], return_buffer=True, return_details=True)
+    r = ret["rendered"]
+    assert r["depth_volume"].shape == (H, W) and r["normals_volume"].shape == (H, W, 3) and r["depth_volume"].requires_grad
+    assert float(r["mask_volume"].detach().mean()) > 0.9                  # every ray ends on the wall of the room
+
+    class _Rot:                                                            # cam.world_transform.detach().rotate(v, inv=True)
+        def detach(self):
+            return self
+
+        def rotate(self, v, inv=False):
+            return v
+    cam = ref_glue._Named("cam0")
+    cam.world_transform = _Rot()
+    scene = ref_glue._Named("scene0")
+    scene.device = dev
+    depth_gt = (r["depth_volume"].detach() * 0.02 + 0.3) + 0.002 * torch.randn(H, W, generator=g).to(dev)   # up to scale / shift
+    hit = o + r["depth_volume"].detach()[..., None] * d
+    normal_gt = -torch.nn.functional.normalize(hit, dim=-1)               # the room's wall faces the camera
+    gtruth = dict(image_mono_depth=depth_gt, image_mono_normals=normal_gt)
+    with ref_glue.reference_mono_loss_module() as mono:
+        depth_loss = mono.MonoDepthLoss(w=0.1, loss_type="monosdf", loss_param=dict(fn_type="mse", gt_pre_scale=50.0, gt_pre_shift=1.0,
+                                                                                     alpha_grad_reg=0.01, grad_reg_scales=3),
+                                        ignore_mask_list=[], mask_pred_thresh=0.5, mask_erode=0, enable_after=0)
+        normal_loss = mono.MonoNormalLoss(w_l1=0.05, w_cos=0.05, ignore_mask_list=[], apply_in_pixel_train_step=True)
+        losses = {}
+        losses.update(depth_loss(scene, ret, None, gtruth, it=10, mode="image_patch"))
+        losses.update(normal_loss(scene, cam, ret, None, gtruth, it=10, mode="image_patch"))
+    assert set(losses) == {"loss_mono_depth.depth", "loss_mono_depth.reg", "loss_mono_normal.l1", "loss_mono_normal.cos"}
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    assert float(losses["loss_mono_normal.cos"]) < 0.05 * 0.5             # rendered normals roughly face the camera already
+    sum(losses.values()).backward()
+    for p in (m.encoding.flattened_params, m.sdf_w, m.sdf_b):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
