@@ -39,9 +39,10 @@ TOL = dict(
     # divides by CDF increments down to 1e-5, so 1e-6 differences of the no-grad SDFs move a fine sample by up to ~1e-3
     # -- the images and the fixed-sample-set values are the tight checks
     # (nablas: a sample that moves by 2e-4 crosses cells of the res-2048 level, whose features are hash noise)
-    f32=dict(t=3e-3, sdf=2e-3, rgb=1e-4, nablas=3e-2, fix=dict(sdf=2e-5, rgb=2e-5, nablas=2e-4),
-             img=dict(mask_volume=1e-4, rgb_volume=1e-4, depth_volume=2e-4, normals_volume=1e-4),
-             grad=5e-4, loss=1e-5, flips=2),
+    # measured (MI355X): t 2.3e-4, images <= 1e-5, sdf / rgb on the oracle's samples 4e-7 / 1e-7, gradients <= 5e-5
+    f32=dict(t=2e-3, sdf=1e-3, rgb=2e-4, nablas=3e-2, fix=dict(sdf=2e-5, rgb=2e-5, nablas=1e-4),
+             img=dict(mask_volume=5e-5, rgb_volume=5e-5, depth_volume=1e-4, normals_volume=5e-5),
+             grad=2e-4, loss=1e-5, flips=2),
     # fp16 MFMA operands (measured at this config: images <= 2.3e-3, sdf 2.4e-4 / 5e-5 near the surface, nablas 5.5e-4).
     # Gradients on the oracle's sample set: 3e-2 on the compressed set (samples near the surface; measured 5e-3); the
     # un-compressed set is dominated by samples far from the surface where the eikonal residual |n| - 1 ~ 1e-3 is a
