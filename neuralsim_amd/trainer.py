@@ -52,6 +52,11 @@ class RenderTrainer:
         # produced while the host waits for the current batch's sample count -- one blocking wait per step
         self.pipeline = pipeline
         self._prefetched = None
+        # the prefetch runs on its own HIP stream (NSIM_PREFETCH_STREAM=0: on the caller's): its dozen small launches and
+        # its hit-ray compaction sync then neither queue behind the sampling kernels of the current step nor drain them
+        self._side = None
+        if pipeline and model.device.type == "cuda" and os.environ.get("NSIM_PREFETCH_STREAM", "1") == "1":
+            self._side = torch.cuda.Stream(device=model.device)
         # encoding_cfg.anneal_cfg{type: hardmask, start_it, stop_it, start_level} (dtu yaml:104-108)
         self.level_anneal = dict(level_anneal) if level_anneal else None
         self.intr, self.c2w, self.WH = intr, c2w, WH
@@ -203,7 +208,14 @@ class RenderTrainer:
         x_uni = batch["x_uni"] if self.num_uniform > 0 else None
         M = int(x_uni.shape[0]) if x_uni is not None else 0
         o_r, d_r = tested["rays_o"].detach().float().contiguous(), tested["rays_d"].detach().float().contiguous()
-        if M:
+        if M and "o_full" in batch:
+            o, d, rz = batch["o_full"], batch["d_full"], batch["ridx_tail"]
+            zc = getattr(self, "_tail_zeros", None)
+            if zc is None or zc[0].shape[0] != M or zc[0].device != dev:
+                zc = self._tail_zeros = (torch.zeros([M], dtype=torch.float32, device=dev),
+                                         torch.zeros([M, ha.shape[1]], dtype=torch.float32, device=dev))
+            tz, ha = zc[0], torch.cat([ha, zc[1]])
+        elif M:
             e = torch.empty([0], dtype=torch.float32, device=dev)
             o, d, tz, rz, ha = append_extra_points(model, o_r, d_r, e, e.long(), ha, x_uni)
         else:
@@ -376,12 +388,32 @@ class RenderTrainer:
         else:
             with torch.no_grad():
                 tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
+        if M > 0 and not rays_o.requires_grad:
+            # per-RAY arrays of the with-grad query (hit rays + the uniform eikonal points as zero-length rays): they do
+            # not depend on the sample count, so they are built here, off the step's critical path
+            R = tested["num_rays"]
+            ez = torch.zeros([M, 3], dtype=torch.float32, device=dev)
+            ez[:, 2] = 1.0
+            extras.update(o_full=torch.cat([tested["rays_o"], extras["x_uni"]]), d_full=torch.cat([tested["rays_d"], ez]),
+                          ridx_tail=torch.arange(R, R + M, device=dev))
         return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested,
                     fidx_hit=fidx[tested["rays_inds"]], **extras)
 
     def _prefetch(self):
-        if self._prefetched is None:
+        if self._prefetched is not None:
+            return
+        if self._side is None:
             self._prefetched = self._make_batch()
+            return
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._side):
+            b = self._make_batch()
+            b["_ready"] = self._side.record_event()
+        # the tensors were allocated on the side stream and are consumed on the caller's
+        for v in list(b.values()) + list(b["tested"].values()):
+            if isinstance(v, torch.Tensor):
+                v.record_stream(main)
+        self._prefetched = b
 
     def sample_uniform_x(self) -> torch.Tensor:
         lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
@@ -426,6 +458,9 @@ class RenderTrainer:
         batch = None
         if self.pipeline:
             batch, self._prefetched = (self._prefetched or self._make_batch()), None
+            ev = batch.pop("_ready", None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
             xy, fidx, gt = batch["xy"], batch["fidx"], batch["gt"]
         else:
             xy, fidx, gt = self.sample_batch()
