@@ -241,8 +241,11 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
  * With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
- * h_planes [NLP,S,2] / J_planes [NLP,S,2,3] (both or neither; NLP = 16 for <= 16 levels, 32 above): when given, the gathered features and their
+ * h_planes [NLP,P,2] / J_planes [NLP,P,2,3] with the pitch P = NSIM_PLANE_PITCH(S) = S rounded up to 32 -- every 32-point
+ * tile of a level is then one 16-byte-aligned 256 B / 768 B piece, which the decoder kernels prefetch straight into LDS
+ * (global_load_lds_dwordx4) -- (both or neither; NLP = 16 for <= 16 levels, 32 above): when given, the gathered features and their
  * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again). */
+#define NSIM_PLANE_PITCH(S) ((((int64_t)(S)) + 31) & ~(int64_t)31)
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,

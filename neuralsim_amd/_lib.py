@@ -49,6 +49,11 @@ class AdamTensor(C.Structure):
 ADAM_MULTI_MAX = 12
 
 
+def plane_pitch(S: int) -> int:
+    """NSIM_PLANE_PITCH (include/nsim.h): pitch of the h / dh-dx planes handed from nsim_field_fwd to the backward."""
+    return (int(S) + 31) & ~31
+
+
 class FieldMeta(C.Structure):
     _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
 

@@ -245,7 +245,8 @@ struct FieldArgs {
   void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16 nc][S] x (f16x2 | f32x2)
   signed char glm_n[8], glm_lv[8][32];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
   signed char glm_half[8][32];                     // ... for all points (0), the first (1) or the second (2) half of them
-  float *h_pl, *J_pl;                              // level-major planes [16 nc][S][2] / [16 nc][S][2][3] saved by the forward
+  float *h_pl, *J_pl;                              // level-major planes [16 nc][PS][2] / [16 nc][PS][2][3] saved by the forward
+  int64_t PS;                                      // ... their pitch: S rounded up to 32 (NSIM_PLANE_PITCH)
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16 nc][S][2]
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products, 8 no dh_appear atomics
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
@@ -460,6 +461,24 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * NW;
+  // MODE 3, <= 16 levels: the planes of the NEXT tile (16 KB: per level 256 B of h and 768 B of dh/dx, each one aligned
+  // piece thanks to the 32-point pitch) are copied global -> LDS by 16 global_load_lds_dwordx4 while this tile computes;
+  // half of a tile used to be the wait for these reads (all workgroups burst together at one wave per SIMD).
+  constexpr bool GLDS = (MODE == 3 && NC == 1);
+  char* pf = GLDS ? smem + wbytes + wave * 16384 : nullptr;
+  auto prefetch_planes = [&](int64_t tile_n) {
+    const int64_t s0 = tile_n * 32;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float* src = lane < 16 ? a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane
+                                   : a.J_pl + ((int64_t)l * a.PS + s0) * 6 + 4 * (lane - 16);
+      nsim_glds16(src, pf + 1024 * l);
+    }
+  };
+  if constexpr (GLDS) {
+    const int64_t t0 = (int64_t)blockIdx.x * NW + wave;
+    if (t0 < ntiles) prefetch_planes(t0);
+  }
   for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += wstride) {
     const int64_t grp = tile / NW;      // (stamps of -DNSIM_KTIME builds: the wave-0 tile sequence of this workgroup)
     (void)grp;
@@ -474,7 +493,26 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // traffic instead of a second latency-bound random gather.
     float h[16 * NC];
     float J[NC == 1 ? 16 : 1][3];     // NC == 2 re-reads dh/dx from the planes where it is consumed
-    if constexpr (FROM_PLANES) {
+    if constexpr (GLDS) {
+      nsim_wait_vm0();                          // this tile's image has landed
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
+          const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
+          h[r0] = valid ? hp[0] : 0.f;
+          h[r0 + 1] = valid ? hp[1] : 0.f;
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {
+            J[r0][c3] = valid ? jp[c3] : 0.f;
+            J[r0 + 1][c3] = valid ? jp[3 + c3] : 0.f;
+          }
+        }
+      nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+      if (tile + wstride < ntiles) prefetch_planes(tile + wstride);
+    } else if constexpr (FROM_PLANES) {
       // all feature reads first, then dh/dx: the first layer needs h only, so the 384 B / point of dh/dx are still in
       // flight (vmcnt is in order) while the decoder starts
 #pragma unroll
@@ -487,7 +525,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             const int r0 = 16 * m + 4 * q + 2 * b;
             h[r0] = h[r0 + 1] = 0.f;
             if (valid) {
-              const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+              const float* hp = a.h_pl + ((int64_t)l * a.PS + s) * 2;
               h[r0] = hp[0];
               h[r0 + 1] = hp[1];
             }
@@ -502,7 +540,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
             if (valid) {
-              const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+              const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
               for (int c3 = 0; c3 < 3; ++c3) {
                 J[r0][c3] = jp[c3];
@@ -549,8 +587,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               J[r0 + 1][c3] = j1[c3] * c.dscale[c3];
             }
             if (a.h_pl && valid) {
-              float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
-              float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+              float* hp = a.h_pl + ((int64_t)l * a.PS + s) * 2;
+              float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
               hp[0] = f0;
               hp[1] = f1;
 #pragma unroll
@@ -630,7 +668,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               for (int b = 0; b < 2; ++b) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
-                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + g[r0] * jp[c3] + g[r0 + 1] * jp[3 + c3];
               }
@@ -692,7 +730,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               const int r0 = 16 * m + 4 * q + 2 * b;
               gh[r0] = gh[r0 + 1] = 0.f;
               if (valid) {
-                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
                 gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
                 gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
               }
@@ -775,7 +813,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               for (int b = 0; b < 2; ++b) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
-                const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
               }
@@ -883,7 +921,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
         const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
         h[r0] = h[r0 + 1] = 0.f;
         if (v) {
-          const float* hp = a.h_pl + ((int64_t)l * a.S + sp) * 2;
+          const float* hp = a.h_pl + ((int64_t)l * a.PS + sp) * 2;
           h[r0] = hp[0];
           h[r0 + 1] = hp[1];
         }
@@ -923,7 +961,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
         if (valid) {
-          const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+          const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
             Jr[r0][c3] = jp[c3];
@@ -1079,7 +1117,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-            const float* jp = a.J_pl + ((int64_t)l * a.S + s) * 6;
+            const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
           }
@@ -1228,8 +1266,9 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
       if (s < Sv) {
         const int64_t e = (int64_t)l * a.S + s;
         if constexpr (WJ) {
-          float* hp = a.h_pl + e * 2;
-          float* jp = a.J_pl + e * 6;
+          const int64_t ep = (int64_t)l * a.PS + s;
+          float* hp = a.h_pl + ep * 2;
+          float* jp = a.J_pl + ep * 6;
           hp[0] = f0[q];
           hp[1] = f1[q];
 #pragma unroll
@@ -2032,6 +2071,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.h_appear = h_appear;
   a.ray_goff = ray_goff;
   a.S = S;
+  a.PS = NSIM_PLANE_PITCH(S);
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
   a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
@@ -2041,7 +2081,11 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
     if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
-    return field_launch<3>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
+    // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS)
+    const size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
+    size_t wl = weights_lds_bytes(meta);
+    if (meta->precision != 0) wl = 0;
+    return field_launch<3>(meta, a, wl + pf_bytes, FIELD_GRID_FWD, (hipStream_t)stream);
   }
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
@@ -2093,6 +2137,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   FieldArgs a = field_args(meta);
   a.wpack = (const char*)wpack;
   a.S = S;
+  a.PS = NSIM_PLANE_PITCH(S);
   a.dsdf = dsdf; a.dnablas = gn;
   a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
   a.dh_pl = dh_planes; a.g_pl = g_planes;

@@ -207,6 +207,29 @@ __device__ __forceinline__ float nsim_log2(float x) {
 #endif
 }
 
+// ------------------------------------------------------------------------ direct global -> LDS copies (gfx950)
+// global_load_lds_dwordx4: every lane names its own 16-byte global source, the destination is the wave-uniform LDS base +
+// 16 * lane (1 KB per instruction), no VGPR is written.  The copy is asynchronous on the VM counter: wait vmcnt(0) before
+// reading the image, and wait lgkmcnt(0) after the last ds_read of an image before overwriting it.
+__device__ __forceinline__ void nsim_glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef NSIM_HOST_EMU
+  memcpy(lds_wave_base + 16 * nsim_lane(), gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void nsim_wait_vm0() {
+#ifndef NSIM_HOST_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void nsim_wait_lgkm0() {
+#ifndef NSIM_HOST_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 // ------------------------------------------------------------------------ MFMA
 // v_mfma_f32_32x32x16_f16: A lane l -> row (l&31), B lane l -> col (l&31),
 // 8 K-slots per lane indexed by (l>>5, e); C/D: col = l&31,

@@ -94,8 +94,9 @@ class _FieldFn(torch.autograd.Function):
         # (pyramids with more than 16 levels exist on the level-major path only: planes in evaluation as well)
         NLP = model.plane_levels
         need_pl = need_bwd or NLP > 16
-        h_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
-        J_pl = torch.empty([NLP, S, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
+        PS = _lib.plane_pitch(S)
+        h_pl = torch.empty([NLP, PS, 2], dtype=torch.float32, device=dev) if need_pl else None
+        J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
         _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))

@@ -250,7 +250,8 @@ class RenderTrainer:
         dha, d_app, drgb = dha.view(R + M, A), d_app.view(self.V, A), drgb.view(St, 3)
         # ---------------------------------------------------------------- forward
         sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
-        h_pl, J_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2, 3], **f32)
+        PS = _lib.plane_pitch(St)
+        h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
         call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha), St,
              ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl))
         ln_inv_s = model.ln_inv_s.detach()
