@@ -927,8 +927,26 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
         }
       }
   };
+  // fp16 mode: the whole 16 KB plane image of a wave's NEXT tile (h and dh/dx) is copied global -> LDS while the group
+  // computes (as in k_field MODE 3); f32 validation mode (its f32 staging leaves no LDS for it) prefetches h into registers
+  constexpr bool GLDS = (PREC == 0);
+  char* pf = GLDS ? stC + 64 * jstage_row_bytes<PREC>() + wave * 16384 : nullptr;
+  auto prefetch_planes = [&](int64_t tile_n) {
+    const int64_t s0 = tile_n * 32;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float* src = lane < 16 ? a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane
+                                   : a.J_pl + ((int64_t)l * a.PS + s0) * 6 + 4 * (lane - 16);
+      nsim_glds16(src, pf + 1024 * l);
+    }
+  };
   float hn[16];
-  load_h_at(hn, ((int64_t)blockIdx.x * JOINT_WAVES + wave) * 32 + j);
+  if constexpr (GLDS) {
+    const int64_t t0 = (int64_t)blockIdx.x * JOINT_WAVES + wave;
+    if (t0 < ntiles) prefetch_planes(t0);
+  } else {
+    load_h_at(hn, ((int64_t)blockIdx.x * JOINT_WAVES + wave) * 32 + j);
+  }
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     KT(1, 0);
     const int64_t s = (grp * JOINT_WAVES + wave) * 32 + j;      // past the end: an invalid point contributes zeros
@@ -950,26 +968,48 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     }
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
     float h[16];
+    float Jr[16][3];      // dh/dx of this group
+    if constexpr (GLDS) {
+      nsim_wait_vm0();                          // this tile's image has landed
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h[r] = hn[r];
-    float Jr[16][3];      // dh/dx of this group: in flight during the recomputed forward
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
-        if (valid) {
-          const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
+          const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
+          h[r0] = valid ? hp[0] : 0.f;
+          h[r0 + 1] = valid ? hp[1] : 0.f;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            Jr[r0][c3] = jp[c3];
-            Jr[r0 + 1][c3] = jp[3 + c3];
+            Jr[r0][c3] = valid ? jp[c3] : 0.f;
+            Jr[r0 + 1][c3] = valid ? jp[3 + c3] : 0.f;
           }
         }
-      }
-    load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
+      nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+      const int64_t tn = (grp + gridDim.x) * JOINT_WAVES + wave;
+      if (tn < ntiles) prefetch_planes(tn);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] = hn[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
+          if (valid) {
+            const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+              Jr[r0][c3] = jp[c3];
+              Jr[r0 + 1][c3] = jp[3 + c3];
+            }
+          }
+        }
+      load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
+    }
     KT(1, 1);
     // ---- decoder forward (recomputed) and d sdf / d h
     float a1[32];
@@ -2153,7 +2193,8 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   if (nc == 1 && !(oldp && atoi(oldp) == 1)) {
     // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
-    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row;
+    // + one 16 KB plane-prefetch buffer per wave in fp16 mode (k_field_bwd_j GLDS)
+    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row + (meta->precision == 0 ? (size_t)JOINT_WAVES * 16384 : 0);
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");

@@ -220,12 +220,16 @@ __device__ __forceinline__ void nsim_glds16(const void* gsrc, char* lds_wave_bas
 #endif
 }
 __device__ __forceinline__ void nsim_wait_vm0() {
-#ifndef NSIM_HOST_EMU
+#ifdef NSIM_HOST_EMU
+  emu::wave_barrier();      // the emulator runs the lanes one after another: all of them have issued their copies
+#else
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 __device__ __forceinline__ void nsim_wait_lgkm0() {
-#ifndef NSIM_HOST_EMU
+#ifdef NSIM_HOST_EMU
+  emu::wave_barrier();
+#else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
