@@ -222,11 +222,13 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
  * Speculatively sized buffers (level-major path): S is the CAPACITY (and the plane pitch); when n_dev != NULL the
  * number of valid points is *n_dev + n_add, read on the device (0 if that exceeds S: the caller under-sized its
  * buffers and redoes the pass) -- the host never learns the size of the marched sample set before launching its
- * first query (one host sync less per step). */
+ * first query (one host sync less per step).
+ * occ_val != NULL (needs x and occ_meta): the SDFs are also folded into the occupancy value grid in the same launch --
+ * nsim_occ_collect's update (``update_from_samples_cfg``) without a pass of its own. */
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
-                   const void* feat_planes, void* stream);
+                   const void* feat_planes, float* occ_val, const NsimOccMeta* occ_meta, float occ_inv_s, void* stream);
 /* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [NLP][S] (NLP = 16 for <= 16 levels, 32 above) of
  * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
  * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */

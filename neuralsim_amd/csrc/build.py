@@ -11,7 +11,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
-HEADERS = ["nsim_common.h", "lotd_dev.h", "mfma_mlp.h", "../../include/nsim.h"]
+HEADERS = ["nsim_common.h", "lotd_dev.h", "mfma_mlp.h", "occ_dev.h", "../../include/nsim.h"]
 LIB = HERE / "libnsim_hip.so"
 BUILD = HERE / "_build"
 

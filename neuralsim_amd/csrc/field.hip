@@ -27,6 +27,7 @@
 //  * PREC=1 selects v_mfma_f32_32x32x2_f32 (exact f32 at the vector rate) for tight parity tests.
 #include "lotd_dev.h"
 #include "mfma_mlp.h"
+#include "occ_dev.h"
 #include <stdlib.h>
 
 // ----------------------------------------------------------------------------------------- layout
@@ -248,6 +249,9 @@ struct FieldArgs {
   float *h_pl, *J_pl;                              // level-major planes [16 nc][PS][2] / [16 nc][PS][2][3] saved by the forward
   int64_t PS;                                      // ... their pitch: S rounded up to 32 (NSIM_PLANE_PITCH)
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16 nc][S][2]
+  float* occ_val;                                  // no-grad query of a training step: fold f(sdf) into this value grid
+  OccDev occ;                                      // ... (update_from_samples_cfg; needs positions in ``x``)
+  float occ_inv_s;
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products, 8 no dh_appear atomics
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
@@ -1476,6 +1480,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
     sdf = sdf + wave_shfl_xor(sdf, 32);
     sdf = sdf + b_out;
     if (p.valid && hi == 0) a.sdf[p.s] = sdf;
+    if (a.occ_val) {      // the 32 points of the tile are the hi == 0 lanes (neighbouring samples of a ray)
+      const bool ok = p.valid && hi == 0;
+      occ_collect_wave(a.occ_val, a.occ, ok, ok ? a.x[3 * p.s] : 0.f, ok ? a.x[3 * p.s + 1] : 0.f, ok ? a.x[3 * p.s + 2] : 0.f,
+                       sdf, a.occ_inv_s);
+    }
   }
 }
 
@@ -2046,10 +2055,11 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
 int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
-                   const void* feat_planes, void* stream) {
+                   const void* feat_planes, float* occ_val, const NsimOccMeta* occ_meta, float occ_inv_s, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
+  if (occ_val && !(x && occ_meta)) return 24;
   if (!feat_planes && !x && !(rays_o && rays_d && t && ridx)) return 24;
   if (ray_goff && !ridx) return 29;
   void* feat_scratch = const_cast<void*>(feat_planes);
@@ -2063,6 +2073,11 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.S = S;
   a.sdf = sdf;
   a.feat_pl = feat_scratch;
+  if (occ_val) {
+    a.occ_val = occ_val;
+    a.occ = occ_dev(occ_meta);
+    a.occ_inv_s = occ_inv_s;
+  }
   const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);

@@ -11,6 +11,7 @@
 // per new sample.  All arithmetic that decides sample membership is written mul-then-add (the library is
 // built with -ffp-contract=off) so the sample set is bit-identical to the oracle's.
 #include "nsim_common.h"
+#include "occ_dev.h"
 
 #define SMP_WAVES_PER_BLOCK 4
 #define SMP_BLOCK (64 * SMP_WAVES_PER_BLOCK)
@@ -19,21 +20,6 @@ __device__ __forceinline__ int64_t smp_wave_id() {
   return (int64_t)blockIdx.x * SMP_WAVES_PER_BLOCK + (threadIdx.x >> 6);
 }
 static inline dim3 smp_grid(int64_t R) { return dim3(nsim_blocks(R, SMP_WAVES_PER_BLOCK)); }
-
-struct OccDev {
-  float mn[3], mx[3], sc[3];
-  int res[3];
-};
-static inline OccDev occ_dev(const NsimOccMeta* m) {
-  OccDev o;
-  for (int i = 0; i < 3; ++i) {
-    o.mn[i] = m->aabb_min[i];
-    o.mx[i] = m->aabb_max[i];
-    o.sc[i] = m->scale[i];
-    o.res[i] = m->res[i];
-  }
-  return o;
-}
 
 // ----------------------------------------------------------------------------------- ray generation
 __global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict__ xy,
@@ -146,16 +132,6 @@ __global__ void __launch_bounds__(256) k_aabb_ray_test(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------------- occupancy grid
-__device__ __forceinline__ bool occ_voxel(const OccDev& m, float px, float py, float pz, int64_t& flat) {
-  const float gx = floorf((px - m.mn[0]) * m.sc[0]);
-  const float gy = floorf((py - m.mn[1]) * m.sc[1]);
-  const float gz = floorf((pz - m.mn[2]) * m.sc[2]);
-  const bool inside = gx >= 0.f && gy >= 0.f && gz >= 0.f && gx < (float)m.res[0] && gy < (float)m.res[1] &&
-                      gz < (float)m.res[2];
-  flat = inside ? ((int64_t)gx + (int64_t)m.res[0] * ((int64_t)gy + (int64_t)m.res[1] * (int64_t)gz)) : 0;
-  return inside;
-}
-
 __global__ void __launch_bounds__(256) k_occ_decay(float* __restrict__ val, int64_t n, float decay) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) val[i] = val[i] * decay;
@@ -172,38 +148,9 @@ __global__ void __launch_bounds__(256) k_occ_update(float* __restrict__ val, con
     const int64_t nd = n_dev[0] + n_add;
     n = nd <= n ? nd : 0;
   }
-  // Consecutive samples of a ray share voxels (64^3 grid: ~6 marching steps per voxel) and most values do not exceed
-  // what the grid already holds: same-address atomics are separate requests that serialise in L2, so (1) equal voxels
-  // of neighbouring lanes are max-reduced inside the wave and only the last lane of a run goes on, (2) it skips the
-  // atomic when a plain read already shows a value >= its own (the grid only grows between refreshes).
-  const int lane = nsim_lane();
-  int64_t flat = -1 - lane;
-  float v = 0.f;
-  bool ok = i < n;
-  if (ok) {
-    int64_t f;
-    ok = occ_voxel(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], f);
-    if (ok) {
-      flat = f;
-      const float s = 1.0f / (1.0f + expf(-sdf[i] * inv_s));
-      v = 4.0f * s * (1.0f - s);
-    }
-  }
-  const int64_t pk = wave_shfl(flat, lane - 1);
-  const unsigned long long heads = wave_ballot(lane == 0 || pk != flat);
-  const unsigned long long below = heads & ((2ull << lane) - 1ull);
-  const int run_start = 63 - __builtin_clzll(below);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = wave_shfl(v, lane - d);
-    if (lane - d >= run_start) v = fmaxf(v, o);
-  }
-  const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-  if (!ok || !last) return;
-  if (val[flat] >= v) return;
-  int iv;
-  memcpy(&iv, &v, 4);
-  atomicMax((int*)val + flat, iv);
+  const bool ok = i < n;
+  occ_collect_wave(val, m, ok, ok ? pts[3 * i] : 0.f, ok ? pts[3 * i + 1] : 0.f, ok ? pts[3 * i + 2] : 0.f, ok ? sdf[i] : 0.f,
+                   inv_s);
 }
 
 __global__ void __launch_bounds__(256) k_occ_pack_bits(const float* __restrict__ val, int64_t nvox, float thre,

@@ -748,7 +748,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
 
     # ------------------------------------------------------------------ point queries
     def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None, n_dev=None,
-                   n_add: int = 0) -> torch.Tensor:
+                   n_add: int = 0, collect: bool = False) -> torch.Tensor:
         """No-grad SDF of S points: level-major gather into feature planes [16][S] (f16x2 | f32x2), then the decoder
         on the planes (csrc/field.hip: k_lotd_gather_lm, k_field_sdf<.., true>).  NSIM_SDF_FUSED=1 selects the single
         fused point-major kernel instead (same values)."""
@@ -762,9 +762,12 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                  device=dev)
             _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
+        # ``collect``: the decoder launch also folds its SDFs into the occupancy values (update_from_samples_cfg)
+        acc = self.accel if collect else None
         _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add),
-                  _lib.ptr(sdf), _lib.ptr(planes))
+                  _lib.ptr(sdf), _lib.ptr(planes), _lib.ptr(acc.occ_val) if acc is not None else None,
+                  acc.meta if acc is not None else None, float(acc.inv_s) if acc is not None else 0.0)
         if _lib.TIMER is not None and n_dev is None:       # speculative sizes are accounted once the true size is known
             _lib.TIMER.note_units("nsim_field_sdf", S)
             if planes is not None:
@@ -852,7 +855,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         return c[key]
 
     def _sample(self, o, d, near, far, qp: dict, jitter, jitter_c, goff=None, woff=None, cap: Optional[int] = None,
-                pre_sync_hook=None):
+                pre_sync_hook=None, need_ridx: bool = True):
         """No-grad sampling: occupancy marching + coarse depths + multi-stage NeuS up-sampling.
 
         ``cap`` = None: the size M of the marched set is read back (host sync) before anything is allocated.
@@ -886,24 +889,26 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         S = M + R * C
         t = torch.empty([S], **f32)
         pi = torch.empty([R, 2], dtype=torch.long, device=dev)
-        ridx = torch.empty([S], dtype=torch.long, device=dev)
         # the level-major query visits every point once per XCD: hand it positions (12 B) instead of (ridx, t, o, d)
         with_x = not self._sdf_fused
+        # per-sample ray indices (8 B each) are written only where somebody reads them: by the point-major / batched
+        # queries on the way, and by the caller at the end (``need_ridx``: the compressed mode re-derives them)
+        fine = [int(n) for n in qp.get("num_fine", [8, 8, 32])]
+        ridx_mid = (not with_x) or goff is not None
+        ridx = torch.empty([S], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and not fine)) else None
         xq = torch.empty([S, 3], **f32) if with_x else None
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
                   _lib.ptr(pi), _lib.ptr(ridx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(xq))
         grid16, wpack = self._shadow()
+        collect = with_x and goff is None and self.accel.collect_armed       # fused into the decoder launches below
         if with_x:
             sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if goff is not None else None, S, dev,
-                                  goff=goff, n_dev=n_dev, n_add=R * C)
+                                  goff=goff, n_dev=n_dev, n_add=R * C, collect=collect)
         else:
             sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
-        collect = with_x and goff is None and self.accel.collect_armed
-        if collect:
-            self.accel.collect(xq, sdf, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
-        for nf, fac in zip(qp.get("num_fine", [8, 8, 32]), qp.get("upsample_inv_s_factors", [1, 4, 16])):
+        for k_stage, (nf, fac) in enumerate(zip(fine, qp.get("upsample_inv_s_factors", [1, 4, 16]))):
             nf = int(nf)
             t_new = torch.empty([R, nf], **f32)
             scratch = torch.empty([S], **f32)
@@ -913,16 +918,15 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             ridx_new = self._arange_repeat(R, nf, dev)
             if with_x:
                 sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if goff is not None else None,
-                                          R * nf, dev, goff=goff)
+                                          R * nf, dev, goff=goff, collect=collect)
             else:
                 sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
-            if collect:
-                self.accel.collect(x_new, sdf_new)
             S2 = S + R * nf
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
             pi2 = torch.empty([R, 2], dtype=torch.long, device=dev)
-            ridx = torch.empty([S2], dtype=torch.long, device=dev)
+            last = k_stage == len(fine) - 1
+            ridx = torch.empty([S2], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and last)) else None
             _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
                       nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None)
             t, sdf, pi, S = t2, sdf2, pi2, S2
@@ -993,14 +997,15 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             cap = self._speculative_cap(R) if compressed else None
             hook = cfg.get("_pre_sync_hook", None)       # called once, right before the first blocking size read
             t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c, goff, woff,
-                                                                      cap=cap, pre_sync_hook=hook if cap is None else None)
+                                                                      cap=cap, pre_sync_hook=hook if cap is None else None,
+                                                                      need_ridx=not compressed)
             if compressed:
                 thre = float(qp.get("compress_thre", 1e-4))
                 t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None,
                                                            pre_sync_hook=hook if cap is not None else None)
                 if cap is not None and M_true > cap:          # the speculation failed: redo with the exact size
                     t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c,
-                                                                              goff, woff, cap=None)
+                                                                              goff, woff, cap=None, need_ridx=False)
                     t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre)
                     M_true = int(total_m.item())
                 if M_true is None:

@@ -17,7 +17,7 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DNSIM_HOST_EMU", "-ffp-con
 def build(force=False):
     LIB.parent.mkdir(exist_ok=True)
     h = hashlib.sha256()
-    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", HERE / "hip_emu.h",
+    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", CSRC / "occ_dev.h", HERE / "hip_emu.h",
                                             HERE / "hip_emu.cpp", CSRC.parent.parent / "include" / "nsim.h"]:
         h.update(f.read_bytes())
     stamp = LIB.parent / "stamp"
