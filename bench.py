@@ -203,16 +203,34 @@ def parity_check(tr):
 
 def time_steps(tr, steps, warmup, it):
     """ms per step of ``steps`` iterations after ``warmup`` untimed ones (device-synchronised on both sides)."""
+    sync = torch.cuda.synchronize if tr.model.device.type == "cuda" else (lambda: None)
     for _ in range(warmup):
         tr.train_step(it)
         it += 1
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(it)
         it += 1
-    torch.cuda.synchronize()
+    sync()
     return (time.perf_counter() - t0) / steps * 1e3, it
+
+
+def measure_exposed_allreduce(tr, out, steps, it, rank, dev):
+    """N > 1: the same steps with the collectives skipped (every rank keeps its local gradients and occupancy values); the
+    difference to ``ms_per_step`` is the all-reduce time the overlap could NOT hide.  Replicas diverge from here on --
+    the measurement is over.  Every rank calls this; rank 0's record gets the two numbers."""
+    import torch.distributed as dist
+    tr.skip_allreduce = True
+    dist.barrier()
+    ms_local, it = time_steps(tr, steps, 2, it)
+    el = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    tr.skip_allreduce = False
+    if rank == 0:
+        out["exposed_allreduce_ms"] = round(out["ms_per_step"] - float(el.item()), 4)
+        out["ms_per_step_without_allreduce"] = round(float(el.item()), 4)
+    return it
 
 
 def main():
@@ -244,19 +262,7 @@ def main():
                        rays_per_gpu=args.rays_per_gpu)
     out, it = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=args.rays_per_gpu)
     if world > 1:
-        # the same K steps with the collectives skipped (every rank keeps its local gradients): the difference is the
-        # all-reduce time that the overlap could NOT hide.  Replicas diverge from here on -- the measurement is over.
-        import torch.distributed as dist
-        k2 = min(args.steps, 32)
-        tr.skip_allreduce = True
-        dist.barrier()
-        ms_local, it = time_steps(tr, k2, 2, it)
-        el = torch.tensor([ms_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        tr.skip_allreduce = False
-        if rank == 0:
-            out["exposed_allreduce_ms"] = round(out["ms_per_step"] - float(el.item()), 4)
-            out["ms_per_step_without_allreduce"] = round(float(el.item()), 4)
+        it = measure_exposed_allreduce(tr, out, min(args.steps, 32), it, rank, dev)
     if rank == 0:
         out["config"]["distant_model"] = bool(args.distant)
         out["config"]["sky_model"] = bool(args.sky)

@@ -145,6 +145,12 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32"):
         assert abs(out["value"] - 16 * world * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2
     else:
         assert out is None
+    if overlap == "1" and wire == "f32":      # the N > 1 tail of bench.main(): same steps without the collectives
+        rec = out if rank == 0 else {}
+        it2 = bench.measure_exposed_allreduce(tr, rec, 2, it_next, rank, dev)
+        assert it2 == it_next + 4 and tr.skip_allreduce is False
+        if rank == 0:
+            assert "exposed_allreduce_ms" in rec and rec["ms_per_step_without_allreduce"] > 0
     dist.barrier()
     (Path(out_dir) / f"bench_ok{rank}").write_text("ok")
     dist.destroy_process_group()
