@@ -85,6 +85,38 @@ def _lookup(root: dict, path: str):
     return cur
 
 
+def _safe_arith(expr: str):
+    """``${eval:...}`` of the reference's configs is arithmetic (``2**20``, ``8*(2**20)``, ``500+1000``, ``int(1.5*4096)``):
+    evaluated by walking the AST -- numbers, + - * / // % **, unary minus, comparisons-free, and calls of
+    min / max / int / float / round / abs only.  (Python's ``eval`` with empty builtins is not a sandbox; a YAML file from
+    somewhere else must not be able to run code here.)"""
+    import ast
+    import operator as op
+    bin_ops = {ast.Add: op.add, ast.Sub: op.sub, ast.Mult: op.mul, ast.Div: op.truediv, ast.FloorDiv: op.floordiv,
+               ast.Mod: op.mod, ast.Pow: op.pow}
+    un_ops = {ast.USub: op.neg, ast.UAdd: op.pos}
+    funcs = {"min": min, "max": max, "int": int, "float": float, "round": round, "abs": abs}
+
+    def ev(n):
+        if isinstance(n, ast.Expression):
+            return ev(n.body)
+        if isinstance(n, ast.Constant) and isinstance(n.value, (int, float, bool)):
+            return n.value
+        if isinstance(n, ast.BinOp) and type(n.op) in bin_ops:
+            a, b = ev(n.left), ev(n.right)
+            if isinstance(n.op, ast.Pow) and abs(b) > 4096:
+                raise ValueError("exponent too large")
+            return bin_ops[type(n.op)](a, b)
+        if isinstance(n, ast.UnaryOp) and type(n.op) in un_ops:
+            return un_ops[type(n.op)](ev(n.operand))
+        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in funcs and not n.keywords:
+            return funcs[n.func.id](*[ev(a) for a in n.args])
+        if isinstance(n, (ast.Tuple, ast.List)):
+            return [ev(e) for e in n.elts]
+        raise ValueError(f"${{eval:...}}: unsupported expression element {type(n).__name__} in {expr!r}")
+    return ev(ast.parse(str(expr).strip(), mode="eval"))
+
+
 def _resolve_str(s: str, root: dict, depth: int = 0):
     """``${a.b}`` -> the value at that path of the ROOT config (typed when the string is nothing but the reference),
     ``${eval:"expr"}`` / ``${eval:expr}`` -> Python arithmetic -- the two interpolation forms the reference's configs
@@ -100,7 +132,7 @@ def _resolve_str(s: str, root: dict, depth: int = 0):
             if len(expr) >= 2 and expr[0] == expr[-1] and expr[0] in "\"'":
                 expr = expr[1:-1]
             expr = _resolve_str(expr, root, depth + 1) if "${" in expr else expr
-            return eval(str(expr), {"__builtins__": {}}, {"min": min, "max": max, "int": int, "float": float})
+            return _safe_arith(expr)
         v = _lookup(root, body)
         return _resolve_str(v, root, depth + 1) if isinstance(v, str) and "${" in v else v
     if m:

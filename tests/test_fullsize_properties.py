@@ -1,5 +1,5 @@
 """BASELINE-size checks (configs[1]: 8192 rays, L=16 / T=2^19 table, 2x64 decoder) through size-independent
-properties -- the oracle cannot be run at this size in test time, so the HIP path is checked against invariants:
+properties (the oracle comparison at this size is tests/test_fullsize_parity.py) -- the HIP path against invariants:
 sortedness / counts of the sampler, agreement of the three field kernels on the same points, weight bounds of the
 compositing, linearity of the backward in its upstream gradients, independence from the scatter's de-duplication
 and from the query chunking.  GPU only (the emulator would take hours at this size)."""

@@ -1,4 +1,5 @@
 """The reference's hot-path import lines resolve against the nr3d_lib shim and hit the HIP-backed implementation."""
+import pytest
 import torch
 
 
@@ -46,3 +47,16 @@ def test_occupied_sampling_and_ray_conversion(backend):
     o, d = torch.randn(5, 3), torch.randn(5, 3)
     oo, dd = LoTDNeuSModel.convert_rays_in_node(o, d, R, t, 2.0)
     assert torch.allclose(oo, (o - t) @ R / 2.0, atol=1e-6) and torch.allclose(dd, d @ R / 2.0, atol=1e-6)
+
+
+def test_config_eval_is_arithmetic_only():
+    """``${eval:...}`` evaluates arithmetic through an AST walk -- no names, attributes or calls beyond min / max / int /
+    float / round / abs -- so a YAML file cannot execute code when it is loaded."""
+    from nr3d_lib.config import _safe_arith, resolve_config
+    assert _safe_arith("2**20") == 1048576 and _safe_arith("8*(2**20)") == 8388608
+    assert _safe_arith("int(1.5*4096)+max(1, 2)") == 6146 and _safe_arith("-3 // 2") == -2
+    c = resolve_config(dict(a=4, b='${eval:"${a}*2+1"}', c="${b}"))
+    assert c.b == 9 and c.c == 9
+    for bad in ("__import__('os').system('true')", "().__class__", "open('x')", "a.b", "[x for x in (1,)]", "2**99999"):
+        with pytest.raises((ValueError, SyntaxError)):
+            _safe_arith(bad)
