@@ -122,6 +122,12 @@ int nsim_neus_alpha_fwd(const float* sdf, const int64_t* pack_infos, int64_t P, 
 int nsim_neus_alpha_bwd(const float* sdf, const float* dalpha, const int64_t* pack_infos, int64_t P,
                         const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, float* dsdf,
                         float* d_ln_inv_s, void* stream);
+/* nsim_neus_alpha_fwd + nsim_composite_fwd in one launch (identical arithmetic; alpha [S] is written for the
+ * backward passes above). */
+int nsim_neus_composite_fwd(const float* sdf, const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s,
+                            const float* t, const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
+                            int normalized_depth, float* alpha, float* vw, float* trans, float* mask, float* depth,
+                            float* rgb_out, float* nrm_out, const int64_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------------------ ray generation */
 /* Camera._get_selected_rays_from_ixy (app/resources/observers/cameras.py:281-310) */
@@ -179,12 +185,14 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
 
 /* ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): from the no-grad SDF of all
  * samples keep those that bound an interval with visibility weight > thre.  count -> counts [R]; emit (given
- * pack_infos_out from the counts) -> compacted t_out / ridx_out. */
+ * pack_infos_out from the counts) -> compacted t_out / ridx_out; emit also appends ``tail_n`` (>= 0) zero-depth samples
+ * on the pseudo-rays R .. R+tail_n-1 behind the kept set (the free eikonal points of the with-grad query), so
+ * t_out / ridx_out hold total + tail_n entries. */
 int nsim_compress_count(const float* sdf, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
                         float ln_inv_s_factor, float forward_inv_s, float thre, int64_t* counts, void* stream);
 int nsim_compress_emit(const float* sdf, const float* t, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
                        float ln_inv_s_factor, float forward_inv_s, float thre, const int64_t* pack_infos_out,
-                       float* t_out, int64_t* ridx_out, void* stream);
+                       float* t_out, int64_t* ridx_out, int64_t tail_n, void* stream);
 
 /* ------------------------------------------------------------------- LoTD encoding (standalone) */
 /* LoTDEncoding.forward / forward_dydx (inspect_rendering.py:468-474): x [S,3] in [-1,1], grid fp16.
@@ -381,6 +389,12 @@ int nsim_eikonal_loss_bwd(const float* nablas, int64_t S, const float* gout, flo
 int nsim_mse_loss_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);
 int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float* gout, float* dpred, void* stream);
 int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, int64_t rows, float* out, void* stream);
+/* The loss head of one training step in a single launch (the reference's total = mse + w (eikonal(render samples) +
+ * eikonal(uniform points)), code_single/tools/train.py:1411-1423 with app/loss/photometric.py + eikonal.py):
+ *   acc[0] += mse(pred, gt) over n_img floats; acc[1] += eikonal(nablas[:S]); acc[2] += eikonal(nablas[S:S+M]);
+ *   d_pred = d total / d pred;  d_nablas [S+M,3] = d total / d nablas.   acc [3] zero on entry. */
+int nsim_train_loss_head(const float* pred, const float* gt, int64_t n_img, const float* nablas, int64_t S, int64_t M,
+                         float w_eikonal, float* acc, float* d_pred, float* d_nablas, void* stream);
 /* Compaction of the AABB-tested rays, (o, d, near, far)[idx] -> [R,...] in one launch
  * (model.ray_test, app/renderers/single_volume_renderer.py:235-238). */
 int nsim_gather_rays(const float* rays_o, const float* rays_d, const float* near, const float* far, const int64_t* idx,

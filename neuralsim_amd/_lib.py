@@ -76,6 +76,7 @@ SIGNATURES = {
     "nsim_alpha_to_vw_fwd": [_P, _P, _I64, _P, _P],
     "nsim_alpha_to_vw_bwd": [_P, _P, _P, _P, _P, _I64, _P],
     "nsim_composite_fwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_neus_composite_fwd": [_P, _P, _F, _F, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_neus_alpha_fwd": [_P, _P, _I64, _P, _F, _F, _P],
     "nsim_neus_alpha_bwd": [_P, _P, _P, _I64, _P, _F, _F, _P, _P],
@@ -92,7 +93,7 @@ SIGNATURES = {
     "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P, _P, _P, _P],
     "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
     "nsim_compress_count": [_P, _P, _I64, _P, _F, _F, _F, _P],
-    "nsim_compress_emit": [_P, _P, _P, _I64, _P, _F, _F, _F, _P, _P, _P],
+    "nsim_compress_emit": [_P, _P, _P, _I64, _P, _F, _F, _F, _P, _P, _P, _I64],
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],
     "nsim_lotd_bwd": [_P, _P, _P, C.POINTER(LotdMeta), _I64, _P],
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
@@ -117,6 +118,7 @@ SIGNATURES = {
     "nsim_eikonal_loss_fwd": [_P, _I64, _P],
     "nsim_eikonal_loss_bwd": [_P, _I64, _P, _P],
     "nsim_mse_loss_fwd": [_P, _P, _I64, _P],
+    "nsim_train_loss_head": [_P, _P, _I64, _P, _I64, _I64, _F, _P, _P, _P],
     "nsim_mse_loss_bwd": [_P, _P, _I64, _P, _P],
     "nsim_rows_scatter_add": [_P, _P, _I64, _I, _I64, _P],
     "nsim_gather_rays": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],

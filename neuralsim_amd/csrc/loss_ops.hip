@@ -64,6 +64,53 @@ __global__ void __launch_bounds__(LOSS_BLOCK) k_mse_bwd(const float* __restrict_
   da[i] = gout[0] * inv_n * 2.0f * (a[i] - b[i]);
 }
 
+// The training step's loss head in ONE launch (six otherwise): acc[0] += mse(pred, gt), acc[1] += eikonal(nab[:S]),
+// acc[2] += eikonal(nab[S:S+M]) and the gradients of  mse + w_eik (eik + eik)  -- d_img = 2 (pred - gt) / n and
+// dnab = w_eik 2 (|n| - 1) n / (|n| count).  None of the gradients needs the loss VALUE, so there is no second pass.
+__global__ void __launch_bounds__(LOSS_BLOCK) k_loss_head(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                          int64_t n_img, const float* __restrict__ nab, int64_t S,
+                                                          int64_t M, float w_eik, float* __restrict__ acc,
+                                                          float* __restrict__ d_img, float* __restrict__ dnab) {
+  __shared__ float red[3][LOSS_BLOCK / 64];
+  const float inv_n = 1.0f / (float)n_img, inv_S = 1.0f / (float)(S > 0 ? S : 1), inv_M = 1.0f / (float)(M > 0 ? M : 1);
+  const int64_t St = S + M, top = n_img > St ? n_img : St;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < top; i += (int64_t)gridDim.x * LOSS_BLOCK) {
+    if (i < n_img) {
+      const float e = pred[i] - gt[i];
+      a0 += e * e;
+      d_img[i] = inv_n * 2.0f * e;
+    }
+    if (i < St) {
+      const float a = nab[3 * i], b = nab[3 * i + 1], c = nab[3 * i + 2];
+      const float nrm = sqrtf(a * a + b * b + c * c);
+      const float e = nrm - 1.0f;
+      const bool ren = i < S;
+      if (ren) a1 += e * e;
+      else a2 += e * e;
+      const float k = nrm > 0.f ? w_eik * (ren ? inv_S : inv_M) * 2.0f * (nrm - 1.0f) / nrm : 0.f;
+      dnab[3 * i] = k * a;
+      dnab[3 * i + 1] = k * b;
+      dnab[3 * i + 2] = k * c;
+    }
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (nsim_lane() == 0) {
+    red[0][threadIdx.x >> 6] = a0;
+    red[1][threadIdx.x >> 6] = a1;
+    red[2][threadIdx.x >> 6] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float tot = 0.f;
+    for (int w = 0; w < LOSS_BLOCK / 64; ++w) tot += red[threadIdx.x][w];
+    const float sc = threadIdx.x == 0 ? inv_n : (threadIdx.x == 1 ? inv_S : inv_M);
+    if (tot != 0.f) atomicAdd(acc + threadIdx.x, tot * sc);
+  }
+}
+
 // rows * C <= ROWS_LDS_MAX: per-block LDS histogram (the few hundred frame embeddings are hit by thousands of rays),
 // flushed with one global atomic per touched entry; larger tables go straight to global atomics.
 #define ROWS_LDS_MAX 4096
@@ -175,6 +222,20 @@ int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float
   if (!dpred || !gout) return 26;
   hipLaunchKernelGGL(k_mse_bwd, dim3(nsim_blocks(n, LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, pred, gt, n,
                      1.0f / (float)n, gout, dpred);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+// acc [3] must be zero on entry.  n_img = number of image VALUES (rays * 3); nablas [S + M, 3]
+int nsim_train_loss_head(const float* pred, const float* gt, int64_t n_img, const float* nablas, int64_t S, int64_t M,
+                         float w_eikonal, float* acc, float* d_pred, float* d_nablas, void* stream) {
+  if (n_img <= 0 || S < 0 || M < 0) return 2;
+  if (!pred || !gt || !acc || !d_pred || (S + M > 0 && (!nablas || !d_nablas))) return 4;
+  const int64_t top = n_img > S + M ? n_img : S + M;
+  int64_t b = nsim_blocks(top, LOSS_BLOCK);
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(k_loss_head, dim3((unsigned)b), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, pred, gt, n_img, nablas, S,
+                     M, w_eikonal, acc, d_pred, d_nablas);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

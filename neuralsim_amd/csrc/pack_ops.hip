@@ -294,22 +294,44 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_alpha_to_vw_bwd(
 }
 
 // ------------------------------------------------------------------------- fused compositing
+__device__ __forceinline__ float nsim_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float neus_inv_s(const float* ln_inv_s, float factor, float forward_inv_s) {
+  return forward_inv_s > 0.f ? forward_inv_s : expf(ln_inv_s[0] * factor);
+}
+
+// FROM_SDF: the NeuS opacities are computed here from ``sdf`` (the arithmetic of k_neus_alpha_fwd) and written to
+// ``alpha_out`` for the backward -- one launch for sdf -> alpha -> vw -> images.
+template <bool FROM_SDF>
 __global__ void __launch_bounds__(PACK_BLOCK) k_composite_fwd(
     const float* __restrict__ alpha, const float* __restrict__ t, const float* __restrict__ rgb,
     const float* __restrict__ nrm, const int64_t* __restrict__ pi, int64_t P, int normalized_depth,
     float* __restrict__ vw, float* __restrict__ trans, float* __restrict__ mask, float* __restrict__ depth,
-    float* __restrict__ rgb_out, float* __restrict__ nrm_out, const int64_t* __restrict__ out_idx) {
+    float* __restrict__ rgb_out, float* __restrict__ nrm_out, const int64_t* __restrict__ out_idx,
+    const float* __restrict__ sdf, const float* __restrict__ ln_inv_s, float factor, float forward_inv_s,
+    float* __restrict__ alpha_out) {
   const int64_t p = pack_wave_id();
   if (p >= P) return;
   const int lane = nsim_lane();
   const int64_t st = pi[2 * p], n = pi[2 * p + 1];
   const int64_t q = out_idx ? out_idx[p] : p;      // row of the per-ray outputs (scatter to all-rays images)
+  const float s = FROM_SDF ? neus_inv_s(ln_inv_s, factor, forward_inv_s) : 0.f;
   float carry = 1.0f;
   float am = 0.f, ad = 0.f, ar[3] = {0.f, 0.f, 0.f}, an[3] = {0.f, 0.f, 0.f};
   for (int64_t base = 0; base < n; base += 64) {
     const int64_t i = base + lane;
     const bool valid = i < n;
-    const float a = valid ? alpha[st + i] : 0.f;
+    float a = 0.f;
+    if (FROM_SDF) {
+      if (i + 1 < n) {
+        const float c0 = nsim_sigmoid(sdf[st + i] * s), c1 = nsim_sigmoid(sdf[st + i + 1] * s);
+        a = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+        a = fminf(fmaxf(a, 0.f), 1.f);
+      }
+      if (valid) alpha_out[st + i] = a;
+    } else {
+      a = valid ? alpha[st + i] : 0.f;
+    }
     float T;
     vw_chunk(a, valid, 1e-10f, carry, T);
     if (valid) {
@@ -410,12 +432,6 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_composite_bwd(
 }
 
 // ------------------------------------------------------------------------------- NeuS sdf -> alpha
-__device__ __forceinline__ float nsim_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ float neus_inv_s(const float* ln_inv_s, float factor, float forward_inv_s) {
-  return forward_inv_s > 0.f ? forward_inv_s : expf(ln_inv_s[0] * factor);
-}
-
 __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_fwd(const float* __restrict__ sdf,
                                                                  const int64_t* __restrict__ pi, int64_t P,
                                                                  const float* __restrict__ ln_inv_s,
@@ -600,8 +616,23 @@ int nsim_composite_fwd(const float* alpha, const float* t, const float* rgb, con
                        void* stream) {
   if (P <= 0) return 0;
   if (!vw || !trans || !mask || !depth) return 4;
-  hipLaunchKernelGGL(k_composite_fwd, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, t, rgb, nrm,
-                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out, out_idx);
+  hipLaunchKernelGGL((k_composite_fwd<false>), pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, alpha, t, rgb, nrm,
+                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out, out_idx, nullptr, nullptr,
+                     0.f, 0.f, nullptr);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_neus_composite_fwd(const float* sdf, const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s,
+                            const float* t, const float* rgb, const float* nrm, const int64_t* pack_infos, int64_t P,
+                            int normalized_depth, float* alpha, float* vw, float* trans, float* mask, float* depth,
+                            float* rgb_out, float* nrm_out, const int64_t* out_idx, void* stream) {
+  if (P <= 0) return 0;
+  if (!sdf || !alpha || !vw || !trans || !mask || !depth) return 4;
+  if (!ln_inv_s && !(forward_inv_s > 0.f)) return 4;
+  hipLaunchKernelGGL((k_composite_fwd<true>), pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, nullptr, t, rgb, nrm,
+                     pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out, out_idx, sdf, ln_inv_s,
+                     ln_inv_s_factor, forward_inv_s, alpha);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -441,10 +441,17 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_compress(const float* __restrict_
                                                          const float* __restrict__ ln_inv_s, float factor,
                                                          float forward_inv_s, float thre, int64_t* __restrict__ counts,
                                                          const int64_t* __restrict__ pi_out, float* __restrict__ t_out,
-                                                         int64_t* __restrict__ ridx_out) {
+                                                         int64_t* __restrict__ ridx_out, int64_t tail_n) {
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
+  if (EMIT && tail_n > 0) {  // tail_n zero-length samples on the pseudo-rays R, R+1, ... behind the kept set
+    const int64_t S = pi_out[2 * (R - 1)] + pi_out[2 * (R - 1) + 1];
+    for (int64_t i = r * 64 + lane; i < tail_n; i += R * 64) {
+      t_out[S + i] = 0.f;
+      ridx_out[S + i] = R + i;
+    }
+  }
   const int64_t st = pi[2 * r], n = pi[2 * r + 1];
   const float s = forward_inv_s > 0.f ? forward_inv_s : expf(ln_inv_s[0] * factor);
   const float* ss = sdf + st;
@@ -604,17 +611,17 @@ int nsim_compress_count(const float* sdf, const int64_t* pack_infos, int64_t R, 
                         float ln_inv_s_factor, float forward_inv_s, float thre, int64_t* counts, void* stream) {
   if (R <= 0) return 0;
   hipLaunchKernelGGL((k_compress<false>), smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, sdf, nullptr, pack_infos, R,
-                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, counts, nullptr, nullptr, nullptr);
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, counts, nullptr, nullptr, nullptr, (int64_t)0);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_compress_emit(const float* sdf, const float* t, const int64_t* pack_infos, int64_t R, const float* ln_inv_s,
                        float ln_inv_s_factor, float forward_inv_s, float thre, const int64_t* pack_infos_out,
-                       float* t_out, int64_t* ridx_out, void* stream) {
+                       float* t_out, int64_t* ridx_out, int64_t tail_n, void* stream) {
   if (R <= 0) return 0;
   hipLaunchKernelGGL((k_compress<true>), smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, sdf, t, pack_infos, R,
-                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, nullptr, pack_infos_out, t_out, ridx_out);
+                     ln_inv_s, ln_inv_s_factor, forward_inv_s, thre, nullptr, pack_infos_out, t_out, ridx_out, tail_n);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -933,7 +933,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts, total_m
 
-    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None):
+    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None, tail: int = 0):
         """``march_occ_multi_upsample_compressed``: drop the samples whose visibility weight (from the no-grad SDFs
         of the sampling pass) is negligible before the with-grad query.  Host sync (size of the kept set; the same
         round-trip also brings back the true marched total ``total_m`` of a speculatively sized sampling pass).
@@ -951,12 +951,14 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             Sk, M_true = int(total.item()), None
         else:
             Sk, M_true = torch.cat([total, total_m]).tolist()
-        t_k = torch.empty([Sk], dtype=torch.float32, device=dev)
-        ridx_k = torch.empty([Sk], dtype=torch.long, device=dev)
+        tail = int(tail) if Sk > 0 else 0
+        t_k = torch.empty([Sk + tail], dtype=torch.float32, device=dev)
+        ridx_k = torch.empty([Sk + tail], dtype=torch.long, device=dev)
         if Sk > 0:
             _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(ln_eff),
-                      self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
-        return t_k, pi_k, ridx_k, M_true
+                      self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k), tail)
+        self._with_tail = (t_k, ridx_k) if tail else None
+        return t_k[:Sk], pi_k, ridx_k[:Sk], M_true
 
     def _speculative_cap(self, R: int) -> Optional[int]:
         """Capacity for the marched set of R rays from the last observed density (1.3x + slack), or None."""
@@ -1001,12 +1003,13 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                                                       need_ridx=not compressed)
             if compressed:
                 thre = float(qp.get("compress_thre", 1e-4))
+                tail = int(cfg.get("_tail_points", 0))
                 t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None,
-                                                           pre_sync_hook=hook if cap is not None else None)
+                                                           pre_sync_hook=hook if cap is not None else None, tail=tail)
                 if cap is not None and M_true > cap:          # the speculation failed: redo with the exact size
                     t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c,
                                                                               goff, woff, cap=None, need_ridx=False)
-                    t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre)
+                    t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre, tail=tail)
                     M_true = int(total_m.item())
                 if M_true is None:
                     M_true = int(sdf_ng.shape[0]) - R * (int(qp.get("num_coarse", 64)) + sum(int(n) for n in qp.get("num_fine", [8, 8, 32])))

@@ -220,34 +220,42 @@ class RenderTrainer:
             o, d, tz, rz, ha = append_extra_points(model, o_r, d_r, e, e.long(), ha, x_uni)
         else:
             o, d = o_r, d_r
-        _o, _d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
-        S = int(t.shape[0])
-        if S == 0:
-            return None
+        # everything that does not depend on the sample count is queued BEFORE the sampling pass and its blocking size
+        # read: the shadow / packed weights, and the zero-initialised buffers out of ONE arena (one memset, not nine)
         call, ptr = _lib.call, _lib.ptr
         f32 = dict(dtype=torch.float32, device=dev)
-        if M:       # per-SAMPLE arrays: depth 0 on ray R + i for the i-th free point
-            t_a, ridx_a = torch.cat([t, tz]), torch.cat([ridx, rz])
-        else:
-            t_a, ridx_a = t, ridx
-        St = S + M
         grid16, wpack = model._shadow()
         fm, NLP = model.field_meta, model.plane_levels
-        # every buffer that must start at zero comes out of ONE arena (one memset instead of nine small ones)
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
         every_ray = R == N                      # rays_inds sorted & unique: identity
         A = ha.shape[1]
-        sizes = [4, 4, n_sdf_w, n_sdf_b, n_rad_w, n_rad_b, (R + M) * A, self.V * A, St * 3, St,
+        sizes = [4, 4, n_sdf_w, n_sdf_b, n_rad_w, n_rad_b, (R + M) * A, self.V * A,
                  0 if every_ray else 2 * N, 0 if every_ray else 6 * N]
         offs, tot = [], 0
         for n in sizes:
             offs.append(tot)
             tot += (n + 3) & ~3
         arena = torch.zeros([tot], **f32)
-        acc, dln, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_app, drgb, dsdf, sc0, vec0 = [
+        acc, dln, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_app, sc0, vec0 = [
             arena[o_:o_ + n] for o_, n in zip(offs, sizes)]
         acc, dln = acc[:3], dln[:1]
-        dha, d_app, drgb = dha.view(R + M, A), d_app.view(self.V, A), drgb.view(St, 3)
+        dha, d_app = dha.view(R + M, A), d_app.view(self.V, A)
+        dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
+        model._with_tail = None
+        cfg["_tail_points"] = M     # the compressed mode's emit kernel appends the free points' samples itself
+        _o, _d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
+        S = int(t.shape[0])
+        if S == 0:
+            return None
+        if M and model._with_tail is not None:
+            t_a, ridx_a = model._with_tail
+        elif M:       # per-SAMPLE arrays: depth 0 on ray R + i for the i-th free point
+            t_a, ridx_a = torch.cat([t, tz]), torch.cat([ridx, rz])
+        else:
+            t_a, ridx_a = t, ridx
+        St = S + M
+        z4 = torch.zeros([St * 4], **f32)       # d rgb / d sdf: the free points have no colour / alpha consumers
+        drgb, dsdf = z4[:St * 3].view(St, 3), z4[St * 3:]
         # ---------------------------------------------------------------- forward
         sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
         PS = _lib.plane_pitch(St)
@@ -255,41 +263,33 @@ class RenderTrainer:
         call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha), St,
              ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl))
         ln_inv_s = model.ln_inv_s.detach()
-        alpha = torch.empty([S], **f32)
-        call("nsim_neus_alpha_fwd", ptr(sdf), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(alpha))
-        vw, trans = torch.empty([S], **f32), torch.empty([S], **f32)
+        alpha, vw, trans = torch.empty([S], **f32), torch.empty([S], **f32), torch.empty([S], **f32)
         nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
         if every_ray:
             sc, vec, out_idx = torch.empty([2, N], **f32), torch.empty([2, N, 3], **f32), None
         else:
             sc, vec, out_idx = sc0.view(2, N), vec0.view(2, N, 3), tested["rays_inds"]
-        call("nsim_composite_fwd", ptr(alpha), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(vw), ptr(trans), ptr(sc[0]),
-             ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
+        # sdf -> alpha -> visibility weights -> images: one launch
+        call("nsim_neus_composite_fwd", ptr(sdf), ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(t), ptr(rgb), ptr(nab),
+             ptr(pi), R, nd, ptr(alpha), ptr(vw), ptr(trans), ptr(sc[0]), ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
         gt = batch["gt"]
-        # acc: mse, eikonal(render samples), eikonal(uniform points)
-        call("nsim_mse_loss_fwd", ptr(vec[0]), ptr(gt), N * 3, ptr(acc))
-        call("nsim_eikonal_loss_fwd", ptr(nab), S, ptr(acc[1:]))
-        if M:
-            call("nsim_eikonal_loss_fwd", ptr(nab[S:]), M, ptr(acc[2:]))
+        # the loss head in one launch: acc = (mse, eikonal(render samples), eikonal(uniform points)) and the gradients of
+        # loss = mse + w (eik + eik) w.r.t. the image and the nablas (they do not depend on the loss values)
+        d_img, dnab = torch.empty([N, 3], **f32), torch.empty([St, 3], **f32)
+        call("nsim_train_loss_head", ptr(vec[0]), ptr(gt), N * 3, ptr(nab), S, M, float(self.w_eikonal), ptr(acc),
+             ptr(d_img), ptr(dnab))
         cst = getattr(self, "_fused_consts", None)
         if cst is None or cst[0] != (dev, float(self.w_eikonal)):
-            cst = self._fused_consts = ((dev, float(self.w_eikonal)), torch.ones([], **f32),
-                                        torch.full([], float(self.w_eikonal), **f32),
+            cst = self._fused_consts = ((dev, float(self.w_eikonal)),
                                         torch.tensor([1.0, self.w_eikonal, self.w_eikonal], **f32))
-        _, one, w_eik, w_vec = cst
-        # ---------------------------------------------------------------- backward of loss = mse + w (eik + eik)
-        d_img = torch.empty([N, 3], **f32)
-        call("nsim_mse_loss_bwd", ptr(vec[0]), ptr(gt), N * 3, ptr(one), ptr(d_img))
-        dalpha, dnab = torch.empty([S], **f32), torch.empty([St, 3], **f32)
-        # (drgb / dsdf come zeroed from the arena: the free points have no colour / alpha consumers)
+        w_vec = cst[1]
+        # ---------------------------------------------------------------- backward
+        dalpha = torch.empty([S], **f32)
+        # (drgb / dsdf come zeroed: the free points have no colour / alpha consumers)
         call("nsim_composite_bwd", ptr(alpha), ptr(trans), ptr(vw), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(sc[0]),
              ptr(sc[1]), None, None, ptr(d_img), None, None, ptr(dalpha), ptr(drgb), None, ptr(out_idx))
         call("nsim_neus_alpha_bwd", ptr(sdf), ptr(dalpha), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(dsdf),
              ptr(dln))
-        call("nsim_eikonal_loss_bwd", ptr(nab), S, ptr(w_eik), ptr(dnab))
-        if M:
-            call("nsim_eikonal_loss_bwd", ptr(nab[S:]), M, ptr(w_eik), ptr(dnab[S:]))
-        dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
         gn_total = torch.empty([St, 3], **f32)
         call("nsim_field_bwd_rad", fm, ptr(wpack), ptr(nab), ptr(rgb), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), ptr(ha),
              St, ptr(dnab), ptr(drgb), ptr(gn_total), ptr(drad_w), ptr(drad_b), ptr(dha), None, None)

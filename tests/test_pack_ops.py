@@ -247,3 +247,37 @@ def test_pack_infos_large_and_capped(backend):
         assert int(totc) == int(n.sum())                                   # the true total, for the caller's check
         assert torch.equal(pic[:, 1], torch.where(end <= cap, n, torch.zeros_like(n)))
         assert torch.equal(pic[:, 0], ref_start.clamp_max(cap)) and int((pic[:, 0] + pic[:, 1]).max()) <= cap
+
+
+def test_neus_composite_fwd_is_alpha_then_composite(backend):
+    """``nsim_neus_composite_fwd`` (one launch: sdf -> alpha -> vw -> images) == nsim_neus_alpha_fwd + nsim_composite_fwd,
+    bit for bit, on ragged packs with empty / one-sample / 64 / 65-sample rays."""
+    from neuralsim_amd import _lib
+    n, pi, S, g = _ragged(11)
+    P = pi.shape[0]
+    dev = backend
+    f32 = dict(dtype=torch.float32, device=dev)
+    sdf = (torch.rand(S, generator=g) * 0.2 - 0.1).to(dev)
+    t = torch.rand(S, generator=g).to(dev)
+    rgb, nrm = torch.rand(S, 3, generator=g).to(dev), torch.randn(S, 3, generator=g).to(dev)
+    ln = torch.tensor([1.3], **f32)
+    pid = pi.to(dev)
+    out_idx = torch.randperm(P + 5, generator=g)[:P].to(dev)
+    for fis, nd, oi in ((0.0, 1, None), (40.0, 0, out_idx)):
+        res = []
+        for fused in (False, True):
+            alpha, vw, tr = (torch.full([S], -7.0, **f32) for _ in range(3))
+            rows = P + 5
+            m, dp = torch.zeros(rows, **f32), torch.zeros(rows, **f32)
+            ro, no = torch.zeros(rows, 3, **f32), torch.zeros(rows, 3, **f32)
+            if fused:
+                _lib.call("nsim_neus_composite_fwd", _lib.ptr(sdf), _lib.ptr(ln), 2.0, fis, _lib.ptr(t), _lib.ptr(rgb),
+                          _lib.ptr(nrm), _lib.ptr(pid), P, nd, _lib.ptr(alpha), _lib.ptr(vw), _lib.ptr(tr), _lib.ptr(m),
+                          _lib.ptr(dp), _lib.ptr(ro), _lib.ptr(no), _lib.ptr(oi))
+            else:
+                _lib.call("nsim_neus_alpha_fwd", _lib.ptr(sdf), _lib.ptr(pid), P, _lib.ptr(ln), 2.0, fis, _lib.ptr(alpha))
+                _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgb), _lib.ptr(nrm), _lib.ptr(pid), P,
+                          nd, _lib.ptr(vw), _lib.ptr(tr), _lib.ptr(m), _lib.ptr(dp), _lib.ptr(ro), _lib.ptr(no), _lib.ptr(oi))
+            res.append([x.cpu() for x in (alpha, vw, tr, m, dp, ro, no)])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)

@@ -118,11 +118,13 @@ def test_fuzz_compress(backend, n, inv_s, thre, seed):
     assert torch.equal(counts_d.cpu(), cnt_ref)
     pi_k = po.get_pack_infos_from_n(counts_d)
     K = int(cnt_ref.sum())
-    t_k = torch.zeros(K, device=backend)
-    ridx_k = torch.zeros(K, dtype=torch.long, device=backend)
+    tail = (seed % 3) * 37          # 0, 37 or 74 zero-depth samples on the pseudo-rays R.. behind the kept set
+    t_k = torch.full([K + tail], -1.0, device=backend)
+    ridx_k = torch.full([K + tail], -1, dtype=torch.long, device=backend)
     _lib.call("nsim_compress_emit", _lib.ptr(dv(sdf)), _lib.ptr(dv(t)), _lib.ptr(dv(pi)), R, _lib.ptr(ln), 1.0, float(inv_s),
-              float(thre), _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k))
-    assert torch.equal(t_k.cpu(), t[keep]) and torch.equal(ridx_k.cpu(), ridx[keep])
+              float(thre), _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k), tail)
+    assert torch.equal(t_k[:K].cpu(), t[keep]) and torch.equal(ridx_k[:K].cpu(), ridx[keep])
+    assert torch.equal(t_k[K:].cpu(), torch.zeros(tail)) and torch.equal(ridx_k[K:].cpu(), torch.arange(R, R + tail))
 
 
 @settings(**SET)
