@@ -66,6 +66,11 @@ int nsim_version(void);
  * true sum and the caller redoes the pass when it later reads total > cap. */
 int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
                            void* stream);
+/* The same, and the kernel also stores (sum(n), seq) to ``notify`` [2] -- HOST-MAPPED pinned words (system-scope
+ * stores, seq last with release order): the host polls notify[1] == seq and reads the size without a stream
+ * synchronisation or a copy, so work queued behind this launch is not drained by the size read.  P > 0. */
+int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
+                                  int64_t* notify, int64_t seq, void* stream);
 /* packed_sum(x [S,C], pack_infos) -> out [P,C]   (single_volume_renderer.py:84-101) */
 int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream);
 /* out[s,c] = x[s,c] (op) per_pack[p, c or 0]; op 0 mul, 1 div, 2 add, 3 sub; x may be NULL (treated as 1 for
@@ -254,12 +259,15 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
  * h_planes [NLP,P,2] / J_planes [NLP,P,2,3] with the pitch P = NSIM_PLANE_PITCH(S) = S rounded up to 32 -- every 32-point
  * tile of a level is then one 16-byte-aligned 256 B / 768 B piece, which the decoder kernels prefetch straight into LDS
  * (global_load_lds_dwordx4) -- (both or neither; NLP = 16 for <= 16 levels, 32 above): when given, the gathered features and their
- * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again). */
+ * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again).
+ * n_dev (may be NULL; needs the planes): the launch is sized for a CAPACITY S while the number of valid points,
+ * n_dev[0] + n_add <= S, is read on the device -- the training step queues this launch before the host has read the
+ * size of the kept sample set (a count above the capacity touches nothing; the caller redoes the launch). */
 #define NSIM_PLANE_PITCH(S) ((((int64_t)(S)) + 31) & ~(int64_t)31)
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
-                   float* h_planes, float* J_planes, void* stream);
+                   float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream);
 /* Backward of nsim_field_fwd = three launches (each its own entry point so that callers can time / overlap them):
  *
  * (1) radiance branch: given dL/drgb [S,3], the saved forward nablas_fwd / rgb_fwd [S,3] and the upstream
@@ -276,10 +284,11 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
  *     be NULL) accumulates dsdf_w / dsdf_b -- including the double-backward terms of nablas w.r.t. the decoder
  *     weights (app/loss/eikonal.py:216-251) -- and writes the hand-off planes dh_planes = dL/dh and
  *     g_planes = d sdf/d h, both [NLP,S,2] (both or neither).  dx [S,3] (may be NULL; initialised by the caller or
- *     by (1)) += (dh/dx)^T dL/dh, the first-order position gradient (LoTD ``dL/dx``). */
+ *     by (1)) += (dh/dx)^T dL/dh, the first-order position gradient (LoTD ``dL/dx``).
+ *     plane_pitch: pitch of h_planes / J_planes when the forward ran at a capacity above S (0 = NSIM_PLANE_PITCH(S)). */
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
-                       float* dsdf_w, float* dsdf_b, float* dx, void* stream);
+                       float* dsdf_w, float* dsdf_b, float* dx, int64_t plane_pitch, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term).
  *     Levels [level_begin, level_begin + level_count) only (level_count <= 0: all) -- a data-parallel caller scatters

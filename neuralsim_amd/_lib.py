@@ -66,6 +66,7 @@ _F = C.c_float
 # name -> argtypes (every function additionally takes the trailing ``void* stream`` unless listed in _NOSTREAM)
 SIGNATURES = {
     "nsim_pack_infos_from_n": [_P, _I64, _P, _P, _I64],
+    "nsim_pack_infos_from_n_notify": [_P, _I64, _P, _P, _I64, _P, _I64],
     "nsim_packed_sum": [_P, _I, _P, _I64, _P],
     "nsim_packed_binary": [_P, _I, _P, _I, _P, _I64, _I, _P],
     "nsim_packed_cmp": [_P, _P, _P, _I64, _I, _P],
@@ -99,9 +100,9 @@ SIGNATURES = {
     "nsim_field_pack_weights": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, C.POINTER(OccMeta), _F],
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
-    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P],
+    "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
-    "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
     "nsim_ray_grad_reduce": [_P, _P, _P, _P, _I64, _P, _P],
     "nsim_lotd_scatter": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _I, _I],
@@ -182,6 +183,43 @@ def ptr(t, dtype=None, name="tensor"):
     if t is not None and dtype is not None and t.dtype != dtype:
         raise TypeError(f"neuralsim_amd: {name} must be {dtype}, got {t.dtype}")
     return t
+
+
+class HostNotify:
+    """Host-mapped (pinned) words a kernel stores a size to, read by the host WITHOUT a stream synchronisation or a copy
+    (``nsim_pack_infos_from_n_notify``): slot s = (value, seq).  ``arm(s)`` -> (address of the slot, the sequence number
+    the kernel must store); ``wait(s, seq)`` spins until the slot carries seq and returns the value, or None after
+    ``timeout_s`` (the caller then falls back to a synchronising read of the device copy)."""
+
+    def __init__(self, slots: int = 2):
+        buf = torch.zeros([slots, 2], dtype=torch.long)
+        self.buf = buf.pin_memory() if torch.cuda.is_available() else buf
+        self.view = self.buf.numpy()
+        self.seq = 0
+
+    def __deepcopy__(self, memo):         # a copy of a model gets words of its own
+        return HostNotify(self.buf.shape[0])
+
+    def __reduce__(self):
+        return (HostNotify, (self.buf.shape[0],))
+
+    def arm(self, slot: int):
+        self.seq += 1
+        return self.buf.data_ptr() + 16 * slot, self.seq
+
+    def wait(self, slot: int, seq: int, timeout_s: float = 2.0):
+        v = self.view
+        n = 0
+        t0 = None
+        while int(v[slot, 1]) != seq:
+            n += 1
+            if n & 1023 == 0:
+                import time
+                now = time.perf_counter()
+                t0 = now if t0 is None else t0
+                if now - t0 > timeout_s:
+                    return None
+        return int(v[slot, 0])
 
 
 class KernelTimer:

@@ -463,6 +463,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   const float b_out = reinterpret_cast<const float*>(W + L.vec[V_SCAL])[0];
   const GridRef gref = grid_ref(a.grid);
 
+  if (MODE == 3 && a.S_dev) {     // speculatively sized launch: the point count comes from device memory, a.S is the
+    const int64_t sd = a.S_dev[0] + a.S_add;      // capacity (and a.PS the pitch); overflow: touch nothing
+    a.S = sd <= a.S ? sd : 0;
+  }
   const int64_t ntiles = (a.S + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * NW;
   // MODE 3, <= 16 levels: the planes of the NEXT tile (16 KB: per level 256 B of h and 768 B of dh/dx, each one aligned
@@ -2111,11 +2115,12 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
-                   float* h_planes, float* J_planes, void* stream) {
+                   float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (ray_goff && !ridx) return 29;
+  if (n_dev && !h_planes) return 28;          // the device-side point count is a feature of the level-major path
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
   if (rgb && !(rays_d && ridx)) return 25;
   if ((h_planes != nullptr) != (J_planes != nullptr)) return 28;
@@ -2127,11 +2132,13 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.ray_goff = ray_goff;
   a.S = S;
   a.PS = NSIM_PLANE_PITCH(S);
+  a.S_dev = n_dev;
+  a.S_add = n_add;
   a.sdf = sdf; a.nablas = nablas; a.rgb = rgb;
   a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
   static const bool fused = getenv("NSIM_FWD_FUSED") && atoi(getenv("NSIM_FWD_FUSED")) == 1;
-  if (h_planes && (!fused || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
+  if (h_planes && (!fused || n_dev || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
     deal_levels(meta, a);
     const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
     if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
@@ -2182,7 +2189,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
-                       float* dsdf_b, float* dx, void* stream) {
+                       float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -2192,7 +2199,8 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   FieldArgs a = field_args(meta);
   a.wpack = (const char*)wpack;
   a.S = S;
-  a.PS = NSIM_PLANE_PITCH(S);
+  if (plane_pitch != 0 && (plane_pitch < S || (plane_pitch & 31))) return 28;
+  a.PS = plane_pitch ? plane_pitch : NSIM_PLANE_PITCH(S);
   a.dsdf = dsdf; a.dnablas = gn;
   a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
   a.dh_pl = dh_planes; a.g_pl = g_planes;

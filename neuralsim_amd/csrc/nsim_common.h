@@ -288,6 +288,16 @@ __device__ __forceinline__ constexpr int mfma_row(int r, int hi) {
   return (r & 3) + 8 * (r >> 2) + 4 * hi;
 }
 
+// a word the HOST reads while the stream keeps running (host-mapped pinned memory): system-scope store
+__device__ __forceinline__ void nsim_store_system(int64_t* p, int64_t v, bool release) {
+#ifdef NSIM_HOST_EMU
+  __atomic_store_n(p, v, release ? __ATOMIC_RELEASE : __ATOMIC_RELAXED);
+#else
+  if (release) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
 // ------------------------------------------------------------------- launching
 #define NSIM_CHECK_LAUNCH()                          \
   do {                                               \

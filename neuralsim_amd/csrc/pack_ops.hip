@@ -24,7 +24,8 @@ static inline dim3 pack_grid(int64_t P) { return dim3(nsim_blocks(P, PACK_WAVES_
 // them -- the 8192-ray batch of the training step is exactly one super-chunk.
 __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t* __restrict__ n, int64_t P,
                                                                     int64_t* __restrict__ pi,
-                                                                    int64_t* __restrict__ total, int64_t cap) {
+                                                                    int64_t* __restrict__ total, int64_t cap,
+                                                                    int64_t* notify, int64_t seq) {
   __shared__ int64_t wtot[PI_THREADS / 64];
   const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
   int64_t carry = 0;
@@ -65,6 +66,10 @@ __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t*
     __syncthreads();
   }
   if (tid == 0 && total) total[0] = carry;
+  if (tid == 0 && notify) {  // host-mapped words: the host spins on notify[1] == seq instead of a stream sync + copy
+    nsim_store_system(notify, carry, false);
+    nsim_store_system(notify + 1, seq, true);
+  }
 }
 
 // ------------------------------------------------------------------------------------ packed_sum
@@ -518,7 +523,18 @@ extern "C" {
 int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
                            void* stream) {
   if (P < 0) return 2;
-  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, P, pack_infos, total, cap);
+  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, P, pack_infos, total, cap,
+                     (int64_t*)nullptr, (int64_t)0);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
+                                  int64_t* notify, int64_t seq, void* stream) {
+  if (P <= 0) return 2;
+  if (!notify) return 4;
+  hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, P, pack_infos, total, cap,
+                     notify, seq);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

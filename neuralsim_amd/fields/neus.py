@@ -64,6 +64,8 @@ def append_extra_points(model, rays_o, rays_d, t, ridx, h_appear, extra_x):
 
 
 # --------------------------------------------------------------------------------------------- autograd
+
+
 class _FieldFn(torch.autograd.Function):
     """(grid, sdf_w, sdf_b, rad_w, rad_b, h_appear) -> (sdf [S], nablas [S,3], rgb [S,3]).
     ``nablas`` is an ordinary differentiable output: its gradient w.r.t. grid and decoder weights (the
@@ -99,7 +101,7 @@ class _FieldFn(torch.autograd.Function):
         J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
         _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
-                  _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl))
+                  _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), None, 0)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
@@ -167,7 +169,7 @@ class _FieldFn(torch.autograd.Function):
         g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
         # (2) SDF-decoder branch on the saved planes
         _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
-                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx))
+                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx), 0)
         d_x = d_o = d_d = None
         if need_dx:
             if gn_total is not None:    # the normals' own dependence on x (mixed second derivatives of the interpolant)
@@ -873,7 +875,13 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         counts = torch.empty([R], dtype=torch.long, device=dev)
         _lib.call("nsim_march_count", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(counts))
-        pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
+        nt = self._host_notify() if cap is not None else None
+        self._notify_seq_m = None
+        if nt is not None:      # the true marched total travels to host-mapped words (read at the compress step's wait)
+            adr, self._notify_seq_m = nt.arm(0)
+            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=int(cap), notify=(adr, self._notify_seq_m))
+        else:
+            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
         if cap is None:
             if pre_sync_hook is not None:
                 pre_sync_hook()                 # independent host work queued ahead of the blocking read
@@ -933,32 +941,94 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts, total_m
 
-    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None, tail: int = 0):
+    def _host_notify(self):
+        """``_lib.HostNotify`` of this model (NSIM_HOST_NOTIFY=0 or a failed wait turn it off)."""
+        nt = getattr(self, "_notify", None)
+        if nt is None:
+            nt = self._notify = _lib.HostNotify(2) if os.environ.get("NSIM_HOST_NOTIFY", "1") == "1" else False
+        return nt or None
+
+    def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None, tail: int = 0,
+                  spec_launch=None):
         """``march_occ_multi_upsample_compressed``: drop the samples whose visibility weight (from the no-grad SDFs
         of the sampling pass) is negligible before the with-grad query.  Host sync (size of the kept set; the same
         round-trip also brings back the true marched total ``total_m`` of a speculatively sized sampling pass).
-        -> t_k, pack_infos_k, ridx_k, M_true (None when total_m is None); all None but M_true on overflow."""
+        -> t_k, pi_k, ridx_k, M_true (None when total_m is None); all None but M_true on overflow.  ``tail`` > 0: the
+        kernel also writes ``tail`` zero-depth samples on the pseudo-rays R.. behind the kept set (the trainer's free
+        eikonal points); t_k / ridx_k are then views of ``self._with_tail = (t [Sk+tail], ridx [Sk+tail])``.
+
+        ``spec_launch(t_full, ridx_full, pi_k, total_dev, cap)`` (with host-mapped size words only): the kept set is
+        emitted into buffers of a CAPACITY taken from the previous iterations and the callback queues the first
+        with-grad launches (device-side point count) BEFORE the host waits for the size -- the stream then has work
+        while the host reads the size and prepares the rest of the step.  ``self._spec_ok`` tells the caller whether
+        those launches stand (False: the kept set outgrew the capacity; everything is redone at the exact size)."""
         R = pi.shape[0]
         dev = t.device
         counts = torch.empty([R], dtype=torch.long, device=dev)
         ln_eff = self._ln_inv_s_eff().detach()
         _lib.call("nsim_compress_count", _lib.ptr(sdf), _lib.ptr(pi), R, _lib.ptr(ln_eff),
                   self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(counts))
-        pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
+        nt = self._host_notify()
+        self._spec_ok = False
+        cap_k = self._keep_cap(R) if (spec_launch is not None and nt is not None) else None
+        seq_k = None
+        if nt is not None:
+            adr, seq_k = nt.arm(1)
+            pi_k, total = po.get_pack_infos_from_n(counts, return_total=True, notify=(adr, seq_k),
+                                                   cap=-1 if cap_k is None else cap_k)
+        else:
+            pi_k, total = po.get_pack_infos_from_n(counts, return_total=True)
+
+        def emit(n_out, tail_):
+            t_o = torch.empty([n_out + tail_], dtype=torch.float32, device=dev)
+            r_o = torch.empty([n_out + tail_], dtype=torch.long, device=dev)
+            _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(ln_eff),
+                      self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_o), _lib.ptr(r_o), tail_)
+            return t_o, r_o
+        if cap_k is not None:       # emit + the caller's first launches at the capacity, ahead of the size read
+            t_k, ridx_k = emit(cap_k, int(tail))
+            spec_launch(t_k, ridx_k, pi_k, total, cap_k)
         if pre_sync_hook is not None:
             pre_sync_hook()                     # e.g. the trainer's prefetch of the next batch (its own sync lands here)
-        if total_m is None:
-            Sk, M_true = int(total.item()), None
-        else:
-            Sk, M_true = torch.cat([total, total_m]).tolist()
+        Sk = M_true = None
+        if nt is not None:          # sizes from the host-mapped words: no stream synchronisation, no copy
+            Sk = nt.wait(1, seq_k)
+            if Sk is not None and total_m is not None:
+                M_true = nt.wait(0, self._notify_seq_m) if self._notify_seq_m is not None else None
+                if M_true is None:
+                    Sk = None
+            if Sk is None:          # never stored (memory not host-coherent?): synchronising reads from here on
+                self._notify = False
+        if Sk is None:
+            if total_m is None:
+                Sk, M_true = int(total.item()), None
+            else:
+                Sk, M_true = torch.cat([total, total_m]).tolist()
+        self._keep_stat = (R, Sk)
+        if cap_k is not None and Sk <= cap_k and Sk > 0:
+            self._spec_ok = True
+            self._with_tail = (t_k[:Sk + int(tail)], ridx_k[:Sk + int(tail)]) if tail else None
+            return t_k[:Sk], pi_k, ridx_k[:Sk], M_true
+        if cap_k is not None:       # outgrown (or empty): exact pack infos, exact emit
+            pi_k = po.get_pack_infos_from_n(counts)
         tail = int(tail) if Sk > 0 else 0
-        t_k = torch.empty([Sk + tail], dtype=torch.float32, device=dev)
-        ridx_k = torch.empty([Sk + tail], dtype=torch.long, device=dev)
         if Sk > 0:
-            _lib.call("nsim_compress_emit", _lib.ptr(sdf), _lib.ptr(t), _lib.ptr(pi), R, _lib.ptr(ln_eff),
-                      self.ln_inv_s_factor, forward_inv_s, thre, _lib.ptr(pi_k), _lib.ptr(t_k), _lib.ptr(ridx_k), tail)
+            t_k, ridx_k = emit(Sk, tail)
+        else:
+            t_k = torch.empty([0], dtype=torch.float32, device=dev)
+            ridx_k = torch.empty([0], dtype=torch.long, device=dev)
         self._with_tail = (t_k, ridx_k) if tail else None
         return t_k[:Sk], pi_k, ridx_k[:Sk], M_true
+
+    def _keep_cap(self, R: int) -> Optional[int]:
+        """Capacity for the kept set of R rays from the last observed one (1.3x + slack), or None."""
+        st = getattr(self, "_keep_stat", None)
+        if st is None or not self._speculate:
+            return None
+        R0, K0 = st
+        if R0 <= 0 or K0 <= 0 or not (0.5 <= R / R0 <= 2.0):
+            return None
+        return ((int(1.3 * K0 * R / R0) + 4096) + 31) & ~31
 
     def _speculative_cap(self, R: int) -> Optional[int]:
         """Capacity for the marched set of R rays from the last observed density (1.3x + slack), or None."""
@@ -1005,7 +1075,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 thre = float(qp.get("compress_thre", 1e-4))
                 tail = int(cfg.get("_tail_points", 0))
                 t_k, pi_k, ridx_k, M_true = self._compress(t, sdf_ng, pi, fis, thre, total_m if cap is not None else None,
-                                                           pre_sync_hook=hook if cap is not None else None, tail=tail)
+                                                           pre_sync_hook=hook if cap is not None else None, tail=tail,
+                                                           spec_launch=cfg.get("_spec_launch") if cap is not None else None)
                 if cap is not None and M_true > cap:          # the speculation failed: redo with the exact size
                     t, sdf_ng, pi, ridx, march_counts, total_m = self._sample(o, d, near, far, qp, jitter, jitter_c,
                                                                               goff, woff, cap=None, need_ridx=False)

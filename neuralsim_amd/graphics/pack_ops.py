@@ -20,15 +20,19 @@ def _f32c(t):
     return t.float().contiguous()
 
 
-def get_pack_infos_from_n(n: torch.Tensor, return_total: bool = False, cap: int = -1):
+def get_pack_infos_from_n(n: torch.Tensor, return_total: bool = False, cap: int = -1, notify=None):
     """[P] counts -> [P,2] (exclusive cumsum, count).  buffer_compose_renderer.py:991,1004.
-    ``cap >= 0`` (internal, speculative buffer sizes): packs ending beyond cap get count 0; total is the true sum."""
+    ``cap >= 0`` (internal, speculative buffer sizes): packs ending beyond cap get count 0; total is the true sum.
+    ``notify`` = (address, seq) of a ``_lib.HostNotify`` slot: the kernel also stores (total, seq) there."""
     n = n.long().contiguous()
     P = n.shape[0]
     pi = torch.empty([P, 2], dtype=torch.long, device=n.device)
     total = torch.empty([1], dtype=torch.long, device=n.device) if P > 0 else \
         torch.zeros([1], dtype=torch.long, device=n.device)          # the kernel always writes total[0]
-    if P > 0:
+    if P > 0 and notify is not None:
+        _lib.call("nsim_pack_infos_from_n_notify", _lib.ptr(n), P, _lib.ptr(pi), _lib.ptr(total), int(cap),
+                  int(notify[0]), int(notify[1]))
+    elif P > 0:
         _lib.call("nsim_pack_infos_from_n", _lib.ptr(n), P, _lib.ptr(pi), _lib.ptr(total), int(cap))
     return (pi, total) if return_total else pi
 

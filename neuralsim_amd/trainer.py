@@ -42,6 +42,9 @@ class RenderTrainer:
         # N > 1: overlap the table-gradient all-reduce with the second half of the scatter (NSIM_OVERLAP_ALLREDUCE=0: off)
         self.overlap_allreduce = os.environ.get("NSIM_OVERLAP_ALLREDUCE", "1") == "1"
         self._step_done = False
+        # the with-grad gather + decoders are queued at a capacity BEFORE the size of the kept sample set is read
+        # (NSIM_SPEC_FORWARD=0: after it, at the exact size)
+        self.spec_forward = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
         # measurement aid (bench.py ``exposed_allreduce_ms``): every rank keeps its local gradients, no collective is issued
         self.skip_allreduce = False
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
@@ -243,6 +246,20 @@ class RenderTrainer:
         dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
         model._with_tail = None
         cfg["_tail_points"] = M     # the compressed mode's emit kernel appends the free points' samples itself
+        spec = {}
+
+        def spec_launch(t_full, ridx_full, pi_k, total_dev, cap_k):
+            # queued BEFORE the host knows the size of the kept set: gather + decoders of the with-grad query at the
+            # capacity, valid points = total_dev[0] + M read on the device
+            Sc = cap_k + M
+            PSc = _lib.plane_pitch(Sc)
+            bufs = (torch.empty([Sc], **f32), torch.empty([Sc, 3], **f32), torch.empty([Sc, 3], **f32),
+                    torch.empty([NLP, PSc, 2], **f32), torch.empty([NLP, PSc, 2, 3], **f32))
+            call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_full), ptr(ridx_full), None,
+                 ptr(ha), Sc, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(bufs[4]), ptr(total_dev), M)
+            spec.update(bufs=bufs, PS=PSc)
+        if self.spec_forward:
+            cfg["_spec_launch"] = spec_launch
         _o, _d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
         S = int(t.shape[0])
         if S == 0:
@@ -257,11 +274,15 @@ class RenderTrainer:
         z4 = torch.zeros([St * 4], **f32)       # d rgb / d sdf: the free points have no colour / alpha consumers
         drgb, dsdf = z4[:St * 3].view(St, 3), z4[St * 3:]
         # ---------------------------------------------------------------- forward
-        sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
-        PS = _lib.plane_pitch(St)
-        h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
-        call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha), St,
-             ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl))
+        if spec and getattr(model, "_spec_ok", False):      # already running (or done): views at the exact size
+            sdf, nab, rgb = spec["bufs"][0][:St], spec["bufs"][1][:St], spec["bufs"][2][:St]
+            h_pl, J_pl, PS = spec["bufs"][3], spec["bufs"][4], spec["PS"]
+        else:
+            sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
+            PS = _lib.plane_pitch(St)
+            h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
+            call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha),
+                 St, ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl), None, 0)
         ln_inv_s = model.ln_inv_s.detach()
         alpha, vw, trans = torch.empty([S], **f32), torch.empty([S], **f32), torch.empty([S], **f32)
         nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
@@ -295,7 +316,7 @@ class RenderTrainer:
              St, ptr(dnab), ptr(drgb), ptr(gn_total), ptr(drad_w), ptr(drad_b), ptr(dha), None, None)
         dh_pl, g_pl = torch.empty([NLP, St, 2], **f32), torch.empty([NLP, St, 2], **f32)
         call("nsim_field_bwd_sdf", fm, ptr(wpack), ptr(h_pl), ptr(J_pl), St, ptr(dsdf), ptr(gn_total), ptr(dh_pl),
-             ptr(g_pl), ptr(dsdf_w), ptr(dsdf_b), None)
+             ptr(g_pl), ptr(dsdf_w), ptr(dsdf_b), None, PS)
         if model.sdf_scale != 1.0:      # d/d(head weights) of head / sdf_scale
             dsdf_w[-64:] /= model.sdf_scale
             dsdf_b[-1:] /= model.sdf_scale

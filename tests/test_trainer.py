@@ -93,6 +93,47 @@ def test_fused_step_equals_autograd_step(backend, variant):
         assert float(d.max()) <= 2 * 5 * 2e-3
 
 
+@pytest.mark.parametrize("mode", ["speculative", "outgrown", "no_notify"])
+def test_speculative_forward_equals_exact_size_forward(backend, mode):
+    """Compressed query mode: from the second iteration on the fused step queues the with-grad gather + decoders at a
+    CAPACITY, before the host has read the size of the kept sample set (``_compress(spec_launch=)``, device-side point
+    count, sizes through host-mapped words).  Same losses / parameters as the step that waits for the size first; a
+    kept set that outgrows the capacity is redone at the exact size (``outgrown``: capacity forced to 32); without the
+    host-mapped words (``no_notify``) nothing is speculated."""
+    outs = []
+    for spec in (False, True):
+        torch.manual_seed(0)
+        m = _tiny(backend)
+        m.ray_query_cfg["query_mode"] = "march_occ_multi_upsample_compressed"
+        if spec and mode == "outgrown":
+            m._keep_cap = lambda R: 32
+        if spec and mode == "no_notify":
+            m._notify = False
+        intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=True,
+                           num_uniform=24, perturb=True)
+        tr.spec_forward = spec
+        assert tr._fused_ok()
+        losses, ok = [], []
+        for it in range(5):
+            losses.append(float(tr.train_step(it)))
+            ok.append(bool(getattr(m, "_spec_ok", False)))
+        if spec and mode == "speculative":
+            assert ok[0] is False and all(ok[1:]), ok          # no capacity before the first observed size
+        else:
+            assert not any(ok), ok
+        outs.append((losses, m.encoding.flattened_params.detach().clone(), m.sdf_w.detach().clone(),
+                     m.rad_w.detach().clone(), tr.appear.detach().clone(), dict(tr.stats)))
+    (la, *pa, sa), (lb, *pb, sb) = outs
+    assert sa == sb and sa["S_f"] > 0
+    assert all(abs(x - y) < 1e-5 * (1 + abs(x)) for x, y in zip(la, lb)), (la, lb)
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        bad = d > (5e-5 + 1e-4 * b.abs())
+        assert float(bad.float().mean()) < 2e-3, (float(bad.float().mean()), float(d.max()))
+        assert float(d.max()) <= 2 * 5 * 2e-3
+
+
 def test_model_built_from_reference_model_params_trains(backend):
     """A model constructed from a reference-style ``model_params`` block (the dtu yaml's keys, a small pyramid) inside
     the trainer: the model's own ``training_before_per_step`` drives level annealing, inv_s control and the occupancy
