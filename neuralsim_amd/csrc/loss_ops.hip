@@ -233,7 +233,7 @@ int nsim_train_loss_head(const float* pred, const float* gt, int64_t n_img, cons
   if (!pred || !gt || !acc || !d_pred || (S + M > 0 && (!nablas || !d_nablas))) return 4;
   const int64_t top = n_img > S + M ? n_img : S + M;
   int64_t b = nsim_blocks(top, LOSS_BLOCK);
-  if (b > 1024) b = 1024;
+  if (b > LOSS_MAX_BLOCKS) b = LOSS_MAX_BLOCKS;     // three single-address atomics per block: they serialise at L2
   hipLaunchKernelGGL(k_loss_head, dim3((unsigned)b), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, pred, gt, n_img, nablas, S,
                      M, w_eikonal, acc, d_pred, d_nablas);
   NSIM_CHECK_LAUNCH();

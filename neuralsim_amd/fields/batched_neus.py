@@ -55,7 +55,7 @@ class OccGridAccelBatched(OccGridAccel):
         for b in range(self.num_batches):
             val = self.occ_val[b * self.nvox:(b + 1) * self.nvox]
             for _ in range(num_steps or self.num_steps):
-                pts = lo + torch.rand([n, 3], device=dev, generator=generator) * (hi - lo)
+                pts = self.draw_points(n, generator)
                 sdf = query_sdf(pts, b).detach().float().contiguous()
                 _lib.call("nsim_occ_decay", _lib.ptr(val), self.nvox, self.ema_decay)
                 _lib.call("nsim_occ_update", _lib.ptr(val), _lib.ptr(pts), _lib.ptr(sdf), n, self.meta, self.inv_s)

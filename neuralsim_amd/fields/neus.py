@@ -355,14 +355,37 @@ class OccGridAccel(nn.Module):
                   _lib.ptr(self.occ_bits))
 
     @torch.no_grad()
-    def update_from_net(self, query_sdf, num_steps=None, num_pts=None, generator=None):
-        """EMA-max refresh from random SDF queries (``init_cfg`` / ``update_from_net_cfg``)."""
+    def draw_points(self, n: int, generator=None) -> torch.Tensor:
+        """The n query points of one refresh pass: point i lies in voxel (sweep + i) mod n_voxels -- voxels in storage
+        order (x fastest), the sweep continuing where the previous pass stopped -- at a uniformly random offset inside
+        the voxel: a STRATIFIED uniform draw (every voxel gets n / n_voxels points per pass, 4 at 2^20 points on 64^3)
+        in a spatially coherent order.  A pass over 2^20 i.i.d. points costs 0.65 ms on MI355X (every hash-table read of
+        every point is a cache miss), the same number of voxel-ordered points 0.385 ms (tools/refresh_probe.py).
+        ``NSIM_OCC_IID=1``: i.i.d. uniform points in the box.  (The sampler of the absent nr3d_lib is not known; both
+        draws are uniform over the box.)"""
         dev = self.occ_val.device
         lo, hi = self.aabb[0], self.aabb[1]
+        if os.environ.get("NSIM_OCC_IID", "0") == "1":
+            return lo + torch.rand([n, 3], device=dev, generator=generator) * (hi - lo)
+        rx, ry, rz = self.resolution
+        nvox = rx * ry * rz
+        sweep = getattr(self, "_sweep", 0) % nvox
+        self._sweep = (sweep + n) % nvox
+        key = (n, sweep, str(dev), self.aabb._version)
+        cache = getattr(self, "_corner_cache", None)
+        if cache is None or cache[0] != key:
+            v = (torch.arange(n, device=dev) + sweep) % nvox
+            ijk = torch.stack([v % rx, (v // rx) % ry, v // (rx * ry)], dim=-1).float()
+            cell = (hi - lo) / torch.tensor([rx, ry, rz], dtype=torch.float32, device=dev)
+            cache = self._corner_cache = (key, lo + ijk * cell, cell)       # min corner of each point's voxel
+        return torch.addcmul(cache[1], torch.rand([n, 3], device=dev, generator=generator), cache[2])
+
+    def update_from_net(self, query_sdf, num_steps=None, num_pts=None, generator=None):
+        """EMA-max refresh from random SDF queries (``init_cfg`` / ``update_from_net_cfg``)."""
         if self.update_from_samples_cfg is not None and self.sync_values is not None:
             self.sync_values(self.occ_val)
         for _ in range(num_steps or self.num_steps):
-            pts = lo + torch.rand([num_pts or self.num_pts, 3], device=dev, generator=generator) * (hi - lo)
+            pts = self.draw_points(num_pts or self.num_pts, generator)
             self.update_from_samples(pts, query_sdf(pts), pack=False)
         self.pack_bits()
 

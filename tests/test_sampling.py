@@ -257,3 +257,27 @@ def test_occupancy_collects_the_sampling_pass(backend):
     assert torch.equal(model.accel.occ_bits, bits0)              # thresholded only by the next refresh
     model.ray_query(ray_tested=tested, config=cfg)               # a second, un-armed pass: unchanged
     assert torch.equal(model.accel.occ_val.cpu(), got)
+
+
+def test_refresh_points_are_a_stratified_sweep(backend):
+    """``OccGridAccel.draw_points``: point i of a pass lies in voxel (sweep + i) mod n_voxels (storage order), the sweep
+    continues across passes, offsets inside the voxel are uniform -- every voxel receives the same number of queries."""
+    from neuralsim_amd.fields.neus import OccGridAccel
+    aabb = torch.tensor([[-1.0, -0.5, -0.25], [1.0, 0.5, 0.75]])
+    acc = OccGridAccel(aabb, resolution=(8, 4, 2), device=backend)
+    nvox = 64
+    g = torch.Generator(device=backend).manual_seed(0)
+    seen = torch.zeros(nvox, dtype=torch.long)
+    start = 0
+    for n in (100, 64, 28, 192):
+        pts = acc.draw_points(n, g).cpu()
+        u = (pts - aabb[0]) / (aabb[1] - aabb[0]) * torch.tensor([8.0, 4.0, 2.0])
+        assert bool((u >= 0).all()) and bool((u < torch.tensor([8.0, 4.0, 2.0])).all())
+        ijk = u.floor().long()
+        v = ijk[:, 0] + 8 * (ijk[:, 1] + 4 * ijk[:, 2])
+        assert torch.equal(v, (torch.arange(n) + start) % nvox)
+        frac = u - u.floor()
+        assert 0.3 < float(frac.mean()) < 0.7
+        seen += torch.bincount(v, minlength=nvox)
+        start = (start + n) % nvox
+    assert int(seen.min()) == int(seen.max()) == 6          # 384 points over 64 voxels
