@@ -66,6 +66,9 @@ def append_extra_points(model, rays_o, rays_d, t, ridx, h_appear, extra_x):
 # --------------------------------------------------------------------------------------------- autograd
 
 
+_SPEC_FORWARD = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
+
+
 class _FieldFn(torch.autograd.Function):
     """(grid, sdf_w, sdf_b, rad_w, rad_b, h_appear) -> (sdf [S], nablas [S,3], rgb [S,3]).
     ``nablas`` is an ordinary differentiable output: its gradient w.r.t. grid and decoder weights (the
@@ -73,14 +76,34 @@ class _FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, grid, sdf_w, sdf_b, rad_w, rad_b, h_appear, x, rays_o, rays_d, t, ridx, with_rgb,
-                goff=None, extra_x=None):
+                goff=None, extra_x=None, pre=None):
         """goff [R] int64 (batched model only): table offset of every ray's instance; needs ridx.
         extra_x [M,3] (ray mode only): additional free points evaluated by the SAME launches (appended as M
         zero-length rays); their sdf / nablas come back as two extra outputs.  The trainer uses it for the uniform
         eikonal points (code_single/tools/train.py:602-613): a separate 4096-point launch chain costs ~0.2 ms of
-        fixed per-launch latency."""
+        fixed per-launch latency.
+        pre (``ray_query``'s speculative launch): the forward kernels are ALREADY queued, at a capacity, on the arrays
+        in ``pre`` (extra points appended) -- only the bookkeeping is left."""
         dev = grid.device
         M = 0
+        ctx.PS = 0
+        if pre is not None:
+            M = pre["M"]
+            rays_o, rays_d, t, ridx, ha = pre["rays_o"], pre["rays_d"], pre["t"], pre["ridx"], pre["ha"]
+            S = t.shape[0]
+            sdf, nablas, rgb = pre["sdf"][:S], pre["nablas"][:S], (pre["rgb"][:S] if with_rgb else None)
+            h_pl, J_pl, ctx.PS = pre["h_pl"], pre["J_pl"], pre["PS"]
+            if _lib.TIMER is not None:
+                _lib.TIMER.note_units("nsim_field_fwd", S)
+            ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
+            ctx.x_shape = None
+            ctx.geom = (None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
+            ctx.goff = None
+            ctx.ha_shape = ha.shape if ha is not None else None
+            if M == 0:
+                return (sdf, nablas, rgb) if with_rgb else (sdf, nablas)
+            Sm = S - M
+            return (sdf[:Sm], nablas[:Sm]) + ((rgb[:Sm],) if with_rgb else ()) + (sdf[Sm:], nablas[Sm:])
         if extra_x is not None:
             assert x is None and goff is None, "extra points ride on a ray-mode query of a single-instance model"
             M = extra_x.shape[0]
@@ -169,7 +192,8 @@ class _FieldFn(torch.autograd.Function):
         g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
         # (2) SDF-decoder branch on the saved planes
         _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
-                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx), 0)
+                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx),
+                  int(ctx.PS))
         d_x = d_o = d_d = None
         if need_dx:
             if gn_total is not None:    # the normals' own dependence on x (mixed second derivatives of the interpolant)
@@ -202,7 +226,7 @@ class _FieldFn(torch.autograd.Function):
             dsdf_b[-1:] /= model.sdf_scale
         if dha is not None and M > 0:
             dha = dha[:dha.shape[0] - M]
-        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_x, d_o, d_d, None, None, None, None, None)
+        return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_x, d_o, d_d, None, None, None, None, None, None)
 
 
 class _NeusAlphaFn(torch.autograd.Function):
@@ -1151,6 +1175,39 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             if return_details:
                 ret["details"] = dict()
             return ret
+        h_appear = ray_tested.get("rays_h_appear", None)
+        extra_x = cfg.get("_extra_pts", None)              # trainer hook: free points riding on the same launches
+        o_g, d_g = ray_tested["rays_o"], ray_tested["rays_d"]
+        # Speculative forward (training, compressed mode, single-instance model, constant rays): the per-ray arrays are
+        # built now, and ``_compress`` calls ``spec_launch`` -- gather + decoders at a CAPACITY, point count read on the
+        # device -- before the host waits for the size of the kept set (see ``_compress``; NSIM_SPEC_FORWARD=0: off)
+        spec = None
+        mode = cfg.get("query_mode", self.ray_query_cfg.get("query_mode", "march_occ_multi_upsample"))
+        if (_SPEC_FORWARD and type(self) is LoTDNeuSModel and mode.endswith("_compressed") and torch.is_grad_enabled()
+                and self.encoding.flattened_params.requires_grad and not (o_g.requires_grad or d_g.requires_grad)):
+            M = int(extra_x.shape[0]) if extra_x is not None else 0
+            o_a, d_a = o_g.detach().float().contiguous(), d_g.detach().float().contiguous()
+            ha_a = h_appear.detach().float().contiguous() if (with_rgb and h_appear is not None) else None
+            if M:
+                e = torch.empty([0], dtype=torch.float32, device=o_a.device)
+                o_a, d_a, _, _, ha_a = append_extra_points(self, o_a, d_a, e, e.long(), ha_a, extra_x)
+            spec = dict(M=M, rays_o=o_a, rays_d=d_a, ha=ha_a)
+
+            def spec_launch(t_full, ridx_full, pi_k, total_dev, cap_k):
+                dev_, NLP = t_full.device, self.plane_levels
+                Sc = cap_k + M
+                PSc = _lib.plane_pitch(Sc)
+                f32 = dict(dtype=torch.float32, device=dev_)
+                grid16, wpack = self._shadow()
+                spec.update(sdf=torch.empty([Sc], **f32), nablas=torch.empty([Sc, 3], **f32),
+                            rgb=torch.empty([Sc, 3], **f32) if with_rgb else None,
+                            h_pl=torch.empty([NLP, PSc, 2], **f32), J_pl=torch.empty([NLP, PSc, 2, 3], **f32), PS=PSc)
+                _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(o_a),
+                          _lib.ptr(d_a), _lib.ptr(t_full), _lib.ptr(ridx_full), None, _lib.ptr(ha_a), Sc,
+                          _lib.ptr(spec["sdf"]), _lib.ptr(spec["nablas"]), _lib.ptr(spec["rgb"]), _lib.ptr(spec["h_pl"]),
+                          _lib.ptr(spec["J_pl"]), _lib.ptr(total_dev), M)
+            cfg["_spec_launch"], cfg["_tail_points"] = spec_launch, M
+            self._with_tail = None
         o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis = self._query_samples(ray_tested, cfg, qp)
         if t.shape[0] == 0:
             ret["volume_buffer"] = dict(type="empty")
@@ -1159,15 +1216,16 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             if return_details:
                 ret["details"] = dict(march_counts=march_counts)
             return ret
-        h_appear = ray_tested.get("rays_h_appear", None)
-        extra_x = cfg.get("_extra_pts", None)              # trainer hook: free points riding on the same launches
+        pre = None
+        if spec is not None and getattr(self, "_spec_ok", False) and "sdf" in spec:
+            t_a, ridx_a = self._with_tail if spec["M"] else (t, ridx)
+            pre = dict(spec, t=t_a, ridx=ridx_a)
         # rays that carry gradients (pose refinement) stay attached for the with-grad query only; the sampling above
         # is no-grad by construction (t is a constant of the differentiable step, as in the reference)
-        o_g, d_g = ray_tested["rays_o"], ray_tested["rays_d"]
         o_in = o_g.float().contiguous() if o_g.requires_grad else o
         d_in = d_g.float().contiguous() if d_g.requires_grad else d
         outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
-                              h_appear if with_rgb else None, None, o_in, d_in, t, ridx, bool(with_rgb), goff, extra_x)
+                              h_appear if with_rgb else None, None, o_in, d_in, t, ridx, bool(with_rgb), goff, extra_x, pre)
         sdf, nablas = outs[0], outs[1]
         rgb = outs[2] if with_rgb else None
         if extra_x is not None:

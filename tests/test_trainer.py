@@ -93,15 +93,19 @@ def test_fused_step_equals_autograd_step(backend, variant):
         assert float(d.max()) <= 2 * 5 * 2e-3
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("mode", ["speculative", "outgrown", "no_notify"])
-def test_speculative_forward_equals_exact_size_forward(backend, mode):
+def test_speculative_forward_equals_exact_size_forward(backend, mode, fused, monkeypatch):
     """Compressed query mode: from the second iteration on the fused step queues the with-grad gather + decoders at a
     CAPACITY, before the host has read the size of the kept sample set (``_compress(spec_launch=)``, device-side point
     count, sizes through host-mapped words).  Same losses / parameters as the step that waits for the size first; a
     kept set that outgrows the capacity is redone at the exact size (``outgrown``: capacity forced to 32); without the
-    host-mapped words (``no_notify``) nothing is speculated."""
+    host-mapped words (``no_notify``) nothing is speculated.  ``fused`` False: the same through ``ray_query`` and the
+    autograd functions (``_FieldFn(pre=)``), the path a reference trainer drives."""
+    from neuralsim_amd.fields import neus as nmod
     outs = []
     for spec in (False, True):
+        monkeypatch.setattr(nmod, "_SPEC_FORWARD", spec)
         torch.manual_seed(0)
         m = _tiny(backend)
         m.ray_query_cfg["query_mode"] = "march_occ_multi_upsample_compressed"
@@ -110,10 +114,10 @@ def test_speculative_forward_equals_exact_size_forward(backend, mode):
         if spec and mode == "no_notify":
             m._notify = False
         intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
-        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=True,
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=fused,
                            num_uniform=24, perturb=True)
         tr.spec_forward = spec
-        assert tr._fused_ok()
+        assert tr._fused_ok() == fused
         losses, ok = [], []
         for it in range(5):
             losses.append(float(tr.train_step(it)))
