@@ -377,6 +377,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
             chunk = marks[i:i + 8]
             print(f"[trace] steps {i}-{i + len(chunk) - 1}: {(chunk[-1] - prev) / len(chunk) * 1e3:.3f} ms/step", file=sys.stderr)
             prev = chunk[-1]
+        if os.environ.get("NSIM_BENCH_TRACE") == "2":       # every step (host-side marks: each step blocks once)
+            d = [marks[0]] + [b - a for a, b in zip(marks, marks[1:])]
+            print("[trace] per step ms: " + " ".join(f"{x * 1e3:.2f}" for x in d), file=sys.stderr)
     if rank != 0:
         return None, it
     ksum = timer.summary() if timer is not None else {}
