@@ -15,6 +15,7 @@
 
 #define SMP_WAVES_PER_BLOCK 4
 #define SMP_BLOCK (64 * SMP_WAVES_PER_BLOCK)
+#define SMP_LDS_FLOATS 512   // per-wave LDS window of the up-sampling / merge kernels (longer rays: global memory)
 
 __device__ __forceinline__ int64_t smp_wave_id() {
   return (int64_t)blockIdx.x * SMP_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -288,6 +289,9 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
                                                                 const float* __restrict__ rays_o,
                                                                 const float* __restrict__ rays_d,
                                                                 float* __restrict__ x_new) {
+  // the running sums of a ray's interval weights live in LDS (<= SMP_LDS_FLOATS intervals; longer rays use the global
+  // scratch): the inverse-CDF search below is eight DEPENDENT reads per new sample -- 13 us per launch from L2
+  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
@@ -295,60 +299,66 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
   const int64_t ni = n - 1;  // intervals
   const float* tt = t + st;
   const float* ss = sdf + st;
-  float* cs = csum + st;
-  float carry_T = 1.0f, carry_S = 0.f;
-  for (int64_t base = 0; base < ni; base += 64) {
-    const int64_t i = base + lane;
-    const bool valid = i < ni;
-    const float a = valid ? upsample_alpha(tt, ss, i, inv_s, use_est) : 0.f;
-    const float f = valid ? (1.0f - a + 1e-7f) : 1.0f;
-    const float incl = wave_incl_prod(f);
-    float excl = wave_shfl(incl, lane - 1);
-    if (lane == 0) excl = 1.0f;
-    const float T = carry_T * excl;
-    carry_T = carry_T * wave_shfl(incl, 63);
-    const float w = valid ? (a * T + 1e-5f) : 0.f;
-    const float ws = wave_incl_sum(w);
-    if (valid) cs[i] = carry_S + ws;
-    carry_S = carry_S + wave_shfl(ws, 63);
+  float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
+  if (x_new) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ro[c] = rays_o[3 * r + c];
+      rd[c] = rays_d[3 * r + c];
+    }
   }
+  auto body = [&](auto cs) {
+    float carry_T = 1.0f, carry_S = 0.f;
+    for (int64_t base = 0; base < ni; base += 64) {
+      const int64_t i = base + lane;
+      const bool valid = i < ni;
+      const float a = valid ? upsample_alpha(tt, ss, i, inv_s, use_est) : 0.f;
+      const float f = valid ? (1.0f - a + 1e-7f) : 1.0f;
+      const float incl = wave_incl_prod(f);
+      float excl = wave_shfl(incl, lane - 1);
+      if (lane == 0) excl = 1.0f;
+      const float T = carry_T * excl;
+      carry_T = carry_T * wave_shfl(incl, 63);
+      const float w = valid ? (a * T + 1e-5f) : 0.f;
+      const float ws = wave_incl_sum(w);
+      if (valid) cs[i] = carry_S + ws;
+      carry_S = carry_S + wave_shfl(ws, 63);
+    }
 #ifndef NSIM_HOST_EMU
-  __threadfence_block();
+    __threadfence_block();
 #endif
-  const float wsum = carry_S;
-  for (int kb = 0; kb < n_fine; kb += 64) {
-    const int k = kb + lane;
-    if (k < n_fine && ni > 0) {
-      const float u = ((float)k + 0.5f) / (float)n_fine;
-      // first interval i with cdf[i+1] = cs[i]/wsum > u, clamped to the last interval
-      int64_t lo = 0, hi = ni;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (cs[mid] / wsum <= u) lo = mid + 1; else hi = mid;
+    const float wsum = carry_S;
+    for (int kb = 0; kb < n_fine; kb += 64) {
+      const int k = kb + lane;
+      if (k >= n_fine) continue;
+      float tn = (n > 0) ? tt[0] : 0.f;
+      if (ni > 0) {
+        const float u = ((float)k + 0.5f) / (float)n_fine;
+        // first interval i with cdf[i+1] = cs[i]/wsum > u, clamped to the last interval
+        int64_t lo = 0, hi = ni;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (cs[mid] / wsum <= u) lo = mid + 1; else hi = mid;
+        }
+        if (lo > ni - 1) lo = ni - 1;
+        const float c_lo = (lo == 0) ? 0.f : cs[lo - 1] / wsum;
+        const float c_hi = cs[lo] / wsum;
+        float den = c_hi - c_lo;
+        if (den < 1e-5f) den = 1.0f;
+        float frac = (u - c_lo) / den;
+        frac = fminf(fmaxf(frac, 0.f), 1.f);
+        const float b_lo = tt[lo], b_hi = tt[lo + 1];
+        tn = b_lo + frac * (b_hi - b_lo);
       }
-      if (lo > ni - 1) lo = ni - 1;
-      const float c_lo = (lo == 0) ? 0.f : cs[lo - 1] / wsum;
-      const float c_hi = cs[lo] / wsum;
-      float den = c_hi - c_lo;
-      if (den < 1e-5f) den = 1.0f;
-      float frac = (u - c_lo) / den;
-      frac = fminf(fmaxf(frac, 0.f), 1.f);
-      const float b_lo = tt[lo], b_hi = tt[lo + 1];
-      const float tn = b_lo + frac * (b_hi - b_lo);
       t_new[r * n_fine + k] = tn;
       if (x_new) {   // the sample's position, so that the level-major query loads 12 B instead of re-deriving it per XCD
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = rays_o[3 * r + c] + tn * rays_d[3 * r + c];
-      }
-    } else if (k < n_fine) {
-      const float tn = (n > 0) ? tt[0] : 0.f;
-      t_new[r * n_fine + k] = tn;
-      if (x_new) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = rays_o[3 * r + c] + tn * rays_d[3 * r + c];
+        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = ro[c] + tn * rd[c];
       }
     }
-  }
+  };
+  if (ni <= SMP_LDS_FLOATS) body(&smp_lds[threadIdx.x >> 6][0]);
+  else body(csum + st);
 }
 
 // -------------------------------------------------------------------------------- sorted merge
@@ -379,6 +389,7 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
                                                               const float* __restrict__ rays_o,
                                                               const float* __restrict__ rays_d,
                                                               float* __restrict__ x_out) {
+  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
   const int64_t r = smp_wave_id();
   if (r >= R) return;
   const int lane = nsim_lane();
@@ -392,34 +403,49 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
     }
   }
   const int64_t so = sa + r * (int64_t)nb;
-  const float* a = t_a + sa;
-  const float* b = t_b + r * (int64_t)nb;
   if (lane == 0) {
     pio[2 * r] = so;
     pio[2 * r + 1] = na + nb;
   }
-  for (int64_t i = lane; i < na; i += 64) {  // a first on ties: b elements strictly smaller precede
-    const float v = a[i];
-    const int64_t pos = i + smp_lower_bound(b, nb, v);
-    t_out[so + pos] = v;
-    if (v_out) v_out[so + pos] = v_a ? v_a[sa + i] : 0.f;
-    if (ridx_out) ridx_out[so + pos] = r;
-    if (x_out) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
-    }
+  // both depth lists of the ray in LDS when they fit (a first, then b): the rank searches are 6-8 DEPENDENT reads each
+  const bool in_lds = na + nb <= SMP_LDS_FLOATS;
+  float* la = &smp_lds[threadIdx.x >> 6][0];
+  float* lb = la + na;
+  if (in_lds) {
+    for (int64_t i = lane; i < na; i += 64) la[i] = t_a[sa + i];
+    for (int64_t j = lane; j < nb; j += 64) lb[j] = t_b[r * (int64_t)nb + j];
+#ifndef NSIM_HOST_EMU
+    __threadfence_block();
+#else
+    emu::wave_barrier();
+#endif
   }
-  for (int64_t j = lane; j < nb; j += 64) {
-    const float v = b[j];
-    const int64_t pos = j + smp_upper_bound(a, na, v);
-    t_out[so + pos] = v;
-    if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
-    if (ridx_out) ridx_out[so + pos] = r;
-    if (x_out) {
+  auto body = [&](auto a, auto b) {
+    for (int64_t i = lane; i < na; i += 64) {  // a first on ties: b elements strictly smaller precede
+      const float v = a[i];
+      const int64_t pos = i + smp_lower_bound(b, nb, v);
+      t_out[so + pos] = v;
+      if (v_out) v_out[so + pos] = v_a ? v_a[sa + i] : 0.f;
+      if (ridx_out) ridx_out[so + pos] = r;
+      if (x_out) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
+        for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
+      }
     }
-  }
+    for (int64_t j = lane; j < nb; j += 64) {
+      const float v = b[j];
+      const int64_t pos = j + smp_upper_bound(a, na, v);
+      t_out[so + pos] = v;
+      if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
+      if (ridx_out) ridx_out[so + pos] = r;
+      if (x_out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x_out[(so + pos) * 3 + c] = ro[c] + v * rd[c];
+      }
+    }
+  };
+  if (in_lds) body((const float*)la, (const float*)lb);
+  else body(t_a + sa, t_b + r * (int64_t)nb);
 }
 
 // ------------------------------------------------------------------ compressed query mode

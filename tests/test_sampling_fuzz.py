@@ -2,7 +2,7 @@
 keep-set of the compressed query mode on random ragged packs -- single-sample rays, packs shorter / longer than a wave
 (64), exact depth ties -- against the oracle.  Index / membership results must be bit-exact."""
 import torch
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, example, given, settings, strategies as st
 
 from oracle import pack_ops as opo, render as orr
 from neuralsim_amd import _lib
@@ -14,7 +14,8 @@ import os  # noqa: E402
 _N = int(os.environ.get("NSIM_FUZZ_EXAMPLES", "0"))
 SET = dict(max_examples=_N or 20, derandomize=_N == 0, deadline=None,
            suppress_health_check=[HealthCheck.function_scoped_fixture])
-counts = st.lists(st.sampled_from([1, 2, 3, 5, 17, 63, 64, 65, 129, 200]), min_size=1, max_size=14)
+# 448 + 64 = 512 is the per-wave LDS window of the merge / up-sampling kernels; 449, 513, 700: their global-memory path
+counts = st.lists(st.sampled_from([1, 2, 3, 5, 17, 63, 64, 65, 129, 200, 448, 449, 513, 700]), min_size=1, max_size=14)
 
 
 def _packs(n, g):
@@ -30,6 +31,8 @@ def _packs(n, g):
 
 @settings(**SET)
 @given(n=counts, nf=st.sampled_from([1, 4, 8, 32, 70]), seed=st.integers(0, 10 ** 6))
+@example(n=[448, 449, 3, 700, 64], nf=64, seed=7)        # both sides of the LDS window (na + nb <= 512)
+@example(n=[480, 481, 513, 1], nf=32, seed=8)
 def test_fuzz_merge_sorted(backend, n, nf, seed):
     g = torch.Generator().manual_seed(seed)
     n, pi, S, ridx, t, near = _packs(n, g)
@@ -60,6 +63,8 @@ def test_fuzz_merge_sorted(backend, n, nf, seed):
 @given(n=st.lists(st.sampled_from([2, 3, 5, 17, 63, 64, 65, 129, 200]), min_size=1, max_size=14),
        nf=st.sampled_from([1, 8, 32, 70]), inv_s=st.sampled_from([16.0, 64.0, 1024.0]), use_est=st.booleans(),
        seed=st.integers(0, 10 ** 6))
+@example(n=[512, 513, 514, 5, 700], nf=32, inv_s=64.0, use_est=True, seed=9)     # 512 intervals = the LDS window
+@example(n=[513, 514, 2, 900], nf=70, inv_s=16.0, use_est=False, seed=10)
 def test_fuzz_upsample_stage(backend, n, nf, inv_s, use_est, seed):
     g = torch.Generator().manual_seed(seed)
     n, pi, S, ridx, t, near = _packs(n, g)
