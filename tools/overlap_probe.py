@@ -78,6 +78,14 @@ def main():
         if a in calls and b in calls:
             out[f"{a[5:]}+{b[5:]} serial"] = round(timed(pair(a, b, False)), 4)
             out[f"{a[5:]}+{b[5:]} two streams"] = round(timed(pair(a, b, True)), 4)
+    # the scatter level by level (its last two arguments are level_begin, level_count)
+    sa = list(calls["nsim_lotd_scatter"])
+    per = {}
+    for l in range(16):
+        sa[-2], sa[-1] = l, 1
+        args = tuple(sa)
+        per[l] = round(timed(lambda: real("nsim_lotd_scatter", *args), 10), 4)
+    out["scatter_per_level_ms"] = per
     print(json.dumps(out, indent=1))
 
 
