@@ -83,13 +83,16 @@ def build_trainer(device, rank, world, seed=42, distant=False, sky=False, sdf_D=
                          target_sphere_radius=None if os.environ.get("NSIM_BENCH_RANDOM_TARGETS") == "1" else SPHERE_RADIUS)
 
 
-def oracle_of(tr):
+def oracle_of(tr, table="master"):
     """oracle.field.FieldParams + occupancy grid carrying exactly the trainer's current weights (test infrastructure:
-    only this file's cpu_baseline / parity legs and tests/ use it)."""
+    only this file's cpu_baseline / parity legs and tests/ use it).  ``table``: "master" = the optimizer's f32 copy of
+    the LoTD table; "stored" = the values of the fp16 table the render kernels read -- the reference's parameter dtype
+    (``params fp16``), i.e. THE weights of a render; the f32 master is optimizer state of this repo."""
     from oracle import field as ofield
     m = tr.model
     cfg = m.encoding.cfg
-    p = ofield.params_from_flat(cfg.lod_res, int(math.log2(cfg.hashmap_size)), m.encoding.flattened_params, m.sdf_w, m.sdf_b,
+    grid = m.encoding.flattened_params if table == "master" else m._shadow()[0].detach().float()
+    p = ofield.params_from_flat(cfg.lod_res, int(math.log2(cfg.hashmap_size)), grid, m.sdf_w, m.sdf_b,
                                 m.rad_w, m.rad_b, m.ln_inv_s, sdf_D=m.sdf_D, ln_inv_s_factor=m.ln_inv_s_factor)
     occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
     return p, occ
@@ -168,17 +171,20 @@ def cpu_baseline(tr, budget_s=20.0, max_iters=3):
 # tests/test_fullsize_parity.py holds the same comparison (plus f32 mode, samples and gradients) under pytest.
 PARITY_RAYS = 2048
 # Gates: PSNR and the 99th percentile of the per-ray colour error -- measured over repeated runs (the trained state differs
-# from run to run: float atomics): 80-88 dB, p99 2e-4, p99.9 1.0-1.4e-3.  The MAXIMUM is one ray of 2048 and heavy-tailed:
-# on rays grazing the surface (mask 0.05-0.3) the fp16 decoders' 2.4e-4 SDF error is multiplied by inv_s ~ 400 inside the
-# sigmoid and flips keep / drop decisions of the compressed query (tools/parity_probe.py: 1e-3 ... 1.4e-2 between runs, the
-# worst rays all grazing) -- it is reported and only guarded against gross failure (a broken kernel moves PSNR and p99).
+# from run to run: float atomics): 73-88 dB, p99 2e-4 - 4e-4, p99.9 1.0e-3 - 2.9e-3.  The MAXIMUM is one ray of 2048 and
+# heavy-tailed (1e-3 ... 1.7e-2 between runs / training lengths).  tools/parity_probe.py on the worst ray of such a run: on
+# the ORACLE's own samples the fp16 field agrees to 4e-5 (sdf) / 7e-4 (nablas) / 2e-4 (rgb); the pixel differs because the
+# fp16 SDFs of the sampling pass (2.4e-4 off, times inv_s ~ 400 inside the sigmoid) move up-sampling and keep / drop
+# decisions, the two pipelines integrate over different sample sets (91 vs 96 samples there), and on a ray whose
+# integrand is rough (grazing, or |nablas| 0.9 - 1.18 along it) the two quadratures differ.  It is reported and only
+# guarded against gross failure (a broken kernel moves PSNR and p99).
 PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=0.25)
 
 
 def parity_check(tr):
     from oracle import render as orr
     m = tr.model
-    p, occ = oracle_of(tr)
+    p, occ = oracle_of(tr, table="stored")
     aabb = m.accel.aabb.detach().cpu()
     intr, c2w, WH = tr.intr.cpu(), tr.c2w.cpu(), tr.WH.cpu()
     g = torch.Generator().manual_seed(11)
