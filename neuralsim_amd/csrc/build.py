@@ -11,13 +11,13 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
-HEADERS = ["nsim_common.h", "lotd_dev.h", "mfma_mlp.h", "occ_dev.h", "../../include/nsim.h"]
+HEADERS = ["nsim_common.h", "nsim_prims.h", "lotd_dev.h", "mfma_mlp.h", "occ_dev.h", "../../include/nsim.h"]
 LIB = HERE / "libnsim_hip.so"
 BUILD = HERE / "_build"
 
 # -ffp-contract=off: sample-membership arithmetic must round exactly like the oracle (mul then add);
 # the hot arithmetic lives on the MFMA pipe, not in contracted VALU FMAs.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{HERE}",
                "-munsafe-fp-atomics", "-Wno-unused-result"] + os.environ.get("NSIM_EXTRA_HIPCC_FLAGS", "").split()
 
 

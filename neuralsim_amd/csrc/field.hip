@@ -961,10 +961,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     const bool valid = s < a.S;
     // the per-lane bias / head vectors are re-read from LDS where they are used: an address the compiler cannot prove
     // loop-invariant keeps it from hoisting 96 of them into registers for the whole launch
-    int vo = 0;
-#ifndef NSIM_HOST_EMU
-    asm volatile("" : "+v"(vo));
-#endif
+    const int vo = nsim_opaque_zero();
     const char* Wv = W + vo;
     float gs = 0.f, gn[3] = {0.f, 0.f, 0.f};
     if (valid) {

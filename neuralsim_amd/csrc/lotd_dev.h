@@ -112,25 +112,7 @@ __device__ __forceinline__ void lotd_load2(const f16* grid, int64_t off, uint32_
   f1 = (float)cv.h[1];
 }
 
-// The whole table behind ONE buffer resource (4 SGPRs) + a 32-bit per-lane byte offset: half the address registers
-// and no 64-bit address arithmetic per corner compared with flat loads (the table is 24.4 MB, far below 4 GiB).
-struct GridRef {
-#ifdef NSIM_HOST_EMU
-  const f16* p;
-#else
-  __amdgpu_buffer_rsrc_t r;
-#endif
-};
-
-__device__ __forceinline__ GridRef grid_ref(const f16* grid) {
-  GridRef g;
-#ifdef NSIM_HOST_EMU
-  g.p = grid;
-#else
-  g.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(grid), 0, 0xffffffff, 0x00020000);
-#endif
-  return g;
-}
+// (GridRef / grid_ref / grid_load_u32: the table behind one buffer resource, nsim_prims.h)
 
 // elem_off = level offset + 2 * vertex index (in fp16 elements)
 __device__ __forceinline__ void lotd_load2(const GridRef& g, uint32_t elem_off, float& f0, float& f1) {
@@ -138,11 +120,7 @@ __device__ __forceinline__ void lotd_load2(const GridRef& g, uint32_t elem_off, 
     uint32_t u;
     f16 h[2];
   } cv;
-#ifdef NSIM_HOST_EMU
-  cv.u = *reinterpret_cast<const uint32_t*>(g.p + elem_off);
-#else
-  cv.u = __builtin_amdgcn_raw_buffer_load_b32(g.r, (int)(elem_off * 2u), 0, 0);
-#endif
+  cv.u = grid_load_u32(g, elem_off);
   f0 = (float)cv.h[0];
   f1 = (float)cv.h[1];
 }

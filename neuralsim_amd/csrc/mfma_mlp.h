@@ -11,15 +11,7 @@
 __device__ __forceinline__ int unit_of(int m, int r, int hi) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ------------------------------------------------------------------------------------- MFMA helpers
-__device__ __forceinline__ void wave_sync_lds() {
-#ifdef NSIM_HOST_EMU
-  emu::wave_barrier();
-#else
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
+// (wave_sync_lds: nsim_prims.h)
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -313,18 +305,7 @@ __device__ __forceinline__ float jrow_sum(const void* stA, int rows, int wave) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + lane * P + 32 * wave + 8 * q);
-#ifdef NSIM_HOST_EMU
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)v[e];
-#else
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const bf16x2 one = {(bf16)1.0f, (bf16)1.0f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x2 pr = {v[2 * e], v[2 * e + 1]};
-          s = __builtin_amdgcn_fdot2_f32_bf16(pr, one, s, false);
-        }
-#endif
+        s = nsim_bf16x8_sum(v, s);
       }
     } else {
       for (int q = 0; q < 32; ++q) s += a[lane * P + 32 * wave + q];

@@ -324,9 +324,7 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
       if (valid) cs[i] = carry_S + ws;
       carry_S = carry_S + wave_shfl(ws, 63);
     }
-#ifndef NSIM_HOST_EMU
-    __threadfence_block();
-#endif
+    nsim_wave_fence();
     const float wsum = carry_S;
     for (int kb = 0; kb < n_fine; kb += 64) {
       const int k = kb + lane;
@@ -414,11 +412,7 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
   if (in_lds) {
     for (int64_t i = lane; i < na; i += 64) la[i] = t_a[sa + i];
     for (int64_t j = lane; j < nb; j += 64) lb[j] = t_b[r * (int64_t)nb + j];
-#ifndef NSIM_HOST_EMU
-    __threadfence_block();
-#else
-    emu::wave_barrier();
-#endif
+    nsim_wave_fence();
   }
   auto body = [&](auto a, auto b) {
     for (int64_t i = lane; i < na; i += 64) {  // a first on ties: b elements strictly smaller precede

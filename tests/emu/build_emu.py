@@ -10,14 +10,15 @@ CSRC = HERE.parent.parent / "neuralsim_amd" / "csrc"
 SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
 LIB = HERE / "_build" / "libnsim_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DNSIM_HOST_EMU", "-ffp-contract=off", f"-I{HERE}", f"-I{CSRC}",
+# -I tests/emu comes FIRST: its nsim_prims.h (the emulator's primitives) shadows the gfx950 one of the product tree
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", f"-I{HERE}", f"-I{CSRC}",
          "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
 
 
 def build(force=False):
     LIB.parent.mkdir(exist_ok=True)
     h = hashlib.sha256()
-    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", CSRC / "occ_dev.h", HERE / "hip_emu.h",
+    for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", CSRC / "occ_dev.h", HERE / "hip_emu.h", HERE / "nsim_prims.h",
                                             HERE / "hip_emu.cpp", CSRC.parent.parent / "include" / "nsim.h"]:
         h.update(f.read_bytes())
     stamp = LIB.parent / "stamp"

@@ -1,7 +1,7 @@
 // hip_emu.h -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
 //
 // A tiny SIMT emulator that lets the *same* kernel sources under
-// neuralsim_amd/csrc/ be compiled for the host (clang++ -DNSIM_HOST_EMU) so that
+// neuralsim_amd/csrc/ be compiled for the host (clang++ -I tests/emu first: nsim_prims.h of this directory) so that
 // kernel logic (indexing, wave-level scans, MFMA fragment bookkeeping, packed
 // segment handling) can be checked against the oracle in the CPU-only authoring
 // container.  Every GPU thread is a fiber; a 64-lane wavefront executes in
