@@ -145,6 +145,18 @@ int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr 
 int nsim_raygen_pinhole_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* c2w,
                             const int64_t* WH, int64_t N, int snap, const float* d_rays_o, const float* d_rays_d,
                             float* d_c2w, void* stream);
+/* The same two with the OpenCV camera model (``camera_model: opencv`` -> ``OpenCVCameraMatHW.lift``,
+ * app/resources/observers/cameras.py:84-87; the street configs' ``consider_distortion: true``,
+ * withmask_withlidar_joint.240219.yaml:141, Waymo calibration (k1, k2, p1, p2, k3),
+ * dataio/autonomous_driving/waymo/preprocess.py:172): distortion [V,5]; the undistorted direction comes from n_iters
+ * rounds of the fixed-point iteration of cv::undistortPoints (5 there).  Implementation in the absent nr3d_lib:
+ * semantics fixed here. */
+int nsim_raygen_opencv(const float* xy, const int64_t* fidx, const float* intr, const float* distortion /*[V,5]*/,
+                       int n_iters, const float* c2w, const int64_t* WH, int64_t N, int snap, float* rays_o,
+                       float* rays_d, void* stream);
+int nsim_raygen_opencv_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                           const float* c2w, const int64_t* WH, int64_t N, int snap, const float* d_rays_o,
+                           const float* d_rays_d, float* d_c2w, void* stream);
 /* AABBSpace.ray_test (call site single_volume_renderer.py:235-238): far < 0 means "no far". */
 int nsim_aabb_ray_test(const float* rays_o, const float* rays_d, int64_t N, const NsimOccMeta* meta,
                        float near, float far, float* near_out, float* far_out, uint8_t* hit, void* stream);

@@ -23,12 +23,38 @@ __device__ __forceinline__ int64_t smp_wave_id() {
 static inline dim3 smp_grid(int64_t R) { return dim3(nsim_blocks(R, SMP_WAVES_PER_BLOCK)); }
 
 // ----------------------------------------------------------------------------------- ray generation
+// ``intr.lift(u, v, 1)``: pixel -> direction in the camera frame.  Pinhole: ((u - cx) / fx, (v - cy) / fy, 1).  OpenCV
+// model (camera_model 'opencv', app/resources/observers/cameras.py:84-87; Waymo's calibration, ``consider_distortion:
+// true`` in the street configs): the pinhole coordinates are the DISTORTED ones, x_d = x (1 + k1 r2 + k2 r4 + k3 r6) +
+// 2 p1 x y + p2 (r2 + 2 x2) (y alike), dist = (k1, k2, p1, p2, k3); the undistorted (x, y) come from the fixed-point
+// iteration of cv::undistortPoints, n_iters rounds (OpenCV runs 5).  nr3d_lib's OpenCVCameraMatHW is absent: the
+// iteration and its count are fixed here.  Written mul-then-add (no contraction) so that the oracle reproduces it.
+__device__ __forceinline__ void raygen_lift(const float* K, const float* dist, int n_iters, float w, float h, float l[3]) {
+  const float x0 = (w - K[2]) / K[0], y0 = (h - K[5]) / K[4];
+  float x = x0, y = y0;
+  if (dist) {
+    const float k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+    for (int it = 0; it < n_iters; ++it) {
+      const float r2 = x * x + y * y;
+      const float icd = 1.0f / (1.0f + ((k3 * r2 + k2) * r2 + k1) * r2);
+      const float dx = 2.0f * p1 * x * y + p2 * (r2 + 2.0f * x * x);
+      const float dy = p1 * (r2 + 2.0f * y * y) + 2.0f * p2 * x * y;
+      x = (x0 - dx) * icd;
+      y = (y0 - dy) * icd;
+    }
+  }
+  l[0] = x;
+  l[1] = y;
+  l[2] = 1.0f;
+}
+
 __global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict__ xy,
                                                          const int64_t* __restrict__ fidx,
                                                          const float* __restrict__ intr,
                                                          const float* __restrict__ c2w,
                                                          const int64_t* __restrict__ WH, int64_t N, int snap,
-                                                         float* __restrict__ rays_o, float* __restrict__ rays_d) {
+                                                         float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                         const float* __restrict__ dist, int n_iters) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int64_t f = fidx[i];
@@ -41,9 +67,9 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict_
     w = wi + 0.5f;
     h = hi + 0.5f;
   }
-  const float* K = intr + f * 9;
-  const float dx = (w - K[2]) / K[0];
-  const float dy = (h - K[5]) / K[4];
+  float l[3];
+  raygen_lift(intr + f * 9, dist ? dist + f * 5 : nullptr, n_iters, w, h, l);
+  const float dx = l[0], dy = l[1];
   const float* M = c2w + f * 16;
   // broadcast-multiply-sum, never a reduced-precision matmul (cameras.py:355-359)
   float d0 = M[0] * dx + M[1] * dy + M[2] * 1.0f;
@@ -69,7 +95,8 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole_bwd(const float* __restr
                                                              const int64_t* __restrict__ WH, int64_t N, int snap,
                                                              const float* __restrict__ d_o,
                                                              const float* __restrict__ d_d,
-                                                             float* __restrict__ d_c2w) {
+                                                             float* __restrict__ d_c2w,
+                                                             const float* __restrict__ dist, int n_iters) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int64_t f = fidx[i];
@@ -82,8 +109,8 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole_bwd(const float* __restr
     w = wi + 0.5f;
     h = hi + 0.5f;
   }
-  const float* K = intr + f * 9;
-  const float l[3] = {(w - K[2]) / K[0], (h - K[5]) / K[4], 1.0f};
+  float l[3];
+  raygen_lift(intr + f * 9, dist ? dist + f * 5 : nullptr, n_iters, w, h, l);
   const float* M = c2w + f * 16;
   float dw[3];
 #pragma unroll
@@ -512,7 +539,18 @@ int nsim_raygen_pinhole(const float* xy, const int64_t* fidx, const float* intr,
                         const int64_t* WH, int64_t N, int snap, float* rays_o, float* rays_d, void* stream) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
-                     WH, N, snap, rays_o, rays_d);
+                     WH, N, snap, rays_o, rays_d, (const float*)nullptr, 0);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_raygen_opencv(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                       const float* c2w, const int64_t* WH, int64_t N, int snap, float* rays_o, float* rays_d,
+                       void* stream) {
+  if (N <= 0) return 0;
+  if (!distortion || n_iters < 0 || n_iters > 64) return 4;
+  hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
+                     WH, N, snap, rays_o, rays_d, distortion, n_iters);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -523,7 +561,18 @@ int nsim_raygen_pinhole_bwd(const float* xy, const int64_t* fidx, const float* i
   if (N <= 0) return 0;
   if (!d_c2w) return 4;
   hipLaunchKernelGGL(k_raygen_pinhole_bwd, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr,
-                     c2w, WH, N, snap, d_rays_o, d_rays_d, d_c2w);
+                     c2w, WH, N, snap, d_rays_o, d_rays_d, d_c2w, (const float*)nullptr, 0);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_raygen_opencv_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                           const float* c2w, const int64_t* WH, int64_t N, int snap, const float* d_rays_o,
+                           const float* d_rays_d, float* d_c2w, void* stream) {
+  if (N <= 0) return 0;
+  if (!d_c2w || !distortion || n_iters < 0 || n_iters > 64) return 4;
+  hipLaunchKernelGGL(k_raygen_pinhole_bwd, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr,
+                     c2w, WH, N, snap, d_rays_o, d_rays_d, d_c2w, distortion, n_iters);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

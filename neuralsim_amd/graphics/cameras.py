@@ -1,5 +1,6 @@
-"""Pinhole ray generation -- mirrors ``Camera.get_selected_rays`` / ``_get_selected_rays_from_ixy``
-(app/resources/observers/cameras.py:281-330) on top of csrc/sampling.hip::k_raygen_pinhole."""
+"""Ray generation -- mirrors ``Camera.get_selected_rays`` / ``_get_selected_rays_from_ixy``
+(app/resources/observers/cameras.py:281-330) on top of csrc/sampling.hip::k_raygen_pinhole, for the pinhole and the
+OpenCV (radial-tangential distortion) camera models (``camera_model: pinhole | opencv``, cameras.py:80-87)."""
 import torch
 
 from .. import _lib
@@ -10,26 +11,34 @@ class _RaygenFn(torch.autograd.Function):
     refined c2w matrices to ``Camera.get_selected_rays``; pixels and intrinsics are constants)."""
 
     @staticmethod
-    def forward(ctx, c2w, xy, fidx, intr, WH, snap):
+    def forward(ctx, c2w, xy, fidx, intr, WH, snap, dist=None, n_iters=0):
         N = xy.shape[0]
         o = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
         d = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
         c2w = c2w.float().contiguous()
-        _lib.call("nsim_raygen_pinhole", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH), N,
-                  snap, _lib.ptr(o), _lib.ptr(d))
-        ctx.save_for_backward(c2w, xy, fidx, intr, WH)
-        ctx.snap = snap
+        if dist is None:
+            _lib.call("nsim_raygen_pinhole", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH), N,
+                      snap, _lib.ptr(o), _lib.ptr(d))
+        else:
+            _lib.call("nsim_raygen_opencv", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist), int(n_iters),
+                      _lib.ptr(c2w), _lib.ptr(WH), N, snap, _lib.ptr(o), _lib.ptr(d))
+        ctx.save_for_backward(c2w, xy, fidx, intr, WH, dist)
+        ctx.snap, ctx.n_iters = snap, int(n_iters)
         return o, d
 
     @staticmethod
     def backward(ctx, g_o, g_d):
-        c2w, xy, fidx, intr, WH = ctx.saved_tensors
+        c2w, xy, fidx, intr, WH, dist = ctx.saved_tensors
         d_c2w = torch.zeros_like(c2w)
         g_o = g_o.float().contiguous() if g_o is not None else None
         g_d = g_d.float().contiguous() if g_d is not None else None
-        _lib.call("nsim_raygen_pinhole_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH),
-                  xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
-        return d_c2w, None, None, None, None, None
+        if dist is None:
+            _lib.call("nsim_raygen_pinhole_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH),
+                      xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
+        else:
+            _lib.call("nsim_raygen_opencv_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist), ctx.n_iters,
+                      _lib.ptr(c2w), _lib.ptr(WH), xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
+        return d_c2w, None, None, None, None, None, None, None
 
 
 def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
@@ -39,6 +48,19 @@ def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tens
     return _RaygenFn.apply(c2w, xy.detach().float().contiguous(), fidx.long().contiguous(),
                            intr.detach().float().contiguous(), WH.long().contiguous(),
                            1 if snap_to_pixel_centers else 0)
+
+
+def opencv_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, distortion: torch.Tensor,
+                         c2w: torch.Tensor, WH: torch.Tensor, snap_to_pixel_centers: bool = True, n_iters: int = 5):
+    """``pinhole_selected_rays`` for ``camera_model: opencv`` (cameras.py:84-87; Waymo's calibration in the street
+    configs): distortion [V,5] = (k1, k2, p1, p2, k3); the lift undistorts with ``n_iters`` rounds of the fixed-point
+    iteration of cv::undistortPoints (5 = OpenCV's own count).  Differentiable w.r.t. ``c2w``."""
+    dist = distortion.detach().float().contiguous()
+    if dist.dim() != 2 or dist.shape[1] != 5 or dist.shape[0] != intr.shape[0]:
+        raise ValueError(f"distortion must be [V,5] = (k1, k2, p1, p2, k3) per frame, got {tuple(dist.shape)}")
+    return _RaygenFn.apply(c2w, xy.detach().float().contiguous(), fidx.long().contiguous(),
+                           intr.detach().float().contiguous(), WH.long().contiguous(),
+                           1 if snap_to_pixel_centers else 0, dist, int(n_iters))
 
 
 def look_at_cameras(V=100, radius=3.0, H=800, W=800, f=1111.1, seed=42, device=None):

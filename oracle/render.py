@@ -31,10 +31,35 @@ from .field import FieldParams, forward_sdf, forward_field, forward_sdf_nablas
 
 
 # ------------------------------------------------------------------------------------- ray gen
+def opencv_distort(x, y, dist):
+    """The OpenCV radial-tangential model (k1, k2, p1, p2, k3) on normalised camera coordinates: undistorted -> distorted
+    (the calibration Waymo ships, dataio/autonomous_driving/waymo/preprocess.py:172)."""
+    k1, k2, p1, p2, k3 = dist.unbind(-1)
+    r2 = x * x + y * y
+    rad = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2
+    return (x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x),
+            y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y)
+
+
+def opencv_undistort(x0, y0, dist, n_iters: int = 5):
+    """distorted -> undistorted normalised coordinates by the fixed-point iteration of cv::undistortPoints (n_iters rounds,
+    5 in OpenCV) -- the ``lift`` of ``camera_model: opencv`` (cameras.py:84-87).  nr3d_lib's OpenCVCameraMatHW is absent:
+    parity unpinned, semantics fixed here; same operation order as the kernel (csrc/sampling.hip raygen_lift)."""
+    k1, k2, p1, p2, k3 = dist.unbind(-1)
+    x, y = x0, y0
+    for _ in range(n_iters):
+        r2 = x * x + y * y
+        icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+        dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+        x, y = (x0 - dx) * icd, (y0 - dy) * icd
+    return x, y
+
+
 def pinhole_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
-                 WH: torch.Tensor, snap_to_pixel_centers: bool = True):
+                 WH: torch.Tensor, snap_to_pixel_centers: bool = True, distortion: torch.Tensor = None, n_iters: int = 5):
     """xy [N,2] in [0,1], fidx [N] frame index, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] (W,H)
-    -> rays_o, rays_d [N,3].  cameras.py:281-310."""
+    -> rays_o, rays_d [N,3].  cameras.py:281-310.  distortion [V,5]: the OpenCV camera model (``opencv_undistort``)."""
     wh_i = WH[fidx]
     if snap_to_pixel_centers:
         wh = (xy * wh_i).long().clamp(torch.zeros_like(wh_i), wh_i - 1).to(xy.dtype) + 0.5
@@ -44,6 +69,8 @@ def pinhole_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: 
     fx, fy, cx, cy = K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]
     dx = (wh[:, 0] - cx) / fx
     dy = (wh[:, 1] - cy) / fy
+    if distortion is not None:
+        dx, dy = opencv_undistort(dx, dy, distortion[fidx], n_iters)
     dirs = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
     R = c2w[fidx, :3, :3]
     rays_d = (R * dirs.unsqueeze(-2)).sum(-1)

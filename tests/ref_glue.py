@@ -397,6 +397,24 @@ class FakePinhole:
         return torch.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], dim=-1)
 
 
+class FakeOpenCV(FakePinhole):
+    """Stand-in for nr3d_lib's OpenCVCameraMatHW (``camera_model: opencv``, cameras.py:84-87): the pinhole lift of the
+    UNDISTORTED coordinates; the undistortion is the oracle's restatement (cv::undistortPoints iteration)."""
+    def __init__(self, mat, WH, distortion, n_iters=5):
+        super().__init__(mat, WH)
+        self.distortion, self.n_iters = distortion, n_iters
+
+    def __getitem__(self, i):
+        return FakeOpenCV(self.mat[i], self._wh[i], self.distortion[i], self.n_iters)
+
+    def lift(self, u, v, d):
+        from oracle import render as orr
+        m = self.mat
+        fx, fy, cx, cy = m[..., 0, 0], m[..., 1, 1], m[..., 0, 2], m[..., 1, 2]
+        x, y = orr.opencv_undistort((u - cx) / fx, (v - cy) / fy, self.distortion, self.n_iters)
+        return torch.stack([x * d, y * d, d], dim=-1)
+
+
 class FakePose:
     """Stand-in for nr3d_lib's TransformMat4x4: ``rotate`` is broadcast-multiply-sum (cameras.py:355-359 forbids mm)."""
     def __init__(self, mat):
@@ -416,8 +434,9 @@ class FakePose:
 
 
 class FakeCamera:
-    def __init__(self, intr, c2w, WH, i_prefix=()):
-        self.intr, self.world_transform = FakePinhole(intr, WH), FakePose(c2w)
+    def __init__(self, intr, c2w, WH, i_prefix=(), distortion=None):
+        self.intr = FakePinhole(intr, WH) if distortion is None else FakeOpenCV(intr, WH, distortion)
+        self.world_transform = FakePose(c2w)
         self.i_prefix, self.device, self.dtype = tuple(i_prefix), intr.device, intr.dtype
 
 

@@ -152,6 +152,14 @@ def test_reference_camera_rays_pin_the_oracle_and_the_kernel(backend):
                 dv = lambda t: t.to(backend).contiguous()         # noqa: E731
                 o_k, d_k = pinhole_selected_rays(dv(xy), dv(fidx), dv(intr), dv(c2w), dv(WH))
                 assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 3e-7
+        # camera_model: opencv (the street configs): the reference's Camera code around a distorted lift vs the kernel
+        from neuralsim_amd.graphics.cameras import opencv_selected_rays
+        dist = torch.tensor([[0.043, -0.36, 0.0008, -0.0006, 0.01]]).repeat(5, 1) * torch.linspace(0.5, 1.5, 5)[:, None]
+        cam_d = ref_glue.FakeCamera(intr, c2w, WH.float(), distortion=dist)
+        o_ref, d_ref = Camera._get_selected_rays_from_ixy(cam_d, fidx, xy, snap_to_pixel_centers=True)
+        o_k, d_k = opencv_selected_rays(dv(xy), dv(fidx), dv(intr), dv(dist), dv(c2w), dv(WH))
+        assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 3e-7
+        assert float((d_k.cpu() - d_o).abs().max()) > 1e-3          # (it is not the pinhole direction)
         one = ref_glue.FakeCamera(intr[2], c2w[2], WH[2].float())
         o_all, d_all = Camera.get_all_rays(one)
     xy_all = all_pixel_xy(56, 40, torch.device("cpu"))
