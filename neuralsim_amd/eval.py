@@ -3,7 +3,7 @@
 ``PSNR``; ``Camera.get_all_rays`` app/resources/observers/cameras.py:332-380)."""
 import torch
 
-from .graphics.cameras import pinhole_selected_rays
+from .graphics.cameras import selected_rays
 
 
 def all_pixel_xy(W: int, H: int, device):
@@ -14,7 +14,8 @@ def all_pixel_xy(W: int, H: int, device):
 
 
 @torch.no_grad()
-def render_image(renderer, model, intr, c2w, WH, frame: int, rays_h_appear=None, rayschunk: int = 65536, **kw):
+def render_image(renderer, model, intr, c2w, WH, frame: int, rays_h_appear=None, rayschunk: int = 65536,
+                 distortion=None, **kw):
     """-> dict of [H, W(,3)] images of camera ``frame``, rendered with the reference's VALIDATION renderer settings
     whatever the renderer was built with: eval mode, ``perturb: false``, ``depth_use_normalized_vw: true``
     (lotd_neus.dtu.230814.yaml:272-278 ``renderer.train`` / ``renderer.val``: the reference keeps two renderer configs) --
@@ -22,7 +23,7 @@ def render_image(renderer, model, intr, c2w, WH, frame: int, rays_h_appear=None,
     W, H = int(WH[frame, 0]), int(WH[frame, 1])
     xy = all_pixel_xy(W, H, intr.device)
     fidx = torch.full([xy.shape[0]], frame, dtype=torch.long, device=intr.device)
-    rays_o, rays_d = pinhole_selected_rays(xy, fidx, intr, c2w, WH)
+    rays_o, rays_d = selected_rays(xy, fidx, intr, c2w, WH, distortion=distortion)     # camera_model: pinhole | opencv
     was_training, cfg_saved = renderer.training, dict(renderer.config)
     renderer.eval()
     renderer.config.update(perturb=False, depth_use_normalized_vw=True)

@@ -63,6 +63,13 @@ def opencv_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tenso
                            1 if snap_to_pixel_centers else 0, dist, int(n_iters))
 
 
+def selected_rays(xy, fidx, intr, c2w, WH, distortion=None, **kw):
+    """``pinhole_selected_rays`` or, with ``distortion`` [V,5], ``opencv_selected_rays`` (``camera_model``, cameras.py:80-87)."""
+    if distortion is None:
+        return pinhole_selected_rays(xy, fidx, intr, c2w, WH, **kw)
+    return opencv_selected_rays(xy, fidx, intr, distortion, c2w, WH, **kw)
+
+
 def look_at_cameras(V=100, radius=3.0, H=800, W=800, f=1111.1, seed=42, device=None):
     """Synthetic posed-camera rig of SURVEY.md sec. 8d: V pinhole views (OpenCV convention, +z forward, +y down)
     on a sphere of ``radius`` around the AABB, looking at the origin."""

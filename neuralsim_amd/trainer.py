@@ -17,7 +17,7 @@ from . import _lib, distributed as ndist
 import os
 
 from .fields.neus import LoTDNeuSModel, volume_integration, append_extra_points, _flat_sizes
-from .graphics.cameras import pinhole_selected_rays
+from .graphics.cameras import selected_rays
 from .optim import FusedAdam
 from .losses import eikonal_loss, mse_loss, embedding_lookup
 
@@ -28,13 +28,16 @@ class RenderTrainer:
                  perturb: bool = True, rank: int = 0, world_size: int = 1, seed: int = 42, learn_inv_s: bool = True,
                  distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
                  target_sphere_radius: Optional[float] = None, pipeline: bool = True,
-                 pose_refine: Optional[dict] = None, c2w_true=None, fused_step: Optional[bool] = None):
+                 pose_refine: Optional[dict] = None, c2w_true=None, fused_step: Optional[bool] = None,
+                 distortion: Optional[torch.Tensor] = None):
         """pose_refine: ``dict(lr=1e-4, start_it=500)`` -- per-frame pose corrections (an axis-angle rotation and a
         translation, ``c2w' = [R Exp(w) | T + dT]``) trained through the rays from ``start_it`` on, standing in for the
         reference's ``LearnableParams`` (withmask_withlidar_joint.240219.yaml:338-352; the parametrisation of the
         absent nr3d_lib is not known -- semantics fixed here).  ``c2w_true``: the poses the synthetic targets are
-        rendered from when they differ from the (noisy) ``c2w`` the training starts with."""
+        rendered from when they differ from the (noisy) ``c2w`` the training starts with.
+        distortion [V,5]: ``camera_model: opencv`` (k1, k2, p1, p2, k3 per frame; the street configs); None = pinhole."""
         self.model = model
+        self.distortion = distortion
         # fused_step (default on, env NSIM_FUSED_STEP=0 turns it off): the differentiable part of the iteration -- field
         # forward, sdf->alpha, compositing, losses and their whole backward -- is issued as one straight chain of
         # launches without the autograd engine in between (``_train_render_fused``); same kernels, same numbers
@@ -130,7 +133,7 @@ class RenderTrainer:
             gt = torch.rand([N, 3], device=dev, generator=self.gen)
         else:
             with torch.no_grad():           # the targets are pixels of the TRUE cameras
-                o, d = pinhole_selected_rays(xy, fidx, self.intr, self.c2w_true, self.WH)
+                o, d = selected_rays(xy, fidx, self.intr, self.c2w_true, self.WH, distortion=self.distortion)
             if self.c2w_true is self.c2w and not self.pose_refine_active():
                 self._ray_cache = (xy, o, d)
             else:
@@ -165,7 +168,7 @@ class RenderTrainer:
         elif self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
-            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH)
+            rays_o, rays_d = selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH, distortion=self.distortion)
         h_appear = None
         if tested is None or self.distant_model is not None or self.sky_model is not None:
             h_appear = embedding_lookup(self.appear, fidx)          # per-ray codes for every ray
@@ -404,7 +407,7 @@ class RenderTrainer:
         if self._ray_cache is not None and self._ray_cache[0] is xy:
             _, rays_o, rays_d = self._ray_cache
         else:
-            rays_o, rays_d = pinhole_selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH)
+            rays_o, rays_d = selected_rays(xy, fidx, self.intr, self.current_c2w(), self.WH, distortion=self.distortion)
         if rays_o.requires_grad:        # pose refinement: the compaction of the hit rays stays in the graph
             tested = self.model.ray_test(rays_o, rays_d, near=self.near, far=self.far)
         else:

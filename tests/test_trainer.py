@@ -34,6 +34,22 @@ def test_train_steps_reduce_loss(backend):
     assert tr.stats["R_hit"] > 0 and tr.stats["S_f"] >= tr.stats["R_hit"] * 16
 
 
+def test_train_steps_with_a_distorted_camera(backend):
+    """``camera_model: opencv`` through the training step (street configs): rays, analytic targets and the prefetched
+    batches all come from the distorted lift; the step trains as with a pinhole rig."""
+    m = _tiny(backend)
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+    dist = torch.tensor([[0.05, -0.3, 0.001, -0.001, 0.01]], device=backend).repeat(4, 1)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=32, lr=2e-3, num_uniform=16, perturb=True, target_sphere_radius=0.5,
+                       distortion=dist)
+    tr_p = RenderTrainer(_tiny(backend), intr, c2w, WH, num_rays=32, lr=2e-3, num_uniform=16, perturb=True,
+                         target_sphere_radius=0.5)
+    b, bp = tr._make_batch(), tr_p._make_batch()
+    assert torch.equal(b["xy"], bp["xy"]) and float((b["rays_d"] - bp["rays_d"]).abs().max()) > 1e-4
+    losses = [float(tr.train_step(it)) for it in range(5)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
 def test_pose_refinement_steps(backend):
     """Pose refinement wired through the step: before ``start_it`` the poses are constants (no gradient, pipelined
     batches), afterwards the per-frame corrections receive finite non-zero gradients through ray generation ->
