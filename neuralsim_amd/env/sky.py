@@ -29,13 +29,13 @@ class _SkyFn(torch.autograd.Function):
         _lib.call("nsim_sky_fwd", model.meta, _lib.ptr(wpack), _lib.ptr(v), _lib.ptr(h_appear), N, _lib.ptr(rgb),
                   _lib.ptr(planes))
         ctx.model, ctx.N = model, N
-        ctx.saved = (planes, rgb, h_appear)
+        ctx.save_for_backward(planes, rgb, h_appear)     # (rgb is an OUTPUT: a plain ctx attribute would be a reference cycle)
         return rgb
 
     @staticmethod
     def backward(ctx, g):
         model, N = ctx.model, ctx.N
-        planes, rgb, ha = ctx.saved
+        planes, rgb, ha = ctx.saved_tensors
         dev = rgb.device
         Np = model.plane_pitch(N)
         scratch = torch.empty([(32 + 512) * Np], dtype=torch.float32, device=dev)

@@ -79,14 +79,16 @@ class _DistantFn(torch.autograd.Function):
             _lib.TIMER.note_units("nsim_distant_bwd", S)
             _lib.TIMER.note_units("nsim_lotd4_scatter", S)
         ctx.model, ctx.S, ctx.K = model, S, K
-        ctx.saved = (u4, rays_d, valid, ha, h_pl, sigma, rgb)
+        # save_for_backward, not a ctx attribute: sigma / rgb are OUTPUTS (output -> grad_fn -> ctx -> output would be a
+        # reference cycle that only the cyclic collector frees: 80 MB per step at 8192 rays x 64 shells)
+        ctx.save_for_backward(u4, rays_d, valid, ha, h_pl, sigma, rgb)
         ctx.ha_shape = h_appear.shape if h_appear is not None else None
         return sigma, rgb
 
     @staticmethod
     def backward(ctx, g_sigma, g_rgb):
         model = ctx.model
-        u4, rays_d, valid, ha, h_pl, sigma, rgb = ctx.saved
+        u4, rays_d, valid, ha, h_pl, sigma, rgb = ctx.saved_tensors
         dev = u4.device
         _, wpack = model._shadow()
         need = ctx.needs_input_grad

@@ -97,7 +97,7 @@ class _FieldFn(torch.autograd.Function):
                 _lib.TIMER.note_units("nsim_field_fwd", S)
             ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
             ctx.x_shape = None
-            ctx.geom = (None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
+            ctx.save_for_backward(None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
             ctx.goff = None
             ctx.ha_shape = ha.shape if ha is not None else None
             if M == 0:
@@ -129,7 +129,9 @@ class _FieldFn(torch.autograd.Function):
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
         ctx.x_shape = x.shape if x is not None else None
-        ctx.geom = (x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
+        # save_for_backward, not a ctx attribute: without extra points nablas / rgb ARE the outputs, and output -> grad_fn
+        # -> ctx -> output would be a reference cycle (the planes of a step, ~150 MB, until the cyclic collector runs)
+        ctx.save_for_backward(x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
         ctx.goff = goff
         ctx.ha_shape = ha.shape if ha is not None else None
         if M == 0:
@@ -141,7 +143,7 @@ class _FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         model = ctx.model
-        x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd, h_pl, J_pl = ctx.geom
+        x, rays_o, rays_d, t, ridx, ha, nab_fwd, rgb_fwd, h_pl, J_pl = ctx.saved_tensors
         S, M = ctx.S, ctx.M
         dev = nab_fwd.device
         g_sdf, g_nab = grads[0], grads[1]

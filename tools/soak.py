@@ -12,8 +12,11 @@ import bench  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    mode = sys.argv[2] if len(sys.argv) > 2 else "fused"           # fused | api | distant
     dev = torch.device("cuda", 0)
-    tr = bench.build_trainer(dev, 0, 1)
+    tr = bench.build_trainer(dev, 0, 1, distant=mode == "distant")
+    if mode == "api":
+        tr.fused_step = False
     m = tr.model
     it = 0
     redo = nospec = 0
@@ -35,7 +38,7 @@ def main():
                             reserved_MB=round(torch.cuda.memory_reserved() / 2 ** 20, 1)))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps(dict(steps=steps, ms_per_step=round(el / steps * 1e3, 4), speculative_redone=redo, not_speculated=nospec,
+    print(json.dumps(dict(mode=mode, steps=steps, ms_per_step=round(el / steps * 1e3, 4), speculative_redone=redo, not_speculated=nospec,
                           notify_alive=bool(m._host_notify() is not None), trace=rec)))
 
 
