@@ -209,7 +209,7 @@ class HostNotify:
         self.seq += 1
         return self.buf.data_ptr() + 16 * slot, self.seq
 
-    def wait(self, slot: int, seq: int, timeout_s: float = 2.0):
+    def wait(self, slot: int, seq: int, timeout_s: float = 10.0):
         v = self.view
         n = 0
         t0 = None

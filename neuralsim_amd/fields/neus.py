@@ -1046,13 +1046,16 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 M_true = nt.wait(0, self._notify_seq_m) if self._notify_seq_m is not None else None
                 if M_true is None:
                     Sk = None
-            if Sk is None:          # never stored (memory not host-coherent?): synchronising reads from here on
-                self._notify = False
-        if Sk is None:
+        if Sk is None:              # no host-mapped words, or the wait timed out: a synchronising read of the device copy
             if total_m is None:
                 Sk, M_true = int(total.item()), None
             else:
                 Sk, M_true = torch.cat([total, total_m]).tolist()
+            if nt is not None and int(nt.view[1, 1]) != seq_k:
+                # the kernel has finished and its store still is not visible: this memory is not host-coherent --
+                # synchronising reads from here on.  (Visible now = the stream was merely slow, e.g. first-use code
+                # loading on a cold box: the words stay in use.)
+                self._notify = False
         self._keep_stat = (R, Sk)
         if cap_k is not None and Sk <= cap_k and Sk > 0:
             self._spec_ok = True
