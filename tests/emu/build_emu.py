@@ -8,7 +8,11 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE.parent.parent / "neuralsim_amd" / "csrc"
 SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
-LIB = HERE / "_build" / "libnsim_emu.so"
+import os
+# NSIM_EMU_EXTRA_FLAGS="-fsanitize=address -g" (with LD_PRELOAD of the ASan runtime) builds an instrumented emulator
+# into its own directory: out-of-bounds accesses of the kernels then fail the emulator tests
+EXTRA = os.environ.get("NSIM_EMU_EXTRA_FLAGS", "").split()
+LIB = HERE / ("_build" + ("_x" + hashlib.sha256(" ".join(EXTRA).encode()).hexdigest()[:8] if EXTRA else "")) / "libnsim_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 # -I tests/emu comes FIRST: its nsim_prims.h (the emulator's primitives) shadows the gfx950 one of the product tree
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", f"-I{HERE}", f"-I{CSRC}",
@@ -17,7 +21,7 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", f"-I{HE
 
 def build(force=False):
     LIB.parent.mkdir(exist_ok=True)
-    h = hashlib.sha256()
+    h = hashlib.sha256(" ".join(EXTRA).encode())
     for f in [CSRC / s for s in SOURCES] + [CSRC / "nsim_common.h", CSRC / "lotd_dev.h", CSRC / "mfma_mlp.h", CSRC / "occ_dev.h", HERE / "hip_emu.h", HERE / "nsim_prims.h",
                                             HERE / "hip_emu.cpp", CSRC.parent.parent / "include" / "nsim.h"]:
         h.update(f.read_bytes())
@@ -29,7 +33,7 @@ def build(force=False):
         src = (CSRC / s) if s.endswith(".hip") else (HERE / s)
         obj = LIB.parent / (s + ".o")
         objs.append(str(obj))
-        procs.append((s, subprocess.Popen([CLANG, *FLAGS, "-c", str(src), "-o", str(obj)], stdout=subprocess.PIPE,
+        procs.append((s, subprocess.Popen([CLANG, *FLAGS, *EXTRA, "-c", str(src), "-o", str(obj)], stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT, text=True)))
     bad = False
     for s, p in procs:
@@ -39,7 +43,7 @@ def build(force=False):
             sys.stderr.write(f"[emu build] FAILED {s}\n{out}\n")
     if bad:
         raise RuntimeError("emulator build failed")
-    subprocess.check_call([CLANG, "-shared", "-fPIC", *objs, "-o", str(LIB)])
+    subprocess.check_call([CLANG, "-shared", "-fPIC", *EXTRA, *objs, "-o", str(LIB)])
     stamp.write_text(h.hexdigest())
     return LIB
 
