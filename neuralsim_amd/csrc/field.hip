@@ -358,7 +358,7 @@ __device__ __forceinline__ TilePoint load_point(const FieldArgs& a, int64_t tile
     if (a.x) {
       p.xx[0] = a.x[3 * p.s]; p.xx[1] = a.x[3 * p.s + 1]; p.xx[2] = a.x[3 * p.s + 2];
       if (a.ridx) p.ray = a.ridx[p.s];
-    } else {
+    } else if (a.ridx) {      // (neither given: a launch that works on the saved planes only, e.g. the SDF-branch backward)
       p.ray = a.ridx[p.s];
       const float tt = a.t[p.s];
 #pragma unroll
