@@ -118,7 +118,7 @@ def allreduce_finish(token):
 def broadcast_module(module: torch.nn.Module, src: int = 0):
     """Make replicas bit-identical (parameters AND buffers such as the occupancy grid) -- what DDP does at
     construction / every forward for buffers (code_single/tools/train.py:1401-1406)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if module is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)

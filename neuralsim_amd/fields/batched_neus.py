@@ -158,6 +158,28 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         self.encoding.flattened_params.add_(0)
         return self
 
+    @torch.no_grad()
+    def geometric_init_instances(self, radii: Sequence[float], noise_scale: float = 0.25):
+        """Every instance its own sphere (radius in units of the half bounding size): the pass-through decoder of
+        ``geometric_init_sphere`` + per-instance sphere levels -- the synthetic stand-in for per-instance latents."""
+        assert len(radii) == self.num_instances
+        self.geometric_init_sphere(float(radii[0]), noise_scale=noise_scale)
+        cfg = self.encoding.cfg
+        lv = max(l for l, t in enumerate(cfg.lod_types) if t == "Dense")
+        Rx, Ry, Rz = cfg.lod_res3[lv]
+        zz, yy, xx = torch.meshgrid(torch.linspace(-1.0, 1.0, Rz), torch.linspace(-1.0, 1.0, Ry),
+                                    torch.linspace(-1.0, 1.0, Rx), indexing="ij")
+        rr = torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2).reshape(-1)
+        half = float((self.accel.aabb[1] - self.accel.aabb[0]).min()) / 2.0
+        n, lo = self.n_params_per_instance, cfg.lod_offsets[lv]
+        full = self.encoding.flattened_params.data
+        for b, r in enumerate(radii):
+            lvl = full[b * n + lo: b * n + lo + cfg.lod_sizes[lv] * 2].view(-1, 2)
+            # object-space distance: the unit-cube sphere scaled to the model's box
+            lvl[:, 0] = ((rr - float(r) / half) * half * self.sdf_scale).half().float().to(lvl.device)
+        self.encoding.flattened_params.add_(0)
+        return self
+
     def init_accel(self, generator=None, **kw):
         self.accel.occ_val.zero_()
         self.accel.update_from_net(lambda pts, b: self.query_sdf(pts, ins_ind=b), generator=generator, **kw)
@@ -222,6 +244,10 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
         want_pairs = bool(dict(config).get("_render", False))
         cfg = dict(config, _render=True) if render_per_obj_individual else config
+        if dict(cfg).get("_jitter_full") is not None and bt["num_rays"] > 0:
+            # perturbation randoms given per RAY of the batch ([N], [N, C]; parity tests): a pair uses its ray's
+            cfg = dict(cfg, _jitter=cfg["_jitter_full"][bt["rays_inds"]].contiguous(),
+                       _jitter_c=cfg["_jitter_c_full"][bt["rays_inds"]].contiguous())
         ret = super().ray_query(ray_input=None, ray_tested=tested, config=cfg, return_buffer=return_buffer,
                                 return_details=return_details, render_per_obj_individual=False)
         if render_per_obj_individual:

@@ -247,11 +247,14 @@ class LoTDNeRFDistantModel(ModelMixin, nn.Module):
         """The close-range object's box this model surrounds (``populate(aabb=cr_obj.model.space.aabb)``,
         app/models/single/nerf.py:170-177)."""
         from ..spatial import AABBSpace
+        a = self.aabb
+        key = (a.data_ptr(), a._version, str(a.device))       # no value comparison: that would be a device->host sync
         sp = getattr(self, "_space", None)
-        if sp is None or sp.aabb.device != self.aabb.device or not torch.equal(sp.aabb, self.aabb):
-            sp = AABBSpace(aabb=self.aabb.detach().clone(), device=self.aabb.device)
-            object.__setattr__(self, "_space", sp)
-        return sp
+        if sp is None or sp[0] != key:
+            from ..spatial import AABBSpace
+            sp = (key, AABBSpace(aabb=a.detach().clone(), device=a.device))
+            object.__setattr__(self, "_space", sp)          # a view of the model's box, not a registered sub-module
+        return sp[1]
 
     def training_before_per_step(self, it: int, logger=None):
         pass

@@ -15,6 +15,7 @@ this file only allocates tensors, sequences launches on the current stream and d
 Host synchronisations per render: two (hit-ray compaction, marched-sample total) -- the reference has three
 (single_volume_renderer.py:340,345,414).
 """
+import ctypes
 import math
 import os
 from typing import Dict, Optional, Sequence
@@ -27,6 +28,10 @@ from ..grid_encodings.lotd import LoTDConfig, LoTDEncoding
 from ..graphics import pack_ops as po
 from ..model_base import ModelMixin
 from ..spatial import AABBSpace, aabb_ray_test
+
+def C_memmove(dst, src):
+    ctypes.memmove(ctypes.byref(dst), ctypes.byref(src), ctypes.sizeof(src))
+
 
 DEFAULT_LOD_RES = [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
 RAD_IN = 26
@@ -551,6 +556,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         # size the sampling buffers from the previous step's density instead of reading the marched total back
         self._speculate = os.environ.get("NSIM_SPECULATE", "1") == "1" and not self._sdf_fused
         self._wpack_versions = None
+        # precision of the SAMPLING pass's no-grad SDF queries (``_sampling_ctx``): None = the field precision
+        # "f32" (default): the discrete decisions of a step follow f32 arithmetic whatever the field precision
+        self.sampling_precision = os.environ.get("NSIM_SAMPLING_PRECISION") or "f32"
         if device is not None:
             self.to(device)
 
@@ -611,11 +619,14 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def space(self) -> AABBSpace:
         """``model.space`` (``.aabb``, ``.get_bounding_volume()``, ``.ray_test``): app/resources/nodes.py:92-103,
         app/models/single/nerf.py:175."""
+        a = self.accel.aabb
+        key = (a.data_ptr(), a._version, str(a.device))       # no value comparison: that would be a device->host sync
         sp = getattr(self, "_space", None)
-        if sp is None or sp.aabb.device != self.accel.aabb.device or not torch.equal(sp.aabb, self.accel.aabb):
-            sp = AABBSpace(aabb=self.accel.aabb.detach().clone(), device=self.accel.aabb.device)
+        if sp is None or sp[0] != key:
+            from ..spatial import AABBSpace
+            sp = (key, AABBSpace(aabb=a.detach().clone(), device=a.device))
             object.__setattr__(self, "_space", sp)          # a view of the model's box, not a registered sub-module
-        return sp
+        return sp[1]
 
     # ------------------------------------------------------------------ optimizer (model_base.ModelMixin)
     def _param_groups(self, cfg: dict):
@@ -653,25 +664,57 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         self.set_active_levels(n)
         return n
 
-    def _shadow(self):
-        """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
-        grid16 = self.encoding.shadow()
+    def _pack_for(self, fm, slot: str):
+        """MFMA-fragment weight pack for the kernels selected by ``fm`` (its precision), cached in ``slot`` and refreshed
+        lazily when a parameter changed in place."""
         vers = (self.sdf_w._version, self.sdf_b._version, self.rad_w._version, self.rad_b._version,
-                self.field_meta.precision, str(self.sdf_w.device))
-        if self._wpack is None or self._wpack_versions != vers:
+                fm.precision, str(self.sdf_w.device), self.sdf_scale)
+        cur = getattr(self, slot, None)
+        if cur is None or cur[0] != vers:
             lib = _lib.get_lib()
-            nbytes = int(lib.nsim_field_wpack_bytes(self.field_meta))
-            if self._wpack is None or self._wpack.numel() != nbytes or self._wpack.device != self.sdf_w.device:
-                self._wpack = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
+            nbytes = int(lib.nsim_field_wpack_bytes(fm))
+            buf = cur[1] if cur is not None else None
+            if buf is None or buf.numel() != nbytes or buf.device != self.sdf_w.device:
+                buf = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
             sw, sb = self.sdf_w.detach(), self.sdf_b.detach()
             if self.sdf_scale != 1.0:       # sdf = head / sdf_scale: fold the divisor into the packed head weights
                 sw, sb = sw.clone(), sb.clone()
                 sw[-64:] /= self.sdf_scale
                 sb[-1:] /= self.sdf_scale
-            _lib.call("nsim_field_pack_weights", self.field_meta, _lib.ptr(sw), _lib.ptr(sb),
-                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(self._wpack))
-            self._wpack_versions = vers
+            _lib.call("nsim_field_pack_weights", fm, _lib.ptr(sw), _lib.ptr(sb),
+                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(buf))
+            object.__setattr__(self, slot, (vers, buf))
+        return getattr(self, slot)[1]
+
+    def _shadow(self):
+        """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
+        grid16 = self.encoding.shadow()
+        if self._wpack_versions is None:        # invalidated by hand (optimizer step, precision switch)
+            object.__setattr__(self, "_wpack_slot", None)
+            object.__setattr__(self, "_wpack_slot_s", None)
+            self._wpack_versions = True
+        self._wpack = self._pack_for(self.field_meta, "_wpack_slot")
         return grid16, self._wpack
+
+    def _sampling_ctx(self):
+        """(FieldMeta, weight pack) of the SAMPLING pass's no-grad SDF queries.  ``sampling_precision = "f32"`` runs them
+        on the exact-f32 kernels (f32 feature planes, v_mfma_f32_32x32x2_f32) while the with-grad query stays fp16: the
+        up-sampler multiplies SDF differences by inv_s up to 1024 and the compressed mode thresholds visibility weights
+        at 1e-4, so the DISCRETE decisions of a step (where fine samples land, which samples are kept) then follow the
+        f32 arithmetic -- they are what the fp16 rounding of an SDF (half an ulp = 2.4e-4 at |sdf| in [0.5, 1)) moves.
+        None / equal to the field precision: one pack, one meta."""
+        sp = self.sampling_precision
+        fm = self.field_meta
+        if sp is None or {"fp16": 0, "f32": 1}[sp] == fm.precision:
+            return fm, self._shadow()[1]
+        fs = getattr(self, "_field_meta_s", None)
+        if fs is None:
+            fs = _lib.FieldMeta()
+            object.__setattr__(self, "_field_meta_s", fs)
+        C_memmove(fs, fm)
+        fs.precision = {"fp16": 0, "f32": 1}[sp]
+        self._shadow()
+        return fs, self._pack_for(fs, "_wpack_slot_s")
 
     @torch.no_grad()
     def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None,
@@ -799,14 +842,14 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
 
     # ------------------------------------------------------------------ point queries
     def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None, n_dev=None,
-                   n_add: int = 0, collect: bool = False) -> torch.Tensor:
+                   n_add: int = 0, collect: bool = False, fm=None) -> torch.Tensor:
         """No-grad SDF of S points: level-major gather into feature planes [16][S] (f16x2 | f32x2), then the decoder
         on the planes (csrc/field.hip: k_lotd_gather_lm, k_field_sdf<.., true>).  NSIM_SDF_FUSED=1 selects the single
         fused point-major kernel instead (same values)."""
         sdf = torch.empty([S], dtype=torch.float32, device=dev)
         if S == 0:
             return sdf
-        fm = self.field_meta
+        fm = self.field_meta if fm is None else fm
         planes = None
         if not self._sdf_fused:
             planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,
@@ -957,10 +1000,13 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
                   _lib.ptr(pi), _lib.ptr(ridx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(xq))
         grid16, wpack = self._shadow()
+        fm_s = None
+        if with_x:
+            fm_s, wpack = self._sampling_ctx()
         collect = with_x and goff is None and self.accel.collect_armed       # fused into the decoder launches below
         if with_x:
             sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if goff is not None else None, S, dev,
-                                  goff=goff, n_dev=n_dev, n_add=R * C, collect=collect)
+                                  goff=goff, n_dev=n_dev, n_add=R * C, collect=collect, fm=fm_s)
         else:
             sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
@@ -975,7 +1021,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             ridx_new = self._arange_repeat(R, nf, dev)
             if with_x:
                 sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if goff is not None else None,
-                                          R * nf, dev, goff=goff, collect=collect)
+                                          R * nf, dev, goff=goff, collect=collect, fm=fm_s)
             else:
                 sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
             S2 = S + R * nf

@@ -34,6 +34,11 @@ def get_pack_infos_from_n(n: torch.Tensor, return_total: bool = False, cap: int 
                   int(notify[0]), int(notify[1]))
     elif P > 0:
         _lib.call("nsim_pack_infos_from_n", _lib.ptr(n), P, _lib.ptr(pi), _lib.ptr(total), int(cap))
+    elif notify is not None:
+        # no pack, no launch: the armed slot gets its (0, seq) from the host, or a waiter would spin into its timeout
+        import ctypes
+        w = (ctypes.c_int64 * 2).from_address(int(notify[0]))
+        w[0], w[1] = 0, int(notify[1])
     return (pi, total) if return_total else pi
 
 

@@ -29,6 +29,20 @@ class FusedAdam:
         self.t = 0
         self._dirty = [model]
 
+    def add_model(self, model, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), learn_inv_s=True):
+        """Parameters of a further NeuS model (a shared batched foreground model next to the background, code_multi)."""
+        enc = model.encoding
+        enc.shadow()
+        new = [dict(p=enc.flattened_params, p16=lambda: enc.params16, betas=betas)]
+        new += [dict(p=p, p16=None, betas=betas) for p in (model.sdf_w, model.sdf_b, model.rad_w, model.rad_b)]
+        if learn_inv_s:
+            new.append(dict(p=model.ln_inv_s, p16=None, betas=invs_betas))
+        for g in new:
+            g["m"] = torch.zeros_like(g["p"], dtype=torch.float32)
+            g["v"] = torch.zeros_like(g["p"], dtype=torch.float32)
+        self.groups += new
+        self._dirty.append(model)
+
     def add_distant_model(self, dm, betas=(0.9, 0.99)):
         """Parameters of a ``LoTDNeRFDistantModel`` (``training_cfg{lr: bglr, betas [.9,.99]}``, dtu yaml :242-247)."""
         dm._shadow()

@@ -60,12 +60,17 @@ class BufferComposeRenderer(nn.Module):
 
     def ray_query(self, rays_o: torch.Tensor, rays_d: torch.Tensor, *, drawables: List[Drawable],
                   rays_h_appear: torch.Tensor = None, near=None, far=None, with_rgb: bool = None,
-                  with_normal: bool = None, sky_model=None, return_buffer=False, return_details=False,
+                  with_normal: bool = None, sky_model=None, distant_model=None, distant_cr_id: str = None,
+                  return_buffer=False, return_details=False,
                   bypass_ray_query_cfg: Dict[str, dict] = None, render_per_obj_in_scene: bool = False,
                   render_per_class_in_scene: bool = False) -> Dict:
         """``render_per_class_in_scene`` / ``render_per_obj_in_scene``: every class's / object's share of the JOINT
         rendering -- its samples weighted by ``vw_in_total`` (reference :729-806; the per-class masks feed the
-        importance sampler of code_multi/tools/train.py:589-592, the per-object images the mono / manhattan losses)."""
+        importance sampler of code_multi/tools/train.py:589-592, the per-object images the mono / manhattan losses).
+        ``distant_model``: the 'Distant' class, queried LAST (reference :162-164) on ALL rays in the frame of its
+        close-range object ``distant_cr_id`` (default: the first single-model drawable), ``near`` := that object's
+        ``far`` on the rays that passed its ray test, rays detached (reference :506-531); its batched [N, K] buffer joins
+        the collect as one pack of K per ray (:598-606)."""
         assert rays_o.dim() == rays_d.dim() == 2
         cfgd = self.config
         with_rgb = cfgd.get("with_rgb", True) if with_rgb is None else with_rgb
@@ -117,8 +122,29 @@ class BufferComposeRenderer(nn.Module):
                         else:
                             R = dr.rotation.to(dev).detach().expand(vb["pack_infos_hit"].shape[0], 3, 3).contiguous()
                             vb["nablas_in_world"] = po.packed_matmul(vb["nablas"], R, vb["pack_infos_hit"])
-                    raw.update(class_name=dr.class_name, obj_id=dr.id, num_rays=tested["num_rays"])
+                    raw.update(class_name=dr.class_name, obj_id=dr.id, num_rays=tested["num_rays"],
+                               rays_inds=tested["rays_inds"], ray_far=tested["far"], _drawable=dr)
                     raw_per_obj_model[dr.id] = raw
+        if distant_model is not None:
+            singles = [r for r in raw_per_obj_model.values() if "_drawable" in r]
+            cr = raw_per_obj_model.get(distant_cr_id) if distant_cr_id is not None else (singles[0] if singles else None)
+            near_dv = torch.full([N], float(near) if near is not None else 0.0, dtype=torch.float32, device=dev)
+            o_dv, d_dv = rays_o, rays_d
+            if cr is not None:
+                o_dv, d_dv = cr["_drawable"].rays_in_object(rays_o, rays_d)
+                if cr["num_rays"] > 0:
+                    near_dv = near_dv.index_put((cr["rays_inds"],), cr["ray_far"])
+            dv_tested = dict(rays_o=o_dv.detach(), rays_d=d_dv.detach(), near=near_dv, rays_h_appear=rays_h_appear,
+                             num_rays=N, rays_inds=torch.arange(N, device=dev))
+            raw = distant_model.ray_query(ray_tested=dv_tested, config=self._query_cfg(distant_model, with_rgb, with_normal,
+                                                                                         bypass.get("Distant")),
+                                          return_buffer=True, return_details=return_details)
+            vb = raw["volume_buffer"]
+            vb["pack_infos_hit"] = po.get_pack_infos_from_n(torch.full([N], int(vb["num_per_hit"]), dtype=torch.long, device=dev))
+            raw.update(class_name="Distant", obj_id="distant", num_rays=N)
+            raw_per_obj_model["distant"] = raw
+        for r in raw_per_obj_model.values():
+            r.pop("_drawable", None)
         # ---- per-ray sample counts over all objects (several batch items may hit the same ray: index_add)
         for raw in raw_per_obj_model.values():
             vb = raw["volume_buffer"]

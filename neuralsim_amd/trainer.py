@@ -19,7 +19,7 @@ import os
 from .fields.neus import LoTDNeuSModel, volume_integration, append_extra_points, _flat_sizes
 from .graphics.cameras import selected_rays
 from .optim import FusedAdam
-from .losses import eikonal_loss, mse_loss, embedding_lookup
+from .losses import eikonal_loss, mse_loss, embedding_lookup, mono_depth_loss, mono_normal_loss
 
 
 class RenderTrainer:
@@ -29,14 +29,24 @@ class RenderTrainer:
                  distant_model=None, sky_model=None, level_anneal: Optional[dict] = None,
                  target_sphere_radius: Optional[float] = None, pipeline: bool = True,
                  pose_refine: Optional[dict] = None, c2w_true=None, fused_step: Optional[bool] = None,
-                 distortion: Optional[torch.Tensor] = None):
+                 distortion: Optional[torch.Tensor] = None, target_images: Optional[torch.Tensor] = None,
+                 mono: Optional[dict] = None, rgb_fn: str = "mse"):
         """pose_refine: ``dict(lr=1e-4, start_it=500)`` -- per-frame pose corrections (an axis-angle rotation and a
         translation, ``c2w' = [R Exp(w) | T + dT]``) trained through the rays from ``start_it`` on, standing in for the
         reference's ``LearnableParams`` (withmask_withlidar_joint.240219.yaml:338-352; the parametrisation of the
         absent nr3d_lib is not known -- semantics fixed here).  ``c2w_true``: the poses the synthetic targets are
         rendered from when they differ from the (noisy) ``c2w`` the training starts with.
-        distortion [V,5]: ``camera_model: opencv`` (k1, k2, p1, p2, k3 per frame; the street configs); None = pinhole."""
+        distortion [V,5]: ``camera_model: opencv`` (k1, k2, p1, p2, k3 per frame; the street configs); None = pinhole.
+        target_images [V,H,W,3]: the dataset's images resident in HBM; a batch gathers its pixels from them, as the
+        reference's pixel loader does from its preloaded images (dataio/data_loader/pixel_loader.py:323-327).
+        mono: the indoor config's monocular supervision (lotd_neus.replica.230814.yaml:236-238, 272-288):
+        ``dict(depth=[V,H,W], normals=[V,H,W,3], patch_hw=(64, 64), w_depth=, w_normal=)`` -- the first h*w rays of every
+        batch are a contiguous pixel patch of one frame (the reference's ``image_patch`` step; the scale-and-shift
+        invariant depth term needs an image region), normals are supervised on every ray.
+        rgb_fn: ``mse`` | ``l1`` (``rgb_fn`` of the street configs, withmask_withlidar_joint.240219.yaml:26)."""
         self.model = model
+        self.target_images, self.mono, self.rgb_fn = target_images, (dict(mono) if mono else None), rgb_fn
+        self._last_aux = None
         self.distortion = distortion
         # fused_step (default on, env NSIM_FUSED_STEP=0 turns it off): the differentiable part of the iteration -- field
         # forward, sdf->alpha, compositing, losses and their whole backward -- is issued as one straight chain of
@@ -129,6 +139,26 @@ class RenderTrainer:
         N = self.num_rays
         xy = torch.rand([N, 2], device=dev, generator=self.gen).clamp_(1e-6, 1 - 1e-6)   # cameras.py:247
         fidx = torch.randint(0, self.V, [N], device=dev, generator=self.gen)
+        if self.mono is not None and self.mono.get("patch_hw"):
+            # image-patch rays (code_single/tools/train.py:738-739: rays_pix [h,w,2]): rows 0 .. h*w-1 of the batch
+            ph, pw = self.mono["patch_hw"]
+            W_, H_ = int(self.WH[0, 0]), int(self.WH[0, 1])
+            r3 = torch.rand([3], device=dev, generator=self.gen)
+            f0 = (r3[0] * self.V).long().clamp_(0, self.V - 1)
+            x0, y0 = (r3[1] * (W_ - pw)).floor(), (r3[2] * (H_ - ph)).floor()
+            yy, xx = torch.meshgrid(torch.arange(ph, device=dev), torch.arange(pw, device=dev), indexing="ij")
+            pxy = torch.stack([(xx.reshape(-1) + x0 + 0.5) / W_, (yy.reshape(-1) + y0 + 0.5) / H_], dim=-1)
+            xy = torch.cat([pxy, xy[ph * pw:]])
+            fidx = torch.cat([f0.expand(ph * pw), fidx[ph * pw:]])
+        if self.target_images is not None:
+            H_, W_ = self.target_images.shape[1], self.target_images.shape[2]
+            ix = (xy[:, 0] * W_).long().clamp_(0, W_ - 1)
+            iy = (xy[:, 1] * H_).long().clamp_(0, H_ - 1)
+            self._ray_cache = None
+            self._last_aux = None
+            if self.mono is not None:
+                self._last_aux = dict(depth=self.mono["depth"][fidx, iy, ix], normals=self.mono["normals"][fidx, iy, ix])
+            return xy, fidx, self.target_images[fidx, iy, ix]
         if self.target_sphere_radius is None:
             gt = torch.rand([N, 3], device=dev, generator=self.gen)
         else:
@@ -184,7 +214,8 @@ class RenderTrainer:
     def _fused_ok(self) -> bool:
         m = self.model
         return (self.fused_step and type(m) is LoTDNeuSModel and self.distant_model is None and self.sky_model is None
-                and not self.pose_refine_active() and getattr(m, "_ctrl_mix", 0.0) == 0.0)
+                and not self.pose_refine_active() and getattr(m, "_ctrl_mix", 0.0) == 0.0 and self.mono is None
+                and self.rgb_fn == "mse")
 
     def _train_render_fused(self, batch: dict) -> Optional[torch.Tensor]:
         """render + loss + backward of one prefetched batch WITHOUT the autograd engine: the launches the autograd path
@@ -421,7 +452,7 @@ class RenderTrainer:
             ez[:, 2] = 1.0
             extras.update(o_full=torch.cat([tested["rays_o"], extras["x_uni"]]), d_full=torch.cat([tested["rays_d"], ez]),
                           ridx_tail=torch.arange(R, R + M, device=dev))
-        return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested,
+        return dict(xy=xy, fidx=fidx, gt=gt, rays_o=rays_o, rays_d=rays_d, tested=tested, aux=self._last_aux,
                     fidx_hit=fidx[tested["rays_inds"]], **extras)
 
     def _prefetch(self):
@@ -444,9 +475,21 @@ class RenderTrainer:
         lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
         return lo + torch.rand([self.num_uniform, 3], device=self.model.device, generator=self.gen) * (hi - lo)
 
-    def loss(self, ret, gt, uni=None):
-        """photometric mse on all rays + eikonal on the close-range render samples and on uniform points."""
-        loss_rgb = mse_loss(ret["rendered"]["rgb_volume"], gt)
+    def loss(self, ret, gt, uni=None, aux=None):
+        """photometric mse (or l1) on all rays + eikonal on the close-range render samples and on uniform points
+        (+ the monocular depth / normal terms of the indoor config when ``mono`` supervision is set)."""
+        if self.rgb_fn == "l1":
+            loss_rgb = (ret["rendered"]["rgb_volume"] - gt).abs().mean()
+        else:
+            loss_rgb = mse_loss(ret["rendered"]["rgb_volume"], gt)
+        if aux is not None and self.mono is not None:
+            r_ = ret["rendered"]
+            occupied = (r_["mask_volume"].detach() > 0.5).float()          # ``pred_not_occupied`` of the ignore list
+            w_n, w_d = float(self.mono.get("w_normal", 0.05)), float(self.mono.get("w_depth", 0.1))
+            loss_rgb = loss_rgb + w_n * mono_normal_loss(r_["normals_volume"], aux["normals"], occupied)
+            if self.mono.get("patch_hw"):
+                n_p = self.mono["patch_hw"][0] * self.mono["patch_hw"][1]
+                loss_rgb = loss_rgb + w_d * mono_depth_loss(r_["depth_volume"][:n_p], aux["depth"][:n_p], occupied[:n_p])
         eik = None
         cr_vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
         if cr_vb["type"] != "empty":
@@ -504,7 +547,7 @@ class RenderTrainer:
             uni = None
             if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
                 uni = model.forward_sdf_nablas(x_uni)
-            loss, parts = self.loss(ret, gt, uni)
+            loss, parts = self.loss(ret, gt, uni, aux=batch.get("aux") if batch is not None else self._last_aux)
             self.optim.zero_grad()
             if refine:
                 self.pose_optim.zero_grad(set_to_none=True)

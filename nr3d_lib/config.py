@@ -104,9 +104,14 @@ def _safe_arith(expr: str):
             return n.value
         if isinstance(n, ast.BinOp) and type(n.op) in bin_ops:
             a, b = ev(n.left), ev(n.right)
-            if isinstance(n.op, ast.Pow) and abs(b) > 4096:
-                raise ValueError("exponent too large")
-            return bin_ops[type(n.op)](a, b)
+            if isinstance(n.op, ast.Pow):
+                # bound the SIZE of the result, not only the exponent: ((2**4096)**4096)**4096 would allocate gigabytes
+                if abs(b) > 4096 or (isinstance(a, int) and isinstance(b, int) and abs(a).bit_length() * abs(b) > 4096):
+                    raise ValueError("${eval:...}: power too large")
+            r = bin_ops[type(n.op)](a, b)
+            if isinstance(r, int) and abs(r).bit_length() > 8192:
+                raise ValueError("${eval:...}: integer too large")
+            return r
         if isinstance(n, ast.UnaryOp) and type(n.op) in un_ops:
             return un_ops[type(n.op)](ev(n.operand))
         if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in funcs and not n.keywords:

@@ -1,19 +1,17 @@
 """``nr3d_lib.models.loss.recon`` -- the elementwise reconstruction losses the reference's loss modules star-import
 (app/loss/photometric.py:67-84, app/loss/weight_reg.py:15): plain torch formulas on renderer outputs, restated from
-their names (implementation absent).  ``mask`` weights the elements; ``reduction`` 'mean' | 'none'."""
+their names (implementation absent).  ``mask`` weights the elements (a [N] mask on [N, 3] errors is broadcast); ``reduction`` as in ``.utils.reduce``."""
 import torch
 import torch.nn.functional as F
+
+from .utils import reduce
 
 __all__ = ["l1_loss", "l2_loss", "mse_loss", "huber_loss", "smooth_l1_loss", "relative_l1_loss", "relative_l2_loss",
            "mape_loss", "smape_loss"]
 
 
 def _reduce(x, mask, reduction):
-    if mask is not None:
-        x = x * mask
-        if reduction == "mean":
-            return x.sum() / (mask.expand_as(x).sum().clamp_min(1))
-    return x.mean() if reduction == "mean" else x
+    return reduce(x, mask=mask, reduction=reduction)       # per-ray masks broadcast over the channel dimension
 
 
 def l1_loss(pred, gt, mask=None, reduction="mean"):

@@ -66,6 +66,7 @@ class FieldParams:
     rad_b: List[torch.Tensor] = field(default_factory=list)
     ln_inv_s: torch.Tensor = None           # scalar f32
     ln_inv_s_factor: float = 10.0
+    sdf_scale: float = 1.0                  # sdf = head(h) / sdf_scale (street config ``sdf_scale: 25``, 240219.yaml:158)
 
     def tensors(self):
         return [self.grid, *self.sdf_w, *self.sdf_b, *self.rad_w, *self.rad_b, self.ln_inv_s]
@@ -139,7 +140,8 @@ def sdf_decoder(h: torch.Tensor, p: FieldParams) -> torch.Tensor:
     n = len(p.sdf_w)
     for li in range(n - 1):
         a = F.softplus(F.linear(a, p.sdf_w[li], p.sdf_b[li]), beta=SOFTPLUS_BETA, threshold=20.0)
-    return F.linear(a, p.sdf_w[-1], p.sdf_b[-1]).squeeze(-1)
+    out = F.linear(a, p.sdf_w[-1], p.sdf_b[-1]).squeeze(-1)
+    return out if p.sdf_scale == 1.0 else out / p.sdf_scale
 
 
 def forward_sdf(x: torch.Tensor, p: FieldParams) -> torch.Tensor:
@@ -179,11 +181,13 @@ def forward_field(x, v, h_appear, p: FieldParams, x_has_grad: bool = False):
 
 
 def params_from_flat(lod_res, log2_hashmap_size, grid, sdf_w, sdf_b, rad_w, rad_b, ln_inv_s, sdf_D=2,
-                     ln_inv_s_factor=10.0, n_feats=2) -> FieldParams:
+                     ln_inv_s_factor=10.0, n_feats=2, sdf_scale=1.0, aabb=None) -> FieldParams:
     """FieldParams from the product's FLAT parameter tensors (same layouts: neuralsim_amd/fields/neus.py ``_flat_sizes``)
     -- the weight exchange of the parity tests / the bench's CPU leg.  ``grid`` is rounded to fp16 and held in f32:
     the kernels read the fp16 shadow of the table (lotd_neus.dtu.230814.yaml:94 ``dtype: half``)."""
     spec = make_lotd_spec(list(lod_res), n_feats, log2_hashmap_size)
+    if aabb is not None:
+        spec.aabb = torch.as_tensor(aabb, dtype=torch.float32).detach().cpu().reshape(2, 3)
     F1 = spec.out_features
     sw, sb, rw, rb = (t.detach().cpu().float() for t in (sdf_w, sdf_b, rad_w, rad_b))
     ws = [sw[:64 * F1].view(64, F1).clone()]
@@ -197,4 +201,5 @@ def params_from_flat(lod_res, log2_hashmap_size, grid, sdf_w, sdf_b, rad_w, rad_
     rws = [rw[:n1].view(64, RAD_IN).clone(), rw[n1:n1 + 4096].view(64, 64).clone(), rw[-192:].view(3, 64).clone()]
     rbs = [rb[:64].clone(), rb[64:128].clone(), rb[128:].clone()]
     return FieldParams(spec=spec, grid=grid.detach().cpu().half().float(), sdf_w=ws, sdf_b=bs, rad_w=rws, rad_b=rbs,
-                       ln_inv_s=ln_inv_s.detach().cpu().float().reshape(()).clone(), ln_inv_s_factor=ln_inv_s_factor)
+                       ln_inv_s=ln_inv_s.detach().cpu().float().reshape(()).clone(), ln_inv_s_factor=ln_inv_s_factor,
+                       sdf_scale=float(sdf_scale))

@@ -374,3 +374,75 @@ def compose_buffers(buffers, N: int, depth_use_normalized_vw: bool = True):
         depths.append(((vw / (m + 1e-10)) * t).sum() if depth_use_normalized_vw else (vw * t).sum())
         rgbs.append((vw[:, None] * c).sum(0))
     return torch.stack(masks), torch.stack(depths), torch.stack(rgbs), cnt
+
+
+# ------------------------------------------------------------------------- single scene: close range + distant + sky
+def render_scene(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max, res, *, query_kw: dict,
+                 distant=None, distant_kw: dict = None, sky=None, depth_use_normalized_vw=False, with_normal=True):
+    """``SingleVolumeRenderer.ray_query`` (app/renderers/single_volume_renderer.py:136-492) restated for one close-range
+    object: the NeuS query on the rays that hit its AABB (:235-267); the distant NeRF++ model on ALL rays with ``near`` :=
+    the close-range ``far`` where the AABB was hit (:281-309); both buffers merged per ray by depth
+    (``merge_two_packs_sorted`` + scatter, :337-375) and integrated (:73-102, :412-442); the sky blended with the residual
+    transmittance (:449-457).
+    ``distant`` = oracle.distant.DistantParams or None, ``distant_kw`` = dict(K, jitter, include_inf, r_min, r_max);
+    ``sky`` = (ws, bs) of oracle.sky or None.  -> dict(rendered, cr=<ray_query result>, dv=<distant buffer>)."""
+    from . import distant as od, sky as osky
+    N = rays_o.shape[0]
+    cr = ray_query(p, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max, res,
+                   depth_use_normalized_vw=depth_use_normalized_vw, **query_kw)
+    near = query_kw.get("near", 0.01)
+    ri = cr["rays_inds"]
+    dv = None
+    if distant is not None:
+        kw = dict(distant_kw or {})
+        near_dv = torch.full([N], float(near))
+        if cr["num_rays"] > 0:
+            near_dv = near_dv.index_put((ri,), cr["far"])
+        dv = od.distant_ray_query(distant, rays_o.detach(), rays_d.detach(), near_dv, h_appear, aabb_min, aabb_max, **kw)
+    has_cr = cr["num_rays"] > 0 and cr["volume_buffer"]["type"] != "empty"
+    rendered = dict(mask_volume=torch.zeros(N), depth_volume=torch.zeros(N), rgb_volume=torch.zeros(N, 3))
+    if with_normal:
+        rendered["normals_volume"] = torch.zeros(N, 3)
+    if has_cr and dv is not None:
+        vb = cr["volume_buffer"]
+        K = dv["t"].shape[1]
+        pi_dv = po.get_pack_infos_from_n(torch.full((N,), K, dtype=torch.long))
+        pidx_dv, pidx_cr, pi_tot = po.merge_two_packs_sorted(dv["t"].flatten(), pi_dv, torch.arange(N), vb["t"],
+                                                              vb["pack_infos_hit"], vb["rays_inds_hit"])
+        S = N * K + vb["t"].shape[0]
+
+        def place(a_dv, a_cr, tail=()):
+            z = torch.zeros([S, *tail])
+            if a_dv is not None:
+                z = z.index_put((pidx_dv,), a_dv)
+            return z.index_put((pidx_cr,), a_cr)
+        tt = place(dv["t"].flatten(), vb["t"])
+        aa = place(dv["opacity_alpha"].flatten(), vb["opacity_alpha"])
+        cc = place(dv["rgb"].flatten(0, 1), vb["rgb"], (3,))
+        nn = place(None, vb["nablas"], (3,)) if with_normal else None
+        out = volume_integration(aa, tt, cc, nn, pi_tot, depth_use_normalized_vw)
+        for k in rendered:
+            rendered[k] = out[k]
+        cr["volume_buffer"]["vw_in_total"] = out["vw"][pidx_cr]
+        dv["vw_in_total"] = out["vw"][pidx_dv].view(N, K)
+    elif has_cr:
+        for k in rendered:
+            rendered[k] = rendered[k].index_put((ri,), cr["rendered"][k])
+    elif dv is not None:
+        K = dv["t"].shape[1]
+        pi_dv = po.get_pack_infos_from_n(torch.full((N,), K, dtype=torch.long))
+        out = volume_integration(dv["opacity_alpha"].flatten(), dv["t"].flatten(), dv["rgb"].flatten(0, 1), None, pi_dv,
+                                 depth_use_normalized_vw)
+        for k in ("mask_volume", "depth_volume", "rgb_volume"):
+            rendered[k] = out[k]
+    rendered["rgb_volume_occupied"] = rendered["rgb_volume"]
+    if sky is not None:
+        ws, bs = sky
+        rgb_sky = osky.sky_forward(F_normalize(rays_d), h_appear, ws, bs)
+        rendered["rgb_sky"] = rgb_sky
+        rendered["rgb_volume"] = osky.blend_sky(rendered["rgb_volume"], rendered["mask_volume"], rgb_sky)
+    return dict(rendered=rendered, cr=cr, dv=dv)
+
+
+def F_normalize(v):
+    return torch.nn.functional.normalize(v, dim=-1)

@@ -95,6 +95,34 @@ def test_ray_query_parity(backend, precision, compressed):
         assert e < 5e-3, (k, e)
 
 
+@pytest.mark.parametrize("compressed", [False, True])
+def test_f32_sampling_pass_fixes_the_discrete_decisions_of_an_fp16_step(backend, compressed):
+    """``sampling_precision = "f32"``: the no-grad SDF queries of the sampling pass run on the exact-f32 kernels, the
+    with-grad query on the fp16 ones -- the sample set (counts, depths) is then the f32 oracle's, the rendered values
+    carry only the fp16 error of the field ON that set."""
+    p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "fp16")
+    model.sampling_precision = "f32"
+    ret_o = orr.ray_query(p, o, d, h_appear, occ, AABB[0], AABB[1], RES, near=0.01, far=None, num_coarse=16,
+                          num_fine=(4, 4, 8), step_size=0.02, max_steps=512, jitter=jit, jitter_c=jit_c,
+                          depth_use_normalized_vw=False, compress=compressed, compress_thre=1e-3)
+    dv = lambda a: a.to(backend).contiguous()       # noqa: E731
+    tested = model.ray_test(dv(o), dv(d), near=0.01, far=None, rays_h_appear=dv(h_appear))
+    ri = ret_o["rays_inds"]
+    cfg = dict(query_param=dict(QP, compress_thre=1e-3), with_rgb=True, with_normal=True, depth_use_normalized_vw=False,
+               _render=True, _jitter=dv(jit[ri]), _jitter_c=dv(jit_c[ri]),
+               query_mode="march_occ_multi_upsample" + ("_compressed" if compressed else ""))
+    ret = model.ray_query(ray_tested=tested, config=cfg, return_details=True)
+    vb, vbo = ret["volume_buffer"], ret_o["volume_buffer"]
+    assert torch.equal(vb["pack_infos_hit"].cpu(), vbo["pack_infos_hit"])         # same kept set as the f32 oracle
+    assert (vb["t"].cpu() - vbo["t"]).abs().max() < 1e-4                          # ... at the same depths
+    assert (ret["details"]["sdf_nograd"].cpu() - ret_o["debug"]["sdf_nograd"]).abs().max() < 2e-5
+    for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+        err = (ret["rendered"][k].cpu() - ret_o["rendered"][k]).abs()
+        assert err.max() < 1e-2 * (3 if k == "depth_volume" else 1), (k, float(err.max()))
+    # the with-grad values are the fp16 kernels' (they differ from the f32 ones in the last bits of an fp16 operand)
+    assert 1e-7 < float((vb["sdf"].detach().cpu() - vbo["sdf"].detach()).abs().max()) < 2e-3
+
+
 def test_ray_query_empty_and_no_perturb(backend):
     p, model, o, d, h_appear, occ, _, _, g = _setup(backend, "f32", N=16, perturb=False)
     dv = lambda a: a.to(backend).contiguous()

@@ -60,3 +60,27 @@ def test_config_eval_is_arithmetic_only():
     for bad in ("__import__('os').system('true')", "().__class__", "open('x')", "a.b", "[x for x in (1,)]", "2**99999"):
         with pytest.raises((ValueError, SyntaxError)):
             _safe_arith(bad)
+
+
+def test_masked_reductions_broadcast_a_per_ray_mask():
+    """``fn(rgb_pred [N,3], rgb_gt [N,3], mask=remain [N], reduction='mean' | 'none')`` (app/loss/photometric.py:108-142;
+    every street config with ``respect_ignore_mask``): the per-ray mask is broadcast over the channels; 'mean' averages
+    ``loss * mask`` over ALL elements, 'mean_in_mask' over the masked-in ones."""
+    from nr3d_lib.models.loss.recon import l1_loss, mse_loss, relative_l2_loss
+    from nr3d_lib.models.loss.utils import reduce
+    g = torch.Generator().manual_seed(0)
+    p, t = torch.rand(8, 3, generator=g), torch.rand(8, 3, generator=g)
+    m = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0], dtype=torch.bool)
+    e = (p - t) ** 2
+    assert torch.allclose(mse_loss(p, t, mask=m, reduction="mean"), (e * m[:, None]).mean())
+    assert torch.allclose(mse_loss(p, t, mask=m, reduction="mean_in_mask"), e[m].mean())
+    assert mse_loss(p, t, mask=m, reduction="none").shape == (8, 3)
+    assert float(mse_loss(p, t, mask=m, reduction="none")[1].abs().sum()) == 0.0
+    assert torch.allclose(l1_loss(p, t, mask=m.float(), reduction="mean"), ((p - t).abs() * m[:, None]).mean())
+    assert torch.allclose(relative_l2_loss(p, t), (e / (t ** 2 + 1e-2)).mean())
+    x = torch.rand(5, generator=g)
+    mk = torch.tensor([1.0, 1, 0, 0, 1])
+    assert torch.allclose(reduce(x, mask=mk, reduction="mean"), (x * mk).mean())
+    assert torch.allclose(reduce(x, mask=mk, reduction="sum"), (x * mk).sum())
+    with pytest.raises(ValueError):
+        reduce(x, reduction="median")

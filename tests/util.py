@@ -81,3 +81,57 @@ def look_at_cameras(V=4, radius=3.0, H=800, W=800, f=1111.1, seed=0):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+# ----------------------------------------------------------------- product -> oracle weight exchange (whole models)
+def oracle_of_neus(m, table="master"):
+    """oracle.field.FieldParams carrying the weights of a product LoTDNeuSModel (any pyramid / AABB / sdf_scale).
+    ``table``: "master" = the f32 optimizer copy rounded to fp16 (what the kernels' shadow holds), as leaf tensors."""
+    cfg = m.encoding.cfg
+    p = ofield.params_from_flat(cfg.lod_res, int(math.log2(cfg.hashmap_size)), m.encoding.flattened_params, m.sdf_w,
+                                m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s, sdf_D=m.sdf_D, ln_inv_s_factor=m.ln_inv_s_factor,
+                                sdf_scale=m.sdf_scale, aabb=m.accel.aabb)
+    n_act = int(m.field_meta.lotd.n_active_levels)
+    if n_act:
+        p.spec.n_active = n_act
+    return p
+
+
+def oracle_of_distant(dm):
+    """oracle.distant.DistantParams carrying the weights of a product LoTDNeRFDistantModel."""
+    from oracle import distant as od
+    c = dm._ctor
+    auto = dict(c.get("lotd_auto_compute_cfg") or {})
+    ext = (dm.aabb[1] - dm.aabb[0]).detach().cpu().tolist()
+    aspect = ext if (dm.lotd_use_cuboid and max(ext) / min(ext) > 1.0 + 1e-6) else None
+    spec = od.make_ngp4d_spec(auto.get("target_num_params", 8 * 2 ** 20), auto.get("min_res_xyz", 8), auto.get("min_res_w", 4),
+                              2, auto.get("log2_hashmap_size", 19), auto.get("per_level_scale", 1.382), aspect=aspect)
+    assert spec.n_params == dm.cfg.n_params and spec.types == dm.cfg.types
+    Fd = 2 * spec.num_levels
+    K1 = Fd + (20 if dm.use_view_dirs else 4)
+    dw, db = dm.den_w.detach().cpu().float(), dm.den_b.detach().cpu().float()
+    rw, rb = dm.rad_w.detach().cpu().float(), dm.rad_b.detach().cpu().float()
+    return od.DistantParams(spec, dm.flattened_params.detach().cpu().half().float(),
+                            [dw[:64 * Fd].view(64, Fd).clone(), dw[64 * Fd:].view(1, 64).clone()],
+                            [db[:64].clone(), db[64:].clone()],
+                            [rw[:64 * K1].view(64, K1).clone(), rw[64 * K1:64 * K1 + 4096].view(64, 64).clone(),
+                             rw[64 * K1 + 4096:].view(3, 64).clone()],
+                            [rb[:64].clone(), rb[64:128].clone(), rb[128:].clone()])
+
+
+def distant_flat_grads(pd):
+    def g(t):
+        return t.grad if t.grad is not None else torch.zeros_like(t)
+    return dict(dv_grid=g(pd.grid), dv_den_w=torch.cat([g(w).reshape(-1) for w in pd.den_w]),
+                dv_den_b=torch.cat([g(b).reshape(-1) for b in pd.den_b]),
+                dv_rad_w=torch.cat([g(w).reshape(-1) for w in pd.rad_w]),
+                dv_rad_b=torch.cat([g(b).reshape(-1) for b in pd.rad_b]))
+
+
+def oracle_of_sky(sm):
+    """(ws, bs) of oracle.sky carrying the weights of a product SimpleSky."""
+    IN, W = sm.in_dim, 256
+    w, b = sm.w.detach().cpu().float(), sm.b.detach().cpu().float()
+    ws = [w[:W * IN].view(W, IN).clone(), w[W * IN:W * IN + W * W].view(W, W).clone(), w[W * IN + W * W:].view(3, W).clone()]
+    bs = [b[:W].clone(), b[W:2 * W].clone(), b[2 * W:].clone()]
+    return ws, bs
