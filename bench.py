@@ -30,20 +30,27 @@ SPHERE_RADIUS = 0.75
 #   scatter               256 f32 atomic adds (1024 B RMW) + dh / g planes (256 B) + gn, x (24 B) = 1304 B
 #   SDF-branch backward   72 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 73 728 FLOP
 #   radiance backward     44 v_mfma_f32_32x32x16_f16 per 32-point tile                           = 45 056 FLOP
-KERNEL_MODEL = {
-    "nsim_distant_fwd": ("hbm", 12 * 16 * 4 + 128 + 16.0),      # 12 levels x 16 corners x 4 B + planes + outputs
-    "nsim_distant_bwd": ("mfma", 56 * 32768 / 32.0),            # 56 MFMA 32x32x16 per 32-point tile
-    "nsim_lotd4_scatter": ("hbm", 12 * 16 * 2 * 4 + 128 + 16.0),
-    # no-grad SDF query = level-major gather (512 B table reads + 64 B fp16 feature planes written per point) ...
-    "nsim_lotd_gather_lm": ("hbm", 576.0),
-    # ... + the decoder on the planes (64 B read; 12 v_mfma_f32_32x32x16_f16 per 32-point tile); with NSIM_SDF_FUSED=1
-    # it is the single fused point-major kernel (gather + decoder, 512 B per point)
-    "nsim_field_sdf": ("hbm", 512.0) if os.environ.get("NSIM_SDF_FUSED", "0") == "1" else ("mfma", 12 * 32768 / 32.0),
-    "nsim_field_fwd": ("hbm", 1052.0),
-    "nsim_lotd_scatter": ("hbm", 1304.0),
-    "nsim_field_bwd_sdf": ("mfma", 73728.0),
-    "nsim_field_bwd_rad": ("mfma", 45056.0),
-}
+def kernel_model(L: int = 16, L4: int = 12):
+    """entry point -> (bound, algorithmic work per sample point); L = levels of the close-range pyramid (16: configs[1];
+    19: the street config), L4 = levels of the distant model's 4-D pyramid."""
+    g = L * 8 * 2 * 2.0                                         # gather: L levels x 8 corners x 2 feats x 2 B (fp16)
+    return {
+        "nsim_distant_fwd": ("hbm", L4 * 16 * 4 + 128 + 16.0),     # L4 levels x 16 corners x 4 B + planes + outputs
+        "nsim_distant_bwd": ("mfma", 56 * 32768 / 32.0),            # 56 MFMA 32x32x16 per 32-point tile
+        "nsim_lotd4_scatter": ("hbm", L4 * 16 * 2 * 4 + 128 + 16.0),
+        # no-grad SDF query = level-major gather (table reads + 4 B per level of fp16 feature planes written per point) ...
+        "nsim_lotd_gather_lm": ("hbm", g + 4.0 * L),
+        # ... + the decoder on the planes (12 v_mfma_f32_32x32x16_f16 per 32-point tile at 2x64); with NSIM_SDF_FUSED=1
+        # it is the single fused point-major kernel (gather + decoder)
+        "nsim_field_sdf": ("hbm", g) if os.environ.get("NSIM_SDF_FUSED", "0") == "1" else ("mfma", 12 * 32768 / 32.0),
+        "nsim_field_fwd": ("hbm", g + 32.0 * L + 28.0),            # gather + the saved h / dh-dx planes + outputs
+        "nsim_lotd_scatter": ("hbm", 64.0 * L + 16.0 * L + 24.0),  # 16 f32 atomic adds per level (RMW) + dh / g planes + gn, x
+        "nsim_field_bwd_sdf": ("mfma", 73728.0),
+        "nsim_field_bwd_rad": ("mfma", 45056.0),
+    }
+
+
+KERNEL_MODEL = kernel_model()
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
@@ -109,11 +116,14 @@ def _sphere_image_cpu(o, d, radius):
     return torch.where(hit[:, None], 0.5 + 0.5 * n, torch.zeros_like(o))
 
 
-def cpu_baseline(tr, budget_s=20.0, max_iters=3):
+def cpu_baseline(tr, iters=3, iters_small=3):
     """The oracle (pure-PyTorch restatement of the reference's algorithm, kind 'port') timed on this box's host cores on
     THE SAME STEP the GPU runs: same weights, occupancy grid and camera rig, the full ray batch, the same query mode
     (``march_occ_multi_upsample_compressed``), the analytic-image targets, the uniform eikonal points, backward, Adam over
-    every parameter, and 1/16 of an occupancy refresh (4 x 2^20 SDF queries every 16 iterations on the GPU side)."""
+    every parameter, and 1/16 of an occupancy refresh (4 x 2^20 SDF queries every 16 iterations on the GPU side).
+    ``value`` = median of ``iters`` timed iterations at the bench's ray count (SURVEY sec. 8d asks the median of >= 5; three
+    keep the default bench run within minutes -- a step takes ~20 s); ``configs0`` = the same step at N = 4096 rays
+    (BASELINE configs[0], the reference's own CPU-runnable size)."""
     from oracle import field as ofield, render as orr
     m = tr.model
     p, occ = oracle_of(tr)
@@ -153,18 +163,22 @@ def cpu_baseline(tr, budget_s=20.0, max_iters=3):
         opt.step()
         return time.perf_counter() - t0
 
+    def median_of(n_rays, n):
+        ts = sorted(step(n_rays, M_full, n_refresh) for _ in range(n))
+        return ts[len(ts) // 2], ts
+
     step(512, 256, 16384)           # warms the allocator / thread pool (untimed)
-    times, spent = [], 0.0
-    while len(times) < max_iters and (spent < budget_s or not times):
-        times.append(step(N_full, M_full, n_refresh))
-        spent += times[-1]
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=N_full / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(times)} timed iteration(s) of the SAME full step ({N_full} rays, {mode}, analytic-image targets, "
-                       f"{M_full} uniform eikonal points, backward, Adam over all {sum(t.numel() for t in p.tensors())} parameters, "
-                       f"{n_refresh} occupancy-refresh queries = 1/16 of a refresh); pure-PyTorch oracle, f32, "
-                       f"{med:.2f} s per step")
+    med, ts = median_of(N_full, iters)
+    out = dict(value=N_full / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"median of {len(ts)} timed iterations of the SAME full step ({N_full} rays, {mode}, analytic-image "
+                      f"targets, {M_full} uniform eikonal points, backward, Adam over all {sum(t.numel() for t in p.tensors())} "
+                      f"parameters, {n_refresh} occupancy-refresh queries = 1/16 of a refresh); pure-PyTorch oracle, f32, "
+                      f"{med:.2f} s per step (all: {', '.join(f'{t:.2f}' for t in ts)})")
+    if iters_small > 0 and N_full != 4096:
+        med0, ts0 = median_of(4096, iters_small)
+        out["configs0"] = dict(value=4096 / med0, unit="rays/s", rays=4096, s_per_step=round(med0, 3), iterations=len(ts0),
+                               what="BASELINE configs[0] size (4096 rays/iter, the reference's CPU-runnable case), same step")
+    return out
 
 
 # fp16-MFMA rendering vs the f32 oracle on identical rays / weights (eval mode, no perturbation): asserted.
@@ -254,9 +268,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the API-path / distant-model side measurements")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-oracle rendering check (profiling runs)")
-    ap.add_argument("--rays-per-gpu", type=int, default=RAYS_PER_GPU,
+    ap.add_argument("--rays-per-gpu", type=int, default=None,
                     help="rays per iteration per GPU (8192 = BASELINE configs[1]; the 4- and 8-GPU BASELINE configs draw "
                          "16384 per GPU: 65536 / 4, 131072 / 8)")
+    ap.add_argument("--config", default="object", choices=("object", "street", "indoor", "multi"),
+                    help="object = BASELINE configs[1] (the metric's workload, default); street / indoor / multi = the shapes of "
+                         "configs[3] / [2] / [4] (neuralsim_amd/scenarios.py; 16384 rays per GPU unless --rays-per-gpu is given) -- "
+                         "what the 4- / 8-GPU BASELINE configs run per GPU")
     ap.add_argument("--distant", action="store_true",
                     help="add the NeRF++ distant-view model (64 shells on every ray), as in the reference's full config")
     ap.add_argument("--sky", action="store_true", help="add the sky MLP (SimpleSky, street configs) blended per ray")
@@ -271,12 +289,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.get_lib()
-    tr = build_trainer(dev, rank, world, distant=args.distant, sky=args.sky, sdf_D=args.sdf_depth,
-                       rays_per_gpu=args.rays_per_gpu)
-    out, it = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=args.rays_per_gpu)
+    if args.rays_per_gpu is None:
+        args.rays_per_gpu = RAYS_PER_GPU if args.config == "object" else 16384
+    if args.config == "object":
+        tr = build_trainer(dev, rank, world, distant=args.distant, sky=args.sky, sdf_D=args.sdf_depth,
+                           rays_per_gpu=args.rays_per_gpu)
+        workload = None
+    else:
+        tr = build_config_trainer(args.config, dev, rank, world, args.rays_per_gpu)
+        workload = WORKLOADS[args.config]
+    out, it = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=args.rays_per_gpu, workload=workload)
     if world > 1:
         it = measure_exposed_allreduce(tr, out, min(args.steps, 32), it, rank, dev)
-    if rank == 0:
+    if rank == 0 and args.config != "object":
+        out["config"]["name"] = args.config
+        out["config"]["launch_chain"] = "autograd"
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
         out["config"]["distant_model"] = bool(args.distant)
         out["config"]["sky_model"] = bool(args.sky)
         out["config"]["sdf_mlp"] = f"{args.sdf_depth}x64"
@@ -294,6 +323,14 @@ def main():
             var["distant_ms"], _ = time_steps(trd, 16, 8, 257)
             del trd
             torch.cuda.empty_cache()
+            # the other BASELINE configurations at their per-GPU shapes (configs[3] / [2] / [4]: 16384 rays), a few steps
+            # each; their oracle parity is tests/test_fullsize_configs.py
+            for name in ("street", "indoor", "multi"):
+                trc = build_config_trainer(name, dev, rank, world, 16384)
+                var[name + "_ms"], _ = time_steps(trc, 12, 6, 257)
+                var[name + "_samples_per_hit_ray"] = round(trc.stats["S_f"] / max(1, trc.stats["R_hit"]), 1)
+                del trc
+                torch.cuda.empty_cache()
             # a full 800 x 800 evaluation view (code_single/tools/eval.py:241-316: rayschunk pieces, validation renderer
             # settings), timed, and its PSNR against the analytic image the model is being trained on
             from neuralsim_amd.eval import psnr, render_image
@@ -316,7 +353,13 @@ def main():
             var["eval_psnr_vs_target_db"] = round(eval_psnr, 2)
             var["api_path_rays_per_s"] = round(args.rays_per_gpu / var["api_path_ms"] * 1e3, 1)
             var["distant_rays_per_s"] = round(args.rays_per_gpu / var["distant_ms"] * 1e3, 1)
+            for name in ("street", "indoor", "multi"):
+                var[name + "_rays_per_s"] = round(16384 / var[name + "_ms"] * 1e3, 1)
             out["variants"] = var
+            # the reference's FULL object-centric config has the distant-view model on every ray
+            # (lotd_neus.dtu.230814.yaml:186-247); BASELINE configs[1] names the hash-grid NeuS only -> `value` is without it
+            out["with_distant_model"] = dict(value=var["distant_rays_per_s"], unit="rays/s", ms_per_step=var["distant_ms"],
+                                             steps=16, note="same workload + NeRF++ distant model (64 shells on every ray)")
         if plain and not args.no_parity:
             out["parity"] = parity_check(tr)
         if plain and not args.no_cpu_baseline:
@@ -330,7 +373,35 @@ def main():
         dist.destroy_process_group()
 
 
-def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
+WORKLOADS = {
+    "street": "BASELINE configs[3] shape: StreetSurf street view (synthetic 6-camera rig on a 200 x 100 x 30 m analytic street), "
+              "{rays} rays/iter/GPU, cuboid 19-level LoTD (T=2^20, ~33 Mi params) + 1x64 SDF MLP (sdf_scale 25) + 2x64 radiance, occ grid "
+              "200x100x30 (1 m voxels), num_coarse 128, num_fine [8,8,32], step .2, upsample_use_estimate_alpha false, compressed query, "
+              "distant NeRF++ model (64 cuboid shells, 16 Mi 4-D table, no view dirs) + sky MLP, l1 photometric + eikonal on render samples "
+              "and 2^16 uniform points, Adam + occupancy refresh inside the timed region",
+    "indoor": "BASELINE configs[2] shape: MonoSDF indoor (synthetic box room seen from inside, inside_out), {rays} rays/iter/GPU = 64x64 image "
+              "patch + pixel rays, L=16 hashgrid (T=2^19) + 2x64 SDF MLP + 2x64 radiance, normals + depth rendered with gradient, losses "
+              "mse + eikonal + mono normal (l1 + cos) + scale-shift-invariant mono depth on the patch, Adam + occupancy refresh",
+    "multi": "BASELINE configs[4] shape: code_multi scene graph -- street background (as configs[3]) + 8 posed instances of one shared "
+             "batched vehicle model (8 dense levels 5..144, per-instance tables, batched occ grid 8x32^3, num_coarse 32, num_fine [8,8]) + "
+             "distant + sky through the BufferComposeRenderer mirror, {rays} rays/iter/GPU, l1 photometric + eikonal, Adam on every model",
+}
+
+
+def build_config_trainer(name, dev, rank, world, rays_per_gpu, precision="fp16"):
+    """Trainer of one BASELINE configuration: "object" = configs[1] (the metric's), "street" / "indoor" / "multi" = the
+    shapes of configs[3] / [2] / [4] (neuralsim_amd/scenarios.py)."""
+    from neuralsim_amd import scenarios as sc
+    if name == "street":
+        return sc.build_street_trainer(dev, rank, world, precision=precision, rays_per_gpu=rays_per_gpu)
+    if name == "indoor":
+        return sc.build_indoor_trainer(dev, rank, world, precision=precision, rays_per_gpu=rays_per_gpu)
+    if name == "multi":
+        return sc.build_multi_trainer(dev, rank, world, precision=precision, rays_per_gpu=rays_per_gpu)
+    raise ValueError(name)
+
+
+def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; the elapsed
     time is the MAX over ranks; rank 0 returns the JSON record (other ranks None) and the next iteration number."""
     from neuralsim_amd import _lib
@@ -358,7 +429,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
         gc.disable()
     fence()
     # HIP events around the modelled kernels only (on the launch stream)
-    _lib.TIMER = _lib.KernelTimer(only=KERNEL_MODEL.keys()) if on_gpu else None
+    dm_ = getattr(tr, "distant_model", None) or getattr(tr, "distant", None)
+    KM = kernel_model(tr.model.encoding.cfg.num_levels, dm_.cfg.num_levels if dm_ is not None else 12)
+    _lib.TIMER = _lib.KernelTimer(only=KM.keys()) if on_gpu else None
     S_f = S_hit = 0
     marks = []
     t0 = time.perf_counter()
@@ -396,9 +469,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
                     unit="rays/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(ms, 3),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
                     config=dict(workload="emulator smoke run"), roofline=None), it
-    dom = max((k for k in ksum if k in KERNEL_MODEL), key=lambda k: ksum[k]["total_ms"])
+    dom = max((k for k in ksum if k in KM), key=lambda k: ksum[k]["total_ms"])
     kd = ksum[dom]
-    bound, per_pt = KERNEL_MODEL[dom]
+    bound, per_pt = KM[dom]
     work_per_launch = kd["units"] * per_pt / max(1, kd["calls"])
     if bound == "hbm":
         achieved, peak, unit = work_per_launch / (kd["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -407,18 +480,25 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
     roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 3), peak=peak, unit=unit,
                     frac=round(achieved / peak, 5), traffic=None, avg_launch_ms=round(kd["avg_ms"], 4),
                     points_per_launch=kd["units"] / max(1, kd["calls"]), work_per_point=per_pt)
-    tf = ROOT / "profiles" / "traffic.json"      # per-launch HBM bytes from rocprofv3 PMC passes, if recorded
-    if tf.exists():
+    if bound == "hbm":
+        # the same rate against the copy bandwidth measured on this chip (MI355X_MICROARCH.md: 6.29 TB/s) next to the 8 TB/s spec
+        roofline["frac_of_measured_copy_6290GBs"] = round(achieved / 6290.0, 5)
+    tf = ROOT / "profiles" / "traffic.json"      # per-launch HBM bytes from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE)
+    if tf.exists() and workload is None:
         try:
-            roofline["traffic"] = json.loads(tf.read_text()).get(dom)
+            rec_t = json.loads(tf.read_text())
+            roofline["traffic"] = rec_t.get(dom)
+            roofline["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "bench command, recorded " + str(rec_t.get("_recorded", "in an earlier profiling "
+                                          "run")) + " -- NOT collected by the run that prints this line")
         except Exception:
             pass
     # per-kernel roofline of every modelled entry point (the MFMA kernels against the dense fp16 peak)
     per_kernel = {}
     for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"]):
-        if k not in KERNEL_MODEL or not v["calls"] or not v["units"]:
+        if k not in KM or not v["calls"] or not v["units"]:
             continue
-        b_, w_ = KERNEL_MODEL[k]
+        b_, w_ = KM[k]
         rate = v["units"] * w_ / (v["total_ms"] * 1e-3)
         per_kernel[k] = dict(calls=v["calls"], total_ms=round(v["total_ms"], 3), avg_ms=round(v["avg_ms"], 4), bound=b_,
                              frac=round(rate / (HBM_PEAK_GBS * 1e9 if b_ == "hbm" else MFMA_PEAK_TFLOPS * 1e12), 5))
@@ -427,13 +507,14 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu):
     out = dict(metric="training rays/sec (fwd+bwd) NeuS 800x800", value=round(total_rays / elapsed, 1),
                unit="rays/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(ms, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
-               config=dict(workload="BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
+               config=dict(workload=workload.format(rays=rays_per_gpu) if workload else
+                           "BASELINE configs[1]: NeuS single object (DTU scan24-style synthetic), "
                                     f"{rays_per_gpu} rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + {tr.model.sdf_D}x64 SDF MLP + 2x64 radiance "
                                     "MLP (SH4, appear 4), synthetic sphere r=0.75 (~40% coverage) supervised by its analytic image, occ grid 64^3, num_coarse 64, "
                                     "num_fine [8,8,32], "
                                     "step .005, query_mode march_occ_multi_upsample_compressed (reference default), inv_s=e^5, eikonal on "
                                     "render samples + 4096 uniform points, "
-                                    "Adam + occupancy refresh every 16 it inside the timed region",
+                           "Adam + occupancy refresh every 16 it inside the timed region",
                            rays_per_gpu=rays_per_gpu, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
                            samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
                            hit_fraction=round(S_hit / (rays_per_gpu * steps), 3)),

@@ -415,6 +415,12 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
   for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += wstride) {
     const NerfPoint p = nerf_point(a, tile, j);
     const int64_t s = p.s;
+    if constexpr (BWD) {
+      // a tile without a single live shell (behind an opaque foreground: the renderer's transmittance mask, folded into
+      // ``valid`` by the host) contributes nothing -- its planes are not read, its dh rows not written (the scatter
+      // skips the same shells)
+      if (wave_ballot(p.valid && a.valid[s] != 0) == 0ull) continue;
+    }
     // -------------------------------------------------------------- features: gather (forward) or planes (backward)
     float rin[32];  // [0,16): own features (first M-tile of the radiance input), [16,32): SH / appearance slots
     if constexpr (!BWD) {

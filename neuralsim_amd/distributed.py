@@ -58,8 +58,9 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
     ``wire_dtype`` (default: env NSIM_ALLREDUCE_DTYPE = bf16 | f32, bf16 if unset): the big tensors (the 12.2 M-entry
     hash-table gradient, 48.8 MB in f32) travel in this type.  The reference trains fp16 parameters under DDP, i.e. it
     all-reduces 2-byte gradients as well (code_single/tools/train.py:1401-1412); bf16 keeps the f32 exponent range, so
-    no loss scale is needed.  xGMI rings are per-link bound: halving the bytes halves the exposed time of the one
-    collective of the step."""
+    no loss scale is needed.  xGMI links are per-link bound: halving the bytes halves the exposed time of the one
+    collective of the step.  A 2-byte wire uses the ``direct`` schedule (``_DirectToken``: one rounding per
+    contribution, f32 accumulation) instead of the backend's ring all-reduce, which accumulates in the wire type."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     if wire_dtype is None:
@@ -73,8 +74,9 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
         (big if p.grad.numel() >= small_numel else small).append(p)
     handles = []
     for p in big:
-        buf = p.grad if wire_dtype == torch.float32 else p.grad.to(wire_dtype)
-        handles.append((p, buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)))
+        if not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
+        handles.append(allreduce_start(p.grad, wire_dtype))
     if small:
         flat = torch.cat([p.grad.reshape(-1) for p in small])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -83,10 +85,8 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
-    for p, buf, h in handles:
-        h.wait()
-        if buf is not p.grad:
-            p.grad.copy_(buf)
+    for tok in handles:
+        allreduce_finish(tok)
     if average:
         for p in params:
             p.grad.div_(world)
@@ -97,17 +97,62 @@ def wire_dtype_default() -> torch.dtype:
         os.environ.get("NSIM_ALLREDUCE_DTYPE", "bf16")]
 
 
+def _algo(wire_dtype: torch.dtype) -> str:
+    """``direct`` (default for a 2-byte wire) | ``ring`` (the backend's own all-reduce; default for an f32 wire) --
+    env NSIM_ALLREDUCE_ALGO overrides."""
+    a = os.environ.get("NSIM_ALLREDUCE_ALGO")
+    return a if a in ("direct", "ring") else ("ring" if wire_dtype == torch.float32 else "direct")
+
+
+class _DirectToken:
+    """Sum-all-reduce as all-to-all + local f32 reduction + all-gather.
+
+    Why not the backend's all-reduce for the 2-byte wire: a ring all-reduce ACCUMULATES in the wire type -- a bf16 sum
+    over 8 ranks rounds after every hop (seven roundings of a growing partial sum).  Here every rank's contribution is
+    rounded to the wire type ONCE, the W contributions of a shard are summed in f32 on the rank that owns the shard, and
+    the total is rounded once more for the way back: the error does not grow with the world size.  Bytes per rank are
+    those of a ring (2 (W-1)/W of the buffer), and on xGMI -- a full mesh of point-to-point links, 7 per GPU -- every
+    rank talks to every peer over its own link in both phases instead of pushing W-1 hops around one ring."""
+
+    def __init__(self, t: torch.Tensor, wire_dtype: torch.dtype):
+        W = dist.get_world_size()
+        n = t.numel()
+        chunk = (n + W - 1) // W
+        flat = t.reshape(-1)
+        send = torch.zeros([W * chunk], dtype=wire_dtype, device=t.device) if W * chunk != n else None
+        if send is None:
+            send = flat.to(wire_dtype).contiguous()
+        else:
+            send[:n] = flat
+        self.t, self.n, self.W, self.chunk, self.wire = t, n, W, chunk, wire_dtype
+        self.recv = torch.empty_like(send)
+        self.send = send
+        self.h = dist.all_to_all_single(self.recv, send, async_op=True)
+
+    def finish(self) -> torch.Tensor:
+        self.h.wait()
+        part = self.recv.view(self.W, self.chunk).float().sum(0).to(self.wire)
+        out = torch.empty([self.W * self.chunk], dtype=self.wire, device=self.t.device)
+        dist.all_gather_into_tensor(out, part)
+        self.t.reshape(-1).copy_(out[:self.n])
+        return self.t
+
+
 def allreduce_start(t: torch.Tensor, wire_dtype: Optional[torch.dtype] = None):
     """Begin an asynchronous sum-all-reduce of ``t`` (travelling as ``wire_dtype``); collectives complete in issue
     order, so a caller interleaves them with the kernels that produce the next tensor.  -> token for
     ``allreduce_finish``."""
     wire_dtype = torch.float32 if wire_dtype is None else wire_dtype
+    if _algo(wire_dtype) == "direct" and t.is_contiguous():
+        return _DirectToken(t, wire_dtype)
     buf = t if (wire_dtype == t.dtype and t.is_contiguous()) else t.to(wire_dtype).contiguous()
     return t, buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 
 
 def allreduce_finish(token):
     """Wait for ``allreduce_start`` and write the sum back into the original tensor."""
+    if isinstance(token, _DirectToken):
+        return token.finish()
     t, buf, h = token
     h.wait()
     if buf is not t:

@@ -61,7 +61,11 @@ class LoTD4Config:
 
 class _DistantFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, grid, den_w, den_b, rad_w, rad_b, h_appear, u4, rays_d, valid, K):
+    def forward(ctx, model, grid, den_w, den_b, rad_w, rad_b, h_appear, u4, rays_d, valid, K, holder=None):
+        """holder: a dict the renderer may fill AFTER the joint compositing with ``keep`` [S] uint8 -- the shells whose
+        transmittance in the joint ray is above the renderer's threshold; the backward then treats the others as
+        invalid (their visibility weight and everything behind them is negligible: an opaque foreground, or the shells
+        behind a dense one) and neither runs their MLP backward nor scatters their table gradient."""
         S = u4.shape[0]
         dev = u4.device
         grid16, wpack = model._shadow()
@@ -79,6 +83,7 @@ class _DistantFn(torch.autograd.Function):
             _lib.TIMER.note_units("nsim_distant_bwd", S)
             _lib.TIMER.note_units("nsim_lotd4_scatter", S)
         ctx.model, ctx.S, ctx.K = model, S, K
+        ctx.holder = holder        # a plain dict of the caller's (no tensor of this node inside: no reference cycle)
         # save_for_backward, not a ctx attribute: sigma / rgb are OUTPUTS (output -> grad_fn -> ctx -> output would be a
         # reference cycle that only the cyclic collector frees: 80 MB per step at 8192 rays x 64 shells)
         ctx.save_for_backward(u4, rays_d, valid, ha, h_pl, sigma, rgb)
@@ -100,6 +105,9 @@ class _DistantFn(torch.autograd.Function):
         dh_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
         gs = g_sigma.float().contiguous() if g_sigma is not None else None
         gr = g_rgb.float().contiguous() if g_rgb is not None else None
+        keep = ctx.holder.get("keep") if ctx.holder is not None else None
+        if keep is not None:
+            valid = valid & keep.reshape(-1)
         _lib.call("nsim_distant_bwd", model.meta, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(sigma.detach()),
                   _lib.ptr(rgb.detach()), _lib.ptr(rays_d), _lib.ptr(ha), _lib.ptr(valid), ctx.S, ctx.K, _lib.ptr(gs),
                   _lib.ptr(gr), _lib.ptr(dh_pl), _lib.ptr(dden_w), _lib.ptr(dden_b), _lib.ptr(drad_w), _lib.ptr(drad_b),
@@ -107,7 +115,7 @@ class _DistantFn(torch.autograd.Function):
         if dgrid is not None:
             _lib.call("nsim_lotd4_scatter", model.cfg.meta, _lib.ptr(u4), _lib.ptr(valid), ctx.S, _lib.ptr(dh_pl),
                       _lib.ptr(dgrid))
-        return (None, dgrid, dden_w, dden_b, model._contract_rad_w(drad_w), drad_b, dha, None, None, None, None)
+        return (None, dgrid, dden_w, dden_b, model._contract_rad_w(drad_w), drad_b, dha, None, None, None, None, None)
 
 
 class _DensityAlphaFn(torch.autograd.Function):
@@ -319,12 +327,13 @@ class LoTDNeRFDistantModel(ModelMixin, nn.Module):
         _lib.call("nsim_distant_shells", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(jitter), N, K, aabb6,
                   self.r_min, self.r_max, _lib.ptr(t), _lib.ptr(u4), _lib.ptr(valid))
         h_appear = ray_tested.get("rays_h_appear", None)
+        holder = {}
         sigma, rgb = _DistantFn.apply(self, self.flattened_params, self.den_w, self.den_b, self.rad_w, self.rad_b,
-                                      h_appear, u4, d, valid, K)
+                                      h_appear, u4, d, valid, K, holder)
         alpha = _DensityAlphaFn.apply(sigma, t.reshape(-1), valid, N, K, self.include_inf)
         vb = dict(type="batched", rays_inds_hit=torch.arange(N, device=dev), num_per_hit=K, t=t,
                   opacity_alpha=alpha.view(N, K), rgb=rgb.view(N, K, 3), sigma=sigma.view(N, K), valid=valid.view(N, K))
-        ret = dict(volume_buffer=vb)
+        ret = dict(volume_buffer=vb, _bwd_holder=holder)
         if render_per_obj_individual:       # this model alone (single_volume_renderer.py:313-317): all rays are "hit"
             from ..graphics.nerf import ray_alpha_to_vw
             vw = ray_alpha_to_vw(alpha.view(N, K))

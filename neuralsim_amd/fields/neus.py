@@ -312,9 +312,9 @@ class _CompositeFn(torch.autograd.Function):
 def volume_integration(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw=False, rays_inds=None,
                        num_rays: int = None) -> Dict[str, torch.Tensor]:
     """``rays_inds`` [P] + ``num_rays``: results as zero-filled [num_rays, ...] images with pack p at row rays_inds[p]."""
-    vw, mask, depth, rgb_o, nrm_o, _ = _CompositeFn.apply(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw,
-                                                         rays_inds, num_rays)
-    out = dict(vw=vw, mask_volume=mask, depth_volume=depth)
+    vw, mask, depth, rgb_o, nrm_o, trans = _CompositeFn.apply(alpha, t, rgb, nablas, pack_infos, depth_use_normalized_vw,
+                                                             rays_inds, num_rays)
+    out = dict(vw=vw, mask_volume=mask, depth_volume=depth, trans=trans)
     if rgb is not None:
         out["rgb_volume"] = rgb_o
     if nablas is not None:
@@ -1295,6 +1295,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                                  rays_inds=ray_tested["rays_inds"] if n_all is not None else None,
                                                  num_rays=n_all)
             ret["rendered"].pop("vw", None)
+            ret["rendered"].pop("trans", None)
         if return_details:
             ret["details"] = dict(march_counts=march_counts, sdf_nograd=sdf_ng, ridx=ridx)
         if cfg.get("with_near_sdf", False):

@@ -211,6 +211,9 @@ class BufferComposeRenderer(nn.Module):
                 vb = raw["volume_buffer"]
                 if vb["type"] != "empty":
                     vb["vw_in_total"] = out["vw"][ranks[vb["pidx_in_total"]]]
+                    thre = float(cfgd.get("distant_bwd_trans_thre", 1e-4))
+                    if thre > 0 and self.training and "_bwd_holder" in raw:
+                        raw["_bwd_holder"]["keep"] = (out["trans"][ranks[vb["pidx_in_total"]]] >= thre).to(torch.uint8)
         norm_depth = cfgd.get("depth_use_normalized_vw", True)
 
         def share(vb, pack_infos):

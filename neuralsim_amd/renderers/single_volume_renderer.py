@@ -199,6 +199,10 @@ class SingleVolumeRenderer(nn.Module):
             tvb["vw"] = out["vw"]
             if pidx_cr is not None:
                 vb["vw_in_total"], dv_vb["vw_in_total"] = out["vw"][pidx_cr], out["vw"][pidx_dv]
+                thre = float(config.get("distant_bwd_trans_thre", 1e-4))
+                if thre > 0 and self.training and "_bwd_holder" in dv_ret:
+                    # shells behind an (almost) opaque stretch of the joint ray: no backward, no table scatter for them
+                    dv_ret["_bwd_holder"]["keep"] = (out["trans"][pidx_dv] >= thre).to(torch.uint8)
             elif vb["type"] != "empty":
                 vb["vw"] = vb["vw_in_total"] = out["vw"]
             else:

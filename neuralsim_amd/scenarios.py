@@ -397,6 +397,10 @@ class ComposeTrainer:
         self.skip_allreduce = False
         self.stats: Dict[str, float] = {}
 
+    @property
+    def model(self):
+        return self.street
+
     def sample_batch(self):
         dev, N = self.street.device, self.num_rays
         xy = torch.rand([N, 2], device=dev, generator=self.gen).clamp_(1e-6, 1 - 1e-6)

@@ -185,3 +185,54 @@ def test_renderer_merges_close_range_and_distant(backend):
     assert float(out["rendered"]["mask_volume"].min()) > 0.99          # include_inf_distance: every ray is opaque
     out["rendered"]["rgb_volume"].sum().backward()
     assert float(dm.flattened_params.grad.abs().sum()) > 0 and float(model.sdf_w.grad.abs().sum()) > 0
+
+
+def test_backward_skips_shells_behind_an_opaque_stretch(backend):
+    """The renderer hands the distant model's backward a transmittance mask (``distant_bwd_trans_thre``, 1e-4 like the
+    compressed query's weight threshold): shells whose transmittance in the JOINT ray is below it get no MLP backward and
+    no table scatter.  Against the unmasked backward the gradients move by the dropped weights only."""
+    from neuralsim_amd.fields.neus import OccGridAccel
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    from util import make_params, model_from_params
+    p = make_params(sdf_D=1, small=True, sphere=True, seed=3, ln_inv_s=0.7, grid_bound=2e-2, noise_scale=1.0)   # sharp surface
+    spec = od.make_ngp4d_spec(target_num_params=2 ** 14, min_res_xyz=3, min_res_w=2, log2_hashmap_size=10)
+    pd = od.make_distant_params(spec, grid_bound=0.5)
+    g = torch.Generator().manual_seed(5)
+    N = 40
+    intr, c2w, WH = look_at_cameras(V=3, seed=3)
+    o, d = orr.pinhole_rays(torch.rand(N, 2, generator=g) * 0.6 + 0.2, torch.randint(0, 3, (N,), generator=g), intr, c2w, WH)
+    o[::5] += torch.tensor([0.0, 4.0, 0.0])                   # rays that see the background only
+    ha = torch.randn(N, 4, generator=g) * 0.3
+    res = [16, 16, 16]
+    val, _ = orr.build_occ_grid(p, AABB[0], AABB[1], res, n_pts=2 ** 13, n_steps=2)
+    model = model_from_params(p, backend, precision="f32")
+    model.accel = OccGridAccel(AABB, resolution=res, device=backend)
+    model.accel.occ_val.copy_(val.to(backend))
+    model.accel.pack_bits()
+    model.ray_query_cfg = dict(query_mode="march_occ_multi_upsample",
+                               query_param=dict(num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+                                                upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128)))
+    dm = _model_from(pd, backend, "f32")
+    dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+    wgt = torch.rand(N, 3, generator=g)
+    grads, kept = {}, {}
+    for thre in (0.0, 1e-4):
+        rend = SingleVolumeRenderer(dict(with_rgb=True, near=0.01, depth_use_normalized_vw=False,
+                                         distant_bwd_trans_thre=thre)).train()
+        for q in dm.parameters():
+            q.grad = None
+        out = rend.render(model, rays=[dv(o), dv(d)], rays_h_appear=dv(ha), distant_model=dm, return_buffer=True,
+                          return_details=True)
+        holder = out["raw_per_obj_model"]["distant"]["_bwd_holder"]
+        kept[thre] = holder.get("keep")
+        (out["rendered"]["rgb_volume"] * dv(wgt)).sum().backward()
+        grads[thre] = [q.grad.clone() for q in (dm.flattened_params, dm.den_w, dm.rad_w)]
+    assert kept[0.0] is None
+    k = kept[1e-4].view(N, -1).cpu()
+    mask = out["rendered"]["mask_volume"].detach().cpu()
+    assert 0 < int((k == 0).sum()) < k.numel()               # some shells sit behind the surface, some rays see far
+    # the dropped shells carry < 1e-4 of the pixel: every gradient moves by about that much, not more
+    for a, b in zip(grads[1e-4], grads[0.0]):
+        assert rel_l2(a.cpu(), b.cpu()) < 2e-3
+    assert float((grads[1e-4][0] != 0).float().mean()) <= float((grads[0.0][0] != 0).float().mean())
+    assert float(mask.max()) > 0.99

@@ -50,6 +50,12 @@ def main():
             "MI355X_MICROARCH.md applies to wide coalesced streams only and is NOT applied here -- the gather / atomic "
             "access widths of these kernels are uncalibrated. Counters are memory-side (Infinity-Cache hits included).")
     (P / f"{TAG}_rocprofv3_pmc_hbm.json").write_text(json.dumps(dict(note=note, kernels=out), indent=1))
+    import subprocess
+    try:
+        sha = subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        sha = "?"
+    traffic["_recorded"] = f"{TAG} (tree after commit {sha})"
     (P / "traffic.json").write_text(json.dumps(traffic, indent=1))
     gp = G / "prof_gaps.json"
     if gp.exists():
