@@ -39,6 +39,7 @@ struct FieldLayout {
   int64_t vec[V_COUNT];
   int64_t total;
   int elt;               // bytes per matrix element (2 | 4)
+  int split;             // 1: every matrix is TWO f16 fragment sets, W = hi + lo / SPLIT_LO_SCALE (precision 2)
 };
 
 static const int kMatUo[M_COUNT] = {64, 64, 64, 32, 64, 64, 32, 64, 64, 32};
@@ -53,6 +54,7 @@ static inline int field_nc(int num_levels) { return num_levels > 16 ? 2 : 1; }
 static inline FieldLayout field_layout(int precision, int nc = 1) {
   FieldLayout L;
   L.elt = precision == 0 ? 2 : 4;
+  L.split = precision == 2 ? 1 : 0;
   int64_t off = 0;
   for (int m = 0; m < M_COUNT; ++m) {
     L.mat[m] = off;
@@ -96,6 +98,16 @@ __host__ __device__ inline SrcOff src_off(int D, int F1 = 32) {
 
 
 // ------------------------------------------------------------------------------------ weight packing
+// precision 2 ("split"): an f32 value travels through the f16 matrix cores as v = hi + lo / SPLIT_LO_SCALE with
+// hi = f16(v), lo = f16((v - hi) * SPLIT_LO_SCALE) -- 22 significant bits; a product W . x is three MFMAs (hi.hi into the
+// main accumulator, hi.lo + lo.hi into a correction accumulator that is folded in with 1 / SPLIT_LO_SCALE), the
+// dropped lo.lo term is 2^-22 relative.  The scale keeps the residuals out of the f16 subnormals.
+#define SPLIT_LO_SCALE 2048.0f
+__device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
+  hi = (f16)v;
+  lo = (f16)((v - (float)hi) * SPLIT_LO_SCALE);
+}
+
 __device__ __forceinline__ float pack_src(int mat, int row, int col, int D, int F1, const float* sdf_w,
                                           const float* rad_w) {
   const SrcOff o = src_off(D, F1);
@@ -130,14 +142,17 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
     if (tid >= base && tid < base + cnt) {
       const int64_t k = tid - base;
       int row, col;
-      if (L.elt == 2) {
+      if (L.elt == 2 || L.split) {
         const int e = (int)(k & 7), lane = (int)((k >> 3) & 63);
         const int fs = (int)(k >> 9);
         const int nS = Ui / 16;
         const int mo = fs / nS, s = fs % nS;
         row = 32 * mo + (lane & 31);
         col = 16 * s + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        ((f16*)(wpack + L.mat[m]))[k] = (f16)pack_src(m, row, col, D, F1, sdf_w, rad_w);
+        const float w = pack_src(m, row, col, D, F1, sdf_w, rad_w);
+        const f16 whi = (f16)w;
+        ((f16*)(wpack + L.mat[m]))[k] = whi;
+        if (L.split) ((f16*)(wpack + L.mat[m]))[cnt + k] = (f16)((w - (float)whi) * SPLIT_LO_SCALE);
       } else {
         const int lane = (int)(k & 63);
         const int fr = (int)(k >> 6);
@@ -313,7 +328,7 @@ template <int PREC>
 __device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs& a, int first, int count,
                                                      FieldLayout& Lk, int& lds_used) {
   Lk = a.lay;
-  if constexpr (PREC == 0) {
+  if constexpr (PREC != 1) {
     const int64_t m0 = a.lay.mat[first];
     const int64_t m1 = (first + count < M_COUNT) ? a.lay.mat[first + count] : a.lay.vec[0];
     const int64_t mbytes = m1 - m0, vbytes = a.lay.total - a.lay.vec[0];
@@ -1365,6 +1380,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       p = load_point(a, tile, j, false);
     }
     f32x16 acc[2] = {zero16(), zero16()};
+    f32x16 accc[PREC == 2 ? 2 : 1];            // split mode: the hi.lo + lo.hi correction, in units of 1 / SPLIT_LO_SCALE
+    if constexpr (PREC == 2) accc[0] = accc[1] = zero16();
 #pragma unroll 1
     for (int rb = 0; rb < 2 * NC; ++rb) {      // one K-step of 8 features per lane-half: levels 16 (rb/2) + 8 (rb%2) + ..
       const int lb = 16 * (rb >> 1) + 8 * (rb & 1);
@@ -1428,6 +1445,24 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
         const f16x8* A = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
 #pragma unroll
         for (int mo = 0; mo < 2; ++mo) acc[mo] = mfma_32x32x16_f16(A[(mo * 2 * NC + rb) * 64 + lane], bv, acc[mo]);
+      } else if constexpr (PREC == 2) {
+        f16x8 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f16 h_, l_;
+          split_f16(f8[e] * SDF_H_SCALE, h_, l_);
+          bh[e] = h_;
+          bl[e] = l_;
+        }
+        const f16x8* Ah = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
+        const f16x8* Al = Ah + 64 * 4 * NC;           // lo fragments follow the [64 x 32 NC] hi ones
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo) {
+          const int fi = (mo * 2 * NC + rb) * 64 + lane;
+          acc[mo] = mfma_32x32x16_f16(Ah[fi], bh, acc[mo]);
+          accc[mo] = mfma_32x32x16_f16(Ah[fi], bl, accc[mo]);
+          accc[mo] = mfma_32x32x16_f16(Al[fi], bh, accc[mo]);
+        }
       } else {
         const float* A = reinterpret_cast<const float*>(W + L.mat[M_W1]);
 #pragma unroll
@@ -1437,9 +1472,52 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
             acc[mo] = mfma_32x32x2_f32(A[(mo * 16 * NC + 8 * rb + e) * 64 + lane], f8[e], acc[mo]);
       }
     }
-    const float inv_h = PREC == 0 ? 1.0f / SDF_H_SCALE : 1.0f;
+    const float inv_h = PREC != 1 ? 1.0f / SDF_H_SCALE : 1.0f;
     float sdf = 0.f;
-    if constexpr (PREC == 0 && SDF_D == 2) {
+    if constexpr (PREC == 2) {
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mo][r] = acc[mo][r] + accc[mo][r] * (1.0f / SPLIT_LO_SCALE);
+    }
+    if constexpr (PREC == 2 && SDF_D == 2) {
+      // second layer on split operands: activations and weights as hi + lo, three MFMAs per K-step
+      f16x8 bqh[4], bql[4];
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          f16 h_, l_;
+          split_f16(softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta), h_, l_);
+          bqh[2 * mo + (r >> 3)][r & 7] = h_;
+          bql[2 * mo + (r >> 3)][r & 7] = l_;
+        }
+      const f16x8* A2h = reinterpret_cast<const f16x8*>(W + L.mat[M_W2]);
+      const f16x8* A2l = A2h + 64 * 8;                 // [64 x 64] hi fragments: 8 per lane
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) {
+        f32x16 acc2 = zero16(), acc2c = zero16();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int fi = (mo * 4 + st) * 64 + lane;
+          acc2 = mfma_32x32x16_f16(A2h[fi], bqh[st], acc2);
+          acc2c = mfma_32x32x16_f16(A2h[fi], bql[st], acc2c);
+          acc2c = mfma_32x32x16_f16(A2l[fi], bqh[st], acc2c);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
+                          softplus_b(acc2[r] + acc2c[r] * (1.0f / SPLIT_LO_SCALE) + vecf(W, L, V_B2, hi, mo * 16 + r), beta,
+                                     inv_beta);
+      }
+    } else if constexpr (PREC == 2) {
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
+                          softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+    } else if constexpr (PREC == 0 && SDF_D == 2) {
       // register-lean second layer: layer-1 activations are packed to f16 B fragments at once (16 VGPRs), each
       // output M-tile is consumed by the head dot-product as soon as its four MFMAs retire
       f16x8 bq[4];
@@ -1885,8 +1963,13 @@ static int field_meta_check(const NsimFieldMeta* m) {
   if (rc) return rc;
   if (m->lotd.num_levels < 1 || m->lotd.num_levels > 32) return 21;
   if (m->sdf_D != 1 && m->sdf_D != 2) return 22;
-  if (m->precision != 0 && m->precision != 1) return 23;
+  if (m->precision != 0 && m->precision != 1 && m->precision != 2) return 23;
   return 0;
+}
+// precision 2 (split f16: f32-equivalent arithmetic on the f16 matrix cores) exists for the no-grad SDF query only
+static int field_meta_check_full(const NsimFieldMeta* m) {
+  const int rc = field_meta_check(m);
+  return rc ? rc : (m->precision == 2 ? 23 : 0);
 }
 
 static FieldArgs field_args(const NsimFieldMeta* meta) {
@@ -1906,8 +1989,8 @@ static unsigned field_grid(int64_t S, int64_t max_blocks, int waves = FIELD_WAVE
 }
 
 static size_t weights_lds_bytes(const NsimFieldMeta* meta, int first = 0, int count = M_COUNT) {
-  if (meta->precision != 0) return 0;
-  const FieldLayout L = field_layout(0, field_nc(meta->lotd.num_levels));
+  if (meta->precision == 1) return 0;
+  const FieldLayout L = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
   const int64_t m1 = (first + count < M_COUNT) ? L.mat[first + count] : L.vec[0];
   return (size_t)(((m1 - L.mat[first]) + (L.total - L.vec[0]) + 15) & ~15);
 }
@@ -2048,7 +2131,7 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
   deal_levels(meta, a);
   const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
   if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_lotd_gather_lm<1, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_lotd_gather_lm<1, false>), gg, dim3(64), 0, (hipStream_t)stream, a);   // f32 planes (1, 2)
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -2082,6 +2165,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
+  if (meta->precision == 2 && !feat_scratch) return 33;     // split precision: level-major path only
   if (field_nc(meta->lotd.num_levels) == 2) {
     if (!feat_scratch) return 33;     // more than 16 levels: level-major path only
     switch (key) {
@@ -2089,6 +2173,8 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((k_field_sdf<2, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL((k_field_sdf<2, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
     }
   } else if (feat_scratch) {   // decoder on the planes gathered by nsim_lotd_gather_lm
     switch (key) {
@@ -2096,6 +2182,8 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((k_field_sdf<2, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL((k_field_sdf<2, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
     }
   } else {
     switch (key) {
@@ -2113,7 +2201,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
                    float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream) {
-  const int rc = field_meta_check(meta);
+  const int rc = field_meta_check_full(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (ray_goff && !ridx) return 29;
@@ -2153,7 +2241,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
                        const float* x, const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                        const float* h_appear, int64_t S, const float* dnablas, const float* drgb, float* gn_out,
                        float* drad_w, float* drad_b, float* dh_appear, float* dx, float* dv, void* stream) {
-  const int rc = field_meta_check(meta);
+  const int rc = field_meta_check_full(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!x && !(rays_o && rays_d && t && ridx)) return 24;
@@ -2187,7 +2275,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
                        float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
-  const int rc = field_meta_check(meta);
+  const int rc = field_meta_check_full(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!dsdf_w || !dsdf_b) return 26;

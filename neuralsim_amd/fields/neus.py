@@ -557,8 +557,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         self._speculate = os.environ.get("NSIM_SPECULATE", "1") == "1" and not self._sdf_fused
         self._wpack_versions = None
         # precision of the SAMPLING pass's no-grad SDF queries (``_sampling_ctx``): None = the field precision
-        # "f32" (default): the discrete decisions of a step follow f32 arithmetic whatever the field precision
-        self.sampling_precision = os.environ.get("NSIM_SAMPLING_PRECISION") or "f32"
+        # "split" (default): the discrete decisions of a step follow f32-equivalent arithmetic whatever the field precision
+        self.sampling_precision = os.environ.get("NSIM_SAMPLING_PRECISION") or "split"
         if device is not None:
             self.to(device)
 
@@ -698,21 +698,24 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
 
     def _sampling_ctx(self):
         """(FieldMeta, weight pack) of the SAMPLING pass's no-grad SDF queries.  ``sampling_precision = "f32"`` runs them
-        on the exact-f32 kernels (f32 feature planes, v_mfma_f32_32x32x2_f32) while the with-grad query stays fp16: the
+        on the exact-f32 kernels (f32 feature planes, v_mfma_f32_32x32x2_f32), ``"split"`` (default) on the f16 matrix
+        cores with every operand carried as hi + lo (22 significant bits, three MFMAs per product: csrc/field.hip
+        ``SPLIT_LO_SCALE``) -- f32-equivalent at a fraction of the f32 MFMA's cost -- while the with-grad query stays fp16: the
         up-sampler multiplies SDF differences by inv_s up to 1024 and the compressed mode thresholds visibility weights
         at 1e-4, so the DISCRETE decisions of a step (where fine samples land, which samples are kept) then follow the
         f32 arithmetic -- they are what the fp16 rounding of an SDF (half an ulp = 2.4e-4 at |sdf| in [0.5, 1)) moves.
         None / equal to the field precision: one pack, one meta."""
         sp = self.sampling_precision
         fm = self.field_meta
-        if sp is None or {"fp16": 0, "f32": 1}[sp] == fm.precision:
+        code = {"fp16": 0, "f32": 1, "split": 2}
+        if sp is None or code[sp] == fm.precision or (sp == "split" and fm.precision == 1):
             return fm, self._shadow()[1]
         fs = getattr(self, "_field_meta_s", None)
         if fs is None:
             fs = _lib.FieldMeta()
             object.__setattr__(self, "_field_meta_s", fs)
         C_memmove(fs, fm)
-        fs.precision = {"fp16": 0, "f32": 1}[sp]
+        fs.precision = code[sp]
         self._shadow()
         return fs, self._pack_for(fs, "_wpack_slot_s")
 
@@ -852,7 +855,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         fm = self.field_meta if fm is None else fm
         planes = None
         if not self._sdf_fused:
-            planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,
+            planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,   # f16x2 | f32x2
                                  device=dev)
             _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                       _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))

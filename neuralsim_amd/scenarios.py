@@ -113,10 +113,21 @@ class AnalyticWorld:
         return dict(hit=hit, t=torch.where(hit, t, torch.zeros_like(t)), normal=nrm, rgb=rgb.clamp(0, 1))
 
 
+def mono_priors(depth: torch.Tensor, normals: torch.Tensor, pos: torch.Tensor):
+    """Monocular cues are network PREDICTIONS of a geometry, not the geometry: depth up to an affine map with a smooth
+    multiplicative error, normals with a smooth angular error (both deterministic functions of the surface point).
+    Priors that coincide with the model's own geometry to the last bit would make the L1 normal term's gradient
+    sign(n - n_gt) -- and the residuals of the scale-and-shift fit -- pure rounding noise."""
+    wob = torch.sin(3.1 * pos[..., 0] + 1.7 * pos[..., 1]) * torch.cos(2.3 * pos[..., 2] + 0.5)
+    d = (depth * 1.7 + 0.3) * (1.0 + 0.06 * wob)
+    dn = torch.stack([torch.sin(2.9 * pos[..., 1] + 0.3), torch.sin(3.7 * pos[..., 2] + 1.1), torch.sin(2.3 * pos[..., 0] + 2.0)], dim=-1)
+    return d, F.normalize(normals + 0.12 * dn, dim=-1)
+
+
 @torch.no_grad()
 def render_dataset(world: AnalyticWorld, intr, c2w, WH, with_mono: bool = False, chunk: int = 2 ** 18):
-    """The synthetic dataset of a scenario: images [V,H,W,3] (+ depth [V,H,W] and world-space normals [V,H,W,3]) of the
-    analytic world from every camera, resident on the cameras' device."""
+    """The synthetic dataset of a scenario: images [V,H,W,3] (+ monocular depth [V,H,W] and world-space normal
+    [V,H,W,3] priors, ``mono_priors``) of the analytic world from every camera, resident on the cameras' device."""
     from .eval import all_pixel_xy
     V, dev = intr.shape[0], intr.device
     W, H = int(WH[0, 0]), int(WH[0, 1])
@@ -131,8 +142,9 @@ def render_dataset(world: AnalyticWorld, intr, c2w, WH, with_mono: bool = False,
             tr = world.trace(o, d)
             img[f].view(-1, 3)[s:s + chunk] = tr["rgb"]
             if with_mono:
-                dep[f].view(-1)[s:s + chunk] = tr["t"]
-                nrm[f].view(-1, 3)[s:s + chunk] = tr["normal"]
+                d_, n_ = mono_priors(tr["t"], tr["normal"], o + tr["t"][:, None] * d)
+                dep[f].view(-1)[s:s + chunk] = d_
+                nrm[f].view(-1, 3)[s:s + chunk] = n_
     return (img, dep, nrm) if with_mono else img
 
 

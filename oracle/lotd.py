@@ -110,7 +110,7 @@ def lotd_forward(x: torch.Tensor, params: torch.Tensor, spec: LoTDSpec, n_active
     S = x.shape[0]
     F = spec.n_feats
     u = spec.unit_coords(x)
-    p32 = params.float()
+    p32 = params if params.dtype in (torch.float32, torch.float64) else params.float()   # f64: conditioning probes
     outs = []
     n_active = getattr(spec, 'n_active', None) if n_active is None else n_active
     for l, R in enumerate(spec.lod_res):

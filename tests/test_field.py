@@ -405,3 +405,31 @@ def test_pose_gradients(backend, levels, precision):
     out = model.forward_sdf_nablas(x_d)
     ((out["sdf"] * dv(ws[:100])).sum() + (out["nablas"] * dv(wn[:100])).sum()).backward()
     assert rel_l2(x_d.grad.cpu(), x_r.grad) < tol
+
+
+@pytest.mark.parametrize("levels,sdf_D", [(16, 2), (16, 1), (19, 2), (24, 1)])
+def test_split_precision_sdf_query(backend, levels, sdf_D):
+    """Precision 2 of the no-grad SDF query (csrc/field.hip ``SPLIT_LO_SCALE``): every operand of the decoder's matrix
+    products -- features, weights, hidden activations -- travels through the f16 matrix cores as hi + lo, three MFMAs per
+    product.  The result must be f32-accurate (the fp16 query of the same model is ~1e-3 off on these weights)."""
+    lod_res = [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(levels)]
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=sdf_D, seed=11, sphere_init=False,
+                                 grid_bound=0.3, noise_scale=1.0)
+    p.grid = p.grid.float()
+    model = model_from_params(p, backend, precision="fp16")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(500, 3, generator=g) * 2 - 1) * 0.95
+    with torch.no_grad():
+        ref = ofield.forward_sdf(x, p)
+    xd = x.to(backend).contiguous()
+    grid16, wpack = model._shadow()
+    err = {}
+    for sp in ("fp16", "split", "f32"):
+        model.sampling_precision = sp
+        fm, wp = model._sampling_ctx()
+        assert fm.precision == {"fp16": 0, "split": 2, "f32": 1}[sp]
+        q = model._sdf_query(grid16, wp, xd, None, None, None, None, x.shape[0], backend, fm=fm).cpu()
+        err[sp] = float((q - ref).abs().max())
+    scale = 1.0 + float(ref.abs().max())
+    assert err["f32"] < 2e-6 * scale and err["split"] < 4e-6 * scale, err
+    assert err["fp16"] > 20 * err["split"], err

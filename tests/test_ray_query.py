@@ -96,12 +96,14 @@ def test_ray_query_parity(backend, precision, compressed):
 
 
 @pytest.mark.parametrize("compressed", [False, True])
-def test_f32_sampling_pass_fixes_the_discrete_decisions_of_an_fp16_step(backend, compressed):
-    """``sampling_precision = "f32"``: the no-grad SDF queries of the sampling pass run on the exact-f32 kernels, the
-    with-grad query on the fp16 ones -- the sample set (counts, depths) is then the f32 oracle's, the rendered values
-    carry only the fp16 error of the field ON that set."""
+@pytest.mark.parametrize("sampling", ["f32", "split"])
+def test_f32_sampling_pass_fixes_the_discrete_decisions_of_an_fp16_step(backend, compressed, sampling):
+    """``sampling_precision``: the no-grad SDF queries of the sampling pass run on the exact-f32 kernels ("f32") or on the
+    f16 matrix cores with hi + lo operands ("split", the default: f32-equivalent), the with-grad query on the fp16 ones
+    -- the sample set (counts, depths) is then the f32 oracle's, the rendered values carry only the fp16 error of the
+    field ON that set."""
     p, model, o, d, h_appear, occ, jit, jit_c, g = _setup(backend, "fp16")
-    model.sampling_precision = "f32"
+    model.sampling_precision = sampling
     ret_o = orr.ray_query(p, o, d, h_appear, occ, AABB[0], AABB[1], RES, near=0.01, far=None, num_coarse=16,
                           num_fine=(4, 4, 8), step_size=0.02, max_steps=512, jitter=jit, jitter_c=jit_c,
                           depth_use_normalized_vw=False, compress=compressed, compress_thre=1e-3)
