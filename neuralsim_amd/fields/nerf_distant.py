@@ -331,7 +331,10 @@ class LoTDNeRFDistantModel(ModelMixin, nn.Module):
         sigma, rgb = _DistantFn.apply(self, self.flattened_params, self.den_w, self.den_b, self.rad_w, self.rad_b,
                                       h_appear, u4, d, valid, K, holder)
         alpha = _DensityAlphaFn.apply(sigma, t.reshape(-1), valid, N, K, self.include_inf)
+        # (``pack_infos_hit`` next to ``num_per_hit``: the reference's renderer reads it on its distant-only path,
+        # app/renderers/single_volume_renderer.py:392-397)
         vb = dict(type="batched", rays_inds_hit=torch.arange(N, device=dev), num_per_hit=K, t=t,
+                  pack_infos_hit=torch.stack([torch.arange(N, device=dev) * K, torch.full([N], K, dtype=torch.long, device=dev)], dim=-1),
                   opacity_alpha=alpha.view(N, K), rgb=rgb.view(N, K, 3), sigma=sigma.view(N, K), valid=valid.view(N, K))
         ret = dict(volume_buffer=vb, _bwd_holder=holder)
         if render_per_obj_individual:       # this model alone (single_volume_renderer.py:313-317): all rays are "hit"

@@ -56,6 +56,21 @@ class FusedAdamTorch(torch.optim.Optimizer):
         super().__init__(param_groups, dict(lr=lr, betas=tuple(betas), eps=eps, shadow16=None, name=""))
         self._on_step = on_step
 
+    def state_dict(self):
+        """Checkpointable (``CheckpointIO.register_modules(optimizer_<name>=...)``, code_single/tools/train.py:1368-1371):
+        the per-group ``shadow16`` callables are runtime wiring, not state."""
+        sd = super().state_dict()
+        sd["param_groups"] = [{k: v for k, v in g.items() if k != "shadow16"} for g in sd["param_groups"]]
+        return sd
+
+    def load_state_dict(self, state_dict):
+        wiring = [g.get("shadow16") for g in self.param_groups]
+        sd = dict(state_dict)
+        sd["param_groups"] = [dict(g, shadow16=None) for g in sd["param_groups"]]
+        super().load_state_dict(sd)
+        for g, w in zip(self.param_groups, wiring):
+            g["shadow16"] = w
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None

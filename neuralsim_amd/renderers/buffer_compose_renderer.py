@@ -16,6 +16,7 @@ frame being rendered.  ``render_per_class_in_scene`` / ``render_per_obj_in_scene
 mirrored: ``render_per_obj_individual`` and its segmentation z-buffer (:276-311), which are evaluation outputs.
 """
 from dataclasses import dataclass
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -211,7 +212,7 @@ class BufferComposeRenderer(nn.Module):
                 vb = raw["volume_buffer"]
                 if vb["type"] != "empty":
                     vb["vw_in_total"] = out["vw"][ranks[vb["pidx_in_total"]]]
-                    thre = float(cfgd.get("distant_bwd_trans_thre", 1e-4))
+                    thre = float(cfgd.get("distant_bwd_trans_thre", os.environ.get("NSIM_DISTANT_BWD_THRE", 1e-3)))
                     if thre > 0 and self.training and "_bwd_holder" in raw:
                         raw["_bwd_holder"]["keep"] = (out["trans"][ranks[vb["pidx_in_total"]]] >= thre).to(torch.uint8)
         norm_depth = cfgd.get("depth_use_normalized_vw", True)

@@ -17,6 +17,7 @@ close-range ("cr") object, which is the part of that file that sits on the hot p
 There is no Scene graph here: the model is passed directly (the reference looks it up through
 ``scene.get_drawable_groups_by_class_name``), rays are expected in the model's object space.
 """
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -199,9 +200,11 @@ class SingleVolumeRenderer(nn.Module):
             tvb["vw"] = out["vw"]
             if pidx_cr is not None:
                 vb["vw_in_total"], dv_vb["vw_in_total"] = out["vw"][pidx_cr], out["vw"][pidx_dv]
-                thre = float(config.get("distant_bwd_trans_thre", 1e-4))
+                thre = float(config.get("distant_bwd_trans_thre", os.environ.get("NSIM_DISTANT_BWD_THRE", 1e-3)))
                 if thre > 0 and self.training and "_bwd_holder" in dv_ret:
-                    # shells behind an (almost) opaque stretch of the joint ray: no backward, no table scatter for them
+                    # shells behind an (almost) opaque stretch of the joint ray: no backward, no table scatter for them.
+                    # 1e-3: the compressed close-range query keeps samples down to a visibility weight of 1e-4, so the
+                    # transmittance it leaves behind an opaque surface is ~1e-4 .. 1e-3, never ~0
                     dv_ret["_bwd_holder"]["keep"] = (out["trans"][pidx_dv] >= thre).to(torch.uint8)
             elif vb["type"] != "empty":
                 vb["vw"] = vb["vw_in_total"] = out["vw"]

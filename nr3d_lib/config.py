@@ -53,6 +53,10 @@ class ConfigDict(dict):
     def copy(self):
         return ConfigDict(self)
 
+    def deepcopy(self):
+        import copy
+        return copy.deepcopy(self)
+
     def __deepcopy__(self, memo):
         import copy
         return ConfigDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
@@ -165,3 +169,74 @@ def load_config(path: str) -> ConfigDict:
     import yaml
     with open(path) as f:
         return resolve_config(yaml.safe_load(f))
+
+
+def save_config(cfg, path: str):
+    import yaml
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg.to_dict() if isinstance(cfg, ConfigDict) else dict(cfg), f, sort_keys=False)
+
+
+def _set_by_path(root: dict, path: str, value):
+    cur = root
+    keys = path.split(".")
+    for k in keys[:-1]:
+        if k not in cur or not isinstance(cur[k], dict):
+            cur[k] = {}
+        cur = cur[k]
+    cur[keys[-1]] = value
+
+
+class BaseConfig:
+    """The command-line front end of the reference's tools (code_single/tools/train.py:1691-1698: ``bc = BaseConfig();
+    bc.parser.add_argument(...); args = bc.parse()``): ``--config file.yaml`` (or ``--resume_dir exp_dir``), registered
+    extra options, and free-form dotted overrides ``--a.b.c=value`` / ``--a.b.c value`` (YAML-typed) merged into the
+    tree BEFORE the ``${...}`` interpolations are resolved; ``exp_dir`` defaults to ``./logs/<config name>``; ``ddp`` /
+    ``device_ids`` are filled in as the trainer expects."""
+
+    def __init__(self):
+        import argparse
+        self.parser = argparse.ArgumentParser()
+        self.parser.add_argument("--config", type=str, default=None)
+        self.parser.add_argument("--resume_dir", type=str, default=None)
+        self.parser.add_argument("--exp_dir", type=str, default=None)
+        self.parser.add_argument("--device_ids", type=str, default=None)
+        self.parser.add_argument("--ddp", action="store_true")
+        self.parser.add_argument("--port", type=int, default=None)
+
+    def parse(self, argv=None, print_config: bool = True) -> ConfigDict:
+        import os
+        import yaml
+        known, extra = self.parser.parse_known_args(argv)
+        path = known.config
+        if path is None and known.resume_dir is not None:
+            path = os.path.join(known.resume_dir, "config.yaml")
+        assert path is not None, "--config <yaml> (or --resume_dir <exp_dir>) is required"
+        with open(path) as f:
+            tree = yaml.safe_load(f)
+        i = 0
+        while i < len(extra):
+            tok = extra[i]
+            assert tok.startswith("--"), f"unrecognised argument {tok!r}"
+            if "=" in tok:
+                k, v = tok[2:].split("=", 1)
+                i += 1
+            else:
+                k, v = tok[2:], extra[i + 1]
+                i += 2
+            _set_by_path(tree, k, yaml.safe_load(v))
+        for k, v in vars(known).items():
+            if k in ("config", "resume_dir") or v is None or (k == "ddp" and not v and "ddp" in tree):
+                continue
+            tree[k] = v
+        tree.setdefault("ddp", False)
+        if isinstance(tree.get("device_ids"), str) or tree.get("device_ids") is None:
+            tree["device_ids"] = parse_device_ids(tree.get("device_ids", -1) if tree.get("device_ids") is not None else -1) or [0]
+        elif isinstance(tree["device_ids"], int):
+            tree["device_ids"] = parse_device_ids(tree["device_ids"]) or [0]
+        if tree.get("exp_dir") is None:
+            tree["exp_dir"] = os.path.join("./logs", os.path.splitext(os.path.basename(path))[0])
+        cfg = resolve_config(tree)
+        if print_config:
+            print(yaml.safe_dump(cfg.to_dict(), sort_keys=False))
+        return cfg

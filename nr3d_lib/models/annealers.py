@@ -29,3 +29,10 @@ def get_anneal_val(type: str = "linear", it: int = 0, start_it: int = 0, stop_it
 
 def get_annealer(**cfg):
     return lambda it: get_anneal_val(it=it, **cfg)
+
+
+def get_anneal_val_milestones(it: int, milestones, vals):
+    """``vals[k]`` for the k-th interval of ``milestones`` (len(vals) == len(milestones) + 1): milestones mark the ends of
+    the intervals (dataio/data_loader/patch_sampler.py:214-228)."""
+    k = sum(1 for m in milestones if int(it) >= int(m))
+    return vals[min(k, len(vals) - 1)]

@@ -141,7 +141,9 @@ def run_reference(mods, s, backward=False):
 
 def run_mirror(s, backward=False):
     from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
-    r = SingleVolumeRenderer(s["common"]).train(s["training"])
+    # distant_bwd_trans_thre 0: the mirror's one deliberate deviation from the reference's renderer (no backward for
+    # distant shells behind an opaque stretch, tests/test_distant.py) is off for the one-to-one comparison
+    r = SingleVolumeRenderer(dict(s["common"], distant_bwd_trans_thre=0.0)).train(s["training"])
     with torch.set_grad_enabled(s["training"]):
         ret = r.ray_query(s["rays_o"], s["rays_d"], model=s["model"], rays_h_appear=s["h_appear"],
                           distant_model=s["distant_model"], sky_model=s["sky_model"], return_buffer=True,

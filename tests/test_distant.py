@@ -188,7 +188,7 @@ def test_renderer_merges_close_range_and_distant(backend):
 
 
 def test_backward_skips_shells_behind_an_opaque_stretch(backend):
-    """The renderer hands the distant model's backward a transmittance mask (``distant_bwd_trans_thre``, 1e-4 like the
+    """The renderer hands the distant model's backward a transmittance mask (``distant_bwd_trans_thre``, default 1e-3; here 1e-4 like the
     compressed query's weight threshold): shells whose transmittance in the JOINT ray is below it get no MLP backward and
     no table scatter.  Against the unmasked backward the gradients move by the dropped weights only."""
     from neuralsim_amd.fields.neus import OccGridAccel

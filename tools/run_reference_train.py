@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""Run the REFERENCE's trainer -- ``/root/reference/code_single/tools/train.py``, source unchanged, executed with runpy --
+on this repository: its ``nr3d_lib`` imports resolve to the shim package of this repository (HIP kernels underneath),
+its dataset is ``neuralsim_amd.dataio.SyntheticObjectDataset`` (``--dataset_cfg.target=...`` override: no files).
+
+    python tools/run_reference_train.py --config <reference yaml> [--a.b.c=value ...]
+
+On a machine without a HIP device (the authoring container) pass ``--emulate``: the kernels run on the test-only host
+emulator (tests/emu) and every ``cuda`` device the trainer asks for is mapped to the CPU -- the trainer hard-codes
+``torch.device('cuda', local_rank)`` (train.py:1204).  Nothing of this is needed on a GPU box.
+"""
+import os
+import runpy
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path(os.environ.get("NSIM_REFERENCE_ROOT", "/root/reference"))
+
+
+def _install_third_party_stubs():
+    """Import-time stand-ins for packages the trainer's modules import at the top but the hot path never calls (none is
+    installed here): a meta-path finder that serves an inert stub for ``<pkg>`` and any ``<pkg>.sub.module``."""
+    import importlib.abc
+    import importlib.machinery
+    import importlib.util
+    import types
+    tops = ("imageio", "skimage", "cv2", "open3d", "vedo", "kornia", "lpips", "icecream", "matplotlib", "mediapy",
+            "trimesh", "plyfile", "pytorch_msssim", "torchmetrics", "torchvision", "tensorboardX", "ffmpeg", "PIL",
+            "pynvml", "tensorboard", "seaborn", "pandas_unused")
+    missing = [t for t in tops if importlib.util.find_spec(t) is None]
+
+    class _Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _inert
+
+    class _Inert:
+        def __call__(self, *a, **k):
+            return self
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return self
+
+        def __mro_entries__(self, bases):
+            return (object,)
+    _inert = _Inert()
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, fullname, path=None, target=None):
+            if fullname.split(".")[0] in missing:
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Stub(spec.name)
+
+        def exec_module(self, module):
+            pass
+    sys.meta_path.append(_Finder())
+    if "torch_scatter" not in sys.modules:
+        if importlib.util.find_spec("torch_scatter") is None:
+            import torch
+            ts = types.ModuleType("torch_scatter")
+
+            def scatter_min(src, index, dim=0, out=None, dim_size=None):
+                """(min per index, argmin) along ``dim`` -- what app/renderers/buffer_compose_renderer.py:25 imports."""
+                n = int(dim_size if dim_size is not None else (out.shape[dim] if out is not None else int(index.max()) + 1))
+                base = out if out is not None else torch.full([n], float("inf"), dtype=src.dtype, device=src.device)
+                res = base.scatter_reduce(dim, index, src, reduce="amin", include_self=True)
+                hit = src == res.gather(dim, index)
+                arg = torch.full([n], src.shape[dim], dtype=torch.long, device=src.device)
+                pos = torch.arange(src.shape[dim], device=src.device)
+                arg = arg.scatter_reduce(dim, index[hit], pos[hit], reduce="amin", include_self=True)
+                if out is not None:
+                    out.copy_(res)
+                return res, arg
+            ts.scatter_min = scatter_min
+            sys.modules["torch_scatter"] = ts
+
+
+def _emulate_cuda_on_cpu():
+    """No HIP device: kernels on the host emulator, ``cuda`` devices mapped to the CPU (authoring container only)."""
+    import ctypes
+    import torch
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    import build_emu
+    from neuralsim_amd import _lib
+    lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
+    _lib.get_lib = lambda: lib
+    _lib.stream_handle = lambda: 0
+    _lib.require_device = lambda t, name="tensor": None
+    real = torch.device
+
+    class _Meta(type):
+        def __instancecheck__(cls, inst):
+            return isinstance(inst, real)
+
+        def __call__(cls, *a, **k):
+            if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+                return real("cpu")
+            return real(*a, **k)
+
+    class device(metaclass=_Meta):
+        pass
+    torch.device = device
+    noop = lambda *a, **k: None       # noqa: E731
+    for fn in ("synchronize", "set_device", "empty_cache", "manual_seed", "manual_seed_all", "reset_peak_memory_stats"):
+        setattr(torch.cuda, fn, noop)
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    torch.cuda.memory_allocated = lambda *a, **k: 0
+    _to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple(real("cpu") if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = real("cpu")
+        return _to(self, *a, **k)
+    torch.Tensor.to = to
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def main(argv):
+    emulate = "--emulate" in argv
+    argv = [a for a in argv if a != "--emulate"]
+    sys.path.insert(0, str(ROOT))
+    if str(REF) not in sys.path:
+        sys.path.append(str(REF))
+    _install_third_party_stubs()
+    if emulate:
+        _emulate_cuda_on_cpu()
+    script = REF / "code_single" / "tools" / "train.py"
+    assert script.exists(), f"{script} not found (NSIM_REFERENCE_ROOT)"
+    sys.argv = [str(script)] + argv
+    cwd = os.getcwd()
+    os.chdir(str(REF))                 # the trainer backs up "./app" etc. relative to the project root
+    try:
+        runpy.run_path(str(script), run_name="__main__")
+    finally:
+        os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
