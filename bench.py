@@ -331,6 +331,13 @@ def main():
                 var[name + "_samples_per_hit_ray"] = round(trc.stats["S_f"] / max(1, trc.stats["R_hit"]), 1)
                 del trc
                 torch.cuda.empty_cache()
+            # the reference's own street iteration: 8192 pixel rays + 8192 lidar beams (with_rgb=False), two optimizer
+            # steps (withmask_withlidar_joint.240219.yaml:7-8; code_single/tools/train.py:1480-1590)
+            from neuralsim_amd import scenarios as sc_
+            trc = sc_.build_street_trainer(dev, rank, world, rays_per_gpu=8192, lidar_rays=8192)
+            var["street_px8192_lidar8192_ms"], _ = time_steps(trc, 12, 6, 257)
+            del trc
+            torch.cuda.empty_cache()
             # a full 800 x 800 evaluation view (code_single/tools/eval.py:241-316: rayschunk pieces, validation renderer
             # settings), timed, and its PSNR against the analytic image the model is being trained on
             from neuralsim_amd.eval import psnr, render_image

@@ -12,7 +12,9 @@ item) and an occupancy grid; the SDF / radiance decoders are shared.  All tables
 ``[num_instances * n_params]`` and all grids in one bitfield, and every kernel on the path takes a per-ray instance
 offset (``ray_goff`` / ``ray_word_off`` in include/nsim.h) -- so B instances cost the launches of one.
 The hyper-network that GENERATES the tables from a latent code (StyleLoTD ``lotd_grower_cfg``, :322-352) lives in the
-absent nr3d_lib and is out of scope: tables are free auto-decoder parameters here (``z_ins`` is not supported).
+absent nr3d_lib; its dense part is restated in grid_encodings/lotd_growers.py: built with ``lotd_grower_cfg`` the model
+grows the batch's tables from latent codes (``set_condition({'ins_id' | 'ins_ind' | 'z_ins'})``), without it the tables
+are free auto-decoder parameters.
 """
 from typing import Dict, List, Optional, Sequence
 
@@ -67,14 +69,34 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
     is_batched_query_supported = True
 
     def __init__(self, num_instances: int, ins_ids: Optional[Sequence[str]] = None, accel_cfg: dict = None,
-                 seed: int = 42, param_bound: float = 1e-4, **kw):
+                 seed: int = 42, param_bound: float = 1e-4, lotd_grower_cfg: dict = None, latents_cfg: dict = None, **kw):
+        """``lotd_grower_cfg`` (``DenseLoTDGrowerFMM`` parameters: z_dim, lod_res, lod_n_feats, D, W, fmm_rank,
+        n_frequencies -- no_fg_occ.221218.yaml:320-337) + ``latents_cfg{z{dim}}`` (:310-312): the per-instance tables are
+        GROWN from per-instance latent codes (auto-decoder: one learnable code per instance) instead of being free
+        parameters; ``set_condition`` then takes ``ins_id`` / ``ins_ind`` (codes looked up) or ``z_ins`` (codes given)."""
         accel_cfg = dict(accel_cfg or {})
+        self.grower = None
+        if lotd_grower_cfg is not None:
+            from ..grid_encodings.lotd_growers import DenseLoTDGrowerFMM
+            gcfg = dict(lotd_grower_cfg)
+            z_dim = int((latents_cfg or {}).get("z", {}).get("dim", gcfg.get("z_dim", 128)))
+            gcfg["z_dim"] = z_dim
+            grower = DenseLoTDGrowerFMM(seed=seed + 5, **gcfg)
+            kw = dict(kw, lod_res=grower.kernel_lod_res, log2_hashmap_size=max(int(kw.get("log2_hashmap_size", 19)),
+                                                                               (max(grower.lod_res) ** 3).bit_length()))
         super().__init__(accel_cfg=accel_cfg, seed=seed, param_bound=param_bound, **kw)
         B = self.num_instances = int(num_instances)
         n = self.n_params_per_instance = self.encoding.cfg.n_params
         assert B * n < 2 ** 31, "instance offsets are 32-bit inside the kernels"
         g = torch.Generator().manual_seed(seed + 17)
-        p = ((torch.rand(B * n, generator=g) * 2 - 1) * param_bound).half().float()
+        self._cond_table = self._cond_table16 = None
+        if lotd_grower_cfg is not None:
+            self.grower = grower
+            assert grower.n_params == n and all(t == "Dense" for t in self.encoding.cfg.lod_types)
+            self.latents = nn.Parameter(torch.randn(B, grower.z_dim, generator=g) * 0.1)      # ``z_ins_all`` (auto-decoder)
+            p = torch.zeros([0])                                           # no free table
+        else:
+            p = ((torch.rand(B * n, generator=g) * 2 - 1) * param_bound).half().float()
         self.encoding.flattened_params = nn.Parameter(p)
         self.encoding.params16 = p.half()
         self.encoding._shadow_version = -1
@@ -87,10 +109,22 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         self._index_maps = {"ins_id": {k: i for i, k in enumerate(ins_ids or [str(i) for i in range(B)])}}
         self.ins_inds_per_batch: Optional[torch.Tensor] = None
 
+    def _param_groups(self, cfg: dict):
+        if self.grower is None:
+            return super()._param_groups(cfg)
+        return [dict(name="latents.z_ins", params=[self.latents]),
+                dict(name="implicit_surface.encoding.grower", params=list(self.grower.parameters())),
+                dict(name="implicit_surface.decoder", params=[self.sdf_w, self.sdf_b]),
+                dict(name="radiance_net", params=[self.rad_w, self.rad_b]),
+                dict(name="ln_inv_s", params=[self.ln_inv_s], betas=tuple(cfg.get("invs_betas", (0.9, 0.999))))]
+
     # ------------------------------------------------------------------ conditions (batched_neus.py:380-407)
     def set_condition(self, batched_infos: Dict):
+        if self.grower is not None:
+            return self._set_condition_grown(batched_infos)
         if "z_ins" in batched_infos:
-            raise NotImplementedError("latent-conditioned table growers (StyleLoTD) live in nr3d_lib; out of scope")
+            raise RuntimeError("set_condition({'z_ins': ...}) needs a model built with lotd_grower_cfg (free per-instance "
+                               "tables have no latent)")
         if "ins_id" in batched_infos:
             ids = batched_infos["ins_id"]
             ids = [ids] if isinstance(ids, str) else ids
@@ -101,10 +135,53 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
             raise RuntimeError("set_condition needs 'ins_id' or 'ins_ind'")
         self.ins_inds_per_batch = inds
 
+    def _set_condition_grown(self, batched_infos: Dict):
+        """``set_condition`` of the latent-conditioned model (app/models/shared/batched_neus.py:380-403): instance
+        indices from ``ins_id`` / ``ins_ind`` (optional when ``z_ins`` is given), codes from ``z_ins`` or the
+        auto-decoder's table, then the batch's tables are grown ONCE for every query of this condition."""
+        inds = None
+        if "ins_id" in batched_infos:
+            ids = batched_infos["ins_id"]
+            ids = [ids] if isinstance(ids, str) else ids
+            inds = torch.tensor([self._index_maps["ins_id"][i] for i in ids], dtype=torch.long, device=self.device)
+        elif "ins_ind" in batched_infos:
+            inds = torch.as_tensor(batched_infos["ins_ind"], dtype=torch.long, device=self.device).reshape(-1)
+        if "z_ins" in batched_infos:
+            z = batched_infos["z_ins"].to(self.device).float().reshape(-1, self.grower.z_dim)
+        else:
+            if inds is None:
+                raise RuntimeError("set_condition needs 'ins_id' / 'ins_ind' when no 'z_ins' is provided")
+            z = self.latents[inds]
+        if inds is not None and inds.shape[0] != z.shape[0]:
+            raise RuntimeError("set_condition: 'z_ins' and the instance list differ in length")
+        self.z_ins_per_batch = z
+        # without instance indices the batch items use occupancy grid 0..B'-1 (a condition on bare codes has no
+        # per-instance state to look up)
+        self.ins_inds_per_batch = inds if inds is not None else torch.arange(z.shape[0], device=self.device)
+        self._cond_table = self.grower(z).reshape(-1)
+        self._cond_table16 = self._cond_table.detach().half()
+
     def clean_condition(self):
         self.ins_inds_per_batch = None
+        self._cond_table = self._cond_table16 = None
 
-    def _offsets(self, ins_inds: torch.Tensor):
+    def _table(self):
+        if self.grower is None:
+            return self.encoding.flattened_params
+        assert self._cond_table is not None, "set_condition() first"
+        return self._cond_table
+
+    def _table16(self):
+        if self.grower is None:
+            return self.encoding.shadow()
+        assert self._cond_table16 is not None, "set_condition() first"
+        return self._cond_table16
+
+    def _offsets(self, ins_inds: torch.Tensor, positions: torch.Tensor = None):
+        """-> (table offset, occupancy word offset) per ray.  Free tables: both by instance index.  Grown tables live in
+        the order of the CONDITION (``positions`` = index of the ray's item in it), the occupancy grids stay per instance."""
+        if self.grower is not None and positions is not None:
+            return positions * self.n_params_per_instance, ins_inds * self.accel.words_per_instance
         return ins_inds * self.n_params_per_instance, ins_inds * self.accel.words_per_instance
 
     # ------------------------------------------------------------------ per-instance point queries
@@ -115,26 +192,39 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         shape = x.shape[:-1]
         xf = x.detach().float().reshape(-1, 3).contiguous()
         S = xf.shape[0]
+        own_condition = False
         if bidx is None:
-            goff = torch.tensor([int(ins_ind) * self.n_params_per_instance], dtype=torch.long, device=xf.device)
+            if self.grower is not None:                 # one instance: grow its table for this query
+                own_condition = self._cond_table is None
+                if own_condition:
+                    self.set_condition({"ins_ind": [int(ins_ind)]})
+                pos = (self.ins_inds_per_batch == int(ins_ind)).nonzero()[:1, 0]
+                goff = pos * self.n_params_per_instance
+            else:
+                goff = torch.tensor([int(ins_ind) * self.n_params_per_instance], dtype=torch.long, device=xf.device)
             ridx = torch.zeros([S], dtype=torch.long, device=xf.device)
         else:
-            goff, _ = self._offsets(self.ins_inds_per_batch)
+            goff, _ = self._offsets(self.ins_inds_per_batch, torch.arange(self.ins_inds_per_batch.shape[0], device=xf.device))
             ridx = bidx.reshape(-1).contiguous()
         grid16, wpack = self._shadow()
-        return self._sdf_query(grid16, wpack, xf, None, None, None, ridx, S, xf.device, goff=goff).reshape(shape)
+        out = self._sdf_query(grid16, wpack, xf, None, None, None, ridx, S, xf.device, goff=goff).reshape(shape)
+        if own_condition:
+            self.clean_condition()
+        return out
 
     def forward_sdf_nablas(self, x: torch.Tensor, bidx: torch.Tensor = None, ins_ind=None, nablas_has_grad=True):
         from .neus import _FieldFn
         shape = x.shape[:-1]
         xf = x.detach().float().reshape(-1, 3).contiguous()
         if bidx is None:
-            goff = torch.tensor([int(ins_ind) * self.n_params_per_instance], dtype=torch.long, device=xf.device)
+            assert self.grower is None or self._cond_table is not None, "grown tables: set_condition() first, then bidx"
+            pos = int(ins_ind) if self.grower is None else int((self.ins_inds_per_batch == int(ins_ind)).nonzero()[0, 0])
+            goff = torch.tensor([pos * self.n_params_per_instance], dtype=torch.long, device=xf.device)
             ridx = torch.zeros([xf.shape[0]], dtype=torch.long, device=xf.device)
         else:
-            goff, _ = self._offsets(self.ins_inds_per_batch)
+            goff, _ = self._offsets(self.ins_inds_per_batch, torch.arange(self.ins_inds_per_batch.shape[0], device=xf.device))
             ridx = bidx.reshape(-1).contiguous()
-        sdf, nablas = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w,
+        sdf, nablas = _FieldFn.apply(self, self._table(), self.sdf_w, self.sdf_b, self.rad_w,
                                      self.rad_b, None, xf, None, None, None, ridx, False, goff)
         if not nablas_has_grad:
             nablas = nablas.detach()
@@ -239,7 +329,7 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
                 assert n_cond == int(batched_ray_input["rays_o"].shape[0]), \
                     "set_condition() covers neither the compacted nor the full batch of batched_ray_tested"
         ins = self.ins_inds_per_batch[which] if bt["num_rays"] > 0 else which
-        goff, woff = self._offsets(ins)
+        goff, woff = self._offsets(ins, which)
         tested = dict(bt)
         tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
         want_pairs = bool(dict(config).get("_render", False))

@@ -101,6 +101,7 @@ class _FieldFn(torch.autograd.Function):
             if _lib.TIMER is not None:
                 _lib.TIMER.note_units("nsim_field_fwd", S)
             ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
+            ctx.grid_numel = grid.numel()
             ctx.x_shape = None
             ctx.save_for_backward(None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
             ctx.goff = None
@@ -133,6 +134,7 @@ class _FieldFn(torch.autograd.Function):
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
+        ctx.grid_numel = grid.numel()
         ctx.x_shape = x.shape if x is not None else None
         # save_for_backward, not a ctx attribute: without extra points nablas / rgb ARE the outputs, and output -> grad_fn
         # -> ctx -> output would be a reference cycle (the planes of a step, ~150 MB, until the cyclic collector runs)
@@ -169,7 +171,7 @@ class _FieldFn(torch.autograd.Function):
         grid16, wpack = model._shadow()
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
         need = ctx.needs_input_grad
-        dgrid = torch.zeros([model.encoding.flattened_params.numel()], dtype=torch.float32, device=dev) if need[1] else None
+        dgrid = torch.zeros([ctx.grid_numel], dtype=torch.float32, device=dev) if need[1] else None
         # one memset for the four small accumulators
         dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], dtype=torch.float32,
                                                      device=dev).split([n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
@@ -686,9 +688,18 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             object.__setattr__(self, slot, (vers, buf))
         return getattr(self, slot)[1]
 
+    def _table(self) -> torch.Tensor:
+        """The flat f32 table the with-grad query differentiates (a model whose tables are GROWN from latents returns the
+        generated tensor of the current condition: fields/batched_neus.py)."""
+        return self.encoding.flattened_params
+
+    def _table16(self) -> torch.Tensor:
+        """The fp16 copy of ``_table()`` the gather kernels read."""
+        return self.encoding.shadow()
+
     def _shadow(self):
         """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
-        grid16 = self.encoding.shadow()
+        grid16 = self._table16()
         if self._wpack_versions is None:        # invalidated by hand (optimizer step, precision switch)
             object.__setattr__(self, "_wpack_slot", None)
             object.__setattr__(self, "_wpack_slot_s", None)
@@ -889,7 +900,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def forward_sdf_nablas(self, x: torch.Tensor, nablas_has_grad: bool = True) -> Dict[str, torch.Tensor]:
         shape = x.shape[:-1]
         xf = (x if x.requires_grad else x.detach()).float().reshape(-1, 3).contiguous()   # dL/dx flows when asked for
-        sdf, nablas = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w,
+        sdf, nablas = _FieldFn.apply(self, self._table(), self.sdf_w, self.sdf_b, self.rad_w,
                                      self.rad_b, None, xf, None, None, None, None, False)
         if not nablas_has_grad:
             nablas = nablas.detach()
@@ -1278,7 +1289,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         # is no-grad by construction (t is a constant of the differentiable step, as in the reference)
         o_in = o_g.float().contiguous() if o_g.requires_grad else o
         d_in = d_g.float().contiguous() if d_g.requires_grad else d
-        outs = _FieldFn.apply(self, self.encoding.flattened_params, self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
+        outs = _FieldFn.apply(self, self._table(), self.sdf_w, self.sdf_b, self.rad_w, self.rad_b,
                               h_appear if with_rgb else None, None, o_in, d_in, t, ridx, bool(with_rgb), goff, extra_x, pre)
         sdf, nablas = outs[0], outs[1]
         rgb = outs[2] if with_rgb else None

@@ -262,8 +262,29 @@ def street_models(device, precision: str = "fp16", seed: int = 42, small: bool =
     return m, dm, sm
 
 
+@torch.no_grad()
+def street_lidar(world: AnalyticWorld, n_ego: int = 10, beams: int = 16384, x_range=(-60.0, 60.0), device=None, seed: int = 9):
+    """A roof lidar on the ego vehicle (``lidar_TOP``): per ego pose ``beams`` rays, azimuth uniform, elevation in
+    [-22, +2.5] degrees; ranges by tracing the analytic world (0 = no return).  -> rays_o, rays_d [F,M,3], ranges [F,M]."""
+    g = torch.Generator().manual_seed(seed)
+    o_l, d_l, r_l = [], [], []
+    for e in range(n_ego):
+        x = x_range[0] + (x_range[1] - x_range[0]) * (e + 0.5) / n_ego
+        az = torch.rand(beams, generator=g) * (2 * math.pi)
+        el = torch.deg2rad(-22.0 + 24.5 * torch.rand(beams, generator=g))
+        d = torch.stack([torch.cos(el) * torch.cos(az), torch.cos(el) * torch.sin(az), torch.sin(el)], dim=-1)
+        o = torch.tensor([x, 0.3 * math.sin(1.3 * e), 0.5]).expand(beams, 3).contiguous()
+        tr = world.trace(o, d)
+        o_l.append(o)
+        d_l.append(d)
+        r_l.append(torch.where(tr["hit"], tr["t"], torch.zeros_like(tr["t"])))
+    out = torch.stack(o_l), torch.stack(d_l), torch.stack(r_l)
+    return tuple(t.to(device) for t in out) if device is not None else out
+
+
 def build_street_trainer(device, rank: int = 0, world_size: int = 1, precision: str = "fp16", rays_per_gpu: int = 16384,
-                         seed: int = 42, small: bool = False, num_uniform: Optional[int] = None, n_ego: int = None):
+                         seed: int = 42, small: bool = False, num_uniform: Optional[int] = None, n_ego: int = None,
+                         lidar_rays: int = 0):
     from . import distributed as ndist
     from .trainer import RenderTrainer
     world = street_world()
@@ -276,9 +297,14 @@ def build_street_trainer(device, rank: int = 0, world_size: int = 1, precision: 
     images = render_dataset(world, intr, c2w, WH)
     if num_uniform is None:
         num_uniform = 256 if small else 2 ** 16                                         # ``num_uniform 2^16`` (yaml:38)
+    lidar = None
+    if lidar_rays:          # the reference's street iteration: a pixel batch AND a lidar batch (yaml:7-8: 8192 + 8192)
+        lo, ld, lr_ = street_lidar(world, n_ego=n_ego or (2 if small else 10), beams=512 if small else 16384, device=device)
+        lidar = dict(rays_o=lo, rays_d=ld, ranges=lr_, num_rays=int(lidar_rays), w_depth=0.02, w_los=0.1, epsilon=1.5,
+                     discard_toofar=80.0, near=0.1, far=200.0)
     return RenderTrainer(m, intr, c2w, WH, num_rays=rays_per_gpu, lr=1e-3, w_eikonal=0.01, num_uniform=num_uniform,
                          near=0.1, far=200.0, rank=rank, world_size=world_size, seed=seed, learn_inv_s=False,
-                         distant_model=dm, sky_model=sm, target_images=images, rgb_fn="l1")
+                         distant_model=dm, sky_model=sm, target_images=images, rgb_fn="l1", lidar=lidar)
 
 
 # ------------------------------------------------------------------------------------------------ indoor (configs[2])

@@ -30,7 +30,7 @@ class RenderTrainer:
                  target_sphere_radius: Optional[float] = None, pipeline: bool = True,
                  pose_refine: Optional[dict] = None, c2w_true=None, fused_step: Optional[bool] = None,
                  distortion: Optional[torch.Tensor] = None, target_images: Optional[torch.Tensor] = None,
-                 mono: Optional[dict] = None, rgb_fn: str = "mse"):
+                 mono: Optional[dict] = None, rgb_fn: str = "mse", lidar: Optional[dict] = None):
         """pose_refine: ``dict(lr=1e-4, start_it=500)`` -- per-frame pose corrections (an axis-angle rotation and a
         translation, ``c2w' = [R Exp(w) | T + dT]``) trained through the rays from ``start_it`` on, standing in for the
         reference's ``LearnableParams`` (withmask_withlidar_joint.240219.yaml:338-352; the parametrisation of the
@@ -43,9 +43,16 @@ class RenderTrainer:
         ``dict(depth=[V,H,W], normals=[V,H,W,3], patch_hw=(64, 64), w_depth=, w_normal=)`` -- the first h*w rays of every
         batch are a contiguous pixel patch of one frame (the reference's ``image_patch`` step; the scale-and-shift
         invariant depth term needs an image region), normals are supervised on every ray.
-        rgb_fn: ``mse`` | ``l1`` (``rgb_fn`` of the street configs, withmask_withlidar_joint.240219.yaml:26)."""
+        rgb_fn: ``mse`` | ``l1`` (``rgb_fn`` of the street configs, withmask_withlidar_joint.240219.yaml:26).
+        lidar: the street config's second step of every iteration (``num_rays_lidar 8192``, yaml:8; losses :453-469;
+        code_single/tools/train.py:860-960 ``train_step_lidar``): ``dict(rays_o [F,M,3], rays_d [F,M,3], ranges [F,M]
+        (0 = no return), num_rays=8192, w_depth=0.02, w_los=0.1, epsilon=1.5, discard_toofar=80)`` -- a batch of lidar
+        beams rendered with ``with_rgb=False`` (no radiance network), l1 depth loss on the returns + the line-of-sight
+        term of ``neus_unisim`` (squared visibility weights further than epsilon from the return), own backward and
+        optimizer step, as in the reference's loop (train.py:1540-1590)."""
         self.model = model
         self.target_images, self.mono, self.rgb_fn = target_images, (dict(mono) if mono else None), rgb_fn
+        self.lidar = dict(lidar) if lidar else None
         self._last_aux = None
         self.distortion = distortion
         # fused_step (default on, env NSIM_FUSED_STEP=0 turns it off): the differentiable part of the iteration -- field
@@ -505,7 +512,56 @@ class RenderTrainer:
             eik = torch.zeros([], device=gt.device)
         return loss_rgb + self.w_eikonal * eik, dict(loss_rgb=loss_rgb.detach(), loss_eikonal=eik.detach())
 
+    # ------------------------------------------------------------------ lidar step (street configs)
+    def sample_lidar_batch(self):
+        L = self.lidar
+        F_, M_ = L["ranges"].shape
+        n = int(L.get("num_rays", 8192))
+        dev = self.model.device
+        idx = torch.randint(0, F_ * M_, [n], device=dev, generator=self.gen)
+        return L["rays_o"].view(-1, 3)[idx], L["rays_d"].view(-1, 3)[idx], L["ranges"].view(-1)[idx]
+
+    def lidar_losses(self, ret, ranges):
+        """-> (loss, parts).  depth: ``l1_loss(depth_pred, ranges, mask, reduction='mean')`` (app/loss/lidar.py:41, 271);
+        line of sight ``neus_unisim`` (:174-206): per ray the sum of vw^2 over the samples further than epsilon from the
+        return, masked mean over the rays of the buffer."""
+        from .graphics import pack_ops as po
+        L = self.lidar
+        valid = (ranges > 0) & (ranges < float(L.get("discard_toofar", 80.0)))
+        m = valid.float()
+        depth = ret["rendered"]["depth_volume"]
+        parts = dict(depth=float(L.get("w_depth", 0.02)) * ((depth - ranges).abs() * m).mean())
+        vb = ret["volume_buffer"]
+        if vb["type"] != "empty":
+            rih, pi = vb["rays_inds_hit"], vb["pack_infos_hit"]
+            gt_ex = torch.repeat_interleave(ranges[rih], pi[:, 1], dim=0)
+            far_off = ((vb["t"] - gt_ex).abs() > float(L.get("epsilon", 1.5))).float()
+            empty = po.packed_sum(far_off * vb["vw"] ** 2, pi).reshape(-1)
+            parts["los"] = float(L.get("w_los", 0.1)) * (empty * m[rih]).mean()
+        return sum(parts.values()), parts
+
+    def train_step_lidar(self, it: int) -> torch.Tensor:
+        o, d, ranges = self.sample_lidar_batch()
+        ret = self.renderer.render(self.model, rays=[o, d], rays_h_appear=None, with_rgb=False, with_normal=False,
+                                   return_buffer=True, return_details=False, distant_model=self.distant_model,
+                                   sky_model=None, near=float(self.lidar.get("near", self.near or 0.0)),
+                                   far=float(self.lidar.get("far", self.far)) if (self.lidar.get("far", self.far) is not None) else None)
+        loss, parts = self.lidar_losses(ret, ranges)
+        self.optim.zero_grad()
+        loss.backward()
+        if not self.skip_allreduce:
+            ndist.allreduce_grads(self.optim.params(), average=False)
+        self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
+        self.stats["lidar_samples"] = int(ret["volume_buffer"]["t"].shape[0]) if ret["volume_buffer"]["type"] != "empty" else 0
+        return loss.detach()
+
     def train_step(self, it: int) -> torch.Tensor:
+        loss = self._train_step_pixel(it)
+        if self.lidar is not None:
+            self._loss_lidar = self.train_step_lidar(it)
+        return loss
+
+    def _train_step_pixel(self, it: int) -> torch.Tensor:
         model = self.model
         self._it = int(it)
         refine = self.pose_refine_active()

@@ -160,5 +160,103 @@ def test_batched_point_queries_and_occupancy(backend):
     m.init_accel(generator=torch.Generator(device=backend).manual_seed(1))
     fr = m.accel.occ_grid.float().mean(dim=(1, 2, 3)).cpu()
     assert fr[1] < fr[0] < fr[2] and float(fr.min()) > 0.002, fr
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):          # free per-instance tables have no latent: z_ins needs lotd_grower_cfg
         m.set_condition({"z_ins": torch.zeros(2, 128)})
+
+
+@pytest.mark.parametrize("by", ["ins_id", "z_ins"])
+def test_latent_conditioned_tables_match_the_oracle(backend, by):
+    """Row a20, the latent -> table path (no_fg_occ.221218.yaml:307-352): a model built with ``lotd_grower_cfg`` grows the
+    batch's dense LoTD tables from latent codes in ``set_condition({'ins_id'})`` (the auto-decoder's codes) or
+    ``set_condition({'z_ins'})`` (codes given) -- rendered images, and the gradients that reach the codes, the grower's
+    weights and the shared decoders, against the oracle's restatement (oracle/growers.py -> oracle.lotd -> oracle.render)."""
+    from oracle import field as ofield, growers as ogrow, lotd as olotd
+    from neuralsim_amd.fields.batched_neus import BatchedLoTDNeuSModel
+    B, N = 3, 20
+    gcfg = dict(lod_res=[3, 5, 8], lod_n_feats=4, D=2, W=32, fmm_rank=4, n_frequencies=3, out_scale=0.5)
+    m = BatchedLoTDNeuSModel(B, ins_ids=[f"car{b}" for b in range(B)], lotd_grower_cfg=gcfg, latents_cfg=dict(z=dict(dim=12)),
+                             sdf_D=2, precision="f32", ln_inv_s_init=0.3, log2_hashmap_size=12,
+                             accel_cfg=dict(resolution=[8, 8, 8])).to(backend)
+    assert m.encoding.cfg.lod_res == [3, 3, 5, 5, 8, 8] and m.encoding.flattened_params.numel() == 0
+    m.accel.set_all_occupied()
+    with torch.no_grad():            # a visible shape: bias the SDF head so that part of the box is inside
+        m.sdf_b[-1] = -0.05
+        m.latents.mul_(5.0)
+        m.sdf_b.add_(0)
+    cond = [2, 0]
+    o, d, g = _rays(len(cond), N)
+    ha = torch.randn(len(cond), N, 4, generator=g) * 0.3
+    dv = lambda a: a.to(backend).contiguous()        # noqa: E731
+    if by == "ins_id":
+        m.set_condition({"ins_id": [f"car{i}" for i in cond]})
+        z_o = m.latents.detach().cpu()[cond].clone().requires_grad_(True)
+    else:
+        z_in = (torch.randn(len(cond), 12, generator=g) * 0.5).to(backend).requires_grad_(True)
+        m.set_condition({"z_ins": z_in, "ins_ind": cond})
+        z_o = z_in.detach().cpu().clone().requires_grad_(True)
+    # ---- oracle: grow the tables, then one single-object query per batch item
+    layers = [{k: getattr(lay, k).detach().cpu().clone().requires_grad_(True) for k in ("weight", "bias", "u_w", "u_b", "v_w", "v_b")}
+              for lay in m.grower.layers]
+    tables = ogrow.grow_tables(z_o, layers, gcfg["lod_res"], 4, 3, 4, 0.5)
+    assert tables.shape == (len(cond), m.n_params_per_instance)
+    assert torch.allclose(m._cond_table.detach().cpu().view(len(cond), -1), tables.detach(), atol=2e-6)
+    p0 = ofield.params_from_flat(m.encoding.cfg.lod_res, 12, tables[0].detach(), m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s,
+                                 sdf_D=2, ln_inv_s_factor=m.ln_inv_s_factor)
+    shared = [*p0.sdf_w, *p0.sdf_b, *p0.rad_w, *p0.rad_b, p0.ln_inv_s]
+    for t_ in shared:
+        t_.requires_grad_(True)
+    occ = torch.ones(8 ** 3, dtype=torch.bool)
+    kw = dict(near=0.01, far=None, num_coarse=16, num_fine=(4, 4, 8), step_size=0.02, max_steps=512, depth_use_normalized_vw=False)
+    wgt = torch.rand(len(cond), N, 3, generator=g)
+    loss_o = 0.0
+    outs = []
+    for k in range(len(cond)):
+        pk = ofield.FieldParams(spec=p0.spec, grid=tables[k].detach().half().float() + (tables[k] - tables[k].detach()),   # fp16 values, f32 grads
+                                sdf_w=p0.sdf_w, sdf_b=p0.sdf_b, rad_w=p0.rad_w, rad_b=p0.rad_b, ln_inv_s=p0.ln_inv_s,
+                                ln_inv_s_factor=p0.ln_inv_s_factor)
+        r = orr.ray_query(pk, o[k], d[k], ha[k], occ, AABB[0], AABB[1], [8, 8, 8], **kw)
+        outs.append(r)
+        if r["num_rays"] > 0:
+            loss_o = loss_o + (r["rendered"]["rgb_volume"] * wgt[k][r["rays_inds"]]).sum() + \
+                0.1 * ((r["volume_buffer"]["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
+    loss_o.backward()
+    # ---- product
+    m.ray_query_cfg = dict(query_mode="march_occ_multi_upsample", query_param=QP)
+    bt = m.batched_ray_test(dv(o), dv(d), near=0.01, far=None, compact_batch=False, rays_h_appear=dv(ha))
+    ret = m.batched_ray_query(batched_ray_tested=bt, config=dict(query_param=QP, with_rgb=True, with_normal=True,
+                                                                 depth_use_normalized_vw=False, _render=True,
+                                                                 query_mode="march_occ_multi_upsample"))
+    assert bt["num_rays"] == sum(r["num_rays"] for r in outs) > 0
+    w_pairs = dv(wgt)[bt["rays_full_bidx"], bt["rays_inds"]]
+    loss = (ret["rendered"]["rgb_volume"] * w_pairs).sum() + \
+        0.1 * ((ret["volume_buffer"]["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
+    assert abs(float(loss) - float(loss_o)) < 2e-4 * (1 + abs(float(loss_o)))
+    loss.backward()
+    m.clean_condition()
+    if by == "ins_id":
+        gz = m.latents.grad.cpu()
+        assert float(gz[1].abs().max()) == 0.0                      # instance 1 is not in the condition
+        assert rel_l2(gz[cond], z_o.grad) < 5e-3
+    else:
+        assert rel_l2(z_in.grad.cpu(), z_o.grad) < 5e-3
+    for lay, ref in zip(m.grower.layers, layers):
+        for k in ("weight", "bias", "u_w", "v_w"):
+            assert rel_l2(getattr(lay, k).grad.cpu(), ref[k].grad) < 5e-3, k
+    assert rel_l2(m.sdf_w.grad.cpu(), torch.cat([w.grad.reshape(-1) for w in p0.sdf_w])) < 5e-3
+    assert rel_l2(m.rad_w.grad.cpu(), torch.cat([w.grad.reshape(-1) for w in p0.rad_w])) < 5e-3
+
+
+def test_grower_at_the_config_sizes():
+    """no_fg_occ.221218.yaml:320-337: z 128 -> dense levels [5, 8, 13, 21] x 4 features, D 5, W 128, rank 10, 6
+    frequencies: 12 095 vertices, 48 380 table entries per instance laid out as 8 kernel levels of 2 features."""
+    from neuralsim_amd.grid_encodings.lotd_growers import DenseLoTDGrowerFMM
+    g = DenseLoTDGrowerFMM(z_dim=128, lod_res=[5, 8, 13, 21], lod_n_feats=4, D=5, W=128, fmm_rank=10, n_frequencies=6)
+    assert sum(g.n_vertices) == 12095 and g.n_params == 48380 and g.kernel_lod_res == [5, 5, 8, 8, 13, 13, 21, 21]
+    assert g.vertex_embedding.shape == (12095, 3 * 13 + 4) and len(g.layers) == 6
+    z = torch.zeros(2, 128)
+    z[1, 3] = 1.0
+    t = g(z)
+    assert t.shape == (2, 48380) and bool(torch.isfinite(t).all()) and float((t[0] - t[1]).abs().max()) > 0
+    # z = 0: the modulation is the constant rank * (rank^-1/4)^2 = sqrt(rank) on every weight
+    W0 = g.layers[0].effective_weight(torch.zeros(1, 128))[0]
+    assert torch.allclose(W0, g.layers[0].weight * (10 ** 0.5), rtol=1e-5)

@@ -475,3 +475,33 @@ def test_reference_mask_entropy_loss(backend):
     sc["model"].encoding.flattened_params.grad = None
     (crisp["loss_mask_entropy.crisp_cr"] + cross["loss_mask_entropy.cross_dv_on_cr"]).backward()
     assert float(sc["model"].encoding.flattened_params.grad.abs().sum()) > 0
+
+
+@needs_reference
+def test_trainer_lidar_losses_equal_the_reference_modules(backend):
+    """``RenderTrainer.lidar_losses`` (the street iteration's lidar step) against the reference's own loss code on the
+    same render: ``LineOfSightLoss(fn_type='neus_unisim')`` (app/loss/lidar.py:174-206) and the masked l1 depth term
+    (``l1_loss(pred, gt, mask, reduction='mean')``, :41 / :271) with the config's weights and ``discard_toofar``."""
+    from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+    from neuralsim_amd.trainer import RenderTrainer
+    from nr3d_lib.models.loss.recon import l1_loss
+    sc = build_scenario("main_train", backend)
+    r = SingleVolumeRenderer(dict(with_rgb=False, with_normal=False, near=0.01, depth_use_normalized_vw=False, perturb=False)).train()
+    ret = r.ray_query(sc["rays_o"], sc["rays_d"], model=sc["model"], return_buffer=True)
+    N = sc["N"]
+    g = torch.Generator().manual_seed(3)
+    ranges = (ret["rendered"]["depth_volume"].detach().cpu() + torch.randn(N, generator=g) * 0.2).clamp_min(0.05)
+    ranges[::5] = 0.0                                   # beams without a return
+    ranges[1::7] = 3.0                                  # ... and beyond discard_toofar
+    ranges = ranges.to(backend)
+    tr = RenderTrainer.__new__(RenderTrainer)
+    tr.lidar = dict(w_depth=0.02, w_los=0.1, epsilon=0.15, discard_toofar=2.5)
+    loss, parts = tr.lidar_losses(ret, ranges)
+    mask = (ranges > 0) & (ranges < 2.5)
+    with ref_glue.reference_lidar_loss_module() as lidar:
+        los = lidar.LineOfSightLoss(w=0.1, fn_type="neus_unisim", fn_param=dict(epsilon=0.15))
+        ref_los = los(None, ret, None, dict(ranges=ranges), it=0, mask=mask)["lidar_loss.los.empty"]
+    ref_depth = 0.02 * l1_loss(ret["rendered"]["depth_volume"], ranges, mask, reduction="mean")
+    assert abs(float(parts["los"]) - float(ref_los)) <= 1e-6 * (1 + abs(float(ref_los)))
+    assert abs(float(parts["depth"]) - float(ref_depth)) <= 1e-6 * (1 + abs(float(ref_depth)))
+    assert float(ref_los) > 0 and float(ref_depth) > 0
