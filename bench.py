@@ -184,15 +184,11 @@ def cpu_baseline(tr, iters=3, iters_small=3):
 # fp16-MFMA rendering vs the f32 oracle on identical rays / weights (eval mode, no perturbation): asserted.
 # tests/test_fullsize_parity.py holds the same comparison (plus f32 mode, samples and gradients) under pytest.
 PARITY_RAYS = 2048
-# Gates: PSNR and the 99th percentile of the per-ray colour error -- measured over repeated runs (the trained state differs
-# from run to run: float atomics): 73-88 dB, p99 2e-4 - 4e-4, p99.9 1.0e-3 - 2.9e-3.  The MAXIMUM is one ray of 2048 and
-# heavy-tailed (1e-3 ... 1.7e-2 between runs / training lengths).  tools/parity_probe.py on the worst ray of such a run: on
-# the ORACLE's own samples the fp16 field agrees to 4e-5 (sdf) / 7e-4 (nablas) / 2e-4 (rgb); the pixel differs because the
-# fp16 SDFs of the sampling pass (2.4e-4 off, times inv_s ~ 400 inside the sigmoid) move up-sampling and keep / drop
-# decisions, the two pipelines integrate over different sample sets (91 vs 96 samples there), and on a ray whose
-# integrand is rough (grazing, or |nablas| 0.9 - 1.18 along it) the two quadratures differ.  It is reported and only
-# guarded against gross failure (a broken kernel moves PSNR and p99).
-PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=0.25)
+# Gates: PSNR, the 99th percentile and the maximum of the per-ray colour error.  Measured (round 3, the sampling pass in
+# f32-equivalent arithmetic, so both sides integrate over the same sample set): 77 dB, p99 2.5e-4, p99.9 1.3e-3, max 1.0e-2
+# (one grazing ray of 2048: the fp16 field differs from the f32 one by ~4e-5 in sdf, times inv_s ~ 150 inside the sigmoid).
+# Round 2 (fp16 sampling pass: different sample sets on 3 % of the rays) needed max <= 0.25.
+PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=2e-2)
 
 
 def parity_check(tr):

@@ -283,6 +283,7 @@ struct NerfArgs {
   int K;                                  // shells per ray (ray = s / K)
   float *sigma, *rgb;                     // forward outputs
   float* h_pl;                            // [16][S][2] saved features
+  int h_from_planes;                      // forward: the features were gathered level-major (k_lotd4_gather_lm)
   const float *sigma_fwd, *rgb_fwd;       // saved forward outputs
   const float *dsigma, *drgb;             // upstream
   float* dh_pl;                           // [16][S][2] hand-off to the scatter
@@ -423,7 +424,23 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
     }
     // -------------------------------------------------------------- features: gather (forward) or planes (backward)
     float rin[32];  // [0,16): own features (first M-tile of the radiance input), [16,32): SH / appearance slots
-    if constexpr (!BWD) {
+    if (!BWD && a.h_from_planes) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b;
+          float f0 = 0.f, f1 = 0.f;
+          if (p.valid && l < a.lotd.num_levels) {
+            const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+            f0 = hp[0];
+            f1 = hp[1];
+          }
+          rin[4 * q + 2 * b] = f0;
+          rin[4 * q + 2 * b + 1] = f1;
+        }
+      }
+    } else if constexpr (!BWD) {
       float u[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.valid) {
 #pragma unroll
@@ -622,6 +639,111 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
   }
 }
 
+// ----------------------------------------------------------------------------------------- 4-D level-major gather
+// The forward's table reads as their own launch, in the form of field.hip's k_lotd_gather_lm: every wave owns
+// G4_PTS x 64 shell points and walks the levels dealt to ITS XCD (block b runs on XCD b % 8 -- used for speed only), so
+// at any moment an XCD streams one or two tables (<= 2 MB each at T = 2^19) through its 4 MB L2 instead of all 16-32 MB
+// of the pyramid at once, with G4_PTS x 16 independent 4-byte loads in flight per lane.  The 64 lanes are consecutive
+// shells of one ray: on the coarse levels they share cells (same lines: coalesced by the texture unit), the fine hashed
+// levels cost one line per x-pair.  Output: the f32 planes h [16][S][2] the decoders (forward AND backward) read.
+#define G4_PTS 2
+struct Gather4Args {
+  Lotd4Dev lotd;
+  const f16* grid;
+  const float* u4;
+  int64_t S;
+  float* h_pl;
+  signed char n[8], lv[8][D4_MAX_LEVELS], half[8][D4_MAX_LEVELS];
+};
+
+__global__ void __launch_bounds__(64) k_lotd4_gather_lm(Gather4Args a) {
+  const int lane = nsim_lane();
+  const int xcd = (int)(blockIdx.x & 7u);
+  const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * G4_PTS) + lane;
+  float u[G4_PTS][4];
+#pragma unroll
+  for (int q = 0; q < G4_PTS; ++q) {
+    const int64_t s = s0 + 64 * q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[q][c] = s < a.S ? a.u4[4 * s + c] : 0.f;
+  }
+  const bool second_half = (blockIdx.x >> 3) >= ((gridDim.x >> 3) + 1) / 2;
+  const int nl = a.n[xcd];
+#pragma unroll 1
+  for (int k = 0; k < nl; ++k) {
+    const int l = a.lv[xcd][k];
+    const int hf = a.half[xcd][k];
+    if ((hf == 1 && second_half) || (hf == 2 && !second_half)) continue;
+    const int Rx = a.lotd.res_xyz[l], Ry = a.lotd.res_y[l], Rz = a.lotd.res_z[l], Rw = a.lotd.res_w[l];
+    const int type = a.lotd.type[l];
+    const uint32_t T = a.lotd.size[l];
+    const int64_t off = a.lotd.offset[l];
+    float f0[G4_PTS], f1[G4_PTS];
+#pragma unroll
+    for (int q = 0; q < G4_PTS; ++q) {
+      const Cell4 c = lotd4_cell(u[q], Rx, Ry, Rz, Rw);
+      f0[q] = f1[q] = 0.f;
+#pragma unroll
+      for (int corner = 0; corner < 16; ++corner) {
+        const float w = lotd4_weight(c, corner);
+        const uint32_t idx = lotd4_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1), c.c0[2] + ((corner >> 2) & 1),
+                                         c.c0[3] + ((corner >> 3) & 1), Rx, Ry, Rz, type, T);
+        float g0, g1;
+        lotd4_load2(a.grid, off, idx, g0, g1);
+        f0[q] = f0[q] + w * g0;
+        f1[q] = f1[q] + w * g1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < G4_PTS; ++q) {
+      const int64_t s = s0 + 64 * q;
+      if (s < a.S) {
+        float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
+        hp[0] = f0[q];
+        hp[1] = f1[q];
+      }
+    }
+  }
+}
+
+// hashed levels cost 1, dense ones ~0.35 (their lines mostly hit L1): most expensive first onto the least loaded XCD,
+// split into two halves of the point range when a whole level would overload it (field.hip deal_levels)
+static void deal_levels4(const NsimLotd4Meta* m, Gather4Args& a) {
+  const int NL = m->num_levels;
+  float cost[D4_MAX_LEVELS], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
+  bool used[D4_MAX_LEVELS] = {false};
+  for (int l = 0; l < NL; ++l) {
+    cost[l] = m->type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f;
+    total += cost[l];
+  }
+  const float limit = total / 8.0f * 1.08f;
+  for (int xc = 0; xc < 8; ++xc) a.n[xc] = 0;
+  auto least = [&]() {
+    int tx = 0;
+    for (int xc = 1; xc < 8; ++xc)
+      if (load[xc] < load[tx]) tx = xc;
+    return tx;
+  };
+  auto put = [&](int xc, int l, int hf, float c) {
+    a.lv[xc][(int)a.n[xc]] = (signed char)l;
+    a.half[xc][(int)a.n[xc]++] = (signed char)hf;
+    load[xc] += c;
+  };
+  for (int it = 0; it < NL; ++it) {
+    int best = -1;
+    for (int l = 0; l < NL; ++l)
+      if (!used[l] && (best < 0 || cost[l] > cost[best] || (cost[l] == cost[best] && m->size[l] > m->size[best]))) best = l;
+    used[best] = true;
+    const int x0 = least();
+    if (load[x0] + cost[best] <= limit || load[x0] == 0.f) {
+      put(x0, best, 0, cost[best]);
+    } else {
+      put(x0, best, 1, 0.5f * cost[best]);
+      put(least(), best, 2, 0.5f * cost[best]);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------- 4-D scatter
 // dgrid[level][vertex][f] += w_c * dh[f]; level-major, one lane per sample, x-adjacent corner pairs issued
 // quad-transposed so {x0.f0,x0.f1,x1.f0,x1.f1} leave as one request (see field.hip / tools/atomic_bench2.hip).
@@ -805,6 +927,20 @@ int nsim_distant_fwd(const NsimDistantMeta* meta, const void* grid_f16, const vo
   a.u4 = u4; a.rays_d = rays_d; a.h_appear = h_appear;
   a.S = S; a.K = K;
   a.sigma = sigma; a.rgb = rgb; a.h_pl = h_planes;
+  static const bool fused_gather = getenv("NSIM_DISTANT_FUSED_GATHER") && atoi(getenv("NSIM_DISTANT_FUSED_GATHER")) == 1;
+  if (h_planes && !fused_gather) {        // training: the table reads as their own level-major launch, decoders on the planes
+    Gather4Args g;
+    g.lotd = a.lotd;
+    g.grid = a.grid;
+    g.u4 = u4;
+    g.S = S;
+    g.h_pl = h_planes;
+    deal_levels4(&meta->lotd, g);
+    const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * G4_PTS)));
+    hipLaunchKernelGGL(k_lotd4_gather_lm, gg, dim3(64), 0, (hipStream_t)stream, g);
+    NSIM_CHECK_LAUNCH();
+    a.h_from_planes = 1;
+  }
   const size_t shmem = meta->precision == 0 ? (size_t)((a.lay.total + 15) & ~15) : 0;
   const dim3 grid(nerf_grid(S, 1024)), block(64 * NERF_WAVES);
   if (meta->precision == 0) hipLaunchKernelGGL((k_nerf<0, 0>), grid, block, shmem, (hipStream_t)stream, a);

@@ -8,9 +8,10 @@ get identical rays, appearance codes and perturbation randoms:
 * ``test_api_path_*``  -- ``ray_test`` + ``ray_query`` + autograd (the drop-in path a reference renderer drives) on 2048
   rays, both query modes.  precision f32 (exact-f32 MFMA): discrete decisions bit-exact (hit rays, march counts, merged /
   compressed sample counts), depths / sdf / colours / images and every gradient tight.  precision fp16 (the product
-  default): images within the stated fp16 tolerance; gradients are compared on the ORACLE's sample set (the up-sampler
-  multiplies the ~1e-4 fp16 error of an SDF by inv_s = 1024, so individual fine samples move -- the sample set is
-  a continuous function of the SDFs, the arithmetic on a given set is what fp16 parity can pin).
+  default): images within the stated fp16 tolerance; gradients are compared on the ORACLE's sample set AND end to end --
+  since round 3 the SDF queries of the sampling pass run in f32-equivalent arithmetic (hi + lo f16 operands on the matrix
+  cores, ``sampling_precision``), so the fp16 step places and keeps the samples the f32 oracle does (in round 2 the
+  up-sampler multiplied the ~1e-4 fp16 error of an SDF by inv_s = 1024 and individual fine samples moved).
 * ``test_fused_step_*`` -- the bench's own launch chain (``RenderTrainer._train_render_fused``: 8192 rays + 4096 uniform
   eikonal points, compressed mode) against the oracle's loss and gradients of the same batch.
 
@@ -241,10 +242,12 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
     else:
         assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
         assert rec["psnr_rgb_db"] > 60.0
-        # end to end the fp16 sampler places a few fine samples elsewhere (59 of 2038 rays kept another count): the table
-        # gradient is entry-specific at the res-2048 level (cell 1e-3), so its rel-L2 is bounded, not tight
+        # Round 3: the sampling pass runs in f32-equivalent arithmetic (``sampling_precision = "split"``), so the fp16 step
+        # works on the oracle's sample set (at most the f32 mode's own threshold flips) and the end-to-end gradients obey
+        # the bounds of the fixed-sample-set leg (round 2, fp16 sampling: 59 of 2038 rays kept another count, gate 0.15)
+        assert rec["rays_with_other_count"] <= TOL["f32"]["flips"], rec
         for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
-            assert rec["e2e_grad_" + k] < 0.15, (k, rec["e2e_grad_" + k])
+            assert rec["e2e_grad_" + k] < gtol, (k, rec["e2e_grad_" + k])
 
 
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
@@ -295,9 +298,7 @@ def test_fused_step_matches_oracle_at_baseline_config(precision):
         for k in got:
             assert rec["grad_" + k] < (tol["grad"] if rec["samples"] == rec["samples_oracle"] else 5e-3), (k, rec["grad_" + k])
     else:
-        assert abs(rec["samples"] - rec["samples_oracle"]) < 0.005 * rec["samples_oracle"]
+        assert abs(rec["samples"] - rec["samples_oracle"]) <= 2 * TOL["f32"]["flips"]      # f32-equivalent sampling pass
         assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
-        # sample membership differs (see the module docstring): the gradient of the SAME loss on a slightly different
-        # quadrature -- bounded, not tight; the tight fp16 gradient check is the fixed-sample-set leg of the API test
-        for k in got:
-            assert rec["grad_" + k] < 0.15, (k, rec["grad_" + k])
+        for k in got:          # compressed set: the fp16 bound of a given sample set (measured 5.9e-3; 0.15 in round 2)
+            assert rec["grad_" + k] < tol["grad"], (k, rec["grad_" + k])
