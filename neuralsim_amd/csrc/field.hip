@@ -196,12 +196,24 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
 // and pass against 12 MFMAs per 32 points).
 #define NSIM_LOG2E 1.4426950408889634f
 #define NSIM_LN2 0.6931471805599453f
-__device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) {
+__device__ __forceinline__ float softplus_exact(float z, float beta, float inv_beta) {
   const float t = nsim_exp2(-fabsf(z) * (beta * NSIM_LOG2E));
   return fmaxf(z, 0.f) + nsim_log2(1.0f + t) * (inv_beta * NSIM_LN2);
 }
+#ifdef NSIM_PROBE_CHEAP_ACT
+// MEASUREMENT AID, never the product build (tools/act_probe.sh): the with-grad decoder kernels with a transcendental-free
+// stand-in of comparable full-rate cost -- the time they lose is the most ANY polynomial activation could win.  The
+// sampling pass (k_field_sdf) keeps the exact form, so the sample sets of a step do not change.
+__device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) {
+  const float q = fmaxf(0.f, 1.0f - 0.25f * beta * fabsf(z));
+  return fmaxf(z, 0.f) + q * q * (inv_beta * NSIM_LN2);
+}
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return fminf(1.0f, 0.72f * a * beta); }
+#else
+__device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) { return softplus_exact(z, beta, inv_beta); }
 // sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)   (abs. error <= 6e-8)
 __device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E)); }
+#endif
 
 __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
   const float x = d[0], y = d[1], z = d[2];
@@ -238,6 +250,12 @@ __device__ __forceinline__ void sh4_grad(const float d[3], const float (&g)[16],
   out[2] = a1 * g[2] - b * y * g[5] + 2.0f * c1 * z * g[6] - b * x * g[7] + gg * x * y * g[10] - 10.0f * h * y * z * g[11] +
            i3 * (15.0f * z2 - 3.0f) * g[12] - 10.0f * h * x * z * g[13] + jj * (x2 - y2) * g[14];
 }
+
+// Plane arrays hold 16 NC levels.  NC == 2 (17..32 levels): the gather writes the pyramid's own levels only and every
+// plane access of the decoders is guarded (a 19-level street pyramid moves 19 / 32 of the bytes).  NC == 1: the gather
+// writes zeros into the planes past num_levels and the guards fold away (measured: run-time guards cost the full 16-level
+// headline kernels 9-10 %).  ``nlv`` = a.lotd.num_levels in scope.
+#define LV_OK(l) (NC == 1 || (l) < nlv)
 
 // ------------------------------------------------------------------------------------------ kernels
 struct FieldArgs {
@@ -488,6 +506,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   // piece thanks to the 32-point pitch) are copied global -> LDS by 16 global_load_lds_dwordx4 while this tile computes;
   // half of a tile used to be the wait for these reads (all workgroups burst together at one wave per SIMD).
   constexpr bool GLDS = (MODE == 3 && NC == 1);
+  const int nlv = a.lotd.num_levels;      // plane levels past it are neither written by the gather nor read here
   char* pf = GLDS ? smem + wbytes + wave * 16384 : nullptr;
   auto prefetch_planes = [&](int64_t tile_n) {
     const int64_t s0 = tile_n * 32;
@@ -525,12 +544,13 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
           const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
           const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
-          h[r0] = valid ? hp[0] : 0.f;
-          h[r0 + 1] = valid ? hp[1] : 0.f;
+          const bool lv = valid && LV_OK(l);
+          h[r0] = lv ? hp[0] : 0.f;
+          h[r0 + 1] = lv ? hp[1] : 0.f;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            J[r0][c3] = valid ? jp[c3] : 0.f;
-            J[r0 + 1][c3] = valid ? jp[3 + c3] : 0.f;
+            J[r0][c3] = lv ? jp[c3] : 0.f;
+            J[r0 + 1][c3] = lv ? jp[3 + c3] : 0.f;
           }
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
@@ -547,7 +567,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             const int l = 16 * m + 4 * q + 2 * hi + b;
             const int r0 = 16 * m + 4 * q + 2 * b;
             h[r0] = h[r0 + 1] = 0.f;
-            if (valid) {
+            if (valid && LV_OK(l)) {
               const float* hp = a.h_pl + ((int64_t)l * a.PS + s) * 2;
               h[r0] = hp[0];
               h[r0 + 1] = hp[1];
@@ -562,7 +582,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             const int r0 = 4 * q + 2 * b;
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
-            if (valid) {
+            if (valid && LV_OK(l)) {
               const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
               for (int c3 = 0; c3 < 3; ++c3) {
@@ -691,6 +711,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               for (int b = 0; b < 2; ++b) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
+                if (!LV_OK(l)) continue;
                 const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + g[r0] * jp[c3] + g[r0 + 1] * jp[3 + c3];
@@ -752,7 +773,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               const int l = 16 * m + 4 * q + 2 * hi + b;
               const int r0 = 16 * m + 4 * q + 2 * b;
               gh[r0] = gh[r0 + 1] = 0.f;
-              if (valid) {
+              if (valid && LV_OK(l)) {
                 const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
                 gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
                 gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
@@ -836,6 +857,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               for (int b = 0; b < 2; ++b) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
+                if (!LV_OK(l)) continue;
                 const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
@@ -860,6 +882,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           for (int b = 0; b < 2; ++b) {
             const int l = 16 * m + 4 * q + 2 * hi + b;
             const int r0 = 16 * m + 4 * q + 2 * b;
+            if (!LV_OK(l)) continue;             // the scatter reads the planes of real levels only
             float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
             float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
             dp[0] = dh[r0];
@@ -911,8 +934,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // (51 KB) = 77 KB -> two workgroups per CU.  J (dh/dx, 48 registers in k_field) is consumed straight from its loads
 // into dL/dg, h is re-read for the last product, g leaves for the scatter as soon as it exists: the live set fits
 // 256 registers = two waves per SIMD (k_field<0,2,2>: 468 registers, 145 KB LDS -> one wave per SIMD).
-// 16-level pyramids (NC = 1); more levels keep k_field<., ., 2, 2>.
-template <int PREC, int SDF_D>
+// NC = 2 (17..32 levels, the street pyramids): the first layer contracts over two 16-level chunks, dW1 is 64 x 64 -> wave w
+// owns its tile (w >> 1, w & 1) over all 128 points like dW2; h / dL/dg / g / dL/dh are 32 wide; dh/dx is consumed
+// straight from its loads (never held: 96 registers), the next group's features are prefetched into registers (the LDS
+// image of a 32-level tile would be 32 KB per wave).  Round 3: k_field<0,1,2,2> 1.76 ms -> this kernel on the street step.
+template <int PREC, int SDF_D, int NC = 1>
 __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -935,15 +961,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   // Software pipeline over the plane reads (512 B per point, the only bulk HBM traffic of this kernel): the features of
   // the NEXT group are requested while this group computes, and dh/dx -- needed only after the recomputed forward -- is
   // requested before it, so that the bursts of all workgroups no longer alternate with their compute phases.
-  auto load_h_at = [&](float (&h)[16], int64_t sp) {
+  const int nlv = a.lotd.num_levels;      // plane levels past it are neither written by the gather nor read here
+  auto load_h_at = [&](float (&h)[16 * NC], int64_t sp) {
     const bool v = sp < a.S;
+#pragma unroll
+    for (int m = 0; m < NC; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+        const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
         h[r0] = h[r0 + 1] = 0.f;
-        if (v) {
+        if (v && LV_OK(l)) {
           const float* hp = a.h_pl + ((int64_t)l * a.PS + sp) * 2;
           h[r0] = hp[0];
           h[r0 + 1] = hp[1];
@@ -952,7 +981,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   };
   // fp16 mode: the whole 16 KB plane image of a wave's NEXT tile (h and dh/dx) is copied global -> LDS while the group
   // computes (as in k_field MODE 3); f32 validation mode (its f32 staging leaves no LDS for it) prefetches h into registers
-  constexpr bool GLDS = (PREC == 0);
+  constexpr bool GLDS = (PREC == 0 && NC == 1);
   char* pf = GLDS ? stC + 64 * jstage_row_bytes<PREC>() + wave * 16384 : nullptr;
   auto prefetch_planes = [&](int64_t tile_n) {
     const int64_t s0 = tile_n * 32;
@@ -963,7 +992,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       nsim_glds16(src, pf + 1024 * l);
     }
   };
-  float hn[16];
+  float hn[16 * NC];
   if constexpr (GLDS) {
     const int64_t t0 = (int64_t)blockIdx.x * JOINT_WAVES + wave;
     if (t0 < ntiles) prefetch_planes(t0);
@@ -987,8 +1016,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
     }
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
-    float h[16];
-    float Jr[16][3];      // dh/dx of this group
+    float h[16 * NC];
+    float Jr[NC == 1 ? 16 : 1][3];      // dh/dx of this group (NC == 2: consumed straight from its loads, below)
+    float gh[16 * NC];                  // dL / dg = J . gn
     if constexpr (GLDS) {
       nsim_wait_vm0();                          // this tile's image has landed
 #pragma unroll
@@ -998,17 +1028,36 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
           const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
           const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
-          h[r0] = valid ? hp[0] : 0.f;
-          h[r0 + 1] = valid ? hp[1] : 0.f;
+          const bool lv = valid && LV_OK(l);
+          h[r0] = lv ? hp[0] : 0.f;
+          h[r0 + 1] = lv ? hp[1] : 0.f;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            Jr[r0][c3] = valid ? jp[c3] : 0.f;
-            Jr[r0 + 1][c3] = valid ? jp[3 + c3] : 0.f;
+            Jr[r0][c3] = lv ? jp[c3] : 0.f;
+            Jr[r0 + 1][c3] = lv ? jp[3 + c3] : 0.f;
           }
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
       const int64_t tn = (grp + gridDim.x) * JOINT_WAVES + wave;
       if (tn < ntiles) prefetch_planes(tn);
+    } else if constexpr (NC == 2) {
+#pragma unroll
+      for (int r = 0; r < 16 * NC; ++r) h[r] = hn[r];
+#pragma unroll
+      for (int m = 0; m < NC; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
+            gh[r0] = gh[r0 + 1] = 0.f;
+            if (valid && LV_OK(l)) {
+              const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+              gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
+              gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+            }
+          }
+      load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[r] = hn[r];
@@ -1019,7 +1068,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
-          if (valid) {
+          if (valid && LV_OK(l)) {
             const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) {
@@ -1033,7 +1082,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     KT(1, 1);
     // ---- decoder forward (recomputed) and d sdf / d h
     float a1[32];
-    dense<PREC, 2, 1>(a1, W + L.mat[M_W1], h, true);
+    dense<PREC, 2, NC>(a1, W + L.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(Wv, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];
@@ -1056,14 +1105,17 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
     }
     {
-      float g[16];
-      dense<PREC, 1, 2>(g, W + L.mat[M_W1T], d1, false);
+      float g[16 * NC];
+      dense<PREC, NC, 2>(g, W + L.mat[M_W1T], d1, false);
       if (valid && a.g_pl) {      // hand-off to the scatter kernel: g = d sdf / d h
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+            const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
+            if (!LV_OK(l)) continue;
             float* gp = a.g_pl + ((int64_t)l * a.S + s) * 2;
             gp[0] = g[r0];
             gp[1] = g[r0 + 1];
@@ -1071,23 +1123,25 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
     }
     // ======================================================================================= backward
-    float gh[16];  // dL / dg = J . gn
+    if constexpr (NC == 1) {
 #pragma unroll
-    for (int f = 0; f < 16; ++f) gh[f] = Jr[f][0] * gn[0] + Jr[f][1] * gn[1] + Jr[f][2] * gn[2];
+      for (int f = 0; f < 16; ++f) gh[f] = Jr[f][0] * gn[0] + Jr[f][1] * gn[1] + Jr[f][2] * gn[2];
+    }
     // ---- dW1 += d1 (x) gh
     KT(1, 2);
     __syncthreads();
     KT(1, 3);                              // the previous group's readers of the staging areas are done
     jstage<PREC, 2>(stA, d1, wave);
-    jstage<PREC, 1>(stB, gh, wave);
+    jstage<PREC, NC>(stB, gh, wave);
     __syncthreads();
     if (do_dw) {
-      if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
+      if constexpr (NC == 2) accW1 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW1);
+      else if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
       else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
     }
     KT(1, 4);
     float dh1[32];  // dL / d d1 = W1 . gh
-    dense<PREC, 2, 1>(dh1, W + L.mat[M_W1], gh, true);
+    dense<PREC, 2, NC>(dh1, W + L.mat[M_W1], gh, true);
     KT(1, 5);
     float dz1[32], whv[32];
     if constexpr (SDF_D == 2) {
@@ -1156,27 +1210,31 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     __syncthreads();
     KT(1, 13);
     jstage<PREC, 2>(stA, dz1, wave);
-    jstage<PREC, 1>(stB, h, wave);
+    jstage<PREC, NC>(stB, h, wave);
     if constexpr (SDF_D == 1) jstage<PREC, 2>(stC, whv, wave);
     __syncthreads();
     if (do_dw) {
-      if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
+      if constexpr (NC == 2) accW1 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW1);
+      else if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
       else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
       bs1 += jrow_sum<PREC>(stA, 64, wave);
       if constexpr (SDF_D == 1) bsh += jrow_sum<PREC>(stC, 64, wave);
     }
     KT(1, 14);
-    float dh[16];
-    dense<PREC, 1, 2>(dh, W + L.mat[M_W1T], dz1, true);
+    float dh[16 * NC];
+    dense<PREC, NC, 2>(dh, W + L.mat[M_W1T], dz1, true);
     KT(1, 15);
     if (a.dx) {   // pose refinement: dL/dx += (dh/dx)^T dL/dh  (dh/dx re-read from the planes: this path is rare)
       float acc[3] = {0.f, 0.f, 0.f};
       if (valid) {
 #pragma unroll
+        for (int m = 0; m < NC; ++m)
+#pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+            const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
+            if (!LV_OK(l)) continue;
             const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
@@ -1191,10 +1249,13 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     }
     if (valid && a.dh_pl) {      // hand-off to the scatter kernel: dL/dh
 #pragma unroll
+      for (int m = 0; m < NC; ++m)
+#pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
+          if (!LV_OK(l)) continue;
           float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
           dp[0] = dh[r0];
           dp[1] = dh[r0 + 1];
@@ -1207,7 +1268,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   // ---- one flush per wave
   const int F1 = 2 * a.lotd.num_levels;
   const SrcOff so = src_off(SDF_D, F1);
-  jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave & 1, 0, accW1);
+  if constexpr (NC == 2) jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave >> 1, wave & 1, accW1);
+  else jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave & 1, 0, accW1);
   if constexpr (SDF_D == 2) {
     jflush_tile(a.dsdf_w + so.w2, 64, 64, 64, wave >> 1, wave & 1, accW2);
     if (bs2 != 0.f) atomicAdd(&a.dsdf_b[so.b2 + lane], bs2);
@@ -1394,18 +1456,20 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = lb + 4 * qq + 2 * hi + b;
-            const int64_t e = (int64_t)l * a.S + (p.valid ? p.s : 0);
+            const int nlv = a.lotd.num_levels;
+            const bool lv = LV_OK(l);      // planes past a 17..32-level pyramid are neither written nor read
+            const int64_t e = (int64_t)(lv ? l : 0) * a.S + (p.valid ? p.s : 0);
             if constexpr (PREC == 0) {
               union {
                 uint32_t u;
                 f16 h[2];
               } cv;
-              cv.u = reinterpret_cast<const uint32_t*>(a.feat_pl)[e];
+              cv.u = lv ? reinterpret_cast<const uint32_t*>(a.feat_pl)[e] : 0u;
               bvp[4 * qq + 2 * b] = cv.h[0];
               bvp[4 * qq + 2 * b + 1] = cv.h[1];
             } else {
-              f8[4 * qq + 2 * b] = reinterpret_cast<const float*>(a.feat_pl)[2 * e];
-              f8[4 * qq + 2 * b + 1] = reinterpret_cast<const float*>(a.feat_pl)[2 * e + 1];
+              f8[4 * qq + 2 * b] = lv ? reinterpret_cast<const float*>(a.feat_pl)[2 * e] : 0.f;
+              f8[4 * qq + 2 * b + 1] = lv ? reinterpret_cast<const float*>(a.feat_pl)[2 * e + 1] : 0.f;
             }
           }
       } else {
@@ -1488,7 +1552,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           f16 h_, l_;
-          split_f16(softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta), h_, l_);
+          split_f16(softplus_exact(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta), h_, l_);
           bqh[2 * mo + (r >> 3)][r & 7] = h_;
           bql[2 * mo + (r >> 3)][r & 7] = l_;
         }
@@ -1507,7 +1571,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
-                          softplus_b(acc2[r] + acc2c[r] * (1.0f / SPLIT_LO_SCALE) + vecf(W, L, V_B2, hi, mo * 16 + r), beta,
+                          softplus_exact(acc2[r] + acc2c[r] * (1.0f / SPLIT_LO_SCALE) + vecf(W, L, V_B2, hi, mo * 16 + r), beta,
                                      inv_beta);
       }
     } else if constexpr (PREC == 2) {
@@ -1516,7 +1580,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
-                          softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+                          softplus_exact(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
     } else if constexpr (PREC == 0 && SDF_D == 2) {
       // register-lean second layer: layer-1 activations are packed to f16 B fragments at once (16 VGPRs), each
       // output M-tile is consumed by the head dot-product as soon as its four MFMAs retire
@@ -1526,7 +1590,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           bq[2 * mo + (r >> 3)][r & 7] =
-              (f16)softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+              (f16)softplus_exact(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
       const f16x8* A2 = reinterpret_cast<const f16x8*>(W + L.mat[M_W2]);
 #pragma unroll
       for (int mo = 0; mo < 2; ++mo) {
@@ -1536,7 +1600,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           sdf = sdf + vecf(W, L, V_WH, hi, mo * 16 + r) *
-                          softplus_b(acc2[r] + vecf(W, L, V_B2, hi, mo * 16 + r), beta, inv_beta);
+                          softplus_exact(acc2[r] + vecf(W, L, V_B2, hi, mo * 16 + r), beta, inv_beta);
       }
     } else {
       float a1[32];
@@ -1544,13 +1608,13 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          a1[mo * 16 + r] = softplus_b(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
+          a1[mo * 16 + r] = softplus_exact(acc[mo][r] * inv_h + vecf(W, L, V_B1, hi, mo * 16 + r), beta, inv_beta);
       if constexpr (SDF_D == 2) {
         float a2[32];
         dense<PREC, 2, 2>(a2, W + L.mat[M_W2], a1, false);
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-          sdf = sdf + vecf(W, L, V_WH, hi, k) * softplus_b(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
+          sdf = sdf + vecf(W, L, V_WH, hi, k) * softplus_exact(a2[k] + vecf(W, L, V_B2, hi, k), beta, inv_beta);
       } else {
 #pragma unroll
         for (int k = 0; k < 32; ++k) sdf = sdf + vecf(W, L, V_WH, hi, k) * a1[k];
@@ -2074,12 +2138,12 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 // loaded XCD -- whole if that keeps the XCD within 8 % of the ideal load, otherwise split into two halves of the point
 // range on two XCDs (3 of the 11 hashed levels of the default pyramid end up split: max load 1.7 instead of 2.0).
 static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
-  // the planes hold 16 nc levels; the ones past num_levels only get zeros written (cheap)
-  const int NL = 16 * field_nc(meta->lotd.num_levels);
+  // the plane arrays hold 16 nc levels; NC == 2: the ones past num_levels are neither written here nor read by the decoders
+  const int NL = field_nc(meta->lotd.num_levels) == 2 ? meta->lotd.num_levels : 16;      // (see LV_OK)
   float cost[32], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
   bool used[32] = {false};
   for (int l = 0; l < NL; ++l) {
-    cost[l] = l >= meta->lotd.num_levels ? (NL > 16 ? 0.05f : 0.35f) : (meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f);
+    cost[l] = l >= meta->lotd.num_levels ? 0.35f : (meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f);
     total += cost[l];
   }
   const float limit = total / 8.0f * 1.08f;
@@ -2298,28 +2362,32 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   // and no accumulator read-modify-write); forced into 256 registers (two waves per SIMD) it spills 177 and takes 0.275 ms,
   // so the two-hidden-layer instantiation runs one wave per SIMD.  NSIM_SDF_BWD_OLD=1: the round-1 kernel (A/B aid).
   const char* oldp = getenv("NSIM_SDF_BWD_OLD");
-  if (nc == 1 && !(oldp && atoi(oldp) == 1)) {
+  if (!(oldp && atoi(oldp) == 1)) {
     // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     // + one 16 KB plane-prefetch buffer per wave in fp16 mode (k_field_bwd_j GLDS)
-    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row + (meta->precision == 0 ? (size_t)JOINT_WAVES * 16384 : 0);
+    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row + (meta->precision == 0 && nc == 1 ? (size_t)JOINT_WAVES * 16384 : 0);
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");
     const int64_t cap = gcap ? atoi(gcap) : 256;          // one resident workgroup per CU (register-limited)
     nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
-    switch (meta->precision * 2 + (meta->sdf_D - 1)) {
+    switch ((nc - 1) * 4 + meta->precision * 2 + (meta->sdf_D - 1)) {
       case 0: hipLaunchKernelGGL((k_field_bwd_j<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_bwd_j<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((k_field_bwd_j<1, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 3: hipLaunchKernelGGL((k_field_bwd_j<1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((k_field_bwd_j<0, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL((k_field_bwd_j<0, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 6: hipLaunchKernelGGL((k_field_bwd_j<1, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 7: hipLaunchKernelGGL((k_field_bwd_j<1, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
     }
     NSIM_CHECK_LAUNCH();
     return 0;
   }
-  // more than 16 levels: fp16: one private accumulator copy per wave + staging, weights from L2; f32: staged weights +
-  // one shared accumulator
+  // NSIM_SDF_BWD_OLD=1 (A/B aid): the round-1 kernel; more than 16 levels: fp16: one private accumulator copy per wave +
+  // staging, weights from L2; f32: staged weights + one shared accumulator
   const size_t acc_bytes = ((6400 + 2048 * (nc - 1)) * 4 + 15) & ~15;
   const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + nw * acc_bytes + nw * stage_bytes(meta)
                                             : weights_lds_bytes(meta, 0, 4) + acc_bytes + FIELD_WAVES * stage_bytes(meta);

@@ -64,6 +64,21 @@ def test_lotd_fwd_dydx_bwd(backend):
     assert rel_l2(enc.flattened_params.grad.cpu(), grid_o.grad) < 1e-5
 
 
+@pytest.fixture
+def poisoned_empty(monkeypatch):
+    """``torch.empty`` hands out NaN-filled float buffers: the plane arrays hold 16 / 32 levels, the gather writes the
+    pyramid's own levels only, so a decoder that reads a plane past ``num_levels`` (or any other buffer it was never
+    given) turns its outputs into NaN."""
+    real = torch.empty
+
+    def empty(*a, **k):
+        t = real(*a, **k)
+        if t.is_floating_point() and t.numel():
+            t.fill_(float("nan"))
+        return t
+    monkeypatch.setattr(torch, "empty", empty)
+
+
 @pytest.mark.parametrize("sdf_D", [1, 2])
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
 def test_field_fwd_bwd(backend, sdf_D, precision):
@@ -255,7 +270,7 @@ def test_anneal_schedule():
 
 
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
-def test_field_fewer_than_16_levels(backend, precision):
+def test_field_fewer_than_16_levels(backend, precision, poisoned_empty):
     """Pyramids with fewer than 16 levels (decoder input 2 L < 32): values, normals, colours and all gradients."""
     from oracle import lotd as olotd
     lod_res = list(SMALL_RES_T[:11])
@@ -301,7 +316,7 @@ def test_field_fewer_than_16_levels(backend, precision):
 
 
 @pytest.mark.parametrize("levels,sdf_D,precision", [(19, 2, "f32"), (19, 2, "fp16"), (24, 1, "f32"), (32, 2, "fp16")])
-def test_field_more_than_16_levels(backend, levels, sdf_D, precision):
+def test_field_more_than_16_levels(backend, levels, sdf_D, precision, poisoned_empty):
     """Pyramids with 17..32 levels (the street configs' auto pyramids have ~18-20): the decoder's first layer contracts
     over two 16-level feature chunks (csrc/field.hip: NC = 2) -- values, normals, colours, the no-grad SDF query and all
     gradients against the oracle."""

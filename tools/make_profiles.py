@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """gpurun_out/prof_*.json (written by tools/refresh_profiles.sh on the GPU box) -> tracked summaries under profiles/."""
 import json
+import re
 import sys
 from pathlib import Path
 
@@ -9,11 +10,11 @@ G, P = ROOT / "gpurun_out", ROOT / "profiles"
 TAG = sys.argv[1] if len(sys.argv) > 1 else "round1"
 # C-ABI entry point -> kernel it launches (substring of the rocprofv3 kernel name)
 ABI = {
-    "nsim_lotd_gather_lm": "k_lotd_gather_lm<0, false>",
-    "nsim_field_sdf": "k_field_sdf<0, 2, true>",
+    "nsim_lotd_gather_lm": "k_lotd_gather_lm<1, false>",   # round 3: f32 feature planes for the split-precision decoder
+    "nsim_field_sdf": "k_field_sdf<2, 2, true",            # round 3: the sampling pass runs the split-precision decoder
     "nsim_field_fwd": "k_field<0, 2, 3>",            # decoder half; its gather half is k_lotd_gather_lm<0, true>
     "nsim_field_fwd(gather)": "k_lotd_gather_lm<0, true>",
-    "nsim_field_bwd_sdf": "k_field<0, 2, 2>",
+    "nsim_field_bwd_sdf": "k_field_bwd_j<0, 2>",
     "nsim_field_bwd_rad": "k_rad_bwd_j<0>",
     "nsim_lotd_scatter": "k_lotd_scatter",
 }
@@ -91,6 +92,37 @@ def main():
                  "(gfx94x derived-metric formula); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; "
                  "waves_per_cu_cycle = SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES = resident waves per busy CU (4 SIMDs).",
             kernels=ks), indent=1))
+    # round 3: the distant-model step, the street configuration, per-level scatter timing
+    def table(src, steps, title, dst, own_only=False):
+        f = G / src
+        if not f.exists():
+            return
+        d = json.loads(f.read_text())
+        out_l = [title, f"{'kernel':72s} {'calls':>7s} {'us/step':>9s} {'avg us':>9s} {'%':>6s}"]
+        rows = d.get("kernels", [])
+        if own_only:        # the library's kernels only (k_* / _Z6k_adam...): ATen rows of such a run are set-up work
+            rows = [k for k in rows if re.search(r"(^|\s|::)k_[a-z0-9_]+|_Z\d+k_", k["name"]) and "at::native" not in k["name"]]
+            tot = sum(k["total_us"] for k in rows)
+            out_l.insert(1, f"library kernels only: {tot / steps:.1f} us per step in {sum(k['calls'] for k in rows) / steps:.0f} launches "
+                            f"(the '%' column is of the WHOLE process, set-up included)")
+        for k in rows[:32]:
+            out_l.append(f"{k['name'][:72]:72s} {k['calls']:7d} {k['total_us'] / steps:9.1f} {k['avg_us']:9.2f} {k['pct']:6.2f}")
+        (P / dst).write_text("\n".join(out_l) + "\n")
+    table("prof_distant_stats.json", 24, f"rocprofv3 --kernel-trace --stats -- python bench.py --distant --steps 16 --warmup 8 "
+          f"--no-cpu-baseline --no-variants --no-parity   (MI355X, {TAG}; 24 steps)", f"{TAG}_distant_rocprofv3_kernel_stats.txt")
+    table("prof_street_stats.json", 12, f"rocprofv3 --kernel-trace --stats -- python bench.py --config street --steps 8 --warmup 4   "
+          f"(MI355X, {TAG}; 12 steps; ATen kernels left out: they are dominated by the one-off dataset synthesis of the set-up)",
+          f"{TAG}_street_rocprofv3_kernel_stats.txt", own_only=True)
+    for src, dst in (("prof_distant_bench.json", f"{TAG}_bench_n1_distant.json"), ("prof_street_bench.json", f"{TAG}_bench_n1_street.json"),
+                     ("prof_scatter_levels.json", f"{TAG}_scatter_levels.json"), ("prof_distant_pmc_sq.json", f"{TAG}_distant_pmc_sq.json"),
+                     ("prof_distant_fusedgather.json", f"{TAG}_bench_n1_distant_fused_gather.json")):
+        f = G / src
+        if f.exists():
+            txt = f.read_text().strip()
+            try:
+                (P / dst).write_text(json.dumps(json.loads(txt.splitlines()[-1] if src.endswith("bench.json") or "fusedgather" in src else txt), indent=1))
+            except Exception:
+                (P / dst).write_text(txt)
     print(json.dumps(traffic, indent=1))
     print(bench["value"], bench["ms_per_step"], bench["roofline"])
 

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): bench line + rocprofv3 kernel stats + gap profile + the HBM and SQ/MFMA PMC passes of
-# the same command (counters in their own runs, --kernel-trace only).  Small JSON summaries land in gpurun_out/ (the raw
-# databases stay in /tmp); tools/make_profiles.py turns them into the tracked files under profiles/.
+# the same command (counters in their own runs, --kernel-trace only), then the kernel stats of the distant-model and
+# street-config steps.  Small JSON summaries land in gpurun_out/ (the raw databases stay in /tmp);
+# tools/make_profiles.py turns them into the tracked files under profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -19,4 +20,15 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o w -- $C
 python $R/tools/prof_summary.py $(find /tmp/p_write -name "*.db" | head -1) $O/prof_pmc_write.json
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/p_sq -o q -- $CMD > /dev/null 2>/tmp/e4.log
 python $R/tools/prof_summary.py $(find /tmp/p_sq -name "*.db" | head -1) $O/prof_pmc_sq.json
+# the distant-model step and the street configuration: kernel stats (steady state: 24 / 12 steps incl. warm-up)
+DCMD="python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_dist -o s -- $DCMD > $O/prof_distant_bench.json 2>/tmp/e5.log
+python $R/tools/prof_summary.py $(find /tmp/p_dist -name "*.db" | head -1) $O/prof_distant_stats.json
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/p_dsq -o q -- $DCMD > /dev/null 2>/tmp/e6.log
+python $R/tools/prof_summary.py $(find /tmp/p_dsq -name "*.db" | head -1) $O/prof_distant_pmc_sq.json
+SCMD="python $R/bench.py --config street --steps 8 --warmup 4"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_street -o s -- $SCMD > $O/prof_street_bench.json 2>/tmp/e7.log
+python $R/tools/prof_summary.py $(find /tmp/p_street -name "*.db" | head -1) $O/prof_street_stats.json
+timeout 300 python $R/tools/scatter_levels.py $O/prof_scatter_levels.json > /dev/null 2>&1
+NSIM_DISTANT_FUSED_GATHER=1 timeout 300 python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity > $O/prof_distant_fusedgather.json 2>/dev/null
 tail -1 $O/prof_bench.json | cut -c1-300
