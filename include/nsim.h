@@ -280,6 +280,15 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
                    float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream);
+/* Optional scratch for the weight-gradient flush of the backward launches (1) and (2) below.  Every workgroup of those
+ * launches ends by adding its partial dW / db into the same few thousand floats; hundreds of same-address atomics per
+ * address serialise in L2 (measured: ~55 us of a 100 us radiance backward).  With a caller-owned, ZEROED buffer of
+ * ``floats`` floats registered for ``stream`` (>= 16 x 8448 covers every decoder shape), workgroup b adds into replica
+ * b % 16 of it and a small second launch folds the replicas into dW / db and zeroes the buffer again: the buffer is zero
+ * whenever no launch of that stream is in flight.  buf = NULL unregisters.  Without a registration (or with
+ * NSIM_GRAD_REPLICAS=1) the launches add into dW / db directly, as before.  The reference has no counterpart: its
+ * autograd backward of the tcnn-style MLP reduces weight gradients inside one GEMM. */
+int nsim_set_grad_scratch(float* buf, int64_t floats, void* stream);
 /* Backward of nsim_field_fwd = three launches (each its own entry point so that callers can time / overlap them):
  *
  * (1) radiance branch: given dL/drgb [S,3], the saved forward nablas_fwd / rgb_fwd [S,3] and the upstream

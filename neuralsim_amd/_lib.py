@@ -103,6 +103,7 @@ SIGNATURES = {
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, C.POINTER(OccMeta), _F],
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
+    "nsim_set_grad_scratch": [_P, _I64],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
@@ -264,10 +265,31 @@ def _marshal(args):
     return out
 
 
+_GRAD_SCRATCH = {}
+_GRAD_SCRATCH_USERS = ("nsim_field_bwd_rad", "nsim_field_bwd_sdf")
+GRAD_SCRATCH_FLOATS = 16 * 8448       # 16 replicas of the largest decoder gradient (64 x 64 + 64 x 64 + 64 + 129 floats)
+
+
+def ensure_grad_scratch(device):
+    """Register (once per device and stream) the zeroed scratch the backward launches spread their weight-gradient
+    flush over (include/nsim.h: nsim_set_grad_scratch); the tensor is kept alive here."""
+    key = (str(device), stream_handle())
+    if key not in _GRAD_SCRATCH:
+        buf = torch.zeros([GRAD_SCRATCH_FLOATS], dtype=torch.float32, device=device)
+        _GRAD_SCRATCH[key] = buf
+        call("nsim_set_grad_scratch", buf, buf.numel())
+    return _GRAD_SCRATCH[key]
+
+
 def call(name: str, *args):
     """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code.  Tensor arguments are
     passed as their device pointers (checked: device-resident, contiguous)."""
     lib = get_lib()
+    if name in _GRAD_SCRATCH_USERS:
+        for a_ in args:
+            if isinstance(a_, _Tensor):
+                ensure_grad_scratch(a_.device)
+                break
     cargs = _marshal(args)
     if TIMER is not None and (TIMER.only is None or name in TIMER.only):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

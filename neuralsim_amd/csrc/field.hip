@@ -286,6 +286,9 @@ struct FieldArgs {
   OccDev occ;                                      // ... (update_from_samples_cfg; needs positions in ``x``)
   float occ_inv_s;
   int ablate;                                      // profiling aid (NSIM_ABLATE): 1 no scatter, 4 no dW products, 8 no dh_appear atomics
+  int code_pf;                                     // bytes of this kernel's own code pulled into L2 by the prologue (stage_weights)
+  int rep_mask;                                    // weight-gradient replicas (nsim_set_grad_scratch): workgroup b flushes into
+  int64_t rep_stride;                              // copy (b & rep_mask) at + rep_stride floats; 0 / 0 = the caller's buffers
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
 };
@@ -329,11 +332,26 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 // phase boundaries of their SECOND group iteration, read back by tools/ktime.py through nsim_debug_ktime.
 #ifdef NSIM_KTIME
 __device__ long long g_ktime[3][64 * 24];
+__device__ long long g_ktime1[3][64 * 24];      // the FIRST group iteration of the same workgroups (cold pass)
+__device__ long long g_kiter[3][64 * 32];       // loop-top stamp of EVERY group iteration (first 32) of the same workgroups
 #define KT(K, i)                                                                                          \
-  if (blockIdx.x < 64 && wave == 0 && lane == 0 && (grp == (int64_t)blockIdx.x + gridDim.x || (i) >= 20)) \
-  g_ktime[K][blockIdx.x * 24 + (i)] = (long long)__builtin_amdgcn_s_memtime()
+  if (blockIdx.x < 64 && wave == 0 && lane == 0) {                                                        \
+    if ((i) == 0 && grp >= 0 && (grp - (int64_t)blockIdx.x) / (int64_t)gridDim.x < 32)                    \
+      g_kiter[K][blockIdx.x * 32 + (grp - (int64_t)blockIdx.x) / (int64_t)gridDim.x] =                   \
+          (long long)__builtin_amdgcn_s_memtime();                                                        \
+    if (grp == (int64_t)blockIdx.x + gridDim.x || (i) >= 20)                                              \
+      g_ktime[K][blockIdx.x * 24 + (i)] = (long long)__builtin_amdgcn_s_memtime();                        \
+    else if (grp == (int64_t)blockIdx.x)                                                                  \
+      g_ktime1[K][blockIdx.x * 24 + (i)] = (long long)__builtin_amdgcn_s_memtime();                       \
+  }
 extern "C" int nsim_debug_ktime(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktime), sizeof(g_ktime));
+}
+extern "C" int nsim_debug_kiter(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kiter), sizeof(g_kiter));
+}
+extern "C" int nsim_debug_ktime1(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktime1), sizeof(g_ktime1));
 }
 #else
 #define KT(K, i)
@@ -346,6 +364,7 @@ template <int PREC>
 __device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs& a, int first, int count,
                                                      FieldLayout& Lk, int& lds_used) {
   Lk = a.lay;
+  nsim_prefetch_own_code(a.code_pf, smem);
   if constexpr (PREC != 1) {
     const int64_t m0 = a.lay.mat[first];
     const int64_t m1 = (first + count < M_COUNT) ? a.lay.mat[first + count] : a.lay.vec[0];
@@ -1268,15 +1287,16 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   // ---- one flush per wave
   const int F1 = 2 * a.lotd.num_levels;
   const SrcOff so = src_off(SDF_D, F1);
-  if constexpr (NC == 2) jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave >> 1, wave & 1, accW1);
-  else jflush_tile(a.dsdf_w + so.w1, F1, 64, F1, wave & 1, 0, accW1);
+  const int64_t ro = (int64_t)(blockIdx.x & (unsigned)a.rep_mask) * a.rep_stride;      // this workgroup's replica
+  if constexpr (NC == 2) jflush_tile(a.dsdf_w + ro + so.w1, F1, 64, F1, wave >> 1, wave & 1, accW1);
+  else jflush_tile(a.dsdf_w + ro + so.w1, F1, 64, F1, wave & 1, 0, accW1);
   if constexpr (SDF_D == 2) {
-    jflush_tile(a.dsdf_w + so.w2, 64, 64, 64, wave >> 1, wave & 1, accW2);
-    if (bs2 != 0.f) atomicAdd(&a.dsdf_b[so.b2 + lane], bs2);
+    jflush_tile(a.dsdf_w + ro + so.w2, 64, 64, 64, wave >> 1, wave & 1, accW2);
+    if (bs2 != 0.f) atomicAdd(&a.dsdf_b[ro + so.b2 + lane], bs2);
   }
-  if (bs1 != 0.f) atomicAdd(&a.dsdf_b[so.b1 + lane], bs1);
-  if (bsh != 0.f) atomicAdd(&a.dsdf_w[so.wh + lane], bsh);
-  if (lane == 0 && bh != 0.f) atomicAdd(&a.dsdf_b[so.bh], bh);
+  if (bs1 != 0.f) atomicAdd(&a.dsdf_b[ro + so.b1 + lane], bs1);
+  if (bsh != 0.f) atomicAdd(&a.dsdf_w[ro + so.wh + lane], bsh);
+  if (lane == 0 && bh != 0.f) atomicAdd(&a.dsdf_b[ro + so.bh], bh);
   { const int64_t grp = -1; KT(1, 22); }
 }
 
@@ -1791,12 +1811,13 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
   { const int64_t grp = -1; KT(0, 21); }
   // ---- one flush per wave
   const SrcOff so = src_off(1);
-  jflush_tile(a.drad_w + so.r2, 64, 64, 64, wave >> 1, wave & 1, accR2);
-  if (wave < 2) jflush_tile(a.drad_w + so.r3, 64, 3, 64, 0, wave, accX);
-  else jflush_tile(a.drad_w + so.r1, 26, 64, 26, wave - 2, 0, accX);
-  if (bs1 != 0.f) atomicAdd(&a.drad_b[so.rb1 + lane], bs1);
-  if (bs2 != 0.f) atomicAdd(&a.drad_b[so.rb2 + lane], bs2);
-  if (lane < 3 && bs3 != 0.f) atomicAdd(&a.drad_b[so.rb3 + lane], bs3);
+  const int64_t ro = (int64_t)(blockIdx.x & (unsigned)a.rep_mask) * a.rep_stride;      // this workgroup's replica
+  jflush_tile(a.drad_w + ro + so.r2, 64, 64, 64, wave >> 1, wave & 1, accR2);
+  if (wave < 2) jflush_tile(a.drad_w + ro + so.r3, 64, 3, 64, 0, wave, accX);
+  else jflush_tile(a.drad_w + ro + so.r1, 26, 64, 26, wave - 2, 0, accX);
+  if (bs1 != 0.f) atomicAdd(&a.drad_b[ro + so.rb1 + lane], bs1);
+  if (bs2 != 0.f) atomicAdd(&a.drad_b[ro + so.rb2 + lane], bs2);
+  if (lane < 3 && bs3 != 0.f) atomicAdd(&a.drad_b[ro + so.rb3 + lane], bs3);
   { const int64_t grp = -1; KT(0, 22); }
 }
 
@@ -2036,11 +2057,73 @@ static int field_meta_check_full(const NsimFieldMeta* m) {
   return rc ? rc : (m->precision == 2 ? 23 : 0);
 }
 
+// ------------------------------------------------------------------------------------ weight-gradient replicas
+// The joint backward kernels end with every workgroup adding its partial weight gradients into the SAME ~6 k floats.
+// 256-512 same-address atomics per address serialise in L2 at ~0.1 us each: s_memtime stamps (tools/ktime.py, round 3)
+// show the last group of the radiance backward waiting ~55 us of a 100 us launch behind that storm.  With a caller-owned,
+// zeroed scratch registered for the stream (nsim_set_grad_scratch), workgroup b flushes into replica b % R instead and a
+// small second launch folds the R copies into the caller's gradient buffers (and zeroes the scratch again).
+struct GradScratch {
+  void* stream;
+  float* buf;
+  int64_t floats;
+};
+static GradScratch g_grad_scratch[16];
+static int g_grad_scratch_n = 0;
+
+__global__ void __launch_bounds__(256) k_rep_reduce(float* __restrict__ sc, int R, int64_t stride, int64_t n_w,
+                                                    float* __restrict__ dst_w, float* __restrict__ dst_b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) {
+    s += sc[r * stride + i];
+    sc[r * stride + i] = 0.f;
+  }
+  if (s != 0.f) {
+    float* d = i < n_w ? dst_w + i : dst_b + (i - n_w);
+    *d = *d + s;
+  }
+}
+
+static int grad_replicas_min_wg() {      // launches with fewer workgroups have no storm to avoid (tests lower it)
+  const char* e = getenv("NSIM_GRAD_REPLICAS_MIN_WG");
+  return e ? atoi(e) : 64;
+}
+
+static int grad_replicas() {
+  static const int r = [] {
+    const char* e = getenv("NSIM_GRAD_REPLICAS");
+    int v = e ? atoi(e) : 16;
+    int p = 1;
+    while (p * 2 <= v && p < 64) p *= 2;      // a power of two, 1 = off
+    return v <= 1 ? 1 : p;
+  }();
+  return r;
+}
+
+// the registered scratch of ``stream`` if it holds R x n floats, else NULL (= flush into the caller's buffers directly)
+static float* grad_scratch(void* stream, int64_t n, int& R) {
+  R = grad_replicas();
+  if (R <= 1) return nullptr;
+  for (int i = 0; i < g_grad_scratch_n; ++i)
+    if (g_grad_scratch[i].stream == stream && g_grad_scratch[i].buf && g_grad_scratch[i].floats >= (int64_t)R * n)
+      return g_grad_scratch[i].buf;
+  return nullptr;
+}
+
+static void grad_scratch_fold(float* sc, int R, int64_t n_w, int64_t n_b, float* dst_w, float* dst_b, hipStream_t stream) {
+  const int64_t n = n_w + n_b;
+  hipLaunchKernelGGL(k_rep_reduce, dim3(nsim_blocks(n, 256)), dim3(256), 0, stream, sc, R, n, n_w, dst_w, dst_b, n);
+}
+
 static FieldArgs field_args(const NsimFieldMeta* meta) {
   FieldArgs a = FieldArgs();
   a.lotd = lotd_dev(&meta->lotd);
   a.lay = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
   a.beta = meta->softplus_beta;
+  static const int code_pf = getenv("NSIM_CODE_PREFETCH") ? atoi(getenv("NSIM_CODE_PREFETCH")) : 0;
+  a.code_pf = code_pf;
   return a;
 }
 
@@ -2226,7 +2309,10 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     a.occ = occ_dev(occ_meta);
     a.occ_inv_s = occ_inv_s;
   }
-  const dim3 grid(field_grid(S, 2048)), block(64 * FIELD_WAVES);
+  // 512 persistent workgroups (two per CU): at 2048 a wave staged 26 KB of weights for ~1.2 tiles of work
+  // (0.0506 -> 0.0463 ms per 0.31 M points; 1024: 0.0483, 256: 0.0706)
+  static const int sdf_grid = getenv("NSIM_SDF_GRID") ? atoi(getenv("NSIM_SDF_GRID")) : 512;
+  const dim3 grid(field_grid(S, sdf_grid)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
   if (meta->precision == 2 && !feat_scratch) return 33;     // split precision: level-major path only
@@ -2296,9 +2382,29 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     const size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
     size_t wl = weights_lds_bytes(meta);
     if (meta->precision != 0) wl = 0;
-    return field_launch<3>(meta, a, wl + pf_bytes, FIELD_GRID_FWD, (hipStream_t)stream);
+    // persistent workgroups: with the plane-prefetch buffers one workgroup fits a CU (124 KB of LDS), 1024 of them ran as
+    // four rounds that each staged the weights and took a cold first tile (s_memtime stamps: 22.5 k vs 16.7 k ticks) --
+    // one round of 256: 0.197 -> 0.189 ms per 0.31 M points (gather included); the 17..32-level kernel fits two per CU
+    static const int fwd_grid_env = getenv("NSIM_FWD_GRID") ? atoi(getenv("NSIM_FWD_GRID")) : 0;
+    const int fwd_grid = fwd_grid_env > 0 ? fwd_grid_env : (pf_bytes ? 256 : 512);
+    return field_launch<3>(meta, a, wl + pf_bytes, fwd_grid, (hipStream_t)stream);
   }
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
+}
+
+int nsim_set_grad_scratch(float* buf, int64_t floats, void* stream) {
+  for (int i = 0; i < g_grad_scratch_n; ++i)
+    if (g_grad_scratch[i].stream == stream) {
+      g_grad_scratch[i].buf = buf;
+      g_grad_scratch[i].floats = buf ? floats : 0;
+      return 0;
+    }
+  if (!buf) return 0;
+  if (g_grad_scratch_n >= 16) return 34;
+  g_grad_scratch[g_grad_scratch_n].stream = stream;
+  g_grad_scratch[g_grad_scratch_n].buf = buf;
+  g_grad_scratch[g_grad_scratch_n++].floats = floats;
+  return 0;
 }
 
 int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float* nablas_fwd, const float* rgb_fwd,
@@ -2330,8 +2436,16 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
   nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);          // two resident workgroups per CU
   const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
+  const SrcOff so = src_off(1);
+  int R = 1;
+  float* sc = nb >= grad_replicas_min_wg() ? grad_scratch(stream, so.n_rad_w + so.n_rad_b, R) : nullptr;
+  if (sc) {
+    a.drad_w = sc; a.drad_b = sc + so.n_rad_w;
+    a.rep_mask = R - 1; a.rep_stride = so.n_rad_w + so.n_rad_b;
+  }
   if (meta->precision == 0) hipLaunchKernelGGL((k_rad_bwd_j<0>), grid, block, shmem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_rad_bwd_j<1>), grid, block, shmem, (hipStream_t)stream, a);
+  if (sc) grad_scratch_fold(sc, R, so.n_rad_w, so.n_rad_b, drad_w, drad_b, (hipStream_t)stream);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -2373,6 +2487,13 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
     const int64_t cap = gcap ? atoi(gcap) : 256;          // one resident workgroup per CU (register-limited)
     nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
+    const SrcOff so = src_off(meta->sdf_D, 2 * meta->lotd.num_levels);
+    int R = 1;
+    float* sc = nb >= grad_replicas_min_wg() ? grad_scratch(stream, so.n_sdf_w + so.n_sdf_b, R) : nullptr;
+    if (sc) {
+      a.dsdf_w = sc; a.dsdf_b = sc + so.n_sdf_w;
+      a.rep_mask = R - 1; a.rep_stride = so.n_sdf_w + so.n_sdf_b;
+    }
     switch ((nc - 1) * 4 + meta->precision * 2 + (meta->sdf_D - 1)) {
       case 0: hipLaunchKernelGGL((k_field_bwd_j<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_bwd_j<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
@@ -2383,6 +2504,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
       case 6: hipLaunchKernelGGL((k_field_bwd_j<1, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 7: hipLaunchKernelGGL((k_field_bwd_j<1, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
     }
+    if (sc) grad_scratch_fold(sc, R, so.n_sdf_w, so.n_sdf_b, dsdf_w, dsdf_b, (hipStream_t)stream);
     NSIM_CHECK_LAUNCH();
     return 0;
   }

@@ -29,6 +29,7 @@ const char* nsim_strerror(int code) {
     case 20: return "field meta is NULL";
     case 21: return "field kernels take 1..32 LoTD levels (<= 64 input features)";
     case 33: return "pyramids with more than 16 levels exist on the level-major path only: the planes arguments are required";
+    case 34: return "too many streams with a registered gradient scratch (16)";
     case 22: return "sdf_D must be 1 or 2";
     case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";
     case 24: return "need either x or (rays_o, rays_d, t, ridx)";

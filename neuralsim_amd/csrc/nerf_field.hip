@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b;
           float f0 = 0.f, f1 = 0.f;
-          if (p.valid) {
+          if (p.valid && l < a.lotd.num_levels) {      // (the level-major gather writes the pyramid's own levels only)
             const float* hp = a.h_pl + ((int64_t)l * a.S + s) * 2;
             f0 = hp[0];
             f1 = hp[1];
@@ -596,6 +596,7 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = 4 * q + 2 * hi + b;
+            if (l >= a.lotd.num_levels) continue;      // (the scatter reads the pyramid's own levels only)
             float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
             dp[0] = dh[4 * q + 2 * b] + din[4 * q + 2 * b];
             dp[1] = dh[4 * q + 2 * b + 1] + din[4 * q + 2 * b + 1];
@@ -942,7 +943,9 @@ int nsim_distant_fwd(const NsimDistantMeta* meta, const void* grid_f16, const vo
     a.h_from_planes = 1;
   }
   const size_t shmem = meta->precision == 0 ? (size_t)((a.lay.total + 15) & ~15) : 0;
-  const dim3 grid(nerf_grid(S, 1024)), block(64 * NERF_WAVES);
+  // persistent workgroups, one per CU (decoder part of nsim_distant_fwd per 0.52 M shells: 0.125 ms at 1024, 0.113 at 256)
+  static const int fwd_grid = getenv("NSIM_NERF_FWD_GRID") ? atoi(getenv("NSIM_NERF_FWD_GRID")) : 256;
+  const dim3 grid(nerf_grid(S, fwd_grid)), block(64 * NERF_WAVES);
   if (meta->precision == 0) hipLaunchKernelGGL((k_nerf<0, 0>), grid, block, shmem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_nerf<1, 0>), grid, block, shmem, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();

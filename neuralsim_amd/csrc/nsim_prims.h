@@ -158,6 +158,21 @@ __device__ __forceinline__ uint32_t grid_load_u32(const GridRef& g, uint32_t ele
 }
 
 // ------------------------------------------------------------------ a word the HOST reads while the stream keeps running
+// The decoder kernels are 9-33 KB of straight-line code and run for ~0.1 ms; between two launches of one of them hundreds
+// of MB stream through L2, so every launch starts with its code in HBM and the first pass through it is a chain of
+// instruction-cache misses to memory.  One 64-byte line per thread, read as DATA from the kernel's own program counter
+// on, puts the next ``bytes`` of code into this XCD's L2 in one round trip; the instruction fetches behind it then miss
+// to L2, not to HBM.  (``bytes`` is at most the distance to the end of the code object's text: the callers are not the
+// last functions of field.hip's ~1 MB text.)
+__device__ __forceinline__ void nsim_prefetch_own_code(int bytes, char* smem) {
+  if (bytes <= 0) return;
+  const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+  uint32_t acc = 0u;
+  for (int i = (int)threadIdx.x * 64; i < bytes; i += (int)blockDim.x * 64)
+    acc ^= *reinterpret_cast<const volatile uint32_t*>(pc + i);
+  if (acc == 0x9e3779b9u && bytes < 0) reinterpret_cast<volatile uint32_t*>(smem)[0] = acc;      // (keeps the loads)
+}
+
 // (host-mapped pinned memory): system-scope store
 __device__ __forceinline__ void nsim_store_system(int64_t* p, int64_t v, bool release) {
   if (release) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

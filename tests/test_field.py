@@ -64,21 +64,6 @@ def test_lotd_fwd_dydx_bwd(backend):
     assert rel_l2(enc.flattened_params.grad.cpu(), grid_o.grad) < 1e-5
 
 
-@pytest.fixture
-def poisoned_empty(monkeypatch):
-    """``torch.empty`` hands out NaN-filled float buffers: the plane arrays hold 16 / 32 levels, the gather writes the
-    pyramid's own levels only, so a decoder that reads a plane past ``num_levels`` (or any other buffer it was never
-    given) turns its outputs into NaN."""
-    real = torch.empty
-
-    def empty(*a, **k):
-        t = real(*a, **k)
-        if t.is_floating_point() and t.numel():
-            t.fill_(float("nan"))
-        return t
-    monkeypatch.setattr(torch, "empty", empty)
-
-
 @pytest.mark.parametrize("sdf_D", [1, 2])
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
 def test_field_fwd_bwd(backend, sdf_D, precision):
@@ -118,6 +103,42 @@ def test_field_fwd_bwd(backend, sdf_D, precision):
         e = rel_l2(v.cpu(), ref[k])
         assert e < gtol, (k, e)
     assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < gtol
+
+
+@pytest.mark.parametrize("levels", [16, 19])
+def test_weight_gradient_replicas_match_the_direct_flush(backend, levels, monkeypatch):
+    """The joint backward launches spread their weight-gradient flush over 16 replicas of a registered scratch and fold
+    them with a second launch (include/nsim.h: nsim_set_grad_scratch): same gradients as the direct flush, twice in a row
+    (the scratch must come back zeroed), accumulating into a non-zero ``.grad``."""
+    lod_res = list(SMALL_RES_T) if levels == 16 else [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(levels)]
+    p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=2, seed=5, sphere_init=False, grid_bound=0.3,
+                                 noise_scale=1.0)
+    p.grid = p.grid.float()
+    model = model_from_params(p, backend, precision="f32")
+    g = torch.Generator().manual_seed(12)
+    R, S = 9, 700
+    dv = lambda a: a.to(backend).contiguous()
+    rays_o, rays_d = dv(torch.randn(R, 3, generator=g) * 0.1), dv(torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1))
+    ridx, t = dv(torch.randint(0, R, (S,), generator=g).sort().values), dv(torch.rand(S, generator=g) * 0.8)
+    ha = leaf(torch.randn(R, 4, generator=g) * 0.5, backend)
+    ws, wn, wr = dv(torch.randn(S, generator=g)), dv(torch.randn(S, 3, generator=g) * 0.1), dv(torch.randn(S, 3, generator=g))
+    params = (model.sdf_w, model.sdf_b, model.rad_w, model.rad_b)
+
+    def grads(min_wg):
+        monkeypatch.setenv("NSIM_GRAD_REPLICAS_MIN_WG", str(min_wg))
+        for q in params:
+            q.grad = torch.full_like(q, 0.25)                # the fold ADDS into what is there
+        sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                       model.rad_b, ha, None, rays_o, rays_d, t, ridx, True)
+        ((sdf * ws).sum() + (nab * wn).sum() + (rgb * wr).sum()).backward()
+        return [q.grad.detach().cpu().clone() for q in params]
+    direct = grads(10 ** 9)
+    for _ in range(2):
+        rep = grads(1)
+        for a_, b_ in zip(rep, direct):
+            assert rel_l2(a_ - 0.25, b_ - 0.25) < 2e-5
+    scratch = _lib.ensure_grad_scratch(model.device)
+    assert float(scratch.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("which", ["sdf_only", "nablas_only", "no_rgb"])
