@@ -221,6 +221,50 @@ int nsim_lotd_fwd(const float* x, const void* grid_f16, const NsimLotdMeta* meta
 int nsim_lotd_bwd(const float* x, const float* dL_dout, const float* dL_ddydx, const NsimLotdMeta* meta,
                   int64_t S, float* dgrid, void* stream);
 
+/* ------------------------------------------------------- permutohedral-lattice encoding */
+/* nr3d_lib.models.grid_encodings.permuto.PermutoEncoding(in_dim, permuto_auto_compute_cfg{type: multi_res, coarsest_res,
+ * finest_res, n_levels, n_feats, log2_hashmap_size, apply_random_shifts_per_level}) -- call sites
+ * app/models/single/neus.py:64-76 (PermutoNeuSObj), docs/exps/exp_permuto_3d_modulated.py:52-60,
+ * code_multi/configs/exps/fg_neus=permuto/all_occ.240201.yaml:438-446.  The implementation is in the absent nr3d_lib; the
+ * kernels follow the published algorithm (Adams et al. 2010, Rosu & Behnke 2023) as restated in oracle/permuto.py:
+ * level l: cf_i = (x_i + shift[l][i]) * scale[l][i] with scale[l][i] = res_l / sqrt((i+1)(i+2)), elevation, nearest
+ * remainder-0 point, ranks, barycentric weights of the in_dim + 1 simplex vertices, vertex hash
+ * k <- (k + key_i) * 2531011 (uint32) over the first in_dim key coordinates, modulo hashmap_size.
+ * Table: fp16, level l at [l * hashmap_size * 2, (l+1) * hashmap_size * 2), two features per entry. */
+typedef struct NsimPermutoMeta {
+  int32_t in_dim;                      /* 2..8 (3 = positions; 3 + k = positions with a k-dim condition concatenated) */
+  int32_t num_levels;                  /* 1..32 */
+  int32_t n_feats;                     /* must be 2 */
+  uint32_t hashmap_size;               /* entries per level, a power of two */
+  float scale[NSIM_MAX_LEVELS][8];
+  float shift[NSIM_MAX_LEVELS][8];     /* ``apply_random_shifts_per_level`` (zeros when off) */
+} NsimPermutoMeta;
+/* PermutoEncoding.forward / forward_dydx: x [S,in_dim] -> out f32 [S, L*2]; dydx (may be NULL) f32 [S, L*2, in_dim]. */
+int nsim_permuto_fwd(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, int64_t S, float* out, float* dydx,
+                     void* stream);
+/* backward w.r.t. the table: dgrid (f32 [L * hashmap_size * 2], accumulated with atomics) += dL/dout . dout/dgrid.
+ * (dL/dx = sum dL/dout . dydx is a host-side contraction of the forward's dydx.) */
+int nsim_permuto_bwd(const NsimPermutoMeta* meta, const float* x, int64_t S, const float* dL_dout, float* dgrid,
+                     void* stream);
+/* The NeuS field's front end (PermutoNeuSObj; GenerativePermutoConcat with z): positions x [S,3] or rays
+ * (rays_o, rays_d [R,3], t [S], ridx [S]); z [R, in_dim - 3] (may be NULL = zeros; needs ridx) is the per-ray condition
+ * concatenated to the position.  Writes LEVEL-MAJOR planes in the layout of nsim_lotd_gather_lm / nsim_field_fwd, so
+ * that nsim_field_sdf (feat_planes) and nsim_field_fwd / _bwd_sdf (h_planes, J_planes; pass grid_f16 = NULL there: "the
+ * planes are already gathered") run unchanged on a permutohedral model: exactly one of
+ *   feat_planes [NL][S] (f16x2 scaled by 1024 when feat_f32 = 0, f32x2 when 1)      -- no-grad query, or
+ *   h_planes [NL][P][2] + J_planes [NL][P][2][3], P = NSIM_PLANE_PITCH(S)            -- with-grad query
+ * (NL = 16 for <= 16 levels, else 32; levels past num_levels are not written).  n_dev / n_add as nsim_lotd_gather_lm. */
+int nsim_permuto_gather(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                        const float* rays_d, const float* t, const int64_t* ridx, const float* z, int64_t S,
+                        const int64_t* n_dev, int64_t n_add, void* feat_planes, int feat_f32, float* h_planes,
+                        float* J_planes, void* stream);
+/* Backward to the table from the decoders' hand-off planes (nsim_field_bwd_sdf): dgrid[v][f] += w_v dL/dh[f]
+ * + g[f] (dw_v/dx . gn)  -- gn [S,3] (may be NULL, then g_planes may be NULL too) is the total dL/dnablas; the weights
+ * are piecewise linear in x, so this is the whole second-order term. */
+int nsim_permuto_scatter(const NsimPermutoMeta* meta, const float* x, const float* rays_o, const float* rays_d,
+                         const float* t, const int64_t* ridx, const float* z, int64_t S, const float* dh_planes,
+                         const float* g_planes, const float* gn, float* dgrid, void* stream);
+
 /* ------------------------------------------------------- fused NeuS field (LoTD + MLPs, MFMA) */
 /* Network description (host struct).  LoTDNeuSModel = LoTDSDF + RadianceNet
  * (app/models/single/neus.py:24-62; lotd_neus.dtu.230814.yaml:92-139). */

@@ -32,6 +32,11 @@ class Lotd4Meta(C.Structure):
                 ("res_y", C.c_int32 * 16), ("res_z", C.c_int32 * 16)]
 
 
+class PermutoMeta(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("num_levels", C.c_int32), ("n_feats", C.c_int32), ("hashmap_size", C.c_uint32),
+                ("scale", (C.c_float * 8) * NSIM_MAX_LEVELS), ("shift", (C.c_float * 8) * NSIM_MAX_LEVELS)]
+
+
 class DistantMeta(C.Structure):
     _fields_ = [("lotd", Lotd4Meta), ("precision", C.c_int32)]
 
@@ -104,6 +109,10 @@ SIGNATURES = {
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_set_grad_scratch": [_P, _I64],
+    "nsim_permuto_fwd": [C.POINTER(PermutoMeta), _P, _P, _I64, _P, _P],
+    "nsim_permuto_bwd": [C.POINTER(PermutoMeta), _P, _I64, _P, _P],
+    "nsim_permuto_gather": [C.POINTER(PermutoMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I, _P, _P],
+    "nsim_permuto_scatter": [C.POINTER(PermutoMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],

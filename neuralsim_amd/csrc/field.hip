@@ -2373,11 +2373,14 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.h_pl = h_planes; a.J_pl = J_planes;
   a.has_rgb = rgb ? 1 : 0;
   static const bool fused = getenv("NSIM_FWD_FUSED") && atoi(getenv("NSIM_FWD_FUSED")) == 1;
-  if (h_planes && (!fused || n_dev || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
-    deal_levels(meta, a);
-    const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
-    if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+  if (!grid_f16 && !h_planes) return 4;
+  if (h_planes && (!grid_f16 || !fused || n_dev || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
+    if (grid_f16) {      // (NULL: the caller's encoding has filled the planes already -- nsim_permuto_gather)
+      deal_levels(meta, a);
+      const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+      if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+    }
     // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS)
     const size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
     size_t wl = weights_lds_bytes(meta);

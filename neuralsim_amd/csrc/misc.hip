@@ -29,6 +29,11 @@ const char* nsim_strerror(int code) {
     case 20: return "field meta is NULL";
     case 21: return "field kernels take 1..32 LoTD levels (<= 64 input features)";
     case 33: return "pyramids with more than 16 levels exist on the level-major path only: the planes arguments are required";
+    case 40: return "permuto meta is NULL";
+    case 41: return "permuto in_dim must be 2..8 (>= 3 for the field front end)";
+    case 42: return "permuto num_levels must be 1..32";
+    case 43: return "permuto n_feats must be 2";
+    case 44: return "permuto hashmap_size must be a power of two";
     case 34: return "too many streams with a registered gradient scratch (16)";
     case 22: return "sdf_D must be 1 or 2";
     case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";

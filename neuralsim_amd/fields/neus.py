@@ -124,13 +124,11 @@ class _FieldFn(torch.autograd.Function):
         # level-major planes of the gathered features / their x-derivative, saved so the backward never re-gathers
         # (pyramids with more than 16 levels exist on the level-major path only: planes in evaluation as well)
         NLP = model.plane_levels
-        need_pl = need_bwd or NLP > 16
+        need_pl = need_bwd or NLP > 16 or model.planes_always
         PS = _lib.plane_pitch(S)
         h_pl = torch.empty([NLP, PS, 2], dtype=torch.float32, device=dev) if need_pl else None
         J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
-        _lib.call("nsim_field_fwd", model.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
-                  _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), None, 0)
+        model._enc_field_fwd(grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, None, 0)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
@@ -206,9 +204,7 @@ class _FieldFn(torch.autograd.Function):
         d_x = d_o = d_d = None
         if need_dx:
             if gn_total is not None:    # the normals' own dependence on x (mixed second derivatives of the interpolant)
-                _lib.call("nsim_lotd_hess_dx", model.encoding.cfg.meta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
-                          _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(g_pl),
-                          _lib.ptr(gn_total), _lib.ptr(dx))
+                model._enc_hess_dx(grid16, x, rays_o, rays_d, t, ridx, ctx.goff, S, g_pl, gn_total, dx)
             if need_x:
                 d_x = dx.reshape(ctx.x_shape)
             else:
@@ -221,9 +217,7 @@ class _FieldFn(torch.autograd.Function):
                     d_o = d_o[:Rt - M] if d_o is not None else None
                     d_d = d_d[:Rt - M] if d_d is not None else None
         if dgrid is not None:   # (3) scatter to the hash grid
-            _lib.call("nsim_lotd_scatter", model.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ctx.goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
-                      _lib.ptr(gn_total), _lib.ptr(dgrid), 0, 0)
+            model._enc_scatter(x, rays_o, rays_d, t, ridx, ctx.goff, S, dh_pl, g_pl, gn_total, dgrid)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd_sdf", S)
             if dgrid is not None:
@@ -854,6 +848,32 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def forward_inv_s(self) -> torch.Tensor:
         return torch.exp(self._ln_inv_s_eff() * self.ln_inv_s_factor)
 
+    # ------------------------------------------------------------------ encoding hooks
+    # The decoder kernels work on level-major planes of features / d features / d x; what fills the planes and what turns
+    # the hand-off planes back into table gradients is the encoding's business.  LoTD: the fused entry points of field.hip
+    # (gather inside nsim_field_fwd).  fields/permuto_neus.py overrides the four hooks with csrc/permuto.hip.
+    planes_always = False       # True: even an evaluation forward goes through the planes (no fused point-major kernel)
+
+    def _enc_field_fwd(self, grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, n_dev,
+                       n_add):
+        _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
+                  _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))
+
+    def _enc_gather_feat(self, fm, grid16, x, rays_o, rays_d, t, ridx, goff, S, n_dev, n_add, planes):
+        _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
+
+    def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid):
+        _lib.call("nsim_lotd_scatter", self.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
+                  _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
+                  _lib.ptr(gn_total), _lib.ptr(dgrid), 0, 0)
+
+    def _enc_hess_dx(self, grid16, x, rays_o, rays_d, t, ridx, goff, S, g_pl, gn_total, dx):
+        _lib.call("nsim_lotd_hess_dx", self.encoding.cfg.meta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(g_pl),
+                  _lib.ptr(gn_total), _lib.ptr(dx))
+
     # ------------------------------------------------------------------ point queries
     def _sdf_query(self, grid16, wpack, x, rays_o, rays_d, t, ridx, S: int, dev, goff=None, n_dev=None,
                    n_add: int = 0, collect: bool = False, fm=None) -> torch.Tensor:
@@ -868,8 +888,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         if not self._sdf_fused:
             planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,   # f16x2 | f32x2
                                  device=dev)
-            _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
-                      _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
+            self._enc_gather_feat(fm, grid16, x, rays_o, rays_d, t, ridx, goff, S, n_dev, n_add, planes)
         # ``collect``: the decoder launch also folds its SDFs into the occupancy values (update_from_samples_cfg)
         acc = self.accel if collect else None
         _lib.call("nsim_field_sdf", fm, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
@@ -1267,10 +1286,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 spec.update(sdf=torch.empty([Sc], **f32), nablas=torch.empty([Sc, 3], **f32),
                             rgb=torch.empty([Sc, 3], **f32) if with_rgb else None,
                             h_pl=torch.empty([NLP, PSc, 2], **f32), J_pl=torch.empty([NLP, PSc, 2, 3], **f32), PS=PSc)
-                _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), None, _lib.ptr(o_a),
-                          _lib.ptr(d_a), _lib.ptr(t_full), _lib.ptr(ridx_full), None, _lib.ptr(ha_a), Sc,
-                          _lib.ptr(spec["sdf"]), _lib.ptr(spec["nablas"]), _lib.ptr(spec["rgb"]), _lib.ptr(spec["h_pl"]),
-                          _lib.ptr(spec["J_pl"]), _lib.ptr(total_dev), M)
+                self._enc_field_fwd(grid16, wpack, None, o_a, d_a, t_full, ridx_full, None, ha_a, Sc, spec["sdf"],
+                                    spec["nablas"], spec["rgb"], spec["h_pl"], spec["J_pl"], total_dev, M)
             cfg["_spec_launch"], cfg["_tail_points"] = spec_launch, M
             self._with_tail = None
         o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis = self._query_samples(ray_tested, cfg, qp)

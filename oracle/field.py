@@ -144,8 +144,26 @@ def sdf_decoder(h: torch.Tensor, p: FieldParams) -> torch.Tensor:
     return out if p.sdf_scale == 1.0 else out / p.sdf_scale
 
 
+def encode(x: torch.Tensor, p: FieldParams) -> torch.Tensor:
+    """features of the field's encoding: LoTD (oracle/lotd.py) or, for a ``PermutoSpec``, the permutohedral lattice
+    (oracle/permuto.py) on AABB-normalised positions with the optional condition ``p.z`` [S or 1, z_dim] concatenated."""
+    from .permuto import PermutoSpec, permuto_forward
+    if isinstance(p.spec, PermutoSpec):
+        aabb = getattr(p, "aabb", None)
+        u = x
+        if aabb is not None:
+            a = torch.as_tensor(aabb, dtype=x.dtype).reshape(2, 3)
+            u = (x - (a[0] + a[1]) * 0.5) / ((a[1] - a[0]) * 0.5)
+        z = getattr(p, "z", None)
+        if p.spec.in_dim > 3:
+            zz = x.new_zeros([x.shape[0], p.spec.in_dim - 3]) if z is None else z.to(x.dtype).expand(x.shape[0], -1)
+            u = torch.cat([u, zz], dim=-1)
+        return permuto_forward(u, p.grid, p.spec)
+    return lotd_forward(x, p.grid, p.spec)
+
+
 def forward_sdf(x: torch.Tensor, p: FieldParams) -> torch.Tensor:
-    return sdf_decoder(lotd_forward(x, p.grid, p.spec), p)
+    return sdf_decoder(encode(x, p), p)
 
 
 def forward_sdf_nablas(x: torch.Tensor, p: FieldParams, nablas_has_grad: bool = True, x_has_grad: bool = False):

@@ -1,0 +1,260 @@
+"""Permutohedral-lattice encoding: csrc/permuto.hip vs the oracle restatement (oracle/permuto.py)."""
+import pytest
+import torch
+
+from oracle import permuto as operm
+from neuralsim_amd.grid_encodings.permuto import PermutoEncoding
+from util import rel_l2
+
+
+def _pair(in_dim, backend, n_levels=5, log2_T=10, seed=3):
+    cfg = dict(type="multi_res", n_levels=n_levels, n_feats=2, log2_hashmap_size=log2_T, coarsest_res=3.0, finest_res=40.0,
+               apply_random_shifts_per_level=True, seed=seed)
+    enc = PermutoEncoding(in_dim, cfg, bound=0.5, seed=seed + 1).to(backend)
+    kw = {k: v for k, v in cfg.items() if k != "type"}
+    spec = operm.make_permuto_spec(in_dim=in_dim, **kw)
+    assert torch.equal(spec.shifts, enc.cfg.shifts) and spec.n_params == enc.cfg.n_params
+    assert all(abs(a - b) < 1e-9 * (1 + abs(a)) for a, b in zip(spec.res, enc.cfg.res))
+    return enc, spec
+
+
+@pytest.mark.parametrize("in_dim", [2, 3, 4, 7, 8])
+def test_permuto_encoding_matches_oracle(backend, in_dim):
+    """values, d features / d x over every input dimension, and the table gradient"""
+    enc, spec = _pair(in_dim, backend)
+    g = torch.Generator().manual_seed(in_dim)
+    S = 301
+    x = torch.rand(S, in_dim, generator=g) * 2 - 1
+    table = enc.flattened_params.detach().cpu().half().float().requires_grad_(True)      # the stored (fp16) values
+    xo = x.clone().requires_grad_(True)
+    ref = operm.permuto_forward(xo, table, spec)
+    out, dydx = enc.forward_dydx(x.to(backend))
+    assert out.shape == (S, spec.out_features) and dydx.shape == (S, spec.out_features, in_dim)
+    assert (out.cpu() - ref).abs().max() < 2e-5 * (1 + ref.abs().max())
+    # dydx column by column through autograd on the oracle
+    w = torch.randn(S, spec.out_features, generator=g)
+    (gx,) = torch.autograd.grad((ref * w).sum(), xo, retain_graph=True)
+    got = PermutoEncoding.backward_dydx(w.to(backend), dydx).cpu()
+    assert rel_l2(got, gx) < 2e-4
+    (ref * w).sum().backward()
+    (out * w.to(backend)).sum().backward()
+    assert rel_l2(enc.flattened_params.grad.cpu(), table.grad) < 2e-5
+    # plain forward (no dydx) gives the same values
+    assert torch.equal(enc(x.to(backend)), out.detach())
+
+
+def test_permuto_encoding_is_continuous_and_interpolates(backend):
+    """barycentric weights: continuous across simplex faces (no jumps along a line)"""
+    enc, spec = _pair(3, backend, n_levels=3)
+    t = torch.linspace(0, 1, 4001)[:, None]
+    a, b = torch.tensor([[-0.9, 0.3, -0.5]]), torch.tensor([[0.8, -0.7, 0.6]])
+    f = enc((a + (b - a) * t).to(backend)).cpu()
+    step = (f[1:] - f[:-1]).abs().max()
+    assert step < 0.05 * f.abs().max(), float(step)
+
+
+# ------------------------------------------------------------------------------------------------ the NeuS field on it
+from oracle import field as ofield                                   # noqa: E402
+from neuralsim_amd.fields.neus import _FieldFn                        # noqa: E402
+from neuralsim_amd.fields.permuto_neus import PermutoNeuSModel        # noqa: E402
+from util import leaf, oracle_flat_grads                              # noqa: E402
+
+PCFG = dict(type="multi_res", n_levels=6, n_feats=2, log2_hashmap_size=11, coarsest_res=2.0, finest_res=24.0,
+            apply_random_shifts_per_level=True, seed=5)
+
+
+def _field_pair(backend, precision, z_dim=0, sdf_D=1, aabb=None, n_levels=6):
+    cfg = dict(PCFG, n_levels=n_levels)
+    m = PermutoNeuSModel(permuto_auto_compute_cfg=cfg, z_dim=z_dim, sdf_D=sdf_D, precision=precision, param_bound=0.4, seed=9,
+                         aabb=aabb)
+    spec = operm.make_permuto_spec(in_dim=3 + z_dim, **{k: v for k, v in cfg.items() if k != "type"})
+    # an oracle FieldParams with the model's weights (decoder layouts as in util.model_from_params, reversed)
+    p = ofield.make_field_params(lod_res=[2] * n_levels, log2_hashmap_size=4, sdf_D=sdf_D, seed=1, sphere_init=False)
+    p.spec = spec
+    p.grid = m.encoding.flattened_params.detach().clone().half().float()
+    F1 = 2 * n_levels
+    sw, sb = m.sdf_w.detach().clone(), m.sdf_b.detach().clone()
+    dims = [F1] + [64] * sdf_D + [1]
+    p.sdf_w, p.sdf_b, o, ob = [], [], 0, 0
+    for li in range(len(dims) - 1):
+        n = dims[li + 1] * dims[li]
+        p.sdf_w.append(sw[o:o + n].view(dims[li + 1], dims[li]).clone())
+        p.sdf_b.append(sb[ob:ob + dims[li + 1]].clone())
+        o, ob = o + n, ob + dims[li + 1]
+    rw, rb = m.rad_w.detach().clone(), m.rad_b.detach().clone()
+    rd = [26, 64, 64, 3]
+    p.rad_w, p.rad_b, o, ob = [], [], 0, 0
+    for li in range(3):
+        n = rd[li + 1] * rd[li]
+        p.rad_w.append(rw[o:o + n].view(rd[li + 1], rd[li]).clone())
+        p.rad_b.append(rb[ob:ob + rd[li + 1]].clone())
+        o, ob = o + n, ob + rd[li + 1]
+    p.ln_inv_s = m.ln_inv_s.detach().clone()
+    p.aabb = m.accel.aabb.detach().cpu().clone()
+    for t_ in p.tensors():
+        t_.requires_grad_(True)
+    return m.to(backend), p
+
+
+@pytest.mark.parametrize("precision,z_dim,sdf_D,n_levels", [("f32", 0, 1, 6), ("fp16", 0, 1, 6), ("f32", 0, 2, 6), ("f32", 4, 1, 6),
+                                                            ("f32", 0, 1, 18)])
+def test_permuto_neus_field_matches_oracle(backend, precision, z_dim, sdf_D, n_levels):
+    """sdf, normals, colours, the no-grad query and every gradient (second-order path through the normals included) of a
+    NeuS field on the permutohedral encoding; z_dim = 4: GenerativePermutoConcat (per-ray latent concatenated); 18 levels:
+    the 17..32-level decoder kernels on permutohedral planes."""
+    aabb = torch.tensor([[-1.0, -0.8, -1.2], [1.0, 0.8, 1.2]])
+    model, p = _field_pair(backend, precision, z_dim=z_dim, sdf_D=sdf_D, aabb=aabb, n_levels=n_levels)
+    g = torch.Generator().manual_seed(2)
+    R, S = 7, 130
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.7
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    dv = lambda a: a.to(backend).contiguous()
+    if z_dim:
+        z = torch.randn(R, z_dim, generator=g) * 0.3
+        model.set_condition(dv(z))
+        p.z = z[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    ha_d = leaf(h_appear, backend)
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    tol = dict(f32=(3e-5, 3e-4, 3e-5, 3e-4), fp16=(4e-3, 5e-2, 4e-3, 3e-2))[precision]
+    assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < tol[1] * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < tol[2]
+    q = model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu()
+    assert (q - sdf_r.detach()).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < tol[3], (k, e)
+    assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < tol[3]
+
+
+def test_permuto_neus_pretrains_to_a_sphere_and_renders(backend):
+    """``geo_init_method: pretrain`` through the model's own kernels, then a ray_query with the occupancy grid built from
+    the network (the sampling pass, compression and the renderer buffers are the LoTD model's code)."""
+    m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=1,
+                         precision="f32", seed=3,
+                         accel_cfg=dict(resolution=[16, 16, 16], init_cfg=dict(num_steps=1, num_pts=4096),
+                                        update_from_net_cfg=dict(num_steps=1, num_pts=4096), update_from_samples_cfg={}),
+                         ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed",
+                                            query_param=dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4, 8],
+                                                             upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4, 16],
+                                                             upsample_use_estimate_alpha=True,
+                                                             march_cfg=dict(step_size=0.05, max_steps=128)))).to(backend)
+    l0 = m.geometric_init_sphere(0.5, num_iters=1, num_pts=2048)
+    l1 = m.geometric_init_sphere(0.5, num_iters=60, num_pts=2048, lr=5e-3)
+    assert l1 < 0.5 * l0 and l1 < 0.08, (l0, l1)
+    m.accel.init(m.query_sdf, generator=torch.Generator(device=backend).manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    N = 24
+    o = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1) * 2.5
+    d = torch.nn.functional.normalize(-o + torch.randn(N, 3, generator=g) * 0.15, dim=-1)
+    tested = m.ray_test(rays_o=o.to(backend), rays_d=d.to(backend), near=0.0, far=6.0)
+    ret = m.ray_query(ray_tested=tested, config=dict(with_rgb=True, with_normal=True, perturb=False), return_buffer=True)
+    vb = ret["volume_buffer"]
+    assert vb["type"] == "packed" and vb["sdf"].numel() > 0 and torch.isfinite(vb["sdf"]).all()
+    # samples sit around the pre-trained surface
+    assert float(vb["sdf"].abs().median()) < 0.2
+
+
+def test_reference_model_params_block_builds_the_permuto_model(backend):
+    """``import_str(model_class)(**model_params, device=...)`` with the Vehicle block of
+    code_multi/configs/exps/fg_neus=permuto/all_occ.240201.yaml:427-492 (shrunk tables), through the nr3d_lib import path
+    the reference's asset classes use (app/models/single/neus.py:24)."""
+    from nr3d_lib.models.fields.neus import PermutoNeuSModel as ShimModel
+    from nr3d_lib.models.grid_encodings.permuto import PermutoEncoding as ShimEnc
+    assert ShimModel is PermutoNeuSModel and ShimEnc is PermutoEncoding
+    model_params = dict(
+        latents_cfg=dict(z_ins=dict(dim=4, weight_init="zero")),
+        dtype="half",
+        var_ctrl_cfg=dict(ln_inv_s_init=0.3, ln_inv_s_factor=10.0),
+        surface_cfg=dict(bounding_size=1.4,
+                         encoding_cfg=dict(permuto_auto_compute_cfg=dict(type="multi_res", coarsest_res=16.0, finest_res=2000.0,
+                                                                         n_levels=16, n_feats=2, log2_hashmap_size=10,
+                                                                         apply_random_shifts_per_level=True)),
+                         decoder_cfg=dict(type="mlp", D=1, W=64), geo_init_method="pretrain"),
+        radiance_cfg=dict(pos_embed_cfg=dict(type="identity"), use_view_dirs=True, dir_embed_cfg=dict(type="spherical", degree=4),
+                          D=2, W=64, skips=[]),
+        accel_cfg=dict(type="occ_grid", resolution=[8, 8, 8], occ_val_fn_cfg=dict(type="sdf", inv_s=256.0), occ_thre=0.3,
+                       ema_decay=0.95, init_cfg=dict(mode="from_net", num_steps=1, num_pts=512),
+                       update_from_net_cfg=dict(num_steps=1, num_pts=512), update_from_samples_cfg={},
+                       n_steps_between_update=16, n_steps_warmup=256))
+    m = ShimModel(**model_params, device=backend)
+    assert m.z_dim == 4 and m.encoding.cfg.permuto.in_dim == 7 and m.encoding.cfg.num_levels == 16
+    assert m.sdf_D == 1 and m.field_meta.precision == 0 and abs(float(m.accel.aabb[1, 0]) - 0.7) < 1e-6
+    m.set_condition(torch.zeros(1, 4, device=backend))
+    x = (torch.rand(64, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(backend)
+    out = m.forward_sdf_nablas(x)
+    assert out["sdf"].shape == (64,) and out["nablas"].shape == (64, 3) and torch.isfinite(out["nablas"]).all()
+
+
+import ref_glue                                                       # noqa: E402
+
+needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="/root/reference is not present")
+
+
+@needs_reference
+def test_reference_permuto_neus_obj_wrapper_runs_unchanged(backend):
+    """The reference's ``PermutoNeuSObj(AssetMixin, PermutoNeuSModel)`` (app/models/single/neus.py:64-95), loaded from
+    /root/reference, on this package's model: construct from a model_params block, populate, optimizer groups,
+    ``asset_training_initialize`` (= the pre-training loop) and one render through the single-volume renderer."""
+    import importlib
+    from test_reference_models import _Node, _Scene
+    with ref_glue.reference_model_wrapper_modules():
+        single = importlib.import_module("app.models.single")
+        Obj = single.PermutoNeuSObj
+        node = _Node("obj0")
+        scene = _Scene([node])
+        mp = dict(dtype="float", var_ctrl_cfg=dict(ln_inv_s_init=0.3, ln_inv_s_factor=10.0),
+                  surface_cfg=dict(bounding_size=2.0,
+                                   encoding_cfg=dict(permuto_auto_compute_cfg=dict(type="multi_res", coarsest_res=2.0,
+                                                                                   finest_res=24.0, n_levels=6, n_feats=2,
+                                                                                   log2_hashmap_size=11,
+                                                                                   apply_random_shifts_per_level=True)),
+                                   decoder_cfg=dict(type="mlp", D=1, W=64), geo_init_method="pretrain", radius_init=0.5),
+                  radiance_cfg=dict(use_view_dirs=True, dir_embed_cfg=dict(type="spherical", degree=4), D=2, W=64, skips=[]),
+                  accel_cfg=dict(type="occ_grid", resolution=[16, 16, 16], occ_val_fn_cfg=dict(type="sdf", inv_s=256.0),
+                                 occ_thre=0.3, ema_decay=0.95, init_cfg=dict(mode="from_net", num_steps=1, num_pts=4096),
+                                 update_from_net_cfg=dict(num_steps=1, num_pts=4096), update_from_samples_cfg={},
+                                 n_steps_between_update=16, n_steps_warmup=256),
+                  ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed",
+                                     query_param=dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4],
+                                                      upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+                                                      upsample_use_estimate_alpha=True,
+                                                      march_cfg=dict(step_size=0.05, max_steps=128))))
+        model = Obj(**mp, device=backend)
+        assert isinstance(model, PermutoNeuSModel) and model.is_ray_query_supported
+        model.asset_init_config(training_cfg=dict(lr=1e-3, eps=1e-15, betas=(0.9, 0.99), scheduler=dict(type="exponential", num_iters=100,
+                                                                                                       min_factor=0.1, warmup_steps=0)),
+                                initialize_cfg=dict(num_iters=40, lr=5e-3, num_pts=2048))
+        model.asset_populate(scene=scene, obj=node, config=model.populate_cfg, device=backend)
+        model.id = Obj.asset_compute_id(scene=scene, obj=node, class_name="Main")
+        assert model.id == "PermutoNeuSObj#Main#scene0#obj0"
+        node.model = model
+        model.training_setup(model.training_cfg)
+        assert [g["name"] for g in model.optimizer.param_groups][0] == "implicit_surface.encoding"
+        assert model.optimizer.param_groups[0]["params"][0] is model.encoding.flattened_params
+        assert model.asset_training_initialize(scene, node, model.initialize_cfg) is True and bool(model.is_pretrained)
+        from neuralsim_amd.graphics.cameras import look_at_cameras, pinhole_selected_rays
+        from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
+        intr, c2w, WH = look_at_cameras(V=3, seed=2, device=backend)
+        g = torch.Generator().manual_seed(0)
+        xy, fidx = torch.rand(32, 2, generator=g).to(backend), torch.randint(0, 3, (32,), generator=g).to(backend)
+        rays_o, rays_d = pinhole_selected_rays(xy, fidx, intr, c2w, WH)
+        renderer = SingleVolumeRenderer(dict(with_rgb=True, with_normal=True, near=0.01, perturb=True)).train()
+        ret = renderer.render(model, rays=[rays_o, rays_d], rays_h_appear=torch.zeros(32, 4, device=backend), return_buffer=True)
+        rgb = ret["rendered"]["rgb_volume"]
+        assert rgb.shape == (32, 3) and torch.isfinite(rgb).all()
+        rgb.sum().backward()
+        assert model.encoding.flattened_params.grad is not None and float(model.encoding.flattened_params.grad.abs().sum()) > 0

@@ -18,7 +18,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="street", choices=("street", "object"))
+    ap.add_argument("--shape", default="street", choices=("street", "object", "permuto"))
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--per-ray", type=int, default=85)
     ap.add_argument("--iters", type=int, default=6)
@@ -34,6 +34,12 @@ def main():
         res = cuboid_ngp_res((aabb[1] - aabb[0]).tolist(), 16, 2048, 19)
         m = LoTDNeuSModel(lod_res=res, log2_hashmap_size=20, sdf_D=1, precision=args.precision, sdf_scale=STREET_SDF_SCALE,
                           aabb=aabb, seed=1).to(dev)
+    elif args.shape == "permuto":      # PermutoNeuSObj at the LoTD object model's table size: 16 levels x 2^19 entries, 2x64 decoder
+        from neuralsim_amd.fields.permuto_neus import PermutoNeuSModel
+        aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+        m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(type="multi_res", n_levels=16, n_feats=2, log2_hashmap_size=19,
+                                                           coarsest_res=16.0, finest_res=2000.0), sdf_D=2,
+                             precision=args.precision, seed=1).to(dev)
     else:
         aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
         m = LoTDNeuSModel(sdf_D=2, precision=args.precision, seed=1).to(dev)
@@ -65,7 +71,7 @@ def main():
         step()
     summ = _lib.TIMER.summary()
     _lib.TIMER = None
-    out = dict(shape=args.shape, levels=len(m.encoding.cfg.lod_res), points=S, precision=args.precision,
+    out = dict(shape=args.shape, levels=m.encoding.cfg.num_levels, points=S, precision=args.precision,
                avg_ms={k: round(v["avg_ms"], 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])},
                ns_per_point={k: round(v["avg_ms"] * 1e6 / S, 4) for k, v in summ.items() if v["avg_ms"] > 0.01})
     print(json.dumps(out))
