@@ -56,17 +56,25 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
 
 
 def build_trainer(device, rank, world, seed=42, distant=False, sky=False, sdf_D=2, precision="fp16", rays_per_gpu=None,
-                  fused_step=None):
+                  fused_step=None, encoding="lotd"):
     """BASELINE configs[1] on one rank.  ``precision``: "fp16" (product default = the reference's ``dtype: half``) or
     "f32" (exact-f32 MFMA validation mode of the same kernels, used by the full-size parity tests)."""
     from neuralsim_amd.fields.neus import LoTDNeuSModel
     from neuralsim_amd.graphics.cameras import look_at_cameras
     from neuralsim_amd.trainer import RenderTrainer
     from neuralsim_amd import distributed as ndist
-    model = LoTDNeuSModel(sdf_D=sdf_D, precision=precision, ln_inv_s_init=0.5, seed=seed).to(device)
-    # DTU-scan-like pixel coverage: a sphere of radius 0.75 covers ~40 % of the 800x800 views of the camera rig
-    # (radius_init 0.5 of the reference config would cover 16 %); see DESIGN.md sec. 7
-    model.geometric_init_sphere(SPHERE_RADIUS)
+    if encoding == "permuto":       # PermutoNeuSObj at the same table size (16 levels x 2^19 entries x 2 features; row f4)
+        from neuralsim_amd.fields.permuto_neus import PermutoNeuSModel
+        model = PermutoNeuSModel(permuto_auto_compute_cfg=dict(type="multi_res", n_levels=16, n_feats=2, log2_hashmap_size=19,
+                                                               coarsest_res=16.0, finest_res=2000.0),
+                                 sdf_D=sdf_D, precision=precision, ln_inv_s_init=0.5, seed=seed).to(device)
+        model.geometric_init_sphere(SPHERE_RADIUS, num_iters=300, num_pts=2 ** 15, lr=2e-3)      # geo_init_method: pretrain
+        model.encoding.flattened_params.grad = model.sdf_w.grad = model.sdf_b.grad = None
+    else:
+        model = LoTDNeuSModel(sdf_D=sdf_D, precision=precision, ln_inv_s_init=0.5, seed=seed).to(device)
+        # DTU-scan-like pixel coverage: a sphere of radius 0.75 covers ~40 % of the 800x800 views of the camera rig
+        # (radius_init 0.5 of the reference config would cover 16 %); see DESIGN.md sec. 7
+        model.geometric_init_sphere(SPHERE_RADIUS)
     model.accel.init(model.query_sdf, generator=torch.Generator(device=device).manual_seed(seed))
     ndist.broadcast_module(model)
     intr, c2w, WH = look_at_cameras(V=100, seed=seed, device=device)
@@ -318,6 +326,13 @@ def main():
             trd = build_trainer(dev, rank, world, distant=True, sdf_D=args.sdf_depth, rays_per_gpu=args.rays_per_gpu)
             var["distant_ms"], _ = time_steps(trd, 16, 8, 257)
             del trd
+            torch.cuda.empty_cache()
+            # the same workload on the permutohedral-lattice encoding (PermutoNeuSObj, app/models/single/neus.py:64-95;
+            # SURVEY row f4): pre-trained to the sphere, stepped through the renderer + autograd path
+            trp = build_trainer(dev, rank, world, sdf_D=args.sdf_depth, rays_per_gpu=args.rays_per_gpu, encoding="permuto")
+            var["permuto_ms"], _ = time_steps(trp, 16, 8, 257)
+            var["permuto_samples_per_hit_ray"] = round(trp.stats["S_f"] / max(1, trp.stats["R_hit"]), 1)
+            del trp
             torch.cuda.empty_cache()
             # the other BASELINE configurations at their per-GPU shapes (configs[3] / [2] / [4]: 16384 rays), a few steps
             # each; their oracle parity is tests/test_fullsize_configs.py

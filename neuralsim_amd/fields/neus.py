@@ -577,6 +577,47 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             self.to(device)
         return self
 
+    def pretrain_sdf_fn(self, target_fn, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14, seed: int = 0,
+                        logger=None) -> float:
+        """The reference's SDF pre-training as an optimisation (``nr3d_lib.models.fields.sdf.pretrain_sdf_*``, called with
+        ``initialize_cfg{num_iters, lr, ...}`` by app/models/single/neus.py:198-236): fit the SDF to ``target_fn(x)``
+        (x [N,3] object coordinates on the model's device -> [N]) at uniformly drawn points of the box with Adam over the
+        encoding and the SDF decoder, through the model's own forward / backward kernels.  Returns the last L1 loss."""
+        dev = self.encoding.flattened_params.device
+        params = [self.encoding.flattened_params, self.sdf_w, self.sdf_b]
+        opt = torch.optim.Adam(params, lr=lr)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        lo, hi = self.accel.aabb[0].to(dev), self.accel.aabb[1].to(dev)
+        loss = torch.zeros([])
+        with torch.enable_grad():
+            for it in range(int(num_iters)):
+                x = lo + (hi - lo) * torch.rand([num_pts, 3], device=dev, generator=g)
+                with torch.no_grad():
+                    target = target_fn(x).to(dev).float()
+                sdf = self.forward_sdf_nablas(x, nablas_has_grad=False)["sdf"]
+                loss = (sdf - target).abs().mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                self._wpack_versions = None
+                if logger is not None and it % 100 == 0:
+                    logger.info(f"pretrain_sdf: it {it} loss {float(loss.detach()):.5f}")
+        for q in params:
+            q.grad = None
+        self.is_pretrained.fill_(True)
+        return float(loss.detach())
+
+    def pretrain_sdf_sphere(self, radius: float = 0.5, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14,
+                            seed: int = 0, logger=None) -> float:
+        """``pretrain_sdf_sphere``: target |u| - radius, u = the AABB-normalised position (r - |u| for ``inside_out``)."""
+        lo, hi = self.accel.aabb[0], self.accel.aabb[1]
+        sign = -1.0 if self.inside_out else 1.0
+
+        def target(x):
+            u = (x - (lo.to(x.device) + hi.to(x.device)) * 0.5) / ((hi.to(x.device) - lo.to(x.device)) * 0.5)
+            return sign * (u.norm(dim=-1) - radius)
+        return self.pretrain_sdf_fn(target, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed, logger=logger)
+
     @torch.no_grad()
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
         """``asset_training_initialize`` -> ``training_initialize`` (app/models/single/neus.py:61-64, :198-236): the
@@ -592,7 +633,13 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             ext = (self.accel.aabb[1] - self.accel.aabb[0]).cpu()
             # radius_init is in object units; the sphere is written in the [-1, 1] coordinates of the shortest axis
             r = float(post.get("radius_init", 0.5)) / (float(ext.min()) / 2.0)
-            self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
+            cfg_i = dict(config or {})
+            if cfg_i.get("geo_init_impl", os.environ.get("NSIM_GEO_INIT", "write")) == "pretrain":
+                # the reference's own procedure: ``initialize_cfg{num_iters, lr}`` optimisation steps on the zeroed table
+                self.pretrain_sdf_sphere(min(r, 0.95), num_iters=int(cfg_i.get("num_iters", 500)), lr=float(cfg_i.get("lr", 2e-3)),
+                                         num_pts=int(cfg_i.get("num_pts", 2 ** 14)), logger=logger)
+            else:       # default: the deterministic write (exact sphere, no iterations)
+                self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
             self.is_pretrained.fill_(True)
             updated = True
         if self.accel is not None:

@@ -171,26 +171,9 @@ class PermutoNeuSModel(LoTDNeuSModel):
     # ---------------------------------------------------------------- geometric initialisation = pre-training
     def geometric_init_sphere(self, radius: float = 0.5, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14,
                               seed: int = 0, **_):
-        """``geo_init_method: pretrain`` (all_occ.240201.yaml:451): fit the SDF to |x| - radius at random points of the
-        box with Adam, through the model's own forward / backward kernels (there is no dense level to write a sphere into)."""
-        dev = self.encoding.flattened_params.device
-        params = [self.encoding.flattened_params, self.sdf_w, self.sdf_b]
-        opt = torch.optim.Adam(params, lr=lr)
-        g = torch.Generator(device=dev).manual_seed(seed)
-        lo, hi = self.accel.aabb[0].to(dev), self.accel.aabb[1].to(dev)
-        sign = -1.0 if self.inside_out else 1.0
-        for _ in range(int(num_iters)):
-            x = lo + (hi - lo) * torch.rand([num_pts, 3], device=dev, generator=g)
-            u = (x - (lo + hi) * 0.5) / ((hi - lo) * 0.5)
-            target = sign * (u.norm(dim=-1) - radius)
-            sdf = self.forward_sdf_nablas(x, nablas_has_grad=False)["sdf"]
-            loss = (sdf - target).abs().mean()
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
-            self._wpack_versions = None
-        self.is_pretrained.fill_(True)
-        return float(loss.detach())
+        """``geo_init_method: pretrain`` (all_occ.240201.yaml:451): there is no dense level to write a sphere into -- the
+        SDF is fitted to |u| - radius by ``LoTDNeuSModel.pretrain_sdf_sphere`` (Adam through the model's own kernels)."""
+        return self.pretrain_sdf_sphere(radius, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed)
 
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
         """``asset_training_initialize`` -> ``training_initialize`` (app/models/single/neus.py:92-95): the pre-training

@@ -4,10 +4,22 @@
 withmask_withlidar_joint.240219.yaml:232-241).
 
 The reference fits the SDF network to the target shape with ``num_iters`` optimisation steps; the implementation lives
-in the absent nr3d_lib.  Here the target is written deterministically into the finest dense level of the table
-(``LoTDNeuSModel.geometric_init_fn``): same starting geometry, no optimisation loop (lr / num_iters / num_points /
-w_eikonal are accepted and ignored)."""
+in the absent nr3d_lib.  By default the target is written deterministically into the finest dense level of the table
+(``LoTDNeuSModel.geometric_init_fn``): same starting geometry, no optimisation loop.  ``geo_init_impl: pretrain`` in the
+``initialize_cfg`` block (or NSIM_GEO_INIT=pretrain) runs the reference's procedure instead: ``num_iters`` Adam steps of
+``lr`` on ``num_points`` random points per step through the model's own kernels (``LoTDNeuSModel.pretrain_sdf_fn``)."""
+import os
+
 import torch
+
+
+def _init(implicit_surface, fn, cfg, logger):
+    if cfg.get("geo_init_impl", os.environ.get("NSIM_GEO_INIT", "write")) == "pretrain":
+        implicit_surface.pretrain_sdf_fn(lambda x: fn(x.detach().cpu()), num_iters=int(cfg.get("num_iters", 500)),
+                                         lr=float(cfg.get("lr", 2e-3)), num_pts=int(cfg.get("num_points", cfg.get("num_pts", 2 ** 14))),
+                                         logger=logger)
+    else:
+        implicit_surface.geometric_init_fn(fn)
 
 _DIM = dict(x=0, y=1, z=2)
 
@@ -28,7 +40,7 @@ def pretrain_sdf_road_surface(implicit_surface, tracks_in_obj: torch.Tensor, flo
             floor = tr[k, d] - float(floor_up_sign) * float(ego_height)
             out[lo:lo + 65536] = float(floor_up_sign) * (xc[:, d] - floor)
         return out
-    implicit_surface.geometric_init_fn(fn)
+    _init(implicit_surface, fn, unused, logger)
 
 
 def pretrain_sdf_capsule(implicit_surface, tracks_in_obj: torch.Tensor, surface_distance: float = 0.2, logger=None,
@@ -43,4 +55,4 @@ def pretrain_sdf_capsule(implicit_surface, tracks_in_obj: torch.Tensor, surface_
         for lo in range(0, x.shape[0], 65536):
             out[lo:lo + 65536] = float(surface_distance) - torch.cdist(x[lo:lo + 65536], tr).min(dim=1).values
         return out
-    implicit_surface.geometric_init_fn(fn)
+    _init(implicit_surface, fn, unused, logger)

@@ -258,3 +258,29 @@ def test_reference_permuto_neus_obj_wrapper_runs_unchanged(backend):
         assert rgb.shape == (32, 3) and torch.isfinite(rgb).all()
         rgb.sum().backward()
         assert model.encoding.flattened_params.grad is not None and float(model.encoding.flattened_params.grad.abs().sum()) > 0
+
+
+def test_training_steps_on_the_permuto_model(backend):
+    """the whole training step (ray generation .. Adam, occupancy refresh) with a PermutoNeuSModel in place of the LoTD
+    model: pre-trained sphere, overfit one batch, the loss goes down and the fp16 shadow follows the master table"""
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+              upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
+    m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
+                         precision="fp16", ln_inv_s_init=0.3, seed=4,
+                         accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
+                                        update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
+                         ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(backend)
+    m.geometric_init_sphere(0.5, num_iters=60, num_pts=2048, lr=5e-3)
+    m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, target_sphere_radius=0.5)
+    assert not tr._fused_ok()                       # the fused launch chain is the LoTD model's; this goes through autograd
+    xy, fidx, gt = tr.sample_batch()
+    tr.sample_batch = lambda: (xy, fidx, gt)
+    before = m.encoding.flattened_params.detach().clone()
+    losses = [float(tr.train_step(it)) for it in range(6)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
+    assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())

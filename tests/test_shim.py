@@ -84,3 +84,21 @@ def test_masked_reductions_broadcast_a_per_ray_mask():
     assert torch.allclose(reduce(x, mask=mk, reduction="sum"), (x * mk).sum())
     with pytest.raises(ValueError):
         reduce(x, reduction="median")
+
+
+def test_lotd_model_can_run_the_reference_pretraining_procedure(backend):
+    """``initialize_cfg{num_iters, lr}`` honoured as an optimisation (``geo_init_impl: pretrain`` / NSIM_GEO_INIT=pretrain)
+    instead of the default deterministic write of the sphere: zero-out, Adam steps through the
+    model's own kernels, then the occupancy grid from the network."""
+    import torch
+    from neuralsim_amd.fields.neus import LoTDNeuSModel
+    m = LoTDNeuSModel(lod_res=[4, 6, 8, 12, 16, 24], log2_hashmap_size=10, sdf_D=1, precision="f32", seed=2,
+                      accel_cfg=dict(resolution=(8, 8, 8), init_cfg=dict(num_steps=1, num_pts=1024),
+                                     update_from_net_cfg=dict(num_steps=1, num_pts=1024), update_from_samples_cfg={})).to(backend)
+    assert not bool(m.is_pretrained)
+    assert m.training_initialize(dict(geo_init_impl="pretrain", num_iters=80, lr=1e-2, num_pts=2048)) is True
+    assert bool(m.is_pretrained) and m.training_initialize(dict(geo_init_impl="pretrain", num_iters=80)) is False
+    x = (torch.rand(512, 3, generator=torch.Generator().manual_seed(0)) * 1.6 - 0.8).to(backend)
+    err = (m.query_sdf(x).cpu() - (x.cpu().norm(dim=-1) - 0.5)).abs().mean()
+    assert float(err) < 0.08, float(err)
+    assert 0.0 < m.accel.frac_occupied() < 1.0
