@@ -273,7 +273,7 @@ typedef struct NsimFieldMeta {
                           * levels: level-major planes of 32 levels, the planes arguments are then mandatory */
   int32_t sdf_D;         /* hidden layers of the SDF decoder: 1 or 2 (width 64, softplus beta) */
   int32_t precision;     /* 0: fp16 MFMA (v_mfma_f32_32x32x16_f16), 1: exact f32 MFMA (32x32x2 f32) */
-  float softplus_beta;   /* 100 */
+  float softplus_beta;   /* 100; a negative value selects relu (decoder_cfg.activation: relu) */
 } NsimFieldMeta;
 
 /* size in bytes of the packed-fragment weight buffer for a given meta */

@@ -196,7 +196,10 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
 // and pass against 12 MFMAs per 32 points).
 #define NSIM_LOG2E 1.4426950408889634f
 #define NSIM_LN2 0.6931471805599453f
+// beta < 0 selects relu (``decoder_cfg.activation: relu``, no_fg_occ.221218.yaml:354-357): a = max(z, 0), sigma = [a > 0]; the
+// curvature terms of the backward, written as beta s (1 - s), vanish by themselves for s in {0, 1}.  (wave-uniform branch)
 __device__ __forceinline__ float softplus_exact(float z, float beta, float inv_beta) {
+  if (beta < 0.f) return fmaxf(z, 0.f);
   const float t = nsim_exp2(-fabsf(z) * (beta * NSIM_LOG2E));
   return fmaxf(z, 0.f) + nsim_log2(1.0f + t) * (inv_beta * NSIM_LN2);
 }
@@ -212,7 +215,10 @@ __device__ __forceinline__ float sig_from_softplus(float a, float beta) { return
 #else
 __device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) { return softplus_exact(z, beta, inv_beta); }
 // sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)   (abs. error <= 6e-8)
-__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E)); }
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) {
+  if (beta < 0.f) return a > 0.f ? 1.0f : 0.f;
+  return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E));
+}
 #endif
 
 __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {

@@ -51,6 +51,8 @@ static int permuto_meta_check(const NsimPermutoMeta* m) {
   return 0;
 }
 
+__device__ __forceinline__ double diff_of(double e, int rem0) { return e - (double)rem0; }
+
 // The enclosing simplex of one point on one level.
 template <int D>
 struct Simplex {
@@ -64,23 +66,27 @@ struct Simplex {
 template <int D, int NS, bool WD>
 __device__ __forceinline__ void permuto_simplex(const float (&x)[D], const float* scale, const float* shift, Simplex<D>& sp,
                                                 float (&dB)[D + 1][NS]) {
-  float cf[D], E[D + 1];
+  // The elevation runs in f64 (full-rate VALU on CDNA): with the per-level random shifts (up to 10) the finest levels work
+  // at |E| ~ 3e4, where an f32 ulp is 2e-3 lattice units -- in f32 the weights carry ~1e-3 of rounding noise, the SDF along
+  // a ray becomes a (slightly) noisy function, and the up-sampler (inv_s up to 1024) amplifies that into different sample
+  // sets for any two implementations that do not round identically (measured at the BASELINE size: 56 of 2038 rays).
+  double cf[D], E[D + 1];
 #pragma unroll
-  for (int i = 0; i < D; ++i) cf[i] = (x[i] + shift[i]) * scale[i];
-  float sm = 0.f;
+  for (int i = 0; i < D; ++i) cf[i] = ((double)x[i] + (double)shift[i]) * (double)scale[i];
+  double sm = 0.0;
 #pragma unroll
   for (int i = D; i >= 1; --i) {
-    E[i] = sm - (float)i * cf[i - 1];
+    E[i] = sm - (double)i * cf[i - 1];
     sm = sm + cf[i - 1];
   }
   E[0] = sm;
   int ssum = 0;
-  float diff[D + 1];
+  double diff[D + 1];
 #pragma unroll
   for (int i = 0; i <= D; ++i) {
-    const float v = E[i] * (1.0f / (float)(D + 1));
-    const float up = ceilf(v) * (float)(D + 1), down = floorf(v) * (float)(D + 1);
-    const float r = (up - E[i] < E[i] - down) ? up : down;
+    const double v = E[i] * (1.0 / (double)(D + 1));
+    const double up = ceil(v) * (double)(D + 1), down = floor(v) * (double)(D + 1);
+    const double r = (up - E[i] < E[i] - down) ? up : down;
     sp.rem0[i] = (int)r;
     diff[i] = E[i] - r;
     sp.rank[i] = 0;
@@ -127,7 +133,7 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[D], const float
   }
 #pragma unroll
   for (int i = 0; i <= D; ++i) {
-    const float delta = (E[i] - (float)sp.rem0[i]) * (1.0f / (float)(D + 1));
+    const float delta = (float)(diff_of(E[i], sp.rem0[i]) * (1.0 / (double)(D + 1)));
     const int kp = D - sp.rank[i], km = D + 1 - sp.rank[i];
 #pragma unroll
     for (int k = 0; k < D + 2; ++k) {      // (select form: no dynamically indexed registers)

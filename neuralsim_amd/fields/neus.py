@@ -545,7 +545,10 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         fm.lotd = self.encoding.cfg.meta
         fm.sdf_D = sdf_D
         fm.precision = {"fp16": 0, "f32": 1}[precision]
-        fm.softplus_beta = float(softplus_beta)
+        # ``decoder_cfg.activation``: softplus(beta) (the single-object / street configs) or relu (the Vehicle decoder of
+        # no_fg_occ.221218.yaml:354-357) -- a non-positive beta selects relu in the kernels
+        fm.softplus_beta = float(softplus_beta) if float(softplus_beta) > 0 else -1.0
+        self.sdf_activation = "softplus" if float(softplus_beta) > 0 else "relu"
         self.field_meta = fm
         self._wpack = None
         self._sdf_fused = os.environ.get("NSIM_SDF_FUSED", "0") == "1" and self.plane_levels == 16

@@ -142,9 +142,12 @@ def neus_native_kwargs(params: dict, aabb=None) -> Tuple[Dict, Dict]:
     enc = dict(sc.get("encoding_cfg") or {})
     dec = dict(sc.get("decoder_cfg") or {})
     _check_decoder("surface_cfg.decoder_cfg", dec, {1, 2})
-    act = dict(dec.get("activation") or dict(type="softplus", beta=100.0))
-    if act.get("type", "softplus") != "softplus":
-        _unsupported("decoder_cfg.activation.type", act.get("type"), "softplus(beta) is what the kernels evaluate")
+    act = dec.get("activation") or dict(type="softplus", beta=100.0)
+    act = dict(type=act) if isinstance(act, str) else dict(act)            # ``activation: relu`` (no_fg_occ.221218.yaml:357)
+    if act.get("type", "softplus") == "relu":
+        act = dict(type="relu", beta=-1.0)
+    elif act.get("type", "softplus") != "softplus":
+        _unsupported("decoder_cfg.activation.type", act.get("type"), "softplus(beta) and relu are what the kernels evaluate")
     if int(sc.get("n_extra_feat_from_output", 0)) != 0:
         _unsupported("surface_cfg.n_extra_feat_from_output", sc["n_extra_feat_from_output"],
                      "the radiance net reads position / normal / view direction / appearance only")

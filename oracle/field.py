@@ -138,8 +138,10 @@ def make_field_params(lod_res=None, n_feats=2, log2_hashmap_size=19, sdf_D=2, W=
 def sdf_decoder(h: torch.Tensor, p: FieldParams) -> torch.Tensor:
     a = h
     n = len(p.sdf_w)
+    relu = getattr(p, "sdf_activation", "softplus") == "relu"       # ``decoder_cfg.activation: relu`` (no_fg_occ.221218.yaml:357)
     for li in range(n - 1):
-        a = F.softplus(F.linear(a, p.sdf_w[li], p.sdf_b[li]), beta=SOFTPLUS_BETA, threshold=20.0)
+        z = F.linear(a, p.sdf_w[li], p.sdf_b[li])
+        a = F.relu(z) if relu else F.softplus(z, beta=SOFTPLUS_BETA, threshold=20.0)
     out = F.linear(a, p.sdf_w[-1], p.sdf_b[-1]).squeeze(-1)
     return out if p.sdf_scale == 1.0 else out / p.sdf_scale
 

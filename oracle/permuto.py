@@ -77,13 +77,17 @@ def init_params_uniform(spec: PermutoSpec, bound: float = 1e-4, seed: int = 42) 
 
 
 def elevate(xs: torch.Tensor) -> torch.Tensor:
-    """xs [S,d] (already shifted and scaled: cf_i) -> elevated [S,d+1]:  E_0 = sum_j cf_j,  E_i = sum_{j>i} cf_j - i cf_i."""
+    """xs [S,d] (already shifted and scaled: cf_i) -> elevated [S,d+1]:  E_0 = sum_j cf_j,  E_i = sum_{j>i} cf_j - i cf_i.
+    Called with f64 inputs (``permuto_forward``), as the kernel computes it: the finest levels work at |E| ~ 3e4 with the
+    random shifts, where an f32 ulp is 2e-3 lattice units -- in f32 the weights would carry ~1e-3 of rounding noise and two
+    implementations would only agree if they rounded identically.  The running sum starts from the last coordinate."""
     S, d = xs.shape
-    tail = torch.flip(torch.cumsum(torch.flip(xs, [1]), dim=1), [1])          # tail[:, i] = sum_{j >= i} xs[:, j]  (0-based)
-    cols = [tail[:, 0]]
-    for i in range(1, d + 1):
-        after = tail[:, i] if i < d else torch.zeros_like(tail[:, 0])           # sum over 1-based j > i
-        cols.append(after - i * xs[:, i - 1])
+    cols = [None] * (d + 1)
+    sm = torch.zeros_like(xs[:, 0])
+    for i in range(d, 0, -1):
+        cols[i] = sm - float(i) * xs[:, i - 1]
+        sm = sm + xs[:, i - 1]
+    cols[0] = sm
     return torch.stack(cols, dim=1)
 
 
@@ -140,10 +144,11 @@ def permuto_forward(x: torch.Tensor, params: torch.Tensor, spec: PermutoSpec) ->
     p32 = params if params.dtype in (torch.float32, torch.float64) else params.float()
     outs = []
     for l in range(spec.num_levels):
-        xs = (x + spec.shifts[l].to(x.dtype)) * spec.scale_factors(l).to(x.dtype)
+        # lattice arithmetic in f64 (as the kernel: see ``elevate``), weights back in the working precision
+        xs = (x.double() + spec.shifts[l].double()) * spec.scale_factors(l).double()
         elev = elevate(xs)
         rem0, rank = simplex(elev)
-        bary = barycentric(elev, rem0, rank)
+        bary = barycentric(elev, rem0, rank).to(x.dtype)
         table = p32[l * T * F:(l + 1) * T * F].view(T, F)
         feat = x.new_zeros([x.shape[0], F])
         for r in range(d + 1):

@@ -469,3 +469,44 @@ def test_split_precision_sdf_query(backend, levels, sdf_D):
     scale = 1.0 + float(ref.abs().max())
     assert err["f32"] < 2e-6 * scale and err["split"] < 4e-6 * scale, err
     assert err["fp16"] > 20 * err["split"], err
+
+
+@pytest.mark.parametrize("precision,sdf_D", [("f32", 2), ("fp16", 2), ("f32", 1)])
+def test_field_with_relu_sdf_decoder(backend, precision, sdf_D):
+    """``decoder_cfg.activation: relu`` (the Vehicle decoder of no_fg_occ.221218.yaml:354-357): values, normals, colours,
+    the no-grad query and all gradients -- the curvature terms of the normals' double backward vanish for relu."""
+    p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=8, noise_scale=1.0)
+    p.sdf_activation = "relu"
+    for t in p.tensors():
+        t.requires_grad_(True)
+    model = model_from_params(p, backend, precision=precision)
+    assert model.sdf_activation == "relu" and model.field_meta.softplus_beta < 0
+    g = torch.Generator().manual_seed(6)
+    R, S = 7, 150
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.8
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    ha_d = leaf(h_appear, backend)
+    dv = lambda a: a.to(backend).contiguous()
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    tol = dict(f32=(2e-5, 2e-4, 2e-5, 3e-4), fp16=(4e-3, 5e-2, 4e-3, 3e-2))[precision]
+    assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < tol[1] * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < tol[2]
+    q = model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu()
+    assert (q - sdf_r.detach()).abs().max() < tol[0] * (1 + sdf_r.abs().max())
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        assert e < tol[3], (k, e)

@@ -66,23 +66,37 @@ def _report(name, rec):
 _RIGS = {}
 
 
-def _rig(precision):
-    """bench.build_trainer (BASELINE configs[1]) + the oracle carrying the same weights and occupancy grid."""
-    if precision in _RIGS:
-        return _RIGS[precision]
+def _rig(precision, encoding="lotd"):
+    """bench.build_trainer (BASELINE configs[1]) + the oracle carrying the same weights and occupancy grid.
+    ``encoding="permuto"``: the same rig with the permutohedral-lattice model (bench ``variants.permuto_ms``; row f4)."""
+    key = (precision, encoding)
+    if key in _RIGS:
+        return _RIGS[key]
     import bench
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    tr = bench.build_trainer(dev, 0, 1, precision=precision)
+    tr = bench.build_trainer(dev, 0, 1, precision=precision, encoding=encoding)
     m = tr.model
     cfg = m.encoding.cfg
+    if encoding == "permuto":
+        from oracle import permuto as operm
+        pc = cfg.permuto
+        assert tr.num_rays == 8192 and pc.num_levels == 16 and pc.hashmap_size == 2 ** 19 and m.sdf_D == 2
+        p = ofield.params_from_flat([2] * 16, 4, torch.zeros(16 * 16), m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s, sdf_D=2,
+                                    ln_inv_s_factor=m.ln_inv_s_factor)
+        p.spec = operm.PermutoSpec(3, list(pc.res), 2, pc.hashmap_size, pc.shifts.clone())
+        p.grid = m.encoding.flattened_params.detach().cpu().half().float().requires_grad_(True)      # the stored (fp16) values
+        p.aabb = m.accel.aabb.detach().cpu().clone()
+        occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
+        _RIGS[key] = (tr, p, occ, dev)
+        return _RIGS[key]
     assert tr.num_rays == 8192 and cfg.n_params == 12196216 and list(cfg.lod_res)[-1] == 2048 and m.sdf_D == 2
     p = ofield.params_from_flat(cfg.lod_res, 19, m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b,
                                 m.ln_inv_s, sdf_D=2, ln_inv_s_factor=m.ln_inv_s_factor)
     occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
-    _RIGS[precision] = (tr, p, occ, dev)
-    return _RIGS[precision]
+    _RIGS[key] = (tr, p, occ, dev)
+    return _RIGS[key]
 
 
 def _fresh(p):
@@ -124,14 +138,32 @@ def _oracle_query(p, occ, tr, o, d, ha, jit, jit_c, compressed, **kw):
                          jitter_c=jit_c, depth_use_normalized_vw=False, compress=compressed, compress_thre=1e-4, **kw)
 
 
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_permuto_model_matches_oracle_at_baseline_size(precision):
+    """The same comparison for the permutohedral-lattice model (PermutoNeuSObj, 16 levels x 2^19 entries, pre-trained to
+    the sphere): ray_test + ray_query + autograd against the oracle's restatement of the lattice (oracle/permuto.py)."""
+    _api_path_body(precision, True, "permuto")
+
+
 @pytest.mark.parametrize("compressed", [True, False])
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
 def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
-    tr, p, occ, dev = _rig(precision)
+    _api_path_body(precision, compressed, "lotd")
+
+
+def _api_path_body(precision, compressed, encoding):
+    tr, p, occ, dev = _rig(precision, encoding)
     m = tr.model
     m._march_stat = None             # exact buffer sizes for the sampling pass (no speculative capacity)
     tol = TOL[precision]
     N = N_API
+    # The pre-trained permutohedral field is ROUGH at the scale of its finest levels (300 Adam steps move all 16 levels of a
+    # hashed lattice alike: |d sdf / d x| reaches ~20 over distances of 5e-4), so the up-sampler's sensitivity (a fine sample
+    # moves by up to ~1e-3 for 1e-6 of SDF difference, TOL above) turns into SDF differences of ~1e-2 at the moved samples and
+    # a few keep / drop flips: the end-to-end leg is held to loose bounds there and the kernel parity is what the
+    # fixed-sample-set leg (both sides on the ORACLE's samples) asserts tightly.
+    e2e_tight = encoding == "lotd"
+    flips_max = tol.get("flips", TOL["f32"]["flips"]) if e2e_tight else max(2, N // 50)
     o, d, fidx, ha, jit, jit_c, gt = _batch(tr, N, seed=11)
     _fresh(p)
     ha_o = leaf(ha)
@@ -177,7 +209,7 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
     same = None
     if precision == "f32":
         # compress keep decisions (vw > 1e-4) sit on a threshold: a 1e-6 SDF difference may flip one of ~4e5
-        assert rec["rays_with_other_count"] <= tol["flips"], rec
+        assert rec["rays_with_other_count"] <= flips_max, rec
         same_ray = (n_p == n_o)
         same = torch.repeat_interleave(same_ray, n_o)               # oracle samples of rays with identical counts
         same_p = torch.repeat_interleave(same_ray, n_p)
@@ -218,19 +250,21 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
     got["h_appear"] = torch.zeros(N, 4, device=dev).index_put((dv(ri),), ha_p2.grad)
     for k, v in got.items():
         rec["fix_grad_" + k] = rel_l2(v.cpu(), ref[k])
-    _report(f"api_{precision}_{'compressed' if compressed else 'full'}", rec)
+    _report(("permuto_" if encoding == "permuto" else "") + f"api_{precision}_{'compressed' if compressed else 'full'}", rec)
 
     # ---------------------------------------------------------------- assertions
     for k, lim in tol["img"].items():
-        assert rec["img_" + k] < lim, (k, rec["img_" + k])
+        assert rec["img_" + k] < (lim if e2e_tight else 0.2), (k, rec["img_" + k])
         assert rec["fix_img_" + k] < lim, ("fix", k, rec["fix_img_" + k])
-    for k in ("sdf", "rgb", "nablas"):
-        assert rec["fix_" + k] < tol["fix"][k], (k, rec["fix_" + k])
+    for k in ("sdf", "rgb", "nablas"):      # (the rough permutohedral field has normals of magnitude ~10: absolute fp16 bound x 4)
+        assert rec["fix_" + k] < tol["fix"][k] * (1 if (e2e_tight or precision == "f32") else 4), (k, rec["fix_" + k])
     assert abs(rec["fix_loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
     gtol = tol["grad"] if (compressed or precision == "f32") else tol["grad_full"]
     for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
         assert rec["fix_grad_" + k] < gtol, (k, rec["fix_grad_" + k])
-    if precision == "f32":
+    if not e2e_tight:
+        assert rec["psnr_rgb_db"] > 55.0 and abs(rec["loss"] - rec["loss_oracle"]) < 2e-2 * (1 + abs(rec["loss_oracle"]))
+    elif precision == "f32":
         assert rec["sdf_nograd_max"] < tol["sdf"]
         assert rec["march_coarse_sdf_max"] < tol["fix"]["sdf"]
         for k in ("t", "sdf", "rgb", "nablas"):
@@ -245,7 +279,7 @@ def test_api_path_matches_oracle_at_baseline_config(precision, compressed):
         # Round 3: the sampling pass runs in f32-equivalent arithmetic (``sampling_precision = "split"``), so the fp16 step
         # works on the oracle's sample set (at most the f32 mode's own threshold flips) and the end-to-end gradients obey
         # the bounds of the fixed-sample-set leg (round 2, fp16 sampling: 59 of 2038 rays kept another count, gate 0.15)
-        assert rec["rays_with_other_count"] <= TOL["f32"]["flips"], rec
+        assert rec["rays_with_other_count"] <= flips_max, rec
         for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b", "ln_inv_s", "h_appear"):
             assert rec["e2e_grad_" + k] < gtol, (k, rec["e2e_grad_" + k])
 

@@ -284,3 +284,17 @@ def test_training_steps_on_the_permuto_model(backend):
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
     assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())
+
+
+def test_permuto_encoding_at_the_reference_scale(backend):
+    """16 levels, 16 .. 2000 cells per unit, T = 2^19, random shifts up to 10 (all_occ.240201.yaml:439-446): the finest
+    levels work at |elevated| ~ 3e4 where an f32 ulp is 2e-3 lattice units, so the SAME order of operations is what makes
+    two implementations agree -- kernel and oracle are equal to the last bit on the host, to rounding of the features on
+    the device."""
+    cfg = dict(type="multi_res", n_levels=16, n_feats=2, log2_hashmap_size=19, coarsest_res=16.0, finest_res=2000.0)
+    enc = PermutoEncoding(3, cfg, bound=0.5, seed=1).to(backend)
+    spec = operm.make_permuto_spec(in_dim=3, **{k: v for k, v in cfg.items() if k != "type"})
+    x = torch.rand(6000, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    ref = operm.permuto_forward(x, enc.flattened_params.detach().cpu().half().float(), spec)
+    out = enc(x.to(backend)).detach().cpu()
+    assert (out - ref).abs().max() < 1e-6
