@@ -196,10 +196,11 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
 // and pass against 12 MFMAs per 32 points).
 #define NSIM_LOG2E 1.4426950408889634f
 #define NSIM_LN2 0.6931471805599453f
-// beta < 0 selects relu (``decoder_cfg.activation: relu``, no_fg_occ.221218.yaml:354-357): a = max(z, 0), sigma = [a > 0]; the
-// curvature terms of the backward, written as beta s (1 - s), vanish by themselves for s in {0, 1}.  (wave-uniform branch)
+// relu (``decoder_cfg.activation: relu``, no_fg_occ.221218.yaml:354-357; meta.softplus_beta < 0) runs through the SAME
+// formulas with beta = 1e30 (field_args): the log term is scaled by 1 / beta -> max(z, 0); sigma = 1 - exp2(-1e30 a) is
+// exactly [a > 0]; the curvature terms of the backward, written as beta s (1 - s), are 1e30 x 0.  No branch, no second
+// code path (a wave-uniform branch here cost the 17..32-level backward 17 % in registers held across both arms).
 __device__ __forceinline__ float softplus_exact(float z, float beta, float inv_beta) {
-  if (beta < 0.f) return fmaxf(z, 0.f);
   const float t = nsim_exp2(-fabsf(z) * (beta * NSIM_LOG2E));
   return fmaxf(z, 0.f) + nsim_log2(1.0f + t) * (inv_beta * NSIM_LN2);
 }
@@ -215,10 +216,7 @@ __device__ __forceinline__ float sig_from_softplus(float a, float beta) { return
 #else
 __device__ __forceinline__ float softplus_b(float z, float beta, float inv_beta) { return softplus_exact(z, beta, inv_beta); }
 // sigma(beta z) recovered from a = softplus(z):  1 - exp(-beta a)   (abs. error <= 6e-8)
-__device__ __forceinline__ float sig_from_softplus(float a, float beta) {
-  if (beta < 0.f) return a > 0.f ? 1.0f : 0.f;
-  return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E));
-}
+__device__ __forceinline__ float sig_from_softplus(float a, float beta) { return 1.0f - nsim_exp2(-a * (beta * NSIM_LOG2E)); }
 #endif
 
 __device__ __forceinline__ void sh4_eval(const float d[3], float (&o)[16]) {
@@ -477,7 +475,9 @@ __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32]
 // decoder weights given dL/dsdf and the TOTAL dL/dnablas, which already includes the radiance net's share).
 // NC: 16-level feature chunks of the decoder input (2 for pyramids of 17..32 levels -- the first layer contracts over
 // 64 features; only on the level-major planes, MODE 2 / 3).
-template <int PREC, int SDF_D, int MODE, int NC = 1>
+// GL2 (MODE 3, NC == 2): the plane image of a tile (1 KB per level of the pyramid) is prefetched into LDS as in the
+// 16-level kernel -- possible while weights + 4 images fit the 160 KB (pyramids of up to 23 levels: the street's 19).
+template <int PREC, int SDF_D, int MODE, int NC = 1, bool GL2 = false>
 __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -530,13 +530,15 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   // MODE 3, <= 16 levels: the planes of the NEXT tile (16 KB: per level 256 B of h and 768 B of dh/dx, each one aligned
   // piece thanks to the 32-point pitch) are copied global -> LDS by 16 global_load_lds_dwordx4 while this tile computes;
   // half of a tile used to be the wait for these reads (all workgroups burst together at one wave per SIMD).
-  constexpr bool GLDS = (MODE == 3 && NC == 1);
+  static_assert(!GL2 || (MODE == 3 && NC == 2), "GL2 is the 17..32-level forward");
+  constexpr bool GLDS = (MODE == 3 && (NC == 1 || GL2));
   const int nlv = a.lotd.num_levels;      // plane levels past it are neither written by the gather nor read here
-  char* pf = GLDS ? smem + wbytes + wave * 16384 : nullptr;
+  char* pf = GLDS ? smem + wbytes + wave * (NC == 1 ? 16384 : 1024 * nlv) : nullptr;
   auto prefetch_planes = [&](int64_t tile_n) {
     const int64_t s0 = tile_n * 32;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
+    for (int l = 0; l < 16 * NC; ++l) {
+      if (!LV_OK(l)) continue;
       const float* src = lane < 16 ? a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane
                                    : a.J_pl + ((int64_t)l * a.PS + s0) * 6 + 4 * (lane - 16);
       nsim_glds16(src, pf + 1024 * l);
@@ -559,14 +561,16 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // ([level][sample][..], coalesced across the 32 samples of a tile) -- 512 B per sample of sequential HBM
     // traffic instead of a second latency-bound random gather.
     float h[16 * NC];
-    float J[NC == 1 ? 16 : 1][3];     // NC == 2 re-reads dh/dx from the planes where it is consumed
+    float J[(NC == 1 || GL2) ? 16 * NC : 1][3];     // NC == 2 without the LDS image re-reads dh/dx where it is consumed
     if constexpr (GLDS) {
       nsim_wait_vm0();                          // this tile's image has landed
+#pragma unroll
+      for (int m = 0; m < NC; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
           const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
           const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
           const bool lv = valid && LV_OK(l);
@@ -717,12 +721,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     if constexpr (FWD) {
       if constexpr (MODE == 3) { KT(2, 3); }
       float nab[3];
-      if constexpr (NC == 1) {
+      if constexpr (NC == 1 || GL2) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
           float acc = 0.f;
 #pragma unroll
-          for (int f = 0; f < 16; ++f) acc = acc + g[f] * J[f][c3];
+          for (int f = 0; f < 16 * NC; ++f) acc = acc + g[f] * J[f][c3];
           nab[c3] = acc + wave_shfl_xor(acc, 32);
         }
       } else {
@@ -2127,7 +2131,7 @@ static FieldArgs field_args(const NsimFieldMeta* meta) {
   FieldArgs a = FieldArgs();
   a.lotd = lotd_dev(&meta->lotd);
   a.lay = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
-  a.beta = meta->softplus_beta;
+  a.beta = meta->softplus_beta > 0.f ? meta->softplus_beta : 1e30f;      // (<= 0: relu, see softplus_exact)
   static const int code_pf = getenv("NSIM_CODE_PREFETCH") ? atoi(getenv("NSIM_CODE_PREFETCH")) : 0;
   a.code_pf = code_pf;
   return a;
@@ -2158,11 +2162,19 @@ static int field_waves(const NsimFieldMeta* meta, int mode) {
 
 template <int MODE>
 static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t shmem, int64_t max_blocks,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool gl2 = false) {
   const int nw = field_waves(meta, MODE);
   const dim3 grid(field_grid(a.S, max_blocks, nw)), block(64 * nw);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
   if (field_nc(meta->lotd.num_levels) == 2) {
+    if constexpr (MODE == 3) {
+      if (gl2 && meta->precision == 0) {      // plane image in LDS (fp16 mode, <= 23 levels)
+        if (meta->sdf_D == 1) hipLaunchKernelGGL((k_field<0, 1, 3, 2, true>), grid, block, shmem, stream, a);
+        else hipLaunchKernelGGL((k_field<0, 2, 3, 2, true>), grid, block, shmem, stream, a);
+        NSIM_CHECK_LAUNCH();
+        return 0;
+      }
+    }
     if constexpr (MODE == 2 || MODE == 3) {
       switch (key) {
         case 0: hipLaunchKernelGGL((k_field<0, 1, MODE, 2>), grid, block, shmem, stream, a); break;
@@ -2387,16 +2399,26 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
       if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
     }
-    // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS)
-    const size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
+    // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS); 17..32 levels, fp16: 1 KB per level and wave
+    // where that still fits the 160 KB of a CU (NSIM_FWD_GL2=0: the direct-load kernel)
     size_t wl = weights_lds_bytes(meta);
     if (meta->precision != 0) wl = 0;
+    size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
+    bool gl2 = false;
+    if (field_nc(meta->lotd.num_levels) == 2 && meta->precision == 0) {
+      static const bool gl2_on = !(getenv("NSIM_FWD_GL2") && atoi(getenv("NSIM_FWD_GL2")) == 0);
+      const size_t img = (size_t)FIELD_WAVES * 1024 * meta->lotd.num_levels;
+      if (gl2_on && wl + img <= 160 * 1024) {
+        gl2 = true;
+        pf_bytes = img;
+      }
+    }
     // persistent workgroups: with the plane-prefetch buffers one workgroup fits a CU (124 KB of LDS), 1024 of them ran as
     // four rounds that each staged the weights and took a cold first tile (s_memtime stamps: 22.5 k vs 16.7 k ticks) --
     // one round of 256: 0.197 -> 0.189 ms per 0.31 M points (gather included); the 17..32-level kernel fits two per CU
     static const int fwd_grid_env = getenv("NSIM_FWD_GRID") ? atoi(getenv("NSIM_FWD_GRID")) : 0;
     const int fwd_grid = fwd_grid_env > 0 ? fwd_grid_env : (pf_bytes ? 256 : 512);
-    return field_launch<3>(meta, a, wl + pf_bytes, fwd_grid, (hipStream_t)stream);
+    return field_launch<3>(meta, a, wl + pf_bytes, fwd_grid, (hipStream_t)stream, gl2);
   }
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
