@@ -123,6 +123,18 @@ def main():
                 (P / dst).write_text(json.dumps(json.loads(txt.splitlines()[-1] if src.endswith("bench.json") or "fusedgather" in src else txt), indent=1))
             except Exception:
                 (P / dst).write_text(txt)
+    for src, dst in (("prof_ktime.txt", f"{TAG}_ktime_timelines.txt"), ("prof_field_bench.jsonl", f"{TAG}_field_bench.jsonl"),
+                     ("prof_bench_noreplicas.json", f"{TAG}_bench_n1_no_grad_replicas.json"),
+                     ("prof_distant_lmgather.json", f"{TAG}_bench_n1_distant_noprofiler.json")):
+        f = G / src
+        if f.exists() and f.stat().st_size:
+            txt = f.read_text()
+            if src.endswith(".json"):
+                try:
+                    txt = json.dumps(json.loads(txt.strip().splitlines()[-1]), indent=1)
+                except Exception:
+                    pass
+            (P / dst).write_text(txt)
     print(json.dumps(traffic, indent=1))
     print(bench["value"], bench["ms_per_step"], bench["roofline"])
 

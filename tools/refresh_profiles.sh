@@ -7,6 +7,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
+rm -f $O/prof_field_bench.jsonl
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity"
 timeout 900 python $R/bench.py > $O/prof_bench.json 2> $O/prof_bench.err
@@ -30,5 +31,13 @@ SCMD="python $R/bench.py --config street --steps 8 --warmup 4"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_street -o s -- $SCMD > $O/prof_street_bench.json 2>/tmp/e7.log
 python $R/tools/prof_summary.py $(find /tmp/p_street -name "*.db" | head -1) $O/prof_street_stats.json
 timeout 300 python $R/tools/scatter_levels.py $O/prof_scatter_levels.json > /dev/null 2>&1
+# fused 4-D gather A/B WITHOUT a profiler on either side
+timeout 300 python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity > $O/prof_distant_lmgather.json 2>/dev/null
 NSIM_DISTANT_FUSED_GATHER=1 timeout 300 python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity > $O/prof_distant_fusedgather.json 2>/dev/null
+# per-iteration s_memtime timelines of the decoder kernels (a -DNSIM_KTIME build next to the product library, if present)
+[ -f $R/neuralsim_amd/csrc/_probe/libnsim_hip_ktime.so ] && (cd $R && timeout 300 python tools/ktime.py > $O/prof_ktime.txt 2>/dev/null)
+# flush storm A/B: direct weight-gradient flush vs replicas, same command
+NSIM_GRAD_REPLICAS=1 timeout 300 $CMD > $O/prof_bench_noreplicas.json 2>/dev/null
+# per-entry-point times of a with-grad query: object / street / permuto shapes
+(cd $R && for sh in object street permuto; do timeout 200 python tools/field_bench.py --shape $sh $( [ $sh = street ] || echo --rays 8192 --per-ray 38 ) >> $O/prof_field_bench.jsonl 2>/dev/null; done)
 tail -1 $O/prof_bench.json | cut -c1-300
