@@ -1477,6 +1477,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll 1
     for (int rb = 0; rb < 2 * NC; ++rb) {      // one K-step of 8 features per lane-half: levels 16 (rb/2) + 8 (rb%2) + ..
       const int lb = 16 * (rb >> 1) + 8 * (rb & 1);
+      // 17..32 levels: K-steps entirely past the pyramid are skipped; inside the last partial one the planes hold zeros
+      // (written by the gather) -- per-lane guards on these loads cost 40 % of the kernel (0.094 -> 0.134 ms per 1.39 M points)
+      if (NC == 2 && lb >= ((a.lotd.num_levels + 7) & ~7)) continue;
       float f8[8];
       f16x8 bvp;
       if constexpr (PLANES) {
@@ -1486,20 +1489,18 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = lb + 4 * qq + 2 * hi + b;
-            const int nlv = a.lotd.num_levels;
-            const bool lv = LV_OK(l);      // planes past a 17..32-level pyramid are neither written nor read
-            const int64_t e = (int64_t)(lv ? l : 0) * a.S + (p.valid ? p.s : 0);
+            const int64_t e = (int64_t)l * a.S + (p.valid ? p.s : 0);
             if constexpr (PREC == 0) {
               union {
                 uint32_t u;
                 f16 h[2];
               } cv;
-              cv.u = lv ? reinterpret_cast<const uint32_t*>(a.feat_pl)[e] : 0u;
+              cv.u = reinterpret_cast<const uint32_t*>(a.feat_pl)[e];
               bvp[4 * qq + 2 * b] = cv.h[0];
               bvp[4 * qq + 2 * b + 1] = cv.h[1];
             } else {
-              f8[4 * qq + 2 * b] = lv ? reinterpret_cast<const float*>(a.feat_pl)[2 * e] : 0.f;
-              f8[4 * qq + 2 * b + 1] = lv ? reinterpret_cast<const float*>(a.feat_pl)[2 * e + 1] : 0.f;
+              f8[4 * qq + 2 * b] = reinterpret_cast<const float*>(a.feat_pl)[2 * e];
+              f8[4 * qq + 2 * b + 1] = reinterpret_cast<const float*>(a.feat_pl)[2 * e + 1];
             }
           }
       } else {
@@ -2240,11 +2241,12 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
 // range on two XCDs (3 of the 11 hashed levels of the default pyramid end up split: max load 1.7 instead of 2.0).
 static void deal_levels(const NsimFieldMeta* meta, FieldArgs& a) {
   // the plane arrays hold 16 nc levels; NC == 2: the ones past num_levels are neither written here nor read by the decoders
-  const int NL = field_nc(meta->lotd.num_levels) == 2 ? meta->lotd.num_levels : 16;      // (see LV_OK)
+  // 17..32 levels: the pyramid's own levels + zeros up to the next multiple of 8 (the sampling decoder's K-step), see LV_OK
+  const int NL = field_nc(meta->lotd.num_levels) == 2 ? ((meta->lotd.num_levels + 7) & ~7) : 16;
   float cost[32], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.f;
   bool used[32] = {false};
   for (int l = 0; l < NL; ++l) {
-    cost[l] = l >= meta->lotd.num_levels ? 0.35f : (meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f);
+    cost[l] = l >= meta->lotd.num_levels ? (NL > 16 ? 0.05f : 0.35f) : (meta->lotd.type[l] == NSIM_LOTD_HASH ? 1.0f : 0.35f);
     total += cost[l];
   }
   const float limit = total / 8.0f * 1.08f;
@@ -2329,7 +2331,11 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   }
   // 512 persistent workgroups (two per CU): at 2048 a wave staged 26 KB of weights for ~1.2 tiles of work
   // (0.0506 -> 0.0463 ms per 0.31 M points; 1024: 0.0483, 256: 0.0706)
-  static const int sdf_grid = getenv("NSIM_SDF_GRID") ? atoi(getenv("NSIM_SDF_GRID")) : 512;
+  static const int sdf_grid_env = getenv("NSIM_SDF_GRID") ? atoi(getenv("NSIM_SDF_GRID")) : 0;
+  // ... and about five tiles per wave beyond that (1.39 M points of the street step: 2048 workgroups 0.094 ms, 512: 0.134 --
+  // with more tiles per wave the static stride balances worse than the dispatcher's backfill of finished workgroups)
+  int64_t sdf_grid = sdf_grid_env > 0 ? sdf_grid_env : ((S + 31) / 32) / (FIELD_WAVES * 5);
+  if (sdf_grid_env <= 0) sdf_grid = sdf_grid < 512 ? 512 : (sdf_grid > 4096 ? 4096 : sdf_grid);
   const dim3 grid(field_grid(S, sdf_grid)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);

@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(256) k_permuto_bwd(PermutoArgs a) {
 template <int MODE>
 static int permuto_launch_fwd(const NsimPermutoMeta* meta, const PermutoArgs& a, hipStream_t stream) {
   // field modes with fewer than 16 levels: rows 0..15 of the plane arrays are all written (zeros past the pyramid)
-  const int rows = (MODE != 0 && meta->num_levels < 16) ? 16 : meta->num_levels;
+  // (more than 16 levels: zeros up to the next multiple of 8, the sampling decoder's K-step)
+  const int rows = MODE == 0 ? meta->num_levels : (meta->num_levels < 16 ? 16 : ((meta->num_levels + 7) & ~7));
   const dim3 grid((unsigned)nsim_blocks(a.S, 256), (unsigned)rows), block(256);
   switch (meta->in_dim) {
     case 2: hipLaunchKernelGGL((k_permuto_fwd<2, 0>), grid, block, 0, stream, a); break;      // (standalone only: the field front end needs in_dim >= 3)
