@@ -220,7 +220,8 @@ class RenderTrainer:
     # ------------------------------------------------------------------ the differentiable part as one launch chain
     def _fused_ok(self) -> bool:
         m = self.model
-        return (self.fused_step and type(m) is LoTDNeuSModel and self.distant_model is None and self.sky_model is None
+        plain = type(m) is LoTDNeuSModel or (type(m).__name__ == "PermutoNeuSModel" and getattr(m, "z_dim", 0) == 0)
+        return (self.fused_step and plain and self.distant_model is None and self.sky_model is None
                 and not self.pose_refine_active() and getattr(m, "_ctrl_mix", 0.0) == 0.0 and self.mono is None
                 and self.rgb_fn == "mse")
 
@@ -296,8 +297,9 @@ class RenderTrainer:
             PSc = _lib.plane_pitch(Sc)
             bufs = (torch.empty([Sc], **f32), torch.empty([Sc, 3], **f32), torch.empty([Sc, 3], **f32),
                     torch.empty([NLP, PSc, 2], **f32), torch.empty([NLP, PSc, 2, 3], **f32))
-            call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_full), ptr(ridx_full), None,
-                 ptr(ha), Sc, ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(bufs[3]), ptr(bufs[4]), ptr(total_dev), M)
+            # (the encoding's hook: LoTD = nsim_field_fwd with its own gather; permutohedral = nsim_permuto_gather + decoders)
+            model._enc_field_fwd(grid16, wpack, None, o, d, t_full, ridx_full, None, ha, Sc, bufs[0], bufs[1], bufs[2], bufs[3],
+                                 bufs[4], total_dev, M)
             spec.update(bufs=bufs, PS=PSc)
         if self.spec_forward:
             cfg["_spec_launch"] = spec_launch
@@ -322,8 +324,7 @@ class RenderTrainer:
             sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
             PS = _lib.plane_pitch(St)
             h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
-            call("nsim_field_fwd", fm, ptr(grid16), ptr(wpack), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, ptr(ha),
-                 St, ptr(sdf), ptr(nab), ptr(rgb), ptr(h_pl), ptr(J_pl), None, 0)
+            model._enc_field_fwd(grid16, wpack, None, o, d, t_a, ridx_a, None, ha, St, sdf, nab, rgb, h_pl, J_pl, None, 0)
         ln_inv_s = model.ln_inv_s.detach()
         alpha, vw, trans = torch.empty([S], **f32), torch.empty([S], **f32), torch.empty([S], **f32)
         nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
@@ -369,7 +370,12 @@ class RenderTrainer:
         self.appear.grad = d_app
         scatter_args = (model.encoding.cfg.meta, None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, St, ptr(dh_pl),
                         ptr(g_pl), ptr(gn_total), ptr(dgrid))
-        if self.world_size > 1 and self.overlap_allreduce:
+        if type(model) is not LoTDNeuSModel:          # another encoding (permutohedral): its own scatter, in one piece
+            model._enc_scatter(None, o, d, t_a, ridx_a, None, St, dh_pl, g_pl, gn_total, dgrid)
+            if self.world_size > 1 and self.overlap_allreduce:
+                grid_p.grad = dgrid
+                self._dp_reduce_step(dgrid, None)
+        elif self.world_size > 1 and self.overlap_allreduce:
             self._dp_reduce_step(dgrid, lambda l0, n: call("nsim_lotd_scatter", *scatter_args, l0, n))
         else:
             call("nsim_lotd_scatter", *scatter_args, 0, 0)
@@ -418,6 +424,10 @@ class RenderTrainer:
         """Two contiguous level ranges of about equal scatter cost (a hashed level ~1, a dense one ~0.35 -- the
         weights of the gather's level dealing): [(level_begin, level_end, param_begin, param_end)] * 2."""
         cfg = self.model.encoding.cfg
+        if not hasattr(cfg, "lod_types"):       # levels of equal size (permutohedral: T entries each)
+            L, per = cfg.num_levels, cfg.n_params // cfg.num_levels
+            k = max(1, L // 2)
+            return [(0, L, 0, cfg.n_params)] if L < 2 else [(0, k, 0, k * per), (k, L, k * per, cfg.n_params)]
         cost = [1.0 if t == "Hash" else 0.35 for t in cfg.lod_types]
         L, tot = cfg.num_levels, sum(cost)
         if L < 2:

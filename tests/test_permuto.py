@@ -276,7 +276,7 @@ def test_training_steps_on_the_permuto_model(backend):
     m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
     intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
     tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, target_sphere_radius=0.5)
-    assert not tr._fused_ok()                       # the fused launch chain is the LoTD model's; this goes through autograd
+    assert tr._fused_ok()                           # the fused launch chain runs on the encoding hooks: this model as well
     xy, fidx, gt = tr.sample_batch()
     tr.sample_batch = lambda: (xy, fidx, gt)
     before = m.encoding.flattened_params.detach().clone()
@@ -284,6 +284,10 @@ def test_training_steps_on_the_permuto_model(backend):
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
     assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())
+    # the fused chain and the autograd path compute the same step (same batch, same randoms): equal losses
+    tr.fused_step = False
+    l_auto = float(tr.train_step(6))
+    assert l_auto == l_auto and abs(l_auto - losses[-1]) < 0.2 * abs(losses[-1]) + 1e-3
 
 
 def test_permuto_encoding_at_the_reference_scale(backend):
@@ -298,3 +302,36 @@ def test_permuto_encoding_at_the_reference_scale(backend):
     ref = operm.permuto_forward(x, enc.flattened_params.detach().cpu().half().float(), spec)
     out = enc(x.to(backend)).detach().cpu()
     assert (out - ref).abs().max() < 1e-6
+
+
+def test_fused_step_equals_autograd_step_on_the_permuto_model(backend):
+    """the straight launch chain (``RenderTrainer._train_render_fused`` on the encoding hooks) vs the renderer + autograd
+    path: same losses and parameters after five iterations (as tests/test_trainer.py pins it for the LoTD model)"""
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+              upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
+                             precision="fp16", ln_inv_s_init=0.3, seed=4,
+                             accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
+                                            update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
+                             ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed", query_param=qp)).to(backend)
+        m.geometric_init_sphere(0.5, num_iters=25, num_pts=2048, lr=5e-3)
+        m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
+        intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=fused, num_uniform=24,
+                           perturb=True)
+        assert tr._fused_ok() == fused
+        losses = [float(tr.train_step(it)) for it in range(5)]
+        outs.append((losses, m.encoding.flattened_params.detach().clone(), m.sdf_w.detach().clone(), m.rad_w.detach().clone(),
+                     dict(tr.stats)))
+    (la, *pa, sa), (lb, *pb, sb) = outs
+    assert sa == sb and sa["S_f"] > 0
+    assert all(abs(x - y) < 1e-4 * (1 + abs(x)) for x, y in zip(la, lb)), (la, lb)
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        bad = d > (5e-5 + 1e-4 * b.abs())
+        assert float(bad.float().mean()) < 5e-3, (float(bad.float().mean()), float(d.max()))
