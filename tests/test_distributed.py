@@ -96,7 +96,7 @@ def test_shard_range_covers_batch():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
-def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None, steps=2):
+def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None, steps=2, model_kind="lotd"):
     """bench.timed_run under two gloo ranks, with the kernel emulator standing in for the GPU (control flow of the
     N>1 path: sharded rays, gradient all-reduce inside train_step, barrier + max-over-ranks timing, rank-0 JSON)."""
     import ctypes
@@ -123,12 +123,25 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None
     from neuralsim_amd.trainer import RenderTrainer
     nd.init_env(backend="gloo", device_type="cpu")
     dev = torch.device("cpu")
-    m = _tiny(dev, seed=42 + rank)                    # replicas differ until broadcast
+    if model_kind == "permuto":       # the permutohedral model through the same N > 1 chain (row f4)
+        from neuralsim_amd.fields.permuto_neus import PermutoNeuSModel
+        qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
+                  upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
+        m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(type="multi_res", n_levels=8, n_feats=2, log2_hashmap_size=10,
+                                                           coarsest_res=2.0, finest_res=24.0), sdf_D=2, precision="fp16",
+                             ln_inv_s_init=0.3, seed=42 + rank,
+                             accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
+                                            update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
+                             ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(dev)
+        m.geometric_init_sphere(0.5, num_iters=15, num_pts=1024, lr=5e-3)
+        m.accel.init(m.query_sdf, num_steps=1, num_pts=2048)
+    else:
+        m = _tiny(dev, seed=42 + rank)                    # replicas differ until broadcast
     nd.broadcast_module(m)
     intr, c2w, WH = look_at_cameras(V=4, seed=1, device=dev)
     tr = RenderTrainer(m, intr, c2w, WH, num_rays=16, lr=1e-3, num_uniform=16, rank=rank, world_size=world)
     assert tr._fused_ok() and tr.overlap_allreduce == (overlap == "1")
-    if overlap == "1":      # two contiguous level ranges covering the pyramid and its parameters
+    if overlap == "1" and model_kind == "lotd":      # two contiguous level ranges covering the pyramid and its parameters
         h = tr._grid_halves()
         cfg = m.encoding.cfg
         assert h[0][0] == 0 and h[0][1] == h[1][0] and h[1][1] == cfg.num_levels
@@ -144,7 +157,7 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None
     if rank == 0:
         torch.save(dict(grid=m.encoding.flattened_params.detach().clone(), sdf_w=w, rad_w=m.rad_w.detach().clone(),
                         appear=tr.appear.detach().clone(), grid0=p0),
-                   str(Path(out_dir) / f"params_overlap{overlap}{wire}{algo or ''}.pt"))
+                   str(Path(out_dir) / f"params_overlap{overlap}{wire}{algo or ''}{'' if model_kind == 'lotd' else model_kind}.pt"))
         assert out["n_gpus"] == world and out["steps"] == steps and out["value"] > 0 and out["scaling"] == "weak"
         assert abs(out["value"] - 16 * world * steps / (out["ms_per_step"] * steps * 1e-3)) / out["value"] < 1e-2
     else:
@@ -170,6 +183,21 @@ def test_bench_control_flow_two_ranks(tmp_path):
         for r in range(world):
             (tmp_path / f"bench_ok{r}").unlink()
     a, b = (torch.load(str(tmp_path / f"params_overlap{o}f32.pt")) for o in ("1", "0"))
+    for k in a:
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, float((a[k] - b[k]).abs().max()))
+
+
+def test_two_ranks_train_the_permuto_model(tmp_path):
+    """the permutohedral model in the N > 1 chain: overlapped halves (equal-sized lattice levels) and the single
+    collective leave the replicas in sync and arrive at the same parameters"""
+    world = 2
+    for overlap in ("1", "0"):
+        mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), overlap, "f32", None, 2, "permuto"), nprocs=world,
+                 join=True)
+        assert all((tmp_path / f"bench_ok{r}").exists() for r in range(world))
+        for r in range(world):
+            (tmp_path / f"bench_ok{r}").unlink()
+    a, b = (torch.load(str(tmp_path / f"params_overlap{o}f32permuto.pt")) for o in ("1", "0"))
     for k in a:
         assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, float((a[k] - b[k]).abs().max()))
 
