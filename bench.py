@@ -238,13 +238,23 @@ def time_steps(tr, steps, warmup, it):
     for _ in range(warmup):
         tr.train_step(it)
         it += 1
+    # the cyclic collector is parked over the timed steps, as in ``timed_run`` (a generation-2 pass over torch's module
+    # graphs costs tens of ms: one of them inside a 12-step variant reads as +5 ms per step); NSIM_BENCH_GC=1 leaves it on
+    import gc
+    park = os.environ.get("NSIM_BENCH_GC") != "1" and gc.isenabled()
+    if park:
+        gc.collect()
+        gc.disable()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(it)
         it += 1
     sync()
-    return (time.perf_counter() - t0) / steps * 1e3, it
+    el = time.perf_counter() - t0
+    if park:
+        gc.enable()
+    return el / steps * 1e3, it
 
 
 def measure_exposed_allreduce(tr, out, steps, it, rank, dev):

@@ -581,11 +581,13 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         return self
 
     def pretrain_sdf_fn(self, target_fn, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14, seed: int = 0,
-                        logger=None) -> float:
+                        logger=None, w_eikonal: float = 0.0) -> float:
         """The reference's SDF pre-training as an optimisation (``nr3d_lib.models.fields.sdf.pretrain_sdf_*``, called with
         ``initialize_cfg{num_iters, lr, ...}`` by app/models/single/neus.py:198-236): fit the SDF to ``target_fn(x)``
         (x [N,3] object coordinates on the model's device -> [N]) at uniformly drawn points of the box with Adam over the
-        encoding and the SDF decoder, through the model's own forward / backward kernels.  Returns the last L1 loss."""
+        encoding and the SDF decoder, through the model's own forward / backward kernels.  ``w_eikonal`` > 0 adds
+        w (|grad sdf| - 1)^2 on the same points (the reference's ``initialize_cfg.w_eikonal``): a hashed encoding fitted
+        by values alone ends up rough at the scale of its finest levels.  Returns the last L1 loss."""
         dev = self.encoding.flattened_params.device
         params = [self.encoding.flattened_params, self.sdf_w, self.sdf_b]
         opt = torch.optim.Adam(params, lr=lr)
@@ -597,10 +599,11 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 x = lo + (hi - lo) * torch.rand([num_pts, 3], device=dev, generator=g)
                 with torch.no_grad():
                     target = target_fn(x).to(dev).float()
-                sdf = self.forward_sdf_nablas(x, nablas_has_grad=False)["sdf"]
-                loss = (sdf - target).abs().mean()
+                out = self.forward_sdf_nablas(x, nablas_has_grad=w_eikonal > 0)
+                loss = (out["sdf"] - target).abs().mean()
+                total = loss if w_eikonal <= 0 else loss + w_eikonal * ((out["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
                 opt.zero_grad(set_to_none=True)
-                loss.backward()
+                total.backward()
                 opt.step()
                 self._wpack_versions = None
                 if logger is not None and it % 100 == 0:
@@ -611,7 +614,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         return float(loss.detach())
 
     def pretrain_sdf_sphere(self, radius: float = 0.5, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14,
-                            seed: int = 0, logger=None) -> float:
+                            seed: int = 0, logger=None, w_eikonal: float = 0.0) -> float:
         """``pretrain_sdf_sphere``: target |u| - radius, u = the AABB-normalised position (r - |u| for ``inside_out``)."""
         lo, hi = self.accel.aabb[0], self.accel.aabb[1]
         sign = -1.0 if self.inside_out else 1.0
@@ -619,7 +622,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         def target(x):
             u = (x - (lo.to(x.device) + hi.to(x.device)) * 0.5) / ((hi.to(x.device) - lo.to(x.device)) * 0.5)
             return sign * (u.norm(dim=-1) - radius)
-        return self.pretrain_sdf_fn(target, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed, logger=logger)
+        return self.pretrain_sdf_fn(target, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed, logger=logger,
+                                    w_eikonal=w_eikonal)
 
     @torch.no_grad()
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:

@@ -170,10 +170,10 @@ class PermutoNeuSModel(LoTDNeuSModel):
 
     # ---------------------------------------------------------------- geometric initialisation = pre-training
     def geometric_init_sphere(self, radius: float = 0.5, num_iters: int = 300, lr: float = 2e-3, num_pts: int = 2 ** 14,
-                              seed: int = 0, **_):
+                              seed: int = 0, w_eikonal: float = 0.1, **_):
         """``geo_init_method: pretrain`` (all_occ.240201.yaml:451): there is no dense level to write a sphere into -- the
         SDF is fitted to |u| - radius by ``LoTDNeuSModel.pretrain_sdf_sphere`` (Adam through the model's own kernels)."""
-        return self.pretrain_sdf_sphere(radius, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed)
+        return self.pretrain_sdf_sphere(radius, num_iters=num_iters, lr=lr, num_pts=num_pts, seed=seed, w_eikonal=w_eikonal)
 
     def training_initialize(self, config=None, logger=None, log_prefix=None) -> bool:
         """``asset_training_initialize`` -> ``training_initialize`` (app/models/single/neus.py:92-95): the pre-training
@@ -187,7 +187,7 @@ class PermutoNeuSModel(LoTDNeuSModel):
             r = float(post.get("radius_init", 0.5)) / (float(ext.min()) / 2.0)
             with torch.enable_grad():
                 self.geometric_init_sphere(min(r, 0.95), num_iters=int(cfg.get("num_iters", 300)), lr=float(cfg.get("lr", 2e-3)),
-                                           num_pts=int(cfg.get("num_pts", 2 ** 14)))
+                                           num_pts=int(cfg.get("num_pts", 2 ** 14)), w_eikonal=float(cfg.get("w_eikonal", 0.1)))
             updated = True
         if self.accel is not None:
             with torch.no_grad():

@@ -17,7 +17,7 @@ def _init(implicit_surface, fn, cfg, logger):
     if cfg.get("geo_init_impl", os.environ.get("NSIM_GEO_INIT", "write")) == "pretrain":
         implicit_surface.pretrain_sdf_fn(lambda x: fn(x.detach().cpu()), num_iters=int(cfg.get("num_iters", 500)),
                                          lr=float(cfg.get("lr", 2e-3)), num_pts=int(cfg.get("num_points", cfg.get("num_pts", 2 ** 14))),
-                                         logger=logger)
+                                         logger=logger, w_eikonal=float(cfg.get("w_eikonal", 0.0)))
     else:
         implicit_surface.geometric_init_fn(fn)
 

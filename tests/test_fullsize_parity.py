@@ -157,11 +157,11 @@ def _api_path_body(precision, compressed, encoding):
     m._march_stat = None             # exact buffer sizes for the sampling pass (no speculative capacity)
     tol = TOL[precision]
     N = N_API
-    # The pre-trained permutohedral field is ROUGH at the scale of its finest levels (300 Adam steps move all 16 levels of a
-    # hashed lattice alike: |d sdf / d x| reaches ~20 over distances of 5e-4), so the up-sampler's sensitivity (a fine sample
-    # moves by up to ~1e-3 for 1e-6 of SDF difference, TOL above) turns into SDF differences of ~1e-2 at the moved samples and
-    # a few keep / drop flips: the end-to-end leg is held to loose bounds there and the kernel parity is what the
-    # fixed-sample-set leg (both sides on the ORACLE's samples) asserts tightly.
+    # The permutohedral model is PRE-TRAINED on the device (300 Adam steps, float atomics: a different field every run).
+    # Fitted by values alone it was rough at the scale of its finest levels (|d sdf / d x| ~ 20 over 5e-4: the up-sampler's
+    # ~1e-3 sample sensitivity became ~1e-2 of SDF, 9-20 rays with another kept count); with the eikonal term of the
+    # pre-training (w 0.1) it measures 2-3 rays, PSNR 101 dB in f32 mode.  The end-to-end leg keeps loose, run-independent
+    # bounds; the kernel parity is what the fixed-sample-set leg (both sides on the ORACLE's samples) asserts tightly.
     e2e_tight = encoding == "lotd"
     flips_max = tol.get("flips", TOL["f32"]["flips"]) if e2e_tight else max(2, N // 50)
     o, d, fidx, ha, jit, jit_c, gt = _batch(tr, N, seed=11)
@@ -261,6 +261,11 @@ def _api_path_body(precision, compressed, encoding):
         assert rec["fix_" + k] < tol["fix"][k] * (1 if (e2e_tight or precision == "f32") else 4), (k, rec["fix_" + k])
     assert abs(rec["fix_loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))
     gtol = tol["grad"] if (compressed or precision == "f32") else tol["grad_full"]
+    if not e2e_tight and precision == "fp16":
+        # pre-trained WITH an eikonal term the lattice field has |n| ~ 1: the eikonal residual of the test loss is then a
+        # difference of cancelling terms (as on the LoTD model's un-compressed set, TOL above): the table gradient gets
+        # the ``grad_full`` bound (measured 7e-2; f32 on the same set 6e-6)
+        gtol = tol["grad_full"]
     if not e2e_tight and precision == "f32":
         # the rough pre-trained lattice field has normals of magnitude ~10 feeding the radiance net: its weight / appearance
         # gradients are sums with cancellation whose f32 value depends on the summation order (measured between two
