@@ -96,7 +96,7 @@ def test_lotd_model_can_run_the_reference_pretraining_procedure(backend):
                       accel_cfg=dict(resolution=(8, 8, 8), init_cfg=dict(num_steps=1, num_pts=1024),
                                      update_from_net_cfg=dict(num_steps=1, num_pts=1024), update_from_samples_cfg={})).to(backend)
     assert not bool(m.is_pretrained)
-    assert m.training_initialize(dict(geo_init_impl="pretrain", num_iters=80, lr=1e-2, num_pts=2048)) is True
+    assert m.training_initialize(dict(geo_init_impl="pretrain", num_iters=50, lr=1e-2, num_pts=1024)) is True
     assert bool(m.is_pretrained) and m.training_initialize(dict(geo_init_impl="pretrain", num_iters=80)) is False
     x = (torch.rand(512, 3, generator=torch.Generator().manual_seed(0)) * 1.6 - 0.8).to(backend)
     err = (m.query_sdf(x).cpu() - (x.cpu().norm(dim=-1) - 0.5)).abs().mean()
