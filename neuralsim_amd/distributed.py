@@ -138,12 +138,51 @@ class _DirectToken:
         return self.t
 
 
+_DIRECT_OK = {}
+
+
+def _direct_ok(device) -> bool:
+    """One-time self-check of the direct exchange on this backend / device (every rank reaches it at the same collective):
+    a 1000-element f32 sum (padding path included) through ``_DirectToken`` against the backend's own all-reduce.  A
+    mismatch or an exception switches this process group to ``ring`` for good, with a warning -- the direct form has run
+    on gloo (world sizes 2 and 8) and on RCCL only at world size 1 before the first multi-GPU run of a round."""
+    key = (dist.get_backend(), str(device))
+    if key in _DIRECT_OK:
+        return _DIRECT_OK[key]
+    if os.environ.get("NSIM_ALLREDUCE_ALGO") == "direct":      # forced: no check
+        _DIRECT_OK[key] = True
+        return True
+    ok = True
+    try:
+        g = torch.Generator().manual_seed(1234 + dist.get_rank())
+        x = torch.randn(1000, generator=g).to(device)
+        ref = x.clone()
+        dist.all_reduce(ref)
+        y = x.clone()
+        _DirectToken(y, torch.float32).finish()
+        ok = bool(torch.allclose(y, ref, rtol=1e-5, atol=1e-5))
+    except Exception as e:      # noqa: BLE001
+        print(f"[neuralsim_amd.distributed] direct all-reduce self-check raised {type(e).__name__}: {e}", flush=True)
+        ok = False
+    try:
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() > 0.5)
+    except Exception:      # noqa: BLE001
+        ok = False
+    if not ok:
+        print("[neuralsim_amd.distributed] direct 2-byte all-reduce failed its self-check on this backend: using the "
+              "backend's ring all-reduce (NSIM_ALLREDUCE_ALGO=ring)", flush=True)
+    _DIRECT_OK[key] = ok
+    return ok
+
+
 def allreduce_start(t: torch.Tensor, wire_dtype: Optional[torch.dtype] = None):
     """Begin an asynchronous sum-all-reduce of ``t`` (travelling as ``wire_dtype``); collectives complete in issue
     order, so a caller interleaves them with the kernels that produce the next tensor.  -> token for
     ``allreduce_finish``."""
     wire_dtype = torch.float32 if wire_dtype is None else wire_dtype
-    if _algo(wire_dtype) == "direct" and t.is_contiguous():
+    if _algo(wire_dtype) == "direct" and t.is_contiguous() and _direct_ok(t.device):
         return _DirectToken(t, wire_dtype)
     buf = t if (wire_dtype == t.dtype and t.is_contiguous()) else t.to(wire_dtype).contiguous()
     return t, buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
