@@ -263,14 +263,16 @@ _Tensor = torch.Tensor
 
 def _marshal(args):
     out = []
+    ap = out.append
     for a in args:
         if isinstance(a, _Tensor):
-            require_device(a)
+            if not a.is_cuda:                 # (one attribute read on the hot path; the refusal itself is require_device's)
+                require_device(a)
             if not a.is_contiguous():
                 raise ValueError("neuralsim_amd: tensor arguments must be contiguous")
-            out.append(a.data_ptr())
+            ap(a.data_ptr())
         else:
-            out.append(a)
+            ap(a)
     return out
 
 
