@@ -190,11 +190,11 @@ class BufferComposeRenderer(nn.Module):
             # ---- sort by depth inside every ray (reference :683-695)
             t_sorted, sort_idx = po.packed_sort(depths, total_pack_infos)
             total_volume_buffer = dict(type="packed", rays_inds_hit=total_rays_inds_hit, pack_infos_hit=total_pack_infos,
-                                       t=t_sorted, opacity_alpha=alphas[sort_idx])
+                                       t=t_sorted, opacity_alpha=po.permute_rows(alphas, sort_idx))
             if with_rgb:
-                total_volume_buffer["rgb"] = rgbs[sort_idx]
+                total_volume_buffer["rgb"] = po.permute_rows(rgbs, sort_idx)
             if with_normal:
-                total_volume_buffer["nablas"] = nabs[sort_idx]
+                total_volume_buffer["nablas"] = po.permute_rows(nabs, sort_idx)
             # ---- integrate (reference :697-718), one fused launch
             tvb = total_volume_buffer
             nab = tvb.get("nablas") if with_normal else None
@@ -207,7 +207,7 @@ class BufferComposeRenderer(nn.Module):
                 if k in out and k in total_rendered:
                     total_rendered[k] = total_rendered[k].index_put((total_rays_inds_hit,), out[k])
             # ---- every object's weights in the context of the whole scene (reference :720-727)
-            ranks = torch.sort(sort_idx).indices
+            ranks = po.inverse_permutation(sort_idx)
             for raw in raw_per_obj_model.values():
                 vb = raw["volume_buffer"]
                 if vb["type"] != "empty":
