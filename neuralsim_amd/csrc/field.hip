@@ -2334,8 +2334,13 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   static const int sdf_grid_env = getenv("NSIM_SDF_GRID") ? atoi(getenv("NSIM_SDF_GRID")) : 0;
   // ... and about five tiles per wave beyond that (1.39 M points of the street step: 2048 workgroups 0.094 ms, 512: 0.134 --
   // with more tiles per wave the static stride balances worse than the dispatcher's backfill of finished workgroups)
-  int64_t sdf_grid = sdf_grid_env > 0 ? sdf_grid_env : ((S + 31) / 32) / (FIELD_WAVES * 5);
-  if (sdf_grid_env <= 0) sdf_grid = sdf_grid < 512 ? 512 : (sdf_grid > 4096 ? 4096 : sdf_grid);
+  // (the 16-level kernel measures best at 512 for every launch size of the object step: 0.0463 ms avg against 0.0523 with
+  // the scaled grid; the scaling is the 17..32-level kernel's)
+  int64_t sdf_grid = sdf_grid_env > 0 ? sdf_grid_env : 512;
+  if (sdf_grid_env <= 0 && field_nc(meta->lotd.num_levels) == 2) {
+    sdf_grid = ((S + 31) / 32) / (FIELD_WAVES * 5);
+    sdf_grid = sdf_grid < 512 ? 512 : (sdf_grid > 4096 ? 4096 : sdf_grid);
+  }
   const dim3 grid(field_grid(S, sdf_grid)), block(64 * FIELD_WAVES);
   const size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
