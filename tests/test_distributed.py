@@ -159,6 +159,12 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None
                         appear=tr.appear.detach().clone(), grid0=p0),
                    str(Path(out_dir) / f"params_overlap{overlap}{wire}{algo or ''}{'' if model_kind == 'lotd' else model_kind}.pt"))
         assert out["n_gpus"] == world and out["steps"] == steps and out["value"] > 0 and out["scaling"] == "weak"
+        # the driver's contract: every key of the one JSON line (``roofline`` is None without HIP events)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in out, k
+        assert out["unit"] == "rays/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
+        assert out["metric"].startswith("training rays/sec") and "workload" in out["config"] and out["data"] == "synthetic"
         assert abs(out["value"] - 16 * world * steps / (out["ms_per_step"] * steps * 1e-3)) / out["value"] < 1e-2
     else:
         assert out is None
