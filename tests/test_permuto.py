@@ -311,15 +311,25 @@ def test_fused_step_equals_autograd_step_on_the_permuto_model(backend):
     from neuralsim_amd.trainer import RenderTrainer
     qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
               upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
+    def build():
+        return PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
+                                precision="fp16", ln_inv_s_init=0.3, seed=4,
+                                accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
+                                               update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
+                                ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed", query_param=qp)).to(backend)
+    # ONE pre-training run: its 20 Adam steps go through the float-atomic scatter, so two runs of it end at two different
+    # fields on hardware (the two legs started from different tables).  Both legs load the same snapshot.
+    torch.manual_seed(0)
+    m0 = build()
+    m0.geometric_init_sphere(0.5, num_iters=20, num_pts=1536, lr=5e-3)
+    snapshot = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+    del m0
     outs = []
     for fused in (False, True):
         torch.manual_seed(0)
-        m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
-                             precision="fp16", ln_inv_s_init=0.3, seed=4,
-                             accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
-                                            update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
-                             ray_query_cfg=dict(query_mode="march_occ_multi_upsample_compressed", query_param=qp)).to(backend)
-        m.geometric_init_sphere(0.5, num_iters=20, num_pts=1536, lr=5e-3)
+        m = build()
+        m.load_state_dict(snapshot)
+        assert torch.equal(m.encoding.shadow(), snapshot["encoding.flattened_params"].half())
         m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
         intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
         tr = RenderTrainer(m, intr, c2w, WH, num_rays=40, lr=2e-3, target_sphere_radius=0.5, fused_step=fused, num_uniform=24,
