@@ -264,6 +264,13 @@ int nsim_permuto_gather(const NsimPermutoMeta* meta, const void* grid_f16, const
 int nsim_permuto_scatter(const NsimPermutoMeta* meta, const float* x, const float* rays_o, const float* rays_d,
                          const float* t, const int64_t* ridx, const float* z, int64_t S, const float* dh_planes,
                          const float* g_planes, const float* gn, float* dgrid, void* stream);
+/* Backward to the CONDITION of a conditioned field (in_dim > 3; GenerativePermutoConcat's learned per-instance codes,
+ * app/models/shared/batched_neus.py:295-407 ``z_ins_all``): dz[ray][c] += sum over the ray's samples, levels and features of
+ * dL/dh . dh/dz_c (dz [R, in_dim - 3], caller-zeroed; z and ridx required).  The normals carry no z term: dh/dx is constant
+ * inside a simplex. */
+int nsim_permuto_dz(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                    const float* rays_d, const float* t, const int64_t* ridx, const float* z, int64_t S,
+                    const float* dh_planes, float* dz, void* stream);
 
 /* ------------------------------------------------------- fused NeuS field (LoTD + MLPs, MFMA) */
 /* Network description (host struct).  LoTDNeuSModel = LoTDSDF + RadianceNet
@@ -327,7 +334,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 /* Optional scratch for the weight-gradient flush of the backward launches (1) and (2) below.  Every workgroup of those
  * launches ends by adding its partial dW / db into the same few thousand floats; hundreds of same-address atomics per
  * address serialise in L2 (measured: ~55 us of a 100 us radiance backward).  With a caller-owned, ZEROED buffer of
- * ``floats`` floats registered for ``stream`` (>= 16 x 8448 covers every decoder shape), workgroup b adds into replica
+ * ``floats`` floats registered for (the calling thread's current device, ``stream``) (>= 16 x 8448 covers every decoder shape), workgroup b adds into replica
  * b % 16 of it and a small second launch folds the replicas into dW / db and zeroes the buffer again: the buffer is zero
  * whenever no launch of that stream is in flight.  buf = NULL unregisters.  Without a registration (or with
  * NSIM_GRAD_REPLICAS=1) the launches add into dW / db directly, as before.  The reference has no counterpart: its

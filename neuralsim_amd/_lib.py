@@ -113,6 +113,7 @@ SIGNATURES = {
     "nsim_permuto_bwd": [C.POINTER(PermutoMeta), _P, _I64, _P, _P],
     "nsim_permuto_gather": [C.POINTER(PermutoMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I, _P, _P],
     "nsim_permuto_scatter": [C.POINTER(PermutoMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
+    "nsim_permuto_dz": [C.POINTER(PermutoMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P],
     "nsim_field_bwd_rad": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_field_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_lotd_hess_dx": [C.POINTER(LotdMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],

@@ -2075,11 +2075,12 @@ static int field_meta_check_full(const NsimFieldMeta* m) {
 // zeroed scratch registered for the stream (nsim_set_grad_scratch), workgroup b flushes into replica b % R instead and a
 // small second launch folds the R copies into the caller's gradient buffers (and zeroes the scratch again).
 struct GradScratch {
+  int device;      // the registry is keyed by (device, stream): the default stream has handle 0 on EVERY device of a process
   void* stream;
   float* buf;
   int64_t floats;
 };
-static GradScratch g_grad_scratch[16];
+static GradScratch g_grad_scratch[64];
 static int g_grad_scratch_n = 0;
 
 __global__ void __launch_bounds__(256) k_rep_reduce(float* __restrict__ sc, int R, int64_t stride, int64_t n_w,
@@ -2114,11 +2115,19 @@ static int grad_replicas() {
 }
 
 // the registered scratch of ``stream`` if it holds R x n floats, else NULL (= flush into the caller's buffers directly)
+static int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  return d;
+}
+
 static float* grad_scratch(void* stream, int64_t n, int& R) {
   R = grad_replicas();
   if (R <= 1) return nullptr;
+  const int dev = current_device();
   for (int i = 0; i < g_grad_scratch_n; ++i)
-    if (g_grad_scratch[i].stream == stream && g_grad_scratch[i].buf && g_grad_scratch[i].floats >= (int64_t)R * n)
+    if (g_grad_scratch[i].device == dev && g_grad_scratch[i].stream == stream && g_grad_scratch[i].buf &&
+        g_grad_scratch[i].floats >= (int64_t)R * n)
       return g_grad_scratch[i].buf;
   return nullptr;
 }
@@ -2435,14 +2444,16 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 }
 
 int nsim_set_grad_scratch(float* buf, int64_t floats, void* stream) {
+  const int dev = current_device();
   for (int i = 0; i < g_grad_scratch_n; ++i)
-    if (g_grad_scratch[i].stream == stream) {
+    if (g_grad_scratch[i].device == dev && g_grad_scratch[i].stream == stream) {
       g_grad_scratch[i].buf = buf;
       g_grad_scratch[i].floats = buf ? floats : 0;
       return 0;
     }
   if (!buf) return 0;
-  if (g_grad_scratch_n >= 16) return 34;
+  if (g_grad_scratch_n >= 64) return 34;
+  g_grad_scratch[g_grad_scratch_n].device = dev;
   g_grad_scratch[g_grad_scratch_n].stream = stream;
   g_grad_scratch[g_grad_scratch_n].buf = buf;
   g_grad_scratch[g_grad_scratch_n++].floats = floats;

@@ -34,7 +34,7 @@ const char* nsim_strerror(int code) {
     case 42: return "permuto num_levels must be 1..32";
     case 43: return "permuto n_feats must be 2";
     case 44: return "permuto hashmap_size must be a power of two";
-    case 34: return "too many streams with a registered gradient scratch (16)";
+    case 34: return "too many (device, stream) pairs with a registered gradient scratch (64)";
     case 22: return "sdf_D must be 1 or 2";
     case 23: return "precision must be 0 (fp16 MFMA) or 1 (f32 MFMA)";
     case 24: return "need either x or (rays_o, rays_d, t, ridx)";

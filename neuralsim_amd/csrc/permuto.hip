@@ -62,8 +62,9 @@ struct Simplex {
 };
 
 // elevated E_0 = sum_j cf_j, E_i = sum_{j > i} cf_j - i cf_i (1-based j; cf_j = (x_{j-1} + shift) * scale), nearest
-// remainder-0 point, ranks, barycentric weights.  WD: also dB[r][c] = d bary[r] / d x_c for the first NS inputs.
-template <int D, int NS, bool WD>
+// remainder-0 point, ranks, barycentric weights.  WD: also dB[r][c] = d bary[r] / d x_{C0 + c} for NS inputs from C0 on
+// (C0 = 0: the spatial inputs; C0 = 3: the condition's, for d L / d z).
+template <int D, int NS, bool WD, int C0 = 0>
 __device__ __forceinline__ void permuto_simplex(const float (&x)[D], const float* scale, const float* shift, Simplex<D>& sp,
                                                 float (&dB)[D + 1][NS]) {
   // The elevation runs in f64 (full-rate VALU on CDNA): with the per-level random shifts (up to 10) the finest levels work
@@ -144,8 +145,9 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[D], const float
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
         // d E_i / d x_c  (c 0-based; j = c + 1):  E_0: scale_c;  E_i: [j > i] scale_c - [i == j] i scale_c
-        const int jj = c + 1;
-        const float dE = (i == 0 ? scale[c] : ((jj > i ? scale[c] : 0.f) - (i == jj ? (float)i * scale[c] : 0.f))) *
+        const int jj = C0 + c + 1;
+        const float sc_ = scale[C0 + c];
+        const float dE = (i == 0 ? sc_ : ((jj > i ? sc_ : 0.f) - (i == jj ? (float)i * sc_ : 0.f))) *
                          (1.0f / (float)(D + 1));
 #pragma unroll
         for (int r = 0; r <= D; ++r) dB[r][c] = dB[r][c] + (r == kp ? dE : 0.f) - (r == rm ? dE : 0.f);
@@ -390,6 +392,62 @@ __global__ void __launch_bounds__(256) k_permuto_bwd(PermutoArgs a) {
   }
 }
 
+// d L / d z of the conditioned field (GenerativePermutoConcat: z is LEARNED -- the auto-decoder's per-instance codes,
+// app/models/shared/batched_neus.py:295-407): dz[ray][c] += sum_levels sum_f dL/dh[l][s][f] . d h[l][f] / d z_c, with
+// d h / d z_c = sum_r (d bary_r / d z_c) table[v_r].  The second-order term has no z part: d h / d x (spatial) is a sum of
+// table values times CONSTANTS inside a simplex, so the normals do not move with z.  Consecutive lanes are consecutive
+// samples of a ray: the run total per (ray, c) is formed in the wave, one atomic per run.
+template <int D>
+__global__ void __launch_bounds__(256) k_permuto_dz(PermutoArgs a, float* __restrict__ dz) {
+  constexpr int NZ = D - 3;
+  const int lane = nsim_lane();
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y;
+  const bool valid = s < a.S;
+  float x[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) x[i] = 0.f;
+  if (valid) permuto_point<D, true>(a, s, x);
+  Simplex<D> sp;
+  float dB[D + 1][NZ];
+  permuto_simplex<D, NZ, true, 3>(x, a.pm.scale[l], a.pm.shift[l], sp, dB);
+  float d0 = 0.f, d1 = 0.f;
+  int64_t ray = -1 - lane;
+  if (valid) {
+    const float* dp = a.dh_pl + ((int64_t)l * a.S + s) * 2;
+    d0 = dp[0];
+    d1 = dp[1];
+    ray = a.ridx ? a.ridx[s] : 0;
+  }
+  float acc[NZ];
+#pragma unroll
+  for (int c = 0; c < NZ; ++c) acc[c] = 0.f;
+  const int64_t base = (int64_t)l * a.pm.T * 2;
+#pragma unroll
+  for (int r = 0; r <= D; ++r) {
+    float g0 = 0.f, g1 = 0.f;
+    if (valid) permuto_load2(a.grid, base, permuto_vertex<D>(sp, r, a.pm.T), g0, g1);
+    const float w = d0 * g0 + d1 * g1;
+#pragma unroll
+    for (int c = 0; c < NZ; ++c) acc[c] = acc[c] + dB[r][c] * w;
+  }
+  const int64_t pk = wave_shfl(ray, lane - 1);
+  const unsigned long long heads = wave_ballot(lane == 0 || pk != ray);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+  for (int c = 0; c < NZ; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const float o = wave_shfl(v, lane - dd);
+      if (lane - dd >= run_start) v = v + o;
+    }
+    const bool emit = valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
+    if (emit && v != 0.f) atomicAdd(dz + (int64_t)NZ * ray + c, v);
+  }
+}
+
 // ================================================================================== C ABI
 template <int MODE>
 static int permuto_launch_fwd(const NsimPermutoMeta* meta, const PermutoArgs& a, hipStream_t stream) {
@@ -497,6 +555,36 @@ int nsim_permuto_scatter(const NsimPermutoMeta* meta, const float* x, const floa
   a.S = S;
   a.dh_pl = dh_planes; a.g_pl = g_planes; a.gn = gn; a.dgrid = dgrid;
   return permuto_launch_bwd<true>(meta, a, (hipStream_t)stream);
+}
+
+int nsim_permuto_dz(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
+                    const float* rays_d, const float* t, const int64_t* ridx, const float* z, int64_t S,
+                    const float* dh_planes, float* dz, void* stream) {
+  const int rc = permuto_meta_check(meta);
+  if (rc) return rc;
+  if (meta->in_dim < 4) return 41;            // no condition inputs
+  if (S <= 0) return 0;
+  if (!grid_f16 || !dh_planes || !dz) return 28;
+  if (!x && !(rays_o && rays_d && t && ridx)) return 24;
+  if (!z || !ridx) return 29;
+  PermutoArgs a = PermutoArgs();
+  a.pm = permuto_dev(meta);
+  a.grid = (const f16*)grid_f16;
+  a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx; a.z = z;
+  a.S = S;
+  a.dh_pl = dh_planes;
+  const dim3 grid((unsigned)nsim_blocks(S, 256), (unsigned)meta->num_levels), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (meta->in_dim) {
+    case 4: hipLaunchKernelGGL((k_permuto_dz<4>), grid, block, 0, st, a, dz); break;
+    case 5: hipLaunchKernelGGL((k_permuto_dz<5>), grid, block, 0, st, a, dz); break;
+    case 6: hipLaunchKernelGGL((k_permuto_dz<6>), grid, block, 0, st, a, dz); break;
+    case 7: hipLaunchKernelGGL((k_permuto_dz<7>), grid, block, 0, st, a, dz); break;
+    case 8: hipLaunchKernelGGL((k_permuto_dz<8>), grid, block, 0, st, a, dz); break;
+    default: return 41;
+  }
+  NSIM_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

@@ -51,7 +51,7 @@ def shard_range(n_total: int, rank: int, world: int):
 
 
 def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_numel: int = 1 << 20,
-                    wire_dtype: Optional[torch.dtype] = None):
+                    wire_dtype: Optional[torch.dtype] = None, skip_absent: bool = False):
     """Sum (or average) ``p.grad`` over ranks: big tensors on their own (asynchronously), everything else through
     one flat f32 bucket.  Parameters whose grad is None on this rank (e.g. no ray hit) contribute zeros.
 
@@ -60,9 +60,23 @@ def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True, small_
     all-reduces 2-byte gradients as well (code_single/tools/train.py:1401-1412); bf16 keeps the f32 exponent range, so
     no loss scale is needed.  xGMI links are per-link bound: halving the bytes halves the exposed time of the one
     collective of the step.  A 2-byte wire uses the ``direct`` schedule (``_DirectToken``: one rounding per
-    contribution, f32 accumulation) instead of the backend's ring all-reduce, which accumulates in the wire type."""
+    contribution, f32 accumulation) instead of the backend's ring all-reduce, which accumulates in the wire type.
+
+    ``skip_absent``: parameters whose grad is None on EVERY rank stay without a gradient (one extra MAX-all-reduce of a
+    presence vector decides it identically on all ranks) -- the optimizer then skips them, as ``torch.optim.Adam`` skips a
+    None grad; zero-filling them instead would give them a momentum-only update that a single-GPU run does not make
+    (the lidar step: no radiance / appearance / sky gradients on any rank)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
+    params = list(params)
+    if skip_absent and params:
+        ref = next((p for p in params if p.grad is not None), params[0])
+        present = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=ref.device)
+        dist.all_reduce(present, op=dist.ReduceOp.MAX)
+        keep = present.cpu().tolist()
+        params = [p for p, k in zip(params, keep) if k > 0.5]
+        if not params:
+            return
     if wire_dtype is None:
         wire_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp16": torch.float16}[
             os.environ.get("NSIM_ALLREDUCE_DTYPE", "bf16")]
@@ -153,9 +167,29 @@ def _direct_ok(device) -> bool:
         _DIRECT_OK[key] = True
         return True
     ok = True
+    # (1) everything a single rank can fail at on its own -- allocation, dtype support, a missing all_to_all_single --
+    # is tried WITHOUT a collective and agreed on (MIN) before any rank enters the exchange: a rank that raised alone
+    # inside the exchange would leave its peers waiting in all_to_all.  (2) the exchange itself runs the same
+    # code on the same shapes on every rank; what is left to diverge there is the transport, and that is the watchdog's
+    # (NCCL_ASYNC_ERROR_HANDLING / the process group's timeout) to report.
     try:
         g = torch.Generator().manual_seed(1234 + dist.get_rank())
         x = torch.randn(1000, generator=g).to(device)
+        W_ = dist.get_world_size()
+        _probe = torch.zeros([W_ * ((1000 + W_ - 1) // W_)], dtype=torch.bfloat16, device=device)
+        _probe[:1000] = x
+        pre = callable(getattr(dist, "all_to_all_single", None)) and callable(getattr(dist, "all_gather_into_tensor", None))
+    except Exception as e:      # noqa: BLE001
+        print(f"[neuralsim_amd.distributed] direct all-reduce precondition raised {type(e).__name__}: {e}", flush=True)
+        pre = False
+    flag0 = torch.tensor([1.0 if pre else 0.0], device=device)
+    dist.all_reduce(flag0, op=dist.ReduceOp.MIN)
+    if flag0.item() < 0.5:
+        print("[neuralsim_amd.distributed] direct all-reduce unavailable on some rank: using the backend's ring all-reduce",
+              flush=True)
+        _DIRECT_OK[key] = False
+        return False
+    try:
         ref = x.clone()
         dist.all_reduce(ref)
         y = x.clone()

@@ -83,6 +83,7 @@ class _DistantFn(torch.autograd.Function):
             _lib.TIMER.note_units("nsim_distant_bwd", S)
             _lib.TIMER.note_units("nsim_lotd4_scatter", S)
         ctx.model, ctx.S, ctx.K = model, S, K
+        ctx.set_materialize_grads(False)       # an unused output arrives as None (not zeros): see backward
         ctx.holder = holder        # a plain dict of the caller's (no tensor of this node inside: no reference cycle)
         # save_for_backward, not a ctx attribute: sigma / rgb are OUTPUTS (output -> grad_fn -> ctx -> output would be a
         # reference cycle that only the cyclic collector frees: 80 MB per step at 8192 rays x 64 shells)
@@ -105,6 +106,8 @@ class _DistantFn(torch.autograd.Function):
         dh_pl = torch.empty([16, ctx.S, 2], dtype=torch.float32, device=dev) if dgrid is not None else None
         gs = g_sigma.float().contiguous() if g_sigma is not None else None
         gr = g_rgb.float().contiguous() if g_rgb is not None else None
+        if gs is None and gr is None:
+            return (None,) * 12
         keep = ctx.holder.get("keep") if ctx.holder is not None else None
         if keep is not None:
             valid = valid & keep.reshape(-1)
@@ -115,6 +118,9 @@ class _DistantFn(torch.autograd.Function):
         if dgrid is not None:
             _lib.call("nsim_lotd4_scatter", model.cfg.meta, _lib.ptr(u4), _lib.ptr(valid), ctx.S, _lib.ptr(dh_pl),
                       _lib.ptr(dgrid))
+        if gr is None:      # the colour output has no consumer (a lidar render, with_rgb=False): the radiance branch was not
+            # differentiated -- no gradient rather than a zero one, as autograd reports an unused sub-network
+            return (None, dgrid, dden_w, dden_b, None, None, None, None, None, None, None, None)
         return (None, dgrid, dden_w, dden_b, model._contract_rad_w(drad_w), drad_b, dha, None, None, None, None, None)
 
 

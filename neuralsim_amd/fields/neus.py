@@ -229,6 +229,8 @@ class _FieldFn(torch.autograd.Function):
             dsdf_b[-1:] /= model.sdf_scale
         if dha is not None and M > 0:
             dha = dha[:dha.shape[0] - M]
+        if gr is None:      # no consumer of the colour (with_rgb=False: lidar renders): the radiance network is not part of
+            drad_w = drad_b = dha = None        # the graph -- None, not zeros, so that optimizers skip it as torch's do
         return (None, dgrid, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_x, d_o, d_d, None, None, None, None, None, None)
 
 

@@ -71,6 +71,27 @@ class _PermutoFieldEncoding(nn.Module):
         return self.params16
 
 
+class _ZTapFn(torch.autograd.Function):
+    """Delivers d L / d z to autograd.  The condition is not an input of ``_FieldFn`` (it rides along ``ridx`` inside the
+    kernels); instead the TABLE handed to ``_FieldFn`` passes through this node together with z.  In the backward,
+    ``_FieldFn.backward`` runs first (it is downstream), its ``_enc_scatter`` hook leaves d L / d z of its samples in
+    ``model._dz_acc``; this node then runs, forwards the table gradient untouched and hands out what has accumulated for
+    its z (any split of the sum over several queries of one condition is a valid split of z.grad)."""
+
+    @staticmethod
+    def forward(ctx, table, z, model):
+        ctx.model, ctx.key, ctx.z_shape = model, id(z), z.shape
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g_table):
+        dz = ctx.model._dz_acc.pop(ctx.key, None)
+        if dz is not None:
+            zs = ctx.z_shape
+            dz = dz.sum(0, keepdim=True).reshape(zs) if (len(zs) == 1 or zs[0] == 1) and dz.shape[0] != 1 else dz.reshape(zs)
+        return g_table, dz, None
+
+
 class PermutoNeuSModel(LoTDNeuSModel):
     """``PermutoNeuSObj(surface_cfg{encoding_cfg{permuto_auto_compute_cfg{...}}, decoder_cfg{D, W: 64}}, radiance_cfg, ...)``.
     ``z_dim`` > 0: ``set_condition(z)`` with z [R_or_1, z_dim] makes every ray (or all of them) carry a latent that is
@@ -116,16 +137,33 @@ class PermutoNeuSModel(LoTDNeuSModel):
         self._sdf_fused = False
         self.geo_init_method = "pretrain"
         self._z_rays = None
+        self._z_src = None          # the caller's z when it requires grad (learned codes): see _ZTapFn
+        self._dz_acc = {}
         if device is not None:
             self.to(device)
 
     # ---------------------------------------------------------------- condition (GenerativePermutoConcat)
     def set_condition(self, z: Optional[torch.Tensor]):
-        """z [R, z_dim] per ray of the next queries, [1, z_dim] / [z_dim] for all of them, None = zeros."""
+        """z [R, z_dim] per ray of the next queries, [1, z_dim] / [z_dim] for all of them, None = zeros.
+        A z that requires grad (the auto-decoder's learned codes, ``z_ins_all`` of AD_GenerativePermutoConcatNeuSObj)
+        receives d L / d z from every with-grad query made under this condition (``nsim_permuto_dz``); the condition must
+        still be set when ``backward`` runs (the kernels re-read z there, as they re-read the rays)."""
+        self._z_src = None
         if z is not None:
             assert self.z_dim > 0 and z.shape[-1] == self.z_dim
+            if z.requires_grad:
+                self._z_src = z
             z = z.detach().float().reshape(-1, self.z_dim).contiguous()
         self._z_rays = z
+
+    def clean_condition(self):
+        self.set_condition(None)
+
+    def _table(self):
+        p = self.encoding.flattened_params
+        if self._z_src is not None and torch.is_grad_enabled():
+            return _ZTapFn.apply(p, self._z_src, self)
+        return p
 
     def _z_for(self, ridx, rays_o, S: int, dev):
         """-> (z [R, z_dim] or None, ridx or a zero index for the point mode with a shared condition)"""
@@ -164,6 +202,15 @@ class PermutoNeuSModel(LoTDNeuSModel):
         _lib.call("nsim_permuto_scatter", self.encoding.cfg.pmeta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(gn_total),
                   _lib.ptr(dgrid))
+        if z is not None and self._z_src is not None:         # learned condition: d L / d z of these samples
+            dz = torch.zeros_like(z)
+            _lib.call("nsim_permuto_dz", self.encoding.cfg.pmeta, _lib.ptr(self.encoding.shadow()), _lib.ptr(x), _lib.ptr(rays_o),
+                      _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(dz))
+            k = id(self._z_src)
+            prev = self._dz_acc.get(k)
+            if prev is not None and prev.shape != dz.shape:          # a shared [1, z_dim] condition seen through two ray counts
+                prev, dz = prev.sum(0, keepdim=True), dz.sum(0, keepdim=True)
+            self._dz_acc[k] = dz if prev is None else prev + dz
 
     def _enc_hess_dx(self, grid16, x, rays_o, rays_d, t, ridx, goff, S, g_pl, gn_total, dx):
         return      # barycentric weights are piecewise LINEAR in x: no second derivative inside a simplex

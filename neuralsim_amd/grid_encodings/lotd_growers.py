@@ -52,7 +52,8 @@ def dense_level_vertices(lod_res: Sequence[int]) -> torch.Tensor:
 
 
 class FMMLinear(nn.Module):
-    """y_b = (W o M(z_b)) x_b + bias,  M(z) = U(z) V(z)^T / sqrt(rank)  -- one modulated weight matrix per instance."""
+    """y_b = (W o M(z_b)) x_b + bias,  M(z) = U(z) V(z)^T, U / V affine in z with biases rank^-1/2: M(0) = 1 exactly -- one
+    modulated weight matrix per instance; at z = 0 the layer IS the plain linear layer ``weight``."""
 
     def __init__(self, in_f: int, out_f: int, z_dim: int, rank: int, gen: torch.Generator):
         super().__init__()
@@ -60,11 +61,12 @@ class FMMLinear(nn.Module):
         self.weight = nn.Parameter((torch.rand(out_f, in_f, generator=gen) * 2 - 1) * bound)
         self.bias = nn.Parameter((torch.rand(out_f, generator=gen) * 2 - 1) * bound)
         zb = 1.0 / math.sqrt(z_dim)
-        # U(0) V(0)^T = all-ones / sqrt(rank) * rank ... the biases start the modulation at exactly 1 for z = 0
+        # U(0) V(0)^T = sum_r rank^-1/2 rank^-1/2 = 1: the biases start the modulation at exactly 1 for z = 0 (with
+        # rank^-1/4 -- round 3 -- every layer started sqrt(rank) too large: ~1000 x over six layers)
         self.u_w = nn.Parameter((torch.rand(out_f * rank, z_dim, generator=gen) * 2 - 1) * zb * 0.3)
         self.v_w = nn.Parameter((torch.rand(in_f * rank, z_dim, generator=gen) * 2 - 1) * zb * 0.3)
-        self.u_b = nn.Parameter(torch.full([out_f * rank], rank ** -0.25))
-        self.v_b = nn.Parameter(torch.full([in_f * rank], rank ** -0.25))
+        self.u_b = nn.Parameter(torch.full([out_f * rank], rank ** -0.5))
+        self.v_b = nn.Parameter(torch.full([in_f * rank], rank ** -0.5))
         self.in_f, self.out_f, self.rank = in_f, out_f, rank
 
     def effective_weight(self, z: torch.Tensor) -> torch.Tensor:

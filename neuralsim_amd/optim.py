@@ -26,8 +26,12 @@ class FusedAdam:
         for g in self.groups:
             g["m"] = torch.zeros_like(g["p"], dtype=torch.float32)
             g["v"] = torch.zeros_like(g["p"], dtype=torch.float32)
-        self.t = 0
         self._dirty = [model]
+
+    @property
+    def t(self) -> int:
+        """The largest per-group step count (what a single global counter used to be; logging / tests read it)."""
+        return max((g.get("t", 0) for g in self.groups), default=0)
 
     def add_model(self, model, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), learn_inv_s=True):
         """Parameters of a further NeuS model (a shared batched foreground model next to the background, code_multi)."""
@@ -65,14 +69,21 @@ class FusedAdam:
     @torch.no_grad()
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0, skip=()):
         """``skip``: parameters the caller updates itself in this iteration through ``step_range`` (AFTER this call:
-        the step counter of the bias corrections advances here)."""
-        self.t += 1
+        the step counter of their bias corrections advances here).
+        Every group keeps its OWN step count, advanced only when the group is updated -- ``torch.optim.Adam`` keeps
+        ``state['step']`` per parameter and skips parameters whose ``.grad`` is None (the reference's second backward +
+        optimizer step of an iteration, the lidar step, leaves the radiance / appearance / sky parameters without a
+        gradient: code_single/tools/train.py:1540-1590)."""
         lr = self.lr if lr is None else lr
         small = []
         for g in self.groups:
             p = g["p"]
-            if p.grad is None or any(p is q for q in skip):
+            if any(p is q for q in skip):
+                g["t"] = g.get("t", 0) + 1
                 continue
+            if p.grad is None:
+                continue
+            t = g["t"] = g.get("t", 0) + 1
             b1, b2 = g["betas"]
             p16 = g["p16"]() if g["p16"] is not None else None
             if p.numel() < (1 << 18) and p16 is None:     # batched below: one launch for all of them
@@ -80,14 +91,14 @@ class FusedAdam:
                 continue
             _lib.call("nsim_adam_step", _lib.ptr(p.data), _lib.ptr(p16), _lib.ptr(p.grad.contiguous()), _lib.ptr(g["m"]),
                       _lib.ptr(g["v"]), p.numel(), float(lr), float(b1), float(b2), float(self.eps),
-                      1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(grad_scale), 0)
+                      1.0 - b1 ** t, 1.0 - b2 ** t, float(grad_scale), 0)
         for k in range(0, len(small), _lib.ADAM_MULTI_MAX):
             chunk = small[k:k + _lib.ADAM_MULTI_MAX]
             arr = (_lib.AdamTensor * len(chunk))()
             for i, (g, grad) in enumerate(chunk):
                 b1, b2 = g["betas"]
                 arr[i] = _lib.AdamTensor(g["p"].data_ptr(), None, grad.data_ptr(), g["m"].data_ptr(), g["v"].data_ptr(),
-                                         g["p"].numel(), b1, b2, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0)
+                                         g["p"].numel(), b1, b2, 1.0 - b1 ** g["t"], 1.0 - b2 ** g["t"], 1.0)
             _lib.call("nsim_adam_multi", arr, len(chunk), float(lr), float(self.eps), float(grad_scale), 0)
         for m in self._dirty:
             m._wpack_versions = None           # MLP weights changed in place: re-pack the MFMA fragments lazily
@@ -101,10 +112,11 @@ class FusedAdam:
         lr = self.lr if lr is None else lr
         g = next(g for g in self.groups if g["p"] is p)
         b1, b2 = g["betas"]
+        t = max(int(g.get("t", 0)), 1)
         p16 = g["p16"]() if g["p16"] is not None else None
         _lib.call("nsim_adam_step", _lib.ptr(p.data.view(-1)[lo:hi]), _lib.ptr(p16.view(-1)[lo:hi] if p16 is not None else None),
                   _lib.ptr(grad.contiguous()), _lib.ptr(g["m"].view(-1)[lo:hi]), _lib.ptr(g["v"].view(-1)[lo:hi]), hi - lo,
-                  float(lr), float(b1), float(b2), float(self.eps), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                  float(lr), float(b1), float(b2), float(self.eps), 1.0 - b1 ** t, 1.0 - b2 ** t,
                   float(grad_scale), 0)
 
     def zero_grad(self):

@@ -551,18 +551,41 @@ class RenderTrainer:
         return sum(parts.values()), parts
 
     def train_step_lidar(self, it: int) -> torch.Tensor:
+        """The iteration's second render + backward + optimizer step (code_single/tools/train.py:860-960, 1540-1590):
+        lidar beams rendered with ``with_rgb=False, with_normal=(eikonal loss configured)`` (:899-904), losses = lidar depth
+        + line of sight (``lidar_losses``) + the eikonal term in mode 'lidar' -- on the render samples with weight
+        ``w_eikonal * on_render_ratio`` (app/loss/eikonal.py:233-250; ``lidar['on_render_ratio']``, default 1) and on
+        ``lidar['num_uniform']`` uniform points (:199-208, default 0).  Parameters outside this graph (radiance, appearance,
+        sky) have no gradient on ANY rank: they are neither reduced nor stepped (``skip_absent``; FusedAdam keeps per-group
+        step counts), as torch's Adam under the reference's DDP leaves them alone."""
+        L = self.lidar
         o, d, ranges = self.sample_lidar_batch()
-        ret = self.renderer.render(self.model, rays=[o, d], rays_h_appear=None, with_rgb=False, with_normal=False,
-                                   return_buffer=True, return_details=False, distant_model=self.distant_model,
-                                   sky_model=None, near=float(self.lidar.get("near", self.near or 0.0)),
-                                   far=float(self.lidar.get("far", self.far)) if (self.lidar.get("far", self.far) is not None) else None)
+        w_eik = float(L.get("w_eikonal", self.w_eikonal))
+        with_normal = w_eik > 0.0
+        ret = self.renderer.render(self.model, rays=[o, d], rays_h_appear=None, with_rgb=False, with_normal=with_normal,
+                                   return_buffer=True, return_details=with_normal, distant_model=self.distant_model,
+                                   sky_model=None, near=float(L.get("near", self.near or 0.0)),
+                                   far=float(L.get("far", self.far)) if (L.get("far", self.far) is not None) else None)
         loss, parts = self.lidar_losses(ret, ranges)
+        if with_normal:
+            cr_vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
+            r_ratio = float(L.get("on_render_ratio", 1.0))
+            if cr_vb["type"] != "empty" and r_ratio > 0.0 and "nablas" in cr_vb:
+                parts["eikonal_render"] = w_eik * r_ratio * eikonal_loss(cr_vb["nablas"])
+                loss = loss + parts["eikonal_render"]
+            n_uni = int(L.get("num_uniform", 0))
+            if n_uni > 0:
+                uni = self.model.sample_pts_uniform(n_uni, generator=self.gen)
+                parts["eikonal_uniform"] = w_eik * eikonal_loss(uni["nablas"])
+                loss = loss + parts["eikonal_uniform"]
         self.optim.zero_grad()
-        loss.backward()
+        if loss.requires_grad:          # no beam hit anything and no distant model: nothing to differentiate on this rank
+            loss.backward()
         if not self.skip_allreduce:
-            ndist.allreduce_grads(self.optim.params(), average=False)
+            ndist.allreduce_grads(self.optim.params(), average=False, skip_absent=True)
         self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
         self.stats["lidar_samples"] = int(ret["volume_buffer"]["t"].shape[0]) if ret["volume_buffer"]["type"] != "empty" else 0
+        self._lidar_parts = {k: float(v.detach()) for k, v in parts.items()}
         return loss.detach()
 
     def train_step(self, it: int) -> torch.Tensor:

@@ -11,7 +11,11 @@ def sorted_ckpts(checkpoint_dir: str) -> List[str]:
     if not os.path.isdir(checkpoint_dir):
         return []
     f = [x for x in os.listdir(checkpoint_dir) if x.endswith(".pt")]
-    key = lambda n: (n.startswith("latest"), n.startswith("final"), n)       # noqa: E731
+    # numbered checkpoints, then ``latest.pt`` (rewritten every ``i_save`` seconds DURING training), then ``final_*.pt``
+    # (written once, after the last iteration -- train.py:1684): ``sorted_ckpts(d)[-1]`` of a finished run is its final
+    # state, of an interrupted run the most recent ``latest.pt`` (render.py:59, extract_mesh.py:38 and the resume path
+    # all take ``[-1]``)
+    key = lambda n: (n.startswith("final"), n.startswith("latest"), n)       # noqa: E731
     return [os.path.join(checkpoint_dir, x) for x in sorted(f, key=key)]
 
 

@@ -41,6 +41,7 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);

@@ -257,6 +257,8 @@ def test_grower_at_the_config_sizes():
     z[1, 3] = 1.0
     t = g(z)
     assert t.shape == (2, 48380) and bool(torch.isfinite(t).all()) and float((t[0] - t[1]).abs().max()) > 0
-    # z = 0: the modulation is the constant rank * (rank^-1/4)^2 = sqrt(rank) on every weight
-    W0 = g.layers[0].effective_weight(torch.zeros(1, 128))[0]
-    assert torch.allclose(W0, g.layers[0].weight * (10 ** 0.5), rtol=1e-5)
+    # z = 0: the modulation is exactly 1 on every weight of every layer (biases rank^-1/2: sum_r u_r v_r = 1) -- the grown
+    # table of the zero code is the plain MLP's output, not sqrt(rank)^6 times it
+    for lay in g.layers:
+        assert torch.allclose(lay.effective_weight(torch.zeros(1, 128))[0], lay.weight, rtol=1e-5, atol=1e-7)
+    assert float(t[0].abs().max()) < 1.0

@@ -113,14 +113,16 @@ def test_permuto_neus_field_matches_oracle(backend, precision, z_dim, sdf_D, n_l
     h_appear = torch.randn(R, 4, generator=g) * 0.5
     x = rays_o[ridx] + t[:, None] * rays_d[ridx]
     dv = lambda a: a.to(backend).contiguous()
-    if z_dim:
+    z_o = z_d = None
+    if z_dim:      # a LEARNED condition (the auto-decoder's codes): d L / d z comes back through ``model._table()``
         z = torch.randn(R, z_dim, generator=g) * 0.3
-        model.set_condition(dv(z))
-        p.z = z[ridx]
+        z_o, z_d = leaf(z), leaf(z, backend)
+        model.set_condition(z_d)
+        p.z = z_o[ridx]
     ha_o = leaf(h_appear)
     sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
     ha_d = leaf(h_appear, backend)
-    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+    sdf, nab, rgb = _FieldFn.apply(model, model._table(), model.sdf_w, model.sdf_b, model.rad_w,
                                    model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
     tol = dict(f32=(3e-5, 3e-4, 3e-5, 3e-4), fp16=(4e-3, 5e-2, 4e-3, 3e-2))[precision]
     assert (sdf.cpu() - sdf_r).abs().max() < tol[0] * (1 + sdf_r.abs().max())
@@ -138,6 +140,24 @@ def test_permuto_neus_field_matches_oracle(backend, precision, z_dim, sdf_D, n_l
         e = rel_l2(v.cpu(), ref[k])
         assert e < tol[3], (k, e)
     assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < tol[3]
+    if z_dim:
+        assert z_d.grad is not None and z_d.grad.shape == (R, z_dim) and not model._dz_acc
+        assert rel_l2(z_d.grad.cpu(), z_o.grad) < tol[3], rel_l2(z_d.grad.cpu(), z_o.grad)
+        # one code shared by all rays ([1, z_dim]) through the point-mode query: the gradient is the sum over the points
+        z1_o, z1_d = leaf(z[:1]), leaf(z[:1], backend)
+        model.set_condition(z1_d)
+        p.z = z1_o.expand(S, z_dim)
+        xs = x.detach().clone()
+        sdf_r, nab_r, _ = ofield.forward_field(xs, rays_d[ridx], ha_o.detach()[ridx], p)
+        out = model.forward_sdf_nablas(dv(xs))
+        (sdf_r * ws).sum().add((nab_r * wn).sum()).backward()
+        (out["sdf"] * dv(ws)).sum().add((out["nablas"] * dv(wn)).sum()).backward()
+        assert z1_d.grad.shape == (1, z_dim) and rel_l2(z1_d.grad.cpu(), z1_o.grad) < tol[3]
+        # a condition that does not require grad costs nothing and leaves nothing behind
+        model.set_condition(dv(z))
+        assert model._table() is model.encoding.flattened_params
+        model.clean_condition()
+        assert model._z_rays is None
 
 
 def test_permuto_neus_pretrains_to_a_sphere_and_renders(backend):

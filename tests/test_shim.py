@@ -102,3 +102,23 @@ def test_lotd_model_can_run_the_reference_pretraining_procedure(backend):
     err = (m.query_sdf(x).cpu() - (x.cpu().norm(dim=-1) - 0.5)).abs().mean()
     assert float(err) < 0.08, float(err)
     assert 0.0 < m.accel.frac_occupied() < 1.0
+
+
+def test_sorted_ckpts_puts_the_final_state_last(tmp_path):
+    """``sorted_ckpts(dir)[-1]`` is what render.py:59 / extract_mesh.py:38 / the resume path load: numbered < latest < final
+    (``latest.pt`` is only rewritten every ``i_save`` seconds, ``final_*.pt`` once after the last iteration, train.py:1684)."""
+    import os
+    from nr3d_lib.checkpoint import CheckpointIO, sorted_ckpts
+    lin = torch.nn.Linear(2, 2)
+    io = CheckpointIO(checkpoint_dir=str(tmp_path))
+    io.register_modules(net=lin)
+    for name, it in (("00000100.pt", 100), ("latest.pt", 150), ("00000200.pt", 200), ("final_00000250.pt", 250)):
+        with torch.no_grad():
+            lin.weight.fill_(float(it))
+        io.save(filename=name, global_step=it)
+    names = [os.path.basename(p) for p in sorted_ckpts(str(tmp_path))]
+    assert names == ["00000100.pt", "00000200.pt", "latest.pt", "final_00000250.pt"]
+    assert io.load_file(None)["global_step"] == 250 and float(lin.weight[0, 0]) == 250.0
+    os.remove(tmp_path / "final_00000250.pt")           # an interrupted run: the most recent latest.pt wins
+    assert io.load_file(None)["global_step"] == 150
+    assert sorted_ckpts(str(tmp_path / "missing")) == []

@@ -203,3 +203,46 @@ def test_model_built_from_reference_model_params_trains(backend):
     assert active[0] == 3 and active[-1] == 0                    # hardmask: levels 0..2 at it 0, all from stop_it on
     assert refreshes == [True, True]                             # it = 2 and 4, each once, with the shared generator
     assert abs(m._ctrl_mix - 0.75) < 1e-6                        # var_ctrl at it 5: (5 - 2) / (6 - 2)
+
+
+def test_lidar_step_touches_only_the_parameters_of_its_graph(backend):
+    """The street iteration = pixel step + lidar step, each with its own backward and optimizer step
+    (code_single/tools/train.py:860-960, 1540-1590).  The lidar render runs with ``with_rgb=False``: radiance, appearance and
+    sky parameters get NO gradient there -- they keep their value, their Adam moments and their step count, as under
+    torch's Adam (per-parameter ``state['step']``, None grads skipped); the SDF side is stepped twice per iteration.  The
+    lidar loss carries the eikonal term (train.py:904 ``with_normal``; app/loss/eikonal.py:233-250) next to depth + line of
+    sight, and a batch in which no beam produced a sample is a no-op instead of an exception."""
+    from neuralsim_amd import scenarios as sc
+    tr = sc.build_street_trainer(backend, small=True, rays_per_gpu=48, lidar_rays=48, num_uniform=16)
+    tr.lidar["num_uniform"] = 16
+    m, dm, sm = tr.model, tr.distant_model, tr.sky_model
+    tr._train_step_pixel(0)
+    grp = {id(g["p"]): g for g in tr.optim.groups}
+    lidar_free = [m.rad_w, m.rad_b, tr.appear, dm.rad_w, dm.rad_b, sm.w, sm.b]
+    in_graph = [m.encoding.flattened_params, m.sdf_w, m.sdf_b, dm.flattened_params, dm.den_w, dm.den_b]
+    assert all(grp[id(p)]["t"] == 1 for p in lidar_free + in_graph)
+    snap = [(p.detach().clone(), grp[id(p)]["m"].clone(), grp[id(p)]["v"].clone()) for p in lidar_free]
+    before = [p.detach().clone() for p in in_graph]
+    loss = tr.train_step_lidar(0)
+    assert float(loss) == float(loss) and tr.stats["lidar_samples"] > 0
+    parts = tr._lidar_parts
+    assert parts["depth"] > 0 and parts["los"] >= 0 and parts["eikonal_render"] > 0 and parts["eikonal_uniform"] > 0
+    assert abs(float(loss) - sum(parts.values())) < 1e-5 * (1 + abs(float(loss)))
+    for p, (p0, m0, v0) in zip(lidar_free, snap):
+        g = grp[id(p)]
+        assert p.grad is None and g["t"] == 1
+        assert torch.equal(p.detach(), p0) and torch.equal(g["m"], m0) and torch.equal(g["v"], v0)
+    for p, p0 in zip(in_graph, before):
+        assert grp[id(p)]["t"] == 2 and not torch.equal(p.detach(), p0)
+    # a batch whose beams all point away from the scene, without the distant model: nothing to differentiate
+    tr.distant_model = None
+    L = tr.lidar
+    L["rays_o"] = torch.full_like(L["rays_o"], 1e4)
+    L["rays_d"] = torch.zeros_like(L["rays_d"])
+    L["rays_d"][..., 2] = 1.0
+    L["num_uniform"] = 0
+    before = [p.detach().clone() for p in in_graph]
+    loss = tr.train_step_lidar(1)
+    assert float(loss) == float(loss) and tr.stats["lidar_samples"] == 0
+    assert all(torch.equal(p.detach(), p0) for p, p0 in zip(in_graph, before))
+    assert all(grp[id(p)]["t"] == 2 for p in in_graph)
