@@ -251,7 +251,7 @@ int nsim_permuto_bwd(const NsimPermutoMeta* meta, const float* x, int64_t S, con
  * concatenated to the position.  Writes LEVEL-MAJOR planes in the layout of nsim_lotd_gather_lm / nsim_field_fwd, so
  * that nsim_field_sdf (feat_planes) and nsim_field_fwd / _bwd_sdf (h_planes, J_planes; pass grid_f16 = NULL there: "the
  * planes are already gathered") run unchanged on a permutohedral model: exactly one of
- *   feat_planes [NL][S] (f16x2 scaled by 1024 when feat_f32 = 0, f32x2 when 1)      -- no-grad query, or
+ *   feat_planes [NL][P] (f16x2 scaled by 1024 when feat_f32 = 0, f32x2 when 1)      -- no-grad query, or
  *   h_planes [NL][P][2] + J_planes [NL][P][2][3], P = NSIM_PLANE_PITCH(S)            -- with-grad query
  * (NL = 16 for <= 16 levels, else 32; levels past num_levels are not written).  n_dev / n_add as nsim_lotd_gather_lm. */
 int nsim_permuto_gather(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
@@ -295,7 +295,7 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
  * feat_planes == NULL: one fused point-major kernel (gather + decoder).
  * feat_planes != NULL: decoder only, on the level-major feature planes written by nsim_lotd_gather_lm for the same
  * points (x / rays / grid are then unused and may be NULL).  Same values either way.
- * Speculatively sized buffers (level-major path): S is the CAPACITY (and the plane pitch); when n_dev != NULL the
+ * Speculatively sized buffers (level-major path): S is the CAPACITY (the plane pitch is NSIM_PLANE_PITCH(S)); when n_dev != NULL the
  * number of valid points is *n_dev + n_add, read on the device (0 if that exceeds S: the caller under-sized its
  * buffers and redoes the pass) -- the host never learns the size of the marched sample set before launching its
  * first query (one host sync less per step).
@@ -305,8 +305,10 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, int64_t S, const int64_t* n_dev, int64_t n_add, float* sdf,
                    const void* feat_planes, float* occ_val, const NsimOccMeta* occ_meta, float occ_inv_s, void* stream);
-/* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [NLP][S] (NLP = 16 for <= 16 levels, 32 above) of
- * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = 16 * S * (4 | 8) bytes, caller-owned.  Every wave
+/* Level-major LoTD gather of the no-grad query (the encoding half of forward_sdf): feat_planes [NLP][P] (NLP = 16 for <= 16 levels, 32 above;
+ * P = NSIM_PLANE_PITCH(S): a 32-point tile of a level is one aligned 128 B | 256 B piece, which nsim_field_sdf copies
+ * straight into LDS, global_load_lds_dwordx4, one tile ahead) of
+ * (fp16 x 2, pre-scaled for the fp16 MFMA decoder | f32 x 2) = NLP * P * (4 | 8) bytes, caller-owned.  Every wave
  * walks the levels in one order and the levels are dealt to the XCDs, so a level's table is read through ONE L2. */
 int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const int64_t* ray_goff, int64_t S,

@@ -1318,6 +1318,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #ifndef NSIM_SDF_MIN_WAVES
 #define NSIM_SDF_MIN_WAVES 2
 #endif
+#ifndef NSIM_SDF_NBUF
+#define NSIM_SDF_NBUF 1      // LDS plane images per wave of the sampling decoder (<= 16 levels); 2 = double-buffered (measured: 0.0387 vs 0.0372 ms)
+#endif
 // Level-major gather of the no-grad SDF query (sampling pass, occupancy refresh): every wave owns GLM_PTS x 64 points
 // and walks the 16 levels in the same order as every other wave of the launch, so at any moment the chip reads ONE
 // level's table (<= 2 MB for T = 2^19), which stays resident in each XCD's 4 MB L2 -- the point-major fused kernel
@@ -1416,7 +1419,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     for (int q = 0; q < GLM_PTS; ++q) {
       const int64_t s = s0 + 64 * q;
       if (s < Sv) {
-        const int64_t e = (int64_t)l * a.S + s;
+        const int64_t e = (int64_t)l * a.PS + s;      // feature planes [NL][P], P = NSIM_PLANE_PITCH(S)
         if constexpr (WJ) {
           const int64_t ep = (int64_t)l * a.PS + s;
           float* hp = a.h_pl + ep * 2;
@@ -1445,8 +1448,14 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   }
 }
 
-template <int PREC, int SDF_D, bool PLANES, int NC = 1>
+// GL (PLANES only): the tile's plane image -- per level 32 points x (f16x2 | f32x2) = 128 B | 256 B, one aligned piece
+// thanks to the 32-point pitch -- is copied global -> LDS (global_load_lds_dwordx4: 8 | 4 levels per instruction) one tile
+// AHEAD, double-buffered for <= 16 levels (2 x 4 KB per wave), single-buffered above (8 KB): without it a tile began with
+// eight dependent-on-nothing but unhidden plane reads per K-step at two waves per SIMD (round 4; the with-grad decoders got
+// the same treatment in round 2).  NSIM_SDF_GLDS=0 launches the GL = false form.
+template <int PREC, int SDF_D, bool PLANES, int NC = 1, bool GL = false>
 __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_sdf(FieldArgs a) {
+  static_assert(!GL || PLANES, "the LDS image is an image of the level-major planes");
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -1463,6 +1472,29 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
   }
   const int64_t ntiles = (Sv + 31) / 32;
   const int64_t wstride = (int64_t)gridDim.x * FIELD_WAVES;
+  // ---- LDS image of the planes (GL)
+  constexpr int LV_BYTES = PREC == 0 ? 128 : 256;               // one level of one tile
+  constexpr int LV_PER_COPY = 1024 / LV_BYTES;                  // levels per global_load_lds_dwordx4 (64 lanes x 16 B)
+  constexpr int IMG_BYTES = 16 * NC * LV_BYTES;
+  constexpr int NBUF = NC == 1 ? NSIM_SDF_NBUF : 1;
+  const int lv_used = NC == 1 ? 16 : ((a.lotd.num_levels + 7) & ~7);       // (wave-uniform) levels the K-steps read
+  char* img = GL ? smem + wbytes + wave * (NBUF * IMG_BYTES) : nullptr;
+  auto prefetch_planes = [&](int64_t tile_n, int buf) {
+    const int64_t s0 = tile_n * 32;
+    const int sub = lane / (64 / LV_PER_COPY), part = lane % (64 / LV_PER_COPY);
+#pragma unroll
+    for (int k = 0; k < 16 * NC / LV_PER_COPY; ++k) {
+      if (NC == 2 && k * LV_PER_COPY >= lv_used) continue;
+      const int l = k * LV_PER_COPY + sub;
+      const char* src = reinterpret_cast<const char*>(a.feat_pl) + ((int64_t)l * a.PS + s0) * (LV_BYTES / 32) + 16 * part;
+      nsim_glds16(src, img + buf * IMG_BYTES + 1024 * k);
+    }
+  };
+  int buf = 0;
+  if constexpr (GL) {
+    const int64_t t0 = (int64_t)blockIdx.x * FIELD_WAVES + wave;
+    if (t0 < ntiles) prefetch_planes(t0, 0);
+  }
   for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < ntiles; tile += wstride) {
     TilePoint p;
     if constexpr (PLANES) {
@@ -1470,6 +1502,15 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       p.valid = p.s < Sv;
     } else {
       p = load_point(a, tile, j, false);
+    }
+    const char* cur = nullptr;
+    if constexpr (GL) {
+      nsim_wait_vm0();                          // this tile's image has landed
+      cur = img + buf * IMG_BYTES;
+      if constexpr (NBUF == 2) {                // the next tile's image goes to the other buffer while this one is read
+        if (tile + wstride < ntiles) prefetch_planes(tile + wstride, buf ^ 1);
+        buf ^= 1;
+      }
     }
     f32x16 acc[2] = {zero16(), zero16()};
     f32x16 accc[PREC == 2 ? 2 : 1];            // split mode: the hi.lo + lo.hi correction, in units of 1 / SPLIT_LO_SCALE
@@ -1482,14 +1523,37 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       if (NC == 2 && lb >= ((a.lotd.num_levels + 7) & ~7)) continue;
       float f8[8];
       f16x8 bvp;
-      if constexpr (PLANES) {
+      if constexpr (GL) {
+        // from the LDS image; lanes past the valid points read whatever the pitch padding holds: zeroed (their columns of
+        // the products are discarded, but nothing non-finite is fed to the matrix cores)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int l = lb + 4 * qq + 2 * hi + b;
+            if constexpr (PREC == 0) {
+              union {
+                uint32_t u;
+                f16 h[2];
+              } cv;
+              cv.u = reinterpret_cast<const uint32_t*>(cur + LV_BYTES * l)[j];
+              if (!p.valid) cv.u = 0u;
+              bvp[4 * qq + 2 * b] = cv.h[0];
+              bvp[4 * qq + 2 * b + 1] = cv.h[1];
+            } else {
+              const float* ip = reinterpret_cast<const float*>(cur + LV_BYTES * l) + 2 * j;
+              f8[4 * qq + 2 * b] = p.valid ? ip[0] : 0.f;
+              f8[4 * qq + 2 * b + 1] = p.valid ? ip[1] : 0.f;
+            }
+          }
+      } else if constexpr (PLANES) {
         // features were gathered level-major by k_lotd_gather_lm (fp16 mode: already scaled by SDF_H_SCALE)
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int l = lb + 4 * qq + 2 * hi + b;
-            const int64_t e = (int64_t)l * a.S + (p.valid ? p.s : 0);
+            const int64_t e = (int64_t)l * a.PS + (p.valid ? p.s : 0);
             if constexpr (PREC == 0) {
               union {
                 uint32_t u;
@@ -1566,6 +1630,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
           for (int mo = 0; mo < 2; ++mo)
             acc[mo] = mfma_32x32x2_f32(A[(mo * 16 * NC + 8 * rb + e) * 64 + lane], f8[e], acc[mo]);
       }
+    }
+    if constexpr (GL && NBUF == 1) {            // one buffer: every lane has read the image, the next copy may overwrite it
+      nsim_wait_lgkm0();
+      if (tile + wstride < ntiles) prefetch_planes(tile + wstride, 0);
     }
     const float inv_h = PREC != 1 ? 1.0f / SDF_H_SCALE : 1.0f;
     float sdf = 0.f;
@@ -2304,6 +2372,7 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
   a.S_dev = n_dev;
   a.S_add = n_add;
   a.feat_pl = feat_planes;
+  a.PS = NSIM_PLANE_PITCH(S);
   deal_levels(meta, a);
   const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
   if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
@@ -2331,6 +2400,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.S_dev = feat_planes ? n_dev : nullptr;   // the speculative size applies to the level-major path only
   a.S_add = n_add;
   a.S = S;
+  a.PS = NSIM_PLANE_PITCH(S);
   a.sdf = sdf;
   a.feat_pl = feat_scratch;
   if (occ_val) {
@@ -2351,28 +2421,40 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     sdf_grid = sdf_grid < 512 ? 512 : (sdf_grid > 4096 ? 4096 : sdf_grid);
   }
   const dim3 grid(field_grid(S, sdf_grid)), block(64 * FIELD_WAVES);
-  const size_t shmem = weights_lds_bytes(meta, 0, 2);
+  size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
   if (meta->precision == 2 && !feat_scratch) return 33;     // split precision: level-major path only
-  if (field_nc(meta->lotd.num_levels) == 2) {
+  static const bool sdf_glds = !(getenv("NSIM_SDF_GLDS") && atoi(getenv("NSIM_SDF_GLDS")) == 0);
+  const int nc = field_nc(meta->lotd.num_levels);
+  const bool gl = sdf_glds && feat_scratch;
+  if (gl)     // the LDS plane image(s) of every wave behind the weights: 2 x (2 | 4) KB for <= 16 levels, 1 x (4 | 8) KB above
+    shmem = ((shmem + 15) & ~(size_t)15) + (size_t)FIELD_WAVES * (nc == 1 ? NSIM_SDF_NBUF : 1) * 16 * nc * (meta->precision == 0 ? 128 : 256);
+  hipStream_t st = (hipStream_t)stream;
+#define NSIM_SDF_LAUNCH(P, D, N)                                                                                  \
+  do {                                                                                                            \
+    if (gl) hipLaunchKernelGGL((k_field_sdf<P, D, true, N, true>), grid, block, shmem, st, a);                    \
+    else hipLaunchKernelGGL((k_field_sdf<P, D, true, N, false>), grid, block, shmem, st, a);                      \
+  } while (0)
+  if (nc == 2) {
     if (!feat_scratch) return 33;     // more than 16 levels: level-major path only
     switch (key) {
-      case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 4: hipLaunchKernelGGL((k_field_sdf<2, 1, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 5: hipLaunchKernelGGL((k_field_sdf<2, 2, true, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 0: NSIM_SDF_LAUNCH(0, 1, 2); break;
+      case 1: NSIM_SDF_LAUNCH(0, 2, 2); break;
+      case 2: NSIM_SDF_LAUNCH(1, 1, 2); break;
+      case 3: NSIM_SDF_LAUNCH(1, 2, 2); break;
+      case 4: NSIM_SDF_LAUNCH(2, 1, 2); break;
+      case 5: NSIM_SDF_LAUNCH(2, 2, 2); break;
     }
   } else if (feat_scratch) {   // decoder on the planes gathered by nsim_lotd_gather_lm
     switch (key) {
-      case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 4: hipLaunchKernelGGL((k_field_sdf<2, 1, true>), grid, block, shmem, (hipStream_t)stream, a); break;
-      case 5: hipLaunchKernelGGL((k_field_sdf<2, 2, true>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 0: NSIM_SDF_LAUNCH(0, 1, 1); break;
+      case 1: NSIM_SDF_LAUNCH(0, 2, 1); break;
+      case 2: NSIM_SDF_LAUNCH(1, 1, 1); break;
+      case 3: NSIM_SDF_LAUNCH(1, 2, 1); break;
+      case 4: NSIM_SDF_LAUNCH(2, 1, 1); break;
+      case 5: NSIM_SDF_LAUNCH(2, 2, 1); break;
     }
+#undef NSIM_SDF_LAUNCH
   } else {
     switch (key) {
       case 0: hipLaunchKernelGGL((k_field_sdf<0, 1, false>), grid, block, shmem, (hipStream_t)stream, a); break;

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
     // plane levels past the pyramid (pyramids of fewer than 16 levels): the 16-level decoder kernels read all 16 planes
     // (zero weight columns) -- keep them finite, as field.hip's level-major gather does
     if constexpr (MODE == 1) {
-      const int64_t e = (int64_t)l * a.S + s;
+      const int64_t e = (int64_t)l * a.PS + s;      // feature planes [NL][P]
       if (a.feat_f32) {
         reinterpret_cast<float*>(a.feat_pl)[2 * e] = 0.f;
         reinterpret_cast<float*>(a.feat_pl)[2 * e + 1] = 0.f;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
       }
     }
   } else if constexpr (MODE == 1) {
-    const int64_t e = (int64_t)l * a.S + s;
+    const int64_t e = (int64_t)l * a.PS + s;      // feature planes [NL][P]
     if (a.feat_f32) {
       reinterpret_cast<float*>(a.feat_pl)[2 * e] = f0;
       reinterpret_cast<float*>(a.feat_pl)[2 * e + 1] = f1;

@@ -942,8 +942,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         fm = self.field_meta if fm is None else fm
         planes = None
         if not self._sdf_fused:
-            planes = torch.empty([self.plane_levels * S * (1 if fm.precision == 0 else 2)], dtype=torch.float32,   # f16x2 | f32x2
-                                 device=dev)
+            # [NLP][P] x (f16x2 | f32x2), P = the 32-point pitch: every tile of a level is one aligned piece (LDS-DMA)
+            planes = torch.empty([self.plane_levels * _lib.plane_pitch(S) * (1 if fm.precision == 0 else 2)],
+                                 dtype=torch.float32, device=dev)
             self._enc_gather_feat(fm, grid16, x, rays_o, rays_d, t, ridx, goff, S, n_dev, n_add, planes)
         # ``collect``: the decoder launch also folds its SDFs into the occupancy values (update_from_samples_cfg)
         acc = self.accel if collect else None
