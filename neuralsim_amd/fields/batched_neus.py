@@ -69,19 +69,24 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
     is_batched_query_supported = True
 
     def __init__(self, num_instances: int, ins_ids: Optional[Sequence[str]] = None, accel_cfg: dict = None,
-                 seed: int = 42, param_bound: float = 1e-4, lotd_grower_cfg: dict = None, latents_cfg: dict = None, **kw):
+                 seed: int = 42, param_bound: float = 1e-4, lotd_grower_cfg: dict = None, latents_cfg: dict = None,
+                 own_latents: bool = True, **kw):
         """``lotd_grower_cfg`` (``DenseLoTDGrowerFMM`` parameters: z_dim, lod_res, lod_n_feats, D, W, fmm_rank,
         n_frequencies -- no_fg_occ.221218.yaml:320-337) + ``latents_cfg{z{dim}}`` (:310-312): the per-instance tables are
         GROWN from per-instance latent codes (auto-decoder: one learnable code per instance) instead of being free
-        parameters; ``set_condition`` then takes ``ins_id`` / ``ins_ind`` (codes looked up) or ``z_ins`` (codes given)."""
+        parameters; ``set_condition`` then takes ``ins_id`` / ``ins_ind`` (codes looked up) or ``z_ins`` (codes given).
+        The reference's block form ``{target: ...MixedLoTDGrower, param: {grower_configs: [DenseLoTDGrowerFMM, VMSplitLoTDGrowerFMM]}}``
+        (:319-352) is accepted as well (``lotd_growers.build_grower``).  ``own_latents=False``: the codes live outside the
+        model (the reference's ``AutoDecoderMixin`` keeps them in ``self._latents``) -- conditions then always carry ``z_ins``."""
         accel_cfg = dict(accel_cfg or {})
         self.grower = None
         if lotd_grower_cfg is not None:
-            from ..grid_encodings.lotd_growers import DenseLoTDGrowerFMM
+            from ..grid_encodings.lotd_growers import build_grower
             gcfg = dict(lotd_grower_cfg)
-            z_dim = int((latents_cfg or {}).get("z", {}).get("dim", gcfg.get("z_dim", 128)))
-            gcfg["z_dim"] = z_dim
-            grower = DenseLoTDGrowerFMM(seed=seed + 5, **gcfg)
+            lat = dict(latents_cfg or {})
+            lat_z = lat.get("z", lat.get("z_ins", {})) or {}
+            z_dim = int(lat_z.get("dim", gcfg.get("z_dim", 128)))
+            grower = build_grower(gcfg, z_dim=z_dim, seed=seed + 5)
             kw = dict(kw, lod_res=grower.kernel_lod_res, log2_hashmap_size=max(int(kw.get("log2_hashmap_size", 19)),
                                                                                (max(grower.lod_res) ** 3).bit_length()))
         super().__init__(accel_cfg=accel_cfg, seed=seed, param_bound=param_bound, **kw)
@@ -93,7 +98,10 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         if lotd_grower_cfg is not None:
             self.grower = grower
             assert grower.n_params == n and all(t == "Dense" for t in self.encoding.cfg.lod_types)
-            self.latents = nn.Parameter(torch.randn(B, grower.z_dim, generator=g) * 0.1)      # ``z_ins_all`` (auto-decoder)
+            if own_latents:
+                self.latents = nn.Parameter(torch.randn(B, grower.z_dim, generator=g) * 0.1)      # ``z_ins_all`` (auto-decoder)
+            else:
+                self.latents = None
             p = torch.zeros([0])                                           # no free table
         else:
             p = ((torch.rand(B * n, generator=g) * 2 - 1) * param_bound).half().float()
@@ -112,7 +120,7 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
     def _param_groups(self, cfg: dict):
         if self.grower is None:
             return super()._param_groups(cfg)
-        return [dict(name="latents.z_ins", params=[self.latents]),
+        return ([dict(name="latents.z_ins", params=[self.latents])] if self.latents is not None else []) + [
                 dict(name="implicit_surface.encoding.grower", params=list(self.grower.parameters())),
                 dict(name="implicit_surface.decoder", params=[self.sdf_w, self.sdf_b]),
                 dict(name="radiance_net", params=[self.rad_w, self.rad_b]),
@@ -149,8 +157,9 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         if "z_ins" in batched_infos:
             z = batched_infos["z_ins"].to(self.device).float().reshape(-1, self.grower.z_dim)
         else:
-            if inds is None:
-                raise RuntimeError("set_condition needs 'ins_id' / 'ins_ind' when no 'z_ins' is provided")
+            if inds is None or self.latents is None:
+                raise RuntimeError("set_condition needs 'ins_id' / 'ins_ind' (and codes owned by the model) when no 'z_ins' "
+                                   "is provided")
             z = self.latents[inds]
         if inds is not None and inds.shape[0] != z.shape[0]:
             raise RuntimeError("set_condition: 'z_ins' and the instance list differ in length")

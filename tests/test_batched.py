@@ -262,3 +262,95 @@ def test_grower_at_the_config_sizes():
     for lay in g.layers:
         assert torch.allclose(lay.effective_weight(torch.zeros(1, 128))[0], lay.weight, rtol=1e-5, atol=1e-7)
     assert float(t[0].abs().max()) < 1.0
+
+
+def _fmm_params(layers):
+    return [{k: getattr(lay, k).detach().cpu().clone() for k in ("weight", "bias", "u_w", "u_b", "v_w", "v_b")} for lay in layers]
+
+
+def test_vm_split_grower_is_the_factorised_field():
+    """``VMSplitLoTDGrowerFMM`` (no_fg_occ.221218.yaml:338-352) grows vector-matrix levels as DENSE vertex tables: (1) equal
+    to the oracle's loop restatement; (2) the expansion is exact -- the trilinear interpolant of the expanded table (what the
+    LoTD kernels compute on a dense level) equals sum_c bilinear(plane_c) x linear(line_c) evaluated directly, at random
+    points; (3) the reference's config block builds it (``build_grower``) next to the dense grower (``MixedLoTDGrower``)."""
+    from oracle import growers as ogrow, lotd as olotd
+    from neuralsim_amd.grid_encodings.lotd_growers import MixedLoTDGrower, VMSplitLoTDGrowerFMM, build_grower
+    res, F = [4, 7], 4
+    g = VMSplitLoTDGrowerFMM(z_dim=6, lod_res=res, lod_n_feats=F, D=2, D_head=2, W=16, fmm_rank=3, n_frequencies=2, out_scale=0.5,
+                             seed=3)
+    z = torch.randn(2, 6, generator=torch.Generator().manual_seed(1)) * 0.7
+    tab = g(z).detach()
+    ref, factors = ogrow.grow_vm_tables(z, _fmm_params(g.trunk), _fmm_params(g.plane_head), _fmm_params(g.line_head), res, F, 2, 3,
+                                        0.5, return_factors=True)
+    assert tab.shape == ref.shape == (2, g.n_params) and g.n_params == sum(r ** 3 * F for r in res)
+    assert torch.allclose(tab, ref, atol=2e-6), float((tab - ref).abs().max())
+    assert g.kernel_lod_res == [4, 4, 7, 7]
+    # (2) trilinear interpolation of the expanded level == the factorised evaluation
+    spec = olotd.make_lotd_spec(lod_res=g.kernel_lod_res, log2_hashmap_size=10)
+    assert all(t == "Dense" for t in spec.lod_types)
+    x = torch.rand(200, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    feat = olotd.lotd_forward(x, ref[1], spec)                              # [N, 2 per kernel level]
+    for l, R in enumerate(res):
+        direct = ogrow.vm_feature_at(x, factors[1][3 * l:3 * l + 3], R)     # [N, F]
+        got = feat[:, 4 * l:4 * l + 4]
+        assert torch.allclose(got, direct, atol=3e-6), (l, float((got - direct).abs().max()))
+    # (3) the reference's block
+    blk = dict(target="nr3d_lib.models.grid_encodings.lotd.lotd_batched_growers.MixedLoTDGrower", param=dict(grower_configs=[
+        dict(target="nr3d_lib.models.grid_encodings.lotd.lotd_batched_growers.DenseLoTDGrowerFMM",
+             param=dict(z_dim=128, lod_res=[3, 5], lod_n_feats=4, pseudo_net_type="same",
+                        pseudo_net_param=dict(activation="relu", fmm_rank=4, equal_lr=False, D=2, W=16,
+                                              embed_cfg=dict(type="sinusoidal_legacy", n_frequencies=2)))),
+        dict(target="nr3d_lib.models.grid_encodings.lotd.lotd_batched_growers.VMSplitLoTDGrowerFMM",
+             param=dict(z_dim=128, lod_res=[6, 9], lod_n_feats=4, pseudo_net_type="shared",
+                        pseudo_net_param=dict(activation="relu", fmm_rank=4, equal_lr=False, D=2, D_head=2, W=16,
+                                              embed_cfg=dict(type="sinusoidal_legacy", n_frequencies=3))))]))
+    mg = build_grower(blk, z_dim=10, seed=1)
+    assert isinstance(mg, MixedLoTDGrower) and mg.z_dim == 10 and mg.kernel_lod_res == [3, 3, 5, 5, 6, 6, 9, 9]
+    t = mg(torch.zeros(1, 10))
+    assert t.shape == (1, mg.n_params) and mg.n_params == (27 + 125 + 216 + 729) * 4 and bool(torch.isfinite(t).all())
+    with pytest.raises(NotImplementedError):
+        build_grower(dict(target="x.VMSplitLoTDGrowerFMM", param=dict(lod_res=[4], pseudo_net_type="same")), z_dim=4)
+
+
+def test_mixed_grower_model_queries_match_the_oracle(backend):
+    """A model grown by dense + vector-matrix levels through the kernels: SDF / normals of ``forward_sdf_nablas`` and the code
+    gradients against the oracle field on the oracle-grown table."""
+    from oracle import field as ofield, growers as ogrow
+    from neuralsim_amd.fields.batched_neus import BatchedLoTDNeuSModel
+    pn = lambda D, nf, **k: dict(activation="relu", fmm_rank=3, equal_lr=False, D=D, W=16,       # noqa: E731
+                                 embed_cfg=dict(type="sinusoidal_legacy", n_frequencies=nf), **k)
+    blk = dict(target="x.MixedLoTDGrower", param=dict(grower_configs=[
+        dict(target="x.DenseLoTDGrowerFMM", param=dict(lod_res=[3, 5], lod_n_feats=4, pseudo_net_type="same", pseudo_net_param=pn(2, 2))),
+        dict(target="x.VMSplitLoTDGrowerFMM", param=dict(lod_res=[6, 9], lod_n_feats=4, pseudo_net_type="shared",
+                                                         pseudo_net_param=pn(2, 2, D_head=2)))]))
+    B = 2
+    m = BatchedLoTDNeuSModel(B, lotd_grower_cfg=blk, latents_cfg=dict(z=dict(dim=5)), sdf_D=1, precision="f32", log2_hashmap_size=10,
+                             accel_cfg=dict(resolution=[8, 8, 8])).to(backend)
+    assert m.encoding.cfg.lod_res == [3, 3, 5, 5, 6, 6, 9, 9] and all(t == "Dense" for t in m.encoding.cfg.lod_types)
+    z = (torch.randn(B, 5, generator=torch.Generator().manual_seed(4)) * 0.8).to(backend).requires_grad_(True)
+    m.set_condition({"z_ins": z})
+    dense, vm = m.grower.growers
+    z_o = z.detach().cpu().clone().requires_grad_(True)
+    t_d = ogrow.grow_tables(z_o, _fmm_params(dense.layers), [3, 5], 4, 2, 3, dense.out_scale)
+    t_v = ogrow.grow_vm_tables(z_o, _fmm_params(vm.trunk), _fmm_params(vm.plane_head), _fmm_params(vm.line_head), [6, 9], 4, 2, 3,
+                               vm.out_scale)
+    tables = torch.cat([t_d, t_v], dim=1)
+    assert torch.allclose(m._cond_table.detach().cpu().view(B, -1), tables.detach(), atol=2e-6)
+    x = torch.rand(60, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8
+    bidx = torch.randint(0, B, (60,), generator=torch.Generator().manual_seed(6))
+    out = m.forward_sdf_nablas(x.to(backend), bidx=bidx.to(backend))
+    w = torch.randn(60, generator=torch.Generator().manual_seed(7))
+    loss_o = 0.0
+    for b in range(B):
+        p = ofield.params_from_flat(m.encoding.cfg.lod_res, 10, tables[b].detach(), m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s,
+                                    sdf_D=1, ln_inv_s_factor=m.ln_inv_s_factor)
+        p.grid = tables[b].detach().half().float() + (tables[b] - tables[b].detach())
+        sel = bidx == b
+        sdf_o, nab_o = ofield.forward_sdf_nablas(x[sel], p)
+        assert (out["sdf"].detach().cpu()[sel] - sdf_o.detach()).abs().max() < 1e-4 * (1 + float(sdf_o.abs().max()))
+        assert (out["nablas"].detach().cpu()[sel] - nab_o.detach()).abs().max() < 1e-3 * (1 + float(nab_o.abs().max()))
+        loss_o = loss_o + (sdf_o * w[sel]).sum() + 0.1 * (nab_o ** 2).sum()
+    loss_o.backward()
+    ((out["sdf"] * w.to(backend)).sum() + 0.1 * (out["nablas"] ** 2).sum()).backward()
+    assert rel_l2(z.grad.cpu(), z_o.grad) < 5e-3, rel_l2(z.grad.cpu(), z_o.grad)
+    m.clean_condition()
