@@ -64,7 +64,107 @@ class OccGridAccelBatched(OccGridAccel):
         self.pack_bits()
 
 
-class BatchedLoTDNeuSModel(LoTDNeuSModel):
+class BatchedRaysMixin:
+    """``batched_ray_test`` / ``batched_ray_query`` over (item, ray) pairs -- shared by the batched LoTD model (per-instance
+    tables: table + occupancy offsets per pair) and the batched permutohedral model (one table, a latent per pair:
+    fields/batched_permuto_neus.py).  The model provides ``ins_inds_per_batch`` (the condition) and
+    ``_pair_extras(ins [R], which [R]) -> dict`` merged into the tested-rays dict of the single-model ``ray_query``."""
+
+    # ------------------------------------------------------------------ batched rays (buffer_compose_renderer.py:222-265)
+    def batched_ray_test(self, rays_o: torch.Tensor, rays_d: torch.Tensor, near=None, far=None, compact_batch=True,
+                         **extra) -> Dict:
+        """rays_o / rays_d [B', N, 3] in the object space of each batch item.  Returns the flat list of (item, ray)
+        pairs that hit the AABB: ``rays_inds [R]`` (index into N), ``rays_full_bidx [R]`` (index into B'),
+        ``rays_bidx [R]`` (index into the compacted list of items that were hit at all), ``full_bidx_map [B'']``
+        (compact -> full), ``num_rays``, ``near``, ``far`` and the filtered inputs."""
+        Bq, N = rays_o.shape[0], rays_o.shape[1]
+        # RAY-major pair order (ray index ascending, the items of one ray consecutive): the renderer regroups the packs
+        # of a ray that crosses several items with ``unique_consecutive`` and relies on exactly this order
+        # (buffer_compose_renderer.py:347-368, "[!!!] Requires ridx to be consecutive and monotonically increasing").
+        flat = super().ray_test(rays_o.transpose(0, 1).reshape(-1, 3), rays_d.transpose(0, 1).reshape(-1, 3), near=near,
+                                far=far)
+        pair = flat["rays_inds"]                                     # = ray * Bq + item
+        rinds = torch.div(pair, Bq, rounding_mode="floor")
+        full_bidx = pair - rinds * Bq
+        if compact_batch:
+            full_bidx_map, bidx = torch.unique(full_bidx, return_inverse=True)      # sorted: order of items kept
+        else:
+            full_bidx_map, bidx = torch.arange(Bq, device=pair.device), full_bidx
+        ret = dict(num_rays=flat["num_rays"], rays_inds=rinds, rays_bidx=bidx, rays_full_bidx=full_bidx,
+                   full_bidx_map=full_bidx_map, rays_o=flat["rays_o"], rays_d=flat["rays_d"], near=flat["near"],
+                   far=flat["far"])
+        for k, v in extra.items():
+            if isinstance(v, torch.Tensor) and v.shape[:2] == (Bq, N):
+                vf = v.transpose(0, 1).reshape(N * Bq, *v.shape[2:])
+                if vf.requires_grad and vf.dim() == 2 and vf.dtype == torch.float32:
+                    from ..losses import embedding_lookup
+                    ret[k] = embedding_lookup(vf, pair)
+                else:
+                    ret[k] = vf[pair]
+            else:
+                ret[k] = v
+        return ret
+
+    def batched_ray_query(self, *, batched_ray_input: dict = None, batched_ray_tested: dict, config,
+                          return_buffer: bool = True, return_details: bool = False,
+                          render_per_obj_individual: bool = False) -> Dict:
+        """``march_occ_multi_upsample[_compressed]`` on the tested (item, ray) pairs; the volume buffer is packed per
+        pair and carries ``rays_bidx_hit`` / ``rays_full_bidx_hit`` next to ``rays_inds_hit``."""
+        assert self.ins_inds_per_batch is not None, "set_condition() first"
+        bt = batched_ray_tested
+        # The reference conditions the model on the COMPACTED batch -- ``set_condition({'ins_id': [ids of the items
+        # that were hit at all]})`` after ``batched_ray_test(compact_batch=True)`` (buffer_compose_renderer.py:247-258)
+        # -- so the condition is indexed by ``rays_bidx``; a condition given over the full batch by ``rays_full_bidx``
+        # (when every item was hit the two coincide).
+        n_cond = int(self.ins_inds_per_batch.shape[0])
+        if "full_bidx_map" in bt and n_cond == int(bt["full_bidx_map"].shape[0]):
+            which = bt["rays_bidx"]
+        else:
+            which = bt["rays_full_bidx"]
+            if batched_ray_input is not None and batched_ray_input.get("rays_o") is not None:
+                assert n_cond == int(batched_ray_input["rays_o"].shape[0]), \
+                    "set_condition() covers neither the compacted nor the full batch of batched_ray_tested"
+        ins = self.ins_inds_per_batch[which] if bt["num_rays"] > 0 else which
+        tested = dict(bt)
+        tested.update(self._pair_extras(ins, which))
+        want_pairs = bool(dict(config).get("_render", False))
+        cfg = dict(config, _render=True) if render_per_obj_individual else config
+        if dict(cfg).get("_jitter_full") is not None and bt["num_rays"] > 0:
+            # perturbation randoms given per RAY of the batch ([N], [N, C]; parity tests): a pair uses its ray's
+            cfg = dict(cfg, _jitter=cfg["_jitter_full"][bt["rays_inds"]].contiguous(),
+                       _jitter_c=cfg["_jitter_c_full"][bt["rays_inds"]].contiguous())
+        ret = super().ray_query(ray_input=None, ray_tested=tested, config=cfg, return_buffer=return_buffer,
+                                return_details=return_details, render_per_obj_individual=False)
+        if render_per_obj_individual:
+            # every batch item alone, as [B', N(, 3)] images over all the rays (buffer_compose_renderer.py:268-275 slices
+            # them per object and indexes them with (rays_full_bidx, rays_inds))
+            assert batched_ray_input is not None and batched_ray_input.get("rays_o") is not None, \
+                "render_per_obj_individual needs batched_ray_input (the [B', N, 3] rays)"
+            Bq, N = batched_ray_input["rays_o"].shape[:2]
+            pairs = ret.pop("rendered", None)
+            dev = bt["rays_inds"].device
+            keys = ["mask_volume", "depth_volume"] + (["rgb_volume"] if dict(config).get("with_rgb", True) else []) + \
+                (["normals_volume"] if dict(config).get("with_normal", False) else [])
+            where = (bt["rays_full_bidx"], bt["rays_inds"])
+            full = {}
+            for k in keys:
+                tail = (3,) if k in ("rgb_volume", "normals_volume") else ()
+                z = torch.zeros([Bq, N, *tail], dtype=torch.float32, device=dev)
+                full[k] = z.index_put(where, pairs[k]) if pairs is not None and k in pairs else z
+            ret["rendered"] = full
+            if want_pairs and pairs is not None:
+                ret["rendered_pairs"] = pairs
+        vb = ret["volume_buffer"]
+        if vb["type"] != "empty":
+            vb["rays_bidx_hit"] = bt["rays_bidx"]
+            vb["rays_full_bidx_hit"] = bt["rays_full_bidx"]
+        return ret
+
+    def ray_test(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__}: use batched_ray_test / batched_ray_query")
+
+
+class BatchedLoTDNeuSModel(BatchedRaysMixin, LoTDNeuSModel):
     is_ray_query_supported = True
     is_batched_query_supported = True
 
@@ -193,6 +293,10 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
             return positions * self.n_params_per_instance, ins_inds * self.accel.words_per_instance
         return ins_inds * self.n_params_per_instance, ins_inds * self.accel.words_per_instance
 
+    def _pair_extras(self, ins: torch.Tensor, which: torch.Tensor) -> Dict:
+        goff, woff = self._offsets(ins, which)
+        return dict(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
+
     # ------------------------------------------------------------------ per-instance point queries
     @torch.no_grad()
     def query_sdf(self, x: torch.Tensor, ins_ind=None, bidx: torch.Tensor = None) -> torch.Tensor:
@@ -206,7 +310,7 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
             if self.grower is not None:                 # one instance: grow its table for this query
                 own_condition = self._cond_table is None
                 if own_condition:
-                    self.set_condition({"ins_ind": [int(ins_ind)]})
+                    self.set_condition({"ins_ind": torch.tensor([int(ins_ind)], dtype=torch.long, device=xf.device)})
                 pos = (self.ins_inds_per_batch == int(ins_ind)).nonzero()[:1, 0]
                 goff = pos * self.n_params_per_instance
             else:
@@ -238,6 +342,42 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         if not nablas_has_grad:
             nablas = nablas.detach()
         return dict(sdf=sdf.reshape(shape), nablas=nablas.reshape(*shape, 3))
+
+    def pretrain_generator_sphere(self, radius: float = 0.5, num_iters: int = 200, lr: float = 1e-3, num_pts: int = 2 ** 12,
+                                  z_std: float = 0.1, n_codes: int = 4, seed: int = 0, logger=None, w_eikonal: float = 0.05) -> float:
+        """Pre-training of a GROWN model (no table to write a sphere into): Adam over the grower and the SDF decoder so that
+        the SDF of codes z ~ N(0, z_std^2) -- the neighbourhood the auto-decoder's codes start in (``zero_init_latents``,
+        no_fg_occ.221218.yaml:388) -- is |u| - radius, through the model's own forward / backward kernels."""
+        assert self.grower is not None
+        dev = self.sdf_w.device
+        params = list(self.grower.parameters()) + [self.sdf_w, self.sdf_b]
+        opt = torch.optim.Adam(params, lr=lr)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        lo, hi = self.accel.aabb[0].to(dev), self.accel.aabb[1].to(dev)
+        saved = (self.ins_inds_per_batch, getattr(self, "z_ins_per_batch", None))
+        loss = torch.zeros([])
+        with torch.enable_grad():
+            for it in range(int(num_iters)):
+                z = torch.randn([n_codes, self.grower.z_dim], device=dev, generator=g) * z_std
+                self._set_condition_grown({"z_ins": z})
+                x = lo + (hi - lo) * torch.rand([num_pts, 3], device=dev, generator=g)
+                bidx = torch.randint(0, n_codes, [num_pts], device=dev, generator=g)
+                u = (x - (lo + hi) * 0.5) / ((hi - lo) * 0.5)
+                out = self.forward_sdf_nablas(x, bidx=bidx)
+                loss = (out["sdf"] - (u.norm(dim=-1) - radius) * float(((hi - lo) * 0.5).min())).abs().mean()
+                total = loss + w_eikonal * ((out["nablas"].norm(dim=-1) - 1.0) ** 2).mean()
+                opt.zero_grad(set_to_none=True)
+                total.backward()
+                opt.step()
+                self._wpack_versions = None
+                if logger is not None and it % 100 == 0:
+                    logger.info(f"pretrain_generator: it {it} loss {float(loss.detach()):.5f}")
+        for q in params:
+            q.grad = None
+        BatchedLoTDNeuSModel.clean_condition(self)
+        self.ins_inds_per_batch = saved[0]
+        self.is_pretrained.fill_(True)
+        return float(loss.detach())
 
     @torch.no_grad()
     def geometric_init_sphere(self, radius: float = 0.5, noise_scale: float = 0.25, inside_out: bool = None,
@@ -283,99 +423,6 @@ class BatchedLoTDNeuSModel(LoTDNeuSModel):
         self.accel.occ_val.zero_()
         self.accel.update_from_net(lambda pts, b: self.query_sdf(pts, ins_ind=b), generator=generator, **kw)
 
-    # ------------------------------------------------------------------ batched rays (buffer_compose_renderer.py:222-265)
-    def batched_ray_test(self, rays_o: torch.Tensor, rays_d: torch.Tensor, near=None, far=None, compact_batch=True,
-                         **extra) -> Dict:
-        """rays_o / rays_d [B', N, 3] in the object space of each batch item.  Returns the flat list of (item, ray)
-        pairs that hit the AABB: ``rays_inds [R]`` (index into N), ``rays_full_bidx [R]`` (index into B'),
-        ``rays_bidx [R]`` (index into the compacted list of items that were hit at all), ``full_bidx_map [B'']``
-        (compact -> full), ``num_rays``, ``near``, ``far`` and the filtered inputs."""
-        Bq, N = rays_o.shape[0], rays_o.shape[1]
-        # RAY-major pair order (ray index ascending, the items of one ray consecutive): the renderer regroups the packs
-        # of a ray that crosses several items with ``unique_consecutive`` and relies on exactly this order
-        # (buffer_compose_renderer.py:347-368, "[!!!] Requires ridx to be consecutive and monotonically increasing").
-        flat = super().ray_test(rays_o.transpose(0, 1).reshape(-1, 3), rays_d.transpose(0, 1).reshape(-1, 3), near=near,
-                                far=far)
-        pair = flat["rays_inds"]                                     # = ray * Bq + item
-        rinds = torch.div(pair, Bq, rounding_mode="floor")
-        full_bidx = pair - rinds * Bq
-        if compact_batch:
-            full_bidx_map, bidx = torch.unique(full_bidx, return_inverse=True)      # sorted: order of items kept
-        else:
-            full_bidx_map, bidx = torch.arange(Bq, device=pair.device), full_bidx
-        ret = dict(num_rays=flat["num_rays"], rays_inds=rinds, rays_bidx=bidx, rays_full_bidx=full_bidx,
-                   full_bidx_map=full_bidx_map, rays_o=flat["rays_o"], rays_d=flat["rays_d"], near=flat["near"],
-                   far=flat["far"])
-        for k, v in extra.items():
-            if isinstance(v, torch.Tensor) and v.shape[:2] == (Bq, N):
-                vf = v.transpose(0, 1).reshape(N * Bq, *v.shape[2:])
-                if vf.requires_grad and vf.dim() == 2 and vf.dtype == torch.float32:
-                    from ..losses import embedding_lookup
-                    ret[k] = embedding_lookup(vf, pair)
-                else:
-                    ret[k] = vf[pair]
-            else:
-                ret[k] = v
-        return ret
-
-    def batched_ray_query(self, *, batched_ray_input: dict = None, batched_ray_tested: dict, config,
-                          return_buffer: bool = True, return_details: bool = False,
-                          render_per_obj_individual: bool = False) -> Dict:
-        """``march_occ_multi_upsample[_compressed]`` on the tested (item, ray) pairs; the volume buffer is packed per
-        pair and carries ``rays_bidx_hit`` / ``rays_full_bidx_hit`` next to ``rays_inds_hit``."""
-        assert self.ins_inds_per_batch is not None, "set_condition() first"
-        bt = batched_ray_tested
-        # The reference conditions the model on the COMPACTED batch -- ``set_condition({'ins_id': [ids of the items
-        # that were hit at all]})`` after ``batched_ray_test(compact_batch=True)`` (buffer_compose_renderer.py:247-258)
-        # -- so the condition is indexed by ``rays_bidx``; a condition given over the full batch by ``rays_full_bidx``
-        # (when every item was hit the two coincide).
-        n_cond = int(self.ins_inds_per_batch.shape[0])
-        if "full_bidx_map" in bt and n_cond == int(bt["full_bidx_map"].shape[0]):
-            which = bt["rays_bidx"]
-        else:
-            which = bt["rays_full_bidx"]
-            if batched_ray_input is not None and batched_ray_input.get("rays_o") is not None:
-                assert n_cond == int(batched_ray_input["rays_o"].shape[0]), \
-                    "set_condition() covers neither the compacted nor the full batch of batched_ray_tested"
-        ins = self.ins_inds_per_batch[which] if bt["num_rays"] > 0 else which
-        goff, woff = self._offsets(ins, which)
-        tested = dict(bt)
-        tested.update(rays_goff=goff.contiguous(), rays_word_off=woff.contiguous())
-        want_pairs = bool(dict(config).get("_render", False))
-        cfg = dict(config, _render=True) if render_per_obj_individual else config
-        if dict(cfg).get("_jitter_full") is not None and bt["num_rays"] > 0:
-            # perturbation randoms given per RAY of the batch ([N], [N, C]; parity tests): a pair uses its ray's
-            cfg = dict(cfg, _jitter=cfg["_jitter_full"][bt["rays_inds"]].contiguous(),
-                       _jitter_c=cfg["_jitter_c_full"][bt["rays_inds"]].contiguous())
-        ret = super().ray_query(ray_input=None, ray_tested=tested, config=cfg, return_buffer=return_buffer,
-                                return_details=return_details, render_per_obj_individual=False)
-        if render_per_obj_individual:
-            # every batch item alone, as [B', N(, 3)] images over all the rays (buffer_compose_renderer.py:268-275 slices
-            # them per object and indexes them with (rays_full_bidx, rays_inds))
-            assert batched_ray_input is not None and batched_ray_input.get("rays_o") is not None, \
-                "render_per_obj_individual needs batched_ray_input (the [B', N, 3] rays)"
-            Bq, N = batched_ray_input["rays_o"].shape[:2]
-            pairs = ret.pop("rendered", None)
-            dev = bt["rays_inds"].device
-            keys = ["mask_volume", "depth_volume"] + (["rgb_volume"] if dict(config).get("with_rgb", True) else []) + \
-                (["normals_volume"] if dict(config).get("with_normal", False) else [])
-            where = (bt["rays_full_bidx"], bt["rays_inds"])
-            full = {}
-            for k in keys:
-                tail = (3,) if k in ("rgb_volume", "normals_volume") else ()
-                z = torch.zeros([Bq, N, *tail], dtype=torch.float32, device=dev)
-                full[k] = z.index_put(where, pairs[k]) if pairs is not None and k in pairs else z
-            ret["rendered"] = full
-            if want_pairs and pairs is not None:
-                ret["rendered_pairs"] = pairs
-        vb = ret["volume_buffer"]
-        if vb["type"] != "empty":
-            vb["rays_bidx_hit"] = bt["rays_bidx"]
-            vb["rays_full_bidx_hit"] = bt["rays_full_bidx"]
-        return ret
-
-    def ray_test(self, *a, **k):
-        raise RuntimeError("BatchedLoTDNeuSModel: use batched_ray_test / batched_ray_query")
 
 
 def num_instances_of(model) -> int:

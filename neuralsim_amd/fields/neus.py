@@ -68,6 +68,18 @@ def append_extra_points(model, rays_o, rays_d, t, ridx, h_appear, extra_x):
     return rays_o, rays_d, t, ridx, h_appear
 
 
+def fine_list(qp: dict):
+    """``num_fine`` per up-sampling stage.  A list names the stages (``num_fine [8, 8, 32]`` with ``upsample_inv_s_factors [1, 4,
+    16]``, lotd_neus.dtu.230814.yaml:150-152); the multi-object configs give ONE number next to two factors (``num_fine: 16,
+    upsample_inv_s_factors: [1, 4]``, all_occ.240201.yaml:481-484): taken as the total, dealt evenly to the stages (the
+    sampler lives in the absent nr3d_lib: semantics fixed here)."""
+    nf = qp.get("num_fine", [8, 8, 32])
+    if isinstance(nf, (list, tuple)):
+        return [int(n) for n in nf]
+    k = max(len(qp.get("upsample_inv_s_factors", [1, 4, 16])), 1)
+    return [max(int(nf) // k, 1)] * k
+
+
 # --------------------------------------------------------------------------------------------- autograd
 
 
@@ -102,6 +114,7 @@ class _FieldFn(torch.autograd.Function):
                 _lib.TIMER.note_units("nsim_field_fwd", S)
             ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
             ctx.grid_numel = grid.numel()
+            ctx.grid16 = None
             ctx.x_shape = None
             ctx.save_for_backward(None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
             ctx.goff = None
@@ -133,6 +146,7 @@ class _FieldFn(torch.autograd.Function):
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
         ctx.grid_numel = grid.numel()
+        ctx.grid16 = grid16        # the table the query read (a grown table of a condition that may be cleaned before the backward)
         ctx.x_shape = x.shape if x is not None else None
         # save_for_backward, not a ctx attribute: without extra points nablas / rgb ARE the outputs, and output -> grad_fn
         # -> ctx -> output would be a reference cycle (the planes of a step, ~150 MB, until the cyclic collector runs)
@@ -166,7 +180,8 @@ class _FieldFn(torch.autograd.Function):
             g_sdf, g_nab = join(g_sdf, ge_s, ()), join(g_nab, ge_n, (3,))
             if g_rgb is not None:
                 g_rgb = join(g_rgb, None, (3,))
-        grid16, wpack = model._shadow()
+        grid16 = ctx.grid16 if ctx.grid16 is not None else model._table16()
+        wpack = model._weight_pack()
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
         need = ctx.needs_input_grad
         dgrid = torch.zeros([ctx.grid_numel], dtype=torch.float32, device=dev) if need[1] else None
@@ -738,6 +753,11 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             object.__setattr__(self, slot, (vers, buf))
         return getattr(self, slot)[1]
 
+    def _per_ray_condition(self) -> bool:
+        """True when the encoding kernels read a per-RAY condition (the conditioned permutohedral model): the sampling pass
+        then hands them the ray index of every sample."""
+        return False
+
     def _table(self) -> torch.Tensor:
         """The flat f32 table the with-grad query differentiates (a model whose tables are GROWN from latents returns the
         generated tensor of the current condition: fields/batched_neus.py)."""
@@ -746,6 +766,16 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def _table16(self) -> torch.Tensor:
         """The fp16 copy of ``_table()`` the gather kernels read."""
         return self.encoding.shadow()
+
+    def _weight_pack(self):
+        """The MFMA-fragment weight pack alone (the backward of a query made under a condition that has been cleaned since
+        -- grown / conditioned tables -- needs the decoders' weights, not the current table)."""
+        if self._wpack_versions is None:
+            object.__setattr__(self, "_wpack_slot", None)
+            object.__setattr__(self, "_wpack_slot_s", None)
+            self._wpack_versions = True
+        self._wpack = self._pack_for(self.field_meta, "_wpack_slot")
+        return self._wpack
 
     def _shadow(self):
         """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
@@ -1083,8 +1113,10 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         with_x = not self._sdf_fused
         # per-sample ray indices (8 B each) are written only where somebody reads them: by the point-major / batched
         # queries on the way, and by the caller at the end (``need_ridx``: the compressed mode re-derives them)
-        fine = [int(n) for n in qp.get("num_fine", [8, 8, 32])]
-        ridx_mid = (not with_x) or goff is not None
+        fine = fine_list(qp)
+        # per-ray state read INSIDE the encoding kernels: instance table offsets (batched LoTD) or a condition per ray (permuto)
+        per_ray = goff is not None or self._per_ray_condition()
+        ridx_mid = (not with_x) or per_ray
         ridx = torch.empty([S], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and not fine)) else None
         xq = torch.empty([S, 3], **f32) if with_x else None
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
@@ -1095,7 +1127,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             fm_s, wpack = self._sampling_ctx()
         collect = with_x and goff is None and self.accel.collect_armed       # fused into the decoder launches below
         if with_x:
-            sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if goff is not None else None, S, dev,
+            sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if per_ray else None, S, dev,
                                   goff=goff, n_dev=n_dev, n_add=R * C, collect=collect, fm=fm_s)
         else:
             sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
@@ -1110,7 +1142,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                       _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new))
             ridx_new = self._arange_repeat(R, nf, dev)
             if with_x:
-                sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if goff is not None else None,
+                sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if per_ray else None,
                                           R * nf, dev, goff=goff, collect=collect, fm=fm_s)
             else:
                 sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
@@ -1271,7 +1303,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                     t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre, tail=tail)
                     M_true = int(total_m.item())
                 if M_true is None:
-                    M_true = int(sdf_ng.shape[0]) - R * (int(qp.get("num_coarse", 64)) + sum(int(n) for n in qp.get("num_fine", [8, 8, 32])))
+                    M_true = int(sdf_ng.shape[0]) - R * (int(qp.get("num_coarse", 64)) + sum(fine_list(qp)))
                 self._march_stat = (R, M_true)
                 if _lib.TIMER is not None and cap is not None:    # the first query's true size, now that it is known
                     S0 = M_true + R * int(qp.get("num_coarse", 64))

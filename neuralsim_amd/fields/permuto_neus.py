@@ -139,6 +139,7 @@ class PermutoNeuSModel(LoTDNeuSModel):
         self._z_rays = None
         self._z_src = None          # the caller's z when it requires grad (learned codes): see _ZTapFn
         self._dz_acc = {}
+        self._z_fwd = {}            # condition of the recent with-grad queries, keyed by their sample arrays (see _remember_z)
         if device is not None:
             self.to(device)
 
@@ -146,8 +147,8 @@ class PermutoNeuSModel(LoTDNeuSModel):
     def set_condition(self, z: Optional[torch.Tensor]):
         """z [R, z_dim] per ray of the next queries, [1, z_dim] / [z_dim] for all of them, None = zeros.
         A z that requires grad (the auto-decoder's learned codes, ``z_ins_all`` of AD_GenerativePermutoConcatNeuSObj)
-        receives d L / d z from every with-grad query made under this condition (``nsim_permuto_dz``); the condition must
-        still be set when ``backward`` runs (the kernels re-read z there, as they re-read the rays)."""
+        receives d L / d z from every with-grad query made under this condition (``nsim_permuto_dz``).  The backward of a
+        query uses the condition it was MADE under (``_remember_z``), whatever has been set since."""
         self._z_src = None
         if z is not None:
             assert self.z_dim > 0 and z.shape[-1] == self.z_dim
@@ -158,6 +159,9 @@ class PermutoNeuSModel(LoTDNeuSModel):
 
     def clean_condition(self):
         self.set_condition(None)
+
+    def _per_ray_condition(self) -> bool:
+        return self.z_dim > 0 and self._z_rays is not None and int(self._z_rays.shape[0]) != 1
 
     def _table(self):
         p = self.encoding.flattened_params
@@ -177,11 +181,24 @@ class PermutoNeuSModel(LoTDNeuSModel):
                 ridx = torch.zeros([S], dtype=torch.long, device=dev)
         return z, ridx
 
+    def _remember_z(self, key: torch.Tensor, z, zr):
+        """The backward kernels re-read z as they re-read the rays; the condition may have changed by then (a batched query
+        sets per-pair codes, the next query others).  Keyed by the query's per-sample array that ``_FieldFn`` saves."""
+        if key is None or z is None:
+            return
+        if len(self._z_fwd) >= 16:
+            self._z_fwd.pop(next(iter(self._z_fwd)))
+        self._z_fwd[(key.data_ptr(), tuple(key.shape))] = (z, zr, self._z_src)
+
+    def _recall_z(self, key: torch.Tensor):
+        return self._z_fwd.pop((key.data_ptr(), tuple(key.shape)), None) if key is not None else None
+
     # ---------------------------------------------------------------- encoding hooks (csrc/permuto.hip)
     def _enc_field_fwd(self, grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, n_dev,
                        n_add):
         assert goff is None and h_pl is not None
         z, zr = self._z_for(ridx, rays_o, S, sdf.device)
+        self._remember_z(ridx if ridx is not None else (x if x is not None else t), z, zr)
         _lib.call("nsim_permuto_gather", self.encoding.cfg.pmeta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(n_dev), int(n_add), None, 0,
                   _lib.ptr(h_pl), _lib.ptr(J_pl))
@@ -198,15 +215,20 @@ class PermutoNeuSModel(LoTDNeuSModel):
                   int(fm.precision != 0), None, None)
 
     def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid):
-        z, zr = self._z_for(ridx, rays_o, S, dgrid.device)
+        rec = self._recall_z(ridx if ridx is not None else (x if x is not None else t))
+        z_src = self._z_src
+        if rec is not None:
+            z, zr, z_src = rec
+        else:
+            z, zr = self._z_for(ridx, rays_o, S, dgrid.device)
         _lib.call("nsim_permuto_scatter", self.encoding.cfg.pmeta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(gn_total),
                   _lib.ptr(dgrid))
-        if z is not None and self._z_src is not None:         # learned condition: d L / d z of these samples
+        if z is not None and z_src is not None:         # learned condition: d L / d z of these samples
             dz = torch.zeros_like(z)
             _lib.call("nsim_permuto_dz", self.encoding.cfg.pmeta, _lib.ptr(self.encoding.shadow()), _lib.ptr(x), _lib.ptr(rays_o),
                       _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(dz))
-            k = id(self._z_src)
+            k = id(z_src)
             prev = self._dz_acc.get(k)
             if prev is not None and prev.shape != dz.shape:          # a shared [1, z_dim] condition seen through two ray counts
                 prev, dz = prev.sum(0, keepdim=True), dz.sum(0, keepdim=True)

@@ -6,7 +6,24 @@ import torch.nn as nn
 
 
 class Embedding(nn.Embedding):
-    pass
+    """``Embedding(num_objs, dim=, weight_init=, dtype=, device=)`` -- the auto-decoder's latent table
+    (app/models/shared/batched_neus.py:108: ``Embedding(self.num_objs, **self.latents_cfg['z_ins'], dtype=torch.float,
+    device=device)`` with ``latents_cfg{z_ins{dim, weight_init: zero | normal | uniform}}``, all_occ.240201.yaml:428-431)."""
+
+    def __init__(self, num_embeddings: int, dim: int = None, weight_init=None, embedding_dim: int = None, dtype=torch.float32,
+                 device=None, std: float = None, **unused):
+        d = int(dim if dim is not None else embedding_dim)
+        super().__init__(int(num_embeddings), d, device=device, dtype=dtype if isinstance(dtype, torch.dtype) else torch.float32)
+        wi = weight_init if isinstance(weight_init, (str, type(None))) else dict(weight_init).get("type")
+        with torch.no_grad():
+            if wi in ("zero", "zeros"):
+                self.weight.zero_()
+            elif wi in (None, "normal"):
+                self.weight.normal_(0.0, float(std) if std is not None else 1.0 / (d ** 0.5))
+            elif wi == "uniform":
+                self.weight.uniform_(-1.0 / (d ** 0.5), 1.0 / (d ** 0.5))
+            else:
+                raise NotImplementedError(f"Embedding.weight_init={weight_init!r}: zero | normal | uniform")
 
 
 class SeqEmbedding(nn.Module):

@@ -1,0 +1,205 @@
+"""``nr3d_lib.models.fields_conditional.neus`` (reference import: app/models/shared/batched_neus.py:30) -- the latent-
+conditioned NeuS models behind the shared foreground classes of code_multi, built on this repository's batched kernels:
+
+* ``StyleLoTDNeuSModel`` -> ``neuralsim_amd.fields.batched_neus.BatchedLoTDNeuSModel`` grown from latents
+  (``lotd_grower_cfg``: dense + vector-matrix levels, neuralsim_amd/grid_encodings/lotd_growers.py);
+  reference classes ``StyleLoTDNeuSObj`` / ``AD_StyleLoTDNeuSObj`` (app/models/shared/batched_neus.py:34-160; config block
+  code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml:307-390).
+* ``GenerativePermutoConcatNeuSModel`` -> ``neuralsim_amd.fields.batched_permuto_neus.BatchedPermutoNeuSModel`` (the latent is
+  concatenated to the position, one shared permutohedral table); reference class ``AD_GenerativePermutoConcatNeuSObj``
+  (:295-407; config block fg_neus=permuto/all_occ.240201.yaml:425-506).
+* ``StyleNeuSLXYModel``: importable name only (an MLP-modulated variant no config of the reference uses).
+
+Life cycle the reference classes drive (MRO ``AutoDecoderMixin, AssetMixin, <this model>``):
+``Model(**model_params, device=)`` with ``.latents_cfg`` / ``.accel_cfg`` readable and mutable afterwards ->
+``asset_populate``: ``self.accel_cfg.update(num_batches=, resolution=)``, ``autodecoder_populate(...)`` and then
+``super().populate(n_latent_dim=, device=)`` -- which is where the network is actually built (the instance count is not
+known before) -> ``super().training_initialize(config=, logger=, log_prefix=, skip_accel=True)`` ->
+``super().set_condition(z=, ins_inds_per_batch=)`` / ``super().clean_condition()`` around every batched query.
+The implementation of these classes lives in the absent nr3d_lib: signatures are the call sites', semantics fixed here."""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from neuralsim_amd.fields.batched_neus import BatchedLoTDNeuSModel
+from neuralsim_amd.fields.batched_permuto_neus import BatchedPermutoNeuSModel
+from neuralsim_amd.fields import ref_config
+
+
+def _plain(v):
+    if hasattr(v, "to_dict"):
+        v = v.to_dict()
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    return v
+
+
+class _DeferredConditionalModel:
+    """Construction in two steps (see the module docstring): ``__init__`` keeps the YAML block, ``populate`` builds."""
+
+    def _defer(self, model_params: dict, device):
+        nn.Module.__init__(self)
+        p = dict(model_params)
+        from nr3d_lib.config import ConfigDict
+        # read and UPDATED by the reference's asset_populate before the build (batched_neus.py:104-119, 352-377)
+        self.latents_cfg = ConfigDict(**_plain(p.pop("latents_cfg", None) or {}))
+        acc = p.pop("accel_cfg", None)
+        self.accel_cfg = ConfigDict(**_plain(acc)) if acc is not None else None
+        self.ray_query_cfg = _plain(p.pop("ray_query_cfg", None) or {})
+        self._cond_params, self._pending_device, self._built = p, device, False
+        self.accel = None
+
+    @property
+    def device(self):
+        if getattr(self, "_built", False):
+            return self.sdf_w.device
+        return torch.device(self._pending_device) if self._pending_device is not None else torch.device("cpu")
+
+    def _keep_registered(self, build):
+        """``build()`` runs the real constructor, which re-initialises the nn.Module registries: what was registered before
+        (the auto-decoder's ``_latents``) is put back."""
+        mods = dict(self._modules)
+        keep = {k: self.__dict__[k] for k in ("_index_maps", "_keys") if k in self.__dict__}      # autodecoder_populate's maps
+        build()
+        for k, v in mods.items():
+            if k not in self._modules:
+                self._modules[k] = v
+        self.__dict__.update(keep)
+        self._built = True
+
+    def _latent_params(self):
+        lat = self._modules.get("_latents")
+        return list(lat.parameters()) if lat is not None else []
+
+    def _latent_dim(self, n_latent_dim: Optional[int]) -> int:
+        if n_latent_dim is not None:
+            return int(n_latent_dim)
+        return sum(int(v.get("dim", 0)) for v in _plain(self.latents_cfg).values())
+
+
+class StyleLoTDNeuSModel(_DeferredConditionalModel, BatchedLoTDNeuSModel):
+    def __init__(self, device=None, **model_params):
+        self._defer(model_params, device)
+
+    def populate(self, n_latent_dim: int = None, device=None, num_instances: int = None, seed: int = 42, **unused):
+        p = dict(self._cond_params)
+        sc = dict(_plain(p.get("surface_cfg") or {}))
+        grower_cfg = sc.pop("lotd_grower_cfg", None)
+        if grower_cfg is None:
+            raise NotImplementedError("StyleLoTDNeuSModel needs surface_cfg.lotd_grower_cfg")
+        epe = sc.pop("extra_pos_embed_cfg", None)
+        if epe is not None and epe.get("type", "identity") not in ("identity", None):
+            # [grown features | embedded position] as the decoder's input: with the config's 8 grown levels x 4 features (32)
+            # + sinusoidal_legacy-6 (39) that is 71 inputs; the fused decoders contract over at most 64 (csrc/field.hip: NC <= 2)
+            raise NotImplementedError(f"surface_cfg.extra_pos_embed_cfg={epe!r}: the fused SDF decoder reads the grown features "
+                                      f"only (<= 64 inputs)")
+        # the encoding of this model IS the grower: hand the decoder / radiance / control blocks to the common translation
+        sc["encoding_cfg"] = dict(lotd_cfg=dict(lod_res=[2], lod_n_feats=2, hashmap_size=16))
+        acc = _plain(self.accel_cfg) if self.accel_cfg is not None else None
+        B = int(num_instances if num_instances is not None else (acc or {}).get("num_batches", 1))
+        acc_native = None
+        if acc is not None:
+            if acc.get("type", "occ_grid_batched") not in ("occ_grid_batched", "occ_grid_batched_ema"):
+                raise NotImplementedError(f"accel_cfg.type={acc.get('type')!r}: occ_grid_batched")
+            acc_native = {k: v for k, v in acc.items() if k not in ("type", "num_batches")}
+        params = dict(p, surface_cfg=sc, accel_cfg=None, ray_query_cfg=self.ray_query_cfg or None)
+        kw, post = ref_config.neus_native_kwargs(params)
+        for k in ("lod_res", "log2_hashmap_size", "accel_cfg"):
+            kw.pop(k, None)
+        kw.pop("param_bound", None)
+        z_dim = self._latent_dim(n_latent_dim)
+        dev = device if device is not None else self._pending_device
+
+        def build():
+            BatchedLoTDNeuSModel.__init__(self, B, lotd_grower_cfg=grower_cfg, latents_cfg=dict(z=dict(dim=z_dim)),
+                                          own_latents=False, accel_cfg=acc_native or {}, seed=seed, **kw)
+        self._keep_registered(build)
+        self._reference_post = post
+        if acc is None:
+            self.accel_disabled = True       # ``accel_cfg: null``: every voxel counts as occupied
+            self.accel.set_all_occupied()
+        if dev is not None:
+            self.to(dev)
+        return self
+
+    # ------------------------------------------------------------------ conditions (batched_neus.py:126-160)
+    def set_condition(self, z: torch.Tensor = None, ins_inds_per_batch: torch.Tensor = None):
+        assert z is not None, "StyleLoTDNeuSModel.set_condition needs the codes of the batch (z)"
+        infos = {"z_ins": z}
+        if ins_inds_per_batch is not None:
+            infos["ins_ind"] = ins_inds_per_batch
+        self._set_condition_grown(infos)
+
+    def clean_condition(self):
+        BatchedLoTDNeuSModel.clean_condition(self)
+
+    def _param_groups(self, cfg: dict):
+        groups = BatchedLoTDNeuSModel._param_groups(self, cfg)
+        lat = self._latent_params()
+        return ([dict(name="latents", params=lat)] if lat else []) + groups
+
+    @torch.no_grad()
+    def training_initialize(self, config=None, logger=None, log_prefix=None, skip_accel: bool = False) -> bool:
+        """Pre-training of the generator (app/models/shared/batched_neus.py:121-130 ``training_initialize(..., skip_accel=True)``
+        followed by the caller's all-instance ``accel.init``): the SDF of codes drawn around the registered ones is fitted to
+        a sphere of ``radius_init`` (Adam over grower + SDF decoder through the model's own kernels); ``initialize_cfg{num_iters,
+        lr, num_pts, z_std}``."""
+        cfg = dict(config or {})
+        updated = False
+        if not bool(self.is_pretrained):
+            post = getattr(self, "_reference_post", {})
+            half = float((self.accel.aabb[1] - self.accel.aabb[0]).min()) / 2.0
+            r = min(float(post.get("radius_init", 0.5 * half)) / half, 0.95)
+            with torch.enable_grad():
+                self.pretrain_generator_sphere(r, num_iters=int(cfg.get("num_iters", 200)), lr=float(cfg.get("lr", 1e-3)),
+                                               num_pts=int(cfg.get("num_pts", 2 ** 12)), z_std=float(cfg.get("z_std", 0.1)),
+                                               logger=logger)
+            updated = True
+        if not skip_accel and self.accel is not None and self.ins_inds_per_batch is not None:
+            self.accel.init(lambda pts, b: self.query_sdf(pts, ins_ind=b), logger=logger)
+        return updated
+
+
+class GenerativePermutoConcatNeuSModel(_DeferredConditionalModel, BatchedPermutoNeuSModel):
+    def __init__(self, device=None, **model_params):
+        self._defer(model_params, device)
+
+    def populate(self, n_latent_dim: int = None, device=None, num_instances: int = None, seed: int = 42, **unused):
+        p = dict(self._cond_params)
+        acc = _plain(self.accel_cfg) if self.accel_cfg is not None else None
+        B = int(num_instances if num_instances is not None else (acc or {}).get("num_batches", 1))
+        if acc is not None and acc.get("type", "occ_grid_batched") not in ("occ_grid_batched", "occ_grid_batched_ema"):
+            raise NotImplementedError(f"accel_cfg.type={acc.get('type')!r}: occ_grid_batched")
+        acc_native = {k: v for k, v in (acc or {}).items() if k not in ("type", "num_batches")}
+        z_dim = self._latent_dim(n_latent_dim)
+        dev = device if device is not None else self._pending_device
+
+        def build():
+            BatchedPermutoNeuSModel.__init__(self, B, z_dim=z_dim, accel_cfg=acc_native, ray_query_cfg=self.ray_query_cfg or None,
+                                             seed=seed, **_plain(p))
+        self._keep_registered(build)
+        if acc is None:
+            self.accel.set_all_occupied()
+        if dev is not None:
+            self.to(dev)
+        return self
+
+    def set_condition(self, z: torch.Tensor = None, ins_inds_per_batch: torch.Tensor = None):
+        BatchedPermutoNeuSModel.set_condition(self, z=z, ins_inds_per_batch=ins_inds_per_batch)
+
+    def clean_condition(self):
+        BatchedPermutoNeuSModel.clean_condition(self)
+
+    def _param_groups(self, cfg: dict):
+        groups = BatchedPermutoNeuSModel._param_groups(self, cfg)
+        lat = self._latent_params()
+        return ([dict(name="latents", params=lat)] if lat else []) + groups
+
+
+class StyleNeuSLXYModel:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("StyleNeuSLXYModel: no configuration of the reference uses it; StyleLoTDNeuSModel and "
+                                  "GenerativePermutoConcatNeuSModel are built")

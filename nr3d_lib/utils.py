@@ -105,6 +105,14 @@ def check_to_torch(x, ref: torch.Tensor = None, dtype=None, device=None) -> torc
     return torch.tensor(x, dtype=dtype, device=device)
 
 
+def check_per_batch_tensors(*tensors) -> int:
+    """``batch_size = check_per_batch_tensors(ins_inds_per_batch, z_ins_per_batch)`` (app/models/shared/batched_neus.py:154):
+    the common leading size of the per-batch-item tensors that are given (None entries are skipped)."""
+    sizes = {int(t.shape[0]) for t in tensors if t is not None}
+    assert len(sizes) <= 1, f"per-batch tensors differ in their leading size: {sorted(sizes)}"
+    return sizes.pop() if sizes else 0
+
+
 def get_shape(x) -> List[int]:
     """Shape of a tensor / array / nested list; [] for scalars and None."""
     if x is None or isinstance(x, numbers.Number):
@@ -287,4 +295,4 @@ def load_rgb(path: str, downscale: float = 1.0):
     raise NotImplementedError("image files: the synthetic datasets of this repository render their images analytically")
 
 
-load_mask = cpu_resize = crop_image = check_per_batch_tensors = load_rgb
+load_mask = cpu_resize = crop_image = load_rgb

@@ -537,14 +537,15 @@ def reference_model_wrapper_modules():
         del sys.modules[k]
     classes = {n: type(n, (_Named,), {}) for n in ("Scene", "SceneNode", "Camera")}
     pk = {}
-    for n in ("app", "app.models", "app.models.single", "app.loss"):
+    for n in ("app", "app.models", "app.models.single", "app.models.shared", "app.loss"):
         pk[n] = _stub_module(n)
         pk[n].__path__ = []
     sys.modules.update(pk)
     sys.modules.update({
         "app.resources": _stub_module("app.resources", Scene=classes["Scene"], SceneNode=classes["SceneNode"]),
         "app.resources.observers": _stub_module("app.resources.observers", Camera=classes["Camera"]),
-        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", check_to_torch=lambda x, **k: torch.as_tensor(x)),
+        "nr3d_lib.utils": _stub_module("nr3d_lib.utils", check_to_torch=lambda x, dtype=None, device=None, **k: torch.as_tensor(x, dtype=dtype, device=device),
+                                       check_per_batch_tensors=__import__("nr3d_lib.utils", fromlist=["x"]).check_per_batch_tensors),
         "nr3d_lib.models.embedders": _stub_module("nr3d_lib.models.embedders", get_embedder=None),
         "nr3d_lib.models.attributes": _stub_module("nr3d_lib.models.attributes", TransformMat4x4=None),
     })
@@ -553,6 +554,7 @@ def reference_model_wrapper_modules():
         for name, rel in (("app.models.asset_base", "app/models/asset_base.py"),
                           ("app.models.single.neus", "app/models/single/neus.py"),
                           ("app.models.single.nerf", "app/models/single/nerf.py"),
+                          ("app.models.shared.batched_neus", "app/models/shared/batched_neus.py"),
                           ("app.loss.clearance", "app/loss/clearance.py"),
                           ("app.loss.weight_reg", "app/loss/weight_reg.py")):
             spec = importlib.util.spec_from_file_location(name, str(REF_ROOT / rel))
@@ -565,6 +567,10 @@ def reference_model_wrapper_modules():
             for n in mods[m].__all__:
                 if hasattr(mods[m], n):
                     setattr(pk["app.models.single"], n, getattr(mods[m], n))
+        # ``model_class: app.models.shared.AD_GenerativePermutoConcatNeuSObj`` (app/models/shared/__init__.py star-imports)
+        for n in mods["app.models.shared.batched_neus"].__all__:
+            if hasattr(mods["app.models.shared.batched_neus"], n):
+                setattr(pk["app.models.shared"], n, getattr(mods["app.models.shared.batched_neus"], n))
         mods["classes"] = classes
         yield mods
     finally:

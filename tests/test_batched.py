@@ -354,3 +354,81 @@ def test_mixed_grower_model_queries_match_the_oracle(backend):
     ((out["sdf"] * w.to(backend)).sum() + 0.1 * (out["nablas"] ** 2).sum()).backward()
     assert rel_l2(z.grad.cpu(), z_o.grad) < 5e-3, rel_l2(z.grad.cpu(), z_o.grad)
     m.clean_condition()
+
+
+def test_batched_permuto_model_matches_per_instance_oracle(backend):
+    """Rows a20 / f4: ``BatchedPermutoNeuSModel`` (the network of AD_GenerativePermutoConcatNeuSObj, all_occ.240201.yaml:425-506)
+    -- ONE permutohedral table, a latent per batch item concatenated to the position, per-instance occupancy grids --
+    through ``set_condition(z=, ins_inds_per_batch=)`` -> ``batched_ray_test`` -> ``batched_ray_query``: rendered colours, the
+    loss, and the gradients of the table, the decoders and the CODES (learned: d L / d z, nsim_permuto_dz) against the
+    single-object oracle run once per item with that item's code.  The condition is changed between forward and backward: the
+    backward uses the codes the query was made under."""
+    from oracle import field as ofield, permuto as operm
+    from neuralsim_amd.fields.batched_permuto_neus import BatchedPermutoNeuSModel
+    B, N, ZD, L = 3, 24, 4, 6
+    pcfg = dict(type="multi_res", n_levels=L, n_feats=2, log2_hashmap_size=11, coarsest_res=2.0, finest_res=16.0,
+                apply_random_shifts_per_level=True, seed=5)
+    m = BatchedPermutoNeuSModel(B, z_dim=ZD, ins_ids=[f"car{b}" for b in range(B)], permuto_auto_compute_cfg=pcfg, sdf_D=1,
+                                precision="f32", param_bound=0.4, seed=9, ln_inv_s_init=0.3, accel_cfg=dict(resolution=[8, 8, 8]))
+    with torch.no_grad():
+        m.sdf_b[-1] = -0.05
+        m.sdf_b.add_(0)
+    m = m.to(backend)
+    m.accel.set_all_occupied()
+    assert m.accel.num_batches == B and m.encoding.cfg.permuto.in_dim == 3 + ZD
+    spec = operm.make_permuto_spec(in_dim=3 + ZD, **{k: v for k, v in pcfg.items() if k != "type"})
+    p = ofield.make_field_params(lod_res=[2] * L, log2_hashmap_size=4, sdf_D=1, seed=1, sphere_init=False)
+    p.spec = spec
+    p.grid = m.encoding.flattened_params.detach().cpu().clone().half().float()
+    F1 = 2 * L
+    sw, sb = m.sdf_w.detach().cpu().clone(), m.sdf_b.detach().cpu().clone()
+    p.sdf_w, p.sdf_b = [sw[:64 * F1].view(64, F1).clone(), sw[64 * F1:].view(1, 64).clone()], [sb[:64].clone(), sb[64:].clone()]
+    rw, rb = m.rad_w.detach().cpu().clone(), m.rad_b.detach().cpu().clone()
+    p.rad_w = [rw[:64 * 26].view(64, 26).clone(), rw[64 * 26:64 * 26 + 4096].view(64, 64).clone(), rw[64 * 26 + 4096:].view(3, 64).clone()]
+    p.rad_b = [rb[:64].clone(), rb[64:128].clone(), rb[128:].clone()]
+    p.ln_inv_s = m.ln_inv_s.detach().cpu().clone()
+    p.aabb = m.accel.aabb.detach().cpu().clone()
+    for t_ in p.tensors():
+        t_.requires_grad_(True)
+    cond = [2, 0]
+    o, d, g = _rays(len(cond), N)
+    ha = torch.randn(len(cond), N, 4, generator=g) * 0.3
+    z0 = torch.randn(len(cond), ZD, generator=g) * 0.4
+    z_o = z0.clone().requires_grad_(True)
+    z_d = z0.clone().to(backend).requires_grad_(True)
+    dv = lambda a: a.to(backend).contiguous()        # noqa: E731
+    qp = dict(QP, num_fine=16, upsample_inv_s_factors=[1, 4])            # one number, two stages (all_occ.240201.yaml:481-484)
+    occ = torch.ones(8 ** 3, dtype=torch.bool)
+    kw = dict(near=0.01, far=None, num_coarse=16, num_fine=(8, 8), step_size=0.02, max_steps=512, depth_use_normalized_vw=False,
+              upsample_inv_s_factors=(1, 4))
+    wgt = torch.rand(len(cond), N, 3, generator=g)
+    loss_o, outs = 0.0, []
+    for k in range(len(cond)):
+        p.z = z_o[k:k + 1]
+        r = orr.ray_query(p, o[k], d[k], ha[k], occ, AABB[0], AABB[1], [8, 8, 8], **kw)
+        outs.append(r)
+        if r["num_rays"] > 0:
+            loss_o = loss_o + (r["rendered"]["rgb_volume"] * wgt[k][r["rays_inds"]]).sum() + \
+                0.1 * ((r["volume_buffer"]["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
+    loss_o.backward()
+    m.set_condition(z=z_d, ins_inds_per_batch=torch.tensor(cond))
+    bt = m.batched_ray_test(dv(o), dv(d), near=0.01, far=None, compact_batch=False, rays_h_appear=dv(ha))
+    ret = m.batched_ray_query(batched_ray_tested=bt, config=dict(query_param=qp, with_rgb=True, with_normal=True,
+                                                                 depth_use_normalized_vw=False, _render=True,
+                                                                 query_mode="march_occ_multi_upsample"))
+    assert bt["num_rays"] == sum(r["num_rays"] for r in outs) > 0
+    w_pairs = dv(wgt)[bt["rays_full_bidx"], bt["rays_inds"]]
+    loss = (ret["rendered"]["rgb_volume"] * w_pairs).sum() + 0.1 * ((ret["volume_buffer"]["nablas"].norm(dim=-1) - 1.0) ** 2).sum()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 3e-4 * (1 + abs(float(loss_o.detach())))
+    # point queries of the condition's items, then ANOTHER condition -- and only then the backward of the batched query
+    x = torch.rand(30, 3, generator=g) * 1.2 - 0.6
+    q1 = m.query_sdf(dv(x), ins_ind=0).cpu()                 # instance 0 = batch item 1
+    p.z = z_o.detach()[1:2]
+    assert (q1 - ofield.forward_sdf(x, p).detach()).abs().max() < 1e-4
+    m.set_condition(z=torch.zeros(1, ZD, device=backend), ins_inds_per_batch=torch.tensor([1]))
+    loss.backward()
+    m.clean_condition()
+    assert rel_l2(z_d.grad.cpu(), z_o.grad) < 5e-3, rel_l2(z_d.grad.cpu(), z_o.grad)
+    assert rel_l2(m.encoding.flattened_params.grad.cpu(), p.grid.grad) < 5e-3
+    assert rel_l2(m.sdf_w.grad.cpu(), torch.cat([w.grad.reshape(-1) for w in p.sdf_w])) < 5e-3
+    assert rel_l2(m.rad_w.grad.cpu(), torch.cat([w.grad.reshape(-1) for w in p.rad_w])) < 5e-3
