@@ -103,7 +103,11 @@ __host__ __device__ inline SrcOff src_off(int D, int F1 = 32) {
 // main accumulator, hi.lo + lo.hi into a correction accumulator that is folded in with 1 / SPLIT_LO_SCALE), the
 // dropped lo.lo term is 2^-22 relative.  The scale keeps the residuals out of the f16 subnormals.
 #define SPLIT_LO_SCALE 2048.0f
+// (saturating: a feature beyond the f16 range -- a street table holds heights in metres, x SDF_H_SCALE -- becomes +-65504, a
+// point that far from every surface, instead of inf and then NaN through the products)
+__device__ __forceinline__ float f16_sat(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
 __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
+  v = f16_sat(v);
   hi = (f16)v;
   lo = (f16)((v - (float)hi) * SPLIT_LO_SCALE);
 }
@@ -1436,8 +1440,8 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
             uint32_t u;
             f16 h[2];
           } cv;
-          cv.h[0] = (f16)(f0[q] * SDF_H_SCALE);
-          cv.h[1] = (f16)(f1[q] * SDF_H_SCALE);
+          cv.h[0] = (f16)f16_sat(f0[q] * SDF_H_SCALE);
+          cv.h[1] = (f16)f16_sat(f1[q] * SDF_H_SCALE);
           reinterpret_cast<uint32_t*>(a.feat_pl)[e] = cv.u;
         } else {
           reinterpret_cast<float*>(a.feat_pl)[2 * e] = f0[q];
@@ -1599,7 +1603,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
           bv = bvp;
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bv[e] = (f16)(f8[e] * SDF_H_SCALE);
+          for (int e = 0; e < 8; ++e) bv[e] = (f16)f16_sat(f8[e] * SDF_H_SCALE);
         }
         const f16x8* A = reinterpret_cast<const f16x8*>(W + L.mat[M_W1]);
 #pragma unroll

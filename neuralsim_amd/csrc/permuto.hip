@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
         uint32_t u;
         f16 h[2];
       } cv;
-      cv.h[0] = (f16)(f0 * PERMUTO_SDF_H_SCALE);
-      cv.h[1] = (f16)(f1 * PERMUTO_SDF_H_SCALE);
+      cv.h[0] = (f16)fminf(fmaxf(f0 * PERMUTO_SDF_H_SCALE, -65504.0f), 65504.0f);
+      cv.h[1] = (f16)fminf(fmaxf(f1 * PERMUTO_SDF_H_SCALE, -65504.0f), 65504.0f);
       reinterpret_cast<uint32_t*>(a.feat_pl)[e] = cv.u;
     }
   } else {

@@ -663,7 +663,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 self.pretrain_sdf_sphere(min(r, 0.95), num_iters=int(cfg_i.get("num_iters", 500)), lr=float(cfg_i.get("lr", 2e-3)),
                                          num_pts=int(cfg_i.get("num_pts", 2 ** 14)), logger=logger)
             else:       # default: the deterministic write (exact sphere, no iterations)
-                self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25)
+                self.geometric_init_sphere(min(r, 0.95), noise_scale=0.25, level=self._geo_init_level())
             self.is_pretrained.fill_(True)
             updated = True
         if self.accel is not None:
@@ -721,6 +721,20 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         only the first n levels are read / trained; None or >= 16 = all."""
         self.encoding.cfg.set_active_levels(n)
         self.field_meta.lotd.n_active_levels = self.encoding.cfg.meta.n_active_levels
+
+    def _geo_init_level(self) -> Optional[int]:
+        """The level a deterministic geometric initialisation is written to: the finest dense level that is ACTIVE at
+        iteration 0.  With ``encoding_cfg.anneal_cfg{type: hardmask, start_level}`` (lotd_neus.dtu.230814.yaml:104-108,
+        withmask_withlidar_joint.240219.yaml:168-172) only levels <= start_level are read when training starts: a sphere /
+        road written into a finer level would be invisible until the annealing reaches it (the reference pre-trains THROUGH
+        the mask -- ``pretrain_after_zero_out`` -- so its initial geometry lives in the active levels as well).  None: no
+        annealing configured, the finest dense level."""
+        an = (getattr(self, "_reference_post", None) or {}).get("anneal")
+        if an is None:
+            return None
+        cfg = self.encoding.cfg
+        dense = [l for l, t in enumerate(cfg.lod_types) if t == "Dense" and l <= int(an.get("start_level", 2))]
+        return max(dense) if dense else None
 
     def anneal_levels(self, it: int, start_it: int = 0, stop_it: int = 1000, start_level: int = 2):
         """Level l is active once it >= start_it + (l - start_level) / (L - 1 - start_level) * (stop_it - start_it)

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 __all__ = ["Attr", "AttrNested", "ObjectWithAttr", "Valid", "Scalar", "Scale", "Vector_3", "Vector_4", "make_vector",
            "Translation", "TransformMat4x4", "TransformMat3x4", "TransformRT", "RotationMat3x3", "CameraMatrix3x3",
+           "RotationQuaternion", "RotationQuaternionRefinedAdd", "TranslationRefinedAdd", "ScalarRefinedAdd",
            "CameraBase", "PinholeCameraMatHW", "OpenCVCameraMatHW", "FisheyeCameraMatHW", "OrthoCameraIntrinsics",
            "check_to_torch"]
 
@@ -108,7 +109,12 @@ class Attr(nn.Module):
         return self._like(t.expand(*tuple(prefix), *t.shape[len(self.prefix):]).contiguous())
 
     def take_along_dim(self, idx: torch.Tensor, dim: int = 0):
-        return self._like(self.tensor.index_select(dim, idx.reshape(-1)).reshape(*idx.shape, *self.tensor.shape[dim + 1:]))
+        """``torch.take_along_dim`` on the prefix: ``idx`` has the rank of the prefix (``stacked.take_along_dim(li.unsqueeze(0),
+        dim=0)[0]`` picks, for every frozen frame, the sensor ``li`` names -- observers/lidars.py:158, cameras.py:494)."""
+        t = self.tensor
+        tail = t.shape[idx.dim():]
+        ie = idx.reshape(*idx.shape, *([1] * len(tail))).expand(*idx.shape, *tail)
+        return self._like(torch.take_along_dim(t, ie, dim=dim))
 
     def interp1d(self, ts_keyframes: torch.Tensor, ts: torch.Tensor):
         """Piecewise-linear interpolation of the per-keyframe values at timestamps ``ts`` (nodes.py:513-518); values
@@ -223,16 +229,26 @@ class TransformMat4x4(Attr):
     def translation(self) -> torch.Tensor:
         return self.tensor[..., :3, 3]
 
+    @staticmethod
+    def _over_points(M: torch.Tensor, x: torch.Tensor, tail: int) -> torch.Tensor:
+        """x [*prefix, *points, 3] against an attribute of prefix [*prefix]: singleton dims for the point dims (the frustum
+        corners of every frame, cameras.py:166-175: pts [F, 8, 3] through a world transform of prefix [F])."""
+        extra = (x.dim() - 1) - (M.dim() - tail)
+        if extra > 0 and M.dim() > tail:
+            M = M.reshape(*M.shape[:M.dim() - tail], *([1] * extra), *M.shape[M.dim() - tail:])
+        return M
+
     def rotate(self, x: torch.Tensor, inv: bool = False) -> torch.Tensor:
         R = self.rotation()
         if inv:
             R = R.transpose(-1, -2)
-        return (R * x.unsqueeze(-2)).sum(-1)            # broadcast-multiply-sum (cameras.py:355-359)
+        return (self._over_points(R, x, 2) * x.unsqueeze(-2)).sum(-1)            # broadcast-multiply-sum (cameras.py:355-359)
 
     def forward(self, x: torch.Tensor, inv: bool = False) -> torch.Tensor:
+        t = self._over_points(self.translation(), x, 1)
         if inv:
-            return self.rotate(x - self.translation(), inv=True)
-        return self.rotate(x) + self.translation()
+            return self.rotate(x - t, inv=True)
+        return self.rotate(x) + t
 
 
 class TransformMat3x4(TransformMat4x4):
@@ -425,6 +441,23 @@ class CameraBase(AttrNested):
         o.downscale = self.downscale
         return o
 
+    @classmethod
+    def stack(cls, cams: List["CameraBase"], dim: int = 0):
+        """``type(cams[0].intr).stack(intrs)`` (app/resources/observers/cameras.py:479: MultiCamBundle): a new leading
+        prefix dimension over the cameras."""
+        o = cls(device=None)
+        for k in cams[0].subattr.keys():
+            o.subattr[k] = type(cams[0].subattr[k]).stack([c.subattr[k] for c in cams], dim=dim)
+        o.downscale = cams[0].downscale
+        return o
+
+    def take_along_dim(self, idx: torch.Tensor, dim: int = 0):
+        o = type(self)(device=None)
+        for k, v in self.subattr.items():
+            o.subattr[k] = v.take_along_dim(idx, dim=dim)
+        o.downscale = self.downscale
+        return o
+
     def set_downscale(self, downscale):
         """``image_downscale`` = (w, h) ratio old / new of the images actually trained on (a scalar, or the 2-vector of
         dataio/data_loader/base_loader.py:355-384); intrinsics and H / W follow it."""
@@ -499,9 +532,51 @@ class PinholeCameraMatHW(CameraBase):
 class OpenCVCameraMatHW(CameraBase):
     model = "opencv"
 
+    N_ITERS = 5          # cv::undistortPoints' default, and the HIP ray generator's (csrc/sampling.hip raygen_lift)
+
+    def _dist(self, like: torch.Tensor) -> torch.Tensor:
+        dd = self.subattr["distortion"].tensor
+        if dd.shape[-1] < 5:
+            dd = torch.cat([dd, dd.new_zeros(*dd.shape[:-1], 5 - dd.shape[-1])], dim=-1)
+        if dd.dim() > 1:
+            dd = dd.reshape(*dd.shape[:-1], *([1] * (like.dim() - (dd.dim() - 1))), dd.shape[-1])
+        return dd
+
     def lift(self, u, v, d):
-        raise NotImplementedError("OpenCVCameraMatHW.lift: the HIP ray generator undistorts in-kernel "
-                                  "(neuralsim_amd.graphics.cameras.opencv_selected_rays)")
+        """pixel (u, v) at depth d -> camera-frame point: the pinhole coordinates are the DISTORTED ones, the undistorted
+        (x, y) come from ``N_ITERS`` rounds of the fixed-point iteration of cv::undistortPoints on (k1, k2, p1, p2, k3) --
+        the arithmetic of the HIP ray generator, operation for operation (``cameras.py:84-87, 281-310`` call this for
+        ``camera_model: opencv``)."""
+        m = self.mat_3x3()
+        if m.dim() > 2:
+            m = m.reshape(*m.shape[:-2], *([1] * (u.dim() - (m.dim() - 2))), 3, 3)
+        x0, y0 = (u - m[..., 0, 2]) / m[..., 0, 0], (v - m[..., 1, 2]) / m[..., 1, 1]
+        dd = self._dist(u)
+        k1, k2, p1, p2, k3 = dd[..., 0], dd[..., 1], dd[..., 2], dd[..., 3], dd[..., 4]
+        x, y = x0, y0
+        for _ in range(self.N_ITERS):
+            r2 = x * x + y * y
+            icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+            dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+            x, y = (x0 - dx) * icd, (y0 - dy) * icd
+        return torch.stack([x * d, y * d, d], dim=-1)
+
+    def proj(self, xyz: torch.Tensor):
+        """camera-frame points -> (u, v, depth) through the forward distortion model."""
+        m = self.mat_3x3()
+        if m.dim() > 2:
+            m = m.reshape(*m.shape[:-2], *([1] * (xyz.dim() - 1 - (m.dim() - 2))), 3, 3)
+        z = xyz[..., 2]
+        zs = torch.where(z.abs() < 1e-9, torch.full_like(z, 1e-9), z)
+        x, y = xyz[..., 0] / zs, xyz[..., 1] / zs
+        dd = self._dist(x)
+        k1, k2, p1, p2, k3 = dd[..., 0], dd[..., 1], dd[..., 2], dd[..., 3], dd[..., 4]
+        r2 = x * x + y * y
+        cd = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2
+        xd = x * cd + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+        yd = y * cd + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+        return m[..., 0, 0] * xd + m[..., 0, 1] * yd + m[..., 0, 2], m[..., 1, 1] * yd + m[..., 1, 2], z
 
 
 class FisheyeCameraMatHW(OpenCVCameraMatHW):
@@ -512,12 +587,144 @@ class OrthoCameraIntrinsics(CameraBase):
     model = "ortho"
 
 
+def quat_to_mat(q: torch.Tensor) -> torch.Tensor:
+    """unit quaternion (w, x, y, z) [..., 4] -> rotation matrix [..., 3, 3]"""
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(*q.shape[:-1], 3, 3)
+
+
+def mat_to_quat(R: torch.Tensor) -> torch.Tensor:
+    """rotation matrix [..., 3, 3] -> unit quaternion (w, x, y, z), w >= 0 (the branch-free 'largest component' form)."""
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22,
+                                                1 - m00 - m11 + m22], dim=-1), min=0.0))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1),
+        torch.stack([R[..., 2, 1] - R[..., 1, 2], q_abs[..., 1] ** 2, R[..., 1, 0] + R[..., 0, 1], R[..., 0, 2] + R[..., 2, 0]], -1),
+        torch.stack([R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] + R[..., 0, 1], q_abs[..., 2] ** 2, R[..., 2, 1] + R[..., 1, 2]], -1),
+        torch.stack([R[..., 1, 0] - R[..., 0, 1], R[..., 2, 0] + R[..., 0, 2], R[..., 2, 1] + R[..., 1, 2], q_abs[..., 3] ** 2], -1),
+    ], dim=-2) / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = q_abs.argmax(dim=-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4)).squeeze(-2)
+    q = torch.where(q[..., :1] < 0, -q, q)
+    return F.normalize(q, dim=-1)
+
+
+class RotationQuaternion(Attr):
+    """Unit quaternion (w, x, y, z) (app/models/scene/learnable_params.py:101: ``RotationQuaternion.from_mat_3x3(...)``)."""
+    shape = (4,)
+
+    @classmethod
+    def default_value(cls):
+        return torch.tensor([1.0, 0.0, 0.0, 0.0])
+
+    @classmethod
+    def from_mat_3x3(cls, R: torch.Tensor, **kw):
+        return cls(mat_to_quat(R.detach()), **kw)
+
+    def quat(self) -> torch.Tensor:
+        return self.tensor
+
+    def mat_3x3(self) -> torch.Tensor:
+        return quat_to_mat(F.normalize(self.tensor, dim=-1))
+
+
+class _RefinedAdd(nn.Module):
+    """``<X>RefinedAdd(attr0=<X>, delta=<Vector>(zeros, learnable=True))`` (learnable_params.py:100-109): the node keeps its
+    dataset value ``attr0`` and learns an additive correction; the sum behaves as an <X>.  The two parts are reachable as
+    ``.subattr.attr0`` / ``.subattr.delta`` (learnable_params.py:318, 337).  Slicing on the prefix returns a plain <X>
+    holding the sliced sum (gradients flow to ``delta``)."""
+
+    def __init__(self, attr0: Attr = None, delta: Attr = None):
+        super().__init__()
+        self.subattr = _SubAttr()
+        self.subattr["attr0"], self.subattr["delta"] = attr0, delta
+
+    @property
+    def attr0(self):
+        return self.subattr["attr0"]
+
+    @property
+    def delta(self):
+        return self.subattr["delta"]
+
+    @property
+    def tensor(self) -> torch.Tensor:
+        return self.attr0.tensor.detach() + self.delta.tensor
+
+    @property
+    def prefix(self):
+        return self.attr0.prefix
+
+    @property
+    def device(self):
+        return self.attr0.tensor.device
+
+    def __len__(self):
+        return len(self.attr0)
+
+    def _plain(self, t):
+        return self.attr0._like(t)
+
+    def __getitem__(self, i):
+        return self._plain(self.tensor[i])
+
+    def interp1d(self, ts_keyframes, ts):
+        return self._plain(self.tensor).interp1d(ts_keyframes, ts)
+
+    def value(self):
+        return self.tensor
+
+
+class RotationQuaternionRefinedAdd(_RefinedAdd):
+    def quat(self):
+        return F.normalize(self.tensor, dim=-1)
+
+    def mat_3x3(self):
+        return quat_to_mat(self.quat())
+
+
+class TranslationRefinedAdd(_RefinedAdd):
+    def vec_3(self):
+        return self.tensor
+
+    def translation(self):
+        return self.tensor
+
+    def forward(self, x, inv: bool = False):
+        return x - self.tensor if inv else x + self.tensor
+
+
+class ScalarRefinedAdd(_RefinedAdd):
+    pass
+
+
 class TransformRT(AttrNested):
     """Rotation + translation as two Attrs (``learnable_params`` builds refined poses this way)."""
 
     def __init__(self, rot: Attr = None, trans: Attr = None, device=None, **kw):
         super().__init__(allow_new_attr=True, device=device, rot=rot if rot is not None else RotationMat3x3(),
                          trans=trans if trans is not None else Translation())
+
+    def _sub(self, rot, trans):
+        o = TransformRT.__new__(TransformRT)
+        AttrNested.__init__(o, allow_new_attr=True, rot=rot, trans=trans)
+        return o
+
+    def __getitem__(self, i):
+        return self._sub(self.subattr["rot"][i], self.subattr["trans"][i])
+
+    def new(self, prefix):
+        return TransformMat4x4().new(prefix)
+
+    def interp1d(self, ts_keyframes, ts):
+        return self._sub(self.subattr["rot"].interp1d(ts_keyframes, ts), self.subattr["trans"].interp1d(ts_keyframes, ts))
+
+    @property
+    def prefix(self):
+        return self.subattr["trans"].prefix
 
     def rotation(self):
         return self.subattr["rot"].mat_3x3()
@@ -532,11 +739,15 @@ class TransformRT(AttrNested):
         bottom[..., 0, 3] = 1.0
         return torch.cat([top, bottom], dim=-2)
 
+    def mat_3x4(self):
+        return torch.cat([self.rotation(), self.translation().unsqueeze(-1)], dim=-1)
+
     def rotate(self, x, inv=False):
         R = self.rotation().transpose(-1, -2) if inv else self.rotation()
-        return (R * x.unsqueeze(-2)).sum(-1)
+        return (TransformMat4x4._over_points(R, x, 2) * x.unsqueeze(-2)).sum(-1)
 
     def forward(self, x, inv=False):
+        t = TransformMat4x4._over_points(self.translation(), x, 1)
         if inv:
-            return self.rotate(x - self.translation(), inv=True)
-        return self.rotate(x) + self.translation()
+            return self.rotate(x - t, inv=True)
+        return self.rotate(x) + t

@@ -13,13 +13,18 @@ import os
 import torch
 
 
-def _init(implicit_surface, fn, cfg, logger):
+def _init(implicit_surface, fn_metres, cfg, logger):
+    # ``sdf_scale``: "the real-world length represented by one unit of SDF" (withmask_withlidar_joint.240219.yaml:24; the
+    # occupancy shell ``inv_s 256 => +- 0.01 sdf`` = +- 0.25 m and ``clearance_sdf 0.02 = 0.5 m`` count in those units): the
+    # network's SDF is distance / sdf_scale, so that is what the targets (distances in object units) are fitted as
+    scale = float(getattr(implicit_surface, "sdf_scale", 1.0))
+    fn = (lambda x: fn_metres(x) / scale) if scale != 1.0 else fn_metres
     if cfg.get("geo_init_impl", os.environ.get("NSIM_GEO_INIT", "write")) == "pretrain":
         implicit_surface.pretrain_sdf_fn(lambda x: fn(x.detach().cpu()), num_iters=int(cfg.get("num_iters", 500)),
                                          lr=float(cfg.get("lr", 2e-3)), num_pts=int(cfg.get("num_points", cfg.get("num_pts", 2 ** 14))),
                                          logger=logger, w_eikonal=float(cfg.get("w_eikonal", 0.0)))
     else:
-        implicit_surface.geometric_init_fn(fn)
+        implicit_surface.geometric_init_fn(fn, level=implicit_surface._geo_init_level())
 
 _DIM = dict(x=0, y=1, z=2)
 

@@ -27,6 +27,8 @@ class IDListedDict:
             return list(self._d.values())[k]
         if isinstance(k, slice):
             return IDListedDict(list(self._d.values())[k])
+        if isinstance(k, (list, tuple)):        # ``scene.observers[lidar_id]`` with a list of ids (train.py:877-885)
+            return [self[i] for i in k]
         return self._d[k]
 
     def __setitem__(self, k, v):

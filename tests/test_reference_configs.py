@@ -157,10 +157,10 @@ def test_street_pretrain_targets(backend):
     assert bool(m.is_pretrained)
     x = torch.tensor([[0.0, 0.0, 0.5], [3.0, 1.0, -1.5], [-5.0, -2.0, -1.9], [2.0, 0.5, 1.5]], device=backend)
     sdf = m.query_sdf(x).cpu()
-    want = x.cpu()[:, 2] - (0.5 - 2.0)                                    # ... so the road is at z = -1.5
-    assert (sdf - want).abs().max() < 0.05
+    want = (x.cpu()[:, 2] - (0.5 - 2.0)) / 25.0                           # ... so the road is at z = -1.5; one SDF unit = 25 m
+    assert (sdf - want).abs().max() < 0.05 / 25.0
     occ = m.accel.occ_grid.cpu()                                          # [X, Y, Z]: only the slab around z = -1.5
     assert bool(occ[:, :, 0].any()) and not bool(occ[:, :, 2:].any())
     pretrain_sdf_capsule(m.implicit_surface, tracks, surface_distance=1.0)
     s2 = m.query_sdf(torch.tensor([[0.0, 0.0, 0.5], [0.0, 3.0, 0.5]], device=backend)).cpu()
-    assert s2[0] > 0.9 and s2[1] < -1.5                                    # free on the track, solid 3 m beside it
+    assert s2[0] > 0.9 / 25.0 and s2[1] < -1.5 / 25.0                      # free on the track, solid 3 m beside it

@@ -77,3 +77,68 @@ def test_reference_trainer_runs_unchanged(tmp_path):
     # resuming picks the checkpoint up (``--resume_dir``): nothing left to do at num_iters
     r2 = _run(exp, ["--num_iters=12", "--training.i_val=-1"])
     assert r2.returncode == 0 and "Everything done." in r2.stdout, (r2.stdout + r2.stderr)[-2000:]
+
+
+# ================================================================================================ the street config (BASELINE configs[3])
+STREET_CFG = REF / "code_single/configs/waymo/streetsurf/withmask_withlidar_joint.240219.yaml"
+S_, DV = "assetbank_cfg.Street.model_params", "assetbank_cfg.Distant.model_params"
+STREET_SMALL = [
+    "--dataset_cfg.target=neuralsim_amd.dataio.SyntheticStreetDataset", "--dataset_cfg.param.n_frames=6",
+    "--dataset_cfg.param.image_h=24", "--dataset_cfg.param.image_w=32", "--scenebank_cfg.scenarios=[synthetic_street]",
+    "--camera_list=[camera_FRONT,camera_FRONT_LEFT,camera_FRONT_RIGHT]", "--lidar_list=[lidar_TOP]", "--lidar_weight=[1.0]",
+    "--num_rays_pixel=128", "--num_rays_lidar=96", "--num_coarse=16", "--num_fine=[4,4,8]", "--step_size=2.0", "--num_uniform=256",
+    "--distant_nsample=8", "--log2_hashmap_size=12", "--max_num_levels=10", "--warmup_steps=1",
+    f"--{S_}.surface_cfg.encoding_cfg.lotd_auto_compute_cfg.target_num_params=131072",
+    f"--{S_}.surface_cfg.encoding_cfg.lotd_auto_compute_cfg.min_res=3", f"--{S_}.accel_cfg.vox_size=8.0",
+    f"--{S_}.accel_cfg.init_cfg.num_pts=8192", f"--{S_}.accel_cfg.init_cfg.num_steps=2",
+    f"--{S_}.accel_cfg.update_from_net_cfg.num_pts=8192", f"--{S_}.accel_cfg.update_from_net_cfg.num_steps=1",
+    f"--{S_}.accel_cfg.n_steps_warmup=2", f"--{S_}.accel_cfg.n_steps_between_update=2",
+    f"--{S_}.ray_query_cfg.query_param.march_cfg.max_steps=256",
+    f"--{DV}.encoding_cfg.lotd_auto_compute_cfg.target_num_params=16384", f"--{DV}.encoding_cfg.lotd_auto_compute_cfg.log2_hashmap_size=10",
+    f"--{DV}.encoding_cfg.lotd_auto_compute_cfg.min_res_xyz=3", f"--{DV}.encoding_cfg.lotd_auto_compute_cfg.min_res_w=2",
+    "--training.i_save=-1", "--training.i_backup=-1", "--training.i_log=1", "--training.error_map.error_map_hw=[6,8]",
+    "--assetbank_cfg.LearnableParams.model_params.enable_after=1",
+]
+
+
+@needs_reference
+def test_reference_trainer_runs_the_street_config(tmp_path):
+    """BASELINE configs[3] through the reference's OWN trainer, source unchanged: ``code_single/tools/train.py --config
+    code_single/configs/waymo/streetsurf/withmask_withlidar_joint.240219.yaml`` with every ``model_params`` block of the YAML
+    (``LoTDNeuSStreet`` cuboid LoTD sized from the camera frusta, ``LoTDNeRFDistant``, ``SimpleSky``, ``ImageEmbeddings``,
+    ``LearnableParams`` pose refinement) on ``neuralsim_amd.dataio.SyntheticStreetDataset``: an ego vehicle with an opencv-model
+    camera rig and a roof lidar as its children (docs/data/autonomous_driving.md:38-100), occupancy / human / ignore masks.  Per
+    iteration the trainer runs the joint pixel step (rgb l1, mask, eikonal, sparsity, clearance ...) AND the lidar step
+    (depth l1 + line of sight, train.py:876-960), each with its own backward and optimizer step; pose refinement switches on
+    after ``enable_after`` and the camera poses receive gradients through ``OpenCVCameraMatHW.lift`` -> rays -> kernels.
+    Sizes shrunk through the trainer's own ``--a.b.c=`` overrides (host emulator)."""
+    exp = tmp_path / "street"
+    cmd = [sys.executable, str(ROOT / "tools" / "run_reference_train.py"), "--emulate", "--config", str(STREET_CFG), "--exp_dir",
+           str(exp), "--num_iters=14", "--training.i_val=8"] + STREET_SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, PYTHONWARNINGS="ignore"), cwd=str(ROOT))
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "Everything done." in r.stdout, tail
+    ck = sorted((exp / "ckpts").glob("final_*.pt"))
+    assert len(ck) == 1 and ck[0].name == "final_00000014.pt"
+    state = torch.load(str(ck[0]), map_location="cpu", weights_only=False)
+    bank = state["asset_bank"]
+    ids = {k.split("#")[0] for k in bank}
+    assert ids == {"LoTDNeuSStreet", "LoTDNeRFDistant", "SimpleSky", "ImageEmbeddings", "LearnableParams"}, ids
+    street = next(v for k, v in bank.items() if k.startswith("LoTDNeuSStreet#Street"))
+    assert any(k.endswith("encoding.flattened_params") for k in street) and bool(street["is_pretrained"])
+    lp = next(v for k, v in bank.items() if k.startswith("LearnableParams"))
+    d_rot = [v for k, v in lp.items() if k.endswith("rot.subattr.delta.tensor")]
+    d_tr = [v for k, v in lp.items() if k.endswith("trans.subattr.delta.tensor")]
+    assert len(d_rot) == len(d_tr) == 3 and all(tuple(v.shape) == (6, 4) for v in d_rot)
+    assert max(float(v.abs().max()) for v in d_rot) > 0 and max(float(v.abs().max()) for v in d_tr) > 0      # the poses moved
+    stats = pickle.loads((exp / "stats.p").read_bytes())
+    for key in ("train_step_pixel.losses/loss_rgb", "train_step_pixel.losses/loss_mask", "train_step_pixel.losses/total",
+                "train_step_lidar.losses/lidar_loss.depth", "train_step_lidar.losses/lidar_loss.los.empty",
+                "train_step_lidar.losses/total"):
+        vals = [v for _, v in stats[key]]
+        assert len(vals) >= 5 and all(v == v and abs(v) < 1e3 for v in vals), (key, vals)
+    assert any(k.startswith("train_step_pixel.losses/loss_eikonal") for k in stats), [k for k in stats if "eikonal" in k]
+    tot = [v for _, v in stats["train_step_pixel.losses/total"]]
+    assert sum(tot[-5:]) < sum(tot[:5]), tot                   # it trains (fresh 128-ray batches: compare windows)
+    # the street model rendered samples (not only the distant model and the sky): its volume buffer statistics were logged
+    assert any(k.startswith("train_step_pixel.obj=street/volume_buffer.opacity_alpha") for k in stats)
