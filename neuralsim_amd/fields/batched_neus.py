@@ -110,8 +110,24 @@ class BatchedRaysMixin:
                           render_per_obj_individual: bool = False) -> Dict:
         """``march_occ_multi_upsample[_compressed]`` on the tested (item, ray) pairs; the volume buffer is packed per
         pair and carries ``rays_bidx_hit`` / ``rays_full_bidx_hit`` next to ``rays_inds_hit``."""
-        assert self.ins_inds_per_batch is not None, "set_condition() first"
         bt = batched_ray_tested
+        empty = int(bt["num_rays"]) == 0
+        # (no pair was hit: the reference's renderer does not even set a condition then -- ``if num_rays > 0:
+        # model.set_condition(...)``, buffer_compose_renderer.py:252-258 -- and still calls the query for its empty buffer)
+        assert empty or self.ins_inds_per_batch is not None, "set_condition() first"
+        if empty:
+            tested = dict(bt)
+            cfg0 = dict(config, _render=True) if render_per_obj_individual else config
+            ret = super().ray_query(ray_input=None, ray_tested=tested, config=cfg0, return_buffer=return_buffer,
+                                    return_details=return_details, render_per_obj_individual=False)
+            if render_per_obj_individual and batched_ray_input is not None and batched_ray_input.get("rays_o") is not None:
+                Bq, N = batched_ray_input["rays_o"].shape[:2]
+                dev = batched_ray_input["rays_o"].device
+                keys = ["mask_volume", "depth_volume"] + (["rgb_volume"] if dict(config).get("with_rgb", True) else []) + \
+                    (["normals_volume"] if dict(config).get("with_normal", False) else [])
+                ret["rendered"] = {k: torch.zeros([Bq, N, *((3,) if k in ("rgb_volume", "normals_volume") else ())],
+                                                  dtype=torch.float32, device=dev) for k in keys}
+            return ret
         # The reference conditions the model on the COMPACTED batch -- ``set_condition({'ins_id': [ids of the items
         # that were hit at all]})`` after ``batched_ray_test(compact_batch=True)`` (buffer_compose_renderer.py:247-258)
         # -- so the condition is indexed by ``rays_bidx``; a condition given over the full batch by ``rays_full_bidx``

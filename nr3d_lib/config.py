@@ -126,7 +126,7 @@ def _safe_arith(expr: str):
     return ev(ast.parse(str(expr).strip(), mode="eval"))
 
 
-def _resolve_str(s: str, root: dict, depth: int = 0):
+def _resolve_str(s: str, root: dict, depth: int = 0, here=()):
     """``${a.b}`` -> the value at that path of the ROOT config (typed when the string is nothing but the reference),
     ``${eval:"expr"}`` / ``${eval:expr}`` -> Python arithmetic -- the two interpolation forms the reference's configs
     use on the model blocks (lotd_neus.dtu.230814.yaml:82-166)."""
@@ -140,10 +140,17 @@ def _resolve_str(s: str, root: dict, depth: int = 0):
             expr = body[5:].strip()
             if len(expr) >= 2 and expr[0] == expr[-1] and expr[0] in "\"'":
                 expr = expr[1:-1]
-            expr = _resolve_str(expr, root, depth + 1) if "${" in expr else expr
+            expr = _resolve_str(expr, root, depth + 1, here) if "${" in expr else expr
             return _safe_arith(expr)
+        where = here
+        if body.startswith("."):        # relative: ``${.sibling}`` / ``${..uncle}`` (``Cyclist: ${.Pedestrian}``, all_occ.240201.yaml:599)
+            n = len(body) - len(body.lstrip("."))
+            base = list(here[:len(here) - n]) if n <= len(here) else []
+            rest = body.lstrip(".")
+            where = tuple(base + rest.split("."))
+            body = ".".join(str(k) for k in where)
         v = _lookup(root, body)
-        return _resolve_str(v, root, depth + 1) if isinstance(v, str) and "${" in v else v
+        return _resolve_str(v, root, depth + 1, tuple(where) if where else here) if isinstance(v, str) and "${" in v else v
     if m:
         return value(m.group(1))
     return pat.sub(lambda mm: str(value(mm.group(1))), s)
@@ -151,14 +158,14 @@ def _resolve_str(s: str, root: dict, depth: int = 0):
 
 def resolve_config(cfg: dict) -> ConfigDict:
     """Resolve every interpolation of a loaded YAML tree against its own root."""
-    def walk(v):
+    def walk(v, here=()):
         if isinstance(v, dict):
-            return {k: walk(x) for k, x in v.items()}
+            return {k: walk(x, here + (k,)) for k, x in v.items()}
         if isinstance(v, list):
-            return [walk(x) for x in v]
+            return [walk(x, here + (i,)) for i, x in enumerate(v)]
         if isinstance(v, str) and "${" in v:
             try:
-                return walk(_resolve_str(v, cfg))
+                return walk(_resolve_str(v, cfg, 0, here), here)
             except (KeyError, TypeError):
                 return v            # references into parts of the harness config that are not present stay verbatim
         return v

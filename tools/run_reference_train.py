@@ -3,7 +3,7 @@
 on this repository: its ``nr3d_lib`` imports resolve to the shim package of this repository (HIP kernels underneath),
 its dataset is ``neuralsim_amd.dataio.SyntheticObjectDataset`` (``--dataset_cfg.target=...`` override: no files).
 
-    python tools/run_reference_train.py --config <reference yaml> [--a.b.c=value ...]
+    python tools/run_reference_train.py [--script code_multi/tools/train.py] --config <reference yaml> [--a.b.c=value ...]
 
 On a machine without a HIP device (the authoring container) pass ``--emulate``: the kernels run on the test-only host
 emulator (tests/emu) and every ``cuda`` device the trainer asks for is mapped to the CPU -- the trainer hard-codes
@@ -136,7 +136,12 @@ def main(argv):
     _install_third_party_stubs()
     if emulate:
         _emulate_cuda_on_cpu()
-    script = REF / "code_single" / "tools" / "train.py"
+    rel = "code_single/tools/train.py"
+    if "--script" in argv:                 # another entry point of the reference (code_multi/tools/train.py), also unchanged
+        i = argv.index("--script")
+        rel = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
+    script = REF / rel
     assert script.exists(), f"{script} not found (NSIM_REFERENCE_ROOT)"
     sys.argv = [str(script)] + argv
     cwd = os.getcwd()
