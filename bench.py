@@ -295,10 +295,18 @@ def main():
     ap.add_argument("--sdf-depth", type=int, default=2, choices=(1, 2),
                     help="hidden layers of the SDF decoder: 2 = BASELINE configs[1] (2x64, the default), 1 = the reference "
                          "yaml's own decoder_cfg D: 1 (lotd_neus.dtu.230814.yaml:120)")
+    ap.add_argument("--allreduce", default=None, choices=("ring", "direct"),
+                    help="N > 1: schedule of the gradient all-reduce -- ring = the backend's (RCCL) all-reduce, direct = all-to-all + "
+                         "f32 reduction + all-gather (one rounding per contribution on the 2-byte wire; self-checked against "
+                         "the ring on first use and abandoned with a warning if it disagrees).  Default: direct for the bf16 wire.")
     args = ap.parse_args()
 
     from neuralsim_amd import _lib, distributed as ndist
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    if args.allreduce is not None:
+        os.environ["NSIM_ALLREDUCE_ALGO"] = "ring" if args.allreduce == "ring" else ""      # "" = default rule + self-check
+        if args.allreduce == "direct":
+            os.environ.pop("NSIM_ALLREDUCE_ALGO")
     rank, local_rank, world = ndist.init_env()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -315,6 +323,9 @@ def main():
     out, it = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=args.rays_per_gpu, workload=workload)
     if world > 1:
         it = measure_exposed_allreduce(tr, out, min(args.steps, 32), it, rank, dev)
+    dist_info = distributed_info(world, dev)         # (collective on N > 1: every rank calls it)
+    if rank == 0:
+        out["distributed"] = dist_info
     if rank == 0 and args.config != "object":
         out["config"]["name"] = args.config
         out["config"]["launch_chain"] = "autograd"
@@ -401,6 +412,25 @@ def main():
         dist.destroy_process_group()
 
 
+def distributed_info(world: int, dev) -> dict:
+    """What the N > 1 run actually was (recorded in the line so that a scaling number can be checked against it): ranks the
+    process group reports, every rank's device, backend, the all-reduce schedule that ended up in use and the wire dtype."""
+    import torch.distributed as dist
+    from neuralsim_amd import distributed as ndist
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+    info = dict(ranks_seen=1, devices=[f"{dev}: {name}"], backend=None, allreduce=None, wire_dtype=None)
+    if world > 1 and dist.is_initialized():
+        names = [None] * dist.get_world_size()
+        dist.all_gather_object(names, f"rank {dist.get_rank()} {dev}: {name}")
+        wire = ndist.wire_dtype_default()
+        algo = ndist._algo(wire)
+        if algo == "direct" and not ndist._DIRECT_OK.get((dist.get_backend(), str(dev)), True):
+            algo = "ring (direct failed its self-check)"
+        info.update(ranks_seen=dist.get_world_size(), devices=names, backend=dist.get_backend(), allreduce=algo,
+                    wire_dtype=str(wire).replace("torch.", ""))
+    return info
+
+
 WORKLOADS = {
     "street": "BASELINE configs[3] shape: StreetSurf street view (synthetic 6-camera rig on a 200 x 100 x 30 m analytic street), "
               "{rays} rays/iter/GPU, cuboid 19-level LoTD (T=2^20, ~33 Mi params) + 1x64 SDF MLP (sdf_scale 25) + 2x64 radiance, occ grid "
@@ -460,6 +490,7 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     dm_ = getattr(tr, "distant_model", None) or getattr(tr, "distant", None)
     KM = kernel_model(tr.model.encoding.cfg.num_levels, dm_.cfg.num_levels if dm_ is not None else 12)
     _lib.TIMER = _lib.KernelTimer(only=KM.keys()) if on_gpu else None
+    _lib.CALL_COUNT = 0
     S_f = S_hit = 0
     marks = []
     t0 = time.perf_counter()
@@ -473,6 +504,8 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     elapsed = time.perf_counter() - t0
     gc.enable()
     timer, _lib.TIMER = _lib.TIMER, None
+    abi_calls = _lib.CALL_COUNT
+    _lib.CALL_COUNT = None
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -547,7 +580,10 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                            samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
                            hit_fraction=round(S_hit / (rays_per_gpu * steps), 3)),
                step_ms=dict(p10=q(0.1), p50=q(0.5), p90=q(0.9), max=round(d[-1] * 1e3, 3)),
-               roofline=roofline, kernels=per_kernel)
+               roofline=roofline, kernels=per_kernel,
+               # C-ABI entry-point calls of this package per step (each is one kernel launch, three of them two); the ATen /
+               # rocprim launches of the host glue (rand, fill, cat, compaction) are on top: profiles/round4_rocprofv3_kernel_stats
+               abi_calls_per_step=round(abi_calls / max(1, steps), 1) if abi_calls is not None else None)
     return out, it
 
 

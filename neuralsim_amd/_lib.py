@@ -293,9 +293,15 @@ def ensure_grad_scratch(device):
     return _GRAD_SCRATCH[key]
 
 
+CALL_COUNT = None        # bench.py sets it to 0 over the timed steps: number of C-ABI calls issued
+
+
 def call(name: str, *args):
     """Invoke a C-ABI entry point on the current stream and raise on a non-zero return code.  Tensor arguments are
     passed as their device pointers (checked: device-resident, contiguous)."""
+    global CALL_COUNT
+    if CALL_COUNT is not None:
+        CALL_COUNT += 1
     lib = get_lib()
     if name in _GRAD_SCRATCH_USERS:
         for a_ in args:

@@ -2419,7 +2419,8 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   // with more tiles per wave the static stride balances worse than the dispatcher's backfill of finished workgroups)
   // (the 16-level kernel measures best at 512 for every launch size of the object step: 0.0463 ms avg against 0.0523 with
   // the scaled grid; the scaling is the 17..32-level kernel's)
-  int64_t sdf_grid = sdf_grid_env > 0 ? sdf_grid_env : 512;
+  // (round 4, LDS-DMA form -- 128 VGPR, 42 KB LDS, three workgroups fit a CU: 768 -> 0.0352 ms, 512: 0.0378, 1024: 0.0372)
+  int64_t sdf_grid = sdf_grid_env > 0 ? sdf_grid_env : (feat_planes ? 768 : 512);
   if (sdf_grid_env <= 0 && field_nc(meta->lotd.num_levels) == 2) {
     sdf_grid = ((S + 31) / 32) / (FIELD_WAVES * 5);
     sdf_grid = sdf_grid < 512 ? 512 : (sdf_grid > 4096 ? 4096 : sdf_grid);

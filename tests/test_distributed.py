@@ -149,6 +149,9 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None
     p0 = m.encoding.flattened_params.detach().clone()
     out, it_next = bench.timed_run(tr, steps=steps, warmup=1, rank=rank, world=world, dev=dev, rays_per_gpu=16)
     assert it_next == 257 + steps
+    info = bench.distributed_info(world, dev)            # what the JSON line records about the N > 1 run (every rank calls it)
+    assert info["ranks_seen"] == world and len(info["devices"]) == world and info["backend"] == "gloo"
+    assert info["allreduce"] in ("ring", "direct") and info["wire_dtype"] in ("bfloat16", "float32", "float16")
     # replicas must still agree after the all-reduced updates
     w = m.sdf_w.detach().clone()
     ws = [torch.zeros_like(w) for _ in range(world)]
@@ -286,3 +289,48 @@ def test_two_rank_overlapped_schedule_on_gpu(tmp_path):
     # amplifies that, and after the first refresh the occupancy (hence the sample sets) may differ: compare the start
     assert torch.allclose(a["losses"][:4], b["losses"][:4], rtol=1e-4, atol=1e-6)
     assert float(a["losses"][-1]) < float(a["losses"][0]) and float(b["losses"][-1]) < float(b["losses"][0])
+
+
+def _street_worker(rank, world, port, out_dir, steps):
+    """The street trainer (configs[3] shape, small: NeuS street + distant + sky, pixel step AND lidar step per iteration) under
+    ``world`` gloo ranks on the kernel emulator: the autograd-path schedule -- ``allreduce_grads`` after each backward, the
+    lidar step with ``skip_absent`` (parameters outside its graph are neither reduced nor stepped on any rank)."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    import ctypes
+    import build_emu
+    from neuralsim_amd import _lib, distributed as nd, scenarios as sc
+    lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
+    _lib.get_lib = lambda: lib
+    _lib.stream_handle = lambda: 0
+    _lib.require_device = lambda t, name="tensor": None
+    nd.init_env(backend="gloo", device_type="cpu")
+    dev = torch.device("cpu")
+    tr = sc.build_street_trainer(dev, rank=rank, world_size=world, small=True, rays_per_gpu=32, lidar_rays=32, num_uniform=16, seed=42)
+    assert not tr._fused_ok() and tr.distant_model is not None and tr.sky_model is not None
+    for it in range(steps):
+        loss = tr.train_step(it)
+        assert float(loss) == float(loss)
+    grp = {id(g["p"]): g for g in tr.optim.groups}
+    assert grp[id(tr.model.sdf_w)]["t"] == 2 * steps and grp[id(tr.model.rad_w)]["t"] == steps       # lidar: no radiance update
+    for name, t in (("grid", tr.model.encoding.flattened_params), ("sdf_w", tr.model.sdf_w), ("rad_w", tr.model.rad_w),
+                    ("distant", tr.distant_model.flattened_params), ("sky", tr.sky_model.w), ("appear", tr.appear)):
+        g = t.detach().clone()
+        gs = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        assert all(torch.equal(gs[0], x) for x in gs[1:]), name
+    dist.barrier()
+    (Path(out_dir) / f"street_ok{rank}").write_text("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_street_trainer_replicas_stay_in_sync(tmp_path, world):
+    """configs[3]'s trainer (pixel + lidar step) at world sizes 2 and 8 (the node size): every rank issues the same
+    collective sequence whatever its batches hit, and the replicas are bit-identical after the all-reduced updates."""
+    mp.spawn(_street_worker, args=(world, _free_port(), str(tmp_path), 2), nprocs=world, join=True)
+    assert all((tmp_path / f"street_ok{r}").exists() for r in range(world))
