@@ -105,6 +105,19 @@ int nsim_alpha_to_vw_fwd(const float* alpha, const int64_t* pack_infos, int64_t 
                          void* stream);
 int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw, const float* dvw,
                          const int64_t* pack_infos, int64_t P, float* dalpha, void* stream);
+/* The differentiable tail of a training step in ONE launch (no reference counterpart: the reference evaluates these with a
+ * dozen torch / nr3d_lib calls -- ``_volume_integration`` app/renderers/single_volume_renderer.py:73-102, the photometric mse
+ * app/loss/photometric.py:88-146, the eikonal term app/loss/eikonal.py:185-253 -- and autograd's backward of each): for the P
+ * hit rays (packs ``pack_infos``, image row ``out_idx[p]`` or p) sdf -> alpha -> visibility weights -> mask / depth / rgb / normal
+ * images; loss = mean((rgb image - gt)^2) over ALL N rays (rays outside the packs render black) + w_eikonal (mean over the S
+ * render samples + mean over the M free points of (|nablas| - 1)^2); acc[0..2] += (mse, eikonal_render, eikonal_free); and the
+ * backward of all of it: dalpha [S], dsdf [S] (rows S.. are the caller's zeros), drgb [S,3], dnablas [S+M,3] (eikonal part
+ * only), d_ln_inv_s += (may be NULL).  alpha / vw / trans [S] are written (the later backward launches read them). */
+int nsim_render_head(const float* sdf, const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, const float* t,
+                     const float* rgb, const float* nablas, const int64_t* pack_infos, int64_t P, int normalized_depth,
+                     const float* gt, int64_t N, int64_t S, int64_t M, float w_eikonal, const int64_t* out_idx, float* alpha,
+                     float* vw, float* trans, float* mask, float* depth, float* rgb_out, float* nrm_out, float* acc,
+                     float* dalpha, float* dsdf, float* drgb, float* dnablas, float* d_ln_inv_s, void* stream);
 /* Fused SingleVolumeRenderer._volume_integration (single_volume_renderer.py:73-102): alpha -> vw -> mask,
  * depth (optionally normalised), rgb, normals per ray.  rgb / nrm (and their outputs) may be NULL.
  * out_idx [P] (may be NULL): row of the per-ray outputs that pack p writes / reads -- the scatter of the hit rays into

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nsim_alpha_to_vw_bwd": [_P, _P, _P, _P, _P, _I64, _P],
     "nsim_composite_fwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
     "nsim_neus_composite_fwd": [_P, _P, _F, _F, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_render_head": [_P, _P, _F, _F, _P, _P, _P, _P, _I64, _I, _P, _I64, _I64, _I64, _F, _P] + [_P] * 13,
     "nsim_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsim_neus_alpha_fwd": [_P, _P, _I64, _P, _F, _F, _P],
     "nsim_neus_alpha_bwd": [_P, _P, _P, _I64, _P, _F, _F, _P, _P],

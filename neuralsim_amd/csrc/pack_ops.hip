@@ -549,6 +549,191 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
   }
 }
 
+// ------------------------------------------------------------------------------- the training step's render head
+// ONE launch for the differentiable tail of the fused training step (round 4; four launches before: nsim_neus_composite_fwd,
+// nsim_train_loss_head, nsim_composite_bwd, nsim_neus_alpha_bwd -- 8 + 8 + 7 + 13 us under rocprofv3, each waiting for its
+// predecessor's drain): per hit ray one wave runs  sdf -> alpha -> visibility weights -> images  (the arithmetic of
+// k_composite_fwd<true>), forms that pixel's photometric-mse gradient, walks back through the compositing (k_composite_bwd)
+// and the sdf -> alpha map (k_neus_alpha_bwd); the samples of a ray are handed between the passes through the per-sample
+// buffers the backward kernels further down read anyway (alpha / vw / trans / dalpha), ordered by wave-level fences.  The
+// remaining workgroups of the SAME launch do the element-wise part of the loss head: sum gt^2 over all N rays (a ray that
+// hits nothing renders black: its residual is gt) and the eikonal terms on the S render samples and the M free points with
+// their gradients.  acc[0] = mse, acc[1] = eikonal(render samples), acc[2] = eikonal(free points), as nsim_train_loss_head.
+struct RenderHeadArgs {
+  const float *sdf, *ln_inv_s, *t, *rgb, *nab, *gt;
+  const int64_t *pi, *out_idx;
+  int64_t P, N, S, M;
+  float factor, forward_inv_s, w_eik;
+  int normalized_depth, ray_blocks;
+  float *alpha, *vw, *trans, *mask, *depth, *rgb_out, *nrm_out, *acc, *dalpha, *dsdf, *drgb, *dnab, *dln;
+};
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_render_head(RenderHeadArgs a) {
+  __shared__ float red[4][PACK_WAVES_PER_BLOCK];
+  const int lane = nsim_lane(), wave = (int)(threadIdx.x >> 6);
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;      // block partial sums: mse, eik render, eik free, d ln_inv_s
+  const float inv_n = 1.0f / (float)(3 * a.N);
+  if ((int)blockIdx.x < a.ray_blocks) {
+    const int64_t p = (int64_t)blockIdx.x * PACK_WAVES_PER_BLOCK + wave;
+    if (p < a.P) {
+      const int64_t st = a.pi[2 * p], n = a.pi[2 * p + 1];
+      const int64_t q = a.out_idx ? a.out_idx[p] : p;
+      const float s = neus_inv_s(a.ln_inv_s, a.factor, a.forward_inv_s);
+      // ---- forward: sdf -> alpha -> vw -> images
+      float carry = 1.0f, am = 0.f, ad = 0.f, ar[3] = {0.f, 0.f, 0.f}, an[3] = {0.f, 0.f, 0.f};
+      for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool valid = i < n;
+        float al = 0.f;
+        if (i + 1 < n) {
+          const float c0 = nsim_sigmoid(a.sdf[st + i] * s), c1 = nsim_sigmoid(a.sdf[st + i + 1] * s);
+          al = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+          al = fminf(fmaxf(al, 0.f), 1.f);
+        }
+        if (valid) a.alpha[st + i] = al;
+        float T;
+        vw_chunk(al, valid, 1e-10f, carry, T);
+        if (valid) {
+          const float w = al * T;
+          a.vw[st + i] = w;
+          a.trans[st + i] = T;
+          am += w;
+          ad += w * a.t[st + i];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            ar[c] += w * a.rgb[(st + i) * 3 + c];
+            an[c] += w * a.nab[(st + i) * 3 + c];
+          }
+        }
+      }
+      am = wave_sum(am);
+      ad = wave_sum(ad);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ar[c] = wave_sum(ar[c]);
+        an[c] = wave_sum(an[c]);
+      }
+      // ---- this pixel's photometric term: (pred - gt)^2, minus the gt^2 the element-wise workgroups add for EVERY ray
+      float gr[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g = a.gt[q * 3 + c], e = ar[c] - g;
+        gr[c] = inv_n * 2.0f * e;
+        if (lane == 0) r0 += e * e - g * g;
+      }
+      if (lane == 0) {
+        a.mask[q] = am;
+        a.depth[q] = a.normalized_depth ? ad / (am + 1e-10f) : ad;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          a.rgb_out[q * 3 + c] = ar[c];
+          a.nrm_out[q * 3 + c] = an[c];
+        }
+      }
+      nsim_wave_fence();
+      // ---- backward of the compositing: d alpha, d rgb (back to front: see k_alpha_to_vw_bwd)
+      float bcarry = 0.f;
+      const int64_t nchunks = (n + 63) / 64;
+      for (int64_t c = nchunks - 1; c >= 0; --c) {
+        const int64_t i = c * 64 + (63 - lane);
+        const bool valid = i < n;
+        float gvw = 0.f, w = 0.f;
+        if (valid) {
+          w = a.vw[st + i];
+          const float x0 = a.rgb[(st + i) * 3 + 0], x1 = a.rgb[(st + i) * 3 + 1], x2 = a.rgb[(st + i) * 3 + 2];
+          gvw = gr[0] * x0 + gr[1] * x1 + gr[2] * x2;
+          a.drgb[(st + i) * 3 + 0] = w * gr[0];
+          a.drgb[(st + i) * 3 + 1] = w * gr[1];
+          a.drgb[(st + i) * 3 + 2] = w * gr[2];
+        }
+        const float g = gvw * w;
+        const float incl = wave_incl_sum(g);
+        const float tot = wave_shfl(incl, 63);
+        float excl = wave_shfl(incl, lane - 1);
+        if (lane == 0) excl = 0.f;
+        const float suffix = bcarry + excl;
+        if (valid) a.dalpha[st + i] = gvw * a.trans[st + i] - suffix / (1.0f - a.alpha[st + i] + 1e-10f);
+        bcarry += tot;
+      }
+      nsim_wave_fence();
+      // ---- backward of sdf -> alpha
+      float ds_acc = 0.f;
+      for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        if (i < n) {
+          float g = 0.f;
+          const float x0 = a.sdf[st + i];
+          const float c0 = nsim_sigmoid(x0 * s);
+          if (i + 1 < n) {
+            const float x1 = a.sdf[st + i + 1];
+            const float c1 = nsim_sigmoid(x1 * s);
+            const float raw = (c0 - c1 + 1e-5f) / (c0 + 1e-5f);
+            if (raw >= 0.f && raw <= 1.f) {
+              const float ga = a.dalpha[st + i];
+              const float den = c0 + 1e-5f;
+              const float da_dc0 = (c1) / (den * den);
+              const float da_dc1 = -1.0f / den;
+              g += ga * da_dc0 * s * c0 * (1.f - c0);
+              ds_acc += ga * (da_dc0 * x0 * c0 * (1.f - c0) + da_dc1 * x1 * c1 * (1.f - c1));
+            }
+          }
+          if (i >= 1) {
+            const float xm = a.sdf[st + i - 1];
+            const float cm = nsim_sigmoid(xm * s);
+            const float raw = (cm - c0 + 1e-5f) / (cm + 1e-5f);
+            if (raw >= 0.f && raw <= 1.f) g += a.dalpha[st + i - 1] * (-1.0f / (cm + 1e-5f)) * s * c0 * (1.f - c0);
+          }
+          a.dsdf[st + i] = g;
+        }
+      }
+      if (a.dln && a.forward_inv_s <= 0.f) r3 = wave_sum(ds_acc) * s * a.factor;
+    }
+  } else {
+    // ---- element-wise part: sum gt^2 over all rays, eikonal terms + gradients on the S + M samples
+    const int64_t eb = (int64_t)blockIdx.x - a.ray_blocks, neb = (int64_t)gridDim.x - a.ray_blocks;
+    const int64_t St = a.S + a.M, n_img = 3 * a.N, top = n_img > St ? n_img : St;
+    const float inv_S = 1.0f / (float)(a.S > 0 ? a.S : 1), inv_M = 1.0f / (float)(a.M > 0 ? a.M : 1);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int64_t i = eb * PACK_BLOCK + threadIdx.x; i < top; i += neb * PACK_BLOCK) {
+      if (i < n_img) {
+        const float g = a.gt[i];
+        a0 += g * g;
+      }
+      if (i < St) {
+        const float x = a.nab[3 * i], y = a.nab[3 * i + 1], z = a.nab[3 * i + 2];
+        const float nrm = sqrtf(x * x + y * y + z * z);
+        const float e = nrm - 1.0f;
+        const bool ren = i < a.S;
+        if (ren) a1 += e * e;
+        else a2 += e * e;
+        const float k = nrm > 0.f ? a.w_eik * (ren ? inv_S : inv_M) * 2.0f * (nrm - 1.0f) / nrm : 0.f;
+        a.dnab[3 * i] = k * x;
+        a.dnab[3 * i + 1] = k * y;
+        a.dnab[3 * i + 2] = k * z;
+      }
+    }
+    r0 = wave_sum(a0);
+    r1 = wave_sum(a1) * inv_S;
+    r2 = wave_sum(a2) * inv_M;
+  }
+  if (lane == 0) {
+    red[0][wave] = r0;
+    red[1][wave] = r1;
+    red[2][wave] = r2;
+    red[3][wave] = r3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float tot = 0.f;
+    for (int w = 0; w < PACK_WAVES_PER_BLOCK; ++w) tot += red[threadIdx.x][w];
+    if (tot != 0.f) {
+      if (threadIdx.x == 0) atomicAdd(a.acc, tot * inv_n);
+      else if (threadIdx.x < 3) atomicAdd(a.acc + threadIdx.x, tot);
+      else if (a.dln) atomicAdd(a.dln, tot);
+    }
+  }
+}
+
 // ================================================================================== C ABI
 extern "C" {
 
@@ -681,6 +866,34 @@ int nsim_neus_composite_fwd(const float* sdf, const float* ln_inv_s, float ln_in
   hipLaunchKernelGGL((k_composite_fwd<true>), pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, nullptr, t, rgb, nrm,
                      pack_infos, P, normalized_depth, vw, trans, mask, depth, rgb_out, nrm_out, out_idx, sdf, ln_inv_s,
                      ln_inv_s_factor, forward_inv_s, alpha);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_render_head(const float* sdf, const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, const float* t,
+                     const float* rgb, const float* nablas, const int64_t* pack_infos, int64_t P, int normalized_depth,
+                     const float* gt, int64_t N, int64_t S, int64_t M, float w_eikonal, const int64_t* out_idx, float* alpha,
+                     float* vw, float* trans, float* mask, float* depth, float* rgb_out, float* nrm_out, float* acc,
+                     float* dalpha, float* dsdf, float* drgb, float* dnablas, float* d_ln_inv_s, void* stream) {
+  if (P < 0 || N <= 0 || S < 0 || M < 0) return 2;
+  if (!gt || !acc || (S + M > 0 && (!nablas || !dnablas))) return 4;
+  if (P > 0 && (!sdf || !t || !rgb || !pack_infos || !alpha || !vw || !trans || !mask || !depth || !rgb_out || !nrm_out ||
+                !dalpha || !dsdf || !drgb)) return 4;
+  if (!ln_inv_s && !(forward_inv_s > 0.f)) return 4;
+  RenderHeadArgs a;
+  a.sdf = sdf; a.ln_inv_s = ln_inv_s; a.t = t; a.rgb = rgb; a.nab = nablas; a.gt = gt;
+  a.pi = pack_infos; a.out_idx = out_idx;
+  a.P = P; a.N = N; a.S = S; a.M = M;
+  a.factor = ln_inv_s_factor; a.forward_inv_s = forward_inv_s; a.w_eik = w_eikonal;
+  a.normalized_depth = normalized_depth;
+  a.ray_blocks = (int)nsim_blocks(P > 0 ? P : 1, PACK_WAVES_PER_BLOCK);
+  if (P == 0) a.ray_blocks = 0;
+  a.alpha = alpha; a.vw = vw; a.trans = trans; a.mask = mask; a.depth = depth; a.rgb_out = rgb_out; a.nrm_out = nrm_out;
+  a.acc = acc; a.dalpha = dalpha; a.dsdf = dsdf; a.drgb = drgb; a.dnab = dnablas; a.dln = d_ln_inv_s;
+  const int64_t top = 3 * N > S + M ? 3 * N : S + M;
+  int64_t eb = nsim_blocks(top, PACK_BLOCK);
+  if (eb > 128) eb = 128;                      // three single-address atomics per workgroup
+  hipLaunchKernelGGL(k_render_head, dim3((unsigned)(a.ray_blocks + eb)), dim3(PACK_BLOCK), 0, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

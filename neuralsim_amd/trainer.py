@@ -65,6 +65,9 @@ class RenderTrainer:
         # the with-grad gather + decoders are queued at a capacity BEFORE the size of the kept sample set is read
         # (NSIM_SPEC_FORWARD=0: after it, at the exact size)
         self.spec_forward = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
+        # the differentiable tail of the fused step (compositing, losses, their backward) as ONE launch (NSIM_RENDER_HEAD=0:
+        # the four launches it replaces)
+        self.render_head = os.environ.get("NSIM_RENDER_HEAD", "1") == "1"
         # measurement aid (bench.py ``exposed_allreduce_ms``): every rank keeps its local gradients, no collective is issued
         self.skip_allreduce = False
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
@@ -332,27 +335,35 @@ class RenderTrainer:
             sc, vec, out_idx = torch.empty([2, N], **f32), torch.empty([2, N, 3], **f32), None
         else:
             sc, vec, out_idx = sc0.view(2, N), vec0.view(2, N, 3), tested["rays_inds"]
-        # sdf -> alpha -> visibility weights -> images: one launch
-        call("nsim_neus_composite_fwd", ptr(sdf), ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(t), ptr(rgb), ptr(nab),
-             ptr(pi), R, nd, ptr(alpha), ptr(vw), ptr(trans), ptr(sc[0]), ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
         gt = batch["gt"]
-        # the loss head in one launch: acc = (mse, eikonal(render samples), eikonal(uniform points)) and the gradients of
-        # loss = mse + w (eik + eik) w.r.t. the image and the nablas (they do not depend on the loss values)
-        d_img, dnab = torch.empty([N, 3], **f32), torch.empty([St, 3], **f32)
-        call("nsim_train_loss_head", ptr(vec[0]), ptr(gt), N * 3, ptr(nab), S, M, float(self.w_eikonal), ptr(acc),
-             ptr(d_img), ptr(dnab))
+        dalpha = torch.empty([S], **f32)
+        if self.render_head:
+            # sdf -> alpha -> visibility weights -> images -> photometric + eikonal losses -> their whole backward down to
+            # d sdf / d rgb / d nablas / d ln_inv_s: ONE launch (csrc/pack_ops.hip k_render_head; four launches otherwise)
+            dnab = torch.empty([St, 3], **f32)
+            call("nsim_render_head", ptr(sdf), ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd,
+                 ptr(gt), N, S, M, float(self.w_eikonal), ptr(out_idx), ptr(alpha), ptr(vw), ptr(trans), ptr(sc[0]), ptr(sc[1]),
+                 ptr(vec[0]), ptr(vec[1]), ptr(acc), ptr(dalpha), ptr(dsdf), ptr(drgb), ptr(dnab), ptr(dln))
+        else:
+            # sdf -> alpha -> visibility weights -> images: one launch
+            call("nsim_neus_composite_fwd", ptr(sdf), ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(t), ptr(rgb), ptr(nab),
+                 ptr(pi), R, nd, ptr(alpha), ptr(vw), ptr(trans), ptr(sc[0]), ptr(sc[1]), ptr(vec[0]), ptr(vec[1]), ptr(out_idx))
+            # the loss head in one launch: acc = (mse, eikonal(render samples), eikonal(uniform points)) and the gradients of
+            # loss = mse + w (eik + eik) w.r.t. the image and the nablas (they do not depend on the loss values)
+            d_img, dnab = torch.empty([N, 3], **f32), torch.empty([St, 3], **f32)
+            call("nsim_train_loss_head", ptr(vec[0]), ptr(gt), N * 3, ptr(nab), S, M, float(self.w_eikonal), ptr(acc),
+                 ptr(d_img), ptr(dnab))
+            # ---------------------------------------------------------------- backward
+            # (drgb / dsdf come zeroed: the free points have no colour / alpha consumers)
+            call("nsim_composite_bwd", ptr(alpha), ptr(trans), ptr(vw), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(sc[0]),
+                 ptr(sc[1]), None, None, ptr(d_img), None, None, ptr(dalpha), ptr(drgb), None, ptr(out_idx))
+            call("nsim_neus_alpha_bwd", ptr(sdf), ptr(dalpha), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(dsdf),
+                 ptr(dln))
         cst = getattr(self, "_fused_consts", None)
         if cst is None or cst[0] != (dev, float(self.w_eikonal)):
             cst = self._fused_consts = ((dev, float(self.w_eikonal)),
                                         torch.tensor([1.0, self.w_eikonal, self.w_eikonal], **f32))
         w_vec = cst[1]
-        # ---------------------------------------------------------------- backward
-        dalpha = torch.empty([S], **f32)
-        # (drgb / dsdf come zeroed: the free points have no colour / alpha consumers)
-        call("nsim_composite_bwd", ptr(alpha), ptr(trans), ptr(vw), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(sc[0]),
-             ptr(sc[1]), None, None, ptr(d_img), None, None, ptr(dalpha), ptr(drgb), None, ptr(out_idx))
-        call("nsim_neus_alpha_bwd", ptr(sdf), ptr(dalpha), ptr(pi), R, ptr(ln_inv_s), model.ln_inv_s_factor, fis, ptr(dsdf),
-             ptr(dln))
         gn_total = torch.empty([St, 3], **f32)
         call("nsim_field_bwd_rad", fm, ptr(wpack), ptr(nab), ptr(rgb), None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), ptr(ha),
              St, ptr(dnab), ptr(drgb), ptr(gn_total), ptr(drad_w), ptr(drad_b), ptr(dha), None, None)

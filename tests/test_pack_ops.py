@@ -281,3 +281,54 @@ def test_neus_composite_fwd_is_alpha_then_composite(backend):
             res.append([x.cpu() for x in (alpha, vw, tr, m, dp, ro, no)])
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("every_ray", [False, True])
+def test_render_head_equals_the_four_launches_it_replaces(backend, every_ray):
+    """``nsim_render_head`` (one launch) vs nsim_neus_composite_fwd -> nsim_train_loss_head -> nsim_composite_bwd ->
+    nsim_neus_alpha_bwd on random packs (empty packs, packs longer than a wave, rays outside the packs): same images, same
+    three loss terms, same d alpha / d sdf / d rgb / d nablas / d ln_inv_s."""
+    from neuralsim_amd import _lib
+    from neuralsim_amd.graphics import pack_ops as po
+    g = torch.Generator().manual_seed(5)
+    N = 37
+    R = N if every_ray else 23
+    n = torch.randint(0, 150, (R,), generator=g)
+    n[3], n[7] = 0, 1
+    S, M = int(n.sum()), 11
+    St = S + M
+    dev = backend
+    f32 = dict(dtype=torch.float32, device=dev)
+    pi = po.get_pack_infos_from_n(n.to(dev))
+    sdf = (torch.randn(S, generator=g) * 0.05).to(dev)
+    t = torch.rand(S, generator=g).to(dev)
+    rgb, nab = torch.rand(S, 3, generator=g).to(dev), (torch.randn(St, 3, generator=g) * 0.7).to(dev)
+    gt = torch.rand(N, 3, generator=g).to(dev)
+    ln = torch.tensor([0.35], **f32)
+    out_idx = None if every_ray else torch.randperm(N, generator=g)[:R].sort().values.to(dev)
+    w_eik, factor, nd = 0.1, 10.0, 0
+    call, ptr = _lib.call, _lib.ptr
+
+    def bufs():
+        z = lambda *sh: torch.zeros(list(sh), **f32)          # noqa: E731
+        e = lambda *sh: torch.empty(list(sh), **f32)          # noqa: E731
+        return dict(alpha=e(S), vw=e(S), trans=e(S), mask=z(N), depth=z(N), img=z(N, 3), nimg=z(N, 3), acc=z(3), dalpha=e(S),
+                    dsdf=z(St), drgb=z(St, 3), dnab=e(St, 3), dln=z(1))
+    a = bufs()
+    call("nsim_neus_composite_fwd", ptr(sdf), ptr(ln), factor, 0.0, ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(a["alpha"]),
+         ptr(a["vw"]), ptr(a["trans"]), ptr(a["mask"]), ptr(a["depth"]), ptr(a["img"]), ptr(a["nimg"]), ptr(out_idx))
+    d_img = torch.empty([N, 3], **f32)
+    call("nsim_train_loss_head", ptr(a["img"]), ptr(gt), N * 3, ptr(nab), S, M, w_eik, ptr(a["acc"]), ptr(d_img), ptr(a["dnab"]))
+    call("nsim_composite_bwd", ptr(a["alpha"]), ptr(a["trans"]), ptr(a["vw"]), ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd,
+         ptr(a["mask"]), ptr(a["depth"]), None, None, ptr(d_img), None, None, ptr(a["dalpha"]), ptr(a["drgb"]), None, ptr(out_idx))
+    call("nsim_neus_alpha_bwd", ptr(sdf), ptr(a["dalpha"]), ptr(pi), R, ptr(ln), factor, 0.0, ptr(a["dsdf"]), ptr(a["dln"]))
+    b = bufs()
+    call("nsim_render_head", ptr(sdf), ptr(ln), factor, 0.0, ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(gt), N, S, M, w_eik,
+         ptr(out_idx), ptr(b["alpha"]), ptr(b["vw"]), ptr(b["trans"]), ptr(b["mask"]), ptr(b["depth"]), ptr(b["img"]), ptr(b["nimg"]),
+         ptr(b["acc"]), ptr(b["dalpha"]), ptr(b["dsdf"]), ptr(b["drgb"]), ptr(b["dnab"]), ptr(b["dln"]))
+    for k in ("alpha", "vw", "trans", "mask", "depth", "img", "nimg", "dalpha", "dsdf", "drgb", "dnab"):
+        x, y = a[k].cpu(), b[k].cpu()
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-7), (k, float((x - y).abs().max()))
+    assert torch.allclose(a["acc"].cpu(), b["acc"].cpu(), rtol=2e-5, atol=1e-7), (a["acc"], b["acc"])
+    assert torch.allclose(a["dln"].cpu(), b["dln"].cpu(), rtol=1e-4, atol=1e-8), (a["dln"], b["dln"])
+    assert float(b["acc"][0]) > 0 and float(b["acc"][1]) > 0 and float(b["acc"][2]) > 0
