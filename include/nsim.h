@@ -212,6 +212,13 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
                       int64_t* pack_infos_out, int64_t* ridx_out, const float* rays_o, const float* rays_d,
                       float* x_out, void* stream);
+/* nsim_merge_sorted of up-sampling stage k followed, in the same launch, by nsim_upsample_stage of stage k + 1 on the merged
+ * samples (both one wave per ray; v_a / v_b / v_out = the no-grad SDFs, required): t_new [R, n_fine] (+ x_new) are the next
+ * stage's draws; scratch [>= merged sample count] as nsim_upsample_stage.  Same values as the two calls. */
+int nsim_merge_upsample(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b, const float* v_b,
+                        int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out, int64_t* ridx_out, float inv_s,
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
+                        const float* rays_d, float* x_new, void* stream);
 
 /* ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): from the no-grad SDF of all
  * samples keep those that bound an interval with visibility weight > thre.  count -> counts [R]; emit (given

@@ -101,6 +101,7 @@ SIGNATURES = {
     "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],
     "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P, _P, _P, _P],
     "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_merge_upsample": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "nsim_compress_count": [_P, _P, _I64, _P, _F, _F, _F, _P],
     "nsim_compress_emit": [_P, _P, _P, _I64, _P, _F, _F, _F, _P, _P, _P, _I64],
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],

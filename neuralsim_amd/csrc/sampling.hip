@@ -307,25 +307,14 @@ __device__ __forceinline__ float upsample_alpha(const float* t, const float* sdf
   }
 }
 
-__global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __restrict__ t,
-                                                                const float* __restrict__ sdf,
-                                                                const int64_t* __restrict__ pi, int64_t R,
-                                                                float inv_s, int n_fine, int use_est,
-                                                                float* __restrict__ csum,
-                                                                float* __restrict__ t_new,
-                                                                const float* __restrict__ rays_o,
-                                                                const float* __restrict__ rays_d,
-                                                                float* __restrict__ x_new) {
-  // the running sums of a ray's interval weights live in LDS (<= SMP_LDS_FLOATS intervals; longer rays use the global
-  // scratch): the inverse-CDF search below is eight DEPENDENT reads per new sample -- 13 us per launch from L2
-  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
-  const int64_t r = smp_wave_id();
-  if (r >= R) return;
+// one ray (one wave): n_fine new depths drawn from the interval weights of the ray's samples tt / ss [n]; ``lds`` holds the
+// running sums when the ray fits (SMP_LDS_FLOATS intervals), the global scratch ``cs_glob`` otherwise
+__device__ __forceinline__ void upsample_ray(const float* tt, const float* ss, int64_t n, int64_t r, float inv_s, int n_fine,
+                                             int use_est, float* lds, float* cs_glob, float* __restrict__ t_new,
+                                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                             float* __restrict__ x_new) {
   const int lane = nsim_lane();
-  const int64_t st = pi[2 * r], n = pi[2 * r + 1];
   const int64_t ni = n - 1;  // intervals
-  const float* tt = t + st;
-  const float* ss = sdf + st;
   float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
   if (x_new) {
 #pragma unroll
@@ -382,8 +371,27 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
       }
     }
   };
-  if (ni <= SMP_LDS_FLOATS) body(&smp_lds[threadIdx.x >> 6][0]);
-  else body(csum + st);
+  if (ni <= SMP_LDS_FLOATS) body(lds);
+  else body(cs_glob);
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __restrict__ t,
+                                                                const float* __restrict__ sdf,
+                                                                const int64_t* __restrict__ pi, int64_t R,
+                                                                float inv_s, int n_fine, int use_est,
+                                                                float* __restrict__ csum,
+                                                                float* __restrict__ t_new,
+                                                                const float* __restrict__ rays_o,
+                                                                const float* __restrict__ rays_d,
+                                                                float* __restrict__ x_new) {
+  // the running sums of a ray's interval weights live in LDS (<= SMP_LDS_FLOATS intervals; longer rays use the global
+  // scratch): the inverse-CDF search below is eight DEPENDENT reads per new sample -- 13 us per launch from L2
+  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int64_t st = pi[2 * r], n = pi[2 * r + 1];
+  upsample_ray(t + st, sdf + st, n, r, inv_s, n_fine, use_est, &smp_lds[threadIdx.x >> 6][0], csum + st, t_new, rays_o, rays_d,
+               x_new);
 }
 
 // -------------------------------------------------------------------------------- sorted merge
@@ -404,21 +412,14 @@ __device__ __forceinline__ int64_t smp_upper_bound(const float* a, int64_t n, fl
   return lo;
 }
 
-__global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restrict__ t_a,
-                                                              const float* __restrict__ v_a,
-                                                              const int64_t* __restrict__ pia,
-                                                              const float* __restrict__ t_b,
-                                                              const float* __restrict__ v_b, int64_t R, int nb,
-                                                              float* __restrict__ t_out, float* __restrict__ v_out,
-                                                              int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
-                                                              const float* __restrict__ rays_o,
-                                                              const float* __restrict__ rays_d,
-                                                              float* __restrict__ x_out) {
-  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
-  const int64_t r = smp_wave_id();
-  if (r >= R) return;
+// one ray (one wave): merge its sorted depth lists a [na] (values v_a) and b [nb] (values v_b) into the packed output at
+// ``so``; ``lds`` holds both lists when they fit
+__device__ __forceinline__ void merge_ray(const float* __restrict__ t_a, const float* __restrict__ v_a, int64_t sa, int64_t na,
+                                          const float* __restrict__ t_b, const float* __restrict__ v_b, int64_t r, int nb,
+                                          int64_t so, float* lds, float* __restrict__ t_out, float* __restrict__ v_out,
+                                          int64_t* __restrict__ ridx_out, const float* __restrict__ rays_o,
+                                          const float* __restrict__ rays_d, float* __restrict__ x_out) {
   const int lane = nsim_lane();
-  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
   float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
   if (x_out) {
 #pragma unroll
@@ -427,14 +428,9 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
       rd[c] = rays_d[3 * r + c];
     }
   }
-  const int64_t so = sa + r * (int64_t)nb;
-  if (lane == 0) {
-    pio[2 * r] = so;
-    pio[2 * r + 1] = na + nb;
-  }
   // both depth lists of the ray in LDS when they fit (a first, then b): the rank searches are 6-8 DEPENDENT reads each
   const bool in_lds = na + nb <= SMP_LDS_FLOATS;
-  float* la = &smp_lds[threadIdx.x >> 6][0];
+  float* la = lds;
   float* lb = la + na;
   if (in_lds) {
     for (int64_t i = lane; i < na; i += 64) la[i] = t_a[sa + i];
@@ -467,6 +463,54 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
   };
   if (in_lds) body((const float*)la, (const float*)lb);
   else body(t_a + sa, t_b + r * (int64_t)nb);
+}
+
+__global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restrict__ t_a,
+                                                              const float* __restrict__ v_a,
+                                                              const int64_t* __restrict__ pia,
+                                                              const float* __restrict__ t_b,
+                                                              const float* __restrict__ v_b, int64_t R, int nb,
+                                                              float* __restrict__ t_out, float* __restrict__ v_out,
+                                                              int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
+                                                              const float* __restrict__ rays_o,
+                                                              const float* __restrict__ rays_d,
+                                                              float* __restrict__ x_out) {
+  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
+  const int64_t so = sa + r * (int64_t)nb;
+  if (nsim_lane() == 0) {
+    pio[2 * r] = so;
+    pio[2 * r + 1] = na + nb;
+  }
+  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, nb, so, &smp_lds[threadIdx.x >> 6][0], t_out, v_out, ridx_out, rays_o, rays_d, x_out);
+}
+
+// merge of up-sampling stage k AND the draw of stage k + 1 in one launch (round 4): both are one-wave-per-ray; the merged
+// samples of a ray are handed from the merge to the draw through t_out / v_out (written and read by the SAME wave, ordered by
+// the wave-level fence), the LDS row is used by the merge first and by the draw's running sums afterwards
+__global__ void __launch_bounds__(SMP_BLOCK) k_merge_upsample(const float* __restrict__ t_a, const float* __restrict__ v_a,
+                                                                const int64_t* __restrict__ pia, const float* __restrict__ t_b,
+                                                                const float* __restrict__ v_b, int64_t R, int nb,
+                                                                float* __restrict__ t_out, float* __restrict__ v_out,
+                                                                int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
+                                                                float inv_s, int n_fine, int use_est, float* __restrict__ csum,
+                                                                float* __restrict__ t_new, const float* __restrict__ rays_o,
+                                                                const float* __restrict__ rays_d, float* __restrict__ x_new) {
+  __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
+  const int64_t r = smp_wave_id();
+  if (r >= R) return;
+  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
+  const int64_t so = sa + r * (int64_t)nb;
+  if (nsim_lane() == 0) {
+    pio[2 * r] = so;
+    pio[2 * r + 1] = na + nb;
+  }
+  float* lds = &smp_lds[threadIdx.x >> 6][0];
+  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, nb, so, lds, t_out, v_out, ridx_out, nullptr, nullptr, nullptr);
+  nsim_wave_fence();
+  upsample_ray(t_out + so, v_out + so, na + nb, r, inv_s, n_fine, use_est, lds, csum + so, t_new, rays_o, rays_d, x_new);
 }
 
 // ------------------------------------------------------------------ compressed query mode
@@ -672,6 +716,20 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
   if (x_out && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
                      R, nb, t_out, v_out, pack_infos_out, ridx_out, rays_o, rays_d, x_out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_merge_upsample(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b, const float* v_b,
+                        int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out, int64_t* ridx_out, float inv_s,
+                        int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
+                        const float* rays_d, float* x_new, void* stream) {
+  if (R <= 0) return 0;
+  if (n_fine <= 0 || !v_a || !v_b || !v_out || !scratch || !t_new) return 4;
+  if (x_new && !(rays_o && rays_d)) return 24;
+  hipLaunchKernelGGL(k_merge_upsample, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b, R,
+                     nb, t_out, v_out, pack_infos_out, ridx_out, inv_s, n_fine, use_estimate_alpha, scratch, t_new, rays_o,
+                     rays_d, x_new);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

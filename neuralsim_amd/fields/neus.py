@@ -84,6 +84,8 @@ def fine_list(qp: dict):
 
 
 _SPEC_FORWARD = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
+# up-sampling: the merge of stage k and the draws of stage k + 1 as ONE launch (nsim_merge_upsample; 0: two launches)
+_FUSE_MERGE_UPSAMPLE = os.environ.get("NSIM_FUSE_MERGE_UPSAMPLE", "1") == "1"
 
 
 class _FieldFn(torch.autograd.Function):
@@ -1147,13 +1149,18 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
-        for k_stage, (nf, fac) in enumerate(zip(fine, qp.get("upsample_inv_s_factors", [1, 4, 16]))):
+        factors = list(qp.get("upsample_inv_s_factors", [1, 4, 16]))
+        stages = list(zip(fine, factors))
+        fuse = _FUSE_MERGE_UPSAMPLE
+        t_new = x_new = None
+        for k_stage, (nf, fac) in enumerate(stages):
             nf = int(nf)
-            t_new = torch.empty([R, nf], **f32)
-            scratch = torch.empty([S], **f32)
-            x_new = torch.empty([R * nf, 3], **f32) if with_x else None
-            _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
-                      _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new))
+            if t_new is None:       # the stage's draws (stage 0, or every stage without the fused merge + draw launch)
+                t_new = torch.empty([R, nf], **f32)
+                scratch = torch.empty([S], **f32)
+                x_new = torch.empty([R * nf, 3], **f32) if with_x else None
+                _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
+                          _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new))
             ridx_new = self._arange_repeat(R, nf, dev)
             if with_x:
                 sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if per_ray else None,
@@ -1164,10 +1171,21 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
             pi2 = torch.empty([R, 2], dtype=torch.long, device=dev)
-            last = k_stage == len(fine) - 1
+            last = k_stage == len(stages) - 1
             ridx = torch.empty([S2], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and last)) else None
-            _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
-                      nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None)
+            if fuse and not last:       # merge of this stage + the draws of the next in one launch
+                nf2, fac2 = int(stages[k_stage + 1][0]), stages[k_stage + 1][1]
+                t_nx = torch.empty([R, nf2], **f32)
+                scratch = torch.empty([S2], **f32)
+                x_nx = torch.empty([R * nf2, 3], **f32) if with_x else None
+                _lib.call("nsim_merge_upsample", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R, nf,
+                          _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), inv_s0 * float(fac2), nf2, use_est,
+                          _lib.ptr(scratch), _lib.ptr(t_nx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_nx))
+                t_new, x_new = t_nx, x_nx
+            else:
+                _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
+                          nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None)
+                t_new = x_new = None
             t, sdf, pi, S = t2, sdf2, pi2, S2
         self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
         return t, sdf, pi, ridx, counts, total_m
