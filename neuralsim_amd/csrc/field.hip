@@ -335,6 +335,9 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 
 
 #define FIELD_WAVES 4
+#ifndef NSIM_FWD_JDIRECT
+#define NSIM_FWD_JDIRECT 1      // k_field MODE 3, <= 16 levels: features through the LDS image, dh/dx straight into registers
+#endif
 
 // Development aid (-DNSIM_KTIME, never in the product build): s_memtime stamps of wave 0 of the first 64 workgroups at
 // phase boundaries of their SECOND group iteration, read back by tools/ktime.py through nsim_debug_ktime.
@@ -397,6 +400,8 @@ __device__ __forceinline__ const char* stage_weights(char* smem, const FieldArgs
 __device__ __forceinline__ float vecf(const char* W, const FieldLayout& L, int v, int hi, int k) {
   return reinterpret_cast<const float*>(W + L.vec[v])[hi * 32 + k];
 }
+
+struct alignas(8) nsim_f2 { float x, y; };
 
 struct TilePoint {
   float xx[3], vd[3];
@@ -537,9 +542,20 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   static_assert(!GL2 || (MODE == 3 && NC == 2), "GL2 is the 17..32-level forward");
   constexpr bool GLDS = (MODE == 3 && (NC == 1 || GL2));
   const int nlv = a.lotd.num_levels;      // plane levels past it are neither written by the gather nor read here
-  char* pf = GLDS ? smem + wbytes + wave * (NC == 1 ? 16384 : 1024 * nlv) : nullptr;
+  // JDIR (<= 16 levels, NSIM_FWD_JDIRECT): the LDS image holds the FEATURES only (4 KB per wave, 4 copies of 4 levels each);
+  // dh/dx -- consumed once, at the very end of the tile -- is loaded straight into registers after the image has been
+  // read, so its latency hides behind the decoder.  LDS per workgroup 124 KB -> 76 KB: TWO workgroups per CU, two waves per
+  // SIMD (the registers, 244 of 512, already allowed it).
+  constexpr bool JDIR = GLDS && NC == 1 && NSIM_FWD_JDIRECT;
+  char* pf = GLDS ? smem + wbytes + wave * (NC == 1 ? (JDIR ? 4096 : 16384) : 1024 * nlv) : nullptr;
   auto prefetch_planes = [&](int64_t tile_n) {
     const int64_t s0 = tile_n * 32;
+    if constexpr (JDIR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)      // lanes 16 k .. 16 k + 15: the 256 B of level 4 i + k
+        nsim_glds16(a.h_pl + ((int64_t)(4 * i + (lane >> 4)) * a.PS + s0) * 2 + 4 * (lane & 15), pf + 1024 * i);
+      return;
+    }
 #pragma unroll
     for (int l = 0; l < 16 * NC; ++l) {
       if (!LV_OK(l)) continue;
@@ -566,7 +582,32 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // traffic instead of a second latency-bound random gather.
     float h[16 * NC];
     float J[(NC == 1 || GL2) ? 16 * NC : 1][3];     // NC == 2 without the LDS image re-reads dh/dx where it is consumed
-    if constexpr (GLDS) {
+    if constexpr (JDIR) {
+      nsim_wait_vm0();                          // this tile's image has landed
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const float* hp = reinterpret_cast<const float*>(pf + 256 * l) + 2 * j;
+          h[r0] = valid ? hp[0] : 0.f;
+          h[r0 + 1] = valid ? hp[1] : 0.f;
+        }
+      nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+      // dh/dx of a point past the end: the last point's (finite values; nothing of such a lane is stored)
+      const int64_t sc = valid ? s : a.S - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const nsim_f2* jp = reinterpret_cast<const nsim_f2*>(a.J_pl + ((int64_t)l * a.PS + sc) * 6);
+          const nsim_f2 v0 = jp[0], v1 = jp[1], v2 = jp[2];
+          J[r0][0] = v0.x; J[r0][1] = v0.y; J[r0][2] = v1.x;
+          J[r0 + 1][0] = v1.y; J[r0 + 1][1] = v2.x; J[r0 + 1][2] = v2.y;
+        }
+      if (tile + wstride < ntiles) prefetch_planes(tile + wstride);
+    } else if constexpr (GLDS) {
       nsim_wait_vm0();                          // this tile's image has landed
 #pragma unroll
       for (int m = 0; m < NC; ++m)
@@ -2510,7 +2551,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     // where that still fits the 160 KB of a CU (NSIM_FWD_GL2=0: the direct-load kernel)
     size_t wl = weights_lds_bytes(meta);
     if (meta->precision != 0) wl = 0;
-    size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * 16384 : 0;
+    size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * (NSIM_FWD_JDIRECT ? 4096 : 16384) : 0;
     bool gl2 = false;
     if (field_nc(meta->lotd.num_levels) == 2 && meta->precision == 0) {
       static const bool gl2_on = !(getenv("NSIM_FWD_GL2") && atoi(getenv("NSIM_FWD_GL2")) == 0);
@@ -2524,7 +2565,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     // four rounds that each staged the weights and took a cold first tile (s_memtime stamps: 22.5 k vs 16.7 k ticks) --
     // one round of 256: 0.197 -> 0.189 ms per 0.31 M points (gather included); the 17..32-level kernel fits two per CU
     static const int fwd_grid_env = getenv("NSIM_FWD_GRID") ? atoi(getenv("NSIM_FWD_GRID")) : 0;
-    const int fwd_grid = fwd_grid_env > 0 ? fwd_grid_env : (pf_bytes ? 256 : 512);
+    const int fwd_grid = fwd_grid_env > 0 ? fwd_grid_env : ((pf_bytes && !(NSIM_FWD_JDIRECT && !gl2)) ? 256 : 512);
     return field_launch<3>(meta, a, wl + pf_bytes, fwd_grid, (hipStream_t)stream, gl2);
   }
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);

@@ -13,7 +13,8 @@ CS = ROOT / "neuralsim_amd" / "csrc"
 def main():
     src = CS / sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{CS}",
+    import os
+    cmd = ["/opt/rocm/bin/hipcc", *os.environ.get("RU_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{CS}",
            "-munsafe-fp-atomics", "--cuda-device-only", "-c", str(src), "-o", "/tmp/_ru.o",
            "-Rpass-analysis=kernel-resource-usage"]
     txt = subprocess.run(cmd, capture_output=True, text=True).stderr
