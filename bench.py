@@ -491,6 +491,7 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     KM = kernel_model(tr.model.encoding.cfg.num_levels, dm_.cfg.num_levels if dm_ is not None else 12)
     _lib.TIMER = _lib.KernelTimer(only=KM.keys()) if on_gpu else None
     _lib.CALL_COUNT = 0
+    _lib.HOST_WAIT = 0.0
     S_f = S_hit = 0
     marks = []
     t0 = time.perf_counter()
@@ -506,6 +507,7 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     timer, _lib.TIMER = _lib.TIMER, None
     abi_calls = _lib.CALL_COUNT
     _lib.CALL_COUNT = None
+    host_wait, _lib.HOST_WAIT = _lib.HOST_WAIT, None
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -583,7 +585,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                roofline=roofline, kernels=per_kernel,
                # C-ABI entry-point calls of this package per step (each is one kernel launch, three of them two); the ATen /
                # rocprim launches of the host glue (rand, fill, cat, compaction) are on top: profiles/round4_rocprofv3_kernel_stats
-               abi_calls_per_step=round(abi_calls / max(1, steps), 1) if abi_calls is not None else None)
+               abi_calls_per_step=round(abi_calls / max(1, steps), 1) if abi_calls is not None else None,
+               # host time blocked on the step's one size read: ~0 = the host (launch overhead) paces the step, not the GPU
+               host_wait_ms_per_step=round(host_wait / max(1, steps) * 1e3, 4))
     return out, it
 
 

@@ -296,6 +296,7 @@ def ensure_grad_scratch(device):
 
 
 CALL_COUNT = None        # bench.py sets it to 0 over the timed steps: number of C-ABI calls issued
+HOST_WAIT = None         # bench.py sets it to 0.0: seconds the host spent blocked on the step's one size read (fields/neus.py _compress)
 
 
 def call(name: str, *args):

@@ -166,17 +166,40 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_interleave_linstep(const int64_t
 }
 
 // ------------------------------------------------------------------------------------ packed_sort
-// Stable rank sort inside one pack: rank(i) = #{j : x_j < x_i  or (x_j == x_i and j < i)}.
-// O(n^2 / 64) per wave -- packs on this path hold O(10..500) samples (buffer_compose_renderer.py:687).  The pack is staged
-// in LDS once and every lane ranks up to four of its elements per sweep over it (an LDS broadcast read per x_j instead of
-// a global load per (i, j) pair: 1.01 ms per 2 M samples of the multi-object step before); packs beyond the staging
-// capacity take the direct path.
+// Stable sort inside one pack: rank(i) = #{j : x_j < x_i  or (x_j == x_i and j < i)}.
+// The packs of this path are CONCATENATIONS OF SORTED RUNS -- the depths of one ray as collected object by object
+// (buffer_compose_renderer.py:648-695: street samples, the samples of every vehicle the ray crosses, the distant shells) -- so
+// the pack is staged in LDS, its run heads (x_i < x_{i-1}) are found with ballots, and
+//   * one run: the pack is in order already (most rays: background + distant shells) -> identity;
+//   * <= PSORT_RUNS runs: rank(i) = offset in its own run + sum over the other runs of a binary search (elements <= x_i of
+//     the runs before it, < x_i of the runs after it: the same stable order) -- O(n runs log n) instead of O(n^2);
+//   * more runs (unstructured input): every lane ranks up to four elements per sweep over the staged pack, O(n^2 / 64).
+// Packs beyond the staging capacity take the direct O(n^2) path on global memory.
+// Round 4, multi-object step: 0.77 ms -> see profiles (2.6 M samples in 16 k packs).
 #define PSORT_CAP 1024
+#define PSORT_RUNS 16
+__device__ __forceinline__ int lds_upper_bound(const float* a, int n, float v) {      // #elements <= v
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int lds_lower_bound(const float* a, int n, float v) {      // #elements < v
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restrict__ x,
                                                               const int64_t* __restrict__ pi, int64_t P,
                                                               float* __restrict__ sorted,
                                                               int64_t* __restrict__ indices) {
   __shared__ float sx[PACK_WAVES_PER_BLOCK][PSORT_CAP];
+  __shared__ int srun[PACK_WAVES_PER_BLOCK][PSORT_RUNS + 1];
   const int64_t p = pack_wave_id();
   if (p >= P) return;
   const int lane = nsim_lane();
@@ -185,6 +208,42 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restr
   if (n <= PSORT_CAP) {
     for (int64_t i = lane; i < n; i += 64) sx[w][i] = x[st + i];
     wave_sync_lds();
+    const int nn = (int)n;
+    int nrun = 0;
+    for (int i0 = 0; i0 < nn; i0 += 64) {
+      const int i = i0 + lane;
+      const bool head = i < nn && (i == 0 || sx[w][i] < sx[w][i - 1]);
+      const unsigned long long m = wave_ballot(head);
+      if (head) {
+        const int pos = nrun + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < PSORT_RUNS) srun[w][pos] = i;
+      }
+      nrun += __popcll(m);
+    }
+    if (nrun <= 1) {
+      for (int i = lane; i < nn; i += 64) {
+        sorted[st + i] = sx[w][i];
+        indices[st + i] = st + i;
+      }
+      return;
+    }
+    if (nrun <= PSORT_RUNS) {
+      if (lane == 0) srun[w][nrun] = nn;
+      wave_sync_lds();
+      for (int i = lane; i < nn; i += 64) {
+        const float xi = sx[w][i];
+        int rank = 0;
+        for (int r = 0; r < nrun; ++r) {
+          const int b = srun[w][r], e = srun[w][r + 1];
+          if (e <= i) rank += lds_upper_bound(&sx[w][b], e - b, xi);
+          else if (b > i) rank += lds_lower_bound(&sx[w][b], e - b, xi);
+          else rank += i - b;
+        }
+        sorted[st + rank] = xi;
+        indices[st + rank] = st + i;
+      }
+      return;
+    }
     for (int64_t i0 = 0; i0 < n; i0 += 256) {      // four elements per lane and sweep
       float xi[4];
       int64_t ii[4], rank[4];

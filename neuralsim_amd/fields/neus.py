@@ -18,6 +18,7 @@ Host synchronisations per render: two (hit-ray compaction, marched-sample total)
 import ctypes
 import math
 import os
+import time
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -1240,6 +1241,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         if pre_sync_hook is not None:
             pre_sync_hook()                     # e.g. the trainer's prefetch of the next batch (its own sync lands here)
         Sk = M_true = None
+        _w0 = time.perf_counter() if _lib.HOST_WAIT is not None else 0.0
         if nt is not None:          # sizes from the host-mapped words: no stream synchronisation, no copy
             Sk = nt.wait(1, seq_k)
             if Sk is not None and total_m is not None:
@@ -1256,6 +1258,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 # synchronising reads from here on.  (Visible now = the stream was merely slow, e.g. first-use code
                 # loading on a cold box: the words stay in use.)
                 self._notify = False
+        if _lib.HOST_WAIT is not None:      # bench.py: host time spent blocked on the size of the kept set
+            _lib.HOST_WAIT += time.perf_counter() - _w0
         self._keep_stat = (R, Sk)
         if cap_k is not None and Sk <= cap_k and Sk > 0:
             self._spec_ok = True

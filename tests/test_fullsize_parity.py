@@ -54,6 +54,10 @@ TOL = dict(
 )
 
 
+# fused chain, permutohedral model: end-to-end gradient bound (rel. L2 per parameter group); set from the measured record
+PERMUTO_FUSED_GRAD = dict(f32=3e-2, fp16=0.2)      # measured: 5.2e-3 (table, 4 samples apart) / 6.5e-2 (table, fp16)
+
+
 def _report(name, rec):
     try:
         REPORT_DIR.mkdir(exist_ok=True)
@@ -308,9 +312,21 @@ def _api_path_body(precision, compressed, encoding):
 
 
 @pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_permuto_fused_step_matches_oracle_at_baseline_size(precision):
+    """The fused launch chain with the permutohedral-lattice model (bench ``variants.permuto_ms``) against the oracle's loss
+    and gradients of the same batch.  The chain samples for itself, so on the rough device-pre-trained lattice field a few
+    rays keep another sample count than the oracle's (see ``_api_path_body``): bounds of the end-to-end kind."""
+    _fused_step_body(precision, "permuto")
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
 def test_fused_step_matches_oracle_at_baseline_config(precision):
     """The bench's launch chain (no autograd engine) on one full batch: 8192 rays + 4096 uniform eikonal points."""
-    tr, p, occ, dev = _rig(precision)
+    _fused_step_body(precision, "lotd")
+
+
+def _fused_step_body(precision, encoding):
+    tr, p, occ, dev = _rig(precision, encoding)
     m = tr.model
     tol = TOL[precision]
     assert tr._fused_ok()
@@ -348,7 +364,17 @@ def test_fused_step_matches_oracle_at_baseline_config(precision):
                samples_oracle=int(ret_o["volume_buffer"]["t"].shape[0]), loss=float(loss), loss_oracle=float(loss_o))
     for k, v in got.items():
         rec["grad_" + k] = rel_l2(v.cpu(), ref[k])
-    _report(f"fused_{precision}", rec)
+    _report(("permuto_" if encoding == "permuto" else "") + f"fused_{precision}", rec)
+    if encoding == "permuto":
+        # measured (MI355X, round 4): f32 4 of 270 528 samples apart, loss 7e-8, gradients <= 5.2e-3 (table), 9.5e-4 (decoder);
+        # fp16 same sample count, table 6.5e-2, decoder weights 6.3e-2 / bias 0.105.  The sample sets differ by the rays whose up-sampling lands on the other
+        # side of a keep threshold, so the gradients agree to the fraction of the loss those rays carry
+        assert abs(rec["samples"] - rec["samples_oracle"]) <= max(8, rec["samples_oracle"] // 200), rec
+        assert abs(rec["loss"] - rec["loss_oracle"]) < 2e-2 * (1 + abs(rec["loss_oracle"]))
+        for k in got:      # (fp16: the decoder's bias gradient is a cancelling sum, see ``_api_path_body``: loose on its own)
+            lim = 1.0 if (k == "sdf_b" and precision == "fp16") else PERMUTO_FUSED_GRAD[precision]
+            assert rec["grad_" + k] < lim, (k, rec["grad_" + k])
+        return
     if precision == "f32":
         assert abs(rec["samples"] - rec["samples_oracle"]) <= 2 * tol["flips"]
         assert abs(rec["loss"] - rec["loss_oracle"]) < tol["loss"] * (1 + abs(rec["loss_oracle"]))

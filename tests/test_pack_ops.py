@@ -163,6 +163,33 @@ def test_packed_sort_and_linstep(backend):
     assert torch.equal(out, opo.interleave_linstep(start, n, 2))
 
 
+def test_packed_sort_of_concatenated_runs(backend):
+    """The compose renderer's packs are concatenations of sorted runs (one per object buffer crossed by the ray): the
+    kernel's identity path (one run), its run-merge path (<= 16 runs, ties inside and ACROSS runs) and its rank-sort paths
+    (many runs; a pack beyond the LDS staging capacity) all give the oracle's stable order."""
+    g = torch.Generator().manual_seed(21)
+    packs = []
+    packs.append(torch.sort(torch.rand(150, generator=g)).values)                                  # one run
+    runs = [torch.sort(torch.rand(k, generator=g)).values for k in (64, 1, 37, 90)]
+    runs[2][5:9] = runs[0][10]                                                                          # ties across runs
+    runs[3][0] = runs[0][10]
+    runs[2] = torch.sort(runs[2]).values
+    runs[3] = torch.sort(runs[3]).values
+    packs.append(torch.cat(runs))                                                                       # four runs
+    packs.append(torch.cat([torch.sort(torch.rand(3, generator=g)).values for _ in range(16)]))     # exactly 16 runs
+    packs.append(torch.rand(200, generator=g))                                                        # ~100 runs
+    packs.append(torch.zeros(70))                                                                       # all equal
+    packs.append(torch.cat([torch.sort(torch.rand(700, generator=g)).values for _ in range(2)]))    # beyond the capacity
+    packs.append(torch.empty(0))
+    packs.append(torch.tensor([0.5]))
+    n = torch.tensor([q.shape[0] for q in packs])
+    pi = opo.get_pack_infos_from_n(n)
+    x = torch.cat(packs)
+    s, idx = po.packed_sort(x.to(backend), pi.to(backend))
+    rs, ridx = opo.packed_sort(x, pi)
+    assert torch.equal(s.cpu(), rs) and torch.equal(idx.cpu(), ridx)
+
+
 def test_merge_two_packs_sorted(backend):
     g = torch.Generator().manual_seed(5)
     na = torch.tensor([3, 0, 5, 70, 1])
