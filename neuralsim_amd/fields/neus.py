@@ -787,20 +787,23 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     def _weight_pack(self):
         """The MFMA-fragment weight pack alone (the backward of a query made under a condition that has been cleaned since
         -- grown / conditioned tables -- needs the decoders' weights, not the current table)."""
-        if self._wpack_versions is None:
-            object.__setattr__(self, "_wpack_slot", None)
-            object.__setattr__(self, "_wpack_slot_s", None)
-            self._wpack_versions = True
+        self._invalidate_packs()
         self._wpack = self._pack_for(self.field_meta, "_wpack_slot")
         return self._wpack
+
+    def _invalidate_packs(self):
+        """After an invalidation by hand (optimizer step, precision switch): the packs are stale, their BUFFERS stay (a fresh
+        ``torch.zeros`` per step and pack was two fill launches of host pace each)."""
+        if self._wpack_versions is None:
+            for slot in ("_wpack_slot", "_wpack_slot_s"):
+                cur = getattr(self, slot, None)
+                object.__setattr__(self, slot, (None, cur[1]) if cur is not None else None)
+            self._wpack_versions = True
 
     def _shadow(self):
         """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
         grid16 = self._table16()
-        if self._wpack_versions is None:        # invalidated by hand (optimizer step, precision switch)
-            object.__setattr__(self, "_wpack_slot", None)
-            object.__setattr__(self, "_wpack_slot_s", None)
-            self._wpack_versions = True
+        self._invalidate_packs()
         self._wpack = self._pack_for(self.field_meta, "_wpack_slot")
         return grid16, self._wpack
 
