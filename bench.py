@@ -556,6 +556,27 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                                           "run")) + " -- NOT collected by the run that prints this line")
         except Exception:
             pass
+    # The ceilings that actually bind the two largest kernels sit between L1 and L2, not at HBM: the random 4-byte gather is
+    # limited by the TCP -> TCC request rate (one 128-byte line per distinct line touched), the gradient scatter by the rate
+    # of atomic requests; both ceilings are measured by micro-benchmarks on this chip, the kernels' request counts by PMC
+    # passes of this command (profiles/round4_l2_requests.json -- recorded, NOT collected by the run that prints this line)
+    lf = ROOT / "profiles" / "round4_l2_requests.json"
+    if lf.exists() and workload is None:
+        try:
+            rec_l = json.loads(lf.read_text())
+            kk = rec_l["kernels"]
+            ga, sc_ = kk["void k_lotd_gather_lm<1, false>(FieldArgs)"], kk["k_lotd_scatter(ScatterArgs)"]
+            roofline["cache_ceilings"] = dict(
+                gather=dict(kernel="k_lotd_gather_lm<1,false>", read_req_per_launch=ga["tcp_tcc_read_req"],
+                            achieved_Greq_s=ga["read_req_per_s"], ceiling_Greq_s=rec_l["calibration"]["l2_read_req_ceiling_per_s"] / 1e9,
+                            frac=ga["frac_of_l2_read_req_ceiling"]),
+                scatter=dict(kernel="k_lotd_scatter", atomic_req_per_launch=sc_["atomic_req"],
+                             achieved_Greq_s=sc_["atomic_req_per_s_G"], ceiling_Greq_s=rec_l["calibration"]["atomic_req_ceiling_per_s"] / 1e9,
+                             frac=sc_["frac_of_atomic_req_ceiling"]),
+                source="profiles/round4_l2_requests.json (rocprofv3 --pmc TCP_TCC_READ_REQ_sum / TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum "
+                       "passes of this command + tools/gather_pair_bench, tools/atomic_bench4), recorded")
+        except Exception:
+            pass
     # per-kernel roofline of every modelled entry point (the MFMA kernels against the dense fp16 peak)
     per_kernel = {}
     for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"]):

@@ -1471,6 +1471,9 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
           float* jp = a.J_pl + ep * 6;
           hp[0] = f0[q];
           hp[1] = f1[q];
+#ifdef NSIM_PROBE_GATHER_NOJ      // timing probe (wrong results): the dh/dx stores dropped but for an impossible case
+          if (f0[q] == 123.456f)
+#endif
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
             jp[c3] = j0[q][c3];

@@ -20,7 +20,7 @@ def main():
     rows = []
     for k, (cb, tb) in b.items():
         ca, ta = a.get(k, (0, 0.0))
-        if cb != ca:
+        if cb > ca:       # (fewer calls in the longer run: a set-up kernel whose count depends on the step count)
             rows.append((k, (cb - ca) / d, (tb - ta) / d))
     rows.sort(key=lambda r: -r[2])
     tot = sum(r[2] for r in rows)
