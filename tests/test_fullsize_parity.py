@@ -371,9 +371,13 @@ def _fused_step_body(precision, encoding):
         # side of a keep threshold, so the gradients agree to the fraction of the loss those rays carry
         assert abs(rec["samples"] - rec["samples_oracle"]) <= max(8, rec["samples_oracle"] // 200), rec
         assert abs(rec["loss"] - rec["loss_oracle"]) < 2e-2 * (1 + abs(rec["loss_oracle"]))
+        # every sample the two sides do NOT share moves the gradients by ~1e-3 of their norm (measured: 4 apart -> 5.2e-3 on
+        # the table): the bound grows with the observed difference, so a run of the device-pre-trained model whose up-sampler
+        # flips a few more rays is judged by the same rule
+        apart = abs(rec["samples"] - rec["samples_oracle"])
         for k in got:      # (fp16: the decoder's bias gradient is a cancelling sum, see ``_api_path_body``: loose on its own)
-            lim = 1.0 if (k == "sdf_b" and precision == "fp16") else PERMUTO_FUSED_GRAD[precision]
-            assert rec["grad_" + k] < lim, (k, rec["grad_" + k])
+            lim = 1.0 if (k == "sdf_b" and precision == "fp16") else PERMUTO_FUSED_GRAD[precision] + 3e-3 * apart
+            assert rec["grad_" + k] < lim, (k, rec["grad_" + k], apart)
         return
     if precision == "f32":
         assert abs(rec["samples"] - rec["samples_oracle"]) <= 2 * tol["flips"]
