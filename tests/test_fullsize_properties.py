@@ -194,3 +194,29 @@ def test_indoor_shaped_config_full_size():
     loss.backward()
     for p in (m.encoding.flattened_params, m.sdf_w, m.rad_w):
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
+
+
+def test_bench_line_carries_the_contract_on_the_device():
+    """``bench.timed_run`` on the device: the one JSON line's contract keys plus the objects the measurement section asks for
+    -- ``roofline`` of the dominant kernel from live HIP events (bound / achieved / peak / unit / frac / traffic), the
+    per-kernel table, the launch count and the host-wait figure; the value is the rays the steps processed over the time."""
+    import json
+    import bench
+    dev = torch.device("cuda", 0)
+    tr = bench.build_trainer(dev, 0, 1)
+    out, it = bench.timed_run(tr, steps=6, warmup=3, rank=0, world=1, dev=dev, rays_per_gpu=tr.num_rays)
+    json.dumps(out)                                            # serialisable as it stands
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "abi_calls_per_step", "host_wait_ms_per_step"):
+        assert k in out, k
+    assert out["steps"] == 6 and out["warmup"] == 3 and out["n_gpus"] == 1 and out["dtype"] == "fp16"
+    assert abs(out["value"] - tr.num_rays / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
+    rf = out["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["kernel"] in out["kernels"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.0 < rf["frac"] < 1.0
+    assert 20 <= out["abi_calls_per_step"] <= 60 and 0.0 <= out["host_wait_ms_per_step"] < out["ms_per_step"]
+    cc = rf.get("cache_ceilings")
+    if cc is not None:                                         # recorded counters (profiles/round4_l2_requests.json)
+        assert 0.0 < cc["gather"]["frac"] < 1.0 and 0.0 < cc["scatter"]["frac"] < 1.0
