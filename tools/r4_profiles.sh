@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-for i in 1 2 3 4 5 6; do
+for i in $(seq 1 ${PERMUTO_REPS:-6}); do
   timeout 200 python -m pytest tests/test_fullsize_parity.py -m gpu -q -k "permuto_model and fp16" > $O/permuto_fp16_rep$i.log 2>&1
   cp $O/parity_fullsize_permuto_api_fp16_compressed.json $O/permuto_fp16_rep$i.json 2>/dev/null
   tail -1 $O/permuto_fp16_rep$i.log
