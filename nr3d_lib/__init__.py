@@ -15,3 +15,5 @@ INTEGRATION.md).  Two kinds of modules live here:
 Names the reference imports for paths outside SURVEY sec. 8 (dynamic / time-conditioned fields, forest blocks, GUI) import
 as placeholders that raise on construction.
 """
+
+import neuralsim_amd  # noqa: F401,E402  (process-wide settings of the product package: see neuralsim_amd/__init__.py)
