@@ -170,6 +170,18 @@ int nsim_raygen_opencv(const float* xy, const int64_t* fidx, const float* intr, 
 int nsim_raygen_opencv_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
                            const float* c2w, const int64_t* WH, int64_t N, int snap, const float* d_rays_o,
                            const float* d_rays_d, float* d_c2w, void* stream);
+/* ... and with the fisheye camera model (``camera_model: fisheye`` -> ``FisheyeCameraMatHW.lift``,
+ * app/resources/observers/cameras.py:88-92; dataio/autonomous_driving/custom/custom_autodrive_dataset.py:512,581): the
+ * OpenCV fisheye (Kannala-Brandt equidistant) model theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8)
+ * the reference applies in app/resources/observers/fisheye.py:36-42; distortion [V,4]; theta from n_iters Newton rounds
+ * (cv::fisheye::undistortPoints runs 10), direction (sin theta x_d / theta_d, sin theta y_d / theta_d, cos theta).
+ * Implementation in the absent nr3d_lib: semantics fixed here. */
+int nsim_raygen_fisheye(const float* xy, const int64_t* fidx, const float* intr, const float* distortion /*[V,4]*/,
+                        int n_iters, const float* c2w, const int64_t* WH, int64_t N, int snap, float* rays_o,
+                        float* rays_d, void* stream);
+int nsim_raygen_fisheye_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                            const float* c2w, const int64_t* WH, int64_t N, int snap, const float* d_rays_o,
+                            const float* d_rays_d, float* d_c2w, void* stream);
 /* AABBSpace.ray_test (call site single_volume_renderer.py:235-238): far < 0 means "no far". */
 int nsim_aabb_ray_test(const float* rays_o, const float* rays_d, int64_t N, const NsimOccMeta* meta,
                        float near, float far, float* near_out, float* far_out, uint8_t* hit, void* stream);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "nsim_raygen_pinhole_bwd": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_raygen_opencv": [_P, _P, _P, _P, _I, _P, _P, _I64, _I, _P, _P],
     "nsim_raygen_opencv_bwd": [_P, _P, _P, _P, _I, _P, _P, _I64, _I, _P, _P, _P],
+    "nsim_raygen_fisheye": [_P, _P, _P, _P, _I, _P, _P, _I64, _I, _P, _P],
+    "nsim_raygen_fisheye_bwd": [_P, _P, _P, _P, _I, _P, _P, _I64, _I, _P, _P, _P],
     "nsim_aabb_ray_test": [_P, _P, _I64, C.POINTER(OccMeta), _F, _F, _P, _P, _P],
     "nsim_occ_decay": [_P, _I64, _F],
     "nsim_occ_update": [_P, _P, _P, _I64, C.POINTER(OccMeta), _F],

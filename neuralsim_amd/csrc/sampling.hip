@@ -29,7 +29,33 @@ static inline dim3 smp_grid(int64_t R) { return dim3(nsim_blocks(R, SMP_WAVES_PE
 // 2 p1 x y + p2 (r2 + 2 x2) (y alike), dist = (k1, k2, p1, p2, k3); the undistorted (x, y) come from the fixed-point
 // iteration of cv::undistortPoints, n_iters rounds (OpenCV runs 5).  nr3d_lib's OpenCVCameraMatHW is absent: the
 // iteration and its count are fixed here.  Written mul-then-add (no contraction) so that the oracle reproduces it.
+// Fisheye model (camera_model 'fisheye', cameras.py:88-92; the OpenCV fisheye / Kannala-Brandt equidistant model the
+// reference's app/resources/observers/fisheye.py:36-42 applies: theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 +
+// k4 theta^8), pixel = f (x_d, y_d) + c with (x_d, y_d) = theta_d (a, b) / r): n_iters < 0 selects it, dist = (k1..k4) with
+// stride 4, -n_iters Newton rounds on theta (cv::fisheye::undistortPoints runs 10) from theta = theta_d.  The lifted
+// direction is (sin theta x_d / theta_d, sin theta y_d / theta_d, cos theta) -- (a, b, 1) cos theta, valid past 90 degrees.
+__device__ __forceinline__ void raygen_lift_fisheye(const float* K, const float* dist, int n_iters, float w, float h, float l[3]) {
+  const float xd = (w - K[2]) / K[0], yd = (h - K[5]) / K[4];
+  const float td = sqrtf(xd * xd + yd * yd);
+  const float k1 = dist[0], k2 = dist[1], k3 = dist[2], k4 = dist[3];
+  float th = td;
+  for (int it = 0; it < n_iters; ++it) {
+    const float t2 = th * th;
+    const float f = th * (1.0f + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2) - td;
+    const float fp = 1.0f + (((9.0f * k4 * t2 + 7.0f * k3) * t2 + 5.0f * k2) * t2 + 3.0f * k1) * t2;
+    th = th - f / fp;
+  }
+  const float sc = td > 1e-8f ? sinf(th) / td : 1.0f;
+  l[0] = xd * sc;
+  l[1] = yd * sc;
+  l[2] = cosf(th);
+}
+
 __device__ __forceinline__ void raygen_lift(const float* K, const float* dist, int n_iters, float w, float h, float l[3]) {
+  if (n_iters < 0) {
+    raygen_lift_fisheye(K, dist, -n_iters, w, h, l);
+    return;
+  }
   const float x0 = (w - K[2]) / K[0], y0 = (h - K[5]) / K[4];
   float x = x0, y = y0;
   if (dist) {
@@ -68,13 +94,13 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole(const float* __restrict_
     h = hi + 0.5f;
   }
   float l[3];
-  raygen_lift(intr + f * 9, dist ? dist + f * 5 : nullptr, n_iters, w, h, l);
-  const float dx = l[0], dy = l[1];
+  raygen_lift(intr + f * 9, dist ? dist + f * (n_iters < 0 ? 4 : 5) : nullptr, n_iters, w, h, l);
+  const float dx = l[0], dy = l[1], dz = l[2];      // (dz == 1.0f for the pinhole / OpenCV models)
   const float* M = c2w + f * 16;
   // broadcast-multiply-sum, never a reduced-precision matmul (cameras.py:355-359)
-  float d0 = M[0] * dx + M[1] * dy + M[2] * 1.0f;
-  float d1 = M[4] * dx + M[5] * dy + M[6] * 1.0f;
-  float d2 = M[8] * dx + M[9] * dy + M[10] * 1.0f;
+  float d0 = M[0] * dx + M[1] * dy + M[2] * dz;
+  float d1 = M[4] * dx + M[5] * dy + M[6] * dz;
+  float d2 = M[8] * dx + M[9] * dy + M[10] * dz;
   const float nrm = fmaxf(sqrtf(d0 * d0 + d1 * d1 + d2 * d2), 1e-12f);
   rays_d[3 * i + 0] = d0 / nrm;
   rays_d[3 * i + 1] = d1 / nrm;
@@ -110,7 +136,7 @@ __global__ void __launch_bounds__(256) k_raygen_pinhole_bwd(const float* __restr
     h = hi + 0.5f;
   }
   float l[3];
-  raygen_lift(intr + f * 9, dist ? dist + f * 5 : nullptr, n_iters, w, h, l);
+  raygen_lift(intr + f * 9, dist ? dist + f * (n_iters < 0 ? 4 : 5) : nullptr, n_iters, w, h, l);
   const float* M = c2w + f * 16;
   float dw[3];
 #pragma unroll
@@ -595,6 +621,28 @@ int nsim_raygen_opencv(const float* xy, const int64_t* fidx, const float* intr, 
   if (!distortion || n_iters < 0 || n_iters > 64) return 4;
   hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
                      WH, N, snap, rays_o, rays_d, distortion, n_iters);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_raygen_fisheye(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                        const float* c2w, const int64_t* WH, int64_t N, int snap, float* rays_o, float* rays_d,
+                        void* stream) {
+  if (N <= 0) return 0;
+  if (!distortion || n_iters < 1 || n_iters > 64) return 4;
+  hipLaunchKernelGGL(k_raygen_pinhole, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr, c2w,
+                     WH, N, snap, rays_o, rays_d, distortion, -n_iters);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_raygen_fisheye_bwd(const float* xy, const int64_t* fidx, const float* intr, const float* distortion, int n_iters,
+                            const float* c2w, const int64_t* WH, int64_t N, int snap, const float* d_rays_o,
+                            const float* d_rays_d, float* d_c2w, void* stream) {
+  if (N <= 0) return 0;
+  if (!d_c2w || !distortion || n_iters < 1 || n_iters > 64) return 4;
+  hipLaunchKernelGGL(k_raygen_pinhole_bwd, dim3(nsim_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, xy, fidx, intr,
+                     c2w, WH, N, snap, d_rays_o, d_rays_d, d_c2w, distortion, -n_iters);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -1,6 +1,7 @@
 """Ray generation -- mirrors ``Camera.get_selected_rays`` / ``_get_selected_rays_from_ixy``
 (app/resources/observers/cameras.py:281-330) on top of csrc/sampling.hip::k_raygen_pinhole, for the pinhole and the
-OpenCV (radial-tangential distortion) camera models (``camera_model: pinhole | opencv``, cameras.py:80-87)."""
+OpenCV (radial-tangential distortion) and the fisheye camera models (``camera_model: pinhole | opencv | fisheye``,
+cameras.py:80-92)."""
 import torch
 
 from .. import _lib
@@ -11,7 +12,7 @@ class _RaygenFn(torch.autograd.Function):
     refined c2w matrices to ``Camera.get_selected_rays``; pixels and intrinsics are constants)."""
 
     @staticmethod
-    def forward(ctx, c2w, xy, fidx, intr, WH, snap, dist=None, n_iters=0):
+    def forward(ctx, c2w, xy, fidx, intr, WH, snap, dist=None, n_iters=0, model="opencv"):
         N = xy.shape[0]
         o = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
         d = torch.empty([N, 3], dtype=torch.float32, device=xy.device)
@@ -20,10 +21,10 @@ class _RaygenFn(torch.autograd.Function):
             _lib.call("nsim_raygen_pinhole", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH), N,
                       snap, _lib.ptr(o), _lib.ptr(d))
         else:
-            _lib.call("nsim_raygen_opencv", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist), int(n_iters),
+            _lib.call("nsim_raygen_" + model, _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist), int(n_iters),
                       _lib.ptr(c2w), _lib.ptr(WH), N, snap, _lib.ptr(o), _lib.ptr(d))
         ctx.save_for_backward(c2w, xy, fidx, intr, WH, dist)
-        ctx.snap, ctx.n_iters = snap, int(n_iters)
+        ctx.snap, ctx.n_iters, ctx.cam_model = snap, int(n_iters), model
         return o, d
 
     @staticmethod
@@ -36,9 +37,10 @@ class _RaygenFn(torch.autograd.Function):
             _lib.call("nsim_raygen_pinhole_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(c2w), _lib.ptr(WH),
                       xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
         else:
-            _lib.call("nsim_raygen_opencv_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist), ctx.n_iters,
-                      _lib.ptr(c2w), _lib.ptr(WH), xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(d_c2w))
-        return d_c2w, None, None, None, None, None, None, None
+            _lib.call("nsim_raygen_" + ctx.cam_model + "_bwd", _lib.ptr(xy), _lib.ptr(fidx), _lib.ptr(intr), _lib.ptr(dist),
+                      ctx.n_iters, _lib.ptr(c2w), _lib.ptr(WH), xy.shape[0], ctx.snap, _lib.ptr(g_o), _lib.ptr(g_d),
+                      _lib.ptr(d_c2w))
+        return d_c2w, None, None, None, None, None, None, None, None
 
 
 def pinhole_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
@@ -63,10 +65,26 @@ def opencv_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tenso
                            1 if snap_to_pixel_centers else 0, dist, int(n_iters))
 
 
-def selected_rays(xy, fidx, intr, c2w, WH, distortion=None, **kw):
-    """``pinhole_selected_rays`` or, with ``distortion`` [V,5], ``opencv_selected_rays`` (``camera_model``, cameras.py:80-87)."""
+def fisheye_selected_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, distortion: torch.Tensor,
+                          c2w: torch.Tensor, WH: torch.Tensor, snap_to_pixel_centers: bool = True, n_iters: int = 10):
+    """``pinhole_selected_rays`` for ``camera_model: fisheye`` (cameras.py:88-92): distortion [V,4] = (k1, k2, k3, k4) of the
+    OpenCV fisheye model (app/resources/observers/fisheye.py:36-42); the lift solves theta_d = theta (1 + k1 theta^2 + ...)
+    with ``n_iters`` Newton rounds (10 = cv::fisheye::undistortPoints).  Differentiable w.r.t. ``c2w``."""
+    dist = distortion.detach().float().contiguous()
+    if dist.dim() != 2 or dist.shape[1] != 4 or dist.shape[0] != intr.shape[0]:
+        raise ValueError(f"fisheye distortion must be [V,4] = (k1, k2, k3, k4) per frame, got {tuple(dist.shape)}")
+    return _RaygenFn.apply(c2w, xy.detach().float().contiguous(), fidx.long().contiguous(),
+                           intr.detach().float().contiguous(), WH.long().contiguous(),
+                           1 if snap_to_pixel_centers else 0, dist, int(n_iters), "fisheye")
+
+
+def selected_rays(xy, fidx, intr, c2w, WH, distortion=None, camera_model: str = None, **kw):
+    """``pinhole_selected_rays``; with ``distortion`` [V,5] ``opencv_selected_rays``; with ``distortion`` [V,4] (or
+    ``camera_model='fisheye'``) ``fisheye_selected_rays`` (``camera_model``, cameras.py:80-92)."""
     if distortion is None:
         return pinhole_selected_rays(xy, fidx, intr, c2w, WH, **kw)
+    if camera_model == "fisheye" or (camera_model is None and distortion.shape[-1] == 4):
+        return fisheye_selected_rays(xy, fidx, intr, distortion, c2w, WH, **kw)
     return opencv_selected_rays(xy, fidx, intr, distortion, c2w, WH, **kw)
 
 

@@ -580,7 +580,56 @@ class OpenCVCameraMatHW(CameraBase):
 
 
 class FisheyeCameraMatHW(OpenCVCameraMatHW):
+    """``camera_model: fisheye`` (cameras.py:88-92): the OpenCV fisheye (Kannala-Brandt equidistant) model the reference
+    applies in app/resources/observers/fisheye.py:31-42, theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4
+    theta^8) with distortion = (k1, k2, k3, k4).  (The class lives in the absent nr3d_lib: semantics fixed here, the
+    arithmetic of the HIP ray generator -- csrc/sampling.hip raygen_lift_fisheye.)"""
     model = "fisheye"
+
+    N_ITERS = 10         # cv::fisheye::undistortPoints' count, and the HIP ray generator's default
+
+    def _dist(self, like: torch.Tensor) -> torch.Tensor:
+        dd = self.subattr["distortion"].tensor
+        if dd.shape[-1] < 4:
+            dd = torch.cat([dd, dd.new_zeros(*dd.shape[:-1], 4 - dd.shape[-1])], dim=-1)
+        if dd.dim() > 1:
+            dd = dd.reshape(*dd.shape[:-1], *([1] * (like.dim() - (dd.dim() - 1))), dd.shape[-1])
+        return dd
+
+    def lift(self, u, v, d):
+        """pixel (u, v) -> d x the UNIT direction of its ray in the camera frame, (sin theta x_d / theta_d, sin theta y_d /
+        theta_d, cos theta) (a lens beyond 90 degrees has no point at z = d; the reference normalises the lifted directions,
+        cameras.py:355-359)."""
+        m = self.mat_3x3()
+        if m.dim() > 2:
+            m = m.reshape(*m.shape[:-2], *([1] * (u.dim() - (m.dim() - 2))), 3, 3)
+        xd, yd = (u - m[..., 0, 2]) / m[..., 0, 0], (v - m[..., 1, 2]) / m[..., 1, 1]
+        dd = self._dist(u)
+        k1, k2, k3, k4 = dd[..., 0], dd[..., 1], dd[..., 2], dd[..., 3]
+        td = torch.sqrt(xd * xd + yd * yd)
+        th = td
+        for _ in range(self.N_ITERS):
+            t2 = th * th
+            f = th * (1.0 + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2) - td
+            fp = 1.0 + (((9.0 * k4 * t2 + 7.0 * k3) * t2 + 5.0 * k2) * t2 + 3.0 * k1) * t2
+            th = th - f / fp
+        sc = torch.where(td > 1e-8, torch.sin(th) / td.clamp_min(1e-12), torch.ones_like(td))
+        return torch.stack([xd * sc * d, yd * sc * d, torch.cos(th) * d], dim=-1)
+
+    def proj(self, xyz: torch.Tensor):
+        """camera-frame points -> (u, v, depth): theta = atan2(|xy|, z) through the forward polynomial."""
+        m = self.mat_3x3()
+        if m.dim() > 2:
+            m = m.reshape(*m.shape[:-2], *([1] * (xyz.dim() - 1 - (m.dim() - 2))), 3, 3)
+        x, y, z = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+        r = torch.sqrt(x * x + y * y)
+        th = torch.atan2(r, z)
+        dd = self._dist(x)
+        k1, k2, k3, k4 = dd[..., 0], dd[..., 1], dd[..., 2], dd[..., 3]
+        t2 = th * th
+        thd = th * (1.0 + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2)
+        sc = torch.where(r > 1e-12, thd / r.clamp_min(1e-12), torch.ones_like(r))
+        return m[..., 0, 0] * (x * sc) + m[..., 0, 2], m[..., 1, 1] * (y * sc) + m[..., 1, 2], z
 
 
 class OrthoCameraIntrinsics(CameraBase):

@@ -56,10 +56,43 @@ def opencv_undistort(x0, y0, dist, n_iters: int = 5):
     return x, y
 
 
+def fisheye_distort(a, b, dist):
+    """The OpenCV fisheye (Kannala-Brandt equidistant) model on normalised camera coordinates (a, b) = (x / z, y / z):
+    theta = atan(r), theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8), (x_d, y_d) = theta_d / r (a, b)
+    -- the reference's own formulas, app/resources/observers/fisheye.py:31-42."""
+    k1, k2, k3, k4 = dist.unbind(-1)
+    r = torch.sqrt(a * a + b * b)
+    th = torch.atan(r)
+    t2 = th * th
+    thd = th * (1.0 + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2)
+    sc = torch.where(r > 1e-8, thd / r.clamp_min(1e-12), torch.ones_like(r))
+    return a * sc, b * sc
+
+
+def fisheye_lift(xd, yd, dist, n_iters: int = 10):
+    """distorted normalised coordinates -> direction in the camera frame (``lift`` of ``camera_model: fisheye``,
+    cameras.py:88-92): theta from ``n_iters`` Newton rounds on theta_d = theta (1 + k1 theta^2 + ...) starting at theta_d
+    (cv::fisheye::undistortPoints runs 10), direction (sin theta x_d / theta_d, sin theta y_d / theta_d, cos theta).
+    nr3d_lib's FisheyeCameraMatHW is absent: parity unpinned, semantics fixed here; the kernel's operation order
+    (csrc/sampling.hip raygen_lift_fisheye)."""
+    k1, k2, k3, k4 = dist.unbind(-1)
+    td = torch.sqrt(xd * xd + yd * yd)
+    th = td
+    for _ in range(n_iters):
+        t2 = th * th
+        f = th * (1.0 + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2) - td
+        fp = 1.0 + (((9.0 * k4 * t2 + 7.0 * k3) * t2 + 5.0 * k2) * t2 + 3.0 * k1) * t2
+        th = th - f / fp
+    sc = torch.where(td > 1e-8, torch.sin(th) / td.clamp_min(1e-12), torch.ones_like(td))
+    return xd * sc, yd * sc, torch.cos(th)
+
+
 def pinhole_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: torch.Tensor,
-                 WH: torch.Tensor, snap_to_pixel_centers: bool = True, distortion: torch.Tensor = None, n_iters: int = 5):
+                 WH: torch.Tensor, snap_to_pixel_centers: bool = True, distortion: torch.Tensor = None, n_iters: int = 5,
+                 camera_model: str = "opencv"):
     """xy [N,2] in [0,1], fidx [N] frame index, intr [V,3,3], c2w [V,4,4] (OpenCV), WH [V,2] (W,H)
-    -> rays_o, rays_d [N,3].  cameras.py:281-310.  distortion [V,5]: the OpenCV camera model (``opencv_undistort``)."""
+    -> rays_o, rays_d [N,3].  cameras.py:281-310.  distortion [V,5]: the OpenCV camera model (``opencv_undistort``);
+    [V,4] with ``camera_model='fisheye'``: ``fisheye_lift``."""
     wh_i = WH[fidx]
     if snap_to_pixel_centers:
         wh = (xy * wh_i).long().clamp(torch.zeros_like(wh_i), wh_i - 1).to(xy.dtype) + 0.5
@@ -69,9 +102,12 @@ def pinhole_rays(xy: torch.Tensor, fidx: torch.Tensor, intr: torch.Tensor, c2w: 
     fx, fy, cx, cy = K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]
     dx = (wh[:, 0] - cx) / fx
     dy = (wh[:, 1] - cy) / fy
-    if distortion is not None:
+    dz = torch.ones_like(dx)
+    if distortion is not None and camera_model == "fisheye":
+        dx, dy, dz = fisheye_lift(dx, dy, distortion[fidx], n_iters)
+    elif distortion is not None:
         dx, dy = opencv_undistort(dx, dy, distortion[fidx], n_iters)
-    dirs = torch.stack([dx, dy, torch.ones_like(dx)], dim=-1)
+    dirs = torch.stack([dx, dy, dz], dim=-1)
     R = c2w[fidx, :3, :3]
     rays_d = (R * dirs.unsqueeze(-2)).sum(-1)
     rays_d = rays_d / rays_d.norm(dim=-1, keepdim=True).clamp_min(1e-12)

@@ -106,6 +106,73 @@ def test_raygen_opencv_distortion(backend):
     assert torch.allclose(c_d.grad.cpu(), c_r.grad, rtol=2e-4, atol=2e-5)
 
 
+def test_raygen_fisheye(backend):
+    """``camera_model: fisheye`` (cameras.py:88-92): the lift inverts the OpenCV fisheye polynomial the reference applies in
+    app/resources/observers/fisheye.py:36-42 (its calibration constants are the test lens).  (1) kernel == oracle
+    restatement; (2) the lifted direction goes back onto the pixel through the reference's FORWARD formulas (10 Newton
+    rounds: < 1e-3 px over a 150-degree lens); (3) the shim's ``FisheyeCameraMatHW.lift`` / ``proj`` are the same
+    arithmetic (what the reference's ``Camera`` calls); (4) zero coefficients = the equidistant lens; (5) pose gradient."""
+    from neuralsim_amd.graphics.cameras import fisheye_selected_rays, selected_rays
+    g = torch.Generator().manual_seed(8)
+    V, N = 4, 500
+    W_, H_ = 1280, 960
+    K = torch.tensor([[318.44998905930794, 0.0, 636.2089399611955], [0.0, 317.8314899911656, 481.71423781914115],
+                      [0.0, 0.0, 1.0]])                                            # fisheye.py:14-17
+    D = torch.tensor([0.18198802503702904, -0.04198598106075817, 0.010013633995507613, -0.0025294664427881705])   # :21
+    _, c2w, _ = look_at_cameras(V=V, seed=3)
+    intr = K.repeat(V, 1, 1)
+    WH = torch.tensor([[W_, H_]], dtype=torch.long).repeat(V, 1)
+    dist = D.repeat(V, 1) * (1.0 + 0.05 * torch.randn(V, 4, generator=g))
+    # pixels inside the lens's image circle: theta_d <= 1.8 (~83 degrees off axis; the polynomial of this lens peaks at 2.19,
+    # the corners of the 1280 x 960 frame lie beyond it -- black in a real fisheye image, no theta solves them)
+    cand = torch.rand(6 * N, 2, generator=g)
+    td_c = torch.sqrt(((cand[:, 0] * W_ - K[0, 2]) / K[0, 0]) ** 2 + ((cand[:, 1] * H_ - K[1, 2]) / K[1, 1]) ** 2)
+    xy = cand[td_c <= 1.8][:N].contiguous()
+    assert xy.shape[0] == N
+    fidx = torch.randint(0, V, (N,), generator=g)
+    dv = lambda t: t.to(backend)
+    o_ref, d_ref = orr.pinhole_rays(xy, fidx, intr, c2w, WH, distortion=dist, n_iters=10, camera_model="fisheye")
+    o, d = fisheye_selected_rays(dv(xy), dv(fidx), dv(intr), dv(dist), dv(c2w), dv(WH))
+    assert torch.equal(o.cpu(), o_ref) and torch.allclose(d.cpu(), d_ref, atol=5e-7)
+    o2, d2 = selected_rays(dv(xy), dv(fidx), dv(intr), dv(c2w), dv(WH), distortion=dv(dist))      # [V,4] selects the model
+    assert torch.equal(d2, d)
+    # back through the reference's forward formulas: direction in the camera frame -> distorted pixel
+    Rm = c2w[fidx, :3, :3]
+    l = (Rm.transpose(1, 2) * d.cpu().unsqueeze(-2)).sum(-1)
+    assert float(l[:, 2].min()) > 0.0                                   # this lens stays inside 90 degrees off axis
+    xd, yd = orr.fisheye_distort(l[:, 0] / l[:, 2], l[:, 1] / l[:, 2], dist[fidx])
+    u, v = xd * K[0, 0] + K[0, 2], yd * K[1, 1] + K[1, 2]
+    wh = (xy * WH[fidx]).long().clamp(torch.zeros_like(WH[fidx]), WH[fidx] - 1).float() + 0.5
+    err = torch.maximum((u - wh[:, 0]).abs(), (v - wh[:, 1]).abs())
+    assert float(err.max()) < 1e-3 * 5, float(err.max())
+    off_axis = torch.acos(l[:, 2].clamp(-1, 1))
+    assert float(off_axis.max()) > 1.2                                  # the corners of the image: ~75 degrees off axis
+    # the shim class the reference's Camera code calls
+    from nr3d_lib.models.attributes import CameraMatrix3x3, FisheyeCameraMatHW, make_vector
+    cam = FisheyeCameraMatHW(mat=CameraMatrix3x3(intr[fidx]), H=WH[fidx][:, 1].float(), W=WH[fidx][:, 0].float(),
+                             distortion=make_vector(4)(dist[fidx]))
+    lifted = cam.lift(wh[:, 0], wh[:, 1], torch.ones(N))
+    assert torch.allclose(lifted / lifted.norm(dim=-1, keepdim=True), l / l.norm(dim=-1, keepdim=True), atol=2e-6)
+    uu, vv, _ = cam.proj(lifted * 3.0)
+    assert float(torch.maximum((uu - wh[:, 0]).abs(), (vv - wh[:, 1]).abs()).max()) < 5e-3
+    # zero coefficients: the equidistant lens, pixel radius = f * theta
+    z4 = torch.zeros(V, 4)
+    _, d_e = fisheye_selected_rays(dv(xy), dv(fidx), dv(intr), dv(z4), dv(c2w), dv(WH))
+    l_e = (Rm.transpose(1, 2) * d_e.cpu().unsqueeze(-2)).sum(-1)
+    th = torch.acos(l_e[:, 2].clamp(-1, 1))
+    rpx = torch.sqrt(((wh[:, 0] - K[0, 2]) / K[0, 0]) ** 2 + ((wh[:, 1] - K[1, 2]) / K[1, 1]) ** 2)
+    assert torch.allclose(th, rpx, atol=2e-6)
+    # pose gradient
+    wo, wd = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+    c_r = leaf(c2w)
+    o_r, d_r = orr.pinhole_rays(xy, fidx, intr, c_r, WH, distortion=dist, n_iters=10, camera_model="fisheye")
+    ((o_r * wo).sum() + (d_r * wd).sum()).backward()
+    c_d = leaf(c2w, backend)
+    o, d = fisheye_selected_rays(dv(xy), dv(fidx), dv(intr), dv(dist), c_d, dv(WH))
+    ((o * dv(wo)).sum() + (d * dv(wd)).sum()).backward()
+    assert torch.allclose(c_d.grad.cpu(), c_r.grad, rtol=2e-4, atol=2e-5)
+
+
 def _sphere_occ(res=(64, 64, 64), shell=0.03):
     ax = [(torch.arange(r) + 0.5) / r * 2 - 1 for r in res]
     zz, yy, xx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
