@@ -43,6 +43,29 @@ def test_fuzz_sort_linstep_sum(backend, n, seed):
     assert torch.allclose(po.packed_sum(v.to(backend), pi.to(backend)).cpu(), opo.packed_sum(v, pi), atol=1e-4)
 
 
+run_lens = st.lists(st.sampled_from([0, 1, 2, 5, 31, 64, 100, 300, 600]), min_size=1, max_size=20)
+
+
+@settings(**SET)
+@given(packs=st.lists(run_lens, min_size=1, max_size=6), seed=st.integers(0, 10 ** 6))
+def test_fuzz_sort_of_run_structured_packs(backend, packs, seed):
+    """Packs that are concatenations of sorted runs (what the compose renderer collects): 1 run (identity path), 2..16 runs
+    (merge path), > 16 runs (rank sort), packs beyond the LDS staging capacity (direct path) -- values drawn from a small
+    set so that ties occur inside and across runs.  The oracle's stable order, bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    xs, n = [], []
+    for runs in packs:
+        parts = [torch.sort(torch.randint(0, 40, (k,), generator=g).float() * 0.125).values for k in runs]
+        x = torch.cat(parts) if parts else torch.empty(0)
+        xs.append(x)
+        n.append(x.shape[0])
+    x, n = torch.cat(xs), torch.tensor(n)
+    pi = opo.get_pack_infos_from_n(n)
+    srt, idx = po.packed_sort(x.to(backend), pi.to(backend))
+    srt_o, idx_o = opo.packed_sort(x, pi)
+    assert torch.equal(srt.cpu(), srt_o) and torch.equal(idx.cpu(), idx_o)
+
+
 @settings(**SET)
 @given(na=counts, nb=counts, seed=st.integers(0, 10 ** 6))
 def test_fuzz_merge_two_packs(backend, na, nb, seed):
