@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel register / scratch / occupancy numbers of a .hip source as the gfx950 backend reports them
 (-Rpass-analysis=kernel-resource-usage, device-only compile; no GPU needed).  Usage: tools/resource_usage.py field.hip [filter]"""
+import os
 import re
 import subprocess
 import sys
@@ -13,7 +14,6 @@ CS = ROOT / "neuralsim_amd" / "csrc"
 def main():
     src = CS / sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    import os
     cmd = ["/opt/rocm/bin/hipcc", *os.environ.get("RU_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{CS}",
            "-munsafe-fp-atomics", "--cuda-device-only", "-c", str(src), "-o", "/tmp/_ru.o",
            "-Rpass-analysis=kernel-resource-usage"]
