@@ -299,9 +299,24 @@ def main():
                     help="N > 1: schedule of the gradient all-reduce -- ring = the backend's (RCCL) all-reduce, direct = all-to-all + "
                          "f32 reduction + all-gather (one rounding per contribution on the 2-byte wire; self-checked against "
                          "the ring on first use and abandoned with a warning if it disagrees).  Default: direct for the bf16 wire.")
+    ap.add_argument("--emulator", action="store_true",
+                    help="TEST HARNESS ONLY (tests/test_distributed.py drives this CLI with it): run a tiny model on the host "
+                         "SIMT emulator of tests/emu over gloo instead of the HIP library over RCCL -- checks how --gpus becomes "
+                         "ranks on a machine without a GPU; the line it prints says so and is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], emulator=args.emulator))      # becomes N ranks; never returns here
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment holds WORLD_SIZE={env_world}: the line would "
+                         f"report a rank count the command did not ask for (run `python bench.py --gpus N`, or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
 
     from neuralsim_amd import _lib, distributed as ndist
+    if args.emulator:
+        return main_emulator(args)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     if args.allreduce is not None:
         os.environ["NSIM_ALLREDUCE_ALGO"] = "ring" if args.allreduce == "ring" else ""      # "" = default rule + self-check
@@ -326,6 +341,7 @@ def main():
     dist_info = distributed_info(world, dev)         # (collective on N > 1: every rank calls it)
     if rank == 0:
         out["distributed"] = dist_info
+        check_rank_count(out, args.gpus)
     if rank == 0 and args.config != "object":
         out["config"]["name"] = args.config
         out["config"]["launch_chain"] = "autograd"
@@ -408,6 +424,81 @@ def main():
             raise SystemExit(f"bench.py: fp16 rendering left the stated tolerance vs the oracle: {out['parity']}")
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(n: int, argv, emulator: bool = False) -> int:
+    """``python bench.py --gpus N`` outside a launcher: become N ranks.  Re-executes this file under
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`` (the
+    command shape the driver itself uses for N > 1; one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    launcher) with the same arguments, and returns the launcher's exit code -- rank 0 of the child prints the JSON line.
+    Refuses (non-zero) when the node has fewer than N devices: N ranks on fewer GPUs would not be an N-GPU number."""
+    import socket
+    import subprocess
+    if not emulator:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} asked for, {have} HIP device(s) visible on this node", file=sys.stderr)
+            return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def check_rank_count(out: dict, gpus: int):
+    """The line must describe the run that was asked for: ``n_gpus`` == ``--gpus`` == the ranks the process group reported.
+    (Round 4's ``--gpus 8`` without a launcher ran ONE rank and printed n_gpus 1.)"""
+    seen = out["distributed"]["ranks_seen"]
+    if not (out["n_gpus"] == gpus == seen):
+        raise SystemExit(f"bench.py: rank count mismatch: --gpus {gpus}, n_gpus {out['n_gpus']}, process group reports {seen}")
+
+
+def main_emulator(args):
+    """``--emulator``: the N-rank control flow of this file on a machine without a GPU (test harness; the product has no CPU
+    path -- the emulator library lives under tests/emu and is injected here exactly as tests/conftest.py injects it)."""
+    import ctypes
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    import build_emu
+    from neuralsim_amd import _lib, distributed as ndist
+    lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
+    _lib.get_lib = lambda: lib
+    _lib.stream_handle = lambda: 0
+    _lib.require_device = lambda t, name="tensor": None
+    torch.set_num_threads(2)
+    torch.manual_seed(0)
+    rank, local_rank, world = ndist.init_env(backend="gloo", device_type="cpu")
+    dev = torch.device("cpu")
+    from test_trainer import _tiny
+    from neuralsim_amd.graphics.cameras import look_at_cameras
+    from neuralsim_amd.trainer import RenderTrainer
+    m = _tiny(dev, seed=42 + rank)                       # replicas differ until the broadcast
+    ndist.broadcast_module(m)
+    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=dev)
+    rays = int(args.rays_per_gpu or 16)
+    tr = RenderTrainer(m, intr, c2w, WH, num_rays=rays, lr=1e-3, num_uniform=16, rank=rank, world_size=world)
+    out, it = timed_run(tr, args.steps, args.warmup, rank, world, dev, rays_per_gpu=rays)
+    import torch.distributed as dist
+    if world > 1:          # replicas agree after the all-reduced updates (asserted on every rank) ...
+        w = m.sdf_w.detach().clone()
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        assert all(torch.equal(ws[0], x) for x in ws[1:]), "replicas diverged"
+        it = measure_exposed_allreduce(tr, out, min(args.steps, 2), it, rank, dev)      # ... and diverge from here on
+    dist_info = distributed_info(world, dev)
+    if rank == 0:
+        out["distributed"] = dist_info
+        out["data"] = "synthetic (HOST EMULATOR of the kernels, tiny model: control-flow check, NOT a measurement)"
+        out["emulator"] = True
+        check_rank_count(out, args.gpus)
+        print(json.dumps(out), flush=True)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

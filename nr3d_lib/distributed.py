@@ -22,6 +22,10 @@ def init_env(args=None, seed: int = 42, backend: str = None, device_type: str = 
     ddp = bool(args.get("ddp", False)) if args is not None else int(os.environ.get("WORLD_SIZE", "1")) > 1
     if ddp or args is None:
         rank, local_rank, world = _nd.init_env(backend=backend, device_type=device_type)
+        if args is not None and ddp:
+            # one process per GPU: the trainer builds ``torch.device(f'cuda:{device_ids[0]}')`` (train.py:77) and hands
+            # ``device_ids`` to DistributedDataParallel (:1405) -- both must name THIS rank's device
+            args["device_ids"] = [local_rank]
     else:
         rank, local_rank, world = 0, 0, 1
     s = int(seed) + rank

@@ -334,3 +334,32 @@ def test_street_trainer_replicas_stay_in_sync(tmp_path, world):
     collective sequence whatever its batches hit, and the replicas are bit-identical after the all-reduced updates."""
     mp.spawn(_street_worker, args=(world, _free_port(), str(tmp_path), 2), nprocs=world, join=True)
     assert all((tmp_path / f"street_ok{r}").exists() for r in range(world))
+
+
+def test_bench_cli_gpus_2_becomes_two_ranks():
+    """``python bench.py --gpus 2`` WITHOUT a launcher environment must become two ranks by itself (it
+    re-executes under ``python -m torch.distributed.run --nproc-per-node 2``) and the line must say n_gpus 2 == ranks seen 2.
+    Driven through the command line, not through ``timed_run``; ``--emulator`` swaps RCCL + libnsim_hip.so for gloo + the
+    host emulator of tests/emu (this machine has no GPU) and a tiny model -- every other line of bench.main's N > 1 flow
+    (launcher, rank-count checks, barrier + max-over-ranks timing, exposed all-reduce leg, rank-0 JSON) is the product's."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--emulator"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["ranks_seen"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert len(out["distributed"]["devices"]) == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["emulator"] is True
+    assert "exposed_allreduce_ms" in out and out["scaling"] == "weak" and out["value"] > 0
+    # a launcher environment that disagrees with --gpus is refused instead of printing a line for another rank count
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--emulator"], capture_output=True, text=True,
+                        timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=str(ROOT))
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stdout + r2.stderr)
+    # without the emulator flag (the product) a node with fewer than N devices is refused too: no silent 1-rank run
+    if not torch.cuda.is_available():
+        r3 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                            timeout=300, env=env, cwd=str(ROOT))
+        assert r3.returncode != 0 and "HIP device" in r3.stderr

@@ -79,6 +79,72 @@ def test_reference_trainer_runs_unchanged(tmp_path):
     assert r2.returncode == 0 and "Everything done." in r2.stdout, (r2.stdout + r2.stderr)[-2000:]
 
 
+@needs_reference
+def test_reference_trainer_ddp_two_ranks(tmp_path):
+    """SURVEY row a21 through the reference's OWN multi-GPU entry: ``code_single/tools/train.py --ddp``,
+    source unchanged, launched as ``python -m torch.distributed.run --nproc-per-node 2`` (gloo + the host emulator here; RCCL
+    on a GPU node): ``nr3d_lib.distributed.init_env(args)`` joins the group and names this rank's device in
+    ``args.device_ids``, rank 0 alone runs ``training_initialize`` (train.py:1396-1399), ``DistributedDataParallel(trainer,
+    device_ids, output_device=local_rank, find_unused_parameters=True)`` (:1401-1406) wraps the shim's models -- its
+    constructor broadcasts rank 0's parameters AND buffers (f32 masters, fp16 shadow tables, occupancy grids), its reducer
+    hooks average the gradients the HIP autograd functions produce --, every rank steps ``local_it = it + rank`` and the loop
+    advances ``it += world_size`` (:1446-1447, :1651).
+
+    Checked: the run finishes on both ranks; 8 global iterations = 4 steps per rank (checkpoint ``final_00000008.pt``, four
+    logged steps); every PARAMETER is bit-identical across the two replicas afterwards (f32 masters; the fp16 shadow buffers
+    follow); the buffers -- occupancy values / bits, the trainer's error maps -- are rank-local between steps BY THE
+    REFERENCE'S DESIGN (rank r refreshes at ``local_it``; the importance sampler sees its own pixels) and are equal again after
+    DDP's pre-forward buffer broadcast, i.e. every rank renders with rank 0's grid.  The schedule is held constant
+    (``--warmup_steps=0 --min_factor=1.0``) because the reference hands rank r the learning rate of iteration ``it + r``
+    (``asset_bank.training_update_lr(local_it)``, :1449): under a decaying / warming schedule its replicas drift by the
+    learning-rate difference on ANY backend (measured here: 8e-6 after four steps) -- a property of the trainer, shown by the
+    second, shorter run below."""
+    def run(exp, dump, extra, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(ROOT / "tools" / "run_reference_train.py"), "--emulate", "--dump-replica-state",
+               str(dump), "--ddp", "--config", str(CFG), "--exp_dir", str(exp)] + SMALL + list(extra)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(PYTHONWARNINGS="ignore", OMP_NUM_THREADS="2")
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=str(ROOT))
+
+    import socket
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    exp, dump = tmp_path / "exp", tmp_path / "dump"
+    r = run(exp, dump, ["--num_iters=8", "--training.i_val=-1", "--training.i_log=1", "--warmup_steps=0", "--min_factor=1.0"], port())
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "Everything done." in r.stdout, tail
+    ck = sorted((exp / "ckpts").glob("final_*.pt"))
+    assert len(ck) == 1 and ck[0].name == "final_00000008.pt", ck          # it += world_size: 4 steps per rank = 8 iterations
+    assert torch.load(str(ck[0]), map_location="cpu", weights_only=False)["global_step"] == 8
+    stats = pickle.loads((exp / "stats.p").read_bytes())
+    key = next(k for k in stats if k.endswith("loss_rgb"))
+    its = [i for i, _ in stats[key]]
+    assert len(its) == 4 and all(b - a == 2 for a, b in zip(its, its[1:])), its        # rank 0 logs it = 0, 2, 4, 6
+    a, b = (torch.load(str(dump / f"rank{k}.pt")) for k in (0, 1))
+    assert a["world"] == b["world"] == 2 and a["find_unused_parameters"] and a["broadcast_buffers"]
+    assert a["ddp_params"] == b["ddp_params"] > 50_000                      # NeuS + distant model + image embeddings
+    params = [k for k in a["state"] if k.startswith("param:")]
+    assert any("encoding.flattened_params" in k for k in params) and any("Distant" in k for k in params), params
+    for k in params:
+        assert torch.equal(a["state"][k], b["state"][k]), (k, float((a["state"][k] - b["state"][k]).abs().max()))
+    for k in a["state"]:
+        if k.startswith("synced_buffer:") or (k.startswith("buffer:") and k.endswith("params16")):
+            assert torch.equal(a["state"][k], b["state"][k]), k             # fp16 shadows follow the masters; DDP's broadcast
+    occ = [k for k in a["state"] if k.startswith("synced_buffer:") and k.endswith("accel.occ_val")]
+    assert len(occ) == 1 and float(a["state"][occ[0]].max()) > 0            # the occupancy grid IS one of the broadcast buffers
+    # the reference's own schedule (exponential + warm-up, yaml:381-386): rank r runs the learning rate of iteration it + r
+    r2 = run(tmp_path / "exp2", tmp_path / "dump2", ["--num_iters=4", "--training.i_val=-1", "--training.i_log=1"], port())
+    assert r2.returncode == 0 and "Everything done." in r2.stdout, (r2.stdout + r2.stderr)[-3000:]
+    a2, b2 = (torch.load(str(tmp_path / "dump2" / f"rank{k}.pt")) for k in (0, 1))
+    drift = max(float((a2["state"][k] - b2["state"][k]).abs().max()) for k in params)
+    assert 0 < drift < 1e-3, drift
+
+
 # ================================================================================================ the street config (BASELINE configs[3])
 STREET_CFG = REF / "code_single/configs/waymo/streetsurf/withmask_withlidar_joint.240219.yaml"
 S_, DV = "assetbank_cfg.Street.model_params", "assetbank_cfg.Distant.model_params"

@@ -125,11 +125,39 @@ def _emulate_cuda_on_cpu():
     torch.Tensor.to = to
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
+    # ``--ddp`` (train.py:1401-1406: DDP(trainer, device_ids=..., output_device=local_rank, find_unused_parameters=True)):
+    # the same wrapper over gloo; a CPU module takes no device ids
+    import torch.nn.parallel as tnp
+    ddp_init = tnp.DistributedDataParallel.__init__
+
+    def ddp_init_cpu(self, module, device_ids=None, output_device=None, **k):
+        return ddp_init(self, module, device_ids=None, output_device=None, **k)
+    tnp.DistributedDataParallel.__init__ = ddp_init_cpu
+
+
+def _remember_ddp_modules():
+    """``--dump-replica-state DIR``: after the trainer returns, every rank writes the state dict (parameters AND buffers) of the
+    module the trainer wrapped in DistributedDataParallel to ``DIR/rank<r>.pt`` -- the replica-consistency check of
+    tests/test_reference_train.py::test_reference_trainer_ddp_two_ranks (the trainer itself only checkpoints on rank 0)."""
+    import torch.nn.parallel as tnp
+    seen = []
+    init = tnp.DistributedDataParallel.__init__
+
+    def remembering_init(self, *a, **k):
+        init(self, *a, **k)
+        seen.append(self)
+    tnp.DistributedDataParallel.__init__ = remembering_init
+    return seen
 
 
 def main(argv):
     emulate = "--emulate" in argv
     argv = [a for a in argv if a != "--emulate"]
+    dump_dir = None
+    if "--dump-replica-state" in argv:
+        i = argv.index("--dump-replica-state")
+        dump_dir = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
     sys.path.insert(0, str(ROOT))
     if str(REF) not in sys.path:
         sys.path.append(str(REF))
@@ -144,12 +172,30 @@ def main(argv):
     script = REF / rel
     assert script.exists(), f"{script} not found (NSIM_REFERENCE_ROOT)"
     sys.argv = [str(script)] + argv
+    wrapped = _remember_ddp_modules() if dump_dir else None
     cwd = os.getcwd()
     os.chdir(str(REF))                 # the trainer backs up "./app" etc. relative to the project root
     try:
         runpy.run_path(str(script), run_name="__main__")
     finally:
         os.chdir(cwd)
+    if dump_dir:
+        import torch
+        assert len(wrapped) == 1, f"expected the trainer to build one DistributedDataParallel wrapper, saw {len(wrapped)}"
+        ddp = wrapped[0]
+        # (named_parameters / named_buffers: the AssetBank's own state_dict refuses a prefix, asset_bank.py:246)
+        state = {"param:" + k: v.detach().cpu().clone() for k, v in ddp.module.named_parameters()}
+        state.update({"buffer:" + k: v.detach().cpu().clone() for k, v in ddp.module.named_buffers()})
+        rank = int(os.environ.get("RANK", "0"))
+        os.makedirs(dump_dir, exist_ok=True)
+        # what every rank would render with at its NEXT forward: DistributedDataParallel(broadcast_buffers=True, the default
+        # the trainer leaves in place) re-broadcasts rank 0's buffers before each forward (collective: every rank calls it)
+        if ddp.will_sync_module_buffers():
+            ddp._sync_buffers()
+        state.update({"synced_buffer:" + k: v.detach().cpu().clone() for k, v in ddp.module.named_buffers()})
+        torch.save(dict(state=state, broadcast_buffers=bool(ddp.broadcast_buffers), find_unused_parameters=bool(ddp.find_unused_parameters), world=int(os.environ.get("WORLD_SIZE", "1")),
+                        ddp_params=sum(p.numel() for p in ddp.module.parameters() if p.requires_grad)),
+                   os.path.join(dump_dir, f"rank{rank}.pt"))
 
 
 if __name__ == "__main__":
