@@ -144,6 +144,8 @@ def cpu_baseline(tr, iters=3, iters_small=3):
     intr, c2w, WH = tr.intr.cpu(), tr.c2w.cpu(), tr.WH.cpu()
     mode = m.ray_query_cfg.get("query_mode", "")
     compress = mode.endswith("_compressed")
+    from neuralsim_amd.fields.neus import marched_only
+    mo = marched_only(m.ray_query_cfg.get("query_param", {}))        # the same sampling mode as the GPU step
     opt = torch.optim.Adam(p.tensors(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
     g = torch.Generator().manual_seed(7)
     N_full, M_full = tr.num_rays, tr.num_uniform
@@ -162,7 +164,7 @@ def cpu_baseline(tr, iters=3, iters_small=3):
         gt = _sphere_image_cpu(o, d, SPHERE_RADIUS)
         ha = tr.appear.detach().cpu()[fidx]
         ret = orr.ray_query(p, o, d, ha, occ, aabb[0], aabb[1], res, near=0.01, jitter=jit, jitter_c=jit_c,
-                            compress=compress)
+                            compress=compress, upsample_on_marched_only=mo)
         loss, _ = orr.render_loss(ret, gt, n_rays, w_eikonal=0.1)
         _, nab_u = ofield.forward_sdf_nablas(x_uni, p)
         loss = loss + 0.1 * ((nab_u.norm(dim=-1) - 1.0) ** 2).mean()
@@ -180,7 +182,7 @@ def cpu_baseline(tr, iters=3, iters_small=3):
     out = dict(value=N_full / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                sample=f"median of {len(ts)} timed iterations of the SAME full step ({N_full} rays, {mode}, analytic-image "
                       f"targets, {M_full} uniform eikonal points, backward, Adam over all {sum(t.numel() for t in p.tensors())} "
-                      f"parameters, {n_refresh} occupancy-refresh queries = 1/16 of a refresh); pure-PyTorch oracle, f32, "
+                      f"parameters, {n_refresh} occupancy-refresh queries = 1/16 of a refresh, upsample_on_marched_only {mo}); pure-PyTorch oracle, f32, "
                       f"{med:.2f} s per step (all: {', '.join(f'{t:.2f}' for t in ts)})")
     if iters_small > 0 and N_full != 4096:
         med0, ts0 = median_of(4096, iters_small)
@@ -214,8 +216,10 @@ def parity_check(tr):
         o, d = orr.pinhole_rays(xy, fidx, intr, c2w, WH)
         ha = tr.appear.detach().cpu()[fidx]
         mode = m.ray_query_cfg.get("query_mode", "")
+        from neuralsim_amd.fields.neus import marched_only
         ret = orr.ray_query(p, o, d, ha, occ, aabb[0], aabb[1], m.accel.resolution, near=0.01,
-                            depth_use_normalized_vw=True, compress=mode.endswith("_compressed"))
+                            depth_use_normalized_vw=True, compress=mode.endswith("_compressed"),
+                            upsample_on_marched_only=marched_only(m.ray_query_cfg.get("query_param", {})))
         rgb_o = torch.zeros(n_par, 3).index_put((ret["rays_inds"],), ret["rendered"]["rgb_volume"])
         from neuralsim_amd.renderers.single_volume_renderer import SingleVolumeRenderer
         rend = SingleVolumeRenderer(dict(with_rgb=True, near=0.01, depth_use_normalized_vw=True)).eval()
@@ -550,6 +554,11 @@ def build_config_trainer(name, dev, rank, world, rays_per_gpu, precision="fp16")
     raise ValueError(name)
 
 
+def _mo(tr) -> bool:
+    from neuralsim_amd.fields.neus import marched_only
+    return bool(marched_only(tr.model.ray_query_cfg.get("query_param", {})))
+
+
 def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; the elapsed
     time is the MAX over ranks; rank 0 returns the JSON record (other ranks None) and the next iteration number."""
@@ -583,7 +592,7 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     _lib.TIMER = _lib.KernelTimer(only=KM.keys()) if on_gpu else None
     _lib.CALL_COUNT = 0
     _lib.HOST_WAIT = 0.0
-    S_f = S_hit = 0
+    S_f = S_hit = S_q = S_live = 0
     marks = []
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -591,6 +600,8 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
         it += 1
         S_f += tr.stats["S_f"]
         S_hit += tr.stats["R_hit"]
+        S_q += tr.stats.get("S_q", 0)
+        S_live += tr.stats.get("R_live", tr.stats["R_hit"])
         marks.append(time.perf_counter() - t0)      # host side; every step blocks once on its sample count
     fence()
     elapsed = time.perf_counter() - t0
@@ -687,12 +698,19 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                                     f"{rays_per_gpu} rays/iter/GPU, L=16 hashgrid (T=2^19, F=2) + {tr.model.sdf_D}x64 SDF MLP + 2x64 radiance "
                                     "MLP (SH4, appear 4), synthetic sphere r=0.75 (~40% coverage) supervised by its analytic image, occ grid 64^3, num_coarse 64, "
                                     "num_fine [8,8,32], "
-                                    "step .005, query_mode march_occ_multi_upsample_compressed (reference default), inv_s=e^5, eikonal on "
+                                    f"step .005, query_mode march_occ_multi_upsample_compressed (reference default), upsample_on_marched_only "
+                                    f"{str(_mo(tr)).lower()} (coarse + fine samples on the rays whose occupancy march found something), inv_s=e^5, eikonal on "
                                     "render samples + 4096 uniform points, "
                            "Adam + occupancy refresh every 16 it inside the timed region",
                            rays_per_gpu=rays_per_gpu, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
+                           upsample_on_marched_only=_mo(tr),
+                           # realised sample statistics: rays that pass the AABB test / whose march finds occupied
+                           # voxels, SDF-only queries of the sampling pass (S_q) and with-grad samples (S_f) per step
                            samples_per_hit_ray=round(S_f / max(1, S_hit), 1),
-                           hit_fraction=round(S_hit / (rays_per_gpu * steps), 3)),
+                           samples_per_marched_ray=round(S_f / max(1, S_live), 1),
+                           hit_fraction=round(S_hit / (rays_per_gpu * steps), 3),
+                           marched_fraction=round(S_live / (rays_per_gpu * steps), 3),
+                           S_q_per_step=round(S_q / steps), S_f_per_step=round(S_f / steps)),
                step_ms=dict(p10=q(0.1), p50=q(0.5), p90=q(0.9), max=round(d[-1] * 1e3, 3)),
                roofline=roofline, kernels=per_kernel,
                # C-ABI entry-point calls of this package per step (each is one kernel launch, three of them two); the ATen /

@@ -71,6 +71,14 @@ int nsim_pack_infos_from_n(const int64_t* n, int64_t P, int64_t* pack_infos, int
  * synchronisation or a copy, so work queued behind this launch is not drained by the size read.  P > 0. */
 int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_infos, int64_t* total, int64_t cap,
                                   int64_t* notify, int64_t seq, void* stream);
+/* ``ray_query_cfg.query_param.upsample_on_marched_only`` (the [R'] hit set of the reference's volume buffers,
+ * single_volume_renderer.py:209-220,289-300: ``rays_inds_hit`` / ``pack_infos_hit`` cover the rays that produced samples): from
+ * the occupancy-march counts n [R]: live_rank [R] = q >= 0 for the q-th ray with n > 0 ("live"), ~q < 0 for a ray with n == 0
+ * (q live rays precede it); live_idx [R] (may be NULL) = the live rays in order, zero-filled past R'; cnts [8] (device) =
+ * {R', sum(n) + R' C, R' nf0, R' nf1, R' nf2, R' nf3, sum(n), 0} -- the device-side point counts of the sampling pass's SDF
+ * queries; notify (may be NULL): host-mapped words receiving (R', seq) as nsim_pack_infos_from_n_notify. */
+int nsim_live_rank(const int64_t* n, int64_t R, int C, int nf0, int nf1, int nf2, int nf3, int64_t* live_rank,
+                   int64_t* live_idx, int64_t* cnts, int64_t* notify, int64_t seq, void* stream);
 /* packed_sum(x [S,C], pack_infos) -> out [P,C]   (single_volume_renderer.py:84-101) */
 int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream);
 /* out[s,c] = x[s,c] (op) per_pack[p, c or 0]; op 0 mul, 1 div, 2 add, 3 sub; x may be NULL (treated as 1 for
@@ -208,29 +216,32 @@ int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near,
                     const NsimOccMeta* meta, float step, int max_steps, const int64_t* pack_infos, float* t_out,
                     void* stream);
 /* coarse_step_cfg{step_mode: linear}: t = near + (far-near) * ((i + u)/C); jitter_c NULL => u = 0.5 */
+/* live_rank (here and in the three entry points below; may be NULL = every ray is live, dense [R, n] layout): the ranks of
+ * nsim_live_rank -- only live rays get samples, and every per-live-ray array (out here; t_b / v_b, t_new, x_new below) is
+ * indexed by the rank q instead of r, i.e. holds R' n compact entries. */
 int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C,
-                       float* out, void* stream);
+                       float* out, const int64_t* live_rank, void* stream);
 /* One NeuS up-sampling stage (num_fine[i], upsample_inv_s * factor[i], upsample_use_estimate_alpha).
  * scratch: float [S]. t_new: [R, n_fine] ascending.  x_new [R, n_fine, 3] (may be NULL; needs rays_o / rays_d [R,3]):
  * positions o + t d of the new samples, so that the level-major query reads 12 B per point instead of re-deriving
  * the point from (ridx, t, o, d) once per XCD. */
 int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
                         int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
-                        const float* rays_d, float* x_new, void* stream);
+                        const float* rays_d, float* x_new, const int64_t* live_rank, void* stream);
 /* Sorted merge of packed (t_a, v_a) with batched (t_b, v_b) [R,nb]; packs must tile the arrays in order.
  * v_a / v_b / v_out may be NULL. pack_infos_out [R,2] is written; ridx_out [S_out] (may be NULL) receives the
  * ray (pack) index of every merged sample; x_out [S_out, 3] (may be NULL; needs rays_o / rays_d) their positions. */
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out,
                       int64_t* pack_infos_out, int64_t* ridx_out, const float* rays_o, const float* rays_d,
-                      float* x_out, void* stream);
+                      float* x_out, const int64_t* live_rank, void* stream);
 /* nsim_merge_sorted of up-sampling stage k followed, in the same launch, by nsim_upsample_stage of stage k + 1 on the merged
  * samples (both one wave per ray; v_a / v_b / v_out = the no-grad SDFs, required): t_new [R, n_fine] (+ x_new) are the next
  * stage's draws; scratch [>= merged sample count] as nsim_upsample_stage.  Same values as the two calls. */
 int nsim_merge_upsample(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b, const float* v_b,
                         int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out, int64_t* ridx_out, float inv_s,
                         int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
-                        const float* rays_d, float* x_new, void* stream);
+                        const float* rays_d, float* x_new, const int64_t* live_rank, void* stream);
 
 /* ``query_mode: march_occ_multi_upsample_compressed`` (lotd_neus.dtu.230814.yaml:157): from the no-grad SDF of all
  * samples keep those that bound an interval with visibility weight > thre.  count -> counts [R]; emit (given

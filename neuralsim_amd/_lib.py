@@ -72,6 +72,7 @@ _F = C.c_float
 SIGNATURES = {
     "nsim_pack_infos_from_n": [_P, _I64, _P, _P, _I64],
     "nsim_pack_infos_from_n_notify": [_P, _I64, _P, _P, _I64, _P, _I64],
+    "nsim_live_rank": [_P, _I64, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I64],
     "nsim_packed_sum": [_P, _I, _P, _I64, _P],
     "nsim_packed_binary": [_P, _I, _P, _I, _P, _I64, _I, _P],
     "nsim_packed_cmp": [_P, _P, _P, _I64, _I, _P],
@@ -100,10 +101,10 @@ SIGNATURES = {
     "nsim_occ_collect": [_P, _P, _P, _I64, _P, _I64, C.POINTER(OccMeta), _F],
     "nsim_march_count": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P],
     "nsim_march_emit": [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(OccMeta), _F, _I, _P, _P],
-    "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P],
-    "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P, _P, _P, _P],
-    "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P],
-    "nsim_merge_upsample": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "nsim_coarse_depths": [_P, _P, _P, _I64, _I, _P, _P],
+    "nsim_upsample_stage": [_P, _P, _P, _I64, _F, _I, _I, _P, _P, _P, _P, _P, _P],
+    "nsim_merge_sorted": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsim_merge_upsample": [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P],
     "nsim_compress_count": [_P, _P, _I64, _P, _F, _F, _F, _P],
     "nsim_compress_emit": [_P, _P, _P, _I64, _P, _F, _F, _F, _P, _P, _P, _I64],
     "nsim_lotd_fwd": [_P, _P, C.POINTER(LotdMeta), _I64, _P, _P],

@@ -1381,11 +1381,20 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #ifndef GLM_PTS
 #define GLM_PTS 4
 #endif
-template <int PREC, bool WJ>
+// Points per lane by launch size (round 5): a small launch (the first two up-sampling draws: R' x 8 points = 30 k on the object
+// workload) at 4 points per lane is ~120 waves per XCD, each walking its levels in sequence -- latency, not requests.
+// One point per lane gives four times the waves.  NSIM_GLM_SMALL = capacity (points) up to which a launch uses 1 point per lane
+// (default 98 304), twice that: 2 points.
+static inline int glm_pts_for(int64_t S) {
+  static const int64_t small = getenv("NSIM_GLM_SMALL") ? atoll(getenv("NSIM_GLM_SMALL")) : 98304;
+  return S <= small ? 1 : (S <= 2 * small ? 2 : GLM_PTS);
+}
+template <int PREC, bool WJ, int GLM_PTS_T = GLM_PTS>
 __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
+  constexpr int NP = GLM_PTS_T;                    // points per lane
   const int lane = nsim_lane();
   const int xcd = (int)(blockIdx.x & 7u);
-  const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * GLM_PTS) + lane;
+  const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * NP) + lane;
   int64_t Sv = a.S;                                 // valid points (<= capacity a.S)
   if (a.S_dev) {
     // more points than the buffers were sized for: the packs are no longer contiguous (nsim_pack_infos_from_n
@@ -1393,10 +1402,13 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     const int64_t sd = a.S_dev[0] + a.S_add;
     Sv = sd <= Sv ? sd : 0;
   }
-  float xx[GLM_PTS][3];
-  uint32_t goff[GLM_PTS];
+  // the grid covers the CAPACITY a.S; a workgroup whose points all lie beyond the valid count has nothing to read or write
+  // (round 5: with device-side counts -- speculative sizes, upsample_on_marched_only -- that is up to half of the grid)
+  if (s0 - lane >= Sv) return;
+  float xx[NP][3];
+  uint32_t goff[NP];
 #pragma unroll
-  for (int q = 0; q < GLM_PTS; ++q) {
+  for (int q = 0; q < NP; ++q) {
     const int64_t s = s0 + 64 * q;
     xx[q][0] = xx[q][1] = xx[q][2] = 0.f;
     goff[q] = 0u;
@@ -1414,7 +1426,9 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
   }
   const GridRef gref = grid_ref(a.grid);
   const int nl = a.glm_n[xcd];
-  const bool second_half = (blockIdx.x >> 3) >= ((gridDim.x >> 3) + 1) / 2;
+  // (a level dealt to two XCDs is split between the two halves of the VALID point range)
+  const int64_t nblk_valid = (Sv + 64 * NP - 1) / (64 * NP);
+  const bool second_half = (int64_t)(blockIdx.x >> 3) >= (nblk_valid + 1) / 2;
 #pragma unroll 1
   for (int k = 0; k < nl; ++k) {
     const int l = a.glm_lv[xcd][k];
@@ -1423,10 +1437,10 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     const LotdRes R = a.lotd.res[l];
     const int type = a.lotd.type[l];
     const uint32_t T = a.lotd.size[l], off = (uint32_t)a.lotd.offset[l];
-    float f0[GLM_PTS], f1[GLM_PTS];
-    float j0[WJ ? GLM_PTS : 1][3], j1[WJ ? GLM_PTS : 1][3];
+    float f0[NP], f1[NP];
+    float j0[WJ ? NP : 1][3], j1[WJ ? NP : 1][3];
 #pragma unroll
-    for (int q = 0; q < GLM_PTS; ++q) {
+    for (int q = 0; q < NP; ++q) {
       const LotdCell c = lotd_cell(xx[q], R, a.lotd);
       f0[q] = f1[q] = 0.f;
       if constexpr (WJ) {
@@ -1461,7 +1475,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < GLM_PTS; ++q) {
+    for (int q = 0; q < NP; ++q) {
       const int64_t s = s0 + 64 * q;
       if (s < Sv) {
         const int64_t e = (int64_t)l * a.PS + s;      // feature planes [NL][P], P = NSIM_PLANE_PITCH(S)
@@ -1494,6 +1508,15 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
       }
     }
   }
+}
+
+template <int PREC, bool WJ>
+static void launch_gather_lm(const FieldArgs& a, int64_t S, hipStream_t stream) {
+  const int pts = glm_pts_for(S);
+  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * pts)));
+  if (pts == 1) hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, 1>), gg, dim3(64), 0, stream, a);
+  else if (pts == 2) hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, 2>), gg, dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, GLM_PTS>), gg, dim3(64), 0, stream, a);
 }
 
 // GL (PLANES only): the tile's plane image -- per level 32 points x (f16x2 | f32x2) = 128 B | 256 B, one aligned piece
@@ -2422,9 +2445,8 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
   a.feat_pl = feat_planes;
   a.PS = NSIM_PLANE_PITCH(S);
   deal_levels(meta, a);
-  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
-  if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, false>), gg, dim3(64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_lotd_gather_lm<1, false>), gg, dim3(64), 0, (hipStream_t)stream, a);   // f32 planes (1, 2)
+  if (meta->precision == 0) launch_gather_lm<0, false>(a, S, (hipStream_t)stream);
+  else launch_gather_lm<1, false>(a, S, (hipStream_t)stream);   // f32 planes (1, 2)
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -2546,9 +2568,8 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   if (h_planes && (!grid_f16 || !fused || n_dev || field_nc(meta->lotd.num_levels) == 2)) {      // training: level-major gather into the planes, then the decoders on the planes
     if (grid_f16) {      // (NULL: the caller's encoding has filled the planes already -- nsim_permuto_gather)
       deal_levels(meta, a);
-      const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
-      if (meta->precision == 0) hipLaunchKernelGGL((k_lotd_gather_lm<0, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((k_lotd_gather_lm<1, true>), gg, dim3(64), 0, (hipStream_t)stream, a);
+      if (meta->precision == 0) launch_gather_lm<0, true>(a, S, (hipStream_t)stream);
+      else launch_gather_lm<1, true>(a, S, (hipStream_t)stream);
     }
     // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS); 17..32 levels, fp16: 1 KB per level and wave
     // where that still fits the 160 KB of a CU (NSIM_FWD_GL2=0: the direct-load kernel)

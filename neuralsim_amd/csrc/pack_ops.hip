@@ -72,6 +72,77 @@ __global__ void __launch_bounds__(PI_THREADS) k_pack_infos_from_n(const int64_t*
   }
 }
 
+// ------------------------------------------------------------------------------------ live-ray ranks
+// ``upsample_on_marched_only`` (ray_query_cfg.query_param): coarse and fine samples go only to the rays whose occupancy march
+// found something.  From the march counts n [R] (one workgroup, the scan structure of k_pack_infos_from_n):
+//   live_rank[r] = q  (>= 0)  r is the q-th live ray (n[r] > 0);   ~q (< 0)  r is dead, q live rays precede it
+//   live_idx[q]  = r          the live rays in order (entries q >= R' are set to 0)
+//   cnts[0] = R', cnts[1] = sum(n) + R' C (points of the first SDF query), cnts[2 + k] = R' nf[k] (points of draw k), cnts[6] = sum(n)
+// and optionally (R', seq) to host-mapped ``notify`` words (see k_pack_infos_from_n).
+struct LiveArgs {
+  int C;
+  int nf[4];
+};
+__global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restrict__ n, int64_t R, LiveArgs la,
+                                                           int64_t* __restrict__ live_rank, int64_t* __restrict__ live_idx,
+                                                           int64_t* __restrict__ cnts, int64_t* notify, int64_t seq) {
+  __shared__ int64_t wtot[PI_THREADS / 64];
+  const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
+  const int64_t LIVE1 = (int64_t)1 << 44;        // (live count << 44) | sample count: one scan carries both sums
+  const int64_t LOW = LIVE1 - 1;
+  int64_t carry = 0;
+  for (int64_t base = 0; base < R; base += (int64_t)PI_THREADS * PI_PER) {
+    const int64_t i0 = base + (int64_t)tid * PI_PER;
+    int64_t v[PI_PER];
+    int64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < PI_PER; ++k) {
+      const int64_t c = (i0 + k) < R ? n[i0 + k] : 0;
+      v[k] = c + (c > 0 ? LIVE1 : 0);
+      mine += v[k];
+    }
+    const int64_t incl = wave_incl_sum(mine);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int64_t before = 0, chunk = 0;
+#pragma unroll
+    for (int w = 0; w < PI_THREADS / 64; ++w) {
+      const int64_t x = wtot[w];
+      before += (w < wave) ? x : 0;
+      chunk += x;
+    }
+    int64_t run = carry + before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < PI_PER; ++k) {
+      const int64_t i = i0 + k;
+      if (i < R) {
+        const int64_t q = run >> 44;
+        const bool live = v[k] >= LIVE1;
+        live_rank[i] = live ? q : ~q;
+        if (live && live_idx) live_idx[q] = i;
+      }
+      run += v[k];
+    }
+    carry += chunk;
+    __syncthreads();
+  }
+  const int64_t Rl = carry >> 44, M = carry & LOW;
+  if (live_idx)
+    for (int64_t i = Rl + tid; i < R; i += PI_THREADS) live_idx[i] = 0;
+  if (tid == 0) {
+    cnts[0] = Rl;
+    cnts[1] = M + Rl * la.C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnts[2 + k] = Rl * la.nf[k];
+    cnts[6] = M;
+    cnts[7] = 0;
+    if (notify) {
+      nsim_store_system(notify, Rl, false);
+      nsim_store_system(notify + 1, seq, true);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ packed_sum
 __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sum(const float* __restrict__ x, int C,
                                                              const int64_t* __restrict__ pi, int64_t P,
@@ -811,6 +882,19 @@ int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_inf
   if (!notify) return 4;
   hipLaunchKernelGGL(k_pack_infos_from_n, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, P, pack_infos, total, cap,
                      notify, seq);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_live_rank(const int64_t* n, int64_t R, int C, int nf0, int nf1, int nf2, int nf3, int64_t* live_rank, int64_t* live_idx,
+                   int64_t* cnts, int64_t* notify, int64_t seq, void* stream) {
+  if (R <= 0) return 2;
+  if (!n || !live_rank || !cnts || C < 0) return 4;
+  LiveArgs la;
+  la.C = C;
+  la.nf[0] = nf0, la.nf[1] = nf1, la.nf[2] = nf2, la.nf[3] = nf3;
+  hipLaunchKernelGGL(k_live_rank, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, R, la, live_rank, live_idx, cnts, notify,
+                     seq);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

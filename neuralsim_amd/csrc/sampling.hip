@@ -22,6 +22,20 @@ __device__ __forceinline__ int64_t smp_wave_id() {
 }
 static inline dim3 smp_grid(int64_t R) { return dim3(nsim_blocks(R, SMP_WAVES_PER_BLOCK)); }
 
+// ``upsample_on_marched_only`` (nsim_live_rank, pack_ops.hip): live_rank[r] = q >= 0 -- ray r is the q-th ray whose march found
+// occupied voxels ("live"); ~q < 0 -- it found none (q live rays precede it).  Only live rays get coarse and fine samples; every
+// per-live-ray array ([R', C] coarse depths, [R', n_fine] draws and their positions / SDFs) is indexed by q, so the points of the
+// SDF queries are compact: R' n instead of R n.  live_rank == NULL: every ray is live and q = r (the dense layout).
+__device__ __forceinline__ bool smp_live(const int64_t* __restrict__ live_rank, int64_t r, int64_t& q) {
+  if (!live_rank) {
+    q = r;
+    return true;
+  }
+  const int64_t e = live_rank[r];
+  q = e >= 0 ? e : ~e;
+  return e >= 0;
+}
+
 // ----------------------------------------------------------------------------------- ray generation
 // ``intr.lift(u, v, 1)``: pixel -> direction in the camera frame.  Pinhole: ((u - cx) / fx, (v - cy) / fy, 1).  OpenCV
 // model (camera_model 'opencv', app/resources/observers/cameras.py:84-87; Waymo's calibration, ``consider_distortion:
@@ -298,13 +312,15 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_march_emit(
 
 __global__ void __launch_bounds__(256) k_coarse_depths(const float* __restrict__ near, const float* __restrict__ far,
                                                         const float* __restrict__ jc, int64_t R, int C,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const int64_t* __restrict__ live_rank) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= R * C) return;
   const int64_t r = j / C;
   const int i = (int)(j % C);
+  int64_t q;
+  if (!smp_live(live_rank, r, q)) return;
   const float u = jc ? jc[j] : 0.5f;
-  out[j] = near[r] + (far[r] - near[r]) * (((float)i + u) / (float)C);
+  out[q * C + i] = near[r] + (far[r] - near[r]) * (((float)i + u) / (float)C);
 }
 
 // ---------------------------------------------------------------------------------------- up-sampling
@@ -335,7 +351,7 @@ __device__ __forceinline__ float upsample_alpha(const float* t, const float* sdf
 
 // one ray (one wave): n_fine new depths drawn from the interval weights of the ray's samples tt / ss [n]; ``lds`` holds the
 // running sums when the ray fits (SMP_LDS_FLOATS intervals), the global scratch ``cs_glob`` otherwise
-__device__ __forceinline__ void upsample_ray(const float* tt, const float* ss, int64_t n, int64_t r, float inv_s, int n_fine,
+__device__ __forceinline__ void upsample_ray(const float* tt, const float* ss, int64_t n, int64_t r, int64_t q, float inv_s, int n_fine,
                                              int use_est, float* lds, float* cs_glob, float* __restrict__ t_new,
                                              const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                              float* __restrict__ x_new) {
@@ -390,10 +406,10 @@ __device__ __forceinline__ void upsample_ray(const float* tt, const float* ss, i
         const float b_lo = tt[lo], b_hi = tt[lo + 1];
         tn = b_lo + frac * (b_hi - b_lo);
       }
-      t_new[r * n_fine + k] = tn;
+      t_new[q * n_fine + k] = tn;
       if (x_new) {   // the sample's position, so that the level-major query loads 12 B instead of re-deriving it per XCD
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x_new[(r * n_fine + k) * 3 + c] = ro[c] + tn * rd[c];
+        for (int c = 0; c < 3; ++c) x_new[(q * n_fine + k) * 3 + c] = ro[c] + tn * rd[c];
       }
     }
   };
@@ -409,14 +425,17 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_upsample_stage(const float* __res
                                                                 float* __restrict__ t_new,
                                                                 const float* __restrict__ rays_o,
                                                                 const float* __restrict__ rays_d,
-                                                                float* __restrict__ x_new) {
+                                                                float* __restrict__ x_new,
+                                                                const int64_t* __restrict__ live_rank) {
   // the running sums of a ray's interval weights live in LDS (<= SMP_LDS_FLOATS intervals; longer rays use the global
   // scratch): the inverse-CDF search below is eight DEPENDENT reads per new sample -- 13 us per launch from L2
   __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
   const int64_t r = smp_wave_id();
   if (r >= R) return;
+  int64_t q;
+  if (!smp_live(live_rank, r, q)) return;      // no marched samples: no draws
   const int64_t st = pi[2 * r], n = pi[2 * r + 1];
-  upsample_ray(t + st, sdf + st, n, r, inv_s, n_fine, use_est, &smp_lds[threadIdx.x >> 6][0], csum + st, t_new, rays_o, rays_d,
+  upsample_ray(t + st, sdf + st, n, r, q, inv_s, n_fine, use_est, &smp_lds[threadIdx.x >> 6][0], csum + st, t_new, rays_o, rays_d,
                x_new);
 }
 
@@ -441,7 +460,7 @@ __device__ __forceinline__ int64_t smp_upper_bound(const float* a, int64_t n, fl
 // one ray (one wave): merge its sorted depth lists a [na] (values v_a) and b [nb] (values v_b) into the packed output at
 // ``so``; ``lds`` holds both lists when they fit
 __device__ __forceinline__ void merge_ray(const float* __restrict__ t_a, const float* __restrict__ v_a, int64_t sa, int64_t na,
-                                          const float* __restrict__ t_b, const float* __restrict__ v_b, int64_t r, int nb,
+                                          const float* __restrict__ t_b, const float* __restrict__ v_b, int64_t r, int64_t q, int nb,
                                           int64_t so, float* lds, float* __restrict__ t_out, float* __restrict__ v_out,
                                           int64_t* __restrict__ ridx_out, const float* __restrict__ rays_o,
                                           const float* __restrict__ rays_d, float* __restrict__ x_out) {
@@ -460,7 +479,7 @@ __device__ __forceinline__ void merge_ray(const float* __restrict__ t_a, const f
   float* lb = la + na;
   if (in_lds) {
     for (int64_t i = lane; i < na; i += 64) la[i] = t_a[sa + i];
-    for (int64_t j = lane; j < nb; j += 64) lb[j] = t_b[r * (int64_t)nb + j];
+    for (int64_t j = lane; j < nb; j += 64) lb[j] = t_b[q * (int64_t)nb + j];
     nsim_wave_fence();
   }
   auto body = [&](auto a, auto b) {
@@ -479,7 +498,7 @@ __device__ __forceinline__ void merge_ray(const float* __restrict__ t_a, const f
       const float v = b[j];
       const int64_t pos = j + smp_upper_bound(a, na, v);
       t_out[so + pos] = v;
-      if (v_out) v_out[so + pos] = v_b ? v_b[r * (int64_t)nb + j] : 0.f;
+      if (v_out) v_out[so + pos] = v_b ? v_b[q * (int64_t)nb + j] : 0.f;
       if (ridx_out) ridx_out[so + pos] = r;
       if (x_out) {
 #pragma unroll
@@ -488,7 +507,7 @@ __device__ __forceinline__ void merge_ray(const float* __restrict__ t_a, const f
     }
   };
   if (in_lds) body((const float*)la, (const float*)lb);
-  else body(t_a + sa, t_b + r * (int64_t)nb);
+  else body(t_a + sa, t_b + q * (int64_t)nb);
 }
 
 __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restrict__ t_a,
@@ -500,17 +519,22 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_sorted(const float* __restr
                                                               int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
                                                               const float* __restrict__ rays_o,
                                                               const float* __restrict__ rays_d,
-                                                              float* __restrict__ x_out) {
+                                                              float* __restrict__ x_out,
+                                                              const int64_t* __restrict__ live_rank) {
   __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
   const int64_t r = smp_wave_id();
   if (r >= R) return;
-  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
-  const int64_t so = sa + r * (int64_t)nb;
+  int64_t q;
+  const bool live = smp_live(live_rank, r, q);
+  const int64_t sa = pia[2 * r], na = live ? pia[2 * r + 1] : 0;
+  const int64_t so = sa + q * (int64_t)nb;       // q live rays precede r, each with nb list-b samples
+  const int nb_r = live ? nb : 0;
   if (nsim_lane() == 0) {
     pio[2 * r] = so;
-    pio[2 * r + 1] = na + nb;
+    pio[2 * r + 1] = na + nb_r;
   }
-  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, nb, so, &smp_lds[threadIdx.x >> 6][0], t_out, v_out, ridx_out, rays_o, rays_d, x_out);
+  if (!live) return;
+  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, q, nb, so, &smp_lds[threadIdx.x >> 6][0], t_out, v_out, ridx_out, rays_o, rays_d, x_out);
 }
 
 // merge of up-sampling stage k AND the draw of stage k + 1 in one launch (round 4): both are one-wave-per-ray; the merged
@@ -523,20 +547,25 @@ __global__ void __launch_bounds__(SMP_BLOCK) k_merge_upsample(const float* __res
                                                                 int64_t* __restrict__ pio, int64_t* __restrict__ ridx_out,
                                                                 float inv_s, int n_fine, int use_est, float* __restrict__ csum,
                                                                 float* __restrict__ t_new, const float* __restrict__ rays_o,
-                                                                const float* __restrict__ rays_d, float* __restrict__ x_new) {
+                                                                const float* __restrict__ rays_d, float* __restrict__ x_new,
+                                                                const int64_t* __restrict__ live_rank) {
   __shared__ float smp_lds[SMP_WAVES_PER_BLOCK][SMP_LDS_FLOATS];
   const int64_t r = smp_wave_id();
   if (r >= R) return;
-  const int64_t sa = pia[2 * r], na = pia[2 * r + 1];
-  const int64_t so = sa + r * (int64_t)nb;
+  int64_t q;
+  const bool live = smp_live(live_rank, r, q);
+  const int64_t sa = pia[2 * r], na = live ? pia[2 * r + 1] : 0;
+  const int64_t so = sa + q * (int64_t)nb;
+  const int nb_r = live ? nb : 0;
   if (nsim_lane() == 0) {
     pio[2 * r] = so;
-    pio[2 * r + 1] = na + nb;
+    pio[2 * r + 1] = na + nb_r;
   }
+  if (!live) return;
   float* lds = &smp_lds[threadIdx.x >> 6][0];
-  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, nb, so, lds, t_out, v_out, ridx_out, nullptr, nullptr, nullptr);
+  merge_ray(t_a, v_a, sa, na, t_b, v_b, r, q, nb, so, lds, t_out, v_out, ridx_out, nullptr, nullptr, nullptr);
   nsim_wave_fence();
-  upsample_ray(t_out + so, v_out + so, na + nb, r, inv_s, n_fine, use_est, lds, csum + so, t_new, rays_o, rays_d, x_new);
+  upsample_ray(t_out + so, v_out + so, na + nb, r, q, inv_s, n_fine, use_est, lds, csum + so, t_new, rays_o, rays_d, x_new);
 }
 
 // ------------------------------------------------------------------ compressed query mode
@@ -738,32 +767,33 @@ int nsim_march_emit(const float* rays_o, const float* rays_d, const float* near,
 }
 
 int nsim_coarse_depths(const float* near, const float* far, const float* jitter_c, int64_t R, int C, float* out,
-                       void* stream) {
+                       const int64_t* live_rank, void* stream) {
   if (R <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(k_coarse_depths, dim3(nsim_blocks(R * C, 256)), dim3(256), 0, (hipStream_t)stream, near, far,
-                     jitter_c, R, C, out);
+                     jitter_c, R, C, out, live_rank);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_upsample_stage(const float* t, const float* sdf, const int64_t* pack_infos, int64_t R, float inv_s,
                         int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
-                        const float* rays_d, float* x_new, void* stream) {
+                        const float* rays_d, float* x_new, const int64_t* live_rank, void* stream) {
   if (R <= 0 || n_fine <= 0) return 0;
   if (x_new && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_upsample_stage, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t, sdf, pack_infos, R, inv_s,
-                     n_fine, use_estimate_alpha, scratch, t_new, rays_o, rays_d, x_new);
+                     n_fine, use_estimate_alpha, scratch, t_new, rays_o, rays_d, x_new, live_rank);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
 
 int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b,
                       const float* v_b, int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out,
-                      int64_t* ridx_out, const float* rays_o, const float* rays_d, float* x_out, void* stream) {
+                      int64_t* ridx_out, const float* rays_o, const float* rays_d, float* x_out, const int64_t* live_rank,
+                      void* stream) {
   if (R <= 0) return 0;
   if (x_out && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_merge_sorted, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b,
-                     R, nb, t_out, v_out, pack_infos_out, ridx_out, rays_o, rays_d, x_out);
+                     R, nb, t_out, v_out, pack_infos_out, ridx_out, rays_o, rays_d, x_out, live_rank);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
@@ -771,13 +801,13 @@ int nsim_merge_sorted(const float* t_a, const float* v_a, const int64_t* pack_in
 int nsim_merge_upsample(const float* t_a, const float* v_a, const int64_t* pack_infos_a, const float* t_b, const float* v_b,
                         int64_t R, int nb, float* t_out, float* v_out, int64_t* pack_infos_out, int64_t* ridx_out, float inv_s,
                         int n_fine, int use_estimate_alpha, float* scratch, float* t_new, const float* rays_o,
-                        const float* rays_d, float* x_new, void* stream) {
+                        const float* rays_d, float* x_new, const int64_t* live_rank, void* stream) {
   if (R <= 0) return 0;
   if (n_fine <= 0 || !v_a || !v_b || !v_out || !scratch || !t_new) return 4;
   if (x_new && !(rays_o && rays_d)) return 24;
   hipLaunchKernelGGL(k_merge_upsample, smp_grid(R), dim3(SMP_BLOCK), 0, (hipStream_t)stream, t_a, v_a, pack_infos_a, t_b, v_b, R,
                      nb, t_out, v_out, pack_infos_out, ridx_out, inv_s, n_fine, use_estimate_alpha, scratch, t_new, rays_o,
-                     rays_d, x_new);
+                     rays_d, x_new, live_rank);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -172,8 +172,9 @@ class BatchedRaysMixin:
                 ret["rendered_pairs"] = pairs
         vb = ret["volume_buffer"]
         if vb["type"] != "empty":
-            vb["rays_bidx_hit"] = bt["rays_bidx"]
-            vb["rays_full_bidx_hit"] = bt["rays_full_bidx"]
+            sel = getattr(self, "_rays_sel", None)      # upsample_on_marched_only: the pairs that produced samples
+            vb["rays_bidx_hit"] = bt["rays_bidx"] if sel is None else bt["rays_bidx"][sel]
+            vb["rays_full_bidx_hit"] = bt["rays_full_bidx"] if sel is None else bt["rays_full_bidx"][sel]
         return ret
 
     def ray_test(self, *a, **k):

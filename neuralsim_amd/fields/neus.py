@@ -81,6 +81,20 @@ def fine_list(qp: dict):
     return [max(int(nf) // k, 1)] * k
 
 
+def marched_only(qp: dict) -> bool:
+    """``query_param.upsample_on_marched_only`` (default True; env NSIM_UPSAMPLE_ON_MARCHED_ONLY=0 flips the default): coarse
+    and fine samples only on the rays whose occupancy march found occupied voxels; the other tested rays stay without
+    samples.  The reference's volume buffers list the rays that produced samples -- ``rays_inds_hit`` / ``pack_infos_hit``
+    are a subset [R'] of the tested rays [R], and a model whose march finds nothing returns ``type: 'empty'``
+    (single_volume_renderer.py:209-220,289-300) --, which is also what an occupancy grid is for: a ray that crosses only
+    empty voxels is not queried.  False restores rounds 1-4: every AABB-hit ray gets num_coarse + sum(num_fine) SDF queries
+    (on the object workload ~60 % of the tested rays see no occupied voxel and were 55 % of the sampling queries)."""
+    v = qp.get("upsample_on_marched_only", None)
+    if v is None:
+        return os.environ.get("NSIM_UPSAMPLE_ON_MARCHED_ONLY", "1") == "1"
+    return bool(v)
+
+
 # --------------------------------------------------------------------------------------------- autograd
 
 
@@ -1114,43 +1128,75 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=int(cap), notify=(adr, self._notify_seq_m))
         else:
             pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
+        fine = fine_list(qp)
+        # ``upsample_on_marched_only``: ranks of the rays whose march found something (q-th live ray <-> ray r) and the
+        # device-side point counts of this pass's SDF queries -- coarse / fine samples and their queries cover R' rays
+        mo = marched_only(qp)
+        lr = live_idx = cnts = None
+        self._live = None
+        if mo:
+            assert len(fine) <= 4, "upsample_on_marched_only: at most four up-sampling stages"
+            lr = torch.empty([R], dtype=torch.long, device=dev)
+            live_idx = torch.empty([R], dtype=torch.long, device=dev)
+            cnts = torch.empty([8], dtype=torch.long, device=dev)
+            adr_l, seq_l = nt.arm(2) if nt is not None else (None, 0)
+            _lib.call("nsim_live_rank", _lib.ptr(counts), R, C, *((list(fine) + [0, 0, 0, 0])[:4]), _lib.ptr(lr), _lib.ptr(live_idx),
+                      _lib.ptr(cnts), adr_l, seq_l)
+            self._live = dict(rank=lr, idx=live_idx, cnts=cnts, seq=seq_l if nt is not None else None, n=None)
+        Rl = R                                  # rays that get coarse / fine samples (an upper bound when sized speculatively)
         if cap is None:
             if pre_sync_hook is not None:
                 pre_sync_hook()                 # independent host work queued ahead of the blocking read
-            M = int(total_m.item())             # host sync: size of the marched set
+            if mo:                              # host sync: size of the marched set and the number of live rays
+                c_host = cnts.tolist()
+                M, Rl = int(c_host[6]), int(c_host[0])
+                self._live["n"] = Rl
+                if Rl == 0:                     # no ray marched into an occupied voxel: no samples at all
+                    self._last_S_q, self._S_per_live = 0, C + sum(int(n) for n in fine)
+                    e = torch.empty([0], **f32)
+                    return (e, e, torch.zeros([R, 2], dtype=torch.long, device=dev),
+                            torch.empty([0], dtype=torch.long, device=dev) if need_ridx else None, counts, total_m)
+            else:
+                M = int(total_m.item())         # host sync: size of the marched set
             n_dev = None
         else:
             M, n_dev = int(cap), total_m
+
+        def n_of(k):
+            """device-side point count of query k (0: marched + coarse, 1 + i: the draws of stage i) when sizes are speculative"""
+            if n_dev is None:
+                return None
+            return cnts[1 + k:2 + k] if mo else (n_dev if k == 0 else None)
         t_m = torch.empty([max(M, 1)], **f32)
         _lib.call("nsim_march_emit", _lib.ptr(o), _lib.ptr(d), _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter), R,
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(pi_m), _lib.ptr(t_m))
-        t_c = torch.empty([R, C], **f32)
-        _lib.call("nsim_coarse_depths", _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter_c), R, C, _lib.ptr(t_c))
-        S = M + R * C
+        t_c = torch.empty([max(Rl, 1), C], **f32)
+        _lib.call("nsim_coarse_depths", _lib.ptr(near), _lib.ptr(far), _lib.ptr(jitter_c), R, C, _lib.ptr(t_c), _lib.ptr(lr))
+        S = M + Rl * C
         t = torch.empty([S], **f32)
         pi = torch.empty([R, 2], dtype=torch.long, device=dev)
         # the level-major query visits every point once per XCD: hand it positions (12 B) instead of (ridx, t, o, d)
         with_x = not self._sdf_fused
         # per-sample ray indices (8 B each) are written only where somebody reads them: by the point-major / batched
         # queries on the way, and by the caller at the end (``need_ridx``: the compressed mode re-derives them)
-        fine = fine_list(qp)
         # per-ray state read INSIDE the encoding kernels: instance table offsets (batched LoTD) or a condition per ray (permuto)
         per_ray = goff is not None or self._per_ray_condition()
         ridx_mid = (not with_x) or per_ray
         ridx = torch.empty([S], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and not fine)) else None
         xq = torch.empty([S, 3], **f32) if with_x else None
         _lib.call("nsim_merge_sorted", _lib.ptr(t_m), None, _lib.ptr(pi_m), _lib.ptr(t_c), None, R, C, _lib.ptr(t), None,
-                  _lib.ptr(pi), _lib.ptr(ridx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(xq))
+                  _lib.ptr(pi), _lib.ptr(ridx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(xq), _lib.ptr(lr))
         grid16, wpack = self._shadow()
         fm_s = None
         if with_x:
             fm_s, wpack = self._sampling_ctx()
         collect = with_x and goff is None and self.accel.collect_armed       # fused into the decoder launches below
+        n0, a0 = (n_of(0), 0) if mo else (n_dev, R * C)
         if with_x:
             sdf = self._sdf_query(grid16, wpack, xq, None, None, None, ridx if per_ray else None, S, dev,
-                                  goff=goff, n_dev=n_dev, n_add=R * C, collect=collect, fm=fm_s)
+                                  goff=goff, n_dev=n0, n_add=a0, collect=collect, fm=fm_s)
         else:
-            sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n_dev, n_add=R * C)
+            sdf = self._query_sdf_rays(o, d, t, ridx, goff, n_dev=n0, n_add=a0)
         inv_s0 = float(qp.get("upsample_inv_s", 64.0))
         use_est = 1 if qp.get("upsample_use_estimate_alpha", True) else 0
         factors = list(qp.get("upsample_inv_s_factors", [1, 4, 16]))
@@ -1160,18 +1206,23 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         for k_stage, (nf, fac) in enumerate(stages):
             nf = int(nf)
             if t_new is None:       # the stage's draws (stage 0, or every stage without the fused merge + draw launch)
-                t_new = torch.empty([R, nf], **f32)
+                t_new = torch.empty([max(Rl, 1), nf], **f32)
                 scratch = torch.empty([S], **f32)
-                x_new = torch.empty([R * nf, 3], **f32) if with_x else None
+                x_new = torch.empty([max(Rl, 1) * nf, 3], **f32) if with_x else None
                 _lib.call("nsim_upsample_stage", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), R, inv_s0 * float(fac), nf, use_est,
-                          _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new))
-            ridx_new = self._arange_repeat(R, nf, dev)
+                          _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_new), _lib.ptr(lr))
+            if not mo:
+                ridx_new = self._arange_repeat(R, nf, dev)
+            elif per_ray or not with_x:     # the draws of live ray q belong to ray live_idx[q]
+                ridx_new = live_idx[:Rl].repeat_interleave(nf)
+            else:
+                ridx_new = None
             if with_x:
                 sdf_new = self._sdf_query(grid16, wpack, x_new, None, None, None, ridx_new if per_ray else None,
-                                          R * nf, dev, goff=goff, collect=collect, fm=fm_s)
+                                          Rl * nf, dev, goff=goff, n_dev=n_of(1 + k_stage) if mo else None, collect=collect, fm=fm_s)
             else:
-                sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1), ridx_new, goff)
-            S2 = S + R * nf
+                sdf_new = self._query_sdf_rays(o, d, t_new.reshape(-1)[:Rl * nf], ridx_new, goff)
+            S2 = S + Rl * nf
             t2 = torch.empty([S2], **f32)
             sdf2 = torch.empty([S2], **f32)
             pi2 = torch.empty([R, 2], dtype=torch.long, device=dev)
@@ -1179,26 +1230,29 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             ridx = torch.empty([S2], dtype=torch.long, device=dev) if (ridx_mid or (need_ridx and last)) else None
             if fuse and not last:       # merge of this stage + the draws of the next in one launch
                 nf2, fac2 = int(stages[k_stage + 1][0]), stages[k_stage + 1][1]
-                t_nx = torch.empty([R, nf2], **f32)
+                t_nx = torch.empty([max(Rl, 1), nf2], **f32)
                 scratch = torch.empty([S2], **f32)
-                x_nx = torch.empty([R * nf2, 3], **f32) if with_x else None
+                x_nx = torch.empty([max(Rl, 1) * nf2, 3], **f32) if with_x else None
                 _lib.call("nsim_merge_upsample", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R, nf,
                           _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), inv_s0 * float(fac2), nf2, use_est,
-                          _lib.ptr(scratch), _lib.ptr(t_nx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_nx))
+                          _lib.ptr(scratch), _lib.ptr(t_nx), _lib.ptr(o), _lib.ptr(d), _lib.ptr(x_nx), _lib.ptr(lr))
                 t_new, x_new = t_nx, x_nx
             else:
                 _lib.call("nsim_merge_sorted", _lib.ptr(t), _lib.ptr(sdf), _lib.ptr(pi), _lib.ptr(t_new), _lib.ptr(sdf_new), R,
-                          nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None)
+                          nf, _lib.ptr(t2), _lib.ptr(sdf2), _lib.ptr(pi2), _lib.ptr(ridx), None, None, None, _lib.ptr(lr))
                 t_new = x_new = None
             t, sdf, pi, S = t2, sdf2, pi2, S2
-        self._last_S_q = S   # SDF-only queries issued by this sampling pass (all samples are queried exactly once)
+        # SDF-only queries issued by this sampling pass (every sample is queried exactly once); with speculative sizes the
+        # exact figure follows at the compress step's wait (``_note_sampling_units``)
+        self._last_S_q = S
+        self._S_per_live = C + sum(int(n) for n in fine)
         return t, sdf, pi, ridx, counts, total_m
 
     def _host_notify(self):
         """``_lib.HostNotify`` of this model (NSIM_HOST_NOTIFY=0 or a failed wait turn it off)."""
         nt = getattr(self, "_notify", None)
         if nt is None:
-            nt = self._notify = _lib.HostNotify(2) if os.environ.get("NSIM_HOST_NOTIFY", "1") == "1" else False
+            nt = self._notify = _lib.HostNotify(3) if os.environ.get("NSIM_HOST_NOTIFY", "1") == "1" else False
         return nt or None
 
     def _compress(self, t, sdf, pi, forward_inv_s: float, thre: float, total_m=None, pre_sync_hook=None, tail: int = 0,
@@ -1261,6 +1315,10 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 # synchronising reads from here on.  (Visible now = the stream was merely slow, e.g. first-use code
                 # loading on a cold box: the words stay in use.)
                 self._notify = False
+        lv = getattr(self, "_live", None)
+        if lv is not None and lv["n"] is None:      # number of live rays of a speculatively sized sampling pass
+            n_l = nt.wait(2, lv["seq"]) if (nt is not None and self._notify and lv["seq"] is not None) else None
+            lv["n"] = int(lv["cnts"][0].item()) if n_l is None else int(n_l)
         if _lib.HOST_WAIT is not None:      # bench.py: host time spent blocked on the size of the kept set
             _lib.HOST_WAIT += time.perf_counter() - _w0
         self._keep_stat = (R, Sk)
@@ -1304,6 +1362,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         R tested rays.  -> (o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis): depths t [S] packed by pi [R,2] with
         ray indices ridx [S] -- constants of the differentiable part that follows."""
         R = ray_tested["num_rays"]
+        self._last_R_tested = int(R)
         o = ray_tested["rays_o"].detach().float().contiguous()
         d = ray_tested["rays_d"].detach().float().contiguous()
         near, far = ray_tested["near"].contiguous(), ray_tested["far"].contiguous()
@@ -1341,14 +1400,21 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                                                                               goff, woff, cap=None, need_ridx=False)
                     t_k, pi_k, ridx_k, _ = self._compress(t, sdf_ng, pi, fis, thre, tail=tail)
                     M_true = int(total_m.item())
+                lv = getattr(self, "_live", None)
+                Rl = int(lv["n"]) if lv is not None else R          # rays that got coarse / fine samples
+                per_live = int(qp.get("num_coarse", 64)) + sum(fine_list(qp))
                 if M_true is None:
-                    M_true = int(sdf_ng.shape[0]) - R * (int(qp.get("num_coarse", 64)) + sum(fine_list(qp)))
+                    M_true = int(sdf_ng.shape[0]) - Rl * per_live
                 self._march_stat = (R, M_true)
-                if _lib.TIMER is not None and cap is not None:    # the first query's true size, now that it is known
-                    S0 = M_true + R * int(qp.get("num_coarse", 64))
-                    _lib.TIMER.note_units("nsim_field_sdf", S0)
-                    if not self._sdf_fused:
-                        _lib.TIMER.note_units("nsim_lotd_gather_lm", S0)
+                self._last_S_q = M_true + Rl * per_live
+                if _lib.TIMER is not None and cap is not None:    # the queries' true sizes, now that they are known
+                    sizes = [M_true + Rl * int(qp.get("num_coarse", 64))]
+                    if lv is not None:      # (the draws of a marched-only pass take their point counts from the device, too)
+                        sizes += [Rl * int(n) for n in fine_list(qp)]
+                    for S0 in sizes:
+                        _lib.TIMER.note_units("nsim_field_sdf", S0)
+                        if not self._sdf_fused:
+                            _lib.TIMER.note_units("nsim_lotd_gather_lm", S0)
                 t, pi, ridx = t_k, pi_k, ridx_k
         self.accel.collect_armed = False         # one sampling pass per arming (evaluation renders never collect)
         return o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis
@@ -1443,7 +1509,16 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         if not qp.get("nablas_has_grad", True):
             nablas = nablas.detach()
         alpha = _NeusAlphaFn.apply(sdf, self._ln_inv_s_eff(), pi, self.ln_inv_s_factor, fis)
-        vb = dict(type="packed", rays_inds_hit=ray_tested["rays_inds"], pack_infos_hit=pi, t=t, opacity_alpha=alpha,
+        # ``upsample_on_marched_only``: the buffer lists the rays that produced samples -- the [R'] hit set of the reference's
+        # buffers (single_volume_renderer.py:209-220,289-300); rays whose march found nothing are not in it.  (Per-sample
+        # arrays are untouched: the dropped rows are empty packs.)  ``self._rays_sel``: the rows kept, for per-ray side arrays
+        rays_inds_hit, pi_hit = ray_tested["rays_inds"], pi
+        self._rays_sel = None
+        lv = getattr(self, "_live", None)
+        if lv is not None and lv.get("n") is not None and int(lv["n"]) < R:
+            self._rays_sel = lv["idx"][:int(lv["n"])]
+            rays_inds_hit, pi_hit = rays_inds_hit[self._rays_sel], pi[self._rays_sel]
+        vb = dict(type="packed", rays_inds_hit=rays_inds_hit, pack_infos_hit=pi_hit, t=t, opacity_alpha=alpha,
                   nablas=nablas, sdf=sdf)
         if with_rgb:
             vb["rgb"] = rgb

@@ -394,7 +394,11 @@ class RenderTrainer:
         if _lib.TIMER is not None:
             for k in ("nsim_field_fwd", "nsim_field_bwd_sdf", "nsim_lotd_scatter", "nsim_field_bwd_rad"):
                 _lib.TIMER.note_units(k, St)
-        self.stats = dict(R_hit=R, S_f=S)
+        # R_hit: rays that passed the AABB test; R_live: those whose occupancy march found something (the rays that get
+        # coarse / fine samples under ``upsample_on_marched_only``); S_q: SDF-only queries of the sampling pass; S_f: with-grad samples
+        lv = getattr(model, "_live", None)
+        self.stats = dict(R_hit=R, R_live=int(lv["n"]) if (lv is not None and lv.get("n") is not None) else R, S_f=S,
+                          S_q=int(getattr(model, "_last_S_q", 0) or 0))
         return torch.dot(acc, w_vec)
 
     def _dp_reduce_step(self, dgrid: torch.Tensor, scatter=None):
@@ -653,8 +657,9 @@ class RenderTrainer:
                 self.pose_optim.zero_grad(set_to_none=True)
             loss.backward()
             vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
-            self.stats = dict(R_hit=int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0,
-                              S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0)
+            n_hit = int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0
+            self.stats = dict(R_hit=int(getattr(model, "_last_R_tested", n_hit)) if n_hit else 0, R_live=n_hit, S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0,
+                              S_q=int(getattr(model, "_last_S_q", 0) or 0))
         if not self._step_done and self.world_size > 1 and self.overlap_allreduce and self._fused_ok():
             # this rank fell back to the autograd path (nothing hit): same collective sequence as its peers
             gp = model.encoding.flattened_params

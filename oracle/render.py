@@ -296,10 +296,18 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
               near=0.01, far=None, num_coarse=64, num_fine=(8, 8, 32), upsample_inv_s=64.0,
               upsample_inv_s_factors=(1, 4, 16), step_size=0.005, max_steps=4096,
               use_estimate_alpha=True, jitter=None, jitter_c=None, forward_inv_s=None,
-              depth_use_normalized_vw=False, sdf_fn=None, compress=False, compress_thre=1e-4) -> Dict:
+              depth_use_normalized_vw=False, sdf_fn=None, compress=False, compress_thre=1e-4,
+              upsample_on_marched_only=True) -> Dict:
     """``query_mode = march_occ_multi_upsample`` on N rays (already in object space, AABB-normalised).
     Returns the volume buffer + per-hit-ray renderings.  ``jitter`` [N] / ``jitter_c`` [N,C] carry the
-    perturbation randoms so that the HIP path can consume the identical numbers."""
+    perturbation randoms so that the HIP path can consume the identical numbers.
+
+    ``upsample_on_marched_only`` (``ray_query_cfg.query_param``; default True): coarse depths and the up-sampling stages run
+    on the rays whose occupancy march found occupied voxels only; the volume buffer lists those rays -- ``rays_inds_hit`` /
+    ``pack_infos_hit`` are the [R'] subset of the R AABB-tested rays that the reference's buffers carry
+    (single_volume_renderer.py:209-220,289-300: the renderer scatters ``rays_inds_hit`` rows into images of all rays; an
+    object whose march found nothing returns ``type: 'empty'``).  ``rendered`` / ``debug`` stay per TESTED ray (rows of
+    rays without samples are empty packs).  False: every tested ray gets num_coarse + sum(num_fine) samples (rounds 1-4)."""
     N = rays_o.shape[0]
     res_t = torch.tensor(res, dtype=torch.long)
     scale = res_t.float() / (aabb_max - aabb_min)
@@ -314,24 +322,47 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
     jit = jitter[rays_inds] if jitter is not None else torch.full((R,), 0.5)
     jc = jitter_c[rays_inds] if jitter_c is not None else None
     query_sdf = sdf_fn if sdf_fn is not None else (lambda x: forward_sdf(x, p))
+    def sample(o_, d_, nr_, fr_, jc_, t_m_, cnt_m_):
+        """coarse depths + up-sampling stages of the given rays (their marched depths t_m_ packed by cnt_m_)"""
+        R_ = o_.shape[0]
+        pi_m_ = po.get_pack_infos_from_n(cnt_m_)
+        t_c = coarse_depths(nr_, fr_, num_coarse, jc_)
+        t_, pi_, _, _ = merge_sorted(t_m_, pi_m_, t_c)
+        ridx_ = po.pack_ridx(pi_, t_.shape[0])
+        sdf_ = query_sdf(o_[ridx_] + t_[:, None] * d_[ridx_])
+        for nf, fac in zip(num_fine, upsample_inv_s_factors):
+            t_new = upsample_stage(t_, sdf_, pi_, upsample_inv_s * fac, nf, use_estimate_alpha)
+            ridx_new = torch.arange(R_).repeat_interleave(nf)
+            sdf_new = query_sdf(o_[ridx_new] + t_new.reshape(-1, 1) * d_[ridx_new])
+            t_old, sdf_old = t_, sdf_
+            t_, pi_, pa, pb = merge_sorted(t_old, pi_, t_new)
+            sdf_ = torch.empty_like(t_)
+            sdf_[pa] = sdf_old
+            sdf_[pb.reshape(-1)] = sdf_new
+        return t_, sdf_, pi_
+
+    live = torch.ones(R, dtype=torch.bool)
     with torch.no_grad():
         t_m, ridx_m, cnt_m = march_lattice(o, d, nr, fr, jit, occ, aabb_min, scale, res_t, step_size, max_steps)
-        pi_m = po.get_pack_infos_from_n(cnt_m)
-        t_c = coarse_depths(nr, fr, num_coarse, jc)
-        t, pi, _, _ = merge_sorted(t_m, pi_m, t_c)
+        if upsample_on_marched_only:
+            # the rays whose march found something, sampled on their own; rays are independent, so this IS the dense pass
+            # restricted to them.  Pack infos go back to all R tested rays (the others: empty packs)
+            live = cnt_m > 0
+            if bool(live.any()):
+                t, sdf, pi_l = sample(o[live], d[live], nr[live], fr[live], jc[live] if jc is not None else None, t_m, cnt_m[live])
+                cnt_all = torch.zeros(R, dtype=torch.long)
+                cnt_all[live] = pi_l[:, 1]
+                pi = po.get_pack_infos_from_n(cnt_all)
+            else:
+                t, sdf, pi = torch.zeros(0), torch.zeros(0), po.get_pack_infos_from_n(torch.zeros(R, dtype=torch.long))
+        else:
+            t, sdf, pi = sample(o, d, nr, fr, jc, t_m, cnt_m)
         ridx = po.pack_ridx(pi, t.shape[0])
-        sdf = query_sdf(o[ridx] + t[:, None] * d[ridx])
-        for nf, fac in zip(num_fine, upsample_inv_s_factors):
-            t_new = upsample_stage(t, sdf, pi, upsample_inv_s * fac, nf, use_estimate_alpha)
-            ridx_new = torch.arange(R).repeat_interleave(nf)
-            sdf_new = query_sdf(o[ridx_new] + t_new.reshape(-1, 1) * d[ridx_new])
-            t_old, sdf_old = t, sdf
-            t, pi, pa, pb = merge_sorted(t_old, pi, t_new)
-            sdf = torch.empty_like(t)
-            sdf[pa] = sdf_old
-            sdf[pb.reshape(-1)] = sdf_new
-            ridx = po.pack_ridx(pi, t.shape[0])
-    ret['debug'] = dict(t=t, sdf_nograd=sdf, pack_infos=pi, march_counts=cnt_m, ridx=ridx, x_nograd=o[ridx] + t[:, None] * d[ridx])
+    ret['debug'] = dict(t=t, sdf_nograd=sdf, pack_infos=pi, march_counts=cnt_m, ridx=ridx, x_nograd=o[ridx] + t[:, None] * d[ridx],
+                        live=live)
+    if t.shape[0] == 0:
+        ret['volume_buffer'] = dict(type='empty')
+        return ret
     if compress:
         # ``march_occ_multi_upsample_compressed``: keep the samples that bound an interval with vw > thre
         with torch.no_grad():
@@ -351,9 +382,10 @@ def ray_query(p: FieldParams, rays_o, rays_d, h_appear, occ, aabb_min, aabb_max,
     sdf_g, nablas, rgb = forward_field(x, v, ha, p, x_has_grad=x.requires_grad)   # rays with grad: pose refinement
     inv_s = p.inv_s() if forward_inv_s is None else torch.as_tensor(float(forward_inv_s))
     alpha = neus_alpha_packed(sdf_g, pi, inv_s)
-    ret['volume_buffer'] = dict(type='packed', rays_inds_hit=rays_inds, pack_infos_hit=pi, t=t,
+    ret['volume_buffer'] = dict(type='packed', rays_inds_hit=rays_inds[live], pack_infos_hit=pi[live], t=t,
                                 opacity_alpha=alpha, rgb=rgb, nablas=nablas, sdf=sdf_g, net_x=x)
-    ret['rendered'] = volume_integration(alpha, t, rgb, nablas, pi, depth_use_normalized_vw)
+    ret['rendered'] = volume_integration(alpha, t, rgb, nablas, pi, depth_use_normalized_vw)       # per TESTED ray
+    ret['pack_infos_tested'] = pi           # the final sample set packed per TESTED ray (rows of rays without samples: n = 0)
     ret['near'], ret['far'] = nr, fr
     return ret
 

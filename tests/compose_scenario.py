@@ -34,13 +34,13 @@ def build(device):
         sky.w.copy_(torch.cat([w.reshape(-1) for w in ws]).to(device))
         sky.b.copy_(torch.cat(bs).to(device))
     dv = lambda a: a.to(device).contiguous()         # noqa: E731
-    intr, c2w, WH = look_at_cameras(V=2, seed=4, H=14, W=14, f=9.0)
+    intr, c2w, WH = look_at_cameras(V=2, seed=4, H=14, W=14, f=20.0)
     eye, fwd = c2w[0, :3, 3], c2w[0, :3, 2]
     # car2 and car0 sit one behind the other on the optical axis of camera 0: the central rays cross BOTH items, i.e.
     # the batched buffer holds two consecutive packs for those rays
-    poses = {"car2": (_rot_y(0.6), eye + 2.0 * fwd, 0.3),
+    poses = {"car2": (_rot_y(0.6), eye + 2.0 * fwd, 0.55),
              "car1": (_rot_y(0.2), torch.tensor([0.0, 40.0, 0.0]), 0.4),          # far outside every ray: never hit
-             "car0": (_rot_y(-0.9), eye + 3.2 * fwd, 0.45)}
+             "car0": (_rot_y(-0.9), eye + 3.4 * fwd, 1.0)}
     poses = {k: (dv(R), dv(t), s) for k, (R, t, s) in poses.items()}
     o, d = orr.pinhole_rays(all_pixel_xy(14, 14, torch.device("cpu")), torch.zeros(196, dtype=torch.long), intr, c2w, WH)
     N = o.shape[0]

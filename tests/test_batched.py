@@ -95,8 +95,17 @@ def test_batched_query_matches_per_instance_oracle(backend, compressed):
     assert bool((bt["rays_inds"][1:] >= bt["rays_inds"][:-1]).all())
     assert torch.equal(bt["full_bidx_map"].cpu(), torch.arange(len(cond))) and torch.equal(bt["rays_bidx"], bt["rays_full_bidx"])
     assert torch.equal(ret["details"]["march_counts"].cpu(), torch.cat([r["debug"]["march_counts"] for r in outs])[perm])
-    n_o = torch.cat([r["volume_buffer"]["pack_infos_hit"][:, 1] for r in outs])
-    assert torch.equal(vb["pack_infos_hit"][:, 1].cpu(), n_o[perm])
+    # per TESTED pair sample counts of the oracle; the buffers list the pairs whose march found something
+    # (``upsample_on_marched_only``): rows ``live`` of the tested pairs, on both sides
+    n_o = torch.cat([(r["debug"]["compress_counts"] if compressed else r["debug"]["pack_infos"][:, 1]) for r in outs])
+    live = torch.cat([r["debug"]["live"] for r in outs])[perm]
+    assert 0 < int(live.sum()) < bt["num_rays"]
+    assert torch.equal(vb["pack_infos_hit"][:, 1].cpu(), n_o[perm][live])
+    assert torch.equal(vb["rays_inds_hit"].cpu(), bt["rays_inds"].cpu()[live])
+    assert torch.equal(vb["rays_bidx_hit"].cpu(), bt["rays_bidx"].cpu()[live])
+    assert torch.equal(vb["rays_full_bidx_hit"].cpu(), bt["rays_full_bidx"].cpu()[live])
+    assert torch.equal(vb["rays_inds_hit"].cpu(), torch.cat([r["volume_buffer"]["rays_inds_hit"] for r in outs])[
+        torch.argsort(torch.cat([r["volume_buffer"]["rays_inds_hit"] * len(cond) + k for k, r in enumerate(outs)]))])
     pi_o = opo_get(n_o)
     samp = torch.cat([torch.arange(int(pi_o[k, 0]), int(pi_o[k, 0] + pi_o[k, 1])) for k in perm.tolist()])   # sample permutation
     assert (vb["t"].cpu() - torch.cat([r["volume_buffer"]["t"] for r in outs])[samp]).abs().max() < 3e-4   # f32 up-sampler noise (1e-7 sdf x inv_s 1024)

@@ -28,7 +28,7 @@ def test_compose_single_plus_batched(backend):
     cfg = dict(query_mode="march_occ_multi_upsample", query_param=QP)
     main.ray_query_cfg = dict(cfg)
     mb.ray_query_cfg = dict(cfg)
-    poses = {"car2": (_rot_y(0.6), torch.tensor([0.9, 0.1, 0.3]), 0.45),
+    poses = {"car2": (_rot_y(0.6), torch.tensor([0.9, 0.1, 0.3]), 0.7),
              "car0": (_rot_y(-0.9), torch.tensor([-0.8, -0.1, 0.5]), 0.4)}
     drawables = [Drawable("main", "Main", main)] + \
         [Drawable(k, "Vehicle", mb, rotation=R, translation=t, scale=s) for k, (R, t, s) in poses.items()]
@@ -48,18 +48,18 @@ def test_compose_single_plus_batched(backend):
     bufs = []
     r = orr.ray_query(pm, o, d, ha, occ_m, AABB[0], AABB[1], RES, **kw)
     vb = r["volume_buffer"]
-    bufs.append(dict(rays_inds=r["rays_inds"], pack_infos=vb["pack_infos_hit"], t=vb["t"], alpha=vb["opacity_alpha"],
+    bufs.append(dict(rays_inds=vb["rays_inds_hit"], pack_infos=vb["pack_infos_hit"], t=vb["t"], alpha=vb["opacity_alpha"],
                      rgb=vb["rgb"]))
     n_vehicle = 0
     for k, (R, t, s) in poses.items():
         ins = int(k[-1])
         oo, dd = orr.convert_rays_in_node(o, d, R, t, s)
         r = orr.ray_query(ps[ins], oo, dd, ha, occs[ins], AABB[0], AABB[1], RES, **kw)
-        if r["num_rays"] == 0:
+        if r["num_rays"] == 0 or r["volume_buffer"]["type"] == "empty":
             continue
         vb = r["volume_buffer"]
         n_vehicle += int(vb["pack_infos_hit"][:, 1].sum())
-        bufs.append(dict(rays_inds=r["rays_inds"], pack_infos=vb["pack_infos_hit"], t=vb["t"], alpha=vb["opacity_alpha"],
+        bufs.append(dict(rays_inds=vb["rays_inds_hit"], pack_infos=vb["pack_infos_hit"], t=vb["t"], alpha=vb["opacity_alpha"],
                          rgb=vb["rgb"]))
     assert n_vehicle > 0 and len(bufs) == 3                   # both vehicles are in view
     mask_o, depth_o, rgb_o, cnt_o = orr.compose_buffers(bufs, N, True)

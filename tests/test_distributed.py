@@ -133,7 +133,7 @@ def _bench_worker(rank, world, port, out_dir, overlap="1", wire="f32", algo=None
                              accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
                                             update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
                              ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(dev)
-        m.geometric_init_sphere(0.5, num_iters=15, num_pts=1024, lr=5e-3)
+        m.geometric_init_sphere(0.5, num_iters=60, num_pts=1024, lr=5e-3)
         m.accel.init(m.query_sdf, num_steps=1, num_pts=2048)
     else:
         m = _tiny(dev, seed=42 + rank)                    # replicas differ until broadcast

@@ -115,7 +115,7 @@ def _discrete_leg(m, p, occ, r, near, far, rec, dev):
     with torch.no_grad():
         _o, _d, t, pi, ridx, sdf_ng, mc, _g, _f = m._query_samples(tested, cfg, dict(cfg["query_param"]))
     assert torch.equal(mc.cpu(), ret_o["debug"]["march_counts"])
-    n_p, n_o = pi[:, 1].cpu(), ret_o["volume_buffer"]["pack_infos_hit"][:, 1]
+    n_p, n_o = pi[:, 1].cpu(), ret_o["pack_infos_tested"][:, 1]
     rec.update(rays=int(r["o"].shape[0]), hit=int(ri.shape[0]), marched=int(mc.sum()), sdf_queries=int(sdf_ng.shape[0]),
                kept=int(n_p.sum()), kept_oracle=int(n_o.sum()), rays_with_other_count=int((n_p != n_o).sum()))
     return ret_o
@@ -177,7 +177,7 @@ def test_street_config_matches_oracle(backend, precision):
                       bypass_ray_query_cfg=dict(_jitter=dv(r["jit"][ri]), _jitter_c=dv(r["jit_c"][ri]), _jitter_dv=dv(r["jit_dv"])))
     rp = out["rendered"]
     vb = out["raw_per_obj_model"]["main"]["volume_buffer"]
-    assert torch.equal(vb["rays_inds_hit"].cpu(), ri)
+    assert torch.equal(vb["rays_inds_hit"].cpu(), sc_o["cr"]["volume_buffer"]["rays_inds_hit"])
     n_p, n_o = vb["pack_infos_hit"][:, 1].cpu(), sc_o["cr"]["volume_buffer"]["pack_infos_hit"][:, 1]
     rec["grad_leg_rays_with_other_count"] = int((n_p != n_o).sum())
     assert torch.equal(out["raw_per_obj_model"]["distant"]["volume_buffer"]["valid"].cpu().bool(), sc_o["dv"]["valid"])
@@ -344,7 +344,7 @@ def test_multi_object_config_matches_oracle(backend, precision):
     ret_s = orr.ray_query(p_s, r["o"], r["d"], ha_o, occ_s, a_s[0], a_s[1], street.accel.resolution, near=0.1, far=200.0,
                           depth_use_normalized_vw=False, **_qkw(street, rs))
     vbs = ret_s["volume_buffer"]
-    bufs = [dict(rays_inds=ret_s["rays_inds"], pack_infos=vbs["pack_infos_hit"], t=vbs["t"], alpha=vbs["opacity_alpha"],
+    bufs = [dict(rays_inds=vbs["rays_inds_hit"], pack_infos=vbs["pack_infos_hit"], t=vbs["t"], alpha=vbs["opacity_alpha"],
                  rgb=vbs["rgb"])]
     eik_terms = [((vbs["nablas"].norm(dim=-1) - 1.0) ** 2)]
     hit_items = 0
@@ -357,7 +357,7 @@ def test_multi_object_config_matches_oracle(backend, precision):
             continue
         hit_items += 1
         vbb = rb["volume_buffer"]
-        bufs.append(dict(rays_inds=rb["rays_inds"], pack_infos=vbb["pack_infos_hit"], t=vbb["t"], alpha=vbb["opacity_alpha"],
+        bufs.append(dict(rays_inds=vbb["rays_inds_hit"], pack_infos=vbb["pack_infos_hit"], t=vbb["t"], alpha=vbb["opacity_alpha"],
                          rgb=vbb["rgb"]))
         eik_terms.append((vbb["nablas"].norm(dim=-1) - 1.0) ** 2)
     assert hit_items == B                                     # every vehicle is in view of the aimed rays

@@ -235,8 +235,8 @@ def _api_path_body(precision, compressed, encoding):
     _zero_grads(tr)
     ha_p2 = leaf(ha[ri], dev)
     o_h, d_h = dv(o[ri]), dv(d[ri])
-    t_o, pi_o = dv(vbo["t"]), dv(vbo["pack_infos_hit"])
-    ridx_o = torch.repeat_interleave(torch.arange(ri.shape[0]), vbo["pack_infos_hit"][:, 1]).to(dev)
+    t_o, pi_o = dv(vbo["t"]), dv(ret_o["pack_infos_tested"])          # packed per TESTED ray (the buffer lists the marched rays)
+    ridx_o = torch.repeat_interleave(torch.arange(ri.shape[0]), ret_o["pack_infos_tested"][:, 1]).to(dev)
     sdf, nab, rgb = _FieldFn.apply(m, m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, ha_p2, None, o_h,
                                    d_h, t_o, ridx_o, True)
     alpha = _NeusAlphaFn.apply(sdf, m.ln_inv_s, pi_o, m.ln_inv_s_factor, 0.0)

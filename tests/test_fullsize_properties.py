@@ -40,11 +40,16 @@ def test_sampler_invariants_full_size(setup):
     R = tested["num_rays"]
     assert R > 0.9 * 8192
     n = pi[:, 1]
-    # packs tile the buffer, every hit ray got num_coarse + sum(num_fine) + marched samples
+    # the buffer lists the rays whose occupancy march found something (upsample_on_marched_only, the default): those and
+    # only those got num_coarse + sum(num_fine) + marched samples; packs tile the buffer
+    mc = ret["details"]["march_counts"]
+    live = mc > 0
+    assert torch.equal(vb["rays_inds_hit"], tested["rays_inds"][live]) and 0.3 * R < int(live.sum()) < 0.7 * R
     assert int(pi[0, 0]) == 0 and torch.equal(pi[1:, 0], torch.cumsum(n, 0)[:-1]) and int(n.sum()) == t.shape[0]
-    assert torch.equal(n, ret["details"]["march_counts"] + 64 + 48)
-    ridx = ret["details"]["ridx"]
-    assert torch.equal(ridx, torch.repeat_interleave(torch.arange(R, device=t.device), n))
+    assert torch.equal(n, mc[live] + 64 + 48)
+    ridx = ret["details"]["ridx"]                 # rows of the TESTED rays
+    n_all = torch.zeros(R, dtype=n.dtype, device=n.device).index_put((live.nonzero()[:, 0],), n)
+    assert torch.equal(ridx, torch.repeat_interleave(torch.arange(R, device=t.device), n_all))
     # ascending depths inside every ray, inside [near, far]
     same = ridx[1:] == ridx[:-1]
     assert bool(((t[1:] >= t[:-1]) | ~same).all())

@@ -292,7 +292,7 @@ def test_training_steps_on_the_permuto_model(backend):
                          accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
                                         update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
                          ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(backend)
-    m.geometric_init_sphere(0.5, num_iters=25, num_pts=1024, lr=5e-3)
+    m.geometric_init_sphere(0.5, num_iters=60, num_pts=1024, lr=5e-3)
     m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
     intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
     tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, target_sphere_radius=0.5)
@@ -341,7 +341,7 @@ def test_fused_step_equals_autograd_step_on_the_permuto_model(backend):
     # fields on hardware (the two legs started from different tables).  Both legs load the same snapshot.
     torch.manual_seed(0)
     m0 = build()
-    m0.geometric_init_sphere(0.5, num_iters=20, num_pts=1536, lr=5e-3)
+    m0.geometric_init_sphere(0.5, num_iters=60, num_pts=1536, lr=5e-3)
     snapshot = {k: v.detach().clone() for k, v in m0.state_dict().items()}
     del m0
     outs = []

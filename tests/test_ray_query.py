@@ -143,7 +143,25 @@ def test_ray_query_empty_and_no_perturb(backend):
     # reference-style integration from the returned volume buffer (single_volume_renderer.py:73-102)
     vb = ret["volume_buffer"]
     again = volume_integration(vb["opacity_alpha"], vb["t"], vb["rgb"], None, vb["pack_infos_hit"], True)
-    assert torch.allclose(again["rgb_volume"], ret["rendered"]["rgb_volume"])
+    # ``rendered`` is per TESTED ray; the buffer lists the rays that produced samples (upsample_on_marched_only): a subset here
+    assert vb["rays_inds_hit"].shape[0] < tested["num_rays"] and vb["pack_infos_hit"].shape[0] == vb["rays_inds_hit"].shape[0]
+    assert bool((vb["pack_infos_hit"][:, 1] > 0).all())
+    full = torch.zeros(o.shape[0], 3, device=backend)
+    assert torch.allclose(full.index_put((vb["rays_inds_hit"],), again["rgb_volume"]),
+                          full.index_put((tested["rays_inds"],), ret["rendered"]["rgb_volume"]))
+    assert torch.equal(vb["rays_inds_hit"].cpu(), ret_o["volume_buffer"]["rays_inds_hit"])
+    assert torch.equal(vb["pack_infos_hit"].cpu(), ret_o["volume_buffer"]["pack_infos_hit"])
+    # ``upsample_on_marched_only: false`` (rounds 1-4): every AABB-tested ray gets coarse + fine samples and is in the buffer
+    qp_all = dict(QP, upsample_on_marched_only=False)
+    ret_a = model.ray_query(ray_tested=tested, config=dict(query_param=qp_all, with_rgb=True, _render=True,
+                                                           depth_use_normalized_vw=True, query_mode="march_occ_multi_upsample"))
+    ret_ao = orr.ray_query(p, o, d, None, occ, AABB[0], AABB[1], RES, num_coarse=16, num_fine=(4, 4, 8), step_size=0.02,
+                           max_steps=512, depth_use_normalized_vw=True, upsample_on_marched_only=False)
+    vba = ret_a["volume_buffer"]
+    assert vba["rays_inds_hit"].shape[0] == tested["num_rays"] and torch.equal(vba["pack_infos_hit"].cpu(), ret_ao["volume_buffer"]["pack_infos_hit"])
+    assert int(vba["t"].shape[0]) > int(vb["t"].shape[0])
+    for k in ("mask_volume", "depth_volume", "rgb_volume"):
+        assert (ret_a["rendered"][k].cpu() - ret_ao["rendered"][k]).abs().max() < 2e-4, k
 
 
 def test_extra_points_ride_on_the_render_launches(backend):

@@ -130,7 +130,9 @@ def test_reference_wrappers_life_cycle_and_model_side_losses(backend):
         raw = ret["raw_per_obj_model"]["main"]
         assert raw["class_name"] == "Main" and raw["volume_buffer"]["type"] == "packed"
         near_sdf = raw["details"]["near_sdf"]
-        assert near_sdf.shape == (raw["volume_buffer"]["rays_inds_hit"].shape[0],) and near_sdf.requires_grad
+        # one value per ray that passed the model's ray_test (the buffer lists the [R'] of them whose march found something)
+        assert near_sdf.shape == (48,) and near_sdf.requires_grad
+        assert 0 < raw["volume_buffer"]["rays_inds_hit"].shape[0] <= 48
         assert float(near_sdf.min()) > 0.5               # the rays enter the box far outside the radius-0.5 sphere
         raw["model_id"] = model.id
         scene.asset_bank = {model.id: model}
@@ -218,7 +220,7 @@ def test_reference_monocular_losses_on_an_image_patch(backend):
                       accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048)),
                       ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp), seed=6).to(dev)
     m.geometric_init_sphere(0.8)
-    m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
+    m.accel.init(m.query_sdf, num_steps=4, num_pts=2 ** 15)     # (32 queries per voxel: the wall is occupied wherever a ray ends)
     g = torch.Generator().manual_seed(3)
     H = W = 16
     d = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1).to(dev)

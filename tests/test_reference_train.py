@@ -217,10 +217,10 @@ MULTI_SMALL = [a for a in STREET_SMALL if "LearnableParams" not in a and "error_
     "--dataset_cfg.param.n_vehicles=3", "--scenebank_cfg.load_class_names=[Street,Vehicle]", "--veh_dtype=float", "--veh_n_levels=6",
     "--veh_log2_hashmap_size=11", f"--{V_}.surface_cfg.encoding_cfg.permuto_auto_compute_cfg.finest_res=24.0",
     f"--{V_}.surface_cfg.encoding_cfg.permuto_auto_compute_cfg.coarsest_res=2.0", f"--{V_}.accel_cfg.resolution=[8,8,8]",
-    f"--{V_}.accel_cfg.init_cfg.num_pts=2048", f"--{V_}.accel_cfg.init_cfg.num_steps=1", f"--{V_}.accel_cfg.update_from_net_cfg.num_pts=2048",
+    f"--{V_}.accel_cfg.init_cfg.num_pts=8192", f"--{V_}.accel_cfg.init_cfg.num_steps=2", f"--{V_}.accel_cfg.update_from_net_cfg.num_pts=2048",
     f"--{V_}.accel_cfg.update_from_net_cfg.num_steps=1", f"--{V_}.ray_query_cfg.query_param.num_coarse=8",
     f"--{V_}.ray_query_cfg.query_param.num_fine=8", f"--{V_}.ray_query_cfg.query_param.march_cfg.max_steps=64",
-    f"--{V_}.ray_query_cfg.query_param.march_cfg.step_size=0.1", "--assetbank_cfg.Vehicle.asset_params.initialize_cfg.num_iters=30",
+    f"--{V_}.ray_query_cfg.query_param.march_cfg.step_size=0.1", "--assetbank_cfg.Vehicle.asset_params.initialize_cfg.num_iters=100",
     "--assetbank_cfg.Vehicle.asset_params.initialize_cfg.num_points=1024", "--assetbank_cfg.Vehicle.asset_params.initialize_cfg.batch_size=3",
 ]
 

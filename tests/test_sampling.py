@@ -244,7 +244,7 @@ def test_coarse_upsample_merge(backend):
     for j in (None, jc):
         out = torch.zeros(R, C, device=backend)
         _lib.call("nsim_coarse_depths", _lib.ptr(dv(near)), _lib.ptr(dv(far)), _lib.ptr(dv(j)) if j is not None else None,
-                  R, C, _lib.ptr(out))
+                  R, C, _lib.ptr(out), None)
         assert torch.equal(out.cpu(), orr.coarse_depths(near, far, C, j))
     # ragged packs incl. > 64 samples; sdf of a sphere crossing
     n = torch.randint(2, 200, (R,), generator=g)
@@ -266,7 +266,7 @@ def test_coarse_upsample_merge(backend):
             x_new = torch.zeros(R, nf, 3, device=backend)
             _lib.call("nsim_upsample_stage", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, inv_s, nf,
                       1 if use_est else 0, _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)),
-                      _lib.ptr(x_new))
+                      _lib.ptr(x_new), None)
             assert torch.allclose(t_new.cpu(), ref, atol=2e-5), (use_est, inv_s, nf, (t_new.cpu() - ref).abs().max())
             assert torch.equal(x_new.cpu(), ro[:, None, :] + t_new.cpu()[..., None] * rd[:, None, :])   # bit-exact o + t d
             assert (t_new.cpu()[:, 1:] >= t_new.cpu()[:, :-1]).all()
@@ -284,7 +284,7 @@ def test_coarse_upsample_merge(backend):
     x_out = torch.zeros(S + R * nf, 3, device=backend)
     _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
               R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), _lib.ptr(dv(ro)),
-              _lib.ptr(dv(rd)), _lib.ptr(x_out))
+              _lib.ptr(dv(rd)), _lib.ptr(x_out), None)
     assert torch.equal(x_out.cpu(), ro[ridx_out.cpu()] + t_out.cpu()[:, None] * rd[ridx_out.cpu()])
     assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
     assert torch.equal(ridx_out.cpu(), opo.pack_ridx(pi_ref, t_ref.shape[0]))
@@ -365,7 +365,7 @@ def test_occupancy_collects_the_sampling_pass(backend):
     want = orr.occ_collect(val0, ret_o["debug"]["x_nograd"], ret_o["debug"]["sdf_nograd"], aabb[0],
                            res_t.float() / (aabb[1] - aabb[0]), res_t)
     got = model.accel.occ_val.cpu()
-    assert float((want > val0).float().mean()) > 0.02           # the pass did raise values
+    assert float((want > val0).float().mean()) > 0.01           # the pass did raise values (samples on the marched rays only)
     # identical up to fine samples that sit within rounding of a voxel face (their positions differ by ~1e-6)
     assert float(((got - want).abs() > 1e-4).float().mean()) < 2e-3
     assert torch.equal(model.accel.occ_bits, bits0)              # thresholded only by the next refresh

@@ -53,7 +53,7 @@ def test_fuzz_merge_sorted(backend, n, nf, seed):
     x_out = torch.zeros(T, 3, device=backend)
     _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
               R, nf, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), _lib.ptr(dv(ro)),
-              _lib.ptr(dv(rd)), _lib.ptr(x_out))
+              _lib.ptr(dv(rd)), _lib.ptr(x_out), None)
     assert torch.equal(pi_out.cpu(), pi_ref) and torch.equal(t_out.cpu(), t_ref) and torch.equal(v_out.cpu(), v_ref)
     assert torch.equal(ridx_out.cpu(), opo.pack_ridx(pi_ref, T))
     assert torch.equal(x_out.cpu(), ro[ridx_out.cpu()] + t_out.cpu()[:, None] * rd[ridx_out.cpu()])
@@ -84,7 +84,7 @@ def test_fuzz_upsample_stage(backend, n, nf, inv_s, use_est, seed):
     t_new, scratch = torch.zeros(R, nf, device=backend), torch.zeros(S, device=backend)
     x_new = torch.zeros(R, nf, 3, device=backend)
     _lib.call("nsim_upsample_stage", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), R, inv_s, nf, int(use_est),
-              _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)), _lib.ptr(x_new))
+              _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)), _lib.ptr(x_new), None)
     tn = t_new.cpu()
     assert torch.isfinite(tn).all() and (tn[:, 1:] >= tn[:, :-1]).all()
     lo = t[pi[:, 0]][:, None]

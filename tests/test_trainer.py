@@ -31,7 +31,8 @@ def test_train_steps_reduce_loss(backend):
     losses = [float(tr.train_step(it)) for it in range(6)]
     assert all(l == l for l in losses)           # no NaN
     assert losses[-1] < losses[0], losses
-    assert tr.stats["R_hit"] > 0 and tr.stats["S_f"] >= tr.stats["R_hit"] * 16
+    assert 0 < tr.stats["R_live"] <= tr.stats["R_hit"] and tr.stats["S_f"] >= tr.stats["R_live"] * 16
+    assert tr.stats["S_q"] >= tr.stats["S_f"]
 
 
 def test_train_steps_with_a_distorted_camera(backend):
