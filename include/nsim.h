@@ -118,7 +118,8 @@ int nsim_alpha_to_vw_bwd(const float* alpha, const float* trans, const float* vw
  * app/loss/photometric.py:88-146, the eikonal term app/loss/eikonal.py:185-253 -- and autograd's backward of each): for the P
  * hit rays (packs ``pack_infos``, image row ``out_idx[p]`` or p) sdf -> alpha -> visibility weights -> mask / depth / rgb / normal
  * images; loss = mean((rgb image - gt)^2) over ALL N rays (rays outside the packs render black) + w_eikonal (mean over the S
- * render samples + mean over the M free points of (|nablas| - 1)^2); acc[0..2] += (mse, eikonal_render, eikonal_free); and the
+ * render samples + mean over the M free points of (|nablas| - 1)^2); acc[0..2] += (mse, eikonal_render, eikonal_free) -- the mse
+ * as a sum of squares only (e^2 of the pack rays + gt^2 of the others; out_idx must be ASCENDING: membership by search); and the
  * backward of all of it: dalpha [S], dsdf [S] (rows S.. are the caller's zeros), drgb [S,3], dnablas [S+M,3] (eikonal part
  * only), d_ln_inv_s += (may be NULL).  alpha / vw / trans [S] are written (the later backward launches read them). */
 int nsim_render_head(const float* sdf, const float* ln_inv_s, float ln_inv_s_factor, float forward_inv_s, const float* t,

@@ -1381,17 +1381,11 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #ifndef GLM_PTS
 #define GLM_PTS 4
 #endif
-// Points per lane by launch size (round 5): a small launch (the first two up-sampling draws: R' x 8 points = 30 k on the object
-// workload) at 4 points per lane is ~120 waves per XCD, each walking its levels in sequence -- latency, not requests.
-// One point per lane gives four times the waves.  NSIM_GLM_SMALL = capacity (points) up to which a launch uses 1 point per lane
-// (default 98 304), twice that: 2 points.
-static inline int glm_pts_for(int64_t S) {
-  static const int64_t small = getenv("NSIM_GLM_SMALL") ? atoll(getenv("NSIM_GLM_SMALL")) : 98304;
-  return S <= small ? 1 : (S <= 2 * small ? 2 : GLM_PTS);
-}
-template <int PREC, bool WJ, int GLM_PTS_T = GLM_PTS>
+template <int PREC, bool WJ>
 __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
-  constexpr int NP = GLM_PTS_T;                    // points per lane
+  // points per lane.  (Round 5: 1 / 2 points per lane for launches of <= 98 k / 196 k points -- four times the waves for the
+  // small up-sampling draws -- measured nothing: 0.0643-0.0658 against 0.0651-0.0666 ms per launch, profiles/round5_gather_ab.txt)
+  constexpr int NP = GLM_PTS;
   const int lane = nsim_lane();
   const int xcd = (int)(blockIdx.x & 7u);
   const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * NP) + lane;
@@ -1512,11 +1506,8 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 
 template <int PREC, bool WJ>
 static void launch_gather_lm(const FieldArgs& a, int64_t S, hipStream_t stream) {
-  const int pts = glm_pts_for(S);
-  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * pts)));
-  if (pts == 1) hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, 1>), gg, dim3(64), 0, stream, a);
-  else if (pts == 2) hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, 2>), gg, dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ, GLM_PTS>), gg, dim3(64), 0, stream, a);
+  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+  hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ>), gg, dim3(64), 0, stream, a);
 }
 
 // GL (PLANES only): the tile's plane image -- per level 32 points x (f16x2 | f32x2) = 128 B | 256 B, one aligned piece

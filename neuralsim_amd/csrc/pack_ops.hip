@@ -686,8 +686,8 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_neus_alpha_bwd(
 // k_composite_fwd<true>), forms that pixel's photometric-mse gradient, walks back through the compositing (k_composite_bwd)
 // and the sdf -> alpha map (k_neus_alpha_bwd); the samples of a ray are handed between the passes through the per-sample
 // buffers the backward kernels further down read anyway (alpha / vw / trans / dalpha), ordered by wave-level fences.  The
-// remaining workgroups of the SAME launch do the element-wise part of the loss head: sum gt^2 over all N rays (a ray that
-// hits nothing renders black: its residual is gt) and the eikonal terms on the S render samples and the M free points with
+// remaining workgroups of the SAME launch do the element-wise part of the loss head: sum gt^2 over the rays OUTSIDE the packs (a
+// ray that hits nothing renders black: its residual is gt) and the eikonal terms on the S render samples and the M free points with
 // their gradients.  acc[0] = mse, acc[1] = eikonal(render samples), acc[2] = eikonal(free points), as nsim_train_loss_head.
 struct RenderHeadArgs {
   const float *sdf, *ln_inv_s, *t, *rgb, *nab, *gt;
@@ -743,13 +743,15 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_render_head(RenderHeadArgs a) {
         ar[c] = wave_sum(ar[c]);
         an[c] = wave_sum(an[c]);
       }
-      // ---- this pixel's photometric term: (pred - gt)^2, minus the gt^2 the element-wise workgroups add for EVERY ray
+      // ---- this pixel's photometric term (pred - gt)^2; the element-wise workgroups add gt^2 for the rays OUTSIDE the packs
+      // (round 4 added gt^2 for every ray there and e^2 - g^2 here: two O(1) sums cancelling to an O(mse) result, ~1e-6 of
+      // order-dependent noise on the reported mse -- ADVICE r4)
       float gr[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float g = a.gt[q * 3 + c], e = ar[c] - g;
         gr[c] = inv_n * 2.0f * e;
-        if (lane == 0) r0 += e * e - g * g;
+        if (lane == 0) r0 += e * e;
       }
       if (lane == 0) {
         a.mask[q] = am;
@@ -826,8 +828,24 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_render_head(RenderHeadArgs a) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int64_t i = eb * PACK_BLOCK + threadIdx.x; i < top; i += neb * PACK_BLOCK) {
       if (i < n_img) {
-        const float g = a.gt[i];
-        a0 += g * g;
+        // a ray outside the packs renders black: its residual is gt.  Rows of the packs: out_idx [P] ASCENDING (the hit-ray
+        // compaction's order), or the first P rays
+        const int64_t ray = i / 3;
+        bool in_pack;
+        if (a.out_idx) {
+          int64_t lo = 0, hi = a.P;
+          while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.out_idx[mid] < ray) lo = mid + 1; else hi = mid;
+          }
+          in_pack = lo < a.P && a.out_idx[lo] == ray;
+        } else {
+          in_pack = ray < a.P;
+        }
+        if (!in_pack) {
+          const float g = a.gt[i];
+          a0 += g * g;
+        }
       }
       if (i < St) {
         const float x = a.nab[3 * i], y = a.nab[3 * i + 1], z = a.nab[3 * i + 2];

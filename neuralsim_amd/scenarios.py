@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import backward_on_calling_thread
 from .fields.neus import LoTDNeuSModel
 from .graphics.cameras import selected_rays
 from .grid_encodings.lotd import cuboid_ngp_res, gen_ngp_res
@@ -387,10 +388,12 @@ def vehicle_model(device, B: int = 8, precision: str = "fp16", seed: int = 42, s
     h = VEHICLE_BOUND / 2
     if small:
         res, l2, occ_res, npts = [3, 5, 8, 13, 21], 13, [16, 16, 16], 2 ** 11
-        qp = dict(num_coarse=8, num_fine=[4, 4], march_cfg=dict(step_size=0.05, max_steps=128))
+        qp = dict(num_coarse=8, num_fine=8, march_cfg=dict(step_size=0.05, max_steps=128))
     else:
         res, l2, occ_res, npts = [5, 8, 13, 21, 34, 55, 89, 144], 22, [32, 32, 32], 2 ** 16
-        qp = dict(num_coarse=32, num_fine=[8, 8], march_cfg=dict(step_size=0.005, max_steps=2048))
+        # ``num_fine: 8`` next to two factors -- the yaml's literal; ``fields.neus.fine_list`` reads a scalar as the TOTAL, dealt
+        # evenly to the stages ([4, 4]): ONE reading of the key for the shim path and for this workload (rounds 3-4 ran [8, 8] here)
+        qp = dict(num_coarse=32, num_fine=8, march_cfg=dict(step_size=0.005, max_steps=2048))
     qp.update(nablas_has_grad=True, upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4], upsample_use_estimate_alpha=True)
     vm = BatchedLoTDNeuSModel(B, ins_ids=[f"car{b}" for b in range(B)], lod_res=res, log2_hashmap_size=l2, sdf_D=2,
                               precision=precision, ln_inv_s_init=0.5, aabb=torch.tensor([[-h, -h, -h], [h, h, h]]),
@@ -479,7 +482,8 @@ class ComposeTrainer:
         ret = self.render(xy, fidx)
         loss, n_s = self.loss(ret, gt)
         self.optim.zero_grad()
-        loss.backward()
+        with backward_on_calling_thread():
+            loss.backward()
         if not self.skip_allreduce:
             ndist.allreduce_grads(self.optim.params(), average=False)
         self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)

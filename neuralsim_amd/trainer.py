@@ -13,7 +13,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, distributed as ndist
+from . import _lib, backward_on_calling_thread, distributed as ndist
 import os
 
 from .fields.neus import LoTDNeuSModel, volume_integration, append_extra_points, _flat_sizes
@@ -595,7 +595,8 @@ class RenderTrainer:
                 loss = loss + parts["eikonal_uniform"]
         self.optim.zero_grad()
         if loss.requires_grad:          # no beam hit anything and no distant model: nothing to differentiate on this rank
-            loss.backward()
+            with backward_on_calling_thread():
+                loss.backward()
         if not self.skip_allreduce:
             ndist.allreduce_grads(self.optim.params(), average=False, skip_absent=True)
         self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
@@ -655,7 +656,8 @@ class RenderTrainer:
             self.optim.zero_grad()
             if refine:
                 self.pose_optim.zero_grad(set_to_none=True)
-            loss.backward()
+            with backward_on_calling_thread():
+                loss.backward()
             vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
             n_hit = int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0
             self.stats = dict(R_hit=int(getattr(model, "_last_R_tested", n_hit)) if n_hit else 0, R_live=n_hit, S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0,

@@ -16,4 +16,4 @@ Names the reference imports for paths outside SURVEY sec. 8 (dynamic / time-cond
 as placeholders that raise on construction.
 """
 
-import neuralsim_amd  # noqa: F401,E402  (process-wide settings of the product package: see neuralsim_amd/__init__.py)
+import neuralsim_amd  # noqa: F401,E402

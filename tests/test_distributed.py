@@ -77,6 +77,18 @@ def _worker(rank, world, port, out_dir):
         ref = t.grad if t.grad is not None else torch.zeros_like(t)
         assert torch.allclose(ga, ref, atol=1e-6, rtol=1e-4), (rank, float((ga - ref).abs().max()))
         assert float((gb - ref).norm()) <= 8e-3 * float(ref.norm()) + 1e-9, (rank, "bf16 wire")
+    # ``skip_absent`` (the lidar step: ADVICE r4): a parameter without a gradient on EVERY rank stays without one (the optimizer
+    # then skips it, as torch.optim.Adam does); one that has a gradient on SOME rank is reduced on all, zeros from the others
+    a_, b_, c_ = (torch.nn.Parameter(torch.zeros(5)) for _ in range(3))
+    a_.grad = torch.full((5,), float(rank + 1))
+    b_.grad = torch.ones(5) if rank == 0 else None
+    c_.grad = None
+    nd.allreduce_grads([a_, b_, c_], average=False, skip_absent=True)
+    assert torch.equal(a_.grad, torch.full((5,), float(sum(range(1, world + 1))))) and torch.equal(b_.grad, torch.ones(5))
+    assert c_.grad is None
+    c_.grad = None
+    nd.allreduce_grads([a_, c_], average=False)               # default: zero-filled, takes part
+    assert c_.grad is not None and float(c_.grad.abs().max()) == 0.0
     dist.barrier()
     (Path(out_dir) / f"ok{rank}").write_text("ok")
     dist.destroy_process_group()

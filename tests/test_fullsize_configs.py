@@ -81,7 +81,8 @@ def _rays(intr, c2w, WH, N, seed, C, K=None):
 
 def _qkw(m, r, compress=True):
     qp = m.ray_query_cfg["query_param"]
-    return dict(num_coarse=qp["num_coarse"], num_fine=tuple(qp["num_fine"]), upsample_inv_s=qp["upsample_inv_s"],
+    from neuralsim_amd.fields.neus import fine_list
+    return dict(num_coarse=qp["num_coarse"], num_fine=tuple(fine_list(qp)), upsample_inv_s=qp["upsample_inv_s"],
                 upsample_inv_s_factors=tuple(qp["upsample_inv_s_factors"]), step_size=qp["march_cfg"]["step_size"],
                 max_steps=qp["march_cfg"]["max_steps"], use_estimate_alpha=qp["upsample_use_estimate_alpha"],
                 jitter=r["jit"], jitter_c=r["jit_c"], compress=compress, compress_thre=1e-4)

@@ -103,3 +103,37 @@ def test_adam_multi_equals_single_tensor_steps(backend):
     _lib.call("nsim_adam_multi", arr, len(sizes), lr, eps, gs, 0)
     for a, b in zip(p1 + m1 + v1, p2 + m2 + v2):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_group_without_gradient_is_skipped_and_keeps_its_own_step_count(backend):
+    """every group keeps its OWN step count, advanced only when the group is updated (``torch.optim.Adam``:
+    per-parameter ``state['step']``, parameters with ``grad is None`` skipped -- the lidar step of the street iteration
+    leaves the radiance / appearance parameters without a gradient, code_single/tools/train.py:1540-1590).  Five steps in
+    which the radiance weights have no gradient on steps 1 and 3: equal to ``torch.optim.Adam`` on the same gradients."""
+    from neuralsim_amd.optim import FusedAdam
+    from test_trainer import _tiny
+    torch.manual_seed(0)
+    m = _tiny(backend)
+    opt = FusedAdam(m, lr=1e-2, eps=1e-15)
+    ps = opt.params()
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    betas = [g["betas"] for g in opt.groups]
+    ropt = torch.optim.Adam([dict(params=[r], betas=b) for r, b in zip(ref, betas)], lr=1e-2, eps=1e-15)
+    rad = next(i for i, p in enumerate(ps) if p is m.rad_w)
+    g = torch.Generator().manual_seed(3)
+    for it in range(5):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i == rad and it in (1, 3):
+                p.grad, r.grad = None, None
+                continue
+            gr = torch.randn(p.shape, generator=g) * 1e-3
+            p.grad, r.grad = gr.to(backend), gr.clone()
+        before = m.rad_w.detach().clone()
+        opt.step()
+        ropt.step()
+        if it in (1, 3):
+            assert torch.equal(m.rad_w.detach(), before)          # no momentum-only update of a skipped group
+    t = [g_.get("t", 0) for g_ in opt.groups]
+    assert t[rad] == 3 and all(x == 5 for i, x in enumerate(t) if i != rad) and opt.t == 5
+    for p, r in zip(ps, ref):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) <= 2e-6 * (1e-2 + float(r.detach().abs().max()))

@@ -339,7 +339,7 @@ def test_render_head_equals_the_four_launches_it_replaces(backend, every_ray):
     def bufs():
         z = lambda *sh: torch.zeros(list(sh), **f32)          # noqa: E731
         e = lambda *sh: torch.empty(list(sh), **f32)          # noqa: E731
-        return dict(alpha=e(S), vw=e(S), trans=e(S), mask=z(N), depth=z(N), img=z(N, 3), nimg=z(N, 3), acc=z(3), dalpha=e(S),
+        return dict(alpha=e(S), vw=e(S), trans=e(S), mask=z(N), depth=z(N), img=z(N, 3), nimg=z(N, 3), acc=z(8), dalpha=e(S),
                     dsdf=z(St), drgb=z(St, 3), dnab=e(St, 3), dln=z(1))
     a = bufs()
     call("nsim_neus_composite_fwd", ptr(sdf), ptr(ln), factor, 0.0, ptr(t), ptr(rgb), ptr(nab), ptr(pi), R, nd, ptr(a["alpha"]),
@@ -356,6 +356,79 @@ def test_render_head_equals_the_four_launches_it_replaces(backend, every_ray):
     for k in ("alpha", "vw", "trans", "mask", "depth", "img", "nimg", "dalpha", "dsdf", "drgb", "dnab"):
         x, y = a[k].cpu(), b[k].cpu()
         assert torch.allclose(x, y, rtol=2e-5, atol=1e-7), (k, float((x - y).abs().max()))
-    assert torch.allclose(a["acc"].cpu(), b["acc"].cpu(), rtol=2e-5, atol=1e-7), (a["acc"], b["acc"])
+    assert torch.allclose(a["acc"].cpu()[:3], b["acc"].cpu()[:3], rtol=2e-5, atol=1e-7), (a["acc"], b["acc"])
     assert torch.allclose(a["dln"].cpu(), b["dln"].cpu(), rtol=1e-4, atol=1e-8), (a["dln"], b["dln"])
     assert float(b["acc"][0]) > 0 and float(b["acc"][1]) > 0 and float(b["acc"][2]) > 0
+
+
+@pytest.mark.parametrize("every_ray", [False, True])
+def test_render_head_against_the_oracle(backend, every_ray):
+    """``nsim_render_head`` against the ORACLE (the one-launch head had only been compared with the four
+    launches it replaces): oracle.render.neus_alpha_packed -> volume_integration (single_volume_renderer.py:73-102) -> photometric
+    mse over ALL N rays (app/loss/photometric.py:88-146) + w (eikonal on the S render samples + eikonal on the M free points,
+    app/loss/eikonal.py:216-251) evaluated in f64 with torch autograd: images, the three loss terms and every gradient the
+    kernel emits (d sdf, d rgb, d nablas, d ln_inv_s).  The predictions are close to the targets on most rays (a trained
+    state), where the mse is a difference of cancelling sums inside the kernel (f64 accumulator)."""
+    from neuralsim_amd import _lib
+    from oracle import pack_ops as opo, render as orr
+    g = torch.Generator().manual_seed(7)
+    N = 41
+    R = N if every_ray else 29
+    n = torch.randint(0, 140, (R,), generator=g)
+    n[2], n[5], n[6] = 0, 1, 2
+    S, M = int(n.sum()), 9
+    St = S + M
+    pi = opo.get_pack_infos_from_n(n)
+    ridx = opo.pack_ridx(pi, S)
+    # a surface crossing on every ray: sdf falls through zero along the pack
+    u = torch.cat([torch.linspace(0, 1, int(k)) if k > 0 else torch.zeros(0) for k in n])
+    t64 = (0.5 + u + 0.01 * torch.rand(S, generator=g)).double()
+    sdf64 = ((0.55 + 0.3 * torch.rand(R, generator=g)[ridx] - u) * 0.4 + 0.01 * torch.randn(S, generator=g)).double().requires_grad_(True)
+    rgb64 = torch.rand(S, 3, generator=g).double().requires_grad_(True)
+    nab64 = (torch.nn.functional.normalize(torch.randn(St, 3, generator=g), dim=-1) * (1 + 0.1 * torch.randn(St, 1, generator=g))).double().requires_grad_(True)
+    ln64 = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    factor, w_eik = 10.0, 0.1
+    out_idx = None if every_ray else torch.randperm(N, generator=g)[:R].sort().values
+    rows = torch.arange(N) if every_ray else out_idx
+    for nd in (0, 1):
+        for x in (sdf64, rgb64, nab64, ln64):
+            x.grad = None
+        inv_s = torch.exp(ln64 * factor)
+        alpha = orr.neus_alpha_packed(sdf64, pi, inv_s)
+        out = orr.volume_integration(alpha, t64, rgb64, nab64[:S], pi, depth_use_normalized_vw=bool(nd))
+        img = torch.zeros(N, 3, dtype=torch.float64).index_put((rows,), out["rgb_volume"])
+        # targets: the rendering itself + a small error on the hit rays (trained state), arbitrary colours elsewhere
+        gt = torch.rand(N, 3, generator=g).double()
+        gt[rows] = (out["rgb_volume"].detach() + 3e-3 * torch.randn(R, 3, generator=g).double()).clamp(0, 1)
+        mse = ((img - gt) ** 2).mean()
+        eik_r = ((nab64[:S].norm(dim=-1) - 1.0) ** 2).mean()
+        eik_f = ((nab64[S:].norm(dim=-1) - 1.0) ** 2).mean()
+        (mse + w_eik * (eik_r + eik_f)).backward()
+        dev = backend
+        f32 = dict(dtype=torch.float32, device=dev)
+        dv = lambda a: a.detach().float().to(dev).contiguous()          # noqa: E731
+        z = lambda *sh: torch.zeros(list(sh), **f32)          # noqa: E731
+        b = dict(alpha=z(S), vw=z(S), trans=z(S), mask=z(N), depth=z(N), img=z(N, 3), nimg=z(N, 3), acc=z(8), dalpha=z(S),
+                 dsdf=z(St), drgb=z(St, 3), dnab=z(St, 3), dln=z(1))
+        call, ptr = _lib.call, _lib.ptr
+        call("nsim_render_head", ptr(dv(sdf64)), ptr(dv(ln64)), factor, 0.0, ptr(dv(t64)), ptr(dv(rgb64)), ptr(dv(nab64)), ptr(pi.to(dev)),
+             R, nd, ptr(dv(gt)), N, S, M, w_eik, ptr(out_idx.to(dev) if out_idx is not None else None), ptr(b["alpha"]), ptr(b["vw"]),
+             ptr(b["trans"]), ptr(b["mask"]), ptr(b["depth"]), ptr(b["img"]), ptr(b["nimg"]), ptr(b["acc"]), ptr(b["dalpha"]),
+             ptr(b["dsdf"]), ptr(b["drgb"]), ptr(b["dnab"]), ptr(b["dln"]))
+        full = lambda v, *sh: torch.zeros([N, *sh], dtype=torch.float64).index_put((rows,), v.detach())          # noqa: E731
+        assert (b["alpha"].cpu().double() - alpha.detach()).abs().max() < 2e-6
+        assert (b["vw"].cpu().double() - out["vw"].detach()).abs().max() < 2e-6
+        assert (b["mask"].cpu().double() - full(out["mask_volume"])).abs().max() < 5e-6
+        assert (b["depth"].cpu().double() - full(out["depth_volume"])).abs().max() < 2e-5
+        assert (b["img"].cpu().double() - full(out["rgb_volume"], 3)).abs().max() < 5e-6
+        assert (b["nimg"].cpu().double() - full(out["normals_volume"], 3)).abs().max() < 5e-6
+        acc = b["acc"].cpu().double()
+        # the mse of a near-converged state: relative to ITS OWN size (1e-5-ish next to sum(gt^2)/3N ~ 0.3)
+        assert float(mse) < 0.3 and abs(float(acc[0]) - float(mse)) < 2e-4 * float(mse) + 1e-9, (float(acc[0]), float(mse))
+        assert abs(float(acc[1]) - float(eik_r)) < 1e-5 * (1 + float(eik_r)) and abs(float(acc[2]) - float(eik_f)) < 1e-5 * (1 + float(eik_f))
+
+        def rel(a_, b_):
+            return float((a_.cpu().double() - b_).norm() / b_.norm().clamp_min(1e-12))
+        assert rel(b["drgb"][:S], rgb64.grad) < 2e-5 and rel(b["dnab"], nab64.grad) < 2e-5
+        assert rel(b["dsdf"][:S], sdf64.grad) < 2e-4, rel(b["dsdf"][:S], sdf64.grad)
+        assert abs(float(b["dln"].cpu()) - float(ln64.grad)) < 2e-3 * abs(float(ln64.grad)) + 1e-9

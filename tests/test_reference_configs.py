@@ -164,3 +164,25 @@ def test_street_pretrain_targets(backend):
     pretrain_sdf_capsule(m.implicit_surface, tracks, surface_distance=1.0)
     s2 = m.query_sdf(torch.tensor([[0.0, 0.0, 0.5], [0.0, 3.0, 0.5]], device=backend)).cpu()
     assert s2[0] > 0.9 / 25.0 and s2[1] < -1.5 / 25.0                      # free on the track, solid 3 m beside it
+
+
+@needs_reference
+def test_scalar_num_fine_has_one_reading():
+    """the multi-object YAMLs give ``num_fine`` as ONE number next to two ``upsample_inv_s_factors``
+    (no_fg_occ.221218.yaml:378-390: 8 with [1, 4]; all_occ.240201.yaml:481-484: 16 with [1, 4]).  ``fields.neus.fine_list`` reads
+    it as the total, dealt evenly to the stages -- and the BASELINE configs[4] workload (``scenarios.vehicle_model``) passes the
+    YAML's literal through the same function instead of holding a second reading ([8, 8] in rounds 3-4)."""
+    import yaml
+    from neuralsim_amd.fields.neus import fine_list
+    for path, want_nf, want in (("code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml", 8, [4, 4]),
+                                ("code_multi/configs/exps/fg_neus=permuto/all_occ.240201.yaml", 16, [8, 8])):
+        text = (CFG.parent.parent / path).read_text()
+        tree = yaml.safe_load(text)
+        qp = tree["assetbank_cfg"]["Vehicle"]["model_params"]["ray_query_cfg"]["query_param"]
+        assert qp["num_fine"] == want_nf and list(qp["upsample_inv_s_factors"]) == [1, 4]
+        assert fine_list(qp) == want
+    assert fine_list(dict(num_fine=[8, 8, 32], upsample_inv_s_factors=[1, 4, 16])) == [8, 8, 32]      # a list names the stages
+    import inspect
+    from neuralsim_amd import scenarios
+    src = inspect.getsource(scenarios.vehicle_model)
+    assert "num_coarse=32, num_fine=8," in src          # the yaml's literal, read by fine_list inside the model

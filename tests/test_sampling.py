@@ -395,3 +395,128 @@ def test_refresh_points_are_a_stratified_sweep(backend):
         seen += torch.bincount(v, minlength=nvox)
         start = (start + n) % nvox
     assert int(seen.min()) == int(seen.max()) == 6          # 384 points over 64 voxels
+
+
+def _rand_packs(g, n_list):
+    from oracle import pack_ops as opo
+    n = torch.tensor(n_list)
+    pi = opo.get_pack_infos_from_n(n)
+    S = int(n.sum())
+    ridx = opo.pack_ridx(pi, S)
+    R = n.shape[0]
+    near = torch.rand(R, generator=g) * 0.5 + 2.0
+    far = near + 1.0 + torch.rand(R, generator=g)
+    t = near[ridx] + torch.rand(S, generator=g) * (far - near)[ridx]
+    t, _ = opo.packed_sort(t, pi)
+    t = t + torch.arange(S).float() * 1e-5
+    sdf = (near[ridx] + 0.4 + 0.4 * torch.rand(R, generator=g)[ridx] - t) * 0.6 + 0.01 * torch.randn(S, generator=g)
+    return n, pi, S, ridx, t, sdf
+
+
+def test_merge_upsample_equals_merge_then_upsample(backend):
+    """``nsim_merge_upsample`` (merge of stage k + draws of stage k + 1, the default path) against the two launches
+    it replaces -- ``nsim_merge_sorted`` then ``nsim_upsample_stage`` -- on random packs incl. rays on both sides of the
+    per-wave LDS window (SMP_LDS_FLOATS = 512 floats): bit-equal t_out / v_out / pack_infos / ridx / t_new / x_new."""
+    g = torch.Generator().manual_seed(21)
+    n, pi, S, ridx, t, sdf = _rand_packs(g, [2, 3, 64, 65, 200, 505, 512, 513, 700, 17, 1, 129])
+    R = n.shape[0]
+    dv = lambda a: a.to(backend).contiguous()        # noqa: E731
+    for nb, nf2, use_est in ((8, 8, 1), (8, 32, 0), (32, 70, 1)):
+        t_b = torch.sort(t[pi[:, 0]][:, None] + torch.rand(R, nb, generator=g) * (t[pi[:, 0] + pi[:, 1] - 1] - t[pi[:, 0]])[:, None], dim=1).values
+        v_b = torch.randn(R, nb, generator=g) * 0.1
+        ro = torch.randn(R, 3, generator=g)
+        rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+        T = S + R * nb
+        outs = []
+        for fused in (True, False):
+            t_out, v_out = torch.zeros(T, device=backend), torch.zeros(T, device=backend)
+            pi_out = torch.zeros(R, 2, dtype=torch.long, device=backend)
+            ridx_out = torch.zeros(T, dtype=torch.long, device=backend)
+            scratch = torch.zeros(T, device=backend)
+            t_new = torch.zeros(R, nf2, device=backend)
+            x_new = torch.zeros(R * nf2, 3, device=backend)
+            if fused:
+                _lib.call("nsim_merge_upsample", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
+                          R, nb, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), 256.0, nf2, use_est,
+                          _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)), _lib.ptr(x_new), None)
+            else:
+                _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi)), _lib.ptr(dv(t_b)), _lib.ptr(dv(v_b)),
+                          R, nb, _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), _lib.ptr(ridx_out), None, None, None, None)
+                _lib.call("nsim_upsample_stage", _lib.ptr(t_out), _lib.ptr(v_out), _lib.ptr(pi_out), R, 256.0, nf2, use_est,
+                          _lib.ptr(scratch), _lib.ptr(t_new), _lib.ptr(dv(ro)), _lib.ptr(dv(rd)), _lib.ptr(x_new), None)
+            outs.append([a.cpu() for a in (t_out, v_out, pi_out, ridx_out, t_new, x_new)])
+        for a, b, nm in zip(outs[0], outs[1], ("t_out", "v_out", "pack_infos", "ridx", "t_new", "x_new")):
+            assert torch.equal(a, b), (nb, nf2, use_est, nm)
+        assert bool((outs[0][4][:, 1:] >= outs[0][4][:, :-1]).all())
+
+
+def test_live_rank_and_compact_sampling(backend):
+    """``upsample_on_marched_only``: ``nsim_live_rank`` (ranks, live list, device-side point counts) and the live-rank form of
+    the sampling kernels -- only rays with marched samples get list-b / new samples, every per-live-ray array is indexed by the
+    rank -- against the dense kernels run on the live rays alone."""
+    g = torch.Generator().manual_seed(5)
+    counts = torch.tensor([0, 5, 0, 0, 70, 1, 0, 600, 3, 0, 0, 64], dtype=torch.long)
+    R = counts.shape[0]
+    live = counts > 0
+    Rl = int(live.sum())
+    C, nfs = 6, [4, 8, 0, 0]
+    dv = lambda a: a.to(backend).contiguous()        # noqa: E731
+    lr = torch.full([R], 123, dtype=torch.long, device=backend)
+    lidx = torch.full([R], 123, dtype=torch.long, device=backend)
+    cnts = torch.zeros(8, dtype=torch.long, device=backend)
+    _lib.call("nsim_live_rank", _lib.ptr(dv(counts)), R, C, *nfs, _lib.ptr(lr), _lib.ptr(lidx), _lib.ptr(cnts), None, 0)
+    q = torch.cumsum(live.long(), 0) - live.long()
+    assert torch.equal(lr.cpu(), torch.where(live, q, ~q))
+    assert torch.equal(lidx.cpu()[:Rl], live.nonzero()[:, 0]) and bool((lidx.cpu()[Rl:] == 0).all())
+    M = int(counts.sum())
+    assert cnts.cpu().tolist() == [Rl, M + Rl * C, Rl * 4, Rl * 8, 0, 0, M, 0]
+    # marched samples of the live rays, coarse depths, merge, draws: live-rank kernels on all R rays == dense kernels on the live ones
+    n, pi_l, S, ridx, t, sdf = _rand_packs(g, counts[live].tolist())
+    from oracle import pack_ops as opo
+    pi = opo.get_pack_infos_from_n(counts)
+    near, far = torch.rand(R, generator=g) + 1.0, torch.rand(R, generator=g) + 3.0
+    jc = torch.rand(R, C, generator=g)
+    ro = torch.randn(R, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+
+    def run(rays, pi_, rank):
+        Rr = rays.shape[0] if rank is None else R
+        nl = rays.shape[0]
+        sel = rays if rank is None else torch.arange(R)
+        t_c = torch.full([nl, C], -1.0, device=backend)
+        _lib.call("nsim_coarse_depths", _lib.ptr(dv(near[sel])), _lib.ptr(dv(far[sel])), _lib.ptr(dv(jc[sel])), Rr, C, _lib.ptr(t_c), _lib.ptr(rank))
+        T = S + nl * C
+        t_o, v_o = torch.zeros(T, device=backend), torch.zeros(T, device=backend)
+        pi_o = torch.zeros(Rr, 2, dtype=torch.long, device=backend)
+        r_o = torch.zeros(T, dtype=torch.long, device=backend)
+        x_o = torch.zeros(T, 3, device=backend)
+        _lib.call("nsim_merge_sorted", _lib.ptr(dv(t)), _lib.ptr(dv(sdf)), _lib.ptr(dv(pi_)), _lib.ptr(t_c), None, Rr, C, _lib.ptr(t_o),
+                  _lib.ptr(v_o), _lib.ptr(pi_o), _lib.ptr(r_o), _lib.ptr(dv(ro[sel])), _lib.ptr(dv(rd[sel])), _lib.ptr(x_o), _lib.ptr(rank))
+        t_n = torch.zeros(nl, 4, device=backend)
+        x_n = torch.zeros(nl * 4, 3, device=backend)
+        scratch = torch.zeros(T, device=backend)
+        _lib.call("nsim_upsample_stage", _lib.ptr(t_o), _lib.ptr(v_o), _lib.ptr(pi_o), Rr, 64.0, 4, 1, _lib.ptr(scratch), _lib.ptr(t_n),
+                  _lib.ptr(dv(ro[sel])), _lib.ptr(dv(rd[sel])), _lib.ptr(x_n), _lib.ptr(rank))
+        v_n = (t_n * 0.5).contiguous()
+        T2 = T + nl * 4
+        t2, v2 = torch.zeros(T2, device=backend), torch.zeros(T2, device=backend)
+        pi2 = torch.zeros(Rr, 2, dtype=torch.long, device=backend)
+        t_n2 = torch.zeros(nl, 8, device=backend)
+        scratch2 = torch.zeros(T2, device=backend)
+        _lib.call("nsim_merge_upsample", _lib.ptr(t_o), _lib.ptr(v_o), _lib.ptr(pi_o), _lib.ptr(t_n), _lib.ptr(v_n), Rr, 4, _lib.ptr(t2),
+                  _lib.ptr(v2), _lib.ptr(pi2), None, 256.0, 8, 1, _lib.ptr(scratch2), _lib.ptr(t_n2), _lib.ptr(dv(ro[sel])),
+                  _lib.ptr(dv(rd[sel])), None, _lib.ptr(rank))
+        return [a.cpu() for a in (t_c, t_o, v_o, pi_o, r_o, x_o, t_n, x_n, t2, v2, pi2, t_n2)]
+    rays_live = live.nonzero()[:, 0]
+    dense = run(rays_live, pi_l, None)
+    comp = run(rays_live, pi, lr)
+    names = ("t_c", "t_o", "v_o", "pi_o", "r_o", "x_o", "t_n", "x_n", "t2", "v2", "pi2", "t_n2")
+    for a, b, nm in zip(comp, dense, names):
+        if nm in ("pi_o", "pi2"):          # [R, 2] over all rays: the live rows are the dense ones, the others are empty packs
+            assert torch.equal(a[live], b), nm
+            assert bool((a[~live][:, 1] == 0).all()), nm
+            assert torch.equal(a[1:, 0], (a[:, 0] + a[:, 1])[:-1]), nm          # packs tile the buffer in ray order
+        elif nm == "r_o":                  # ray indices are those of the full ray list
+            assert torch.equal(a, rays_live[b]), nm
+        else:
+            assert torch.equal(a, b), nm

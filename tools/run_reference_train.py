@@ -164,6 +164,11 @@ def main(argv):
     _install_third_party_stubs()
     if emulate:
         _emulate_cuda_on_cpu()
+    if os.environ.get("NSIM_AUTOGRAD_MT", "0") != "1":
+        # this process IS the trainer (one GPU per process): its ``loss.backward()`` runs on the calling thread -- the hand-off
+        # to autograd's device thread costs 0.28 ms per step on the Python-side backward functions (neuralsim_amd/__init__.py)
+        import torch
+        torch.autograd.set_multithreading_enabled(False)
     rel = "code_single/tools/train.py"
     if "--script" in argv:                 # another entry point of the reference (code_multi/tools/train.py), also unchanged
         i = argv.index("--script")
