@@ -66,7 +66,7 @@ class BatchedPermutoNeuSModel(BatchedRaysMixin, PermutoNeuSModel):
         try:
             return super().batched_ray_query(**kw)
         finally:        # back to one row per batch item (point queries index it with bidx); the query's backward keeps the
-            if self.z_ins_per_batch is not None:      # per-pair codes it was made under (PermutoNeuSModel._remember_z)
+            if self.z_ins_per_batch is not None:      # per-pair codes it was made under (the enc_state on its ctx)
                 PermutoNeuSModel.set_condition(self, self.z_ins_per_batch)
 
     # ------------------------------------------------------------------ per-instance point queries

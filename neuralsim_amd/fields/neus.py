@@ -130,6 +130,7 @@ class _FieldFn(torch.autograd.Function):
             if _lib.TIMER is not None:
                 _lib.TIMER.note_units("nsim_field_fwd", S)
             ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
+            ctx.enc_state = pre.get("enc_state")
             ctx.grid_numel = grid.numel()
             ctx.grid16 = None
             ctx.x_shape = None
@@ -158,7 +159,10 @@ class _FieldFn(torch.autograd.Function):
         PS = _lib.plane_pitch(S)
         h_pl = torch.empty([NLP, PS, 2], dtype=torch.float32, device=dev) if need_pl else None
         J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
-        model._enc_field_fwd(grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, None, 0)
+        # (the encoding's hook may return per-query state its backward hooks need -- the permutohedral model's condition z --,
+        # carried on ctx: the backward of a query uses what the query was MADE with)
+        ctx.enc_state = model._enc_field_fwd(grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl,
+                                             None, 0)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_fwd", S)
         ctx.model, ctx.S, ctx.with_rgb, ctx.M = model, S, with_rgb, M
@@ -249,7 +253,7 @@ class _FieldFn(torch.autograd.Function):
                     d_o = d_o[:Rt - M] if d_o is not None else None
                     d_d = d_d[:Rt - M] if d_d is not None else None
         if dgrid is not None:   # (3) scatter to the hash grid
-            model._enc_scatter(x, rays_o, rays_d, t, ridx, ctx.goff, S, dh_pl, g_pl, gn_total, dgrid)
+            model._enc_scatter(x, rays_o, rays_d, t, ridx, ctx.goff, S, dh_pl, g_pl, gn_total, dgrid, enc_state=ctx.enc_state)
         if _lib.TIMER is not None:
             _lib.TIMER.note_units("nsim_field_bwd_sdf", S)
             if dgrid is not None:
@@ -984,7 +988,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         _lib.call("nsim_lotd_gather_lm", fm, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes))
 
-    def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid):
+    def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid, enc_state=None):
         _lib.call("nsim_lotd_scatter", self.encoding.cfg.meta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), S, _lib.ptr(dh_pl), _lib.ptr(g_pl),
                   _lib.ptr(gn_total), _lib.ptr(dgrid), 0, 0)
@@ -1480,8 +1484,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 spec.update(sdf=torch.empty([Sc], **f32), nablas=torch.empty([Sc, 3], **f32),
                             rgb=torch.empty([Sc, 3], **f32) if with_rgb else None,
                             h_pl=torch.empty([NLP, PSc, 2], **f32), J_pl=torch.empty([NLP, PSc, 2, 3], **f32), PS=PSc)
-                self._enc_field_fwd(grid16, wpack, None, o_a, d_a, t_full, ridx_full, None, ha_a, Sc, spec["sdf"],
-                                    spec["nablas"], spec["rgb"], spec["h_pl"], spec["J_pl"], total_dev, M)
+                spec["enc_state"] = self._enc_field_fwd(grid16, wpack, None, o_a, d_a, t_full, ridx_full, None, ha_a, Sc, spec["sdf"],
+                                                        spec["nablas"], spec["rgb"], spec["h_pl"], spec["J_pl"], total_dev, M)
             cfg["_spec_launch"], cfg["_tail_points"] = spec_launch, M
             self._with_tail = None
         o, d, t, pi, ridx, sdf_ng, march_counts, goff, fis = self._query_samples(ray_tested, cfg, qp)

@@ -85,7 +85,8 @@ class _ZTapFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_table):
-        dz = ctx.model._dz_acc.pop(ctx.key, None)
+        ent = ctx.model._dz_acc.pop(ctx.key, None)
+        dz = ent[1] if ent is not None else None
         if dz is not None:
             zs = ctx.z_shape
             dz = dz.sum(0, keepdim=True).reshape(zs) if (len(zs) == 1 or zs[0] == 1) and dz.shape[0] != 1 else dz.reshape(zs)
@@ -139,7 +140,6 @@ class PermutoNeuSModel(LoTDNeuSModel):
         self._z_rays = None
         self._z_src = None          # the caller's z when it requires grad (learned codes): see _ZTapFn
         self._dz_acc = {}
-        self._z_fwd = {}            # condition of the recent with-grad queries, keyed by their sample arrays (see _remember_z)
         if device is not None:
             self.to(device)
 
@@ -148,7 +148,7 @@ class PermutoNeuSModel(LoTDNeuSModel):
         """z [R, z_dim] per ray of the next queries, [1, z_dim] / [z_dim] for all of them, None = zeros.
         A z that requires grad (the auto-decoder's learned codes, ``z_ins_all`` of AD_GenerativePermutoConcatNeuSObj)
         receives d L / d z from every with-grad query made under this condition (``nsim_permuto_dz``).  The backward of a
-        query uses the condition it was MADE under (``_remember_z``), whatever has been set since."""
+        query uses the condition it was MADE under (the ``enc_state`` its forward hook returned), whatever has been set since."""
         self._z_src = None
         if z is not None:
             assert self.z_dim > 0 and z.shape[-1] == self.z_dim
@@ -181,24 +181,11 @@ class PermutoNeuSModel(LoTDNeuSModel):
                 ridx = torch.zeros([S], dtype=torch.long, device=dev)
         return z, ridx
 
-    def _remember_z(self, key: torch.Tensor, z, zr):
-        """The backward kernels re-read z as they re-read the rays; the condition may have changed by then (a batched query
-        sets per-pair codes, the next query others).  Keyed by the query's per-sample array that ``_FieldFn`` saves."""
-        if key is None or z is None:
-            return
-        if len(self._z_fwd) >= 16:
-            self._z_fwd.pop(next(iter(self._z_fwd)))
-        self._z_fwd[(key.data_ptr(), tuple(key.shape))] = (z, zr, self._z_src)
-
-    def _recall_z(self, key: torch.Tensor):
-        return self._z_fwd.pop((key.data_ptr(), tuple(key.shape)), None) if key is not None else None
-
     # ---------------------------------------------------------------- encoding hooks (csrc/permuto.hip)
     def _enc_field_fwd(self, grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, n_dev,
                        n_add):
         assert goff is None and h_pl is not None
         z, zr = self._z_for(ridx, rays_o, S, sdf.device)
-        self._remember_z(ridx if ridx is not None else (x if x is not None else t), z, zr)
         _lib.call("nsim_permuto_gather", self.encoding.cfg.pmeta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(n_dev), int(n_add), None, 0,
                   _lib.ptr(h_pl), _lib.ptr(J_pl))
@@ -206,6 +193,11 @@ class PermutoNeuSModel(LoTDNeuSModel):
         _lib.call("nsim_field_fwd", self.field_meta, None, _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), None, _lib.ptr(ha), S, _lib.ptr(sdf),
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))
+        # the condition this query was made under travels with the query (``_FieldFn`` keeps it on its ctx and hands it to
+        # ``_enc_scatter``): the backward kernels re-read z as they re-read the rays, and the condition may have changed by then
+        # (a batched query sets per-pair codes, the next query others).  Rounds 3-4 looked it up in a 16-entry FIFO keyed by the
+        # data pointer of a sample array (silent fall-back to the CURRENT condition on a miss)
+        return (z, zr, self._z_src) if z is not None else None
 
     def _enc_gather_feat(self, fm, grid16, x, rays_o, rays_d, t, ridx, goff, S, n_dev, n_add, planes):
         assert goff is None
@@ -214,12 +206,13 @@ class PermutoNeuSModel(LoTDNeuSModel):
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes),
                   int(fm.precision != 0), None, None)
 
-    def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid):
-        rec = self._recall_z(ridx if ridx is not None else (x if x is not None else t))
-        z_src = self._z_src
-        if rec is not None:
-            z, zr, z_src = rec
-        else:
+    def _enc_scatter(self, x, rays_o, rays_d, t, ridx, goff, S, dh_pl, g_pl, gn_total, dgrid, enc_state=None):
+        if enc_state is not None:
+            z, zr, z_src = enc_state
+        else:       # an unconditioned model, or a caller that runs forward and backward under ONE condition and says so by omission
+            assert self.z_dim == 0 or self._z_src is None, \
+                "a query made under a LEARNED condition must hand its enc_state (z, zr, z_src) to the backward"
+            z_src = None
             z, zr = self._z_for(ridx, rays_o, S, dgrid.device)
         _lib.call("nsim_permuto_scatter", self.encoding.cfg.pmeta, _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d),
                   _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(gn_total),
@@ -230,9 +223,11 @@ class PermutoNeuSModel(LoTDNeuSModel):
                       _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(dh_pl), _lib.ptr(dz))
             k = id(z_src)
             prev = self._dz_acc.get(k)
+            prev = prev[1] if prev is not None else None
             if prev is not None and prev.shape != dz.shape:          # a shared [1, z_dim] condition seen through two ray counts
                 prev, dz = prev.sum(0, keepdim=True), dz.sum(0, keepdim=True)
-            self._dz_acc[k] = dz if prev is None else prev + dz
+            # (the entry holds z_src itself: an id() is only unique among LIVE objects)
+            self._dz_acc[k] = (z_src, dz if prev is None else prev + dz)
 
     def _enc_hess_dx(self, grid16, x, rays_o, rays_d, t, ridx, goff, S, g_pl, gn_total, dx):
         return      # barycentric weights are piecewise LINEAR in x: no second derivative inside a simplex

@@ -301,9 +301,9 @@ class RenderTrainer:
             bufs = (torch.empty([Sc], **f32), torch.empty([Sc, 3], **f32), torch.empty([Sc, 3], **f32),
                     torch.empty([NLP, PSc, 2], **f32), torch.empty([NLP, PSc, 2, 3], **f32))
             # (the encoding's hook: LoTD = nsim_field_fwd with its own gather; permutohedral = nsim_permuto_gather + decoders)
-            model._enc_field_fwd(grid16, wpack, None, o, d, t_full, ridx_full, None, ha, Sc, bufs[0], bufs[1], bufs[2], bufs[3],
-                                 bufs[4], total_dev, M)
-            spec.update(bufs=bufs, PS=PSc)
+            st = model._enc_field_fwd(grid16, wpack, None, o, d, t_full, ridx_full, None, ha, Sc, bufs[0], bufs[1], bufs[2], bufs[3],
+                                      bufs[4], total_dev, M)
+            spec.update(bufs=bufs, PS=PSc, enc_state=st)
         if self.spec_forward:
             cfg["_spec_launch"] = spec_launch
         _o, _d, t, pi, ridx, _sdf_ng, _mc, _goff, fis = model._query_samples(tested, cfg, qp)
@@ -323,11 +323,12 @@ class RenderTrainer:
         if spec and getattr(model, "_spec_ok", False):      # already running (or done): views at the exact size
             sdf, nab, rgb = spec["bufs"][0][:St], spec["bufs"][1][:St], spec["bufs"][2][:St]
             h_pl, J_pl, PS = spec["bufs"][3], spec["bufs"][4], spec["PS"]
+            enc_state = spec.get("enc_state")
         else:
             sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
             PS = _lib.plane_pitch(St)
             h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
-            model._enc_field_fwd(grid16, wpack, None, o, d, t_a, ridx_a, None, ha, St, sdf, nab, rgb, h_pl, J_pl, None, 0)
+            enc_state = model._enc_field_fwd(grid16, wpack, None, o, d, t_a, ridx_a, None, ha, St, sdf, nab, rgb, h_pl, J_pl, None, 0)
         ln_inv_s = model.ln_inv_s.detach()
         alpha, vw, trans = torch.empty([S], **f32), torch.empty([S], **f32), torch.empty([S], **f32)
         nd = int(bool(cfg.get("depth_use_normalized_vw", True)))
@@ -382,7 +383,7 @@ class RenderTrainer:
         scatter_args = (model.encoding.cfg.meta, None, ptr(o), ptr(d), ptr(t_a), ptr(ridx_a), None, St, ptr(dh_pl),
                         ptr(g_pl), ptr(gn_total), ptr(dgrid))
         if type(model) is not LoTDNeuSModel:          # another encoding (permutohedral): its own scatter, in one piece
-            model._enc_scatter(None, o, d, t_a, ridx_a, None, St, dh_pl, g_pl, gn_total, dgrid)
+            model._enc_scatter(None, o, d, t_a, ridx_a, None, St, dh_pl, g_pl, gn_total, dgrid, enc_state=enc_state)
             if self.world_size > 1 and self.overlap_allreduce:
                 grid_p.grad = dgrid
                 self._dp_reduce_step(dgrid, None)
