@@ -415,6 +415,25 @@ class FakeOpenCV(FakePinhole):
         return torch.stack([x * d, y * d, d], dim=-1)
 
 
+class FakeFisheye(FakePinhole):
+    """Stand-in for nr3d_lib's FisheyeCameraMatHW (``camera_model: fisheye``, cameras.py:88-92): the lift inverts the OpenCV
+    fisheye polynomial the reference applies in app/resources/observers/fisheye.py:36-42 (the oracle's restatement, 10 Newton
+    rounds); the direction it returns is scaled to depth d along z like the pinhole lift (the Camera code normalises it)."""
+    def __init__(self, mat, WH, distortion, n_iters=10):
+        super().__init__(mat, WH)
+        self.distortion, self.n_iters = distortion, n_iters
+
+    def __getitem__(self, i):
+        return FakeFisheye(self.mat[i], self._wh[i], self.distortion[i], self.n_iters)
+
+    def lift(self, u, v, d):
+        from oracle import render as orr
+        m = self.mat
+        fx, fy, cx, cy = m[..., 0, 0], m[..., 1, 1], m[..., 0, 2], m[..., 1, 2]
+        x, y, z = orr.fisheye_lift((u - cx) / fx, (v - cy) / fy, self.distortion, self.n_iters)
+        return torch.stack([x * d, y * d, z * d], dim=-1)
+
+
 class FakePose:
     """Stand-in for nr3d_lib's TransformMat4x4: ``rotate`` is broadcast-multiply-sum (cameras.py:355-359 forbids mm)."""
     def __init__(self, mat):
@@ -435,7 +454,10 @@ class FakePose:
 
 class FakeCamera:
     def __init__(self, intr, c2w, WH, i_prefix=(), distortion=None):
-        self.intr = FakePinhole(intr, WH) if distortion is None else FakeOpenCV(intr, WH, distortion)
+        if distortion is None:
+            self.intr = FakePinhole(intr, WH)
+        else:
+            self.intr = FakeFisheye(intr, WH, distortion) if distortion.shape[-1] == 4 else FakeOpenCV(intr, WH, distortion)
         self.world_transform = FakePose(c2w)
         self.i_prefix, self.device, self.dtype = tuple(i_prefix), intr.device, intr.dtype
 

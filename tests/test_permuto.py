@@ -221,7 +221,7 @@ def test_reference_model_params_block_builds_the_permuto_model(backend):
 
 import ref_glue                                                       # noqa: E402
 
-needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="/root/reference is not present")
+needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="executes the reference's own sources from /root/reference (authoring container only; emulator backend). What it pins is replayed on the GPU box from frozen reference outputs: tests/test_reference_frozen.py, test_reference_glue.py::test_*_fixture")
 
 
 @needs_reference

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 CFG = Path("/root/reference/code_single/configs")
-needs_reference = pytest.mark.skipif(not CFG.exists(), reason="/root/reference is not present")
+needs_reference = pytest.mark.skipif(not CFG.exists(), reason="executes the reference's own sources from /root/reference (authoring container only; emulator backend). What it pins is replayed on the GPU box from frozen reference outputs: tests/test_reference_frozen.py, test_reference_glue.py::test_*_fixture")
 
 
 def _load(rel):

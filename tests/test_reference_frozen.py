@@ -1,0 +1,175 @@
+"""Replay of the reference-pinned checks on a machine WITHOUT /root/reference (the GPU box): tests/golden/reference_fixture.pt
+holds the outputs of the reference's own sources (``Camera._get_selected_rays_from_ixy`` / ``get_all_rays``,
+``SingleVolumeRenderer._volume_integration``, ``LineOfSightLoss`` + ``l1_loss``) and the resolved ``model_params`` blocks of
+the hot path's YAMLs, frozen by tests/golden/make_reference_fixture.py in the authoring container.  The live
+versions -- the same comparisons against the reference's modules as they lie under /root/reference -- are
+tests/test_reference_glue.py and tests/test_reference_configs.py."""
+from pathlib import Path
+
+import pytest
+import torch
+
+FIX = Path(__file__).resolve().parent / "golden" / "reference_fixture.pt"
+
+
+@pytest.fixture(scope="module")
+def fx():
+    assert FIX.exists(), "tests/golden/reference_fixture.pt is missing (python tests/golden/make_reference_fixture.py)"
+    return torch.load(str(FIX), map_location="cpu", weights_only=False)
+
+
+def test_frozen_reference_camera_rays(backend, fx):
+    """SURVEY row a1 (cameras.py:281-310, 332-360): the ray-generation kernels and the oracle against the rays the
+    reference's ``Camera`` code produced -- pinhole (snapped and not), OpenCV-distorted and fisheye rigs, ``get_all_rays``."""
+    from oracle import render as orr
+    from neuralsim_amd.eval import all_pixel_xy
+    from neuralsim_amd.graphics.cameras import fisheye_selected_rays, opencv_selected_rays, pinhole_selected_rays
+    c = fx["cameras"]
+    dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+    xy, fidx, intr, c2w, WH = c["xy"], c["fidx"], c["intr"], c["c2w"], c["WH"]
+    for snap in (True, False):
+        o_ref, d_ref = c[f"pinhole_snap{int(snap)}"]
+        o_o, d_o = orr.pinhole_rays(xy, fidx, intr, c2w, WH, snap_to_pixel_centers=snap)
+        assert torch.equal(o_ref, o_o) and float((d_ref - d_o).abs().max()) <= 2e-7
+        o_k, d_k = pinhole_selected_rays(dv(xy), dv(fidx), dv(intr), dv(c2w), dv(WH), snap_to_pixel_centers=snap)
+        assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 3e-7, snap
+    o_ref, d_ref = c["opencv"]
+    o_k, d_k = opencv_selected_rays(dv(xy), dv(fidx), dv(intr), dv(c["dist_opencv"]), dv(c2w), dv(WH))
+    assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 3e-7
+    assert float((d_ref - c["pinhole_snap1"][1]).abs().max()) > 1e-3          # (it is not the pinhole direction)
+    o_ref, d_ref = c["fisheye"]
+    o_k, d_k = fisheye_selected_rays(dv(xy), dv(fidx), dv(c["intr_fisheye"]), dv(c["dist_fisheye"]), dv(c2w), dv(WH))
+    assert torch.equal(o_k.cpu(), o_ref) and float((d_k.cpu() - d_ref).abs().max()) <= 2e-6
+    o_o, d_o = orr.pinhole_rays(xy, fidx, c["intr_fisheye"], c2w, WH, distortion=c["dist_fisheye"], n_iters=10, camera_model="fisheye")
+    assert float((d_o - d_ref).abs().max()) <= 1e-6
+    W, H = int(WH[2, 0]), int(WH[2, 1])
+    o_all, d_all = c["all_rays_frame2"]
+    xy_all = all_pixel_xy(W, H, torch.device("cpu"))
+    f2 = torch.full([W * H], 2)
+    o_k, d_k = pinhole_selected_rays(dv(xy_all), dv(f2), dv(intr), dv(c2w), dv(WH))
+    assert o_all.shape == (W * H, 3) and torch.equal(o_k.cpu(), o_all) and float((d_k.cpu() - d_all).abs().max()) <= 3e-7
+
+
+def test_frozen_reference_volume_integration(backend, fx):
+    """``_volume_integration`` (single_volume_renderer.py:73-102), both depth modes, train / eval normals: the oracle AND the
+    product's ``volume_integration`` (HIP compositing kernels) against what the reference's code returned."""
+    from oracle import render as orr
+    from neuralsim_amd.fields.neus import volume_integration
+    v = fx["volume_integration"]
+    dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+    rih, pi, N = v["rays_inds_hit"], v["pack_infos_hit"], v["N"]
+    keep = torch.zeros(N, dtype=torch.bool)
+    keep[rih] = True
+    assert len(v["cases"]) == 4
+    for (training, norm_depth), ref in v["cases"].items():
+        nab = v["nablas"] if training else torch.nn.functional.normalize(v["nablas"].clamp(-1, 1), dim=-1)
+        o = orr.volume_integration(v["alpha"], v["t"], v["rgb"], nab, pi, norm_depth)
+        got = volume_integration(dv(v["alpha"]), dv(v["t"]), dv(v["rgb"]), dv(nab), dv(pi), norm_depth)
+        assert torch.allclose(ref["vw"], o["vw"], atol=1e-6) and torch.allclose(got["vw"].cpu(), ref["vw"], atol=1e-6)
+        for k in ("mask_volume", "depth_volume", "rgb_volume", "normals_volume"):
+            assert torch.allclose(ref[k][rih], o[k], atol=1e-5), (k, training, norm_depth)
+            assert torch.allclose(got[k].cpu(), ref[k][rih], atol=2e-5), (k, training, norm_depth)
+            assert float(ref[k][~keep].abs().sum()) == 0.0
+
+
+def test_frozen_reference_lidar_losses(backend, fx):
+    """``LineOfSightLoss`` (app/loss/lidar.py:174-210; nerf / neus_urban / neus_unisim) and the masked l1 depth term on a frozen
+    lidar volume buffer: ``RenderTrainer.lidar_losses`` (the street iteration's lidar step, HIP pack ops underneath) and the
+    formulas on the oracle's pack ops against the values the reference's modules returned."""
+    from oracle import pack_ops as opo
+    from neuralsim_amd.trainer import RenderTrainer
+    L = fx["lidar"]
+    want = L["losses"]
+    dv = lambda t: t.to(backend).contiguous()         # noqa: E731
+    ret = dict(volume_buffer=dict(type="packed", vw=dv(L["vw"]), t=dv(L["t"]), pack_infos_hit=dv(L["pack_infos_hit"]),
+                                  rays_inds_hit=dv(L["rays_inds_hit"])), rendered=dict(depth_volume=dv(L["depth_volume"])))
+    tr = RenderTrainer.__new__(RenderTrainer)
+    tr.lidar = dict(w_depth=0.02, w_los=0.1, epsilon=0.15, discard_toofar=2.5)
+    loss, parts = tr.lidar_losses(ret, dv(L["ranges"]))
+    assert want["neus_unisim.lidar_loss.los.empty"] > 1e-4 and want["depth_l1_w0.02"] > 1e-4
+    assert abs(float(parts["los"]) - want["neus_unisim.lidar_loss.los.empty"]) <= 1e-5 * (1 + want["neus_unisim.lidar_loss.los.empty"])
+    assert abs(float(parts["depth"]) - want["depth_l1_w0.02"]) <= 1e-5 * (1 + want["depth_l1_w0.02"])
+    # the same formulas on the oracle's pack ops (f64)
+    pi, t, vw = L["pack_infos_hit"], L["t"].double(), L["vw"].double()
+    rih, mh = L["rays_inds_hit"], L["mask"][L["rays_inds_hit"]].double()
+    gt_ex = torch.repeat_interleave(L["ranges"][rih].double(), pi[:, 1])
+    sig = 0.1
+    tgt = torch.exp(torch.distributions.normal.Normal(0.0, sig / 3.0).log_prob(t - gt_ex))
+    nb = opo.packed_sum(((t <= gt_ex + sig) & (t >= gt_ex - sig)) * (vw - tgt) ** 2, pi)
+    em = opo.packed_sum((t < gt_ex - sig) * vw ** 2, pi)
+    eu = opo.packed_sum(((t - gt_ex).abs() > 0.15) * vw ** 2, pi)
+    ora = {"nerf.lidar_loss.los.neighbor": 0.1 * (nb * mh).mean(), "nerf.lidar_loss.los.empty": 0.1 * (em * mh).mean(),
+           "neus_unisim.lidar_loss.los.empty": 0.1 * (eu * mh).mean()}
+    ora["neus_urban.lidar_loss.los.neighbor"], ora["neus_urban.lidar_loss.los.empty"] = \
+        ora["nerf.lidar_loss.los.neighbor"], ora["nerf.lidar_loss.los.empty"]
+    for k, vv in ora.items():
+        assert abs(float(vv) - want[k]) <= 1e-5 * (1 + abs(want[k])), (k, float(vv), want[k])
+
+
+@pytest.mark.parametrize("key,inside_out,final_inv_s", [("dtu", False, 2000.0), ("replica", True, 1200.0)])
+def test_frozen_object_centric_blocks_build_the_model(backend, fx, key, inside_out, final_inv_s):
+    """The ``model_params`` block of lotd_neus.dtu / replica.230814.yaml (resolved, frozen) through ``cls(**model_params)`` ->
+    ``populate`` -> ``training_initialize`` -> ``training_before_per_step``: level list of yaml:97, Dense / Hash split, table
+    size, occupancy settings, hardmask and inv_s schedules -- the outcomes tests/test_reference_configs.py asserts live."""
+    import copy
+    from nr3d_lib.models.fields.neus import LoTDNeuSModel
+    blk = fx["configs"][key]["blocks"]["Main"]
+    mp = copy.deepcopy(blk["model_params"])
+    full = LoTDNeuSModel(**copy.deepcopy(mp), device=None)                  # the real 16-level / 2^19 block (host only)
+    cfg = full.encoding.cfg
+    assert cfg.lod_res == [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+    assert cfg.lod_types == ["Dense"] * 5 + ["Hash"] * 11 and cfg.hashmap_size == 2 ** 19 and cfg.n_params == 12196216
+    assert full.sdf_D == 1 and full.inside_out == inside_out and full.field_meta.precision == 0
+    assert full.ray_query_cfg["query_mode"] == "march_occ_multi_upsample_compressed"
+    assert full.ray_query_cfg["query_param"]["num_fine"] == [8, 8, 32]
+    assert full.accel.resolution == [64, 64, 64] and full.accel.n_steps_warmup == 256
+    assert full._var_ctrl == dict(start_it=2000, stop_it=fx["configs"][key]["num_iters"], final_inv_s=final_inv_s)
+    small = copy.deepcopy(mp)
+    small["surface_cfg"]["encoding_cfg"]["lotd_auto_compute_cfg"].update(num_levels=8, log2_hashmap_size=12, max_res=64)
+    small["accel_cfg"].update(resolution=[16, 16, 16], init_cfg=dict(num_steps=2, num_pts=2 ** 12),
+                              update_from_net_cfg=dict(num_steps=2, num_pts=2 ** 12), n_steps_warmup=2, n_steps_between_update=2)
+    m = LoTDNeuSModel(**small, device=backend)
+    m.populate(device=backend)
+    assert m.training_initialize(blk["initialize_cfg"]) is True
+    assert 0.0 < m.accel.frac_occupied() < 0.8
+    s = m.query_sdf(torch.tensor([[0.0, 0.0, 0.0], [0.9, 0.0, 0.0]], device=backend)).cpu()
+    assert (s[0] > 0 > s[1]) if inside_out else (s[0] < 0 < s[1])
+    m.training_before_per_step(0)
+    assert m.encoding.cfg.meta.n_active_levels == 3
+    m.training_before_per_step(1000)
+    assert m.encoding.cfg.meta.n_active_levels == 0
+    m.training_before_per_step(4750)
+    assert abs(m._ctrl_mix - 0.5) < 1e-6
+    m.training_after_per_step(4750)
+
+
+def test_frozen_street_blocks(backend, fx):
+    """withmask_withlidar_joint.240219.yaml (resolved, frozen): the Street block's cuboid pyramid and ``vox_size`` occupancy
+    grid sized at ``populate(aabb=)``, the street variants of the Distant and Sky blocks."""
+    import copy
+    from nr3d_lib.models.fields.neus import LoTDNeuSModel
+    from neuralsim_amd.env import SimpleSky
+    from neuralsim_amd.fields.nerf_distant import LoTDNeRFDistantModel
+    c = fx["configs"]["street"]
+    m = LoTDNeuSModel(**copy.deepcopy(c["blocks"]["Street"]["model_params"]), device=None)
+    with pytest.raises(AssertionError):
+        m.populate(device=None)
+    aabb = torch.tensor([[-60.0, -20.0, -4.0], [60.0, 20.0, 12.0]])
+    m.populate(aabb=aabb)
+    cfg = m.encoding.cfg
+    assert cfg.hashmap_size == 2 ** 20 and 30 * 2 ** 20 < cfg.n_params < 36 * 2 ** 20
+    assert cfg.lod_res3[0][0] > cfg.lod_res3[0][1] > cfg.lod_res3[0][2] == 16
+    assert m.accel.resolution == [120, 40, 16] and m.sdf_scale == 25.0 and m.sdf_D == 1
+    assert m.ray_query_cfg["query_param"]["num_coarse"] == 128
+    assert m.ray_query_cfg["query_param"]["upsample_use_estimate_alpha"] is False
+    dp = copy.deepcopy(c["blocks"]["Distant"]["model_params"])
+    dp["encoding_cfg"]["lotd_auto_compute_cfg"].update(target_num_params=2 ** 14, log2_hashmap_size=10, min_res_xyz=3, min_res_w=2)
+    d = LoTDNeRFDistantModel(**dp, device=backend).populate(aabb=aabb, device=backend)
+    assert d.include_inf is False and d.use_view_dirs is False and d.K == c["distant_nsample"]
+    assert d.cfg.cuboid and d.cfg.res3[0] == [23, 8, 3]
+    sky = SimpleSky(**copy.deepcopy(c["blocks"]["Sky"]["model_params"]), device=backend)
+    assert sky.n_frequencies == 10 and sky.n_appear == 4
+    # the object-centric Distant block
+    d2 = LoTDNeRFDistantModel(**copy.deepcopy(fx["configs"]["dtu"]["blocks"]["Distant"]["model_params"]))
+    assert d2.include_inf and d2.use_view_dirs and d2.K == 64 and (d2.r_min, d2.r_max) == (1.0, 1000.0)
+    assert d2.cfg.n_params >= 8 * 2 ** 20 and d2.cfg.num_levels == 12

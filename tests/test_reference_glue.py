@@ -18,7 +18,7 @@ import ref_glue
 from renderer_scenario import SCENARIOS, build_scenario, run_mirror, run_reference
 
 GOLDEN = Path(__file__).resolve().parent / "golden" / "renderer_fixture.pt"
-needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="/root/reference is not present")
+needs_reference = pytest.mark.skipif(not ref_glue.reference_available(), reason="executes the reference's own sources from /root/reference (authoring container only; emulator backend). What it pins is replayed on the GPU box from frozen reference outputs: tests/test_reference_frozen.py, test_reference_glue.py::test_*_fixture")
 
 
 def _cmp(a, b, tol, what):

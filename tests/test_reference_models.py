@@ -20,7 +20,8 @@ import ref_glue
 
 CFG = Path("/root/reference/code_single/configs")
 needs_reference = pytest.mark.skipif(not (CFG.exists() and ref_glue.reference_available()),
-                                     reason="/root/reference is not present")
+                                     reason="executes the reference's own sources from /root/reference (authoring container only; "
+                                            "emulator backend): the model wrappers / loss modules of app/ cannot travel to the GPU box")
 
 
 def _cfg():

@@ -21,7 +21,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 REF = Path("/root/reference")
 CFG = REF / "code_single/configs/object_centric/lotd_neus.dtu.230814.yaml"
-needs_reference = pytest.mark.skipif(not CFG.exists(), reason="/root/reference is not present")
+needs_reference = pytest.mark.skipif(not CFG.exists(), reason="executes the reference's own sources from /root/reference (authoring container only; emulator backend). What it pins is replayed on the GPU box from frozen reference outputs: tests/test_reference_frozen.py, test_reference_glue.py::test_*_fixture")
 
 M, D = "assetbank_cfg.Main.model_params", "assetbank_cfg.Distant.model_params"
 SMALL = [
