@@ -679,6 +679,23 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                        "passes of this command + tools/gather_pair_bench, tools/atomic_bench4), recorded")
         except Exception:
             pass
+    # The MFMA kernels against the ceiling of their own CHAIN (round 5): tools/decoder_chain_bench.hip runs the 32 -> 64 -> 64 -> 1
+    # chains -- the same products and softplus / sigmoid evaluations -- on register-resident tiles, no planes, no LDS staging
+    # (profiles/round5_decoder_chain_bench.txt: G points/s chip-wide, best of 1 / 2 / 4 waves per SIMD and both tile shapes);
+    # recorded, NOT measured by the run that prints this line.  A 64-wide softplus network tops out at 12-23 % of the dense
+    # f16 MFMA peak on this chip; `frac_of_chain_ceiling` = the product kernel's points/s over that ceiling
+    CHAIN_CEIL = {"nsim_field_sdf": ("forward (sdf query); the product runs it in split precision: 3 MFMAs per product", 24.67e9),
+                  "nsim_field_fwd": ("forward + d sdf / d h (+ the level-major gather and the radiance forward in the same entry point)", 17.17e9),
+                  "nsim_field_bwd_sdf": ("2nd-order backward chain + weight-gradient MFMAs", 7.88e9)}
+    chain = {}
+    for k, (what, ceil_pts) in CHAIN_CEIL.items():
+        v = ksum.get(k)
+        if v and v["units"] and v["total_ms"] > 0 and workload is None:
+            pts_s = v["units"] / (v["total_ms"] * 1e-3)
+            chain[k] = dict(chain=what, ceiling_Gpts_s=round(ceil_pts / 1e9, 2), achieved_Gpts_s=round(pts_s / 1e9, 3),
+                            frac_of_chain_ceiling=round(pts_s / ceil_pts, 4))
+    if chain:
+        roofline["chain_ceilings"] = dict(kernels=chain, source="profiles/round5_decoder_chain_bench.txt (tools/decoder_chain_bench.hip on MI355X), recorded")
     # per-kernel roofline of every modelled entry point (the MFMA kernels against the dense fp16 peak)
     per_kernel = {}
     for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"]):

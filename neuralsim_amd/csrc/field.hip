@@ -1814,6 +1814,12 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
   const char* W = stage_weights<PREC>(smem, a, M_R1, 6, L, wbytes);
   char* stA = smem + wbytes;
   char* stB = stA + 64 * jstage_row_bytes<PREC>();
+  // fp16 mode (round 5): the network input of the group is staged ONCE, right after the first barrier of the iteration, into a
+  // third area of 32 rows (8.7 KB: 78 KB in all, still two workgroups per CU) -- it is the B operand of the LAST weight-gradient
+  // product (dR1 += dr1 (x) rin), and holding its 16 registers across the whole backward chain was what pushed the kernel
+  // 13 dwords past its 256 registers (52 B of scratch since round 3).  f32 validation mode: one workgroup per CU, staged late.
+  constexpr bool RIN_EARLY = PREC == 0;
+  char* stC = stB + 64 * jstage_row_bytes<PREC>();
   f32x16 accR2 = zero16(), accX = zero16();
   float bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;      // this wave's share of d rb1[lane], d rb2[lane], d rb3[lane < 3]
 
@@ -1860,24 +1866,22 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
     KT(0, 4);
     jstage<PREC, 1>(stA, dout, wave);
     jstage<PREC, 2>(stB, r2, wave);
+    if constexpr (RIN_EARLY) jstage<PREC, 1>(stC, rin, wave);      // (its readers of the previous group passed the barrier above)
     KT(0, 5);
     __syncthreads();
     KT(0, 6);
     if (wave < 2) accX = jdw_tile<PREC>(stA, 0, stB, wave, accX);
     bs3 += jrow_sum<PREC>(stA, 3, wave);
     KT(0, 7);
-    float dr2s[32], dr2[32];
+    float dr2s[32];
     dense<PREC, 2, 1>(dr2s, W + L.mat[M_R3T], douts, false);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      dr2s[k] = r2[k] > 0.f ? dr2s[k] : 0.f;
-      dr2[k] = dr2s[k] * inv_sc;
-    }
-    // ---- dR2 += dr2 (x) r1, d rb2 += rowsum(dr2)
+    for (int k = 0; k < 32; ++k) dr2s[k] = r2[k] > 0.f ? dr2s[k] : 0.f;
+    // ---- dR2 += dr2 (x) r1, d rb2 += rowsum(dr2)      (dr2 = dr2s / sc, formed where it is staged)
     KT(0, 8);
     __syncthreads();
     KT(0, 9);
-    jstage<PREC, 2>(stA, dr2, wave);
+    jstage_scaled<PREC, 2>(stA, dr2s, inv_sc, wave);
     jstage<PREC, 2>(stB, r1, wave);
     KT(0, 10);
     __syncthreads();
@@ -1885,22 +1889,19 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
     accR2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accR2);
     bs2 += jrow_sum<PREC>(stA, 64, wave);
     KT(0, 12);
-    float dr1s[32], dr1[32];
+    float dr1s[32];
     dense<PREC, 2, 2>(dr1s, W + L.mat[M_R2T], dr2s, false);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      dr1s[k] = r1[k] > 0.f ? dr1s[k] : 0.f;
-      dr1[k] = dr1s[k] * inv_sc;
-    }
+    for (int k = 0; k < 32; ++k) dr1s[k] = r1[k] > 0.f ? dr1s[k] : 0.f;
     // ---- dR1 += dr1 (x) rin, d rb1 += rowsum(dr1)
     KT(0, 13);
     __syncthreads();
     KT(0, 14);
-    jstage<PREC, 2>(stA, dr1, wave);
-    jstage<PREC, 1>(stB, rin, wave);
+    jstage_scaled<PREC, 2>(stA, dr1s, inv_sc, wave);
+    if constexpr (!RIN_EARLY) jstage<PREC, 1>(stB, rin, wave);
     __syncthreads();
     KT(0, 15);
-    if (wave >= 2) accX = jdw_tile<PREC>(stA, wave - 2, stB, 0, accX);
+    if (wave >= 2) accX = jdw_tile<PREC>(stA, wave - 2, RIN_EARLY ? stC : stB, 0, accX);
     bs1 += jrow_sum<PREC>(stA, 64, wave);
     KT(0, 16);
     float din[16];
@@ -1942,7 +1943,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES, PREC == 0 ? 2 : 1) k_rad_bwd
     if (a.dh_appear && !(a.ablate & 8)) {
       float c0 = hi == 1 ? din[10] : din[12], c1 = hi == 1 ? din[11] : din[13];
       if (halfwave_run_sum2(p.ray, p.valid, c0, c1)) {
-        float* dst = a.dh_appear + 4 * p.ray + (hi == 1 ? 0 : 2);
+        // (an offset the compiler cannot hoist: the lane-constant half of this address was one of the values it kept in -- and
+        // spilled from -- registers across the whole loop)
+        float* dst = a.dh_appear + 4 * p.ray + ((lane + nsim_opaque_zero()) >> 5 == 1 ? 0 : 2);
         atomicAdd(dst, c0);
         atomicAdd(dst + 1, c1);
       }
@@ -2628,7 +2631,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   const int64_t tiles = (S + 31) / 32;
   // workgroup-joint weight gradients: weights + one staging area in LDS, two workgroups per CU
   const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
-  const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + 128 * row;
+  const size_t shmem = weights_lds_bytes(meta, M_R1, 6) + (meta->precision == 0 ? 160 : 128) * row;      // (+ the early rin area)
   int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
   nb = nb > 512 ? 512 : (nb < 1 ? 1 : nb);          // two resident workgroups per CU
   const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);

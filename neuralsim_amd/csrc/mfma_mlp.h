@@ -265,6 +265,18 @@ __device__ __forceinline__ void jstage(void* st, const float (&v)[NM * 16], int 
     for (int r = 0; r < 16; ++r) p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = (T)v[m * 16 + r];
 }
 
+// the same for v * scale (a chain carried in scaled form is un-scaled where it is staged: no second copy of it in registers)
+template <int PREC, int NM>
+__device__ __forceinline__ void jstage_scaled(void* st, const float (&v)[NM * 16], float scale, int wave) {
+  typedef typename JStageT<PREC>::T T;
+  T* p = reinterpret_cast<T*>(st);
+  const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = (T)(v[m * 16 + r] * scale);
+}
+
 // acc += A[32 mo + row][:] . B[32 no + col][:]^T over the staged points [16 S0, 16 S1)  (default: all JOINT_PTS)
 template <int PREC, int S0 = 0, int S1 = JOINT_PTS / 16>
 __device__ __forceinline__ f32x16 jdw_tile(const void* stA, int mo, const void* stB, int no, f32x16 acc) {

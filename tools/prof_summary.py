@@ -32,6 +32,14 @@ def main():
                                 grid=r[8], wg=r[9]) for r in rows if "k_" in r[0]]
     except Exception as e:
         res["dispatch_error"] = str(e)
+    try:        # launches of one kernel at different sizes (the sampling pass issues its gather / decoder at 4-5 sizes per step)
+        rows = db.execute("select name, grid_x, count(*), avg(duration), min(duration), max(duration) from kernels "
+                          "where name like '%k_lotd_gather_lm%' or name like '%k_field_sdf%' group by name, grid_x "
+                          "order by name, grid_x").fetchall()
+        res["by_grid"] = [dict(name=r[0][:100], grid=r[1], n=r[2], avg_us=round(r[3] / 1e3, 2), min_us=round(r[4] / 1e3, 2),
+                               max_us=round(r[5] / 1e3, 2)) for r in rows if r[2] >= 4][:200]
+    except Exception as e:
+        res["by_grid_error"] = str(e)
     json.dump(res, open(out, "w"), indent=1)
     if "--delete" in sys.argv:
         import os
