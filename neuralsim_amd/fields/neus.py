@@ -99,6 +99,9 @@ def marched_only(qp: dict) -> bool:
 
 
 _SPEC_FORWARD = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
+# evaluation (no-grad) forward through the level-major gather + the decoders on the planes instead of the fused point-major
+# kernel (k_field<0,2,1,1>: 512 registers + 61 spilled, one wave per SIMD).  Round 5 A/B: see DESIGN.md sec. 4
+_EVAL_PLANES = os.environ.get("NSIM_EVAL_PLANES", "0") == "1"
 # up-sampling: the merge of stage k and the draws of stage k + 1 as ONE launch (nsim_merge_upsample; 0: two launches)
 _FUSE_MERGE_UPSAMPLE = os.environ.get("NSIM_FUSE_MERGE_UPSAMPLE", "1") == "1"
 
@@ -155,7 +158,7 @@ class _FieldFn(torch.autograd.Function):
         # level-major planes of the gathered features / their x-derivative, saved so the backward never re-gathers
         # (pyramids with more than 16 levels exist on the level-major path only: planes in evaluation as well)
         NLP = model.plane_levels
-        need_pl = need_bwd or NLP > 16 or model.planes_always
+        need_pl = need_bwd or NLP > 16 or model.planes_always or _EVAL_PLANES
         PS = _lib.plane_pitch(S)
         h_pl = torch.empty([NLP, PS, 2], dtype=torch.float32, device=dev) if need_pl else None
         J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
