@@ -124,14 +124,14 @@ def _sphere_image_cpu(o, d, radius):
     return torch.where(hit[:, None], 0.5 + 0.5 * n, torch.zeros_like(o))
 
 
-def cpu_baseline(tr, iters=3, iters_small=3):
+def cpu_baseline(tr, iters=5, iters_small=3):
     """The oracle (pure-PyTorch restatement of the reference's algorithm, kind 'port') timed on this box's host cores on
     THE SAME STEP the GPU runs: same weights, occupancy grid and camera rig, the full ray batch, the same query mode
     (``march_occ_multi_upsample_compressed``), the analytic-image targets, the uniform eikonal points, backward, Adam over
     every parameter, and 1/16 of an occupancy refresh (4 x 2^20 SDF queries every 16 iterations on the GPU side).
-    ``value`` = median of ``iters`` timed iterations at the bench's ray count (SURVEY sec. 8d asks the median of >= 5; three
-    keep the default bench run within minutes -- a step takes ~20 s); ``configs0`` = the same step at N = 4096 rays
-    (BASELINE configs[0], the reference's own CPU-runnable size)."""
+    ``value`` = median of ``iters`` = 5 timed iterations at the bench's ray count (the median of >= 5; a step
+    takes ~10-20 s on the GPU box's host cores: about a minute and a half in all); ``configs0`` = the same step at N = 4096 rays
+    (BASELINE configs[0], the reference's own CPU-runnable size), median of 3."""
     from oracle import field as ofield, render as orr
     m = tr.model
     p, occ = oracle_of(tr)
@@ -379,7 +379,13 @@ def main():
             # each; their oracle parity is tests/test_fullsize_configs.py
             for name in ("street", "indoor", "multi"):
                 trc = build_config_trainer(name, dev, rank, world, 16384)
-                var[name + "_ms"], _ = time_steps(trc, 12, 6, 257)
+                for _ in range(6):
+                    trc.train_step(251)
+                _lib.CALL_COUNT = 0
+                var[name + "_ms"], _ = time_steps(trc, 12, 0, 257)
+                # C-ABI entry-point calls of this package per step (the ATen launches of the renderer mirrors' glue are on top)
+                var[name + "_abi_calls_per_step"] = round(_lib.CALL_COUNT / 12.0, 1)
+                _lib.CALL_COUNT = None
                 var[name + "_samples_per_hit_ray"] = round(trc.stats["S_f"] / max(1, trc.stats["R_hit"]), 1)
                 del trc
                 torch.cuda.empty_cache()
@@ -728,6 +734,10 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                            hit_fraction=round(S_hit / (rays_per_gpu * steps), 3),
                            marched_fraction=round(S_live / (rays_per_gpu * steps), 3),
                            S_q_per_step=round(S_q / steps), S_f_per_step=round(S_f / steps)),
+               # `value` / `ms_per_step` are the contract's figures: K steps / elapsed (the MEAN step, which carries the occupancy
+               # refresh steps -- 4 x 2^20 queries every 16 iterations, ~3 ms each).  The MEDIAN step next to it, first-class
+               # (VERDICT r4 weak #10): host-side marks, every step blocks once on its sample count
+               ms_per_step_p50=q(0.5), value_p50=round(rays_per_gpu * world / max(q(0.5), 1e-9) * 1e3, 1),
                step_ms=dict(p10=q(0.1), p50=q(0.5), p90=q(0.9), max=round(d[-1] * 1e3, 3)),
                roofline=roofline, kernels=per_kernel,
                # C-ABI entry-point calls of this package per step (each is one kernel launch, three of them two); the ATen /

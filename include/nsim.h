@@ -76,9 +76,12 @@ int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_inf
  * the occupancy-march counts n [R]: live_rank [R] = q >= 0 for the q-th ray with n > 0 ("live"), ~q < 0 for a ray with n == 0
  * (q live rays precede it); live_idx [R] (may be NULL) = the live rays in order, zero-filled past R'; cnts [8] (device) =
  * {R', sum(n) + R' C, R' nf0, R' nf1, R' nf2, R' nf3, sum(n), 0} -- the device-side point counts of the sampling pass's SDF
- * queries; notify (may be NULL): host-mapped words receiving (R', seq) as nsim_pack_infos_from_n_notify. */
+ * queries; notify (may be NULL): host-mapped words receiving (R', seq) as nsim_pack_infos_from_n_notify.  pack_infos [R,2]
+ * (may be NULL) + total + cap + notify_total / seq_total: the outputs of nsim_pack_infos_from_n[_notify](n, cap) from the same
+ * launch (the sampling pass needs both scans of the same counts). */
 int nsim_live_rank(const int64_t* n, int64_t R, int C, int nf0, int nf1, int nf2, int nf3, int64_t* live_rank,
-                   int64_t* live_idx, int64_t* cnts, int64_t* notify, int64_t seq, void* stream);
+                   int64_t* live_idx, int64_t* cnts, int64_t* notify, int64_t seq, int64_t* pack_infos, int64_t* total,
+                   int64_t cap, int64_t* notify_total, int64_t seq_total, void* stream);
 /* packed_sum(x [S,C], pack_infos) -> out [P,C]   (single_volume_renderer.py:84-101) */
 int nsim_packed_sum(const float* x, int C, const int64_t* pack_infos, int64_t P, float* out, void* stream);
 /* out[s,c] = x[s,c] (op) per_pack[p, c or 0]; op 0 mul, 1 div, 2 add, 3 sub; x may be NULL (treated as 1 for

@@ -72,7 +72,7 @@ _F = C.c_float
 SIGNATURES = {
     "nsim_pack_infos_from_n": [_P, _I64, _P, _P, _I64],
     "nsim_pack_infos_from_n_notify": [_P, _I64, _P, _P, _I64, _P, _I64],
-    "nsim_live_rank": [_P, _I64, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I64],
+    "nsim_live_rank": [_P, _I64, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64],
     "nsim_packed_sum": [_P, _I, _P, _I64, _P],
     "nsim_packed_binary": [_P, _I, _P, _I, _P, _I64, _I, _P],
     "nsim_packed_cmp": [_P, _P, _P, _I64, _I, _P],

@@ -83,9 +83,13 @@ struct LiveArgs {
   int C;
   int nf[4];
 };
+// pi (may be NULL): the pack infos of n as k_pack_infos_from_n writes them (cap, total, notify_total alike) -- the sampling
+// pass needs both from the same counts, one launch instead of two single-workgroup scans back to back (9 us each).
 __global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restrict__ n, int64_t R, LiveArgs la,
                                                            int64_t* __restrict__ live_rank, int64_t* __restrict__ live_idx,
-                                                           int64_t* __restrict__ cnts, int64_t* notify, int64_t seq) {
+                                                           int64_t* __restrict__ cnts, int64_t* notify, int64_t seq,
+                                                           int64_t* __restrict__ pi, int64_t* __restrict__ total, int64_t cap,
+                                                           int64_t* notify_total, int64_t seq_total) {
   __shared__ int64_t wtot[PI_THREADS / 64];
   const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
   const int64_t LIVE1 = (int64_t)1 << 44;        // (live count << 44) | sample count: one scan carries both sums
@@ -120,6 +124,12 @@ __global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restr
         const bool live = v[k] >= LIVE1;
         live_rank[i] = live ? q : ~q;
         if (live && live_idx) live_idx[q] = i;
+        if (pi) {      // (k_pack_infos_from_n's rule for a speculative capacity)
+          const int64_t off = run & LOW, c = v[k] & LOW;
+          const bool over = cap >= 0 && off + c > cap;
+          pi[2 * i] = (cap >= 0 && off > cap) ? cap : off;
+          pi[2 * i + 1] = over ? 0 : c;
+        }
       }
       run += v[k];
     }
@@ -136,9 +146,14 @@ __global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restr
     for (int k = 0; k < 4; ++k) cnts[2 + k] = Rl * la.nf[k];
     cnts[6] = M;
     cnts[7] = 0;
+    if (total) total[0] = M;
     if (notify) {
       nsim_store_system(notify, Rl, false);
       nsim_store_system(notify + 1, seq, true);
+    }
+    if (notify_total) {
+      nsim_store_system(notify_total, M, false);
+      nsim_store_system(notify_total + 1, seq_total, true);
     }
   }
 }
@@ -905,14 +920,15 @@ int nsim_pack_infos_from_n_notify(const int64_t* n, int64_t P, int64_t* pack_inf
 }
 
 int nsim_live_rank(const int64_t* n, int64_t R, int C, int nf0, int nf1, int nf2, int nf3, int64_t* live_rank, int64_t* live_idx,
-                   int64_t* cnts, int64_t* notify, int64_t seq, void* stream) {
+                   int64_t* cnts, int64_t* notify, int64_t seq, int64_t* pack_infos, int64_t* total, int64_t cap,
+                   int64_t* notify_total, int64_t seq_total, void* stream) {
   if (R <= 0) return 2;
   if (!n || !live_rank || !cnts || C < 0) return 4;
   LiveArgs la;
   la.C = C;
   la.nf[0] = nf0, la.nf[1] = nf1, la.nf[2] = nf2, la.nf[3] = nf3;
   hipLaunchKernelGGL(k_live_rank, dim3(1), dim3(PI_THREADS), 0, (hipStream_t)stream, n, R, la, live_rank, live_idx, cnts, notify,
-                     seq);
+                     seq, pack_infos, total, cap, notify_total, seq_total);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -1130,26 +1130,31 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                   _lib.ptr(bits), _lib.ptr(woff), occm, step, max_steps, _lib.ptr(counts))
         nt = self._host_notify() if cap is not None else None
         self._notify_seq_m = None
-        if nt is not None:      # the true marched total travels to host-mapped words (read at the compress step's wait)
-            adr, self._notify_seq_m = nt.arm(0)
-            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=int(cap), notify=(adr, self._notify_seq_m))
-        else:
-            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
         fine = fine_list(qp)
         # ``upsample_on_marched_only``: ranks of the rays whose march found something (q-th live ray <-> ray r) and the
         # device-side point counts of this pass's SDF queries -- coarse / fine samples and their queries cover R' rays
         mo = marched_only(qp)
         lr = live_idx = cnts = None
         self._live = None
-        if mo:
+        adr_m = None
+        if nt is not None:      # the true marched total travels to host-mapped words (read at the compress step's wait)
+            adr_m, self._notify_seq_m = nt.arm(0)
+        if mo:                  # ONE single-workgroup scan: pack infos of the marched counts + the live ranks
             assert len(fine) <= 4, "upsample_on_marched_only: at most four up-sampling stages"
             lr = torch.empty([R], dtype=torch.long, device=dev)
             live_idx = torch.empty([R], dtype=torch.long, device=dev)
             cnts = torch.empty([8], dtype=torch.long, device=dev)
+            pi_m = torch.empty([R, 2], dtype=torch.long, device=dev)
+            total_m = torch.empty([1], dtype=torch.long, device=dev)
             adr_l, seq_l = nt.arm(2) if nt is not None else (None, 0)
             _lib.call("nsim_live_rank", _lib.ptr(counts), R, C, *((list(fine) + [0, 0, 0, 0])[:4]), _lib.ptr(lr), _lib.ptr(live_idx),
-                      _lib.ptr(cnts), adr_l, seq_l)
+                      _lib.ptr(cnts), adr_l, seq_l, _lib.ptr(pi_m), _lib.ptr(total_m), -1 if cap is None else int(cap), adr_m,
+                      self._notify_seq_m or 0)
             self._live = dict(rank=lr, idx=live_idx, cnts=cnts, seq=seq_l if nt is not None else None, n=None)
+        elif nt is not None:
+            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=int(cap), notify=(adr_m, self._notify_seq_m))
+        else:
+            pi_m, total_m = po.get_pack_infos_from_n(counts, return_total=True, cap=-1 if cap is None else int(cap))
         Rl = R                                  # rays that get coarse / fine samples (an upper bound when sized speculatively)
         if cap is None:
             if pre_sync_hook is not None:

@@ -44,6 +44,29 @@ class Drawable:
                                                   self.scale)
 
 
+def _rays_in_objects(grp, rays_o, rays_d):
+    """World -> object rays of all the items of a batched group at once, [B', N, 3] each: the broadcast-multiply-sum of
+    ``convert_rays_in_node`` (scenes.py:686-708) with the items' poses stacked -- the same element-wise operations in the same
+    order as one call per item (bit-identical), in 7 launches instead of 14 per item (the 8-vehicle step issued 112 here)."""
+    if all(dr.rotation is None for dr in grp):
+        B = len(grp)
+        return rays_o.unsqueeze(0).expand(B, *rays_o.shape).contiguous(), rays_d.unsqueeze(0).expand(B, *rays_d.shape).contiguous()
+    eye = torch.eye(3, device=rays_o.device, dtype=rays_o.dtype)
+    rot = torch.stack([dr.rotation.to(rays_o) if dr.rotation is not None else eye for dr in grp])                     # [B', 3, 3]
+    tr = torch.stack([dr.translation.to(rays_o) if dr.rotation is not None else torch.zeros_like(eye[0]) for dr in grp])
+    sc = torch.stack([torch.as_tensor(dr.scale if dr.rotation is not None else 1.0, dtype=rays_o.dtype, device=rays_o.device).reshape(())
+                      for dr in grp])
+    Rt = rot.transpose(-1, -2)[:, None]                                                                                # [B', 1, 3, 3]
+    o = ((rays_o[None] - tr[:, None]).unsqueeze(-2) * Rt).sum(-1)
+    d = (rays_d[None].unsqueeze(-2) * Rt).sum(-1)
+    # ``x / python_scalar`` (the per-item form) is a multiplication by the f32 reciprocal on the device and a true division on
+    # the host (ATen): the same here, so that the stacked form reproduces the per-item one bit for bit on either
+    if rays_o.is_cuda:
+        inv = (1.0 / sc)[:, None, None]
+        return o * inv, d * inv
+    return o / sc[:, None, None], d / sc[:, None, None]
+
+
 class BufferComposeRenderer(nn.Module):
     def __init__(self, config: Optional[dict] = None):
         super().__init__()
@@ -93,8 +116,7 @@ class BufferComposeRenderer(nn.Module):
             cls = grp[0].class_name
             qcfg = self._query_cfg(model, with_rgb, with_normal, bypass.get(cls))
             if getattr(model, "is_batched_query_supported", False):
-                oo = torch.stack([dr.rays_in_object(rays_o, rays_d)[0] for dr in grp])      # [B', N, 3]
-                dd = torch.stack([dr.rays_in_object(rays_o, rays_d)[1] for dr in grp])
+                oo, dd = _rays_in_objects(grp, rays_o, rays_d)                               # [B', N, 3]
                 extra = {}
                 if rays_h_appear is not None:
                     extra["rays_h_appear"] = rays_h_appear.unsqueeze(0).expand(len(grp), *rays_h_appear.shape)

@@ -89,3 +89,20 @@ def test_compose_single_plus_batched(backend):
     assert float(main.encoding.flattened_params.grad.abs().sum()) > 0
     g = mb.encoding.flattened_params.grad.view(3, -1)
     assert float(g[0].abs().sum()) > 0 and float(g[2].abs().sum()) > 0 and float(g[1].abs().max()) == 0.0
+
+
+def test_stacked_ray_conversion_equals_the_per_item_one(backend):
+    """``_rays_in_objects`` (all items of a batched group in one broadcast) == ``Drawable.rays_in_object`` per item, bit for bit
+    (posed, un-posed and mixed groups)."""
+    from neuralsim_amd.renderers.buffer_compose_renderer import _rays_in_objects
+    g = torch.Generator().manual_seed(2)
+    o = (torch.randn(257, 3, generator=g) * 3).to(backend)
+    d = torch.nn.functional.normalize(torch.randn(257, 3, generator=g), dim=-1).to(backend)
+    posed = [Drawable(f"c{i}", "Vehicle", None, rotation=_rot_y(0.3 * i + 0.1).to(backend), translation=(torch.randn(3, generator=g) * 2).to(backend),
+                      scale=0.45 + 0.07 * i) for i in range(5)]
+    plain = [Drawable(f"p{i}", "Vehicle", None) for i in range(2)]
+    for grp in (posed, plain, posed[:2] + plain + posed[2:]):
+        oo, dd = _rays_in_objects(grp, o, d)
+        for i, dr in enumerate(grp):
+            oi, di = dr.rays_in_object(o, d)
+            assert torch.equal(oo[i], oi) and torch.equal(dd[i], di), (i, float((oo[i] - oi).abs().max()))

@@ -429,6 +429,7 @@ def test_render_head_against_the_oracle(backend, every_ray):
 
         def rel(a_, b_):
             return float((a_.cpu().double() - b_).norm() / b_.norm().clamp_min(1e-12))
-        assert rel(b["drgb"][:S], rgb64.grad) < 2e-5 and rel(b["dnab"], nab64.grad) < 2e-5
+        # (d rgb = vw x 2 e / 3N with e = pred - gt ~ 3e-3 formed in f32 from O(1) values: relative error ~ 1e-7 / 3e-3)
+        assert rel(b["drgb"][:S], rgb64.grad) < 2e-4 and rel(b["dnab"], nab64.grad) < 2e-5
         assert rel(b["dsdf"][:S], sdf64.grad) < 2e-4, rel(b["dsdf"][:S], sdf64.grad)
         assert abs(float(b["dln"].cpu()) - float(ln64.grad)) < 2e-3 * abs(float(ln64.grad)) + 1e-9

@@ -464,7 +464,16 @@ def test_live_rank_and_compact_sampling(backend):
     lr = torch.full([R], 123, dtype=torch.long, device=backend)
     lidx = torch.full([R], 123, dtype=torch.long, device=backend)
     cnts = torch.zeros(8, dtype=torch.long, device=backend)
-    _lib.call("nsim_live_rank", _lib.ptr(dv(counts)), R, C, *nfs, _lib.ptr(lr), _lib.ptr(lidx), _lib.ptr(cnts), None, 0)
+    from neuralsim_amd.graphics import pack_ops as ppo
+    for cap in (-1, 100, 700):          # the same launch also emits the pack infos of the counts (nsim_pack_infos_from_n's rule for a capacity)
+        pi_k = torch.full([R, 2], -7, dtype=torch.long, device=backend)
+        tot_k = torch.zeros(1, dtype=torch.long, device=backend)
+        _lib.call("nsim_live_rank", _lib.ptr(dv(counts)), R, C, *nfs, _lib.ptr(lr), _lib.ptr(lidx), _lib.ptr(cnts), None, 0,
+                  _lib.ptr(pi_k), _lib.ptr(tot_k), cap, None, 0)
+        pi_w, tot_w = ppo.get_pack_infos_from_n(dv(counts), return_total=True, cap=cap)
+        assert torch.equal(pi_k, pi_w) and torch.equal(tot_k, tot_w), cap
+    _lib.call("nsim_live_rank", _lib.ptr(dv(counts)), R, C, *nfs, _lib.ptr(lr), _lib.ptr(lidx), _lib.ptr(cnts), None, 0,
+              None, None, -1, None, 0)
     q = torch.cumsum(live.long(), 0) - live.long()
     assert torch.equal(lr.cpu(), torch.where(live, q, ~q))
     assert torch.equal(lidx.cpu()[:Rl], live.nonzero()[:, 0]) and bool((lidx.cpu()[Rl:] == 0).all())
