@@ -668,7 +668,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     # limited by the TCP -> TCC request rate (one 128-byte line per distinct line touched), the gradient scatter by the rate
     # of atomic requests; both ceilings are measured by micro-benchmarks on this chip, the kernels' request counts by PMC
     # passes of this command (profiles/round4_l2_requests.json -- recorded, NOT collected by the run that prints this line)
-    lf = ROOT / "profiles" / "round4_l2_requests.json"
+    lf = ROOT / "profiles" / "l2_requests.json"
+    if not lf.exists():
+        lf = ROOT / "profiles" / "round4_l2_requests.json"
     if lf.exists() and workload is None:
         try:
             rec_l = json.loads(lf.read_text())
@@ -681,8 +683,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                 scatter=dict(kernel="k_lotd_scatter", atomic_req_per_launch=sc_["atomic_req"],
                              achieved_Greq_s=sc_["atomic_req_per_s_G"], ceiling_Greq_s=rec_l["calibration"]["atomic_req_ceiling_per_s"] / 1e9,
                              frac=sc_["frac_of_atomic_req_ceiling"]),
-                source="profiles/round4_l2_requests.json (rocprofv3 --pmc TCP_TCC_READ_REQ_sum / TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum "
-                       "passes of this command + tools/gather_pair_bench, tools/atomic_bench4), recorded")
+                source=f"profiles/{lf.name} (rocprofv3 --pmc TCP_TCC_READ_REQ_sum / TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum passes of this "
+                       f"command + tools/gather_pair_bench, tools/atomic_bench4), recorded {rec_l.get('_recorded', 'round 4')} -- NOT "
+                       "collected by the run that prints this line")
         except Exception:
             pass
     # The MFMA kernels against the ceiling of their own CHAIN (round 5): tools/decoder_chain_bench.hip runs the 32 -> 64 -> 64 -> 1

@@ -12,9 +12,9 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "round1"
 ABI = {
     "nsim_lotd_gather_lm": "k_lotd_gather_lm<1, false>",   # round 3: f32 feature planes for the split-precision decoder
     "nsim_field_sdf": "k_field_sdf<2, 2, true",            # round 3: the sampling pass runs the split-precision decoder
-    "nsim_field_fwd": "k_field<0, 2, 3>",            # decoder half; its gather half is k_lotd_gather_lm<0, true>
+    "nsim_field_fwd": "k_field<0, 2, 3",             # decoder half; its gather half is k_lotd_gather_lm<0, true>
     "nsim_field_fwd(gather)": "k_lotd_gather_lm<0, true>",
-    "nsim_field_bwd_sdf": "k_field_bwd_j<0, 2>",
+    "nsim_field_bwd_sdf": "k_field_bwd_j<0, 2",
     "nsim_field_bwd_rad": "k_rad_bwd_j<0>",
     "nsim_lotd_scatter": "k_lotd_scatter",
 }
@@ -92,6 +92,42 @@ def main():
                  "(gfx94x derived-metric formula); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; "
                  "waves_per_cu_cycle = SQ_WAVE_CYCLES / SQ_BUSY_CU_CYCLES = resident waves per busy CU (4 SIMDs).",
             kernels=ks), indent=1))
+    # L2-side request counters (round 4: by hand; round 5: this block): the gathers against the L2 -> L1 request ceiling, the
+    # scatter against the atomic-request ceiling -- bench.py quotes profiles/l2_requests.json as roofline.cache_ceilings
+    l2 = G / "prof_pmc_l2.json"
+    if l2.exists():
+        q = json.loads(l2.read_text())
+        disp = {d["name"]: d for d in q.get("dispatch", [])}
+        CEIL_R, CEIL_A = 267e9, 20.7e9
+        ks = {}
+        for name, c in q.get("pmc", {}).items():
+            if "k_lotd_gather_lm" not in name and "k_lotd_scatter" not in name:
+                continue
+            v = {k: x["avg"] for k, x in c.items()}
+            d = disp.get(name)
+            us = d["avg_ns"] / 1e3 if d else None
+            rec = dict(launches=int(next(iter(c.values()))["n"]), avg_us_under_pmc=round(us, 1) if us else None,
+                       tcp_tcc_read_req=int(v.get("TCP_TCC_READ_REQ_sum", 0)), tcp_cache_accesses=int(v.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0)),
+                       atomic_req=int(v.get("TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum", 0)), tcc_hit=int(v.get("TCC_HIT_sum", 0)),
+                       tcc_miss=int(v.get("TCC_MISS_sum", 0)))
+            if us:
+                rec["read_req_per_s"] = round(rec["tcp_tcc_read_req"] / (us * 1e-6) / 1e9, 1)
+                rec["frac_of_l2_read_req_ceiling"] = round(rec["tcp_tcc_read_req"] / (us * 1e-6) / CEIL_R, 3)
+                if rec["atomic_req"]:
+                    rec["atomic_req_per_s_G"] = round(rec["atomic_req"] / (us * 1e-6) / 1e9, 2)
+                    rec["frac_of_atomic_req_ceiling"] = round(rec["atomic_req"] / (us * 1e-6) / CEIL_A, 3)
+            ks[name] = rec
+        rec_all = dict(
+            command="rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum "
+                    f"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity  (tools/refresh_profiles.sh; MI355X, {TAG}, tree after commit {sha})",
+            calibration=dict(what="tools/gather_pair_bench: a random 4-byte gather from an L2-resident table sustains 256-267 G TCP->TCC "
+                                  "read requests/s (profiles/round4_gather_pair_bench.txt) -- the L2 -> L1 request ceiling; tools/atomic_bench4 / "
+                                  "tools/atomic_alloc_bench: 20.7-21.0 G 16-byte atomic requests/s whatever the scope, table size, XCD partition "
+                                  "or allocation (profiles/round4_atomic_scope_probe.txt, profiles/round5_atomic_alloc_bench.txt)",
+                             l2_read_req_ceiling_per_s=CEIL_R, atomic_req_ceiling_per_s=CEIL_A),
+            kernels=ks)
+        (P / f"{TAG}_l2_requests.json").write_text(json.dumps(rec_all, indent=1))
+        (P / "l2_requests.json").write_text(json.dumps(dict(rec_all, _recorded=f"{TAG} (tree after commit {sha})"), indent=1))
     # round 3: the distant-model step, the street configuration, per-level scatter timing
     def table(src, steps, title, dst, own_only=False):
         f = G / src

@@ -21,6 +21,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o w -- $C
 python $R/tools/prof_summary.py $(find /tmp/p_write -name "*.db" | head -1) $O/prof_pmc_write.json
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/p_sq -o q -- $CMD > /dev/null 2>/tmp/e4.log
 python $R/tools/prof_summary.py $(find /tmp/p_sq -name "*.db" | head -1) $O/prof_pmc_sq.json
+# L2-side request counters of the same command (own pass): read requests of the gathers, atomic requests of the scatter
+timeout 600 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d /tmp/p_l2 -o c -- $CMD > /dev/null 2>/tmp/e8.log
+python $R/tools/prof_summary.py $(find /tmp/p_l2 -name "*.db" | head -1) $O/prof_pmc_l2.json
 # the distant-model step and the street configuration: kernel stats (steady state: 24 / 12 steps incl. warm-up)
 DCMD="python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_dist -o s -- $DCMD > $O/prof_distant_bench.json 2>/tmp/e5.log
@@ -30,6 +33,7 @@ python $R/tools/prof_summary.py $(find /tmp/p_dsq -name "*.db" | head -1) $O/pro
 SCMD="python $R/bench.py --config street --steps 8 --warmup 4"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_street -o s -- $SCMD > $O/prof_street_bench.json 2>/tmp/e7.log
 python $R/tools/prof_summary.py $(find /tmp/p_street -name "*.db" | head -1) $O/prof_street_stats.json
+[ "${NSIM_PROFILE_EXTRAS:-0}" = "1" ] || exit 0      # the round-3 A/B legs below only on request
 timeout 300 python $R/tools/scatter_levels.py $O/prof_scatter_levels.json > /dev/null 2>&1
 # fused 4-D gather A/B WITHOUT a profiler on either side
 timeout 300 python $R/bench.py --distant --steps 16 --warmup 8 --no-cpu-baseline --no-variants --no-parity > $O/prof_distant_lmgather.json 2>/dev/null
