@@ -54,16 +54,20 @@ def _rays_in_objects(grp, rays_o, rays_d):
     eye = torch.eye(3, device=rays_o.device, dtype=rays_o.dtype)
     rot = torch.stack([dr.rotation.to(rays_o) if dr.rotation is not None else eye for dr in grp])                     # [B', 3, 3]
     tr = torch.stack([dr.translation.to(rays_o) if dr.rotation is not None else torch.zeros_like(eye[0]) for dr in grp])
-    sc = torch.stack([torch.as_tensor(dr.scale if dr.rotation is not None else 1.0, dtype=rays_o.dtype, device=rays_o.device).reshape(())
-                      for dr in grp])
+    scales = [dr.scale if dr.rotation is not None else 1.0 for dr in grp]
+    if any(torch.is_tensor(s_) for s_ in scales):       # a learnable / tensor scale: the per-item form
+        pairs = [dr.rays_in_object(rays_o, rays_d) for dr in grp]
+        return torch.stack([p_[0] for p_ in pairs]), torch.stack([p_[1] for p_ in pairs])
     Rt = rot.transpose(-1, -2)[:, None]                                                                                # [B', 1, 3, 3]
     o = ((rays_o[None] - tr[:, None]).unsqueeze(-2) * Rt).sum(-1)
     d = (rays_d[None].unsqueeze(-2) * Rt).sum(-1)
-    # ``x / python_scalar`` (the per-item form) is a multiplication by the f32 reciprocal on the device and a true division on
-    # the host (ATen): the same here, so that the stacked form reproduces the per-item one bit for bit on either
+    # ``x / python_scalar`` (the per-item form) is, in ATen, on the device a multiplication by the reciprocal formed on the HOST
+    # in double and rounded to f32 (BinaryDivTrueKernel: ``inv_b = opmath_t(1.0 / double(b))``), on the host a true division:
+    # the same here, so that the stacked form reproduces the per-item one bit for bit on either
     if rays_o.is_cuda:
-        inv = (1.0 / sc)[:, None, None]
-        return o * inv, d * inv
+        inv = torch.tensor([1.0 / float(s_) for s_ in scales], dtype=torch.float64).to(rays_o.dtype).to(rays_o.device)
+        return o * inv[:, None, None], d * inv[:, None, None]
+    sc = torch.tensor([float(s_) for s_ in scales], dtype=rays_o.dtype, device=rays_o.device)
     return o / sc[:, None, None], d / sc[:, None, None]
 
 
