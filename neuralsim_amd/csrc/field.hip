@@ -1564,6 +1564,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
       p.valid = p.s < Sv;
     } else {
       p = load_point(a, tile, j, false);
+      p.valid = p.valid && p.s < Sv;            // (a device-side point count below the capacity: round 5)
     }
     const char* cur = nullptr;
     if constexpr (GL) {
@@ -2461,7 +2462,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   a.wpack = (const char*)wpack;
   a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.ridx = ridx;
   a.ray_goff = ray_goff;
-  a.S_dev = feat_planes ? n_dev : nullptr;   // the speculative size applies to the level-major path only
+  a.S_dev = n_dev;                            // (round 5: the point-major form honours a device-side point count as well)
   a.S_add = n_add;
   a.S = S;
   a.PS = NSIM_PLANE_PITCH(S);
@@ -2488,7 +2489,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
   const dim3 grid(field_grid(S, sdf_grid)), block(64 * FIELD_WAVES);
   size_t shmem = weights_lds_bytes(meta, 0, 2);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
-  if (meta->precision == 2 && !feat_scratch) return 33;     // split precision: level-major path only
+  // (split precision without planes -- the fused point-major form -- exists for <= 16 levels since round 5: small launches)
   static const bool sdf_glds = !(getenv("NSIM_SDF_GLDS") && atoi(getenv("NSIM_SDF_GLDS")) == 0);
   const int nc = field_nc(meta->lotd.num_levels);
   const bool gl = sdf_glds && feat_scratch;
@@ -2526,6 +2527,8 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
       case 1: hipLaunchKernelGGL((k_field_sdf<0, 2, false>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((k_field_sdf<1, 1, false>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 3: hipLaunchKernelGGL((k_field_sdf<1, 2, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((k_field_sdf<2, 1, false>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL((k_field_sdf<2, 2, false>), grid, block, shmem, (hipStream_t)stream, a); break;
     }
   }
   NSIM_CHECK_LAUNCH();

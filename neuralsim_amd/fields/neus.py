@@ -102,6 +102,7 @@ _SPEC_FORWARD = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
 # evaluation (no-grad) forward through the level-major gather + the decoders on the planes instead of the fused point-major
 # kernel (k_field<0,2,1,1>: 512 registers + 61 spilled, one wave per SIMD).  Round 5 A/B: see DESIGN.md sec. 4
 _EVAL_PLANES = os.environ.get("NSIM_EVAL_PLANES", "0") == "1"
+_SDF_FUSED_BELOW = int(os.environ.get("NSIM_SDF_FUSED_BELOW", "0"))
 # up-sampling: the merge of stage k and the draws of stage k + 1 as ONE launch (nsim_merge_upsample; 0: two launches)
 _FUSE_MERGE_UPSAMPLE = os.environ.get("NSIM_FUSE_MERGE_UPSAMPLE", "1") == "1"
 
@@ -1012,7 +1013,11 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             return sdf
         fm = self.field_meta if fm is None else fm
         planes = None
-        if not self._sdf_fused:
+        # small launches (the first up-sampling draws: R' x 8 points) as ONE fused point-major launch instead of the level-major
+        # gather + the decoder on the planes: NSIM_SDF_FUSED_BELOW = capacity in points (0: never; measured in DESIGN sec. 4)
+        small = (_SDF_FUSED_BELOW > 0 and S <= _SDF_FUSED_BELOW and x is not None and goff is None and self.plane_levels == 16
+                 and type(self)._enc_gather_feat is LoTDNeuSModel._enc_gather_feat)
+        if not self._sdf_fused and not small:
             # [NLP][P] x (f16x2 | f32x2), P = the 32-point pitch: every tile of a level is one aligned piece (LDS-DMA)
             planes = torch.empty([self.plane_levels * _lib.plane_pitch(S) * (1 if fm.precision == 0 else 2)],
                                  dtype=torch.float32, device=dev)

@@ -510,3 +510,30 @@ def test_field_with_relu_sdf_decoder(backend, precision, sdf_D):
     for k, v in got.items():
         e = rel_l2(v.cpu(), ref[k])
         assert e < tol[3], (k, e)
+
+
+def test_small_sdf_query_fused_point_major_equals_level_major(backend, monkeypatch):
+    """Round 5: a small no-grad SDF launch of the sampling pass (split precision) as ONE fused point-major launch
+    (``NSIM_SDF_FUSED_BELOW``) == the level-major gather + the decoder on the planes, also with a device-side point count below
+    the capacity (points past it are neither read nor folded into the occupancy values)."""
+    from neuralsim_amd.fields import neus as nmod
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=5, ln_inv_s=0.45, grid_bound=2e-2, noise_scale=1.0)
+    m = model_from_params(p, backend, precision="fp16")
+    assert m.sampling_precision == "split"
+    g = torch.Generator().manual_seed(4)
+    S = 1000
+    x = (torch.rand(S, 3, generator=g) * 1.8 - 0.9).to(backend)
+    x[700:] = float("nan")                                   # past the device-side count: must not be touched
+    fm_s, wpack = m._sampling_ctx()
+    grid16, _ = m._shadow()
+    n_dev = torch.tensor([640], dtype=torch.long, device=backend)
+    outs = []
+    for below in (0, 4096):
+        monkeypatch.setattr(nmod, "_SDF_FUSED_BELOW", below)
+        m.accel.occ_val.zero_()
+        full = m._sdf_query(grid16, wpack, x[:700].contiguous(), None, None, None, None, 700, backend, fm=fm_s)
+        part = m._sdf_query(grid16, wpack, x, None, None, None, None, S, backend, n_dev=n_dev, n_add=60, collect=True, fm=fm_s)
+        outs.append((full.cpu(), part.cpu()[:700], m.accel.occ_val.cpu().clone()))
+    (f0, p0, o0), (f1, p1, o1) = outs
+    assert torch.equal(f0, f1) and torch.equal(p0, p1) and torch.equal(f0, p0)
+    assert torch.equal(o0, o1) and bool(torch.isfinite(o1).all()) and float(o1.max()) > 0
