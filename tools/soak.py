@@ -32,7 +32,8 @@ def main():
             else:
                 redo += 1
         if it % 500 == 0 or it == steps - 1:
-            rec.append(dict(it=it, loss=round(float(loss), 6), S_f=tr.stats["S_f"], R_hit=tr.stats["R_hit"],
+            rec.append(dict(it=it, loss=round(float(loss), 6), S_f=tr.stats["S_f"], S_q=tr.stats.get("S_q"), R_hit=tr.stats["R_hit"],
+                            R_live=tr.stats.get("R_live"),
                             occupied=round(m.accel.frac_occupied(), 4),
                             mem_MB=round(torch.cuda.max_memory_allocated() / 2 ** 20, 1),
                             reserved_MB=round(torch.cuda.memory_reserved() / 2 ** 20, 1)))
