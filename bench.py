@@ -730,6 +730,8 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                            "Adam + occupancy refresh every 16 it inside the timed region",
                            rays_per_gpu=rays_per_gpu, parallelism=f"dp{world} (rays sharded, RCCL grad all-reduce)",
                            upsample_on_marched_only=_mo(tr),
+                           adam="touched-entries tables (NSIM_LAZY_ADAM=1, opt-in: NOT the reference's optimizer)"
+                           if getattr(tr.optim, "lazy_tables", False) else "dense (the reference's torch.optim.Adam rule)",
                            # realised sample statistics: rays that pass the AABB test / whose march finds occupied
                            # voxels, SDF-only queries of the sampling pass (S_q) and with-grad samples (S_f) per step
                            samples_per_hit_ray=round(S_f / max(1, S_hit), 1),

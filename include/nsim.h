@@ -535,7 +535,9 @@ int nsim_sphere_image(const float* rays_o, const float* rays_d, int64_t N, float
 
 /* ------------------------------------------------------------------------------- optimizer */
 /* Adam (training_cfg{eps 1e-15, betas [.9,.99]}, lotd_neus.dtu.230814.yaml:178-184) on f32 master params;
- * p16 (may be NULL) receives the fp16 copy used by the kernels; grad is scaled by grad_scale and zeroed. */
+ * p16 (may be NULL) receives the fp16 copy used by the kernels; grad is scaled by grad_scale; zero_grad bit 0: the gradient is
+ * zeroed; bit 1 (opt-in, SURVEY sec. 8f-3 "Adam only on touched hash entries"): entries whose gradient is exactly 0 this step
+ * are skipped entirely -- no moment decay, no update (torch.optim.SparseAdam's rule; NOT the reference's dense optimizer). */
 int nsim_adam_step(float* p, void* p16, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float bias1, float bias2, float grad_scale, int zero_grad,
                    void* stream);

@@ -10,8 +10,15 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, f16* __rest
                                                float grad_scale, int zero_grad) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // zero_grad: bit 0 = zero the gradient; bit 1 = TOUCHED-ENTRIES ("lazy") mode -- an entry whose gradient is exactly zero
+  // this step is left alone: no moment decay, no update, nothing but its gradient word read (the rule of
+  // torch.optim.SparseAdam).  Opt-in: a dense Adam moves such an entry by its decaying first moment, so the trajectory
+  // differs from the reference's optimizer.
+  const bool lazy = (zero_grad & 2) != 0;
+  zero_grad &= 1;
   for (; i < n; i += stride) {
     const float g = grad[i] * grad_scale;
+    if (lazy && g == 0.f) continue;
     const float mi = b1 * m[i] + (1.0f - b1) * g;
     const float vi = b2 * v[i] + (1.0f - b2) * g * g;
     m[i] = mi;

@@ -12,9 +12,16 @@ from . import _lib
 
 
 class FusedAdam:
-    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), eps=1e-15, learn_inv_s=True):
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), invs_betas=(0.9, 0.999), eps=1e-15, learn_inv_s=True,
+                 lazy_tables: bool = None):
+        """``lazy_tables`` (default: env NSIM_LAZY_ADAM=1, else False): the hash TABLES are updated on the entries a step touched
+        only -- an entry with a zero gradient keeps its moments and its value (torch.optim.SparseAdam's rule).
+        Opt-in and off by default: the reference trains with a dense Adam, which moves an untouched entry by its decaying first
+        moment, so the trajectory differs.  Decoder weights and scalars are always dense."""
+        import os
         self.model = model
         self.lr, self.eps = lr, eps
+        self.lazy_tables = (os.environ.get("NSIM_LAZY_ADAM", "0") == "1") if lazy_tables is None else bool(lazy_tables)
         self.groups = []
         enc = model.encoding
         enc.shadow()
@@ -91,7 +98,7 @@ class FusedAdam:
                 continue
             _lib.call("nsim_adam_step", _lib.ptr(p.data), _lib.ptr(p16), _lib.ptr(p.grad.contiguous()), _lib.ptr(g["m"]),
                       _lib.ptr(g["v"]), p.numel(), float(lr), float(b1), float(b2), float(self.eps),
-                      1.0 - b1 ** t, 1.0 - b2 ** t, float(grad_scale), 0)
+                      1.0 - b1 ** t, 1.0 - b2 ** t, float(grad_scale), 2 if (self.lazy_tables and p16 is not None) else 0)
         for k in range(0, len(small), _lib.ADAM_MULTI_MAX):
             chunk = small[k:k + _lib.ADAM_MULTI_MAX]
             arr = (_lib.AdamTensor * len(chunk))()
@@ -117,7 +124,7 @@ class FusedAdam:
         _lib.call("nsim_adam_step", _lib.ptr(p.data.view(-1)[lo:hi]), _lib.ptr(p16.view(-1)[lo:hi] if p16 is not None else None),
                   _lib.ptr(grad.contiguous()), _lib.ptr(g["m"].view(-1)[lo:hi]), _lib.ptr(g["v"].view(-1)[lo:hi]), hi - lo,
                   float(lr), float(b1), float(b2), float(self.eps), 1.0 - b1 ** t, 1.0 - b2 ** t,
-                  float(grad_scale), 0)
+                  float(grad_scale), 2 if (self.lazy_tables and p16 is not None) else 0)
 
     def zero_grad(self):
         for g in self.groups:

@@ -137,3 +137,37 @@ def test_group_without_gradient_is_skipped_and_keeps_its_own_step_count(backend)
     assert t[rad] == 3 and all(x == 5 for i, x in enumerate(t) if i != rad) and opt.t == 5
     for p, r in zip(ps, ref):
         assert float((p.detach().cpu() - r.detach()).abs().max()) <= 2e-6 * (1e-2 + float(r.detach().abs().max()))
+
+
+def test_lazy_table_adam_updates_touched_entries_only(backend):
+    """SURVEY sec. 8f-3 (opt-in, ``FusedAdam(lazy_tables=True)`` / NSIM_LAZY_ADAM=1): hash-table entries whose gradient is zero
+    in a step keep value AND moments; touched entries follow Adam with the group's step count (torch.optim.SparseAdam's rule,
+    restated here entry by entry); the decoder tensors stay dense; the default (False) is the reference's dense Adam."""
+    from neuralsim_amd.optim import FusedAdam
+    from test_trainer import _tiny
+    torch.manual_seed(0)
+    m = _tiny(backend)
+    opt = FusedAdam(m, lr=1e-2, eps=1e-15, lazy_tables=True)
+    assert FusedAdam(_tiny(backend), lr=1e-2).lazy_tables is False
+    gp = m.encoding.flattened_params
+    n = gp.numel()
+    p_ref, m_ref, v_ref = gp.detach().cpu().double().clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    w0 = m.sdf_w.detach().clone()
+    g = torch.Generator().manual_seed(2)
+    b1, b2 = 0.9, 0.99
+    for it in range(1, 5):
+        grad = torch.randn(n, generator=g) * 1e-3
+        grad[torch.rand(n, generator=g) < 0.6] = 0.0                      # 60 % of the entries untouched this step
+        gp.grad = grad.to(backend)
+        m.sdf_w.grad = torch.zeros_like(m.sdf_w)                           # a dense tensor with a zero gradient still decays / moves
+        m.sdf_w.grad[0] = 1e-3 if it == 1 else 0.0
+        opt.step()
+        t_ = grad != 0
+        gd = grad.double()
+        m_ref[t_] = b1 * m_ref[t_] + (1 - b1) * gd[t_]
+        v_ref[t_] = b2 * v_ref[t_] + (1 - b2) * gd[t_] ** 2
+        p_ref[t_] -= 1e-2 / (1 - b1 ** it) * m_ref[t_] / (v_ref[t_].sqrt() / (1 - b2 ** it) ** 0.5 + 1e-15)
+    assert float((gp.detach().cpu().double() - p_ref).abs().max()) < 1e-6
+    assert torch.equal(m.encoding.shadow().cpu(), gp.detach().half().cpu())           # the fp16 shadow follows the touched entries
+    # dense tensor: the entry touched only in step 1 kept moving in steps 2-4 (momentum), as dense Adam does
+    assert float((m.sdf_w.detach()[0] - w0[0]).abs()) > 1.5e-2
