@@ -65,9 +65,12 @@ class RenderTrainer:
         # the with-grad gather + decoders are queued at a capacity BEFORE the size of the kept sample set is read
         # (NSIM_SPEC_FORWARD=0: after it, at the exact size)
         self.spec_forward = os.environ.get("NSIM_SPEC_FORWARD", "1") == "1"
-        # the differentiable tail of the fused step (compositing, losses, their backward) as ONE launch (NSIM_RENDER_HEAD=0:
-        # the four launches it replaces)
-        self.render_head = os.environ.get("NSIM_RENDER_HEAD", "1") == "1"
+        # the differentiable tail of the fused step (compositing, losses, their backward): four launches (default since round 5), or
+        # ONE (NSIM_RENDER_HEAD=1, round 4's nsim_render_head).  Round 4 measured the two alike; with the marched-only sampling of
+        # round 5 (55 % of the rays carry empty packs) the four launches are ahead: 1.513 / 1.521 against 1.543 / 1.566 ms per
+        # step, alternated in one call (profiles/round5_render_head_ab.txt) -- one wave per ray walking its samples three times
+        # is the longer critical path (60 us against 8 + 8 + 7 + 13)
+        self.render_head = os.environ.get("NSIM_RENDER_HEAD", "0") == "1"
         # measurement aid (bench.py ``exposed_allreduce_ms``): every rank keeps its local gradients, no collective is issued
         self.skip_allreduce = False
         # synthetic supervision: None = random colours; r = analytic image of a Lambert-free sphere of radius r
