@@ -24,7 +24,8 @@ def init_env(backend: Optional[str] = None, device_type: str = "cuda"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if device_type == "cuda" else "gloo"
+            # NSIM_DIST_BACKEND=gloo: two ranks sharing ONE GPU (RCCL refuses duplicate devices) -- test / measurement aid
+            backend = os.environ.get("NSIM_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
