@@ -349,6 +349,9 @@ def main():
     if rank == 0 and args.config != "object":
         out["config"]["name"] = args.config
         out["config"]["launch_chain"] = "autograd"
+        # N > 1: the tables leave during the backward, one model's exchange under the next model's kernels
+        out["config"]["gradient_exchange"] = ("backward hooks (ndist.BackwardReducer)" if os.environ.get("NSIM_OVERLAP_ALLREDUCE", "1") == "1"
+                                              else "after the backward")
         print(json.dumps(out), flush=True)
     elif rank == 0:
         out["config"]["distant_model"] = bool(args.distant)

@@ -3,9 +3,10 @@
 Mirrors what the reference gets from ``nr3d_lib.distributed.init_env`` + ``DistributedDataParallel``
 (code_single/tools/train.py:1195,1401-1406): every rank holds a full replica (24-100 MB: trivial next to 288 GB
 of HBM), draws / receives its own shard of the ray batch, and the only data-path collective per step is ONE
-sum-all-reduce of the gradients.  No bucketing-by-autograd-hook is needed because the whole backward is a
-single fused kernel: the gradient set becomes available at once, as two flat buffers (the LoTD table gradient
-and the concatenated MLP/scalar gradients).
+sum-all-reduce of the gradients.  The fused launch chain of the headline step needs no bucketing-by-autograd-hook: its
+backward is a fixed kernel sequence and the table gradient leaves in two halves around the scatter
+(``RenderTrainer._dp_reduce_step``).  The autograd-path steps (street / indoor / multi-object: several models per
+backward) use ``BackwardReducer`` below: one table's exchange under the next model's backward kernels.
 """
 import os
 from typing import List, Optional, Sequence
@@ -232,6 +233,118 @@ def allreduce_finish(token):
     if buf is not t:
         t.copy_(buf)
     return t
+
+
+class BackwardReducer:
+    """The gradient exchange of an AUTOGRAD-path training step, overlapped with its backward (what DDP's bucketed
+    all-reduce does for the reference: ``DDP(trainer, find_unused_parameters=True)``, code_single/tools/train.py:1401-1406).
+
+    The steps of BASELINE configs[2..4] (street, indoor, multi-object) run several models through the autograd engine; the
+    engine finishes their table gradients one after the other (a model queried LATER in the forward gets its gradient
+    EARLIER).  A post-accumulate hook on every big parameter (>= ``small_numel`` entries: the hash tables) starts that
+    parameter's all-reduce the moment its gradient exists, so that it travels while the other models' backward kernels --
+    scatters of several ms -- still run; the small parameters go through one flat bucket after the backward, as in
+    ``allreduce_grads``.
+
+    Collectives are matched across ranks by ISSUE ORDER, and ranks may finish their gradients in different orders (or not at
+    all: a rank whose rays missed a model).  The big parameters therefore leave in ONE fixed order on every rank: parameter k
+    is released only once parameters 0..k-1 have been; whatever the backward did not release (in that order) is released by
+    ``finish``, absent gradients as zeros.  The order is the one rank 0 observed in the first armed step (broadcast then):
+    the first step runs without overlap, every later step overlaps whatever finishes in that order.
+
+    Use: ``r.begin(); loss.backward(); r.finish_small(); optim.step(skip=r.big); for p in r.finish_big(): optim.step_range(p)``
+    (``reduce_and_step`` does exactly that)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], small_numel: int = 1 << 20, wire_dtype: Optional[torch.dtype] = None):
+        self.params = list(params)
+        self.big = [p for p in self.params if p.numel() >= small_numel]
+        self.wire = wire_dtype
+        self._armed = False
+        self._order_known = False
+        self._fired: List[int] = []
+        self._ready = [False] * len(self.big)
+        self._toks = [None] * len(self.big)
+        self._next = 0
+        self.log: List[tuple] = []       # (big index, "backward" | "finish") per released parameter of the last step
+        self.on_release = None           # test hook: called with the big index right before its collective is issued
+        self._pos = {id(p): i for i, p in enumerate(self.big)}       # position of a parameter in the CURRENT release order
+        for p in self.big:
+            p.register_post_accumulate_grad_hook(lambda p_: self._on_grad(self._pos[id(p_)]))
+
+    def begin(self):
+        self._armed = True
+        self._fired = []
+        self._ready = [False] * len(self.big)
+        self._toks = [None] * len(self.big)
+        self._next = 0
+        self.log = []
+
+    def _start(self, k: int, where: str):
+        p = self.big[k]
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        elif not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
+        if self.on_release is not None:
+            self.on_release(k)
+        wire = self.wire if self.wire is not None else wire_dtype_default()
+        self._toks[k] = allreduce_start(p.grad, wire)
+        self.log.append((k, where))
+
+    def _on_grad(self, i: int):
+        if not self._armed:
+            return
+        self._fired.append(i)
+        self._ready[i] = True
+        if not self._order_known:        # first armed step: observe only
+            return
+        while self._next < len(self.big) and self._ready[self._next]:
+            self._start(self._next, "backward")
+            self._next += 1
+
+    def finish_small(self):
+        """After the backward: release what is left of the big parameters (fixed order), then reduce the small ones through
+        one flat f32 bucket (blocking: a few hundred KB) and write the sums back into their ``.grad``."""
+        self._armed = False
+        for k in range(self._next, len(self.big)):
+            self._start(k, "finish")
+        self._next = len(self.big)
+        small = [p for p in self.params if not any(p is q for q in self.big)]
+        if small:
+            for p in small:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p, dtype=torch.float32)
+            flat = torch.cat([p.grad.reshape(-1).float() for p in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for p in small:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        if not self._order_known:
+            # adopt rank 0's completion order (parameters it never saw a gradient for go last, in index order)
+            order = self._fired + [i for i in range(len(self.big)) if i not in self._fired]
+            t = torch.tensor(order, dtype=torch.int64, device=self.big[0].device if self.big else "cpu")
+            if self.big:
+                dist.broadcast(t, src=0)
+            order = [int(v) for v in t.tolist()]
+            self.big = [self.big[i] for i in order]
+            self._toks = [self._toks[i] for i in order]
+            self._pos = {id(p): i for i, p in enumerate(self.big)}
+            self._order_known = True
+
+    def finish_big(self):
+        """Yields every big parameter once its sum has arrived in ``.grad`` (issue order = arrival order)."""
+        for k, p in enumerate(self.big):
+            allreduce_finish(self._toks[k])
+            self._toks[k] = None
+            yield p
+
+    def reduce_and_step(self, optim, grad_scale: float):
+        self.finish_small()
+        optim.step(grad_scale=grad_scale, skip=tuple(self.big))
+        for p in self.finish_big():
+            optim.step_range(p, 0, p.numel(), p.grad.reshape(-1), grad_scale=grad_scale)
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0):

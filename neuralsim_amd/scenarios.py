@@ -22,6 +22,7 @@ dataio/data_loader/pixel_loader.py:323-327).
 CPU test-suite.  Used by bench.py (``variants.street_ms / indoor_ms / multi_ms``) and tests/test_fullsize_configs.py.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -436,6 +437,7 @@ class ComposeTrainer:
         if sky is not None:
             self.optim.add_sky_model(sky)
         self.skip_allreduce = False
+        self._reducer = None
         self.stats: Dict[str, float] = {}
 
     @property
@@ -482,11 +484,20 @@ class ComposeTrainer:
         ret = self.render(xy, fidx)
         loss, n_s = self.loss(ret, gt)
         self.optim.zero_grad()
+        red = None
+        if self.world_size > 1 and not self.skip_allreduce and os.environ.get("NSIM_OVERLAP_ALLREDUCE", "1") == "1":
+            if self._reducer is None:       # the table gradients leave during the backward (ndist.BackwardReducer)
+                self._reducer = ndist.BackwardReducer(self.optim.params())
+            red = self._reducer
+            red.begin()
         with backward_on_calling_thread():
             loss.backward()
-        if not self.skip_allreduce:
-            ndist.allreduce_grads(self.optim.params(), average=False)
-        self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
+        if red is not None:
+            red.reduce_and_step(self.optim, 1.0 / self.world_size)
+        else:
+            if not self.skip_allreduce:
+                ndist.allreduce_grads(self.optim.params(), average=False)
+            self.optim.step(grad_scale=1.0 if self.skip_allreduce else 1.0 / self.world_size)
         self.stats = dict(S_f=n_s, R_hit=int((ret["ray_intersections"]["samples_cnt"] > 0).sum()))
         return loss.detach()
 

@@ -405,6 +405,15 @@ class RenderTrainer:
                           S_q=int(getattr(model, "_last_S_q", 0) or 0))
         return torch.dot(acc, w_vec)
 
+    def _backward_reducer(self):
+        """The hook-driven gradient exchange of the autograd path (None: single rank, switched off, the measurement aid
+        ``skip_allreduce``, or a configuration that runs the fused launch chain with its own two-half schedule)."""
+        if self.world_size <= 1 or not self.overlap_allreduce or self.skip_allreduce or self._fused_ok():
+            return None
+        if getattr(self, "_reducer", None) is None:
+            self._reducer = ndist.BackwardReducer(self.optim.params())
+        return self._reducer
+
     def _dp_reduce_step(self, dgrid: torch.Tensor, scatter=None):
         """Data-parallel reduction + optimizer step with the hash-table gradient leaving in two halves: the all-reduce of
         the coarse half runs while the fine half is still being scattered (``scatter(level_begin, level_count)``), and
@@ -660,6 +669,9 @@ class RenderTrainer:
             self.optim.zero_grad()
             if refine:
                 self.pose_optim.zero_grad(set_to_none=True)
+            red = self._backward_reducer()
+            if red is not None:
+                red.begin()
             with backward_on_calling_thread():
                 loss.backward()
             vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
@@ -672,6 +684,10 @@ class RenderTrainer:
             self._dp_reduce_step(gp.grad if gp.grad is not None else torch.zeros_like(gp))
         if self._step_done:         # the overlapped data-parallel path reduced and stepped already
             self._step_done = False
+        elif self._backward_reducer() is not None:
+            # autograd-path configurations (distant / sky / lidar models next to the main one): the table gradients left
+            # during the backward, one model's exchange under the next model's scatter (ndist.BackwardReducer)
+            self._backward_reducer().reduce_and_step(self.optim, 1.0 / self.world_size)
         else:
             # sum over ranks; the 1/world of the mean is folded into the fused Adam pass (no extra sweep over 48 MB)
             if not self.skip_allreduce:

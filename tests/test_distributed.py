@@ -303,7 +303,7 @@ def test_two_rank_overlapped_schedule_on_gpu(tmp_path):
     assert float(a["losses"][-1]) < float(a["losses"][0]) and float(b["losses"][-1]) < float(b["losses"][0])
 
 
-def _street_worker(rank, world, port, out_dir, steps):
+def _street_worker(rank, world, port, out_dir, steps, overlap="1", tag=None):
     """The street trainer (configs[3] shape, small: NeuS street + distant + sky, pixel step AND lidar step per iteration) under
     ``world`` gloo ranks on the kernel emulator: the autograd-path schedule -- ``allreduce_grads`` after each backward, the
     lidar step with ``skip_absent`` (parameters outside its graph are neither reduced nor stepped on any rank)."""
@@ -311,6 +311,9 @@ def _street_worker(rank, world, port, out_dir, steps):
     sys.path.insert(0, str(ROOT / "tests"))
     sys.path.insert(0, str(ROOT / "tests" / "emu"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["NSIM_OVERLAP_ALLREDUCE"] = overlap
+    if tag is not None:
+        os.environ["NSIM_ALLREDUCE_DTYPE"] = "f32"       # exact sums: the two schedules must agree to the bit
     torch.set_num_threads(1)
     torch.manual_seed(0)
     import ctypes
@@ -324,9 +327,44 @@ def _street_worker(rank, world, port, out_dir, steps):
     dev = torch.device("cpu")
     tr = sc.build_street_trainer(dev, rank=rank, world_size=world, small=True, rays_per_gpu=32, lidar_rays=32, num_uniform=16, seed=42)
     assert not tr._fused_ok() and tr.distant_model is not None and tr.sky_model is not None
+    released = []
+    if overlap == "1":
+        # the small tables of this test count as "big" parameters: they leave through the hook-driven exchange
+        tr._reducer = red = nd.BackwardReducer(tr.optim.params(), small_numel=1 << 12)
+        names = {id(tr.model.encoding.flattened_params): "street_table", id(tr.distant_model.flattened_params): "distant_table"}
+        _lib.CALL_COUNT = 0
+        red.on_release = lambda k: released.append((names.get(id(red.big[k]), "other"), _lib.CALL_COUNT))
+        fin0 = red.finish_small
+
+        def finish_small():
+            released.append(("backward_done", _lib.CALL_COUNT))
+            fin0()
+        red.finish_small = finish_small
+    per_step = []
     for it in range(steps):
+        del released[:]
         loss = tr.train_step(it)
         assert float(loss) == float(loss)
+        per_step.append(list(released))
+    if overlap == "1":
+        assert {"street_table", "distant_table"} <= {n for n, _ in per_step[0]}, per_step[0]
+        # first armed step: the completion order is observed, nothing leaves before the backward is over
+        i0 = [n for n, _ in per_step[0]].index("backward_done")
+        assert i0 == 0, per_step[0]
+        # every later step: the table of the model whose backward finishes first leaves while kernels of the other models'
+        # backward are still being launched (ABI calls between its release and the end of the backward)
+        for ev in per_step[1:]:
+            seq = [n for n, _ in ev]
+            done = dict(ev)["backward_done"]
+            early = [(n, c) for n, c in ev[:seq.index("backward_done")]]
+            assert early and early[0][1] < done, ev
+            # the distant model's table is on its way before the street model's three backward launches + scatter are issued
+            assert dict(ev)["distant_table"] + 3 <= dict(ev)["street_table"] <= done, ev
+        # ... and every rank released in the same order
+        order = [n for n, _ in per_step[-1] if n != "backward_done"]
+        orders = [None] * world
+        dist.all_gather_object(orders, order)
+        assert all(o == orders[0] for o in orders), orders
     grp = {id(g["p"]): g for g in tr.optim.groups}
     assert grp[id(tr.model.sdf_w)]["t"] == 2 * steps and grp[id(tr.model.rad_w)]["t"] == steps       # lidar: no radiance update
     for name, t in (("grid", tr.model.encoding.flattened_params), ("sdf_w", tr.model.sdf_w), ("rad_w", tr.model.rad_w),
@@ -336,6 +374,11 @@ def _street_worker(rank, world, port, out_dir, steps):
         dist.all_gather(gs, g)
         assert all(torch.equal(gs[0], x) for x in gs[1:]), name
     dist.barrier()
+    if tag is not None and rank == 0:
+        torch.save({n: t.detach().clone() for n, t in (("grid", tr.model.encoding.flattened_params), ("sdf_w", tr.model.sdf_w),
+                                                         ("distant", tr.distant_model.flattened_params), ("sky", tr.sky_model.w),
+                                                         ("appear", tr.appear))}, str(Path(out_dir) / f"street_{tag}.pt"))
+        (Path(out_dir) / f"street_{tag}_events.txt").write_text(repr(per_step))
     (Path(out_dir) / f"street_ok{rank}").write_text("ok")
     dist.destroy_process_group()
 
@@ -346,6 +389,75 @@ def test_street_trainer_replicas_stay_in_sync(tmp_path, world):
     collective sequence whatever its batches hit, and the replicas are bit-identical after the all-reduced updates."""
     mp.spawn(_street_worker, args=(world, _free_port(), str(tmp_path), 2), nprocs=world, join=True)
     assert all((tmp_path / f"street_ok{r}").exists() for r in range(world))
+
+
+def test_street_exchange_overlaps_the_backward(tmp_path):
+    """The autograd-path exchange of configs[3] (``ndist.BackwardReducer``): from the second step on a table's all-reduce is
+    issued during the backward, before the kernels of the model that finishes last; all ranks release in one order; and the
+    overlapped schedule gives the bit-identical parameters of the plain one (``allreduce_grads`` after the backward) with an
+    exact wire."""
+    world = 2
+    for overlap, tag in (("1", "overlap"), ("0", "plain")):
+        mp.spawn(_street_worker, args=(world, _free_port(), str(tmp_path), 3, overlap, tag), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "street_overlap.pt"), torch.load(tmp_path / "street_plain.pt")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    ev = (tmp_path / "street_overlap_events.txt").read_text()
+    assert "distant_table" in ev and "street_table" in ev
+
+
+def _multi_worker(rank, world, port, out_dir, overlap, tag):
+    """The multi-object trainer (configs[4] shape, small: street + two posed vehicle instances of one shared model + distant +
+    sky through ``BufferComposeRenderer``) under ``world`` gloo ranks on the kernel emulator, exact wire."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NSIM_OVERLAP_ALLREDUCE=overlap, NSIM_ALLREDUCE_DTYPE="f32")
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    import ctypes
+    import build_emu
+    from neuralsim_amd import _lib, distributed as nd, scenarios as sc
+    lib = _lib.bind(ctypes.CDLL(str(build_emu.build())))
+    _lib.get_lib = lambda: lib
+    _lib.stream_handle = lambda: 0
+    _lib.require_device = lambda t, name="tensor": None
+    nd.init_env(backend="gloo", device_type="cpu")
+    tr = sc.build_multi_trainer(torch.device("cpu"), rank=rank, world_size=world, small=True, rays_per_gpu=32, seed=42, B=2)
+    if overlap == "1":
+        tr._reducer = nd.BackwardReducer(tr.optim.params(), small_numel=1 << 12)
+    logs = []
+    for it in range(3):
+        loss = tr.train_step(it)
+        assert float(loss) == float(loss)
+        if overlap == "1":
+            logs.append(list(tr._reducer.log))
+    state = {f"p{i}": p.detach().clone() for i, p in enumerate(tr.optim.params())}
+    for n, t in state.items():
+        gs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gs, t)
+        assert all(torch.equal(gs[0], x) for x in gs[1:]), n
+    if overlap == "1":
+        # street table, vehicle table (the shared model's grower), distant table, sky, decoder blocks >= 4096 entries
+        assert len(tr._reducer.big) >= 4
+        assert all(w == "finish" for _, w in logs[0]) and sum(w == "backward" for _, w in logs[-1]) >= 3, logs
+    if rank == 0:
+        torch.save(state, str(Path(out_dir) / f"multi_{tag}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_object_trainer_two_ranks_overlapped_exchange(tmp_path):
+    """configs[4]'s trainer at world size 2: replicas bit-identical after three steps, the hook-driven exchange releases the
+    models' tables during the backward, and its result equals the plain schedule's to the bit (exact wire)."""
+    world = 2
+    for overlap, tag in (("1", "overlap"), ("0", "plain")):
+        mp.spawn(_multi_worker, args=(world, _free_port(), str(tmp_path), overlap, tag), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "multi_overlap.pt"), torch.load(tmp_path / "multi_plain.pt")
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_bench_cli_gpus_2_becomes_two_ranks():
