@@ -374,7 +374,9 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
  * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again).
  * n_dev (may be NULL; needs the planes): the launch is sized for a CAPACITY S while the number of valid points,
  * n_dev[0] + n_add <= S, is read on the device -- the training step queues this launch before the host has read the
- * size of the kept sample set (a count above the capacity touches nothing; the caller redoes the launch). */
+ * size of the kept sample set (a count above the capacity touches nothing; the caller redoes the launch).
+ * wpack == NULL (needs grid_f16 and the planes): GATHER ONLY -- the planes are written, no decoder runs (the caller's
+ * decoder is another one: nsim_wide_fwd); sdf / nablas / rgb are then unused. */
 #define NSIM_PLANE_PITCH(S) ((((int64_t)(S)) + 31) & ~(int64_t)31)
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
@@ -410,6 +412,27 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
                        float* dsdf_w, float* dsdf_b, float* dx, int64_t plane_pitch, void* stream);
+/* The SDF decoder with an embedded-position block appended to its input (csrc/wide_field.hip):
+ * ``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: N}`` of the StyleLoTD Vehicle block
+ * (code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml:319-321).  Input = [2 num_levels features | x_n (3),
+ * sin(2^k x_n) (3), cos(2^k x_n) (3), k = 0..N-1], x_n = the AABB-normalised position in [-1, 1] (meta->lotd.x_scale /
+ * x_shift); at most 128 values.  Weights are the f32 MASTER tensors (no packed fragments): sdf_w = [W1 (64 x FIN),
+ * (W2 (64 x 64)), w_head (64)], sdf_b = [64, (64), 1], FIN = 2 num_levels + 3 + 6 N; rad_w / rad_b as for
+ * nsim_field_pack_weights.  meta->precision is not read: f32 arithmetic.  The features and their x-derivative come from
+ * level-major f32 planes: nsim_lotd_gather_lm with an f32 meta for the no-grad query, nsim_field_fwd with wpack = NULL
+ * ("gather only") for the with-grad one; the hand-off planes of the backward feed nsim_lotd_scatter, the radiance
+ * backward is nsim_field_bwd_rad.  Points, n_dev / n_add, plane pitches: as for nsim_field_sdf / _fwd / _bwd_sdf. */
+int nsim_wide_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
+                  const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
+                  const int64_t* n_dev, int64_t n_add, const float* feat_planes, float* sdf, void* stream);
+int nsim_wide_fwd(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* rad_w,
+                  const float* rad_b, const float* x, const float* rays_o, const float* rays_d, const float* t,
+                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const float* J_planes,
+                  float* sdf, float* nablas, float* rgb, const int64_t* n_dev, int64_t n_add, void* stream);
+int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
+                      const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
+                      const float* h_planes, const float* J_planes, int64_t plane_pitch, const float* dsdf,
+                      const float* gn, float* dh_planes, float* g_planes, float* dsdf_w, float* dsdf_b, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term).
  *     Levels [level_begin, level_begin + level_count) only (level_count <= 0: all) -- a data-parallel caller scatters

@@ -113,6 +113,9 @@ SIGNATURES = {
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, C.POINTER(OccMeta), _F],
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
+    "nsim_wide_sdf": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P],
+    "nsim_wide_fwd": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
+    "nsim_wide_bwd_sdf": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_set_grad_scratch": [_P, _I64],
     "nsim_permuto_fwd": [C.POINTER(PermutoMeta), _P, _P, _I64, _P, _P],
     "nsim_permuto_bwd": [C.POINTER(PermutoMeta), _P, _I64, _P, _P],

@@ -10,7 +10,7 @@ import sys
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "permuto.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
+SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "wide_field.hip", "permuto.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
 HEADERS = ["nsim_common.h", "nsim_prims.h", "lotd_dev.h", "mfma_mlp.h", "occ_dev.h", "../../include/nsim.h"]
 LIB = HERE / "libnsim_hip.so"
 BUILD = HERE / "_build"

@@ -2567,6 +2567,10 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
       deal_levels(meta, a);
       if (meta->precision == 0) launch_gather_lm<0, true>(a, S, (hipStream_t)stream);
       else launch_gather_lm<1, true>(a, S, (hipStream_t)stream);
+      if (!wpack) {      // gather only: the caller runs another decoder on the planes (wide_field.hip)
+        NSIM_CHECK_LAUNCH();
+        return 0;
+      }
     }
     // <= 16 levels: + one 16 KB plane-prefetch buffer per wave (k_field GLDS); 17..32 levels, fp16: 1 KB per level and wave
     // where that still fits the 160 KB of a CU (NSIM_FWD_GL2=0: the direct-load kernel)

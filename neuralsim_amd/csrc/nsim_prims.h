@@ -104,6 +104,10 @@ __device__ __forceinline__ float nsim_fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float nsim_fast_log(float x) { return __logf(x); }
 __device__ __forceinline__ float nsim_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float nsim_log2(float x) { return __builtin_amdgcn_logf(x); }
+// v_sin_f32 / v_cos_f32 (input in revolutions, range reduction in the pipe): |x| of a few tens, abs. error ~2e-6 -- the
+// libm forms carry a Payne-Hanek slow path that costs every lane 84 bytes of scratch
+__device__ __forceinline__ float nsim_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
+__device__ __forceinline__ float nsim_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
 
 // ------------------------------------------------------------------ direct global -> LDS copies
 // global_load_lds_dwordx4: every lane names its own 16-byte global source, the destination is the wave-uniform LDS base +

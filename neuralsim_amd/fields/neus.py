@@ -38,8 +38,9 @@ DEFAULT_LOD_RES = [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 10
 RAD_IN = 26
 
 
-def _flat_sizes(D: int, L: int = 16):
-    n_sdf_w = 64 * 2 * L + (64 * 64 if D == 2 else 0) + 64
+def _flat_sizes(D: int, L: int = 16, E: int = 0):
+    """E: width of the embedded-position block appended to the SDF decoder's input (``extra_pos_embed_cfg``; 0 = none)."""
+    n_sdf_w = 64 * (2 * L + E) + (64 * 64 if D == 2 else 0) + 64
     n_sdf_b = 64 * D + 1
     n_rad_w = 64 * RAD_IN + 64 * 64 + 3 * 64
     n_rad_b = 131
@@ -207,7 +208,7 @@ class _FieldFn(torch.autograd.Function):
                 g_rgb = join(g_rgb, None, (3,))
         grid16 = ctx.grid16 if ctx.grid16 is not None else model._table16()
         wpack = model._weight_pack()
-        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels)
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels, model.pos_embed_E)
         need = ctx.needs_input_grad
         dgrid = torch.zeros([ctx.grid_numel], dtype=torch.float32, device=dev) if need[1] else None
         # one memset for the four small accumulators
@@ -238,9 +239,19 @@ class _FieldFn(torch.autograd.Function):
         dh_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
         g_pl = torch.empty([NLP, S, 2], dtype=torch.float32, device=dev) if need_pl else None
         # (2) SDF-decoder branch on the saved planes
-        _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
-                  _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx),
-                  int(ctx.PS))
+        if model.pos_embed_E:
+            if need_dx:
+                raise NotImplementedError("pose refinement through a model with extra_pos_embed_cfg (csrc/wide_field.hip has no "
+                                          "dL/dx output)")
+            sw_, sb_ = model._wide_weights()
+            _lib.call("nsim_wide_bwd_sdf", fm, int(model.pos_embed_n), _lib.ptr(sw_), _lib.ptr(sb_), _lib.ptr(x),
+                      _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(h_pl), _lib.ptr(J_pl),
+                      int(ctx.PS), _lib.ptr(gs), _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w),
+                      _lib.ptr(dsdf_b))
+        else:
+            _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
+                      _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx),
+                      int(ctx.PS))
         d_x = d_o = d_d = None
         if need_dx:
             if gn_total is not None:    # the normals' own dependence on x (mixed second derivatives of the interpolant)
@@ -499,11 +510,17 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                  precision: str = "fp16", softplus_beta: float = 100.0, ln_inv_s_init: float = 0.1,
                  ln_inv_s_factor: float = 10.0, bounding_size: float = 2.0, aabb: torch.Tensor = None,
                  accel_cfg: dict = None, ray_query_cfg: dict = None, param_bound: float = 1e-4, seed: int = 42,
-                 sdf_scale: float = 1.0, inside_out: bool = False, device=None, **reference_params):
+                 sdf_scale: float = 1.0, inside_out: bool = False, device=None, pos_embed_frequencies: int = None,
+                 **reference_params):
         """``sdf_scale``: the decoder output is divided by it (street config ``sdf_scale: 25``,
         withmask_withlidar_joint.240219.yaml:158); ``inside_out``: sign of the geometric initialisation (indoor config
         ``inside_out: true``, lotd_neus.replica.230814.yaml:95).  Both live in the absent nr3d_lib -- semantics fixed
         here: sdf = head(h) / sdf_scale (folded into the packed head weights), inside_out => initial sdf = r - |x|.
+
+        ``pos_embed_frequencies`` N (``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: N}``,
+        no_fg_occ.221218.yaml:319-321): the SDF decoder reads [features | x_n, sin(2^k x_n), cos(2^k x_n), k < N] (x_n = the
+        AABB-normalised position); such a model runs its decoder on csrc/wide_field.hip (f32, first layers up to 128 wide)
+        instead of the 64-input MFMA kernels -- gather, radiance backward, scatter and sampling stay the common path.
 
         ``reference_params``: the reference's ``model_params`` block passed verbatim, as
         ``import_str(model_class)(**model_params, device=device)`` does (app/resources/asset_bank.py:129-138) --
@@ -535,15 +552,20 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         # the level-major planes hold 16 levels per feature chunk of the decoder's first layer (csrc/field.hip: NC)
         self.plane_levels = 16 if len(lod_res) <= 16 else 32
         self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
+        self.pos_embed_n = None if pos_embed_frequencies is None else int(pos_embed_frequencies)
+        self.pos_embed_E = 0 if self.pos_embed_n is None else 3 + 6 * self.pos_embed_n
+        assert 2 * len(lod_res) + self.pos_embed_E <= 128, "csrc/wide_field.hip: first layers up to 128 inputs"
+        if self.pos_embed_E:
+            self.planes_always = True       # the wide decoder reads the level-major planes in every mode
         self.encoding = LoTDEncoding(LoTDConfig(lod_res, 2, log2_hashmap_size), bound=param_bound, seed=seed)
-        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D, len(lod_res))
+        n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D, len(lod_res), self.pos_embed_E)
         g = torch.Generator().manual_seed(seed + 1)
 
         def lin(o, i, scale=1.0):
             b = 1.0 / math.sqrt(i)
             return ((torch.rand(o, i, generator=g) * 2 - 1) * b * scale, (torch.rand(o, generator=g) * 2 - 1) * b * scale)
         ws, bs = [], []
-        dims = [2 * len(lod_res)] + [64] * sdf_D + [1]
+        dims = [2 * len(lod_res) + self.pos_embed_E] + [64] * sdf_D + [1]
         for li in range(len(dims) - 1):
             w, b = lin(dims[li + 1], dims[li])
             ws.append(w.reshape(-1))
@@ -783,6 +805,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             if buf is None or buf.numel() != nbytes or buf.device != self.sdf_w.device:
                 buf = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
             sw, sb = self.sdf_w.detach(), self.sdf_b.detach()
+            if self.pos_embed_E:            # the packed fragments serve the radiance kernels only: feature columns of W1
+                F1, FIN = 2 * self.encoding.cfg.num_levels, 2 * self.encoding.cfg.num_levels + self.pos_embed_E
+                sw = torch.cat([sw[:64 * FIN].view(64, FIN)[:, :F1].reshape(-1), sw[64 * FIN:]])
             if self.sdf_scale != 1.0:       # sdf = head / sdf_scale: fold the divisor into the packed head weights
                 sw, sb = sw.clone(), sb.clone()
                 sw[-64:] /= self.sdf_scale
@@ -873,7 +898,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         lvl = self.encoding.flattened_params.data[cfg.lod_offsets[lv]: cfg.lod_offsets[lv] + cfg.lod_sizes[lv] * 2].view(-1, 2)
         lvl[:, 0] = sdf.half().float().to(lvl.device)
         D = self.sdf_D
-        F1 = 2 * cfg.num_levels
+        F1 = 2 * cfg.num_levels + self.pos_embed_E      # (row width of W1: the embedded-position columns come last)
         # units 0 / 1 of every hidden layer carry +s / -s (s = the stored SDF): softplus(s) - softplus(-s) == s exactly, and
         # the activations are small near the surface, where the fp16 MFMA operands need their resolution (one unit
         # carrying s + 2 through softplus' linear region has an fp16 spacing of 2e-3: a staircase SDF)
@@ -982,8 +1007,27 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
     # (gather inside nsim_field_fwd).  fields/permuto_neus.py overrides the four hooks with csrc/permuto.hip.
     planes_always = False       # True: even an evaluation forward goes through the planes (no fused point-major kernel)
 
+    def _wide_weights(self):
+        """(sdf_w, sdf_b) as the wide decoder reads them: the f32 masters with the ``sdf_scale`` divisor folded into the head."""
+        sw, sb = self.sdf_w.detach(), self.sdf_b.detach()
+        if self.sdf_scale != 1.0:
+            sw, sb = sw.clone(), sb.clone()
+            sw[-64:] /= self.sdf_scale
+            sb[-1:] /= self.sdf_scale
+        return sw.contiguous(), sb.contiguous()
+
     def _enc_field_fwd(self, grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, n_dev,
                        n_add):
+        if self.pos_embed_E:        # gather only (wpack NULL), then the wide decoder + radiance forward on the planes
+            _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), None, _lib.ptr(x), _lib.ptr(rays_o),
+                      _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), None, S, None, None, None,
+                      _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))
+            sw, sb = self._wide_weights()
+            _lib.call("nsim_wide_fwd", self.field_meta, int(self.pos_embed_n), _lib.ptr(sw), _lib.ptr(sb),
+                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(x), _lib.ptr(rays_o),
+                      _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S, _lib.ptr(h_pl), _lib.ptr(J_pl),
+                      _lib.ptr(sdf), _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(n_dev), int(n_add))
+            return None
         _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))
@@ -1012,6 +1056,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         if S == 0:
             return sdf
         fm = self.field_meta if fm is None else fm
+        if self.pos_embed_E:
+            return self._sdf_query_wide(grid16, x, rays_o, rays_d, t, ridx, S, dev, goff, n_dev, n_add, collect, sdf)
         planes = None
         # small launches (the first up-sampling draws: R' x 8 points) as ONE fused point-major launch instead of the level-major
         # gather + the decoder on the planes: NSIM_SDF_FUSED_BELOW = capacity in points (0: never; measured in DESIGN sec. 4)
@@ -1032,6 +1078,25 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             _lib.TIMER.note_units("nsim_field_sdf", S)
             if planes is not None:
                 _lib.TIMER.note_units("nsim_lotd_gather_lm", S)
+        return sdf
+
+    def _sdf_query_wide(self, grid16, x, rays_o, rays_d, t, ridx, S, dev, goff, n_dev, n_add, collect, sdf):
+        """The no-grad query of a model with an embedded-position block: f32 feature planes from the level-major gather, then
+        csrc/wide_field.hip's decoder (one arithmetic for sampling and occupancy: f32)."""
+        fm32 = getattr(self, "_field_meta_f32", None)
+        if fm32 is None:
+            fm32 = _lib.FieldMeta()
+            object.__setattr__(self, "_field_meta_f32", fm32)
+        C_memmove(fm32, self.field_meta)
+        fm32.precision = 1
+        planes = torch.empty([self.plane_levels * _lib.plane_pitch(S) * 2], dtype=torch.float32, device=dev)
+        self._enc_gather_feat(fm32, grid16, x, rays_o, rays_d, t, ridx, goff, S, n_dev, n_add, planes)
+        sw, sb = self._wide_weights()
+        _lib.call("nsim_wide_sdf", fm32, int(self.pos_embed_n), _lib.ptr(sw), _lib.ptr(sb), _lib.ptr(x), _lib.ptr(rays_o),
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(n_dev), int(n_add), _lib.ptr(planes), _lib.ptr(sdf))
+        if collect:         # update_from_samples_cfg: fold the SDFs into the occupancy values (a pass of its own here)
+            pts = x if x is not None else torch.addcmul(rays_o[ridx], t.unsqueeze(-1), rays_d[ridx])
+            self.accel.collect(pts.contiguous(), sdf, n_dev, n_add)
         return sdf
 
     @torch.no_grad()

@@ -227,7 +227,7 @@ class RenderTrainer:
     def _fused_ok(self) -> bool:
         m = self.model
         plain = type(m) is LoTDNeuSModel or (type(m).__name__ == "PermutoNeuSModel" and getattr(m, "z_dim", 0) == 0)
-        return (self.fused_step and plain and self.distant_model is None and self.sky_model is None
+        return (self.fused_step and plain and not getattr(m, "pos_embed_E", 0) and self.distant_model is None and self.sky_model is None
                 and not self.pose_refine_active() and getattr(m, "_ctrl_mix", 0.0) == 0.0 and self.mono is None
                 and self.rgb_fn == "mse")
 

@@ -91,11 +91,13 @@ class StyleLoTDNeuSModel(_DeferredConditionalModel, BatchedLoTDNeuSModel):
         if grower_cfg is None:
             raise NotImplementedError("StyleLoTDNeuSModel needs surface_cfg.lotd_grower_cfg")
         epe = sc.pop("extra_pos_embed_cfg", None)
+        n_embed = None
         if epe is not None and epe.get("type", "identity") not in ("identity", None):
-            # [grown features | embedded position] as the decoder's input: with the config's 8 grown levels x 4 features (32)
-            # + sinusoidal_legacy-6 (39) that is 71 inputs; the fused decoders contract over at most 64 (csrc/field.hip: NC <= 2)
-            raise NotImplementedError(f"surface_cfg.extra_pos_embed_cfg={epe!r}: the fused SDF decoder reads the grown features "
-                                      f"only (<= 64 inputs)")
+            # [grown features | embedded position] as the decoder's input (no_fg_occ.221218.yaml:319-321: 32 + 39 = 71 values):
+            # the model then runs its SDF decoder on csrc/wide_field.hip (LoTDNeuSModel ``pos_embed_frequencies``)
+            if epe.get("type") not in ("sinusoidal_legacy", "sinusoidal"):
+                raise NotImplementedError(f"surface_cfg.extra_pos_embed_cfg={epe!r}: identity | sinusoidal_legacy")
+            n_embed = int(epe.get("n_frequencies", 6))
         # the encoding of this model IS the grower: hand the decoder / radiance / control blocks to the common translation
         sc["encoding_cfg"] = dict(lotd_cfg=dict(lod_res=[2], lod_n_feats=2, hashmap_size=16))
         acc = _plain(self.accel_cfg) if self.accel_cfg is not None else None
@@ -109,6 +111,8 @@ class StyleLoTDNeuSModel(_DeferredConditionalModel, BatchedLoTDNeuSModel):
         kw, post = ref_config.neus_native_kwargs(params)
         for k in ("lod_res", "log2_hashmap_size", "accel_cfg"):
             kw.pop(k, None)
+        if n_embed is not None:
+            kw["pos_embed_frequencies"] = n_embed
         kw.pop("param_bound", None)
         z_dim = self._latent_dim(n_latent_dim)
         dev = device if device is not None else self._pending_device

@@ -7,7 +7,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE.parent.parent / "neuralsim_amd" / "csrc"
-SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "permuto.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
+SOURCES = ["pack_ops.hip", "sampling.hip", "lotd.hip", "field.hip", "wide_field.hip", "permuto.hip", "nerf_field.hip", "sky.hip", "loss_ops.hip", "optim.hip", "misc.hip"]
 import os
 # NSIM_EMU_EXTRA_FLAGS="-fsanitize=address -g" (with LD_PRELOAD of the ASan runtime) builds an instrumented emulator
 # into its own directory: out-of-bounds accesses of the kernels then fail the emulator tests

@@ -30,6 +30,8 @@ inline float nsim_fast_exp(float x) { return expf(x); }
 inline float nsim_fast_log(float x) { return logf(x); }
 inline float nsim_exp2(float x) { return exp2f(x); }
 inline float nsim_log2(float x) { return log2f(x); }
+inline float nsim_sin(float x) { return sinf(x); }
+inline float nsim_cos(float x) { return cosf(x); }
 
 inline void nsim_glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base + 16 * nsim_lane(), gsrc, 16); }
 inline void nsim_wait_vm0() { emu::wave_barrier(); }       // all lanes have issued their copies

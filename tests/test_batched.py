@@ -173,20 +173,23 @@ def test_batched_point_queries_and_occupancy(backend):
         m.set_condition({"z_ins": torch.zeros(2, 128)})
 
 
-@pytest.mark.parametrize("by", ["ins_id", "z_ins"])
-def test_latent_conditioned_tables_match_the_oracle(backend, by):
+@pytest.mark.parametrize("by,embed", [("ins_id", None), ("z_ins", None), ("z_ins", 6)])
+def test_latent_conditioned_tables_match_the_oracle(backend, by, embed):
     """Row a20, the latent -> table path (no_fg_occ.221218.yaml:307-352): a model built with ``lotd_grower_cfg`` grows the
     batch's dense LoTD tables from latent codes in ``set_condition({'ins_id'})`` (the auto-decoder's codes) or
     ``set_condition({'z_ins'})`` (codes given) -- rendered images, and the gradients that reach the codes, the grower's
-    weights and the shared decoders, against the oracle's restatement (oracle/growers.py -> oracle.lotd -> oracle.render)."""
+    weights and the shared decoders, against the oracle's restatement (oracle/growers.py -> oracle.lotd -> oracle.render).
+    ``embed`` 6: with ``surface_cfg.extra_pos_embed_cfg{sinusoidal_legacy, 6}`` of that block (:319-321) -- the shared decoder
+    reads [grown features | embedded position] on csrc/wide_field.hip, sampling pass and occupancy included."""
     from oracle import field as ofield, growers as ogrow, lotd as olotd
     from neuralsim_amd.fields.batched_neus import BatchedLoTDNeuSModel
     B, N = 3, 20
     gcfg = dict(lod_res=[3, 5, 8], lod_n_feats=4, D=2, W=32, fmm_rank=4, n_frequencies=3, out_scale=0.5)
     m = BatchedLoTDNeuSModel(B, ins_ids=[f"car{b}" for b in range(B)], lotd_grower_cfg=gcfg, latents_cfg=dict(z=dict(dim=12)),
                              sdf_D=2, precision="f32", ln_inv_s_init=0.3, log2_hashmap_size=12,
-                             accel_cfg=dict(resolution=[8, 8, 8])).to(backend)
+                             accel_cfg=dict(resolution=[8, 8, 8]), pos_embed_frequencies=embed).to(backend)
     assert m.encoding.cfg.lod_res == [3, 3, 5, 5, 8, 8] and m.encoding.flattened_params.numel() == 0
+    assert m.sdf_w.numel() == 64 * (12 + (0 if embed is None else 39)) + 4096 + 64
     m.accel.set_all_occupied()
     with torch.no_grad():            # a visible shape: bias the SDF head so that part of the box is inside
         m.sdf_b[-1] = -0.05
@@ -210,7 +213,7 @@ def test_latent_conditioned_tables_match_the_oracle(backend, by):
     assert tables.shape == (len(cond), m.n_params_per_instance)
     assert torch.allclose(m._cond_table.detach().cpu().view(len(cond), -1), tables.detach(), atol=2e-6)
     p0 = ofield.params_from_flat(m.encoding.cfg.lod_res, 12, tables[0].detach(), m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, m.ln_inv_s,
-                                 sdf_D=2, ln_inv_s_factor=m.ln_inv_s_factor)
+                                 sdf_D=2, ln_inv_s_factor=m.ln_inv_s_factor, pos_embed_n=embed)
     shared = [*p0.sdf_w, *p0.sdf_b, *p0.rad_w, *p0.rad_b, p0.ln_inv_s]
     for t_ in shared:
         t_.requires_grad_(True)
@@ -222,7 +225,7 @@ def test_latent_conditioned_tables_match_the_oracle(backend, by):
     for k in range(len(cond)):
         pk = ofield.FieldParams(spec=p0.spec, grid=tables[k].detach().half().float() + (tables[k] - tables[k].detach()),   # fp16 values, f32 grads
                                 sdf_w=p0.sdf_w, sdf_b=p0.sdf_b, rad_w=p0.rad_w, rad_b=p0.rad_b, ln_inv_s=p0.ln_inv_s,
-                                ln_inv_s_factor=p0.ln_inv_s_factor)
+                                ln_inv_s_factor=p0.ln_inv_s_factor, pos_embed_n=embed)
         r = orr.ray_query(pk, o[k], d[k], ha[k], occ, AABB[0], AABB[1], [8, 8, 8], **kw)
         outs.append(r)
         if r["num_rays"] > 0:

@@ -1,5 +1,6 @@
 """LoTD encoding and the fused MFMA field kernels (forward, backward incl. the second-order normal terms)
 vs the oracle (oracle/lotd.py, oracle/field.py)."""
+import os
 import pytest
 import torch
 
@@ -537,3 +538,77 @@ def test_small_sdf_query_fused_point_major_equals_level_major(backend, monkeypat
     (f0, p0, o0), (f1, p1, o1) = outs
     assert torch.equal(f0, f1) and torch.equal(p0, p1) and torch.equal(f0, p0)
     assert torch.equal(o0, o1) and bool(torch.isfinite(o1).all()) and float(o1.max()) > 0
+
+
+def _with_pos_embed(p, n_freq, seed):
+    """Widen the oracle decoder's first layer by the embedded-position block (random columns)."""
+    g = torch.Generator().manual_seed(seed)
+    E = 3 + 6 * n_freq
+    w1 = p.sdf_w[0].detach()
+    extra = (torch.rand(64, E, generator=g) * 2 - 1) * (1.0 / (w1.shape[1] + E) ** 0.5)
+    p.sdf_w[0] = torch.cat([w1, extra], dim=1)
+    p.pos_embed_n = n_freq
+    return p
+
+
+@pytest.mark.parametrize("case", ["vehicle_relu", "softplus_D1_aabb", "softplus_D2_scale", "ten_frequencies"])
+def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
+    """``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: 6}`` (the StyleLoTD Vehicle block,
+    no_fg_occ.221218.yaml:319-321, with its relu 2x64 decoder :354-357): the decoder reads [features | embedded position]
+    (71 inputs) on csrc/wide_field.hip -- values, normals, colours, the no-grad query and every gradient against the oracle,
+    including the second-order path of the normals through the embedded position's own x-derivative."""
+    sdf_D = 1 if case == "softplus_D1_aabb" else 2
+    p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=11, noise_scale=1.0)
+    # (first-layer widths 71 / 53 / 71 / 95: the 72-, 56- and 104-wide instantiations of k_wide; above 72 the weight-gradient row
+    # of a lane goes through LDS instead of registers)
+    n_freq = {"softplus_D1_aabb": 3, "ten_frequencies": 10}.get(case, 6)
+    _with_pos_embed(p, n_freq, seed=3)
+    if case == "vehicle_relu":
+        p.sdf_activation = "relu"
+    if case == "softplus_D1_aabb":          # a non-cubic box: x_n and d x_n / d x differ per axis
+        p.spec.aabb = torch.tensor([[-0.7, -0.5, -0.9], [0.7, 0.6, 0.8]])
+    if case == "softplus_D2_scale":
+        p.sdf_scale = 4.0
+    for t in p.tensors():
+        t.requires_grad_(True)
+    model = model_from_params(p, backend, precision="fp16" if case == "vehicle_relu" else "f32")
+    assert model.pos_embed_E == 3 + 6 * n_freq and model.sdf_w.numel() == 64 * (32 + model.pos_embed_E) + (4096 if sdf_D == 2 else 0) + 64
+    g = torch.Generator().manual_seed(6)
+    R, S = 9, 203
+    rays_o = torch.randn(R, 3, generator=g) * 0.1
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    ridx = torch.randint(0, R, (S,), generator=g).sort().values
+    t = torch.rand(S, generator=g) * 0.45
+    h_appear = torch.randn(R, 4, generator=g) * 0.5
+    x = rays_o[ridx] + t[:, None] * rays_d[ridx]
+    ha_o = leaf(h_appear)
+    sdf_r, nab_r, rgb_r = ofield.forward_field(x, rays_d[ridx], ha_o[ridx], p)
+    ha_d = leaf(h_appear, backend)
+    dv = lambda a: a.to(backend).contiguous()
+    sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
+                                   model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
+    # (fp16 field precision: the TABLE is read as fp16 -- the oracle's grid holds fp16-representable values -- the decoder is f32)
+    assert (sdf.cpu() - sdf_r).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
+    assert (nab.cpu() - nab_r).abs().max() < 2e-4 * (1 + nab_r.abs().max())
+    assert (rgb.cpu() - rgb_r).abs().max() < 2e-5
+    q = model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu()
+    assert (q - sdf_r.detach()).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
+    assert (model.query_sdf(dv(x)).cpu() - sdf_r.detach()).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
+    # points mode, no colour (the eikonal query of uniform points)
+    out = model.forward_sdf_nablas(dv(x[:50]))
+    assert (out["nablas"].detach().cpu() - nab_r[:50].detach()).abs().max() < 2e-4 * (1 + nab_r.abs().max())
+    ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
+    (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
+    (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
+    ref = oracle_flat_grads(p)
+    got = dict(grid=model.encoding.flattened_params.grad, sdf_w=model.sdf_w.grad, sdf_b=model.sdf_b.grad,
+               rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
+    for k, v in got.items():
+        e = rel_l2(v.cpu(), ref[k])
+        # (fp16 field precision: the radiance backward runs on the f16 matrix cores and its dL/dnablas feeds the second-order
+        # terms of every SDF-side gradient -- the tolerance of test_field_with_relu_sdf_decoder; the wide decoder is f32 either way)
+        assert e < (3e-2 if case == "vehicle_relu" else 3e-4), (k, e)
+    assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < (3e-2 if case == "vehicle_relu" else 3e-4)
+    # the embedded-position columns of W1 carry gradient (first- and second-order terms)
+    FIN = 32 + model.pos_embed_E
+    assert float(model.sdf_w.grad[:64 * FIN].view(64, FIN)[:, 32:].abs().max()) > 0

@@ -378,7 +378,9 @@ def test_reference_ad_style_lotd_model_from_its_config_block(backend):
     ``StyleLoTDNeuSModel`` from the Vehicle block of fg_neus=hyper_lotd/no_fg_occ.221218.yaml:307-390 -- MixedLoTDGrower =
     DenseLoTDGrowerFMM + VMSplitLoTDGrowerFMM, relu decoder, occ_grid_batched.  That YAML predates the reference's code: it
     names ``AD_StyleLoTDNeuS`` (the class is ``AD_StyleLoTDNeuSObj``) and ``latents_cfg.z`` (the class reads
-    ``latents_cfg['z_ins']``, :108) -- both renamed here; ``extra_pos_embed_cfg`` is refused by name (71 decoder inputs)."""
+    ``latents_cfg['z_ins']``, :108) -- both renamed here.  ``surface_cfg.extra_pos_embed_cfg{sinusoidal_legacy, 6}`` stays in the
+    block: the decoder reads [grown features | embedded position] (16 + 39 inputs at this test's four grown levels, 32 + 39 in
+    the YAML) on csrc/wide_field.hip."""
     import importlib
     c = _multi_cfg("fg_neus=hyper_lotd/no_fg_occ.221218.yaml")
     v = c.assetbank_cfg.Vehicle
@@ -399,11 +401,7 @@ def test_reference_ad_style_lotd_model_from_its_config_block(backend):
     with ref_glue.reference_model_wrapper_modules() as mods:
         shared = importlib.import_module("app.models.shared")
         Cls = shared.AD_StyleLoTDNeuSObj
-        with pytest.raises(NotImplementedError, match="extra_pos_embed_cfg"):
-            bad = Cls(**mp, device=backend)
-            bad.accel_cfg.update(num_batches=1)
-            bad.populate(n_latent_dim=12, device=backend)
-        mp["surface_cfg"].pop("extra_pos_embed_cfg")
+        assert mp["surface_cfg"]["extra_pos_embed_cfg"] == dict(type="sinusoidal_legacy", n_frequencies=6)
         model = Cls(**mp, device=backend)
         model.asset_init_config(**ap)
         nodes = _obj_nodes(mods, 3)
@@ -412,6 +410,7 @@ def test_reference_ad_style_lotd_model_from_its_config_block(backend):
         model.asset_populate(scene=[scene], obj=nodes, config=model.populate_cfg, device=backend)
         assert model.num_objs == 3 and model.accel.num_batches == 3 and model.grower.z_dim == 12
         assert model.encoding.cfg.lod_res == [3, 3, 5, 5, 6, 6, 9, 9] and model.sdf_activation == "relu"
+        assert model.pos_embed_n == 6 and model.sdf_w.numel() == 64 * (16 + 39) + 4096 + 64
         assert model.asset_training_initialize(scene, nodes, model.initialize_cfg) is True
         assert model.ins_inds_per_batch is None and 0.0 < model.accel.frac_occupied() <= 1.0
         with torch.no_grad():

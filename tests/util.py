@@ -40,6 +40,7 @@ def model_from_params(p, device, precision="f32", log2_hashmap_size=None):
     m = LoTDNeuSModel(lod_res=p.spec.lod_res, log2_hashmap_size=l2, sdf_D=len(p.sdf_w) - 1, precision=precision,
                       softplus_beta=-1.0 if getattr(p, "sdf_activation", "softplus") == "relu" else 100.0,
                       ln_inv_s_init=float(p.ln_inv_s), ln_inv_s_factor=p.ln_inv_s_factor,
+                      pos_embed_frequencies=getattr(p, "pos_embed_n", None), sdf_scale=float(getattr(p, "sdf_scale", 1.0)),
                       aabb=torch.as_tensor(p.spec.aabb, dtype=torch.float32) if getattr(p.spec, "aabb", None) is not None else None)
     with torch.no_grad():
         m.encoding.flattened_params.copy_(p.grid.detach().float())

@@ -18,7 +18,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="street", choices=("street", "object", "permuto"))
+    ap.add_argument("--shape", default="street", choices=("street", "object", "permuto", "vehicle", "vehicle_noembed"))
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--per-ray", type=int, default=85)
     ap.add_argument("--iters", type=int, default=6)
@@ -40,6 +40,13 @@ def main():
         m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(type="multi_res", n_levels=16, n_feats=2, log2_hashmap_size=19,
                                                            coarsest_res=16.0, finest_res=2000.0), sdf_D=2,
                              precision=args.precision, seed=1).to(dev)
+    elif args.shape.startswith("vehicle"):
+        # the decoder shape of the StyleLoTD Vehicle block (no_fg_occ.221218.yaml:307-357): 8 grown levels x 4 features = 16 plane
+        # levels, relu 2x64 decoder, + sinusoidal_legacy-6 position embedding (71 inputs: csrc/wide_field.hip) | without it (MFMA)
+        aabb = torch.tensor([[-0.7, -0.7, -0.7], [0.7, 0.7, 0.7]])
+        res = [5, 5, 8, 8, 13, 13, 21, 21, 34, 34, 55, 55, 89, 89, 144, 144]
+        m = LoTDNeuSModel(lod_res=res, log2_hashmap_size=22, sdf_D=2, precision=args.precision, softplus_beta=-1.0, aabb=aabb,
+                          pos_embed_frequencies=6 if args.shape == "vehicle" else None, seed=1).to(dev)
     else:
         aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
         m = LoTDNeuSModel(sdf_D=2, precision=args.precision, seed=1).to(dev)
