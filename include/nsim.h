@@ -337,6 +337,10 @@ int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta);
  * rad_w: [Wr1 (64x26), Wr2 (64x64), Wr3 (3x64)], rad_b [64,64,3]. */
 int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b,
                             const float* rad_w, const float* rad_b, void* wpack, void* stream);
+/* Two packs of the same master weights in ONE launch (a model whose sampling pass runs at another precision than its field
+ * keeps two: every optimizer step re-packs both). */
+int nsim_field_pack_weights2(const NsimFieldMeta* meta_a, void* wpack_a, const NsimFieldMeta* meta_b, void* wpack_b,
+                             const float* sdf_w, const float* sdf_b, const float* rad_w, const float* rad_b, void* stream);
 /* No-grad SDF query (model.query_sdf / forward_sdf; inspect_rendering.py:120-128).
  * Points are x[s] (if x != NULL) or rays_o[ridx[s]] + t[s] * rays_d[ridx[s]].
  * feat_planes == NULL: one fused point-major kernel (gather + decoder).
@@ -542,6 +546,10 @@ int nsim_eikonal_loss_bwd(const float* nablas, int64_t S, const float* gout, flo
 int nsim_mse_loss_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);
 int nsim_mse_loss_bwd(const float* pred, const float* gt, int64_t n, const float* gout, float* dpred, void* stream);
 int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, int64_t rows, float* out, void* stream);
+/* its forward: out[i, :] = table[idx[i], :] (i < n; an index outside [0, rows) gives zeros), followed by ``tail`` zero rows
+ * (the free points a training step appends to its rays carry no appearance code) -- out [n + tail, C]. */
+int nsim_rows_gather(const float* table, const int64_t* idx, int64_t n, int C, int64_t rows, int64_t tail, float* out,
+                     void* stream);
 /* The loss head of one training step in a single launch (the reference's total = mse + w (eikonal(render samples) +
  * eikonal(uniform points)), code_single/tools/train.py:1411-1423 with app/loss/photometric.py + eikonal.py):
  *   acc[0] += mse(pred, gt) over n_img floats; acc[1] += eikonal(nablas[:S]); acc[2] += eikonal(nablas[S:S+M]);

@@ -143,6 +143,8 @@ SIGNATURES = {
     "nsim_train_loss_head": [_P, _P, _I64, _P, _I64, _I64, _F, _P, _P, _P],
     "nsim_mse_loss_bwd": [_P, _P, _I64, _P, _P],
     "nsim_rows_scatter_add": [_P, _P, _I64, _I, _I64, _P],
+    "nsim_rows_gather": [_P, _P, _I64, _I, _I64, _I64, _P],
+    "nsim_field_pack_weights2": [C.POINTER(FieldMeta), _P, C.POINTER(FieldMeta), _P, _P, _P, _P, _P],
     "nsim_gather_rays": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P],
     "nsim_sphere_image": [_P, _P, _I64, _F, _P],
     "nsim_adam_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I],

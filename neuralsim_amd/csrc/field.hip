@@ -134,10 +134,10 @@ struct PackDims {
   int uo[M_COUNT], ui[M_COUNT];
 };
 
-__global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims, int D, int F1, const float* __restrict__ sdf_w,
-                                                     const float* __restrict__ sdf_b, const float* __restrict__ rad_w,
-                                                     const float* __restrict__ rad_b, char* __restrict__ wpack) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void field_pack_elem(const FieldLayout& L, const PackDims& dims, int D, int F1,
+                                                const float* __restrict__ sdf_w, const float* __restrict__ sdf_b,
+                                                const float* __restrict__ rad_w, const float* __restrict__ rad_b,
+                                                char* __restrict__ wpack, int64_t tid) {
   // matrices: one thread per element
   int64_t base = 0;
   for (int m = 0; m < M_COUNT; ++m) {
@@ -190,6 +190,26 @@ __global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims
     }
     ((float*)(wpack + L.vec[v]))[k] = val;
   }
+}
+
+__global__ void __launch_bounds__(256) k_field_pack(FieldLayout L, PackDims dims, int D, int F1, const float* __restrict__ sdf_w,
+                                                     const float* __restrict__ sdf_b, const float* __restrict__ rad_w,
+                                                     const float* __restrict__ rad_b, char* __restrict__ wpack) {
+  field_pack_elem(L, dims, D, F1, sdf_w, sdf_b, rad_w, rad_b, wpack, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// two packs (field precision + sampling precision) of the same weights: blockIdx.y selects the pack
+struct PackTwo {
+  FieldLayout L[2];
+  PackDims dims[2];
+  char* out[2];
+};
+__global__ void __launch_bounds__(256) k_field_pack2(PackTwo p, int D, int F1, const float* __restrict__ sdf_w,
+                                                      const float* __restrict__ sdf_b, const float* __restrict__ rad_w,
+                                                      const float* __restrict__ rad_b) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.y == 0) field_pack_elem(p.L[0], p.dims[0], D, F1, sdf_w, sdf_b, rad_w, rad_b, p.out[0], tid);
+  else field_pack_elem(p.L[1], p.dims[1], D, F1, sdf_w, sdf_b, rad_w, rad_b, p.out[1], tid);
 }
 
 // ------------------------------------------------------------------------------------ activations
@@ -2374,6 +2394,36 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   total += (int64_t)V_COUNT * 64;
   hipLaunchKernelGGL(k_field_pack, dim3(nsim_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, L, dims,
                      meta->sdf_D, 2 * meta->lotd.num_levels, sdf_w, sdf_b, rad_w, rad_b, (char*)wpack);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_field_pack_weights2(const NsimFieldMeta* meta_a, void* wpack_a, const NsimFieldMeta* meta_b, void* wpack_b,
+                             const float* sdf_w, const float* sdf_b, const float* rad_w, const float* rad_b, void* stream) {
+  int rc = field_meta_check(meta_a);
+  if (rc) return rc;
+  rc = field_meta_check(meta_b);
+  if (rc) return rc;
+  if (meta_a->sdf_D != meta_b->sdf_D || meta_a->lotd.num_levels != meta_b->lotd.num_levels) return 2;
+  if (!wpack_a || !wpack_b) return 4;
+  const int nc = field_nc(meta_a->lotd.num_levels);
+  PackTwo p;
+  const NsimFieldMeta* ms[2] = {meta_a, meta_b};
+  int64_t most = 0;
+  for (int q = 0; q < 2; ++q) {
+    p.L[q] = field_layout(ms[q]->precision, nc);
+    int64_t total = (int64_t)V_COUNT * 64;
+    for (int m = 0; m < M_COUNT; ++m) {
+      p.dims[q].uo[m] = mat_uo(m, nc);
+      p.dims[q].ui[m] = mat_ui(m, nc);
+      total += (int64_t)p.dims[q].uo[m] * p.dims[q].ui[m];
+    }
+    most = total > most ? total : most;
+  }
+  p.out[0] = (char*)wpack_a;
+  p.out[1] = (char*)wpack_b;
+  hipLaunchKernelGGL(k_field_pack2, dim3(nsim_blocks(most, 256), 2), dim3(256), 0, (hipStream_t)stream, p, meta_a->sdf_D,
+                     2 * meta_a->lotd.num_levels, sdf_w, sdf_b, rad_w, rad_b);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

@@ -252,6 +252,33 @@ int nsim_rows_scatter_add(const float* g, const int64_t* idx, int64_t n, int C, 
   return 0;
 }
 
+// out[i, :] = table[idx[i], :] for i < n, zeros for n <= i < n + tail (the forward of ``embed[fidx]`` with the zero rows of
+// the step's appended free points in the same launch)
+__global__ void __launch_bounds__(LOSS_BLOCK) k_rows_gather(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                            int64_t n, int C, int64_t rows, int64_t tail, float* __restrict__ out) {
+  const int64_t tot = (n + tail) * C;
+  for (int64_t i = (int64_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < tot; i += (int64_t)gridDim.x * LOSS_BLOCK) {
+    const int64_t r = i / C;
+    float v = 0.f;
+    if (r < n) {
+      const int64_t k = idx[r];
+      if (k >= 0 && k < rows) v = table[k * C + (i % C)];
+    }
+    out[i] = v;
+  }
+}
+
+int nsim_rows_gather(const float* table, const int64_t* idx, int64_t n, int C, int64_t rows, int64_t tail, float* out,
+                     void* stream) {
+  if (n < 0 || tail < 0 || C <= 0) return 2;
+  if (n + tail == 0) return 0;
+  if (!out || (n > 0 && (!table || !idx))) return 4;
+  hipLaunchKernelGGL(k_rows_gather, loss_grid((n + tail) * C), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, table, idx, n, C, rows,
+                     tail, out);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
 int nsim_sphere_image(const float* rays_o, const float* rays_d, int64_t N, float radius, float* rgb, void* stream) {
   if (N < 0) return 2;
   if (N == 0) return 0;

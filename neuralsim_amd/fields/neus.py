@@ -851,8 +851,37 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         """(fp16 grid shadow, MFMA-fragment weight pack), refreshed lazily when a parameter changed in place."""
         grid16 = self._table16()
         self._invalidate_packs()
+        self._pack_pair()
         self._wpack = self._pack_for(self.field_meta, "_wpack_slot")
         return grid16, self._wpack
+
+    def _pack_pair(self):
+        """Both packs of a model whose sampling pass runs at another precision than its field are stale after every optimizer
+        step: re-pack them in ONE launch (nsim_field_pack_weights2) instead of one each."""
+        sp, fm = self.sampling_precision, self.field_meta
+        code = {"fp16": 0, "f32": 1, "split": 2}
+        if sp is None or code[sp] == fm.precision or (sp == "split" and fm.precision == 1) or self.pos_embed_E or self.sdf_scale != 1.0:
+            return
+        a, b = getattr(self, "_wpack_slot", None), getattr(self, "_wpack_slot_s", None)
+        if a is None or b is None or a[1] is None or b[1] is None:        # first use: the single-pack path allocates
+            return
+        dev = str(self.sdf_w.device)
+        va = (self.sdf_w._version, self.sdf_b._version, self.rad_w._version, self.rad_b._version, fm.precision, dev, self.sdf_scale)
+        vb = va[:4] + (code[sp], dev, self.sdf_scale)
+        if a[0] == va or b[0] == vb or a[1].device != self.sdf_w.device or b[1].device != self.sdf_w.device:
+            return
+        fs = getattr(self, "_field_meta_s", None)
+        if fs is None:
+            return
+        C_memmove(fs, fm)
+        fs.precision = code[sp]
+        lib = _lib.get_lib()
+        if a[1].numel() != int(lib.nsim_field_wpack_bytes(fm)) or b[1].numel() != int(lib.nsim_field_wpack_bytes(fs)):
+            return
+        _lib.call("nsim_field_pack_weights2", fm, _lib.ptr(a[1]), fs, _lib.ptr(b[1]), _lib.ptr(self.sdf_w.detach()),
+                  _lib.ptr(self.sdf_b.detach()), _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()))
+        object.__setattr__(self, "_wpack_slot", (va, a[1]))
+        object.__setattr__(self, "_wpack_slot_s", (vb, b[1]))
 
     def _sampling_ctx(self):
         """(FieldMeta, weight pack) of the SAMPLING pass's no-grad SDF queries.  ``sampling_precision = "f32"`` runs them

@@ -255,21 +255,25 @@ class RenderTrainer:
         qp = dict(cfg.get("query_param", model.ray_query_cfg.get("query_param", {})))
         # the per-RAY arrays of the with-grad query (hit rays + the uniform eikonal points as zero-length rays) do not
         # depend on the sample count: they are queued BEFORE the sampling pass and its blocking size read
-        ha = self.appear.detach()[batch["fidx_hit"]]
         x_uni = batch["x_uni"] if self.num_uniform > 0 else None
         M = int(x_uni.shape[0]) if x_uni is not None else 0
         o_r, d_r = tested["rays_o"].detach().float().contiguous(), tested["rays_d"].detach().float().contiguous()
+        A_ = int(self.appear.shape[1])
         if M and "o_full" in batch:
             o, d, rz = batch["o_full"], batch["d_full"], batch["ridx_tail"]
             zc = getattr(self, "_tail_zeros", None)
-            if zc is None or zc[0].shape[0] != M or zc[0].device != dev:
-                zc = self._tail_zeros = (torch.zeros([M], dtype=torch.float32, device=dev),
-                                         torch.zeros([M, ha.shape[1]], dtype=torch.float32, device=dev))
-            tz, ha = zc[0], torch.cat([ha, zc[1]])
+            if zc is None or zc.shape[0] != M or zc.device != dev:
+                zc = self._tail_zeros = torch.zeros([M], dtype=torch.float32, device=dev)
+            tz = zc
+            # the appearance codes of the hit rays + the zero rows of the appended free points: one launch (rows_gather)
+            ha = torch.empty([R + M, A_], dtype=torch.float32, device=dev)
+            _lib.call("nsim_rows_gather", _lib.ptr(self.appear.detach()), _lib.ptr(batch["fidx_hit"]), R, A_, self.V, M, _lib.ptr(ha))
         elif M:
+            ha = self.appear.detach()[batch["fidx_hit"]]
             e = torch.empty([0], dtype=torch.float32, device=dev)
             o, d, tz, rz, ha = append_extra_points(model, o_r, d_r, e, e.long(), ha, x_uni)
         else:
+            ha = self.appear.detach()[batch["fidx_hit"]]
             o, d = o_r, d_r
         # everything that does not depend on the sample count is queued BEFORE the sampling pass and its blocking size
         # read: the shadow / packed weights, and the zero-initialised buffers out of ONE arena (one memset, not nine)
@@ -286,12 +290,15 @@ class RenderTrainer:
         for n in sizes:
             offs.append(tot)
             tot += (n + 3) & ~3
-        arena = torch.zeros([tot], **f32)
+        # (the table gradient and the arena are ONE zero fill: the gradient first -- its start stays 16-byte aligned)
+        n_grid = model.encoding.flattened_params.numel()
+        n_grid_pad = (n_grid + 3) & ~3
+        zeros = torch.zeros([n_grid_pad + tot], **f32)
+        dgrid, arena = zeros[:n_grid], zeros[n_grid_pad:]
         acc, dln, dsdf_w, dsdf_b, drad_w, drad_b, dha, d_app, sc0, vec0 = [
             arena[o_:o_ + n] for o_, n in zip(offs, sizes)]
         acc, dln = acc[:3], dln[:1]
         dha, d_app = dha.view(R + M, A), d_app.view(self.V, A)
-        dgrid = torch.zeros([model.encoding.flattened_params.numel()], **f32)
         model._with_tail = None
         cfg["_tail_points"] = M     # the compressed mode's emit kernel appends the free points' samples itself
         spec = {}

@@ -612,3 +612,43 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
     # the embedded-position columns of W1 carry gradient (first- and second-order terms)
     FIN = 32 + model.pos_embed_E
     assert float(model.sdf_w.grad[:64 * FIN].view(64, FIN)[:, 32:].abs().max()) > 0
+
+
+def test_pair_pack_equals_the_two_single_packs(backend):
+    """``nsim_field_pack_weights2`` (field precision + sampling precision in one launch) writes the bytes of two
+    ``nsim_field_pack_weights`` calls."""
+    from neuralsim_amd import _lib
+    p = make_params(sdf_D=2, small=True, sphere=False, grid_bound=0.3, seed=4, noise_scale=1.0)
+    m = model_from_params(p, backend, precision="fp16")
+    fa, fb = _lib.FieldMeta(), _lib.FieldMeta()
+    import ctypes
+    for f in (fa, fb):
+        ctypes.memmove(ctypes.byref(f), ctypes.byref(m.field_meta), ctypes.sizeof(f))
+    fa.precision, fb.precision = 0, 2
+    lib = _lib.get_lib()
+    na, nb = int(lib.nsim_field_wpack_bytes(fa)), int(lib.nsim_field_wpack_bytes(fb))
+    ws = [m.sdf_w.detach(), m.sdf_b.detach(), m.rad_w.detach(), m.rad_b.detach()]
+    one_a, one_b = (torch.zeros([n], dtype=torch.uint8, device=backend) for n in (na, nb))
+    two_a, two_b = (torch.zeros([n], dtype=torch.uint8, device=backend) for n in (na, nb))
+    _lib.call("nsim_field_pack_weights", fa, *[_lib.ptr(w) for w in ws], _lib.ptr(one_a))
+    _lib.call("nsim_field_pack_weights", fb, *[_lib.ptr(w) for w in ws], _lib.ptr(one_b))
+    _lib.call("nsim_field_pack_weights2", fa, _lib.ptr(two_a), fb, _lib.ptr(two_b), *[_lib.ptr(w) for w in ws])
+    assert torch.equal(one_a.cpu(), two_a.cpu()) and torch.equal(one_b.cpu(), two_b.cpu())
+    assert int(one_a.cpu().count_nonzero()) > na // 4 and int(one_b.cpu().count_nonzero()) > nb // 4
+    # the model's own lazy refresh uses it once both packs exist: same sampling-pass SDFs before / after an in-place update
+    x = (torch.rand(300, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(backend)
+    fm_s, _ = m._sampling_ctx()
+    with torch.no_grad():
+        m.sdf_w.mul_(1.01)
+    m._wpack_versions = None
+    calls = []
+    orig = _lib.call
+    _lib.call = lambda name, *a, **k: (calls.append(name), orig(name, *a, **k))[1]
+    try:
+        fm_s, wp_s = m._sampling_ctx()
+    finally:
+        _lib.call = orig
+    assert calls.count("nsim_field_pack_weights2") == 1 and "nsim_field_pack_weights" not in calls, calls
+    ref = torch.zeros([nb], dtype=torch.uint8, device=backend)
+    _lib.call("nsim_field_pack_weights", fb, *[_lib.ptr(w.detach()) for w in (m.sdf_w, m.sdf_b, m.rad_w, m.rad_b)], _lib.ptr(ref))
+    assert torch.equal(wp_s.cpu(), ref.cpu())

@@ -433,3 +433,17 @@ def test_render_head_against_the_oracle(backend, every_ray):
         assert rel(b["drgb"][:S], rgb64.grad) < 2e-4 and rel(b["dnab"], nab64.grad) < 2e-5
         assert rel(b["dsdf"][:S], sdf64.grad) < 2e-4, rel(b["dsdf"][:S], sdf64.grad)
         assert abs(float(b["dln"].cpu()) - float(ln64.grad)) < 2e-3 * abs(float(ln64.grad)) + 1e-9
+
+
+def test_rows_gather_with_zero_tail(backend, poisoned_empty):
+    """``nsim_rows_gather``: out[:n] = table[idx], then ``tail`` zero rows; out-of-range indices give zero rows."""
+    from neuralsim_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(7, 4, generator=g)
+    idx = torch.tensor([3, 0, 6, 6, 2, -1, 7, 1], dtype=torch.long)
+    out = torch.empty([8 + 5, 4], dtype=torch.float32, device=backend)
+    _lib.call("nsim_rows_gather", _lib.ptr(table.to(backend)), _lib.ptr(idx.to(backend)), 8, 4, 7, 5, _lib.ptr(out))
+    ref = torch.zeros(13, 4)
+    ok = (idx >= 0) & (idx < 7)
+    ref[:8][ok] = table[idx[ok]]
+    assert torch.equal(out.cpu(), ref)
