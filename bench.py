@@ -43,7 +43,7 @@ def kernel_model(L: int = 16, L4: int = 12):
         # ... + the decoder on the planes (12 v_mfma_f32_32x32x16_f16 per 32-point tile at 2x64); with NSIM_SDF_FUSED=1
         # it is the single fused point-major kernel (gather + decoder)
         "nsim_field_sdf": ("hbm", g) if os.environ.get("NSIM_SDF_FUSED", "0") == "1" else ("mfma", 12 * 32768 / 32.0),
-        "nsim_field_fwd": ("hbm", g + 32.0 * L + 28.0),            # gather + the saved h / dh-dx planes + outputs
+        "nsim_field_fwd": ("hbm", g + 20.0 * L + 28.0),            # gather + the saved h (8 B) / f16 dh-dx (12 B) planes per level + outputs
         "nsim_lotd_scatter": ("hbm", 64.0 * L + 16.0 * L + 24.0),  # 16 f32 atomic adds per level (RMW) + dh / g planes + gn, x
         "nsim_field_bwd_sdf": ("mfma", 73728.0),
         "nsim_field_bwd_rad": ("mfma", 45056.0),

@@ -299,12 +299,13 @@ int nsim_permuto_bwd(const NsimPermutoMeta* meta, const float* x, int64_t S, con
  * that nsim_field_sdf (feat_planes) and nsim_field_fwd / _bwd_sdf (h_planes, J_planes; pass grid_f16 = NULL there: "the
  * planes are already gathered") run unchanged on a permutohedral model: exactly one of
  *   feat_planes [NL][P] (f16x2 scaled by 1024 when feat_f32 = 0, f32x2 when 1)      -- no-grad query, or
- *   h_planes [NL][P][2] + J_planes [NL][P][2][3], P = NSIM_PLANE_PITCH(S)            -- with-grad query
+ *   h_planes [NL][P][2] + J_planes [NL][P][2][3], P = NSIM_PLANE_PITCH(S)            -- with-grad query; J_planes in the
+ *       element type the decoders' meta asks for (nsim_jplane_elem_bytes): feat_f32 = 0 writes f16 (2 bytes), 1 writes f32
  * (NL = 16 for <= 16 levels, else 32; levels past num_levels are not written).  n_dev / n_add as nsim_lotd_gather_lm. */
 int nsim_permuto_gather(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const float* z, int64_t S,
                         const int64_t* n_dev, int64_t n_add, void* feat_planes, int feat_f32, float* h_planes,
-                        float* J_planes, void* stream);
+                        void* J_planes, void* stream);
 /* Backward to the table from the decoders' hand-off planes (nsim_field_bwd_sdf): dgrid[v][f] += w_v dL/dh[f]
  * + g[f] (dw_v/dx . gn)  -- gn [S,3] (may be NULL, then g_planes may be NULL too) is the total dL/dnablas; the weights
  * are piecewise linear in x, so this is the whole second-order term. */
@@ -372,7 +373,7 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
  * With-grad query: forward_sdf_nablas + radiance. v: view dirs per sample taken from
  * rays_d[ridx]; h_appear [R,4] per ray (may be NULL => zeros). Outputs sdf [S], nablas [S,3], rgb [S,3]
  * (rgb may be NULL: with_rgb=False, code_single/tools/train.py:896-902).
- * h_planes [NLP,P,2] / J_planes [NLP,P,2,3] with the pitch P = NSIM_PLANE_PITCH(S) = S rounded up to 32 -- every 32-point
+ * h_planes [NLP,P,2] (f32) / J_planes [NLP,P,2,3] (f16 | f32: nsim_jplane_elem_bytes) with the pitch P = NSIM_PLANE_PITCH(S) = S rounded up to 32 -- every 32-point
  * tile of a level is then one 16-byte-aligned 256 B / 768 B piece, which the decoder kernels prefetch straight into LDS
  * (global_load_lds_dwordx4) -- (both or neither; NLP = 16 for <= 16 levels, 32 above): when given, the gathered features and their
  * derivative w.r.t. x are saved level-major for the backward launches (which then never gather again).
@@ -385,7 +386,11 @@ int nsim_lotd_gather_lm(const NsimFieldMeta* meta, const void* grid_f16, const f
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
-                   float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream);
+                   float* h_planes, void* J_planes, const int64_t* n_dev, int64_t n_add, void* stream);
+/* Element size of the dh/dx planes (J_planes) for this meta: 2 (f16: the fp16 field mode -- 192 B per point instead of 384,
+ * the dominant plane traffic of the with-grad gather and of the two decoders that read them) or 4 (f32: the f32 mode).
+ * J_planes holds NLP * P * 6 such elements. */
+int nsim_jplane_elem_bytes(const NsimFieldMeta* meta);
 /* Optional scratch for the weight-gradient flush of the backward launches (1) and (2) below.  Every workgroup of those
  * launches ends by adding its partial dW / db into the same few thousand floats; hundreds of same-address atomics per
  * address serialise in L2 (measured: ~55 us of a 100 us radiance backward).  With a caller-owned, ZEROED buffer of
@@ -413,7 +418,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
  *     g_planes = d sdf/d h, both [NLP,S,2] (both or neither).  dx [S,3] (may be NULL; initialised by the caller or
  *     by (1)) += (dh/dx)^T dL/dh, the first-order position gradient (LoTD ``dL/dx``).
  *     plane_pitch: pitch of h_planes / J_planes when the forward ran at a capacity above S (0 = NSIM_PLANE_PITCH(S)). */
-int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const void* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
                        float* dsdf_w, float* dsdf_b, float* dx, int64_t plane_pitch, void* stream);
 /* The SDF decoder with an embedded-position block appended to its input (csrc/wide_field.hip):
@@ -423,7 +428,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
  * x_shift); at most 128 values.  Weights are the f32 MASTER tensors (no packed fragments): sdf_w = [W1 (64 x FIN),
  * (W2 (64 x 64)), w_head (64)], sdf_b = [64, (64), 1], FIN = 2 num_levels + 3 + 6 N; rad_w / rad_b as for
  * nsim_field_pack_weights.  meta->precision is not read: f32 arithmetic.  The features and their x-derivative come from
- * level-major f32 planes: nsim_lotd_gather_lm with an f32 meta for the no-grad query, nsim_field_fwd with wpack = NULL
+ * level-major planes (features f32, dh/dx in the meta's plane type): nsim_lotd_gather_lm with an f32 meta for the no-grad query, nsim_field_fwd with wpack = NULL
  * ("gather only") for the with-grad one; the hand-off planes of the backward feed nsim_lotd_scatter, the radiance
  * backward is nsim_field_bwd_rad.  Points, n_dev / n_add, plane pitches: as for nsim_field_sdf / _fwd / _bwd_sdf. */
 int nsim_wide_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
@@ -431,11 +436,11 @@ int nsim_wide_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w,
                   const int64_t* n_dev, int64_t n_add, const float* feat_planes, float* sdf, void* stream);
 int nsim_wide_fwd(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* rad_w,
                   const float* rad_b, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const float* J_planes,
+                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const void* J_planes,
                   float* sdf, float* nablas, float* rgb, const int64_t* n_dev, int64_t n_add, void* stream);
 int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
                       const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                      const float* h_planes, const float* J_planes, int64_t plane_pitch, const float* dsdf,
+                      const float* h_planes, const void* J_planes, int64_t plane_pitch, const float* dsdf,
                       const float* gn, float* dh_planes, float* g_planes, float* dsdf_w, float* dsdf_b, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term).

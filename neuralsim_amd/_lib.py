@@ -59,6 +59,13 @@ def plane_pitch(S: int) -> int:
     return (int(S) + 31) & ~31
 
 
+def jplane_dtype(fm):
+    """torch dtype of the dh/dx planes (J_planes) the kernels selected by ``fm`` write / read: f16 in the fp16 field mode, else f32
+    (nsim_jplane_elem_bytes, include/nsim.h)."""
+    import torch
+    return torch.float16 if int(get_lib().nsim_jplane_elem_bytes(fm)) == 2 else torch.float32
+
+
 class FieldMeta(C.Structure):
     _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
 
@@ -155,6 +162,7 @@ NOSTREAM = {
     "nsim_strerror": ([_I], C.c_char_p),
     "nsim_version": ([], _I),
     "nsim_field_wpack_bytes": ([C.POINTER(FieldMeta)], _I64),
+    "nsim_jplane_elem_bytes": ([C.POINTER(FieldMeta)], _I),
     "nsim_distant_wpack_bytes": ([C.POINTER(DistantMeta)], _I64),
     "nsim_sky_wpack_bytes": ([C.POINTER(SkyMeta)], _I64),
     "nsim_sky_plane_pitch": ([_I64], _I64),

@@ -307,7 +307,8 @@ struct FieldArgs {
   void* feat_pl;                                   // no-grad SDF query: level-major feature planes [16 nc][S] x (f16x2 | f32x2)
   signed char glm_n[8], glm_lv[8][32];             // levels gathered by the blocks of XCD x (blockIdx % 8) ...
   signed char glm_half[8][32];                     // ... for all points (0), the first (1) or the second (2) half of them
-  float *h_pl, *J_pl;                              // level-major planes [16 nc][PS][2] / [16 nc][PS][2][3] saved by the forward
+  float* h_pl;                                     // level-major planes [16 nc][PS][2] saved by the forward
+  void* J_pl;                                      // ... and [16 nc][PS][2][3] of JPlane<precision>::T (f16 | f32)
   int64_t PS;                                      // ... their pitch: S rounded up to 32 (NSIM_PLANE_PITCH)
   float *dh_pl, *g_pl;                             // backward -> scatter hand-off planes [16 nc][S][2]
   float* occ_val;                                  // no-grad query of a training step: fold f(sdf) into this value grid
@@ -422,6 +423,32 @@ __device__ __forceinline__ float vecf(const char* W, const FieldLayout& L, int v
 }
 
 struct alignas(8) nsim_f2 { float x, y; };
+// the six dh/dx values of one (level, point) -- d f0 / dx, d f1 / dx -- from a plane or its LDS image: three aligned pair loads
+// (f16: three 32-bit loads + unpack instead of six 16-bit ones)
+template <class T>
+struct alignas(2 * sizeof(T)) JPair;
+template <class T>
+__device__ __forceinline__ void jload6(const T* p, float (&a)[3], float (&b)[3]);
+// two consecutive dh/dx plane elements as one aligned load (8 bytes f32 | 4 bytes f16)
+template <class T>
+struct alignas(2 * sizeof(T)) JPair {
+  T x, y;
+};
+template <class T>
+__device__ __forceinline__ void jstore6(T* p, const float (&a)[3], const float (&b)[3]) {
+  JPair<T>* q = reinterpret_cast<JPair<T>*>(p);
+  JPair<T> v0, v1, v2;
+  v0.x = (T)a[0]; v0.y = (T)a[1]; v1.x = (T)a[2];
+  v1.y = (T)b[0]; v2.x = (T)b[1]; v2.y = (T)b[2];
+  q[0] = v0; q[1] = v1; q[2] = v2;
+}
+template <class T>
+__device__ __forceinline__ void jload6(const T* p, float (&a)[3], float (&b)[3]) {
+  const JPair<T>* q = reinterpret_cast<const JPair<T>*>(p);
+  const JPair<T> v0 = q[0], v1 = q[1], v2 = q[2];
+  a[0] = (float)v0.x; a[1] = (float)v0.y; a[2] = (float)v1.x;
+  b[0] = (float)v1.y; b[1] = (float)v2.x; b[2] = (float)v2.y;
+}
 
 struct TilePoint {
   float xx[3], vd[3];
@@ -508,6 +535,7 @@ __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32]
 // 16-level kernel -- possible while weights + 4 images fit the 160 KB (pyramids of up to 23 levels: the street's 19).
 template <int PREC, int SDF_D, int MODE, int NC = 1, bool GL2 = false>
 __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
+  using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -579,9 +607,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
     for (int l = 0; l < 16 * NC; ++l) {
       if (!LV_OK(l)) continue;
-      const float* src = lane < 16 ? a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane
-                                   : a.J_pl + ((int64_t)l * a.PS + s0) * 6 + 4 * (lane - 16);
-      nsim_glds16(src, pf + 1024 * l);
+      // 16 bytes per lane: lanes 0..15 the 256 B of features, the next 48 (f32) | 24 (f16) lanes the tile's dh/dx
+      constexpr int JL = 16 / (int)sizeof(JT);      // dh/dx elements per lane
+      const void* src = lane < 16 ? (const void*)(a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane)
+                                  : (const void*)(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s0) * 6 + JL * (lane - 16));
+      if (lane < 16 + 192 / JL) nsim_glds16(src, pf + 1024 * l);
     }
   };
   if constexpr (GLDS) {
@@ -621,10 +651,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-          const nsim_f2* jp = reinterpret_cast<const nsim_f2*>(a.J_pl + ((int64_t)l * a.PS + sc) * 6);
-          const nsim_f2 v0 = jp[0], v1 = jp[1], v2 = jp[2];
-          J[r0][0] = v0.x; J[r0][1] = v0.y; J[r0][2] = v1.x;
-          J[r0 + 1][0] = v1.y; J[r0 + 1][1] = v2.x; J[r0 + 1][2] = v2.y;
+          jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + sc) * 6, J[r0], J[r0 + 1]);
         }
       if (tile + wstride < ntiles) prefetch_planes(tile + wstride);
     } else if constexpr (GLDS) {
@@ -637,14 +664,16 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         for (int b = 0; b < 2; ++b) {
           const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
           const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
-          const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
+          const JT* jp = reinterpret_cast<const JT*>(pf + 1024 * l + 256) + 6 * j;
           const bool lv = valid && LV_OK(l);
           h[r0] = lv ? hp[0] : 0.f;
           h[r0 + 1] = lv ? hp[1] : 0.f;
+          float ja[3], jb[3];
+          jload6(jp, ja, jb);
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            J[r0][c3] = lv ? jp[c3] : 0.f;
-            J[r0 + 1][c3] = lv ? jp[3 + c3] : 0.f;
+            J[r0][c3] = lv ? ja[c3] : 0.f;
+            J[r0 + 1][c3] = lv ? jb[c3] : 0.f;
           }
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
@@ -677,12 +706,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) J[r0][c3] = J[r0 + 1][c3] = 0.f;
             if (valid && LV_OK(l)) {
-              const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
-#pragma unroll
-              for (int c3 = 0; c3 < 3; ++c3) {
-                J[r0][c3] = jp[c3];
-                J[r0 + 1][c3] = jp[3 + c3];
-              }
+              jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, J[r0], J[r0 + 1]);
             }
           }
       }
@@ -725,14 +749,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
             }
             if (a.h_pl && valid) {
               float* hp = a.h_pl + ((int64_t)l * a.PS + s) * 2;
-              float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+              JT* jp = reinterpret_cast<JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6;
               hp[0] = f0;
               hp[1] = f1;
-#pragma unroll
-              for (int c3 = 0; c3 < 3; ++c3) {
-                jp[c3] = J[r0][c3];
-                jp[3 + c3] = J[r0 + 1][c3];
-              }
+              jstore6(jp, J[r0], J[r0 + 1]);
             }
           }
         }
@@ -806,9 +826,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
                 if (!LV_OK(l)) continue;
-                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+                float ja[3], jb[3];
+                jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, ja, jb);
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + g[r0] * jp[c3] + g[r0 + 1] * jp[3 + c3];
+                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + g[r0] * ja[c3] + g[r0 + 1] * jb[c3];
               }
         }
 #pragma unroll
@@ -868,9 +889,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               const int r0 = 16 * m + 4 * q + 2 * b;
               gh[r0] = gh[r0 + 1] = 0.f;
               if (valid && LV_OK(l)) {
-                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
-                gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
-                gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+                float ja[3], jb[3];
+                jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, ja, jb);
+                gh[r0] = ja[0] * gn[0] + ja[1] * gn[1] + ja[2] * gn[2];
+                gh[r0 + 1] = jb[0] * gn[0] + jb[1] * gn[1] + jb[2] * gn[2];
               }
             }
       }
@@ -952,9 +974,10 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
                 const int l = 16 * m + 4 * q + 2 * hi + b;
                 const int r0 = 16 * m + 4 * q + 2 * b;
                 if (!LV_OK(l)) continue;
-                const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+                float ja[3], jb[3];
+                jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, ja, jb);
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
+                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * ja[c3] + dh[r0 + 1] * jb[c3];
               }
         }
 #pragma unroll
@@ -1034,6 +1057,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // image of a 32-level tile would be 32 KB per wave).  Round 3: k_field<0,1,2,2> 1.76 ms -> this kernel on the street step.
 template <int PREC, int SDF_D, int NC = 1>
 __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
+  using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
   const int wave = (int)(threadIdx.x >> 6);
@@ -1081,9 +1105,11 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     const int64_t s0 = tile_n * 32;
 #pragma unroll
     for (int l = 0; l < 16; ++l) {
-      const float* src = lane < 16 ? a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane
-                                   : a.J_pl + ((int64_t)l * a.PS + s0) * 6 + 4 * (lane - 16);
-      nsim_glds16(src, pf + 1024 * l);
+      // 16 bytes per lane: lanes 0..15 the 256 B of features, the next 48 (f32) | 24 (f16) lanes the tile's dh/dx
+      constexpr int JL = 16 / (int)sizeof(JT);      // dh/dx elements per lane
+      const void* src = lane < 16 ? (const void*)(a.h_pl + ((int64_t)l * a.PS + s0) * 2 + 4 * lane)
+                                  : (const void*)(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s0) * 6 + JL * (lane - 16));
+      if (lane < 16 + 192 / JL) nsim_glds16(src, pf + 1024 * l);
     }
   };
   float hn[16 * NC];
@@ -1121,14 +1147,16 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
           const float* hp = reinterpret_cast<const float*>(pf + 1024 * l) + 2 * j;
-          const float* jp = reinterpret_cast<const float*>(pf + 1024 * l + 256) + 6 * j;
+          const JT* jp = reinterpret_cast<const JT*>(pf + 1024 * l + 256) + 6 * j;
           const bool lv = valid && LV_OK(l);
           h[r0] = lv ? hp[0] : 0.f;
           h[r0 + 1] = lv ? hp[1] : 0.f;
+          float ja[3], jb[3];
+          jload6(jp, ja, jb);
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) {
-            Jr[r0][c3] = lv ? jp[c3] : 0.f;
-            Jr[r0 + 1][c3] = lv ? jp[3 + c3] : 0.f;
+            Jr[r0][c3] = lv ? ja[c3] : 0.f;
+            Jr[r0 + 1][c3] = lv ? jb[c3] : 0.f;
           }
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
@@ -1146,9 +1174,10 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
             const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
             gh[r0] = gh[r0 + 1] = 0.f;
             if (valid && LV_OK(l)) {
-              const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
-              gh[r0] = jp[0] * gn[0] + jp[1] * gn[1] + jp[2] * gn[2];
-              gh[r0 + 1] = jp[3] * gn[0] + jp[4] * gn[1] + jp[5] * gn[2];
+              float ja[3], jb[3];
+              jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, ja, jb);
+              gh[r0] = ja[0] * gn[0] + ja[1] * gn[1] + ja[2] * gn[2];
+              gh[r0 + 1] = jb[0] * gn[0] + jb[1] * gn[1] + jb[2] * gn[2];
             }
           }
       load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
@@ -1163,12 +1192,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #pragma unroll
           for (int c3 = 0; c3 < 3; ++c3) Jr[r0][c3] = Jr[r0 + 1][c3] = 0.f;
           if (valid && LV_OK(l)) {
-            const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
-#pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) {
-              Jr[r0][c3] = jp[c3];
-              Jr[r0 + 1][c3] = jp[3 + c3];
-            }
+            jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, Jr[r0], Jr[r0 + 1]);
           }
         }
       load_h_at(hn, ((grp + gridDim.x) * JOINT_WAVES + wave) * 32 + j);      // next group's features (zeros past the end)
@@ -1329,9 +1353,10 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
           for (int b = 0; b < 2; ++b) {
             const int l = 16 * m + 4 * q + 2 * hi + b, r0 = 16 * m + 4 * q + 2 * b;
             if (!LV_OK(l)) continue;
-            const float* jp = a.J_pl + ((int64_t)l * a.PS + s) * 6;
+            float ja[3], jb[3];
+            jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + s) * 6, ja, jb);
 #pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * jp[c3] + dh[r0 + 1] * jp[3 + c3];
+            for (int c3 = 0; c3 < 3; ++c3) acc[c3] = acc[c3] + dh[r0] * ja[c3] + dh[r0 + 1] * jb[c3];
           }
       }
 #pragma unroll
@@ -1403,6 +1428,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #endif
 template <int PREC, bool WJ>
 __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
+  using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes (WJ)
   // points per lane.  (Round 5: 1 / 2 points per lane for launches of <= 98 k / 196 k points -- four times the waves for the
   // small up-sampling draws -- measured nothing: 0.0643-0.0658 against 0.0651-0.0666 ms per launch, profiles/round5_gather_ab.txt)
   constexpr int NP = GLM_PTS;
@@ -1496,17 +1522,13 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
         if constexpr (WJ) {
           const int64_t ep = (int64_t)l * a.PS + s;
           float* hp = a.h_pl + ep * 2;
-          float* jp = a.J_pl + ep * 6;
+          JT* jp = reinterpret_cast<JT*>(a.J_pl) + ep * 6;
           hp[0] = f0[q];
           hp[1] = f1[q];
 #ifdef NSIM_PROBE_GATHER_NOJ      // timing probe (wrong results): the dh/dx stores dropped but for an impossible case
           if (f0[q] == 123.456f)
 #endif
-#pragma unroll
-          for (int c3 = 0; c3 < 3; ++c3) {
-            jp[c3] = j0[q][c3];
-            jp[3 + c3] = j1[q][c3];
-          }
+          jstore6(jp, j0[q], j1[q]);
         } else if constexpr (PREC == 0) {
           union {
             uint32_t u;
@@ -2398,6 +2420,8 @@ int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const
   return 0;
 }
 
+int nsim_jplane_elem_bytes(const NsimFieldMeta* meta) { return meta ? NSIM_J_ELEM_BYTES(meta->precision) : 0; }
+
 int nsim_field_pack_weights2(const NsimFieldMeta* meta_a, void* wpack_a, const NsimFieldMeta* meta_b, void* wpack_b,
                              const float* sdf_w, const float* sdf_b, const float* rad_w, const float* rad_b, void* stream) {
   int rc = field_meta_check(meta_a);
@@ -2588,7 +2612,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
 int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* wpack, const float* x,
                    const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx,
                    const int64_t* ray_goff, const float* h_appear, int64_t S, float* sdf, float* nablas, float* rgb,
-                   float* h_planes, float* J_planes, const int64_t* n_dev, int64_t n_add, void* stream) {
+                   float* h_planes, void* J_planes, const int64_t* n_dev, int64_t n_add, void* stream) {
   const int rc = field_meta_check_full(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
@@ -2706,7 +2730,7 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   return 0;
 }
 
-int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const float* J_planes,
+int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const void* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
                        float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
   const int rc = field_meta_check_full(meta);
@@ -2721,7 +2745,7 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   if (plane_pitch != 0 && (plane_pitch < S || (plane_pitch & 31))) return 28;
   a.PS = plane_pitch ? plane_pitch : NSIM_PLANE_PITCH(S);
   a.dsdf = dsdf; a.dnablas = gn;
-  a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<float*>(J_planes);
+  a.h_pl = const_cast<float*>(h_planes); a.J_pl = const_cast<void*>(J_planes);
   a.dh_pl = dh_planes; a.g_pl = g_planes;
   a.dsdf_w = dsdf_w; a.dsdf_b = dsdf_b;
   a.dx = dx;

@@ -17,6 +17,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// dh/dx planes of the with-grad query (nsim_field_fwd -> nsim_field_bwd_sdf; include/nsim.h): f16 in the fp16 field mode
+// (192 instead of 384 bytes per point: the dominant plane traffic of the with-grad gather and of both decoders that read them),
+// f32 in the f32 validation mode.  NSIM_J16=0 keeps f32 planes in both modes (A/B aid).
+#ifndef NSIM_J16
+#define NSIM_J16 1
+#endif
+template <int PREC>
+struct JPlane {
+  using T = float;
+};
+#if NSIM_J16
+template <>
+struct JPlane<0> {
+  using T = f16;
+};
+#endif
+#define NSIM_J_ELEM_BYTES(precision) ((NSIM_J16 && (precision) == 0) ? 2 : 4)
+
 // The hardware primitives: nsim_lane, wave_shfl, wave_ballot, quad_bcast, the float scans / reductions on DPP, the
 // in-wave ordering points, the transcendental pipes, LDS-DMA, MFMA, the buffer-resource table loads, the system-scope
 // store -- neuralsim_amd/csrc/nsim_prims.h (gfx950).

@@ -194,7 +194,8 @@ struct PermutoArgs {
   float *out, *dydx;                               // standalone forward
   void* feat_pl;                                   // field, no-grad: [NL][S] (f16x2 scaled | f32x2)
   int feat_f32;
-  float *h_pl, *J_pl;                              // field, with-grad
+  float* h_pl;                                     // field, with-grad
+  void* J_pl;                                      // ... dh/dx planes: f16 (feat_f32 == 0 and NSIM_J16) | f32
   const float *dL_dout;                            // standalone backward [S, L F]
   const float *dh_pl, *g_pl, *gn;                  // field backward
   float* dgrid;
@@ -249,7 +250,10 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
       const int64_t ep = (int64_t)l * a.PS + s;
       a.h_pl[ep * 2] = a.h_pl[ep * 2 + 1] = 0.f;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a.J_pl[ep * 6 + c] = 0.f;
+      for (int c = 0; c < 6; ++c) {
+        if (NSIM_J16 && !a.feat_f32) reinterpret_cast<f16*>(a.J_pl)[ep * 6 + c] = (f16)0.f;
+        else reinterpret_cast<float*>(a.J_pl)[ep * 6 + c] = 0.f;
+      }
     }
     return;
   }
@@ -309,13 +313,22 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
   } else {
     const int64_t ep = (int64_t)l * a.PS + s;
     float* hp = a.h_pl + ep * 2;
-    float* jp = a.J_pl + ep * 6;
     hp[0] = f0;
     hp[1] = f1;
+    if (NSIM_J16 && !a.feat_f32) {      // the decoders of an fp16 field read f16 dh/dx planes (nsim_jplane_elem_bytes)
+      f16* jp = reinterpret_cast<f16*>(a.J_pl) + ep * 6;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      jp[c] = j0[c];
-      jp[3 + c] = j1[c];
+      for (int c = 0; c < 3; ++c) {
+        jp[c] = (f16)j0[c];
+        jp[3 + c] = (f16)j1[c];
+      }
+    } else {
+      float* jp = reinterpret_cast<float*>(a.J_pl) + ep * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        jp[c] = j0[c];
+        jp[3 + c] = j1[c];
+      }
     }
   }
 }
@@ -516,7 +529,7 @@ int nsim_permuto_bwd(const NsimPermutoMeta* meta, const float* x, int64_t S, con
 int nsim_permuto_gather(const NsimPermutoMeta* meta, const void* grid_f16, const float* x, const float* rays_o,
                         const float* rays_d, const float* t, const int64_t* ridx, const float* z, int64_t S,
                         const int64_t* n_dev, int64_t n_add, void* feat_planes, int feat_f32, float* h_planes,
-                        float* J_planes, void* stream) {
+                        void* J_planes, void* stream) {
   const int rc = permuto_meta_check(meta);
   if (rc) return rc;
   if (meta->in_dim < 3) return 41;

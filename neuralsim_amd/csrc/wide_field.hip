@@ -48,7 +48,9 @@ struct WideArgs {
   int64_t S, PS;
   const int64_t* S_dev;
   int64_t S_add;
-  const float *h_pl, *J_pl;         // f32 planes [NLP][PS][2], [NLP][PS][2][3]
+  const float* h_pl;                // f32 planes [NLP][PS][2]
+  const void* J_pl;                 // dh/dx planes [NLP][PS][2][3], f16 (j16) | f32
+  int j16;
   float *sdf, *nablas, *rgb;
   // backward
   const float *dsdf, *dnablas;
@@ -244,8 +246,13 @@ __device__ __forceinline__ void wide_points(const WideArgs& a, const WideLds& L,
     if (a.J_pl) {      // (the no-grad query has feature planes only)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        J0[p][c] = a.J_pl[3 * o0 + c];
-        J1[p][c] = a.J_pl[3 * o1 + c];
+        if (a.j16) {
+          J0[p][c] = (float)reinterpret_cast<const f16*>(a.J_pl)[3 * o0 + c];
+          J1[p][c] = (float)reinterpret_cast<const f16*>(a.J_pl)[3 * o1 + c];
+        } else {
+          J0[p][c] = reinterpret_cast<const float*>(a.J_pl)[3 * o0 + c];
+          J1[p][c] = reinterpret_cast<const float*>(a.J_pl)[3 * o1 + c];
+        }
       }
     }
     gs[p] = 0.f;
@@ -661,6 +668,7 @@ static int wide_args(const NsimFieldMeta* meta, int n_freq, WideArgs& a) {
   a.FIN = a.F1 + 3 + 6 * n_freq;
   if (a.FIN > 128) return 36;
   a.beta = meta->softplus_beta > 0.f ? meta->softplus_beta : -1.f;
+  a.j16 = NSIM_J_ELEM_BYTES(meta->precision) == 2;
   return 0;
 }
 
@@ -714,7 +722,7 @@ int nsim_wide_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w,
 
 int nsim_wide_fwd(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* rad_w,
                   const float* rad_b, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const float* J_planes,
+                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const void* J_planes,
                   float* sdf, float* nablas, float* rgb, const int64_t* n_dev, int64_t n_add, void* stream) {
   WideArgs a;
   const int rc = wide_args(meta, n_freq, a);
@@ -736,7 +744,7 @@ int nsim_wide_fwd(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w,
 
 int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
                       const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                      const float* h_planes, const float* J_planes, int64_t plane_pitch, const float* dsdf,
+                      const float* h_planes, const void* J_planes, int64_t plane_pitch, const float* dsdf,
                       const float* dnablas, float* dh_planes, float* g_planes, float* dsdf_w, float* dsdf_b, void* stream) {
   WideArgs a;
   const int rc = wide_args(meta, n_freq, a);

@@ -163,7 +163,7 @@ class _FieldFn(torch.autograd.Function):
         need_pl = need_bwd or NLP > 16 or model.planes_always or _EVAL_PLANES
         PS = _lib.plane_pitch(S)
         h_pl = torch.empty([NLP, PS, 2], dtype=torch.float32, device=dev) if need_pl else None
-        J_pl = torch.empty([NLP, PS, 2, 3], dtype=torch.float32, device=dev) if need_pl else None
+        J_pl = torch.empty([NLP, PS, 2, 3], dtype=_lib.jplane_dtype(model.field_meta), device=dev) if need_pl else None
         # (the encoding's hook may return per-query state its backward hooks need -- the permutohedral model's condition z --,
         # carried on ctx: the backward of a query uses what the query was MADE with)
         ctx.enc_state = model._enc_field_fwd(grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl,
@@ -1590,7 +1590,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
                 grid16, wpack = self._shadow()
                 spec.update(sdf=torch.empty([Sc], **f32), nablas=torch.empty([Sc, 3], **f32),
                             rgb=torch.empty([Sc, 3], **f32) if with_rgb else None,
-                            h_pl=torch.empty([NLP, PSc, 2], **f32), J_pl=torch.empty([NLP, PSc, 2, 3], **f32), PS=PSc)
+                            h_pl=torch.empty([NLP, PSc, 2], **f32),
+                            J_pl=torch.empty([NLP, PSc, 2, 3], dtype=_lib.jplane_dtype(self.field_meta), device=dev_), PS=PSc)
                 spec["enc_state"] = self._enc_field_fwd(grid16, wpack, None, o_a, d_a, t_full, ridx_full, None, ha_a, Sc, spec["sdf"],
                                                         spec["nablas"], spec["rgb"], spec["h_pl"], spec["J_pl"], total_dev, M)
             cfg["_spec_launch"], cfg["_tail_points"] = spec_launch, M

@@ -187,7 +187,8 @@ class PermutoNeuSModel(LoTDNeuSModel):
         assert goff is None and h_pl is not None
         z, zr = self._z_for(ridx, rays_o, S, sdf.device)
         _lib.call("nsim_permuto_gather", self.encoding.cfg.pmeta, _lib.ptr(grid16), _lib.ptr(x), _lib.ptr(rays_o),
-                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(n_dev), int(n_add), None, 0,
+                  _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(zr), _lib.ptr(z), S, _lib.ptr(n_dev), int(n_add), None,
+                  int(J_pl.dtype != torch.float16),      # (with-grad outputs: the flag selects the dh/dx plane type, f16 | f32)
                   _lib.ptr(h_pl), _lib.ptr(J_pl))
         # grid = NULL: the planes are filled -- decoders only
         _lib.call("nsim_field_fwd", self.field_meta, None, _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),

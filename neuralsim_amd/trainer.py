@@ -309,7 +309,7 @@ class RenderTrainer:
             Sc = cap_k + M
             PSc = _lib.plane_pitch(Sc)
             bufs = (torch.empty([Sc], **f32), torch.empty([Sc, 3], **f32), torch.empty([Sc, 3], **f32),
-                    torch.empty([NLP, PSc, 2], **f32), torch.empty([NLP, PSc, 2, 3], **f32))
+                    torch.empty([NLP, PSc, 2], **f32), torch.empty([NLP, PSc, 2, 3], dtype=_lib.jplane_dtype(fm), device=dev))
             # (the encoding's hook: LoTD = nsim_field_fwd with its own gather; permutohedral = nsim_permuto_gather + decoders)
             st = model._enc_field_fwd(grid16, wpack, None, o, d, t_full, ridx_full, None, ha, Sc, bufs[0], bufs[1], bufs[2], bufs[3],
                                       bufs[4], total_dev, M)
@@ -337,7 +337,7 @@ class RenderTrainer:
         else:
             sdf, nab, rgb = torch.empty([St], **f32), torch.empty([St, 3], **f32), torch.empty([St, 3], **f32)
             PS = _lib.plane_pitch(St)
-            h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], **f32)
+            h_pl, J_pl = torch.empty([NLP, PS, 2], **f32), torch.empty([NLP, PS, 2, 3], dtype=_lib.jplane_dtype(fm), device=dev)
             enc_state = model._enc_field_fwd(grid16, wpack, None, o, d, t_a, ridx_a, None, ha, St, sdf, nab, rgb, h_pl, J_pl, None, 0)
         ln_inv_s = model.ln_inv_s.detach()
         alpha, vw, trans = torch.empty([S], **f32), torch.empty([S], **f32), torch.empty([S], **f32)
