@@ -287,27 +287,36 @@ def test_training_steps_on_the_permuto_model(backend):
     from neuralsim_amd.trainer import RenderTrainer
     qp = dict(nablas_has_grad=True, num_coarse=8, num_fine=[4, 4], upsample_inv_s=64.0, upsample_inv_s_factors=[1, 4],
               upsample_use_estimate_alpha=True, march_cfg=dict(step_size=0.05, max_steps=128))
-    m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
-                         precision="fp16", ln_inv_s_init=0.3, seed=4,
-                         accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
-                                        update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
-                         ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(backend)
-    m.geometric_init_sphere(0.5, num_iters=60, num_pts=1024, lr=5e-3)
-    m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
-    intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
-    tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, target_sphere_radius=0.5)
+    def build():
+        torch.manual_seed(0)            # (the occupancy initialisation draws from the global generator)
+        m = PermutoNeuSModel(permuto_auto_compute_cfg=dict(PCFG, n_levels=8, log2_hashmap_size=12, finest_res=32.0), sdf_D=2,
+                             precision="fp16", ln_inv_s_init=0.3, seed=4,
+                             accel_cfg=dict(resolution=(16, 16, 16), update_from_net_cfg=dict(num_steps=1, num_pts=2048),
+                                            update_from_samples_cfg={}, n_steps_between_update=4, n_steps_warmup=2),
+                             ray_query_cfg=dict(query_mode="march_occ_multi_upsample", query_param=qp)).to(backend)
+        m.geometric_init_sphere(0.5, num_iters=60, num_pts=1024, lr=5e-3)
+        m.accel.init(m.query_sdf, num_steps=1, num_pts=4096)
+        intr, c2w, WH = look_at_cameras(V=4, seed=1, device=backend)
+        tr = RenderTrainer(m, intr, c2w, WH, num_rays=24, lr=2e-3, num_uniform=32, perturb=True, target_sphere_radius=0.5)
+        xy, fidx, gt = tr.sample_batch()
+        tr.sample_batch = lambda: (xy, fidx, gt)
+        return m, tr
+    m, tr = build()
     assert tr._fused_ok()                           # the fused launch chain runs on the encoding hooks: this model as well
-    xy, fidx, gt = tr.sample_batch()
-    tr.sample_batch = lambda: (xy, fidx, gt)
     before = m.encoding.flattened_params.detach().clone()
-    losses = [float(tr.train_step(it)) for it in range(6)]
-    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    losses = [float(tr.train_step(it)) for it in range(7)]
+    assert all(l == l for l in losses) and losses[-2] < losses[0], losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
     assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())
-    # the fused chain and the autograd path compute the same step (same batch, same randoms): equal losses
-    tr.fused_step = False
-    l_auto = float(tr.train_step(6))
-    assert l_auto == l_auto and abs(l_auto - losses[-1]) < 0.2 * abs(losses[-1]) + 1e-3
+    # the fused chain and the autograd path compute the same step: a second, identically built trainer takes the same six fused
+    # steps, then step 6 through the autograd path (same batch, same randoms) -- the loss of THAT step against the first
+    # trainer's (float atomics reorder the two histories by ~1e-6 per step, fp16 arithmetic by more: 5 %)
+    m2, tr2 = build()
+    losses2 = [float(tr2.train_step(it)) for it in range(6)]
+    assert all(abs(a_ - b_) < 0.05 * abs(a_) + 1e-4 for a_, b_ in zip(losses[:6], losses2)), (losses, losses2)
+    tr2.fused_step = False
+    l_auto = float(tr2.train_step(6))
+    assert l_auto == l_auto and abs(l_auto - losses[6]) < 0.05 * abs(losses[6]) + 2e-4, (l_auto, losses)
 
 
 def test_permuto_encoding_at_the_reference_scale(backend):
