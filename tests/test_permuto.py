@@ -304,19 +304,43 @@ def test_training_steps_on_the_permuto_model(backend):
     m, tr = build()
     assert tr._fused_ok()                           # the fused launch chain runs on the encoding hooks: this model as well
     before = m.encoding.flattened_params.detach().clone()
-    losses = [float(tr.train_step(it)) for it in range(7)]
-    assert all(l == l for l in losses) and losses[-2] < losses[0], losses
+    losses = [float(tr.train_step(it)) for it in range(10)]
+    # (jittered samples: single losses scatter by ~10 % -- the trend over three steps at both ends)
+    assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3]), losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
     assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())
-    # the fused chain and the autograd path compute the same step: a second, identically built trainer takes the same six fused
-    # steps, then step 6 through the autograd path (same batch, same randoms) -- the loss of THAT step against the first
-    # trainer's (float atomics reorder the two histories by ~1e-6 per step, fp16 arithmetic by more: 5 %)
-    m2, tr2 = build()
-    losses2 = [float(tr2.train_step(it)) for it in range(6)]
-    assert all(abs(a_ - b_) < 0.05 * abs(a_) + 1e-4 for a_, b_ in zip(losses[:6], losses2)), (losses, losses2)
-    tr2.fused_step = False
-    l_auto = float(tr2.train_step(6))
-    assert l_auto == l_auto and abs(l_auto - losses[6]) < 0.05 * abs(losses[6]) + 2e-4, (l_auto, losses)
+    # the fused chain and the autograd path compute the same step: the state after these steps is rolled back (parameters, buffers,
+    # Adam moments and step counts, generators, no prefetched batch) and the next step is taken both ways -- same batch, same randoms
+    import copy
+
+    def snapshot():
+        return dict(model=copy.deepcopy(m.state_dict()), appear=tr.appear.detach().clone(),
+                    opt=[(g["m"].clone(), g["v"].clone(), g.get("t", 0)) for g in tr.optim.groups],
+                    gens=[g_.get_state() for g_ in (tr.gen, tr.gen_shared)], rng=torch.get_rng_state(),
+                    dev_rng=torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+
+    def restore(st):
+        m.load_state_dict(st["model"])
+        with torch.no_grad():
+            tr.appear.copy_(st["appear"])
+        for g_, (mm, vv, tt) in zip(tr.optim.groups, st["opt"]):
+            g_["m"].copy_(mm)
+            g_["v"].copy_(vv)
+            g_["t"] = tt
+        for g_, s_ in zip((tr.gen, tr.gen_shared), st["gens"]):
+            g_.set_state(s_)
+        torch.set_rng_state(st["rng"])
+        if st["dev_rng"] is not None:
+            torch.cuda.set_rng_state(st["dev_rng"])
+        tr._prefetched = None
+        m._wpack_versions = None
+    tr._prefetched = None
+    st = snapshot()
+    l_fused = float(tr.train_step(10))
+    restore(st)
+    tr.fused_step = False
+    l_auto = float(tr.train_step(10))
+    assert l_auto == l_auto and abs(l_auto - l_fused) < 0.02 * abs(l_fused) + 1e-5, (l_auto, l_fused)
 
 
 def test_permuto_encoding_at_the_reference_scale(backend):
