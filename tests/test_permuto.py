@@ -304,7 +304,7 @@ def test_training_steps_on_the_permuto_model(backend):
     m, tr = build()
     assert tr._fused_ok()                           # the fused launch chain runs on the encoding hooks: this model as well
     before = m.encoding.flattened_params.detach().clone()
-    losses = [float(tr.train_step(it)) for it in range(10)]
+    losses = [float(tr.train_step(it)) for it in range(8)]
     # (jittered samples: single losses scatter by ~10 % -- the trend over three steps at both ends)
     assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3]), losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
@@ -336,10 +336,10 @@ def test_training_steps_on_the_permuto_model(backend):
         m._wpack_versions = None
     tr._prefetched = None
     st = snapshot()
-    l_fused = float(tr.train_step(10))
+    l_fused = float(tr.train_step(9))        # (not an occupancy-refresh iteration: its stratified sweep is host state)
     restore(st)
     tr.fused_step = False
-    l_auto = float(tr.train_step(10))
+    l_auto = float(tr.train_step(9))
     assert l_auto == l_auto and abs(l_auto - l_fused) < 0.02 * abs(l_fused) + 1e-5, (l_auto, l_fused)
 
 
