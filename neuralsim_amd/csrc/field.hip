@@ -356,6 +356,9 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 
 
 #define FIELD_WAVES 4
+#ifndef NSIM_BWD_JDIRECT
+#define NSIM_BWD_JDIRECT 1      // k_field_bwd_j, <= 16 levels, fp16 mode: features through the LDS image, dh/dx as packed pairs straight into registers
+#endif
 #ifndef NSIM_FWD_JDIRECT
 #define NSIM_FWD_JDIRECT 1      // k_field MODE 3, <= 16 levels: features through the LDS image, dh/dx straight into registers
 #endif
@@ -1101,8 +1104,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   // computes (as in k_field MODE 3); f32 validation mode (its f32 staging leaves no LDS for it) prefetches h into registers
   constexpr bool GLDS = (PREC == 0 && NC == 1);
   char* pf = GLDS ? stC + 64 * jstage_row_bytes<PREC>() + wave * 16384 : nullptr;
+  // BJD: the image holds the FEATURES only (4 copies of 4 levels each, 256 B per level); dh/dx -- consumed once, for dL/dg = J . gn,
+  // AFTER the recomputed forward -- is loaded as packed pairs straight from the planes at the top of a group: 24 registers
+  // (f16) instead of 48 converted floats live across the forward, no LDS round trip, the loads fly under the forward
+  constexpr bool BJD = GLDS && NSIM_BWD_JDIRECT;
   auto prefetch_planes = [&](int64_t tile_n) {
     const int64_t s0 = tile_n * 32;
+    if constexpr (BJD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)      // lanes 16 k .. 16 k + 15: the 256 B of level 4 i + k
+        nsim_glds16(a.h_pl + ((int64_t)(4 * i + (lane >> 4)) * a.PS + s0) * 2 + 4 * (lane & 15), pf + 1024 * i);
+      return;
+    }
 #pragma unroll
     for (int l = 0; l < 16; ++l) {
       // 16 bytes per lane: lanes 0..15 the 256 B of features, the next 48 (f32) | 24 (f16) lanes the tile's dh/dx
@@ -1137,9 +1150,35 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     }
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
     float h[16 * NC];
-    float Jr[NC == 1 ? 16 : 1][3];      // dh/dx of this group (NC == 2: consumed straight from its loads, below)
+    float Jr[(NC == 1 && !BJD) ? 16 : 1][3];      // dh/dx of this group (NC == 2 / BJD: consumed straight from its loads, below)
+    JPair<JT> Jq[BJD ? 8 : 1][3];                 // BJD: the (level, point) entries of this lane as stored (three pairs each)
     float gh[16 * NC];                  // dL / dg = J . gn
-    if constexpr (GLDS) {
+    if constexpr (BJD) {
+      nsim_wait_vm0();                          // this tile's feature image has landed
+      const int64_t sc = valid ? s : a.S - 1;   // (a point past the end reads the last point's finite values; nothing of it is stored)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
+          const float* hp = reinterpret_cast<const float*>(pf + 256 * l) + 2 * j;
+          h[r0] = valid ? hp[0] : 0.f;
+          h[r0 + 1] = valid ? hp[1] : 0.f;
+        }
+      nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int l = 4 * q + 2 * hi + b;
+          const JPair<JT>* jp = reinterpret_cast<const JPair<JT>*>(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + sc) * 6);
+          Jq[2 * q + b][0] = jp[0];
+          Jq[2 * q + b][1] = jp[1];
+          Jq[2 * q + b][2] = jp[2];
+        }
+      const int64_t tn = (grp + gridDim.x) * JOINT_WAVES + wave;
+      if (tn < ntiles) prefetch_planes(tn);
+    } else if constexpr (GLDS) {
       nsim_wait_vm0();                          // this tile's image has landed
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -1241,7 +1280,15 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
     }
     // ======================================================================================= backward
-    if constexpr (NC == 1) {
+    if constexpr (BJD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {      // entry e = 2 q + b holds features r0 = 4 q + 2 b (d f0 / dx) and r0 + 1 (d f1 / dx)
+        const int r0 = 4 * (e >> 1) + 2 * (e & 1);
+        const float m = valid ? 1.f : 0.f;
+        gh[r0] = m * ((float)Jq[e][0].x * gn[0] + (float)Jq[e][0].y * gn[1] + (float)Jq[e][1].x * gn[2]);
+        gh[r0 + 1] = m * ((float)Jq[e][1].y * gn[0] + (float)Jq[e][2].x * gn[1] + (float)Jq[e][2].y * gn[2]);
+      }
+    } else if constexpr (NC == 1) {
 #pragma unroll
       for (int f = 0; f < 16; ++f) gh[f] = Jr[f][0] * gn[0] + Jr[f][1] * gn[1] + Jr[f][2] * gn[2];
     }
