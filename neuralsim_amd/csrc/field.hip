@@ -359,6 +359,9 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 #ifndef NSIM_BWD_JDIRECT
 #define NSIM_BWD_JDIRECT 1      // k_field_bwd_j, <= 16 levels, fp16 mode: features through the LDS image, dh/dx as packed pairs straight into registers
 #endif
+#ifndef NSIM_FWD_JPACKED
+#define NSIM_FWD_JPACKED 1      // ... and held there as the packed pairs of the planes until the normals are formed (0: converted at the load)
+#endif
 #ifndef NSIM_FWD_JDIRECT
 #define NSIM_FWD_JDIRECT 1      // k_field MODE 3, <= 16 levels: features through the LDS image, dh/dx straight into registers
 #endif
@@ -635,6 +638,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // traffic instead of a second latency-bound random gather.
     float h[16 * NC];
     float J[(NC == 1 || GL2) ? 16 * NC : 1][3];     // NC == 2 without the LDS image re-reads dh/dx where it is consumed
+    constexpr bool JPK = JDIR && NSIM_FWD_JPACKED;
+    JPair<JT> Jq[JPK ? 8 : 1][3];                   // JPK: this lane's (level, point) entries as stored
     if constexpr (JDIR) {
       nsim_wait_vm0();                          // this tile's image has landed
 #pragma unroll
@@ -654,7 +659,14 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int l = 4 * q + 2 * hi + b, r0 = 4 * q + 2 * b;
-          jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + sc) * 6, J[r0], J[r0 + 1]);
+          if constexpr (JPK) {      // held as stored -- three packed pairs -- until the normals are formed after the decoder: 24 registers in f16
+            const JPair<JT>* jp = reinterpret_cast<const JPair<JT>*>(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + sc) * 6);
+            Jq[2 * q + b][0] = jp[0];
+            Jq[2 * q + b][1] = jp[1];
+            Jq[2 * q + b][2] = jp[2];
+          } else {
+            jload6(reinterpret_cast<const JT*>(a.J_pl) + ((int64_t)l * a.PS + sc) * 6, J[r0], J[r0 + 1]);
+          }
         }
       if (tile + wstride < ntiles) prefetch_planes(tile + wstride);
     } else if constexpr (GLDS) {
@@ -809,7 +821,18 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     if constexpr (FWD) {
       if constexpr (MODE == 3) { KT(2, 3); }
       float nab[3];
-      if constexpr (NC == 1 || GL2) {
+      if constexpr (JPK) {
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {      // entry e = 2 q + b: features r0 = 4 q + 2 b (d f0 / dx) and r0 + 1 (d f1 / dx)
+          const int r0 = 4 * (e >> 1) + 2 * (e & 1);
+          acc[0] = acc[0] + g[r0] * (float)Jq[e][0].x + g[r0 + 1] * (float)Jq[e][1].y;
+          acc[1] = acc[1] + g[r0] * (float)Jq[e][0].y + g[r0 + 1] * (float)Jq[e][2].x;
+          acc[2] = acc[2] + g[r0] * (float)Jq[e][1].x + g[r0 + 1] * (float)Jq[e][2].y;
+        }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) nab[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
+      } else if constexpr (NC == 1 || GL2) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
           float acc = 0.f;
