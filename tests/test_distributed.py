@@ -460,6 +460,58 @@ def test_multi_object_trainer_two_ranks_overlapped_exchange(tmp_path):
         assert torch.equal(a[k], b[k]), k
 
 
+def _reducer_worker(rank, world, port, out_dir):
+    """``BackwardReducer`` alone: three 'tables' whose gradients arrive in DIFFERENT orders on the two ranks, one of them not at
+    all on rank 1 -- every rank must issue the same collective sequence (no deadlock, no mismatched sizes) and every sum be right."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NSIM_ALLREDUCE_DTYPE="f32")
+    torch.set_num_threads(1)
+    from neuralsim_amd import distributed as nd
+    nd.init_env(backend="gloo", device_type="cpu")
+    g = torch.Generator().manual_seed(5)
+    A, B, Cc = (torch.nn.Parameter(torch.randn(n, generator=g)) for n in (5000, 7001, 4099))      # different sizes: a mismatch would fail
+    small = torch.nn.Parameter(torch.randn(17, generator=g))
+    red = nd.BackwardReducer([A, B, Cc, small], small_numel=4096)
+    assert len(red.big) == 3
+
+    def loss_fn(step):
+        w = float(rank + 1 + step)
+        if rank == 0:       # completion order of the engine: the LAST used parameter's gradient is ready first
+            return (A * w).sum() * 1.0 + (B * 2 * w).sum() + (Cc * 3 * w).sum() + (small * w).sum()
+        # rank 1: another expression order, and B not in the graph at all (its rays missed that model)
+        return (Cc * 3 * w).sum() + (small * w).sum() + (A * w).sum()
+    for step in range(3):
+        for p in (A, B, Cc, small):
+            p.grad = None
+        red.begin()
+        loss_fn(step).backward()
+        red.finish_small()
+        for _ in red.finish_big():
+            pass
+        w0, w1 = 1.0 + step, 2.0 + step
+        assert torch.allclose(A.grad, torch.full_like(A, w0 + w1))
+        assert torch.allclose(B.grad, torch.full_like(B, 2 * w0))                 # rank 1 contributed zeros
+        assert torch.allclose(Cc.grad, torch.full_like(Cc, 3 * (w0 + w1)))
+        assert torch.allclose(small.grad, torch.full_like(small, w0 + w1))
+        order = [id(p) for p in red.big]
+        orders = [None] * world
+        dist.all_gather_object(orders, [[id(A), id(B), id(Cc)].index(i) for i in order])
+        assert orders[0] == orders[1], orders                                     # one release order on every rank
+        if step >= 1:
+            assert [k for k, _ in red.log] == [0, 1, 2]                             # released in that order ...
+            if rank == 0:
+                assert sum(w == "backward" for _, w in red.log) >= 1                # ... and during the backward where possible
+    dist.barrier()
+    (Path(out_dir) / f"reducer_ok{rank}").write_text("ok")
+    dist.destroy_process_group()
+
+
+def test_backward_reducer_keeps_one_collective_order(tmp_path):
+    mp.spawn(_reducer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"reducer_ok{r}").exists() for r in range(2))
+
+
 def test_bench_cli_gpus_2_becomes_two_ranks():
     """``python bench.py --gpus 2`` WITHOUT a launcher environment must become two ranks by itself (it
     re-executes under ``python -m torch.distributed.run --nproc-per-node 2``) and the line must say n_gpus 2 == ranks seen 2.
