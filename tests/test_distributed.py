@@ -303,6 +303,44 @@ def test_two_rank_overlapped_schedule_on_gpu(tmp_path):
     assert float(a["losses"][-1]) < float(a["losses"][0]) and float(b["losses"][-1]) < float(b["losses"][0])
 
 
+def _gpu_street_worker(rank, world, port, out_dir):
+    """The street trainer's hook-driven exchange (``BackwardReducer``) with the real HIP kernels and streams: two ranks sharing ONE
+    GPU over gloo, the small tables counted as 'big' so that they leave through the hooks."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), NSIM_OVERLAP_ALLREDUCE="1", NSIM_ALLREDUCE_DTYPE="f32")
+    torch.manual_seed(0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from neuralsim_amd import distributed as nd, scenarios as sc
+    dev = torch.device("cuda", 0)
+    tr = sc.build_street_trainer(dev, rank=rank, world_size=world, small=True, rays_per_gpu=64, lidar_rays=64, num_uniform=32, seed=42)
+    assert not tr._fused_ok()
+    tr._reducer = red = nd.BackwardReducer(tr.optim.params(), small_numel=1 << 12)
+    logs = []
+    for it in range(4):
+        loss = tr.train_step(it)
+        assert float(loss) == float(loss)
+        logs.append(list(red.log))
+    assert all(w == "finish" for _, w in logs[0]) and sum(w == "backward" for _, w in logs[-1]) >= 2, logs
+    for name, t in (("grid", tr.model.encoding.flattened_params), ("sdf_w", tr.model.sdf_w), ("rad_w", tr.model.rad_w),
+                    ("distant", tr.distant_model.flattened_params), ("sky", tr.sky_model.w), ("appear", tr.appear)):
+        g = t.detach().clone()
+        gs = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        assert torch.equal(gs[0], gs[1]), name
+    dist.barrier()
+    (Path(out_dir) / f"gpu_street_ok{rank}").write_text("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_street_exchange_during_the_backward_on_gpu(tmp_path):
+    mp.spawn(_gpu_street_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"gpu_street_ok{r}").exists() for r in range(2))
+
+
 def _street_worker(rank, world, port, out_dir, steps, overlap="1", tag=None):
     """The street trainer (configs[3] shape, small: NeuS street + distant + sky, pixel step AND lidar step per iteration) under
     ``world`` gloo ranks on the kernel emulator: the autograd-path schedule -- ``allreduce_grads`` after each backward, the
