@@ -551,17 +551,24 @@ def _with_pos_embed(p, n_freq, seed):
     return p
 
 
-@pytest.mark.parametrize("case", ["vehicle_relu", "softplus_D1_aabb", "softplus_D2_scale", "ten_frequencies"])
+@pytest.mark.parametrize("case", ["vehicle_relu", "softplus_D1_aabb", "softplus_D2_scale", "ten_frequencies", "24_levels"])
 def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
     """``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: 6}`` (the StyleLoTD Vehicle block,
     no_fg_occ.221218.yaml:319-321, with its relu 2x64 decoder :354-357): the decoder reads [features | embedded position]
     (71 inputs) on csrc/wide_field.hip -- values, normals, colours, the no-grad query and every gradient against the oracle,
     including the second-order path of the normals through the embedded position's own x-derivative."""
     sdf_D = 1 if case == "softplus_D1_aabb" else 2
-    p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=11, noise_scale=1.0)
-    # (first-layer widths 71 / 53 / 71 / 95: the 72-, 56- and 104-wide instantiations of k_wide; above 72 the weight-gradient row
-    # of a lane goes through LDS instead of registers)
-    n_freq = {"softplus_D1_aabb": 3, "ten_frequencies": 10}.get(case, 6)
+    if case == "24_levels":     # a 24-level pyramid (the 32-level planes of the gather) + ten frequencies: 48 + 63 = 111 inputs
+        lod_res = [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(24)]
+        p = ofield.make_field_params(lod_res=lod_res, log2_hashmap_size=12, sdf_D=sdf_D, seed=11, sphere_init=False,
+                                     grid_bound=0.3, noise_scale=1.0)
+        p.grid = p.grid.float()
+    else:
+        p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=11, noise_scale=1.0)
+    # (first-layer widths 71 / 53 / 71 / 95 / 111: the 72-, 56-, 104- and 128-wide instantiations of k_wide; above 72 the
+    # weight-gradient row of a lane goes through LDS instead of registers)
+    n_freq = {"softplus_D1_aabb": 3, "ten_frequencies": 10, "24_levels": 10}.get(case, 6)
+    F1 = 2 * len(p.spec.lod_res)
     _with_pos_embed(p, n_freq, seed=3)
     if case == "vehicle_relu":
         p.sdf_activation = "relu"
@@ -572,7 +579,7 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
     for t in p.tensors():
         t.requires_grad_(True)
     model = model_from_params(p, backend, precision="fp16" if case == "vehicle_relu" else "f32")
-    assert model.pos_embed_E == 3 + 6 * n_freq and model.sdf_w.numel() == 64 * (32 + model.pos_embed_E) + (4096 if sdf_D == 2 else 0) + 64
+    assert model.pos_embed_E == 3 + 6 * n_freq and model.sdf_w.numel() == 64 * (F1 + model.pos_embed_E) + (4096 if sdf_D == 2 else 0) + 64
     g = torch.Generator().manual_seed(6)
     R, S = 9, 203
     rays_o = torch.randn(R, 3, generator=g) * 0.1
@@ -610,8 +617,8 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
         assert e < (3e-2 if case == "vehicle_relu" else 3e-4), (k, e)
     assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < (3e-2 if case == "vehicle_relu" else 3e-4)
     # the embedded-position columns of W1 carry gradient (first- and second-order terms)
-    FIN = 32 + model.pos_embed_E
-    assert float(model.sdf_w.grad[:64 * FIN].view(64, FIN)[:, 32:].abs().max()) > 0
+    FIN = F1 + model.pos_embed_E
+    assert float(model.sdf_w.grad[:64 * FIN].view(64, FIN)[:, F1:].abs().max()) > 0
 
 
 def test_pair_pack_equals_the_two_single_packs(backend):
