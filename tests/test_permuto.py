@@ -304,9 +304,12 @@ def test_training_steps_on_the_permuto_model(backend):
     m, tr = build()
     assert tr._fused_ok()                           # the fused launch chain runs on the encoding hooks: this model as well
     before = m.encoding.flattened_params.detach().clone()
-    losses = [float(tr.train_step(it)) for it in range(8)]
-    # (jittered samples: single losses scatter by ~10 % -- the trend over three steps at both ends)
-    assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3]), losses
+    # every step on the SAME batch with the SAME jitter draws (util.steps_on_a_fixed_objective): the losses are values of one
+    # function of the parameters along Adam's trajectory.  (Rounds 3-5 asserted a trend over freshly jittered 24-ray steps,
+    # which is noise of ~10 % around a pre-trained field's loss: it failed on the driver's box twice.)
+    from util import steps_on_a_fixed_objective
+    losses = steps_on_a_fixed_objective(tr, range(8))
+    assert all(l == l for l in losses) and losses[-1] < losses[0] and min(losses[4:]) < 0.97 * losses[0], losses
     assert tr.stats["R_hit"] > 0 and not torch.equal(before, m.encoding.flattened_params.detach())
     assert torch.equal(m.encoding.shadow(), m.encoding.flattened_params.detach().half())
     # the fused chain and the autograd path compute the same step: the state after these steps is rolled back (parameters, buffers,

@@ -5,7 +5,7 @@ import torch
 from neuralsim_amd.fields.neus import LoTDNeuSModel
 from neuralsim_amd.graphics.cameras import look_at_cameras
 from neuralsim_amd.trainer import RenderTrainer
-from util import SMALL_RES
+from util import SMALL_RES, steps_on_a_fixed_objective
 
 
 def _tiny(backend, seed=42):
@@ -28,7 +28,7 @@ def test_train_steps_reduce_loss(backend):
     xy, fidx, gt = tr.sample_batch()
     fixed = lambda: (xy, fidx, gt)
     tr.sample_batch = fixed                      # overfit one batch
-    losses = [float(tr.train_step(it)) for it in range(6)]
+    losses = steps_on_a_fixed_objective(tr, range(6))        # one batch, one set of jitter draws: a fixed objective
     assert all(l == l for l in losses)           # no NaN
     assert losses[-1] < losses[0], losses
     assert 0 < tr.stats["R_live"] <= tr.stats["R_hit"] and tr.stats["S_f"] >= tr.stats["R_live"] * 16
@@ -49,7 +49,7 @@ def test_train_steps_with_a_distorted_camera(backend):
     assert torch.equal(b["xy"], bp["xy"]) and float((b["rays_d"] - bp["rays_d"]).abs().max()) > 1e-4
     xy, fidx, gt = tr.sample_batch()
     tr.sample_batch = lambda: (xy, fidx, gt)         # overfit one batch (fresh batches of 32 rays are too noisy to compare)
-    losses = [float(tr.train_step(it)) for it in range(6)]
+    losses = steps_on_a_fixed_objective(tr, range(6))
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
 
 
@@ -196,9 +196,10 @@ def test_model_built_from_reference_model_params_trains(backend):
     xy, fidx, gt = tr.sample_batch()
     tr.sample_batch = lambda: (xy, fidx, gt)
     losses, active = [], []
-    for it in range(6):
-        losses.append(float(tr.train_step(it)))
-        active.append(m.encoding.cfg.meta.n_active_levels)
+    real_step = tr.train_step
+    tr.train_step = lambda it: (real_step(it), active.append(m.encoding.cfg.meta.n_active_levels))[0]
+    losses = steps_on_a_fixed_objective(tr, range(6))            # one batch, one set of jitter draws
+    tr.train_step = real_step
     # the loss falls between two level activations (a freshly unmasked level perturbs it: hardmask annealing)
     assert all(l == l for l in losses) and losses[2] < losses[0] and losses[-1] < losses[3], losses
     assert active[0] == 3 and active[-1] == 0                    # hardmask: levels 0..2 at it 0, all from stop_it on

@@ -1,5 +1,6 @@
 """Shared helpers for the parity tests (oracle <-> product weight exchange, synthetic cameras)."""
 import math
+import os
 
 import torch
 
@@ -137,3 +138,27 @@ def oracle_of_sky(sm):
     ws = [w[:W * IN].view(W, IN).clone(), w[W * IN:W * IN + W * W].view(W, W).clone(), w[W * IN + W * W:].view(3, W).clone()]
     bs = [b[:W].clone(), b[W:2 * W].clone(), b[2 * W:].clone()]
     return ws, bs
+
+
+def steps_on_a_fixed_objective(tr, its):
+    """``tr.train_step(it)`` for every ``it`` of ``its`` with the trainer's random streams rewound before each step, on a
+    trainer whose ``sample_batch`` was pinned to one batch: every step then sees the SAME pixels, the SAME marching / depth
+    jitter and the SAME uniform eikonal points, so the returned losses are values of one fixed function of the parameters
+    along the optimiser's trajectory.  "The loss went down" on that sequence is a statement about the step (gradient sign,
+    Adam, shadow refresh), not about which jitter a step happened to draw -- a trend over freshly jittered 24-ray batches is
+    noise (0.0154, 0.0140, 0.0163, 0.0139 ... on the driver's box)."""
+    state = (tr.gen.get_state(), tr.gen_shared.get_state(), torch.get_rng_state(),
+             torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+    losses = []
+    for it in its:
+        tr._prefetched = None                       # (a batch drawn ahead of time carries the previous draw's jitter)
+        tr.gen.set_state(state[0])
+        tr.gen_shared.set_state(state[1])
+        torch.set_rng_state(state[2])
+        if state[3] is not None:
+            torch.cuda.set_rng_state(state[3])
+        losses.append(float(tr.train_step(it)))
+    tr._prefetched = None
+    if os.environ.get('NSIM_PRINT_LOSSES'):
+        print('losses', ['%.5f' % l for l in losses])
+    return losses
