@@ -444,8 +444,13 @@ template <class T>
 __device__ __forceinline__ void jstore6(T* p, const float (&a)[3], const float (&b)[3]) {
   JPair<T>* q = reinterpret_cast<JPair<T>*>(p);
   JPair<T> v0, v1, v2;
-  v0.x = (T)a[0]; v0.y = (T)a[1]; v1.x = (T)a[2];
-  v1.y = (T)b[0]; v2.x = (T)b[1]; v2.y = (T)b[2];
+  if constexpr (sizeof(T) == 2) {   // f16 planes: dscale (R - 1) * (feature difference) of a fine level can pass 65504 -> saturate, never inf
+    v0.x = (T)f16_sat(a[0]); v0.y = (T)f16_sat(a[1]); v1.x = (T)f16_sat(a[2]);
+    v1.y = (T)f16_sat(b[0]); v2.x = (T)f16_sat(b[1]); v2.y = (T)f16_sat(b[2]);
+  } else {
+    v0.x = (T)a[0]; v0.y = (T)a[1]; v1.x = (T)a[2];
+    v1.y = (T)b[0]; v2.x = (T)b[1]; v2.y = (T)b[2];
+  }
   q[0] = v0; q[1] = v1; q[2] = v2;
 }
 template <class T>

@@ -90,53 +90,60 @@ __global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restr
                                                            int64_t* __restrict__ cnts, int64_t* notify, int64_t seq,
                                                            int64_t* __restrict__ pi, int64_t* __restrict__ total, int64_t cap,
                                                            int64_t* notify_total, int64_t seq_total) {
+  // two sums ride one pass: the sample counts (int64) and the live-ray count.  (Rounds 4-5 packed both into one int64 scan with
+  // the live count in bits 44..63: 2^19 live rays reached the sign bit -- an 800x800 image queried in one chunk has 640 k rays.)
   __shared__ int64_t wtot[PI_THREADS / 64];
+  __shared__ int64_t wlive[PI_THREADS / 64];
   const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
-  const int64_t LIVE1 = (int64_t)1 << 44;        // (live count << 44) | sample count: one scan carries both sums
-  const int64_t LOW = LIVE1 - 1;
-  int64_t carry = 0;
+  int64_t carry = 0, carry_live = 0;
   for (int64_t base = 0; base < R; base += (int64_t)PI_THREADS * PI_PER) {
     const int64_t i0 = base + (int64_t)tid * PI_PER;
     int64_t v[PI_PER];
-    int64_t mine = 0;
+    int64_t mine = 0, mine_live = 0;
 #pragma unroll
     for (int k = 0; k < PI_PER; ++k) {
-      const int64_t c = (i0 + k) < R ? n[i0 + k] : 0;
-      v[k] = c + (c > 0 ? LIVE1 : 0);
+      v[k] = (i0 + k) < R ? n[i0 + k] : 0;
       mine += v[k];
+      mine_live += v[k] > 0 ? 1 : 0;
     }
-    const int64_t incl = wave_incl_sum(mine);
-    if (lane == 63) wtot[wave] = incl;
+    const int64_t incl = wave_incl_sum(mine), incl_live = wave_incl_sum(mine_live);
+    if (lane == 63) {
+      wtot[wave] = incl;
+      wlive[wave] = incl_live;
+    }
     __syncthreads();
-    int64_t before = 0, chunk = 0;
+    int64_t before = 0, chunk = 0, before_live = 0, chunk_live = 0;
 #pragma unroll
     for (int w = 0; w < PI_THREADS / 64; ++w) {
-      const int64_t x = wtot[w];
+      const int64_t x = wtot[w], y = wlive[w];
       before += (w < wave) ? x : 0;
       chunk += x;
+      before_live += (w < wave) ? y : 0;
+      chunk_live += y;
     }
     int64_t run = carry + before + incl - mine;
+    int64_t q = carry_live + before_live + incl_live - mine_live;
 #pragma unroll
     for (int k = 0; k < PI_PER; ++k) {
       const int64_t i = i0 + k;
       if (i < R) {
-        const int64_t q = run >> 44;
-        const bool live = v[k] >= LIVE1;
+        const bool live = v[k] > 0;
         live_rank[i] = live ? q : ~q;
         if (live && live_idx) live_idx[q] = i;
         if (pi) {      // (k_pack_infos_from_n's rule for a speculative capacity)
-          const int64_t off = run & LOW, c = v[k] & LOW;
-          const bool over = cap >= 0 && off + c > cap;
-          pi[2 * i] = (cap >= 0 && off > cap) ? cap : off;
-          pi[2 * i + 1] = over ? 0 : c;
+          const bool over = cap >= 0 && run + v[k] > cap;
+          pi[2 * i] = (cap >= 0 && run > cap) ? cap : run;
+          pi[2 * i + 1] = over ? 0 : v[k];
         }
+        q += live ? 1 : 0;
       }
       run += v[k];
     }
     carry += chunk;
+    carry_live += chunk_live;
     __syncthreads();
   }
-  const int64_t Rl = carry >> 44, M = carry & LOW;
+  const int64_t Rl = carry_live, M = carry;
   if (live_idx)
     for (int64_t i = Rl + tid; i < R; i += PI_THREADS) live_idx[i] = 0;
   if (tid == 0) {

@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(256) k_permuto_fwd(PermutoArgs a) {
       f16* jp = reinterpret_cast<f16*>(a.J_pl) + ep * 6;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        jp[c] = (f16)j0[c];
-        jp[3 + c] = (f16)j1[c];
+        jp[c] = (f16)fminf(fmaxf(j0[c], -65504.0f), 65504.0f);        // (saturate: a fine level's scale x feature jump can pass the f16 range)
+        jp[3 + c] = (f16)fminf(fmaxf(j1[c], -65504.0f), 65504.0f);
       }
     } else {
       float* jp = reinterpret_cast<float*>(a.J_pl) + ep * 6;

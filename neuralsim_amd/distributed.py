@@ -266,6 +266,8 @@ class BackwardReducer:
         self._toks = [None] * len(self.big)
         self._next = 0
         self.log: List[tuple] = []       # (big index, "backward" | "finish") per released parameter of the last step
+        self._absent_here = set()        # ids of big parameters this rank had no gradient for (zeros went on the wire)
+        self.absent = set()              # ids of the parameters NO rank had a gradient for in this step (after finish_small)
         self.on_release = None           # test hook: called with the big index right before its collective is issued
         self._pos = {id(p): i for i, p in enumerate(self.big)}       # position of a parameter in the CURRENT release order
         for p in self.big:
@@ -278,10 +280,13 @@ class BackwardReducer:
         self._toks = [None] * len(self.big)
         self._next = 0
         self.log = []
+        self._absent_here = set()
+        self.absent = set()
 
     def _start(self, k: int, where: str):
         p = self.big[k]
         if p.grad is None:
+            self._absent_here.add(id(p))          # zeros on the wire (the issue order is fixed); see finish_small
             p.grad = torch.zeros_like(p, dtype=torch.float32)
         elif not p.grad.is_contiguous():
             p.grad = p.grad.contiguous()
@@ -310,16 +315,29 @@ class BackwardReducer:
             self._start(k, "finish")
         self._next = len(self.big)
         small = [p for p in self.params if not any(p is q for q in self.big)]
-        if small:
+        # Presence agreement rides on the small bucket (ONE collective, at the same place of every rank's sequence): a flag per
+        # parameter, 1 where this rank has a gradient.  A parameter NO rank has a gradient for -- a sky or distant model absent
+        # from every rank's batch, the radiance heads in the lidar step -- keeps ``.grad = None`` and is not stepped, exactly as
+        # at world size 1 (torch Adam and the reference's DDP(find_unused_parameters=True) skip it).  Rounds 4-5 zero-filled
+        # it on every rank: a momentum-only update and an advanced step count, i.e. world size > 1 drifted from world size 1.
+        if self.params:
+            here = [0.0 if (p.grad is None or id(p) in self._absent_here) else 1.0 for p in self.params]
+            dev = self.params[0].device
+            flags = torch.tensor(here, dtype=torch.float32, device=dev)
             for p in small:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p, dtype=torch.float32)
-            flat = torch.cat([p.grad.reshape(-1).float() for p in small])
+            flat = torch.cat([p.grad.reshape(-1).float() for p in small] + [flags])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            seen = flat[flat.numel() - len(self.params):].tolist()
+            self.absent = {id(p) for p, c in zip(self.params, seen) if c == 0.0}
             off = 0
             for p in small:
                 n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                if id(p) in self.absent:
+                    p.grad = None
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
         if not self._order_known:
             # adopt rank 0's completion order (parameters it never saw a gradient for go last, in index order)
@@ -336,13 +354,26 @@ class BackwardReducer:
     def finish_big(self):
         """Yields every big parameter once its sum has arrived in ``.grad`` (issue order = arrival order)."""
         for k, p in enumerate(self.big):
-            allreduce_finish(self._toks[k])
-            self._toks[k] = None
+            if self._toks[k] is not None:
+                allreduce_finish(self._toks[k])
+                self._toks[k] = None
+            if id(p) in self.absent:     # zeros from every rank: no gradient anywhere, no step (see finish_small)
+                p.grad = None
+                continue
             yield p
+
+    def drop_absent_big(self):
+        """Wait out the (all-zero) exchange of the big parameters no rank had a gradient for and restore ``.grad = None``."""
+        for k, p in enumerate(self.big):
+            if id(p) in self.absent and self._toks[k] is not None:
+                allreduce_finish(self._toks[k])
+                self._toks[k] = None
+                p.grad = None
 
     def reduce_and_step(self, optim, grad_scale: float):
         self.finish_small()
-        optim.step(grad_scale=grad_scale, skip=tuple(self.big))
+        self.drop_absent_big()
+        optim.step(grad_scale=grad_scale, skip=tuple(p for p in self.big if id(p) not in self.absent))
         for p in self.finish_big():
             optim.step_range(p, 0, p.numel(), p.grad.reshape(-1), grad_scale=grad_scale)
 

@@ -95,7 +95,10 @@ class StyleLoTDNeuSModel(_DeferredConditionalModel, BatchedLoTDNeuSModel):
         if epe is not None and epe.get("type", "identity") not in ("identity", None):
             # [grown features | embedded position] as the decoder's input (no_fg_occ.221218.yaml:319-321: 32 + 39 = 71 values):
             # the model then runs its SDF decoder on csrc/wide_field.hip (LoTDNeuSModel ``pos_embed_frequencies``)
-            if epe.get("type") not in ("sinusoidal_legacy", "sinusoidal"):
+            # only the legacy layout ([x | sin(2^k x), cos(2^k x) per k], no pi) is what the reference's configs use and what the
+            # kernel's column order was written against; the non-legacy embedder's source is not in /root/reference, so a
+            # checkpoint of such a model could load with permuted first-layer columns and no error -- refuse it instead
+            if epe.get("type") != "sinusoidal_legacy":
                 raise NotImplementedError(f"surface_cfg.extra_pos_embed_cfg={epe!r}: identity | sinusoidal_legacy")
             n_embed = int(epe.get("n_frequencies", 6))
         # the encoding of this model IS the grower: hand the decoder / radiance / control blocks to the common translation

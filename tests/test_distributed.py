@@ -510,8 +510,11 @@ def _reducer_worker(rank, world, port, out_dir):
     g = torch.Generator().manual_seed(5)
     A, B, Cc = (torch.nn.Parameter(torch.randn(n, generator=g)) for n in (5000, 7001, 4099))      # different sizes: a mismatch would fail
     small = torch.nn.Parameter(torch.randn(17, generator=g))
-    red = nd.BackwardReducer([A, B, Cc, small], small_numel=4096)
-    assert len(red.big) == 3
+    # ... and two parameters NO rank has a gradient for (a sky / distant model outside every rank's batch): they must come out
+    # with ``.grad is None`` -- un-stepped, as at world size 1 -- while B (absent on rank 1 only) gets rank 0's sum
+    D_big, d_small = torch.nn.Parameter(torch.randn(4500, generator=g)), torch.nn.Parameter(torch.randn(9, generator=g))
+    red = nd.BackwardReducer([A, B, Cc, small, D_big, d_small], small_numel=4096)
+    assert len(red.big) == 4
 
     def loss_fn(step):
         w = float(rank + 1 + step)
@@ -520,13 +523,15 @@ def _reducer_worker(rank, world, port, out_dir):
         # rank 1: another expression order, and B not in the graph at all (its rays missed that model)
         return (Cc * 3 * w).sum() + (small * w).sum() + (A * w).sum()
     for step in range(3):
-        for p in (A, B, Cc, small):
+        for p in (A, B, Cc, small, D_big, d_small):
             p.grad = None
         red.begin()
         loss_fn(step).backward()
         red.finish_small()
-        for _ in red.finish_big():
-            pass
+        stepped = [p for p in red.finish_big()]
+        assert D_big.grad is None and d_small.grad is None and not any(p is D_big for p in stepped)
+        assert red.absent == {id(D_big), id(d_small)}, (rank, step, [(i, id(p) in red.absent) for i, p in enumerate(red.params)])
+        assert sum(any(p is q for p in stepped) for q in (A, B, Cc)) == 3
         w0, w1 = 1.0 + step, 2.0 + step
         assert torch.allclose(A.grad, torch.full_like(A, w0 + w1))
         assert torch.allclose(B.grad, torch.full_like(B, 2 * w0))                 # rank 1 contributed zeros
@@ -534,10 +539,10 @@ def _reducer_worker(rank, world, port, out_dir):
         assert torch.allclose(small.grad, torch.full_like(small, w0 + w1))
         order = [id(p) for p in red.big]
         orders = [None] * world
-        dist.all_gather_object(orders, [[id(A), id(B), id(Cc)].index(i) for i in order])
+        dist.all_gather_object(orders, [[id(A), id(B), id(Cc), id(D_big)].index(i) for i in order])
         assert orders[0] == orders[1], orders                                     # one release order on every rank
         if step >= 1:
-            assert [k for k, _ in red.log] == [0, 1, 2]                             # released in that order ...
+            assert [k for k, _ in red.log] == [0, 1, 2, 3]                          # released in that order ...
             if rank == 0:
                 assert sum(w == "backward" for _, w in red.log) >= 1                # ... and during the backward where possible
     dist.barrier()

@@ -450,6 +450,33 @@ def test_merge_upsample_equals_merge_then_upsample(backend):
         assert bool((outs[0][4][:, 1:] >= outs[0][4][:, :-1]).all())
 
 
+def test_live_rank_beyond_2_to_the_19_live_rays(backend):
+    """an 800x800 image queried in one chunk (``rayschunk: 0``) is 640 k rays; rounds 4-5 carried the live count in bits 44..63
+    of the sample-count scan, which reached the sign bit at 2^19 live rays.  700 k rays, 5 in 6 live."""
+    R = 700_001 if backend.type == "cuda" else 530_000
+    g = torch.Generator().manual_seed(11)
+    counts = torch.randint(0, 6, [R], generator=g)
+    counts[R - 1] = 3
+    live = counts > 0
+    Rl = int(live.sum())
+    assert Rl > 2 ** 19 or backend.type != "cuda"
+    C, nfs = 16, [8, 8, 16, 0]
+    lr = torch.full([R], 123, dtype=torch.long, device=backend)
+    lidx = torch.full([R], 123, dtype=torch.long, device=backend)
+    cnts = torch.zeros(8, dtype=torch.long, device=backend)
+    pi_k = torch.full([R, 2], -7, dtype=torch.long, device=backend)
+    tot_k = torch.zeros(1, dtype=torch.long, device=backend)
+    _lib.call("nsim_live_rank", _lib.ptr(counts.to(backend)), R, C, *nfs, _lib.ptr(lr), _lib.ptr(lidx), _lib.ptr(cnts), None, 0,
+              _lib.ptr(pi_k), _lib.ptr(tot_k), -1, None, 0)
+    q = torch.cumsum(live.long(), 0) - live.long()
+    assert torch.equal(lr.cpu(), torch.where(live, q, ~q))
+    assert torch.equal(lidx.cpu()[:Rl], live.nonzero()[:, 0]) and bool((lidx.cpu()[Rl:] == 0).all())
+    M = int(counts.sum())
+    assert cnts.cpu().tolist() == [Rl, M + Rl * C, Rl * 8, Rl * 8, Rl * 16, 0, M, 0] and int(tot_k) == M
+    off = torch.cumsum(counts, 0) - counts
+    assert torch.equal(pi_k.cpu(), torch.stack([off, counts], -1))
+
+
 def test_live_rank_and_compact_sampling(backend):
     """``upsample_on_marched_only``: ``nsim_live_rank`` (ranks, live list, device-side point counts) and the live-rank form of
     the sampling kernels -- only rays with marched samples get list-b / new samples, every per-live-ray array is indexed by the
