@@ -2105,6 +2105,14 @@ struct ScatterArgs {
   int level_begin;      // this launch covers levels [level_begin, level_begin + gridDim.y)
 };
 
+// CONSEC (default since round 6; NSIM_SCATTER_GROUP=0: the rounds 1-5 form): which 16 samples of the wave's 64 share one atomic
+// instruction.  The atomic unit retires (distinct 64-byte sector, instruction) pairs at ~21 G/s however many lanes of the
+// instruction fall into the sector (profiles/round4_atomic_line_bench.txt), so the launch costs the number of such pairs.
+// Issue I of the quad transposition used to take the samples 4q + I (a DPP quad broadcast): 16 samples spread over the whole
+// chunk.  Taking the 16 CONSECUTIVE samples 16 I + q instead (six ds_bpermute per issue) puts neighbours on a ray -- which sit
+// in x-adjacent cells of one sector, or at fine levels simply in the same cell row -- into the same instruction:
+// tools/scatter_sector_model.py counts 10-11 % fewer pairs on the bench step's sample set.
+template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
   const int l = a.level_begin + (int)blockIdx.y;
@@ -2186,10 +2194,24 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
     const int ee = rq < 2 ? e0 : e1;                                                                         \
     if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
   }
-      NSIM_QUAD_ISSUE(0)
-      NSIM_QUAD_ISSUE(1)
-      NSIM_QUAD_ISSUE(2)
-      NSIM_QUAD_ISSUE(3)
+      if constexpr (CONSEC) {
+        const uint32_t k0 = emit[0] ? idx[0] : 0xffffffffu, k1 = emit[1] ? idx[1] : 0xffffffffu;
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+          const int src = 16 * I + (lane >> 2);
+          const uint32_t i0 = wave_shfl(k0, src), i1 = wave_shfl(k1, src);
+          const float a0 = wave_shfl(v0[0], src), a1 = wave_shfl(v1[0], src);
+          const float b0 = wave_shfl(v0[1], src), b1 = wave_shfl(v1[1], src);
+          const uint32_t ii = rq < 2 ? i0 : i1;
+          const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));
+          if (ii != 0xffffffffu) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);
+        }
+      } else {
+        NSIM_QUAD_ISSUE(0)
+        NSIM_QUAD_ISSUE(1)
+        NSIM_QUAD_ISSUE(2)
+        NSIM_QUAD_ISSUE(3)
+      }
 #undef NSIM_QUAD_ISSUE
     }
   }
@@ -2900,7 +2922,12 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   const int64_t chunks = (S + 63) / 64;
   sa.level_begin = level_begin;
   const dim3 grid(nsim_blocks(chunks, 4, 4096), level_count);
-  hipLaunchKernelGGL(k_lotd_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  const char* eg = getenv("NSIM_SCATTER_GROUP");       // (read per launch: A/B runs flip it inside one process)
+  const bool consec = !(eg && atoi(eg) == 0);
+  if (consec)
+    hipLaunchKernelGGL(k_lotd_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  else
+    hipLaunchKernelGGL(k_lotd_scatter<false>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

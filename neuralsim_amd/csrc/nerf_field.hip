@@ -758,6 +758,9 @@ struct Scatter4Args {
   int dedup_max_rw;
 };
 
+// CONSEC: issue I of the quad transposition carries the 16 consecutive shells 16 I + q instead of the shells 4q + I (see
+// k_lotd_scatter in field.hip: the atomic unit is paid per distinct 64-byte sector per instruction; NSIM_SCATTER_GROUP=0: off)
+template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
   const int lane = nsim_lane();
   const int l = blockIdx.y;
@@ -825,10 +828,24 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
     const int ee = rq < 2 ? e0 : e1;                                                                       \
     if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                              \
   }
-      NSIM_QUAD4(0)
-      NSIM_QUAD4(1)
-      NSIM_QUAD4(2)
-      NSIM_QUAD4(3)
+      if constexpr (CONSEC) {
+        const uint32_t k0 = emit[0] ? idx[0] : 0xffffffffu, k1 = emit[1] ? idx[1] : 0xffffffffu;
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+          const int src = 16 * I + (lane >> 2);
+          const uint32_t i0 = wave_shfl(k0, src), i1 = wave_shfl(k1, src);
+          const float a0 = wave_shfl(v0[0], src), a1 = wave_shfl(v1[0], src);
+          const float b0 = wave_shfl(v0[1], src), b1 = wave_shfl(v1[1], src);
+          const uint32_t ii = rq < 2 ? i0 : i1;
+          const float vv = rq == 0 ? a0 : (rq == 1 ? a1 : (rq == 2 ? b0 : b1));
+          if (ii != 0xffffffffu) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);
+        }
+      } else {
+        NSIM_QUAD4(0)
+        NSIM_QUAD4(1)
+        NSIM_QUAD4(2)
+        NSIM_QUAD4(3)
+      }
 #undef NSIM_QUAD4
     }
   }
@@ -998,7 +1015,11 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   sa.dedup_max_rw = 1 << 30;      // every level: 3.62 -> 1.73 ms per 0.52 M shell points (levels with Rw <= 16 / 64 only: 2.07 / 1.76)
   if (const char* e = getenv("NSIM_DEDUP4_MAX_RW")) sa.dedup_max_rw = atoi(e);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
-  hipLaunchKernelGGL(k_lotd4_scatter, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  const char* eg = getenv("NSIM_SCATTER_GROUP");
+  if (!(eg && atoi(eg) == 0))
+    hipLaunchKernelGGL(k_lotd4_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
+  else
+    hipLaunchKernelGGL(k_lotd4_scatter<false>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   NSIM_CHECK_LAUNCH();
   return 0;
 }
