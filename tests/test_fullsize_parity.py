@@ -258,6 +258,30 @@ def _api_path_body(precision, compressed, encoding):
     rec["fix_grad_sdf_dec"] = rel_l2(torch.cat([got["sdf_w"].cpu().flatten(), got["sdf_b"].cpu().flatten()]),
                                      torch.cat([ref["sdf_w"].flatten(), ref["sdf_b"].flatten()]))
     rec["ref_norm_sdf_w"], rec["ref_norm_sdf_b"] = float(ref["sdf_w"].norm()), float(ref["sdf_b"].norm())
+    if not e2e_tight:
+        # ---- a WELL-CONDITIONED gradient check on the same sample set: random cotangents on the field's three outputs.
+        # The render loss above is close to stationary for the pre-trained decoder -- its weight gradient is a sum of signed
+        # terms that cancel to a norm which differs from one device pre-training to the next (float atomics), so a relative
+        # error against that norm measures the conditioning of the run, not the kernels (flake hunt, round 6: 0.017 in two
+        # runs, 0.104 in the third; round 4: 0.02 .. 0.48 on the bias part).  With random signs nothing cancels: the relative
+        # error is the kernels' own fp16 / f32 error whatever field the pre-training ended at.
+        S_o = int(vbo["t"].shape[0])
+        gr = torch.Generator().manual_seed(123)
+        c_sdf, c_nab, c_rgb = torch.randn(S_o, generator=gr), torch.randn(S_o, 3, generator=gr), torch.randn(S_o, 3, generator=gr)
+        _fresh(p)
+        ridx_c = ridx_o.cpu()
+        x_c = (o[ri][ridx_c] + vbo["t"].detach()[:, None] * d[ri][ridx_c])
+        sdf_r, nab_r, rgb_r = ofield.forward_field(x_c, d[ri][ridx_c], ha[ri][ridx_c], p)
+        ((sdf_r * c_sdf).sum() + (nab_r * c_nab).sum() + (rgb_r * c_rgb).sum()).div(S_o).backward()
+        ref_r = oracle_flat_grads(p)
+        _zero_grads(tr)
+        ha_p3 = leaf(ha[ri], dev)
+        sdf3, nab3, rgb3 = _FieldFn.apply(m, m.encoding.flattened_params, m.sdf_w, m.sdf_b, m.rad_w, m.rad_b, ha_p3, None, o_h,
+                                          d_h, t_o, ridx_o, True)
+        ((sdf3 * dv(c_sdf)).sum() + (nab3 * dv(c_nab)).sum() + (rgb3 * dv(c_rgb)).sum()).div(S_o).backward()
+        got_r = _product_grads(tr)
+        for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b"):
+            rec["rnd_grad_" + k] = rel_l2(got_r[k].cpu(), ref_r[k])
     _report(("permuto_" if encoding == "permuto" else "") + f"api_{precision}_{'compressed' if compressed else 'full'}", rec)
 
     # ---------------------------------------------------------------- assertions
@@ -284,11 +308,19 @@ def _api_path_body(precision, compressed, encoding):
         # The bias gradient of the device-pre-trained decoder is sum_i dL/d(pre-activation_i): signed terms that cancel, to a
         # norm that differs from one pre-training run to the next (float atomics); its relative error is run dependent (round 4, 8 fresh-process runs on identical forward errors: 0.02 .. 0.06 seven times, 0.48 once, with
         # sdf_w at 0.02 .. 0.09 throughout).  The decoder's gradient is asserted as one vector (weights + biases); the
-        # bias part alone is reported (``fix_grad_sdf_b``, ``ref_norm_sdf_b``) and bounded loosely.
-        fix_keys[fix_keys.index("sdf_b")] = "sdf_dec"
+        # bias part alone is reported (``fix_grad_sdf_b``, ``ref_norm_sdf_b``) and bounded loosely.  Round 6: the flake hunt
+        # (3 fresh-process suites on one lease) saw the combined vector at 0.017, 0.017 and 0.104 -- the render-loss gradient of
+        # the decoder is bounded loosely as a whole (0.5); the kernels' own error is what the random-cotangent leg asserts.
+        fix_keys.remove("sdf_b")
+        fix_keys.remove("sdf_w")
         assert rec["fix_grad_sdf_b"] < 1.0, rec["fix_grad_sdf_b"]
+        assert rec["fix_grad_sdf_dec"] < 0.5, rec["fix_grad_sdf_dec"]
     for k in fix_keys:
         assert rec["fix_grad_" + k] < gtol, (k, rec["fix_grad_" + k])
+    if not e2e_tight:
+        # random cotangents: f32 = the exact-f32 kernels (measured <= 1e-5), fp16 = f16 MFMA operands / f16 tables
+        for k in ("grid", "sdf_w", "sdf_b", "rad_w", "rad_b"):
+            assert rec["rnd_grad_" + k] < (2e-4 if precision == "f32" else 3e-2), (k, rec["rnd_grad_" + k])
     if not e2e_tight:
         assert rec["psnr_rgb_db"] > 55.0 and abs(rec["loss"] - rec["loss_oracle"]) < 2e-2 * (1 + abs(rec["loss_oracle"]))
     elif precision == "f32":

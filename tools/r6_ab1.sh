@@ -23,3 +23,7 @@ for l in sys.stdin:
 "
 tail -5 $OUT/new_tests.log
 cat $OUT/atomic_conflict_bench.txt
+for i in 1 2 3; do
+  python -m pytest tests/test_fullsize_parity.py -q -m gpu -s -p no:cacheprovider -k "permuto_model" > $OUT/permuto_parity_$i.log 2>&1
+  echo "permuto parity $i rc=$?"; grep -o '"rnd_grad_[a-z_]*": [0-9.e-]*' $OUT/permuto_parity_$i.log | tr '\n' ' '; echo
+done
