@@ -2105,13 +2105,14 @@ struct ScatterArgs {
   int level_begin;      // this launch covers levels [level_begin, level_begin + gridDim.y)
 };
 
-// CONSEC (default since round 6; NSIM_SCATTER_GROUP=0: the rounds 1-5 form): which 16 samples of the wave's 64 share one atomic
-// instruction.  The atomic unit retires (distinct 64-byte sector, instruction) pairs at ~21 G/s however many lanes of the
-// instruction fall into the sector (profiles/round4_atomic_line_bench.txt), so the launch costs the number of such pairs.
-// Issue I of the quad transposition used to take the samples 4q + I (a DPP quad broadcast): 16 samples spread over the whole
-// chunk.  Taking the 16 CONSECUTIVE samples 16 I + q instead (six ds_bpermute per issue) puts neighbours on a ray -- which sit
-// in x-adjacent cells of one sector, or at fine levels simply in the same cell row -- into the same instruction:
-// tools/scatter_sector_model.py counts 10-11 % fewer pairs on the bench step's sample set.
+// CONSEC (NSIM_SCATTER_GROUP=1; a measured null, kept for the record): which 16 samples of the wave's 64 share one atomic
+// instruction.  The atomic unit retires one request per distinct 64-byte sector per instruction at ~21 G/s
+// (profiles/round4_atomic_line_bench.txt), so the launch costs the number of such requests.  Issue I of the quad
+// transposition takes the samples 4q + I (a DPP quad broadcast): 16 samples spread over the whole chunk.  Taking the 16
+// CONSECUTIVE samples 16 I + q instead (six ds_bpermute per issue) puts neighbours on a ray into one instruction -- but
+// neighbours in x-adjacent cells share a VERTEX, and lanes of one instruction on the same address are separate requests
+// (profiles/round6_atomic_conflict_bench.txt): the request model (tools/scatter_sector_model.py) gives 25.13 -> 24.92 per
+// point and the bench step measured 0.376 ms either way (profiles/round6_scatter_requests.json).
 template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
@@ -2923,7 +2924,7 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   sa.level_begin = level_begin;
   const dim3 grid(nsim_blocks(chunks, 4, 4096), level_count);
   const char* eg = getenv("NSIM_SCATTER_GROUP");       // (read per launch: A/B runs flip it inside one process)
-  const bool consec = !(eg && atoi(eg) == 0);
+  const bool consec = eg && atoi(eg) == 1;
   if (consec)
     hipLaunchKernelGGL(k_lotd_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   else

@@ -758,8 +758,8 @@ struct Scatter4Args {
   int dedup_max_rw;
 };
 
-// CONSEC: issue I of the quad transposition carries the 16 consecutive shells 16 I + q instead of the shells 4q + I (see
-// k_lotd_scatter in field.hip: the atomic unit is paid per distinct 64-byte sector per instruction; NSIM_SCATTER_GROUP=0: off)
+// CONSEC (NSIM_SCATTER_GROUP=1, off by default): issue I of the quad transposition carries the 16 consecutive shells 16 I + q
+// instead of the shells 4q + I -- a measured null, see k_lotd_scatter in field.hip (street step 12.3 / 12.2 ms, profiles/round6_scatter_requests.json)
 template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
   const int lane = nsim_lane();
@@ -1016,7 +1016,7 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   if (const char* e = getenv("NSIM_DEDUP4_MAX_RW")) sa.dedup_max_rw = atoi(e);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
   const char* eg = getenv("NSIM_SCATTER_GROUP");
-  if (!(eg && atoi(eg) == 0))
+  if (eg && atoi(eg) == 1)
     hipLaunchKernelGGL(k_lotd4_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   else
     hipLaunchKernelGGL(k_lotd4_scatter<false>, grid, dim3(256), 0, (hipStream_t)stream, sa);

@@ -114,9 +114,8 @@ def test_hip_and_oracle_converge_to_matched_psnr(backend):
         return [render_image(tr.renderer, m, intr_e, c2w_e, WH_e, frame=f, rays_h_appear=ha0)["rgb_volume"].detach().cpu()
                 for f in range(intr_e.shape[0])]
 
-    targets = None
     imgs_o0 = _oracle_views(p, occ, aabb, res, intr_e.cpu(), c2w_e.cpu(), WH_e.cpu(), mo)
-    targets = [RenderTrainer.sphere_image(o, d, RADIUS).view(HW, HW, 3) for _, o, d in imgs_o0]
+    targets = [RenderTrainer.sphere_image(o.to(backend), d.to(backend), RADIUS).cpu().view(HW, HW, 3) for _, o, d in imgs_o0]
     psnr_h0 = sum(psnr(a, t) for a, t in zip(hip_views(), targets)) / len(targets)
     psnr_o0 = sum(psnr(a, t) for (a, _, _), t in zip(imgs_o0, targets)) / len(targets)
     assert abs(psnr_h0 - psnr_o0) < 0.2, (psnr_h0, psnr_o0)               # same weights: same image

@@ -33,28 +33,47 @@ def level_layout(lod_res, T):
     return sizes, types, offs
 
 
-def distinct_per_row(a):
-    """a [rows, n] int64 with -1 = inactive -> number of distinct non-negative values per row"""
-    s = np.sort(a, axis=1)
-    first = np.concatenate([np.ones((s.shape[0], 1), bool), s[:, 1:] != s[:, :-1]], 1)
-    return int((first & (s >= 0)).sum())
+def requests_per_row(rows, sector_of):
+    """rows [n, m] int64 table-entry indices of the lanes of one atomic instruction (-1 = inactive) -> atomic requests:
+    one per distinct 64-byte sector, and lanes adding to the SAME address ride in separate requests
+    (profiles/round6_atomic_conflict_bench.txt: K quads on the same 16 bytes cost K requests; K quads on K different 16-byte
+    pieces of one sector cost one) -> per sector, the largest multiplicity of any of its addresses."""
+    s = np.sort(rows, axis=1)
+    valid = s >= 0
+    m = s.shape[1]
+    same = np.concatenate([np.zeros((s.shape[0], 1), bool), s[:, 1:] == s[:, :-1]], 1) & valid
+    mult = np.ones_like(s)
+    for k in range(1, m):
+        mult[:, k] = np.where(same[:, k], mult[:, k - 1] + 1, 1)
+    sec = np.where(valid, sector_of(s), -1)
+    newsec = np.concatenate([np.ones((s.shape[0], 1), bool), sec[:, 1:] != sec[:, :-1]], 1)
+    rm = mult.copy()
+    for k in range(1, m):
+        rm[:, k] = np.where(newsec[:, k], mult[:, k], np.maximum(rm[:, k - 1], mult[:, k]))
+    last = np.concatenate([newsec[:, 1:], np.ones((s.shape[0], 1), bool)], 1)
+    return int((rm * (last & valid)).sum())
 
 
-def model(x, ridx, lod_res, T, group="strided", dedup=True, chunk=64):
-    """-> per level dict(sectors, instr, atomics)   group: 'strided' (lanes 4q+I per issue: the round 1-5 kernel) |
-    'consecutive' (lanes 16I+q per issue)"""
+def model(x, ridx, lod_res, T, group="strided", dedup=True, cross=False, entry_bytes=8, chunk=64):
+    """-> per level dict(requests, ...).   group: 'strided' (issue I = lanes 4q + I: the kernel of rounds 1-6) | 'consecutive'
+    (issue I = lanes 16 I + q: k_lotd_scatter<true>, NSIM_SCATTER_GROUP=1);  dedup: runs of equal vertex index across the wave are
+    summed by shuffles first (the kernel does);  cross: additionally fold a sample's x+1 corner into the NEXT sample's x corner
+    when they are the same vertex (x-adjacent cells);  entry_bytes: 8 = two f32 per vertex (the kernel), 4 = a packed bf16 / f16
+    pair per vertex (global_atomic_pk_add_*: VERDICT r5 item 4 probe ii)."""
     S = x.shape[0]
     pad = (-S) % chunk
     sizes, types, offs = level_layout(lod_res, T)
+    per_sector = 64 // entry_bytes
     out = []
     u = x * 0.5 + 0.5
     for l, R in enumerate(lod_res):
         R = int(R)
         pos = u * (R - 1)
         c0 = np.clip(np.floor(pos), 0, R - 2).astype(np.int64)
-        tot_sec = tot_instr = tot_atom = 0
+        tot_req = tot_atom = 0
+        base = offs[l] // 2
         for yz in range(4):
-            sec_dx, emit_dx = [], []
+            idxs, emits = [], []
             for dx in range(2):
                 cx, cy, cz = c0[:, 0] + dx, c0[:, 1] + (yz & 1), c0[:, 2] + (yz >> 1)
                 if types[l] == "dense":
@@ -68,20 +87,21 @@ def model(x, ridx, lod_res, T, group="strided", dedup=True, chunk=64):
                     emit = (idxp != nxt) & (idxp >= 0)
                 else:
                     emit = idxp >= 0
-                sector = (offs[l] + 2 * idxp) // 16
-                sec_dx.append(np.where(emit, sector, -1))
-                emit_dx.append(emit)
-                tot_atom += 2 * int(emit.sum())
-            both = np.stack(sec_dx, -1)                      # [chunks, 64, 2]
+                idxs.append(idxp)
+                emits.append(emit)
+            if cross:
+                nxt0 = np.concatenate([idxs[0][:, 1:], np.full((idxs[0].shape[0], 1), -2)], 1)
+                emits[1] = emits[1] & ~(idxs[1] == nxt0)
+            both = np.stack([np.where(emits[0], idxs[0], -1), np.where(emits[1], idxs[1], -1)], -1)      # [chunks, 64, 2]
             nc = both.shape[0]
             if group == "strided":
-                rows = both.reshape(nc, 16, 4, 2).transpose(0, 2, 1, 3).reshape(nc * 4, 32)      # issue I = lanes 4q + I
+                rows = both.reshape(nc, 16, 4, 2).transpose(0, 2, 1, 3).reshape(nc * 4, 32)
             else:
-                rows = both.reshape(nc * 4, 32)                                                   # issue I = lanes 16I + q
-            tot_sec += distinct_per_row(rows)
-            tot_instr += int((rows >= 0).any(1).sum())
-        out.append(dict(level=l, res=R, type=types[l], sectors=tot_sec, instr=tot_instr, lane_atomics=tot_atom,
-                        sectors_per_point=round(tot_sec / S, 3)))
+                rows = both.reshape(nc * 4, 32)
+            tot_req += requests_per_row(rows, lambda e: (base + e) // per_sector)
+            tot_atom += 2 * int(emits[0].sum() + emits[1].sum())
+        out.append(dict(level=l, res=R, type=types[l], requests=tot_req, lane_atomics=tot_atom,
+                        requests_per_point=round(tot_req / S, 3)))
     return out
 
 
@@ -95,17 +115,20 @@ def main():
     lod_res, T = [int(r) for r in d["lod_res"]], int(d["hashmap_size"])
     aabb = d["aabb"]
     x = (x - aabb[0]) / (aabb[1] - aabb[0]) * 2 - 1
-    res = dict(points=int(x.shape[0]), variants={})
-    for name, kw in (("round5_strided_dedup", dict(group="strided", dedup=True)),
-                     ("consecutive_dedup", dict(group="consecutive", dedup=True)),
-                     ("consecutive_nodedup", dict(group="consecutive", dedup=False)),
-                     ("strided_nodedup", dict(group="strided", dedup=False))):
+    res = dict(points=int(x.shape[0]), rule="requests = per instruction, per distinct 64-byte sector: the largest number of lanes "
+               "on one address (tools/atomic_conflict_bench.hip); ~21 G requests/s chip-wide", variants={})
+    for name, kw in (("kernel (strided issue, run dedup)", dict(group="strided")),
+                     ("consecutive issue (NSIM_SCATTER_GROUP=1)", dict(group="consecutive")),
+                     ("consecutive issue + cross-corner fold", dict(group="consecutive", cross=True)),
+                     ("strided issue + cross-corner fold", dict(group="strided", cross=True)),
+                     ("strided issue, no dedup", dict(group="strided", dedup=False)),
+                     ("packed 2-byte pair per vertex (pk_add), strided issue", dict(group="strided", entry_bytes=4)),
+                     ("packed 2-byte pair per vertex (pk_add), consecutive + fold", dict(group="consecutive", cross=True, entry_bytes=4))):
         lv = model(x, ridx, lod_res, T, **kw)
-        tot = sum(v["sectors"] for v in lv)
-        res["variants"][name] = dict(sectors=tot, sectors_per_point=round(tot / x.shape[0], 2),
-                                     us_at_21G=round(tot / 21.0e3, 1), instr=sum(v["instr"] for v in lv), levels=lv)
-        print(name, "sectors/point", round(tot / x.shape[0], 2), "-> us at 21 G/s:", round(tot / 21.0e3, 1),
-              [v["sectors_per_point"] for v in lv])
+        tot = sum(v["requests"] for v in lv)
+        res["variants"][name] = dict(requests=tot, requests_per_point=round(tot / x.shape[0], 2), us_at_21G=round(tot / 21.0e3, 1),
+                                     per_level=[v["requests_per_point"] for v in lv])
+        print(f"{name:62s} requests/point {tot / x.shape[0]:6.2f}  -> {tot / 21.0e3:6.1f} us at 21 G/s")
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
 
