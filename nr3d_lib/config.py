@@ -232,8 +232,15 @@ class BaseConfig:
                 k, v = tok[2:], extra[i + 1]
                 i += 2
             _set_by_path(tree, k, yaml.safe_load(v))
+        builtin = ("config", "resume_dir", "exp_dir", "device_ids", "ddp", "port")
         for k, v in vars(known).items():
-            if k in ("config", "resume_dir") or v is None or (k == "ddp" and not v and "ddp" in tree):
+            if k in ("config", "resume_dir") or (k == "ddp" and not v and "ddp" in tree):
+                continue
+            if v is None:
+                # an option a TOOL registered (``bc.parser.add_argument("--cam_id", default=None)``, code_single/tools/eval.py:
+                # 606-634) exists on the parsed config with its default, None included -- eval.py:143 reads ``args.cam_id``
+                if k not in builtin:
+                    tree.setdefault(k, None)
                 continue
             tree[k] = v
         tree.setdefault("ddp", False)
