@@ -205,6 +205,47 @@ PARITY_RAYS = 2048
 PARITY_TOL = dict(min_psnr_db=60.0, p99_abs_rgb=2e-3, max_abs_rgb=2e-2)
 
 
+def convergence_record(dev, rank=0, world=1, steps=3000, checkpoints=(0, 250, 1000, 3000), n_views=3, sdf_D=2):
+    """train the bench workload (fused chain, BASELINE configs[1], the bench's own learning rate and occupancy
+    schedule) for ``steps`` iterations from the bench's initialisation and score HELD-OUT 800 x 800 views -- cameras of another
+    seed than the 100 training views -- against the analytic target image the model is supervised with, the way the reference's
+    eval tool scores a run (code_single/tools/eval.py:241-316: per-frame PSNR / SSIM of ``rgb_volume``, then the mean).
+    -> dict(psnr_db=[...], ssim=[...] at the checkpoints, rays_per_s of the training in between)."""
+    from neuralsim_amd.eval import all_pixel_xy, psnr, render_image, ssim
+    from neuralsim_amd.graphics.cameras import look_at_cameras, pinhole_selected_rays
+    tr = build_trainer(dev, rank, world, sdf_D=sdf_D)
+    intr, c2w, WH = look_at_cameras(V=n_views, seed=4242, device=dev)
+    W_, H_ = int(WH[0, 0]), int(WH[0, 1])
+    xy = all_pixel_xy(W_, H_, dev)
+    gts = []
+    for f in range(n_views):
+        o_, d_ = pinhole_selected_rays(xy, torch.full([xy.shape[0]], f, dtype=torch.long, device=dev), intr, c2w, WH)
+        gts.append(tr.sphere_image(o_, d_, SPHERE_RADIUS).view(H_, W_, 3))
+    ha = torch.zeros(1, tr.appear.shape[1], device=dev)          # a held-out view has no appearance code of its own
+
+    def score():
+        ps, ss = [], []
+        for f in range(n_views):
+            img = render_image(tr.renderer, tr.model, intr, c2w, WH, frame=f, rays_h_appear=ha)["rgb_volume"]
+            ps.append(psnr(img, gts[f]))
+            ss.append(ssim(img, gts[f]))
+        return round(sum(ps) / n_views, 2), round(sum(ss) / n_views, 4)
+    rec = dict(steps=[], psnr_db=[], ssim=[], train_ms_per_step=[], views=n_views, image="800x800", held_out=True,
+               target="analytic image of the supervised sphere (colour = 0.5 + 0.5 normal, black background)")
+    it, done = 0, 0
+    for cp in checkpoints:
+        if cp > done:
+            ms, it = time_steps(tr, cp - done, 0, it)
+            rec["train_ms_per_step"].append(round(ms, 3))
+            done = cp
+        p_, s_ = score()
+        rec["steps"].append(cp)
+        rec["psnr_db"].append(p_)
+        rec["ssim"].append(s_)
+    rec["rays"] = tr.num_rays
+    return rec
+
+
 def parity_check(tr):
     from oracle import render as orr
     m = tr.model
@@ -442,6 +483,9 @@ def main():
             gt_img = tr.sphere_image(o_, d_, SPHERE_RADIUS).view(H_, W_, 3)
             eval_psnr = psnr(img["rgb_volume"], gt_img)
             var = {k: round(v, 3) for k, v in var.items()}
+            # training converges to the target on held-out views (the fused chain's own run; the oracle-matched small-size run is
+            # tests/test_convergence.py, recorded in profiles/round6_matched_psnr_small.json)
+            var["convergence"] = convergence_record(dev, rank, world, sdf_D=args.sdf_depth)
             var["eval_800x800_rays_per_s"] = round(W_ * H_ / var["eval_800x800_ms"] * 1e3, 1)
             var["eval_psnr_vs_target_db"] = round(eval_psnr, 2)
             var[key + "_rays_per_s"] = round(args.rays_per_gpu / var[key + "_ms"] * 1e3, 1)
