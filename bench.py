@@ -780,6 +780,18 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
             pts_s = v["units"] / (v["total_ms"] * 1e-3)
             chain[k] = dict(chain=what, ceiling_Gpts_s=round(ceil_pts / 1e9, 2), achieved_Gpts_s=round(pts_s / 1e9, 3),
                             frac_of_chain_ceiling=round(pts_s / ceil_pts, 4))
+    ks = ROOT / "profiles" / "kernel_split.json"       # recorded: the decoder kernel's share of the nsim_field_fwd entry point
+    if "nsim_field_fwd" in chain and ks.exists():
+        sp = json.loads(ks.read_text())
+        f_ = sp["nsim_field_fwd"]
+        share = f_["decoder_avg_us"] / (f_["decoder_avg_us"] + f_["gather_avg_us"])
+        c_ = chain["nsim_field_fwd"]
+        c_["decoder_kernel_alone"] = dict(share_of_entry_point_time=round(share, 3),
+                                          achieved_Gpts_s=round(c_["achieved_Gpts_s"] / share, 3),
+                                          frac_of_chain_ceiling=round(c_["frac_of_chain_ceiling"] / share, 4),
+                                          note="the entry point's HIP-event time x the decoder kernel's share of it in the rocprofv3 "
+                                               "kernel trace (its level-major gather is the other kernel); the radiance forward is part "
+                                               "of the decoder kernel and not of the chain", source="profiles/kernel_split.json: " + sp.get("_recorded", ""))
     if chain:
         roofline["chain_ceilings"] = dict(kernels=chain, source="profiles/round5_decoder_chain_bench.txt (tools/decoder_chain_bench.hip on MI355X), recorded")
     # per-kernel roofline of every modelled entry point (the MFMA kernels against the dense fp16 peak)

@@ -33,6 +33,17 @@ def main():
     (P / f"{TAG}_rocprofv3_kernel_stats.json").write_text(json.dumps(dict(
         command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-variants --no-parity",
         kernels=st["kernels"][:40], dispatch=st.get("dispatch", [])), indent=1))
+    # the two kernels behind the nsim_field_fwd entry point, separately: bench.py states the forward decoder against its chain
+    # ceiling on the decoder kernel's own time, from this recorded split
+    def avg_us(sub):
+        k = next((k for k in st["kernels"] if sub in k["name"]), None)
+        return (k["avg_us"], k["calls"]) if k else (None, 0)
+    (dec_us, dec_n), (gat_us, gat_n) = avg_us(ABI["nsim_field_fwd"]), avg_us(ABI["nsim_field_fwd(gather)"])
+    if dec_us and gat_us:
+        (P / "kernel_split.json").write_text(json.dumps(dict(
+            nsim_field_fwd=dict(decoder_kernel=ABI["nsim_field_fwd"], decoder_avg_us=dec_us, gather_kernel=ABI["nsim_field_fwd(gather)"],
+                                gather_avg_us=gat_us, launches=dec_n),
+            _recorded=f"{TAG}: rocprofv3 --kernel-trace --stats of the bench command (profiles/{TAG}_rocprofv3_kernel_stats.txt)"), indent=1))
     fe = json.loads((G / "prof_pmc_fetch.json").read_text()).get("pmc", {})
     wr = json.loads((G / "prof_pmc_write.json").read_text()).get("pmc", {})
     out, traffic = {}, {}
