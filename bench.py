@@ -410,7 +410,11 @@ def main():
             # the distant-view model on every ray (lotd_neus.dtu.230814.yaml:186-247)
             var = {}
             tr.fused_step = False
+            _lib.HOST_WAIT = 0.0       # (how long the host sat in the step's one size read: > 0 means the GPU is the bound)
+            _lib.CALL_COUNT = None
             var["api_path_ms"], it = time_steps(tr, 24, 6, it)
+            var["api_path_host_wait_ms"] = _lib.HOST_WAIT * 1e3 / 30.0
+            _lib.HOST_WAIT = None
             tr.fused_step = True
             # the OTHER sampling semantics (VERDICT r5 weak 2 / ADVICE r5): coarse + fine samples on every AABB-tested ray, the
             # reading of rounds 1-4 -- ``upsample_on_marched_only`` is a key of THIS package (absent from the reference), so the
