@@ -312,6 +312,61 @@ def ensure_grad_scratch(device):
 
 
 CALL_COUNT = None        # bench.py sets it to 0 over the timed steps: number of C-ABI calls issued
+# ------------------------------------------------------------------------------------------------ zero arena
+# The autograd-path step (``ray_test`` + ``ray_query`` + autograd: what a reference renderer drives) zero-fills ~19 buffers per
+# iteration -- gradient accumulators, images that hit rays are scattered into, loss scalars --, each its own fill launch
+# (58 us of GPU time and ~19 allocator + launch round trips on the host per step, profiles/round6_step_kernels_api.txt).  A
+# trainer that owns the step brackets it with ``arena_begin`` / ``arena_end``: ONE zeroed f32 buffer sized from the previous
+# step's demand, ``zeros()`` hands out 16-byte aligned views of it.  Outside a bracket (the reference's own trainer on the shim,
+# the tests' direct calls) and for anything that does not fit, ``zeros()`` IS ``torch.zeros``.
+class _Arena:
+    __slots__ = ("buf", "off", "cap", "demand", "device", "stream")
+
+
+_ARENA = None
+_ARENA_DEMAND = {}
+
+
+def arena_begin(device):
+    global _ARENA
+    if os.environ.get("NSIM_ZERO_ARENA", "1") != "1":
+        _ARENA = None
+        return
+    a = _Arena()
+    a.device, a.off, a.demand = device, 0, 0
+    want = _ARENA_DEMAND.get(str(device), 0)
+    a.cap = (int(want * 1.125) + 1024) if want else 0
+    a.buf = torch.zeros([a.cap], dtype=torch.float32, device=device) if a.cap else None
+    a.stream = stream_handle() if device.type == "cuda" else 0
+    _ARENA = a
+
+
+def arena_end():
+    global _ARENA
+    a = _ARENA
+    if a is not None:
+        _ARENA_DEMAND[str(a.device)] = a.demand
+    _ARENA = None
+
+
+def zeros(shape, dtype=torch.float32, device=None):
+    """``torch.zeros(shape, dtype=torch.float32, device=device)``, as a view of the step's arena when one is open (same device,
+    same stream -- the prefetch of the next batch runs on its own stream and must not touch a buffer the main stream zeroes)."""
+    a = _ARENA
+    if a is None or dtype != torch.float32 or device != a.device:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    n = 1
+    for d_ in shape:
+        n *= int(d_)
+    pad = (n + 3) & ~3
+    a.demand += pad
+    if a.off + pad > a.cap or (a.device.type == "cuda" and stream_handle() != a.stream):
+        return torch.zeros(shape, dtype=dtype, device=device)
+    v = a.buf[a.off:a.off + n].view(shape)
+    a.off += pad
+    return v
+
+
 HOST_WAIT = None         # bench.py sets it to 0.0: seconds the host spent blocked on the step's one size read (fields/neus.py _compress)
 
 

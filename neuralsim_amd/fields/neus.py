@@ -142,6 +142,7 @@ class _FieldFn(torch.autograd.Function):
             ctx.save_for_backward(None, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
             ctx.goff = None
             ctx.ha_shape = ha.shape if ha is not None else None
+            ctx.set_materialize_grads(False)
             if M == 0:
                 return (sdf, nablas, rgb) if with_rgb else (sdf, nablas)
             Sm = S - M
@@ -179,6 +180,7 @@ class _FieldFn(torch.autograd.Function):
         ctx.save_for_backward(x, rays_o, rays_d, t, ridx, ha, nablas, rgb, h_pl, J_pl)
         ctx.goff = goff
         ctx.ha_shape = ha.shape if ha is not None else None
+        ctx.set_materialize_grads(False)      # unused outputs (the free points' sdf) arrive as None: backward handles it
         if M == 0:
             return (sdf, nablas, rgb) if with_rgb else (sdf, nablas)
         Sm = S - M
@@ -200,8 +202,8 @@ class _FieldFn(torch.autograd.Function):
             def join(a, b, tail):
                 if a is None and b is None:
                     return None
-                a = a.float() if a is not None else torch.zeros([Sm, *tail], dtype=torch.float32, device=dev)
-                b = b.float() if b is not None else torch.zeros([M, *tail], dtype=torch.float32, device=dev)
+                a = a.float() if a is not None else _lib.zeros([Sm, *tail], device=dev)
+                b = b.float() if b is not None else _lib.zeros([M, *tail], device=dev)
                 return torch.cat([a, b])
             g_sdf, g_nab = join(g_sdf, ge_s, ()), join(g_nab, ge_n, (3,))
             if g_rgb is not None:
@@ -210,11 +212,12 @@ class _FieldFn(torch.autograd.Function):
         wpack = model._weight_pack()
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(model.sdf_D, model.encoding.cfg.num_levels, model.pos_embed_E)
         need = ctx.needs_input_grad
-        dgrid = torch.zeros([ctx.grid_numel], dtype=torch.float32, device=dev) if need[1] else None
+        # (zero-filled accumulators: views of the step's arena when the trainer opened one, _lib.zeros)
+        dgrid = _lib.zeros([ctx.grid_numel], device=dev) if need[1] else None
         # one memset for the four small accumulators
-        dsdf_w, dsdf_b, drad_w, drad_b = torch.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b], dtype=torch.float32,
-                                                     device=dev).split([n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
-        dha = torch.zeros(ctx.ha_shape, dtype=torch.float32, device=dev) if (ha is not None and need[6]) else None
+        dsdf_w, dsdf_b, drad_w, drad_b = _lib.zeros([n_sdf_w + n_sdf_b + n_rad_w + n_rad_b],
+                                                    device=dev).split([n_sdf_w, n_sdf_b, n_rad_w, n_rad_b])
+        dha = _lib.zeros(list(ctx.ha_shape), device=dev) if (ha is not None and need[6]) else None
         gs = g_sdf.float().contiguous() if g_sdf is not None else None
         gn = g_nab.float().contiguous() if g_nab is not None else None
         gr = g_rgb.float().contiguous() if (ctx.with_rgb and g_rgb is not None) else None
@@ -300,7 +303,7 @@ class _NeusAlphaFn(torch.autograd.Function):
     def backward(ctx, g):
         sdf, ln_inv_s, pack_infos = ctx.saved_tensors
         dsdf = torch.empty_like(sdf)
-        dln = torch.zeros_like(ln_inv_s)
+        dln = _lib.zeros(list(ln_inv_s.shape), device=ln_inv_s.device) if ln_inv_s.dtype == torch.float32 else torch.zeros_like(ln_inv_s)
         _lib.call("nsim_neus_alpha_bwd", _lib.ptr(sdf), _lib.ptr(g.float().contiguous()), _lib.ptr(pack_infos),
                   pack_infos.shape[0], _lib.ptr(ln_inv_s), ctx.factor, ctx.fis, _lib.ptr(dsdf), _lib.ptr(dln))
         return dsdf, dln, None, None, None
@@ -328,9 +331,9 @@ class _CompositeFn(torch.autograd.Function):
             rgb_o = (torch.empty if rgbc is not None else torch.zeros)([P, 3], **f32)
             nrm_o = (torch.empty if nrmc is not None else torch.zeros)([P, 3], **f32)
         else:
-            sc = torch.zeros([2, N], **f32)
+            sc = _lib.zeros([2, N], device=dev)
             mask, depth = sc[0], sc[1]
-            vec = torch.zeros([2, N, 3], **f32)
+            vec = _lib.zeros([2, N, 3], device=dev)
             rgb_o, nrm_o = vec[0], vec[1]
             out_idx = out_idx.contiguous()
         _lib.call("nsim_composite_fwd", _lib.ptr(alpha), _lib.ptr(t), _lib.ptr(rgbc), _lib.ptr(nrmc),
@@ -339,6 +342,9 @@ class _CompositeFn(torch.autograd.Function):
         ctx.save_for_backward(alpha, trans, vw, t, rgbc, nrmc, pack_infos, mask, depth, out_idx)
         ctx.nd = int(normalized_depth)
         ctx.mark_non_differentiable(trans)
+        # an image nothing consumed (a photometric loss reads rgb alone) arrives as None in backward, not as a zero tensor the
+        # engine fills first: the kernel takes NULL for an absent gradient (five fills per training step otherwise)
+        ctx.set_materialize_grads(False)
         return vw, mask, depth, rgb_o, nrm_o, trans
 
     @staticmethod
@@ -1577,7 +1583,15 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             M = int(extra_x.shape[0]) if extra_x is not None else 0
             o_a, d_a = o_g.detach().float().contiguous(), d_g.detach().float().contiguous()
             ha_a = h_appear.detach().float().contiguous() if (with_rgb and h_appear is not None) else None
-            if M:
+            pre_od = cfg.get("_extra_pre", None)      # trainer hook: [R + M] ray arrays built with the batch (hit rays + the points)
+            if M and pre_od is not None and pre_od[0].shape[0] == o_a.shape[0] + M:
+                o_a, d_a = pre_od
+                if ha_a is not None:                  # appearance codes: zero rows for the free points (one cat instead of five)
+                    hz = getattr(self, "_extra_hz", None)
+                    if hz is None or hz.shape != (M, ha_a.shape[1]) or hz.device != ha_a.device:
+                        hz = self._extra_hz = torch.zeros([M, ha_a.shape[1]], dtype=torch.float32, device=ha_a.device)
+                    ha_a = torch.cat([ha_a, hz])
+            elif M:
                 e = torch.empty([0], dtype=torch.float32, device=o_a.device)
                 o_a, d_a, _, _, ha_a = append_extra_points(self, o_a, d_a, e, e.long(), ha_a, extra_x)
             spec = dict(M=M, rays_o=o_a, rays_d=d_a, ha=ha_a)

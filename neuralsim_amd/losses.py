@@ -11,7 +11,7 @@ class _EikonalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nablas):
         nab = nablas.float().reshape(-1, 3).contiguous()
-        out = torch.zeros([], dtype=torch.float32, device=nab.device)
+        out = _lib.zeros([], device=nab.device)
         _lib.call("nsim_eikonal_loss_fwd", _lib.ptr(nab), nab.shape[0], _lib.ptr(out))
         ctx.save_for_backward(nab)
         ctx.shape = nablas.shape
@@ -35,7 +35,7 @@ class _MseFn(torch.autograd.Function):
     def forward(ctx, pred, gt):
         p = pred.float().contiguous()
         g = gt.float().contiguous()
-        out = torch.zeros([], dtype=torch.float32, device=p.device)
+        out = _lib.zeros([], device=p.device)
         _lib.call("nsim_mse_loss_fwd", _lib.ptr(p), _lib.ptr(g), p.numel(), _lib.ptr(out))
         ctx.save_for_backward(p, g)
         return out
@@ -66,7 +66,7 @@ class _EmbedFn(torch.autograd.Function):
         idx, = ctx.saved_tensors
         g = g.float().contiguous()
         C = g.shape[-1]
-        out = torch.zeros([ctx.rows, C], dtype=torch.float32, device=g.device)
+        out = _lib.zeros([ctx.rows, C], device=g.device)
         _lib.call("nsim_rows_scatter_add", _lib.ptr(g), _lib.ptr(idx), idx.shape[0], C, ctx.rows, _lib.ptr(out))
         return out, None
 

@@ -120,7 +120,7 @@ class SingleVolumeRenderer(nn.Module):
         vb = cr_ret["volume_buffer"]
         if vb["type"] != "empty":
             rih, pih = vb["rays_inds_hit"], vb["pack_infos_hit"]
-            total_num_samples_per_ray[rih] += pih[:, 1]
+            total_num_samples_per_ray.index_put_((rih,), pih[:, 1])      # (first writer into the zeros; hit rays are unique)
             vb.update(rays_inds_collect=rih, pack_infos_collect=pih)
             if "nablas" in vb:
                 if world_transform is None:

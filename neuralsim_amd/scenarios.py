@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import backward_on_calling_thread
+from . import _lib, backward_on_calling_thread
 from .fields.neus import LoTDNeuSModel
 from .graphics.cameras import selected_rays
 from .grid_encodings.lotd import cuboid_ngp_res, gen_ngp_res
@@ -481,6 +481,7 @@ class ComposeTrainer:
         if it >= va.n_steps_warmup and it % va.n_steps_between_update == 0:
             va.update_from_net(self.vehicles.query_sdf, generator=self.gen_shared)
         xy, fidx, gt = self.sample_batch()
+        _lib.arena_begin(gt.device)      # zero-filled buffers of the step: one arena (_lib.zeros)
         ret = self.render(xy, fidx)
         loss, n_s = self.loss(ret, gt)
         self.optim.zero_grad()
@@ -492,6 +493,7 @@ class ComposeTrainer:
             red.begin()
         with backward_on_calling_thread():
             loss.backward()
+        _lib.arena_end()
         if red is not None:
             red.reduce_and_step(self.optim, 1.0 / self.world_size)
         else:

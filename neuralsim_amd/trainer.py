@@ -201,6 +201,8 @@ class RenderTrainer:
         tested = None
         if batch is not None:
             rays_o, rays_d, tested = batch["rays_o"], batch["rays_d"], dict(batch["tested"])
+            if extra_pts is not None and "o_full" in batch and extra_pts is batch.get("x_uni"):
+                bypass["_extra_pre"] = (batch["o_full"], batch["d_full"])      # [R + M] ray arrays, built with the batch
             # no prefetch under pose refinement: it would build the next batch's graph on pose parameters that this
             # step's optimizer then updates in place
             if self.pipeline and not self.pose_refine_active():
@@ -555,7 +557,8 @@ class RenderTrainer:
             eik = e2 if eik is None else eik + e2
         if eik is None:
             eik = torch.zeros([], device=gt.device)
-        return loss_rgb + self.w_eikonal * eik, dict(loss_rgb=loss_rgb.detach(), loss_eikonal=eik.detach())
+        # (``torch.add(a, b, alpha=w)``: a + w b as ONE launch forward and one backward)
+        return torch.add(loss_rgb, eik, alpha=self.w_eikonal), dict(loss_rgb=loss_rgb.detach(), loss_eikonal=eik.detach())
 
     # ------------------------------------------------------------------ lidar step (street configs)
     def sample_lidar_batch(self):
@@ -668,6 +671,7 @@ class RenderTrainer:
             self.optim.zero_grad()
             loss = self._train_render_fused(batch)
         if loss is None:
+            _lib.arena_begin(model.device)       # zero-filled buffers of the autograd-path step out of one arena (_lib.zeros)
             ret = self.render(xy, fidx, extra_pts=x_uni, batch=batch)
             uni = None
             if x_uni is not None and "extra_pts" not in ret["raw_per_obj_model"]["main"]:     # no ray hit anything
@@ -681,6 +685,7 @@ class RenderTrainer:
                 red.begin()
             with backward_on_calling_thread():
                 loss.backward()
+            _lib.arena_end()
             vb = ret["raw_per_obj_model"]["main"]["volume_buffer"]
             n_hit = int(vb["rays_inds_hit"].shape[0]) if vb["type"] != "empty" else 0
             self.stats = dict(R_hit=int(getattr(model, "_last_R_tested", n_hit)) if n_hit else 0, R_live=n_hit, S_f=int(vb["t"].shape[0]) if vb["type"] != "empty" else 0,

@@ -97,7 +97,7 @@ def _oracle_views(p, occ, aabb, res, intr, c2w, WH, mo):
 def test_hip_and_oracle_converge_to_matched_psnr(backend):
     on_gpu = backend.type == "cuda"
     # emulator: the machinery only (a handful of steps of a toy size); MI355X: the claim
-    N, K, log2_T, n_uni, HW = (384, 120, 15, 128, 48) if on_gpu else (48, 3, 10, 16, 12)
+    N, K, log2_T, n_uni, HW = (384, 72, 15, 128, 48) if on_gpu else (48, 3, 10, 16, 12)
     lr = 5e-3
     m, tr = _build(backend, log2_T, N, n_uni, lr, V=12)
     p = oracle_of_neus(m)                                    # the SAME initial weights (table as its fp16 shadow holds it)
@@ -159,6 +159,6 @@ def test_hip_and_oracle_converge_to_matched_psnr(backend):
     if not on_gpu:
         assert abs(psnr_h - psnr_o) < 0.5, rec
         return
-    # both trained (measured on MI355X, 240 steps of 512 rays: 15.89 -> 18.30 dB on BOTH sides, last losses 0.00994 / 0.00980)
+    # both trained (measured on MI355X: 240 steps of 512 rays 15.89 -> 18.30 / 18.30 dB; 120 steps of 384 rays 15.94 -> 18.12 / 18.13 dB)
     assert psnr_o > psnr_o0 + 0.8 and psnr_h > psnr_h0 + 0.8, rec
     assert abs(psnr_h - psnr_o) <= 0.5, rec
