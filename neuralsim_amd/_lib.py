@@ -329,7 +329,11 @@ _ARENA_DEMAND = {}
 
 def arena_begin(device):
     global _ARENA
-    if os.environ.get("NSIM_ZERO_ARENA", "1") != "1":
+    # OFF by default -- a measured null (profiles/round6_api_path_arena_ab.txt, MI355X, alternated in one call): API path 1.84 /
+    # 1.90 ms per step without, 1.92 / 1.97 with; street 12.2 vs 12.7, multi-object 15.5 vs 15.9.  The fills it removes are
+    # not on the critical path (the stretch between the forward and the large backward kernels is paced by the host's
+    # autograd nodes, not by the GPU), and one large memset at the start of the step is in the way of the sampling pass.
+    if os.environ.get("NSIM_ZERO_ARENA", "0") != "1":
         _ARENA = None
         return
     a = _Arena()

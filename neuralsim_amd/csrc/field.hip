@@ -2196,6 +2196,30 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
     if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
   }
       if constexpr (CONSEC) {
+        if (dedup) {
+          // cross-corner fold: neighbours on a ray in x-adjacent cells share the vertex (x0 + 1, y, z) -- the x + 1 corner of the
+          // run before is the x corner of this run.  Lanes of one instruction on the same address are separate requests, so the
+          // earlier run's total for that vertex is added to this run's (both sit on the LAST lane of their runs) and the
+          // earlier one is not emitted.  Runs of the two corners have the same boundaries (same cell), found once more here.
+          const uint32_t key0 = valid ? idx[0] : 0xffffffffu;
+          const uint32_t pk0 = wave_shfl(key0, lane - 1);
+          const unsigned long long heads0 = wave_ballot(lane == 0 || pk0 != key0);
+          const unsigned long long below0 = heads0 & ((2ull << lane) - 1ull);
+          const int rs = 63 - __builtin_clzll(below0);                       // first lane of my run
+          const int prev_last = rs > 0 ? rs - 1 : 0;                         // last lane of the run before
+          const uint32_t p_idx1 = wave_shfl(emit[1] ? idx[1] : 0xffffffffu, prev_last);
+          const float p_v0 = wave_shfl(v0[1], prev_last), p_v1 = wave_shfl(v1[1], prev_last);
+          const uint32_t n_idx0 = wave_shfl(key0, lane + 1);                 // head of the next run (I am a run's last lane when I emit)
+          const unsigned long long lasts0 = (heads0 >> 1) | (1ull << 63);    // lane l is the last of its run
+          const bool take = emit[0] && rs > 0 && p_idx1 == idx[0] && p_idx1 != 0xffffffffu;
+          const bool nxt_valid_emit = lane < 63 && n_idx0 == idx[1] && n_idx0 != 0xffffffffu;
+          // the next run's last lane must itself emit its x corner (it does whenever it is valid: emit[0] = valid && last)
+          if (take) {
+            v0[0] += p_v0;
+            v1[0] += p_v1;
+          }
+          if (emit[1] && nxt_valid_emit && ((lasts0 >> lane) & 1ull)) emit[1] = false;
+        }
         const uint32_t k0 = emit[0] ? idx[0] : 0xffffffffu, k1 = emit[1] ? idx[1] : 0xffffffffu;
 #pragma unroll
         for (int I = 0; I < 4; ++I) {
