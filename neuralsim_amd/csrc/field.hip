@@ -2103,6 +2103,7 @@ struct ScatterArgs {
   float* dgrid;
   int dedup_max_res;
   int level_begin;      // this launch covers levels [level_begin, level_begin + gridDim.y)
+  int parity_slots;     // the eight vertices of a cell are enumerated by the PARITY of their coordinates (round 6, default on)
 };
 
 // CONSEC (NSIM_SCATTER_GROUP=1; a measured null, kept for the record): which 16 samples of the wave's 64 share one atomic
@@ -2151,6 +2152,7 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
     const LotdCell c = lotd_cell(xx, R, a.lotd);
     const float q0[3] = {g0 * gn[0] * c.dscale[0], g0 * gn[1] * c.dscale[1], g0 * gn[2] * c.dscale[2]};
     const float q1[3] = {g1 * gn[0] * c.dscale[0], g1 * gn[1] * c.dscale[1], g1 * gn[2] * c.dscale[2]};
+    const int px0 = a.parity_slots ? (c.c0[0] & 1) : 0, py0 = a.parity_slots ? (c.c0[1] & 1) : 0, pz0 = a.parity_slots ? (c.c0[2] & 1) : 0;
 #pragma unroll
     for (int yz = 0; yz < 4; ++yz) {
       uint32_t idx[2];
@@ -2158,10 +2160,16 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
       bool emit[2];
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const int corner = dx | (yz << 1);
+        // Parity slots: slot (dx, yz) holds the vertex whose coordinates have the parities (dx, yz & 1, yz >> 1) -- the eight
+        // vertices of a cell have the eight parity combinations exactly once -- so a vertex SHARED by neighbouring cells sits in
+        // the same slot in both, and the run merge below (equal vertex index on consecutive lanes) folds the four vertices of the
+        // face two consecutive cells on a ray share, chains of cells included, with no further logic.  Atomic requests per point
+        // by the request model (tools/scatter_sector_model.py): 25.1 -> 20.4 on the object step, 43.5 -> 37.5 on the street step.
+        const int corner = (dx ^ px0) | (((yz & 1) ^ py0) << 1) | (((yz >> 1) ^ pz0) << 2);
         float w, dw[3];
         lotd_corner_w(c, corner, w, dw);
-        idx[dx] = voff + lotd_index(c.c0[0] + dx, c.c0[1] + (yz & 1), c.c0[2] + (yz >> 1), R, a.lotd.type[l], a.lotd.size[l]);
+        idx[dx] = voff + lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1), c.c0[2] + (corner >> 2), R, a.lotd.type[l],
+                                    a.lotd.size[l]);
         v0[dx] = w * dh0 + (dw[0] * q0[0] + dw[1] * q0[1] + dw[2] * q0[2]);
         v1[dx] = w * dh1 + (dw[0] * q1[0] + dw[1] * q1[1] + dw[2] * q1[2]);
         emit[dx] = valid;
@@ -2196,30 +2204,6 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
     if (ee) atomicAdd(base + 2 * (int64_t)ii + (rq & 1), vv);                                                \
   }
       if constexpr (CONSEC) {
-        if (dedup) {
-          // cross-corner fold: neighbours on a ray in x-adjacent cells share the vertex (x0 + 1, y, z) -- the x + 1 corner of the
-          // run before is the x corner of this run.  Lanes of one instruction on the same address are separate requests, so the
-          // earlier run's total for that vertex is added to this run's (both sit on the LAST lane of their runs) and the
-          // earlier one is not emitted.  Runs of the two corners have the same boundaries (same cell), found once more here.
-          const uint32_t key0 = valid ? idx[0] : 0xffffffffu;
-          const uint32_t pk0 = wave_shfl(key0, lane - 1);
-          const unsigned long long heads0 = wave_ballot(lane == 0 || pk0 != key0);
-          const unsigned long long below0 = heads0 & ((2ull << lane) - 1ull);
-          const int rs = 63 - __builtin_clzll(below0);                       // first lane of my run
-          const int prev_last = rs > 0 ? rs - 1 : 0;                         // last lane of the run before
-          const uint32_t p_idx1 = wave_shfl(emit[1] ? idx[1] : 0xffffffffu, prev_last);
-          const float p_v0 = wave_shfl(v0[1], prev_last), p_v1 = wave_shfl(v1[1], prev_last);
-          const uint32_t n_idx0 = wave_shfl(key0, lane + 1);                 // head of the next run (I am a run's last lane when I emit)
-          const unsigned long long lasts0 = (heads0 >> 1) | (1ull << 63);    // lane l is the last of its run
-          const bool take = emit[0] && rs > 0 && p_idx1 == idx[0] && p_idx1 != 0xffffffffu;
-          const bool nxt_valid_emit = lane < 63 && n_idx0 == idx[1] && n_idx0 != 0xffffffffu;
-          // the next run's last lane must itself emit its x corner (it does whenever it is valid: emit[0] = valid && last)
-          if (take) {
-            v0[0] += p_v0;
-            v1[0] += p_v1;
-          }
-          if (emit[1] && nxt_valid_emit && ((lasts0 >> lane) & 1ull)) emit[1] = false;
-        }
         const uint32_t k0 = emit[0] ? idx[0] : 0xffffffffu, k1 = emit[1] ? idx[1] : 0xffffffffu;
 #pragma unroll
         for (int I = 0; I < 4; ++I) {
@@ -2944,6 +2928,8 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   sa.dedup_max_res = 1 << 30;   // every level (compressed query mode keeps neighbouring fine samples: 0.345 -> 0.319 ms; it was 600 for the un-compressed mode)
   const char* e = getenv("NSIM_DEDUP_MAX_RES");
   if (e) sa.dedup_max_res = atoi(e);
+  const char* ep = getenv("NSIM_SCATTER_PARITY");      // 0: slots by corner offset, as rounds 1-5 (A/B aid)
+  sa.parity_slots = !(ep && atoi(ep) == 0);
   const int64_t chunks = (S + 63) / 64;
   sa.level_begin = level_begin;
   const dim3 grid(nsim_blocks(chunks, 4, 4096), level_count);

@@ -756,6 +756,7 @@ struct Scatter4Args {
   const float* dh_pl;
   float* dgrid;
   int dedup_max_rw;
+  int parity_slots;
 };
 
 // CONSEC (NSIM_SCATTER_GROUP=1, off by default): issue I of the quad transposition carries the 16 consecutive shells 16 I + q
@@ -786,6 +787,7 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
       dh1 = dp[1];
     }
     const Cell4 c = lotd4_cell(u, Rx, Ry, Rz, Rw);
+    const int pmask = a.parity_slots ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2) | ((c.c0[3] & 1) << 3)) : 0;
 #pragma unroll
     for (int yzw = 0; yzw < 8; ++yzw) {
       uint32_t idx[2];
@@ -793,9 +795,11 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
       int emit[2];
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const int corner = dx | (yzw << 1);
+        // parity slots (see k_lotd_scatter, field.hip): slot (dx, yzw) holds the vertex with those coordinate parities, so the
+        // vertices two consecutive shells' cells share sit in the same slot and the run merge below folds them
+        const int corner = (dx | (yzw << 1)) ^ pmask;
         const float w = lotd4_weight(c, corner);
-        idx[dx] = lotd4_index(c.c0[0] + dx, c.c0[1] + (yzw & 1), c.c0[2] + ((yzw >> 1) & 1), c.c0[3] + (yzw >> 2), Rx,
+        idx[dx] = lotd4_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1), c.c0[2] + ((corner >> 2) & 1), c.c0[3] + (corner >> 3), Rx,
                               Ry, Rz, a.lotd.type[l], a.lotd.size[l]);
         v0[dx] = w * dh0;
         v1[dx] = w * dh1;
@@ -1014,6 +1018,8 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   sa.u4 = u4; sa.valid = valid; sa.S = S; sa.dh_pl = dh_planes; sa.dgrid = dgrid;
   sa.dedup_max_rw = 1 << 30;      // every level: 3.62 -> 1.73 ms per 0.52 M shell points (levels with Rw <= 16 / 64 only: 2.07 / 1.76)
   if (const char* e = getenv("NSIM_DEDUP4_MAX_RW")) sa.dedup_max_rw = atoi(e);
+  const char* ep = getenv("NSIM_SCATTER_PARITY");
+  sa.parity_slots = !(ep && atoi(ep) == 0);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
   const char* eg = getenv("NSIM_SCATTER_GROUP");
   if (eg && atoi(eg) == 1)
