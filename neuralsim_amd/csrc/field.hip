@@ -2106,14 +2106,18 @@ struct ScatterArgs {
   int parity_slots;     // the eight vertices of a cell are enumerated by the PARITY of their coordinates (round 6, default on)
 };
 
-// CONSEC (NSIM_SCATTER_GROUP=1; a measured null, kept for the record): which 16 samples of the wave's 64 share one atomic
-// instruction.  The atomic unit retires one request per distinct 64-byte sector per instruction at ~21 G/s
-// (profiles/round4_atomic_line_bench.txt), so the launch costs the number of such requests.  Issue I of the quad
-// transposition takes the samples 4q + I (a DPP quad broadcast): 16 samples spread over the whole chunk.  Taking the 16
-// CONSECUTIVE samples 16 I + q instead (six ds_bpermute per issue) puts neighbours on a ray into one instruction -- but
-// neighbours in x-adjacent cells share a VERTEX, and lanes of one instruction on the same address are separate requests
-// (profiles/round6_atomic_conflict_bench.txt): the request model (tools/scatter_sector_model.py) gives 25.13 -> 24.92 per
-// point and the bench step measured 0.376 ms either way (profiles/round6_scatter_requests.json).
+// CONSEC (default since round 6; NSIM_SCATTER_GROUP=0: the strided form of rounds 1-5): which 16 samples of the wave's 64 share
+// one atomic instruction.  The atomic unit retires one request per distinct 64-byte sector per wave instruction at ~21 G/s, and
+// lanes of one instruction on the SAME address are separate requests (profiles/round4_atomic_line_bench.txt,
+// profiles/round6_atomic_conflict_bench.txt) -- so a launch costs the number of such requests, which tools/scatter_sector_model.py
+// counts on a dumped step's sample set (25.1 modelled, 24.9 measured per point for the rounds 1-5 kernel).  Issue I of the quad
+// transposition used to take the samples 4q + I (a DPP quad broadcast); it now takes the 16 CONSECUTIVE samples 16 I + q (six
+// ds_bpermute per issue): neighbours on a ray, whose vertex rows share sectors.  On its own that measured nothing (neighbouring
+// cells share VERTICES, i.e. addresses: 0.376 ms either way); with the parity slots below, which fold the shared vertices
+// first, it is worth another 8 %.  MI355X, bench step / street step (profiles/round6_scatter_requests.json):
+//     slots by corner offset, strided issue (rounds 1-5)   0.376 ms   3.32 ms    25.1 / 43.5 requests per point (model)
+//     parity slots, strided issue                           0.309      2.84       20.4 / 37.5
+//     parity slots, consecutive issue (default)             0.286      2.47       17.8 / 32.4
 template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
@@ -2934,7 +2938,7 @@ int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* ray
   sa.level_begin = level_begin;
   const dim3 grid(nsim_blocks(chunks, 4, 4096), level_count);
   const char* eg = getenv("NSIM_SCATTER_GROUP");       // (read per launch: A/B runs flip it inside one process)
-  const bool consec = eg && atoi(eg) == 1;
+  const bool consec = !(eg && atoi(eg) == 0);
   if (consec)
     hipLaunchKernelGGL(k_lotd_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   else

@@ -759,8 +759,9 @@ struct Scatter4Args {
   int parity_slots;
 };
 
-// CONSEC (NSIM_SCATTER_GROUP=1, off by default): issue I of the quad transposition carries the 16 consecutive shells 16 I + q
-// instead of the shells 4q + I -- a measured null, see k_lotd_scatter in field.hip (street step 12.3 / 12.2 ms, profiles/round6_scatter_requests.json)
+// CONSEC (default since round 6, NSIM_SCATTER_GROUP=0: off): issue I of the quad transposition carries the 16 consecutive shells
+// 16 I + q instead of the shells 4q + I; with the parity slots (NSIM_SCATTER_PARITY) the street step's 4-D scatter went
+// 2.15 -> 1.99 (parity slots) -> 1.74 ms (+ consecutive issue), see k_lotd_scatter in field.hip
 template <bool CONSEC>
 __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
   const int lane = nsim_lane();
@@ -1022,7 +1023,7 @@ int nsim_lotd4_scatter(const NsimLotd4Meta* meta, const float* u4, const uint8_t
   sa.parity_slots = !(ep && atoi(ep) == 0);
   const dim3 grid(nsim_blocks((S + 63) / 64, 4, 4096), meta->num_levels);
   const char* eg = getenv("NSIM_SCATTER_GROUP");
-  if (eg && atoi(eg) == 1)
+  if (!(eg && atoi(eg) == 0))
     hipLaunchKernelGGL(k_lotd4_scatter<true>, grid, dim3(256), 0, (hipStream_t)stream, sa);
   else
     hipLaunchKernelGGL(k_lotd4_scatter<false>, grid, dim3(256), 0, (hipStream_t)stream, sa);

@@ -17,7 +17,7 @@ import numpy as np
 P1, P2 = np.uint32(2654435761), np.uint32(805459861)
 
 
-def level_layout(lod_res, T):
+def level_layout(lod_res, T):      # (cubic levels; model() lays cuboid ones out itself)
     sizes, types = [], []
     for r in lod_res:
         n = int(r) ** 3
@@ -54,30 +54,43 @@ def requests_per_row(rows, sector_of):
     return int((rm * (last & valid)).sum())
 
 
-def model(x, ridx, lod_res, T, group="strided", dedup=True, cross=False, entry_bytes=8, chunk=64):
-    """-> per level dict(requests, ...).   group: 'strided' (issue I = lanes 4q + I: the kernel of rounds 1-6) | 'consecutive'
-    (issue I = lanes 16 I + q: k_lotd_scatter<true>, NSIM_SCATTER_GROUP=1);  dedup: runs of equal vertex index across the wave are
-    summed by shuffles first (the kernel does);  cross: additionally fold a sample's x+1 corner into the NEXT sample's x corner
-    when they are the same vertex (x-adjacent cells);  entry_bytes: 8 = two f32 per vertex (the kernel), 4 = a packed bf16 / f16
-    pair per vertex (global_atomic_pk_add_*: VERDICT r5 item 4 probe ii)."""
-    S = x.shape[0]
+def model(u, lod_res, T, group="strided", dedup=True, cross=False, slots="offset", entry_bytes=8, chunk=64):
+    """-> per level dict(requests, ...).   u [S, 3]: positions in the pyramid's unit cube; lod_res [L] or [L, 3] (cuboid levels).
+    slots: 'offset' -- slot (dx, yz) holds the corner c0 + (dx, yz & 1, yz >> 1) (the kernel of rounds 1-5) | 'parity' -- slot
+    (dx, yz) holds the vertex whose coordinates have those parities (round 6: a vertex shared by neighbouring cells keeps its slot,
+    so the per-slot run merge folds it);  group: 'strided' (issue I = lanes 4q + I) | 'consecutive' (issue I = lanes 16 I + q:
+    NSIM_SCATTER_GROUP=1);  dedup: runs of equal vertex index on consecutive lanes of a slot are summed by shuffles first (the
+    kernel does);  cross ('offset' slots only): fold a sample's x + 1 corner into the next sample's x corner when they are the same
+    vertex;  entry_bytes: 8 = two f32 per vertex (the kernel), 4 = a packed 2-byte pair per vertex (global_atomic_pk_add_*)."""
+    S = u.shape[0]
     pad = (-S) % chunk
-    sizes, types, offs = level_layout(lod_res, T)
+    res = np.asarray(lod_res)
+    if res.ndim == 1:
+        res = np.stack([res] * 3, -1)
+    sizes, types, offs, o = [], [], [], 0
+    for r in res:
+        n = int(r[0]) * int(r[1]) * int(r[2])
+        sizes.append(n if n <= T else T)
+        types.append("dense" if n <= T else "hash")
+        offs.append(o)
+        o += 2 * sizes[-1]
     per_sector = 64 // entry_bytes
     out = []
-    u = x * 0.5 + 0.5
-    for l, R in enumerate(lod_res):
-        R = int(R)
+    for l, R in enumerate(res):
+        R = R.astype(np.int64)
         pos = u * (R - 1)
-        c0 = np.clip(np.floor(pos), 0, R - 2).astype(np.int64)
+        c0 = np.minimum(np.maximum(np.floor(pos), 0), R - 2).astype(np.int64)
+        par = c0 & 1 if slots == "parity" else np.zeros_like(c0)
         tot_req = tot_atom = 0
         base = offs[l] // 2
         for yz in range(4):
             idxs, emits = [], []
             for dx in range(2):
-                cx, cy, cz = c0[:, 0] + dx, c0[:, 1] + (yz & 1), c0[:, 2] + (yz >> 1)
+                cx = c0[:, 0] + (dx ^ par[:, 0])
+                cy = c0[:, 1] + ((yz & 1) ^ par[:, 1])
+                cz = c0[:, 2] + ((yz >> 1) ^ par[:, 2])
                 if types[l] == "dense":
-                    idx = cx + R * (cy + R * cz)
+                    idx = cx + R[0] * (cy + R[1] * cz)
                 else:
                     h = cx.astype(np.uint32) ^ (cy.astype(np.uint32) * P1) ^ (cz.astype(np.uint32) * P2)
                     idx = (h & np.uint32(T - 1)).astype(np.int64)
@@ -89,7 +102,7 @@ def model(x, ridx, lod_res, T, group="strided", dedup=True, cross=False, entry_b
                     emit = idxp >= 0
                 idxs.append(idxp)
                 emits.append(emit)
-            if cross:
+            if cross and slots == "offset":
                 nxt0 = np.concatenate([idxs[0][:, 1:], np.full((idxs[0].shape[0], 1), -2)], 1)
                 emits[1] = emits[1] & ~(idxs[1] == nxt0)
             both = np.stack([np.where(emits[0], idxs[0], -1), np.where(emits[1], idxs[1], -1)], -1)      # [chunks, 64, 2]
@@ -100,35 +113,33 @@ def model(x, ridx, lod_res, T, group="strided", dedup=True, cross=False, entry_b
                 rows = both.reshape(nc * 4, 32)
             tot_req += requests_per_row(rows, lambda e: (base + e) // per_sector)
             tot_atom += 2 * int(emits[0].sum() + emits[1].sum())
-        out.append(dict(level=l, res=R, type=types[l], requests=tot_req, lane_atomics=tot_atom,
+        out.append(dict(level=l, res=[int(v) for v in R], type=types[l], requests=tot_req, lane_atomics=tot_atom,
                         requests_per_point=round(tot_req / S, 3)))
     return out
 
 
 def main():
     d = np.load(sys.argv[1])
-    if "x" in d.files:
-        x = d["x"]
-    else:
-        x = d["o"][d["ridx"]] + d["t"][:, None] * d["d"][d["ridx"]]
-    ridx = d["ridx"]
-    lod_res, T = [int(r) for r in d["lod_res"]], int(d["hashmap_size"])
+    x = d["x"] if "x" in d.files else d["o"][d["ridx"]] + d["t"][:, None] * d["d"][d["ridx"]]
+    lod_res, T = np.asarray(d["lod_res"]), int(d["hashmap_size"])
     aabb = d["aabb"]
-    x = (x - aabb[0]) / (aabb[1] - aabb[0]) * 2 - 1
-    res = dict(points=int(x.shape[0]), rule="requests = per instruction, per distinct 64-byte sector: the largest number of lanes "
-               "on one address (tools/atomic_conflict_bench.hip); ~21 G requests/s chip-wide", variants={})
-    for name, kw in (("kernel (strided issue, run dedup)", dict(group="strided")),
-                     ("consecutive issue (NSIM_SCATTER_GROUP=1)", dict(group="consecutive")),
-                     ("consecutive issue + cross-corner fold", dict(group="consecutive", cross=True)),
-                     ("strided issue + cross-corner fold", dict(group="strided", cross=True)),
-                     ("strided issue, no dedup", dict(group="strided", dedup=False)),
-                     ("packed 2-byte pair per vertex (pk_add), strided issue", dict(group="strided", entry_bytes=4)),
-                     ("packed 2-byte pair per vertex (pk_add), consecutive + fold", dict(group="consecutive", cross=True, entry_bytes=4))):
-        lv = model(x, ridx, lod_res, T, **kw)
+    u = (x - aabb[0]) / (aabb[1] - aabb[0])
+    res = dict(points=int(x.shape[0]), levels=[[int(v) for v in np.atleast_1d(r)] for r in lod_res], hashmap_size=T,
+               rule="requests = per wave instruction, per distinct 64-byte sector: the largest number of lanes on one address "
+                    "(tools/atomic_conflict_bench.hip); ~21 G requests/s chip-wide", variants={})
+    for name, kw in (("rounds 1-5 kernel: corner-offset slots, strided issue, run dedup", dict()),
+                     ("corner-offset slots, no dedup", dict(dedup=False)),
+                     ("corner-offset slots, consecutive issue", dict(group="consecutive")),
+                     ("corner-offset slots, consecutive issue + cross-corner fold", dict(group="consecutive", cross=True)),
+                     ("corner-offset slots, packed 2-byte pair per vertex (pk_add)", dict(entry_bytes=4)),
+                     ("PARITY slots, strided issue (round 6 kernel, default)", dict(slots="parity")),
+                     ("PARITY slots, consecutive issue (NSIM_SCATTER_GROUP=1)", dict(slots="parity", group="consecutive")),
+                     ("PARITY slots, consecutive issue, packed 2-byte pair per vertex", dict(slots="parity", group="consecutive", entry_bytes=4))):
+        lv = model(u, lod_res, T, **kw)
         tot = sum(v["requests"] for v in lv)
         res["variants"][name] = dict(requests=tot, requests_per_point=round(tot / x.shape[0], 2), us_at_21G=round(tot / 21.0e3, 1),
                                      per_level=[v["requests_per_point"] for v in lv])
-        print(f"{name:62s} requests/point {tot / x.shape[0]:6.2f}  -> {tot / 21.0e3:6.1f} us at 21 G/s")
+        print(f"{name:72s} requests/point {tot / x.shape[0]:6.2f}  -> {tot / 21.0e3:7.1f} us at 21 G/s")
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
 
