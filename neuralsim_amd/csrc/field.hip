@@ -25,6 +25,9 @@
 //  * fp16 MFMA operands are re-scaled per tile by an exact power of two (dyn_scale) so that the tiny
 //    upstream gradients of a volume-render loss do not underflow -- no global loss scaler is required;
 //  * PREC=1 selects v_mfma_f32_32x32x2_f32 (exact f32 at the vector rate) for tight parity tests.
+#ifndef NSIM_SCATTER_SCAN_EXIT
+#define NSIM_SCATTER_SCAN_EXIT 1
+#endif
 #include "lotd_dev.h"
 #include "mfma_mlp.h"
 #include "occ_dev.h"
@@ -1540,6 +1543,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     }
   }
   const GridRef gref = grid_ref(a.grid);
+  const int gpar = a.gather_parity;
   const int nl = a.glm_n[xcd];
   // (a level dealt to two XCDs is split between the two halves of the VALID point range)
   const int64_t nblk_valid = (Sv + 64 * NP - 1) / (64 * NP);
@@ -1562,9 +1566,13 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) j0[q][c3] = j1[q][c3] = 0.f;
       }
+      // NSIM_GATHER_PARITY=1 (probe, round 6): slot k reads the vertex with the coordinate parities k, as the scatter does, so
+      // that one load instruction's 64 consecutive samples name fewer distinct vertices (the sum runs in another order)
+      const int pm = gpar ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2)) : 0;
       if (l < a.lotd.n_active)
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner) {
+      for (int slot = 0; slot < 8; ++slot) {
+        const int corner = slot ^ pm;
         float w, dw[3];
         lotd_corner_w(c, corner, w, dw);
         const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
@@ -2187,6 +2195,9 @@ __global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
           const int run_start = 63 - __builtin_clzll(below);
 #pragma unroll
           for (int d = 1; d < 64; d <<= 1) {
+            // (wave-uniform early exit: no run of this slot reaches d lanes back -- at the fine levels runs are 1-3 lanes long
+            // and two of the six rounds do all the work; -DNSIM_SCATTER_SCAN_EXIT=0 keeps all six)
+            if (NSIM_SCATTER_SCAN_EXIT && !wave_ballot(lane - d >= run_start)) break;
             const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
             if (lane - d >= run_start) {
               v0[dx] += o0;

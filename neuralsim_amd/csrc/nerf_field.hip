@@ -8,6 +8,9 @@
 // code_single/configs/object_centric/lotd_neus.dtu.230814.yaml:186-247).  Executable spec: oracle/distant.py.
 // Same register-resident transposed-MFMA scheme as field.hip (mfma_mlp.h); no second-order terms are needed here
 // (the distant model has ``use_nablas: false``).
+#ifndef NSIM_SCATTER_SCAN_EXIT
+#define NSIM_SCATTER_SCAN_EXIT 1
+#endif
 #include "mfma_mlp.h"
 #include <stdlib.h>
 
@@ -813,6 +816,9 @@ __global__ void __launch_bounds__(256) k_lotd4_scatter(Scatter4Args a) {
           const int run_start = 63 - __builtin_clzll(below);
 #pragma unroll
           for (int d = 1; d < 64; d <<= 1) {
+            // (wave-uniform early exit: no run of this slot reaches d lanes back -- at the fine levels runs are 1-3 lanes long
+            // and two of the six rounds do all the work; -DNSIM_SCATTER_SCAN_EXIT=0 keeps all six)
+            if (NSIM_SCATTER_SCAN_EXIT && !wave_ballot(lane - d >= run_start)) break;
             const float o0 = wave_shfl(v0[dx], lane - d), o1 = wave_shfl(v1[dx], lane - d);
             if (lane - d >= run_start) {
               v0[dx] += o0;
