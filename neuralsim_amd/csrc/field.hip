@@ -742,9 +742,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           const LotdRes R = a.lotd.res[l];
           const LotdCell c = lotd_cell(p.xx, R, a.lotd);
           float f0 = 0.f, f1 = 0.f, j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+          const int pm = lotd_slot_mask(c);
           if (l < a.lotd.n_active)      // hardmask annealing: masked levels are never read
 #pragma unroll
-          for (int corner = 0; corner < 8; ++corner) {
+          for (int slot = 0; slot < 8; ++slot) {
+            const int corner = slot ^ pm;
             float w, dw[3];
             lotd_corner_w(c, corner, w, dw);
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
@@ -1543,7 +1545,6 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
     }
   }
   const GridRef gref = grid_ref(a.grid);
-  const int gpar = a.gather_parity;
   const int nl = a.glm_n[xcd];
   // (a level dealt to two XCDs is split between the two halves of the VALID point range)
   const int64_t nblk_valid = (Sv + 64 * NP - 1) / (64 * NP);
@@ -1566,9 +1567,7 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) j0[q][c3] = j1[q][c3] = 0.f;
       }
-      // NSIM_GATHER_PARITY=1 (probe, round 6): slot k reads the vertex with the coordinate parities k, as the scatter does, so
-      // that one load instruction's 64 consecutive samples name fewer distinct vertices (the sum runs in another order)
-      const int pm = gpar ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2)) : 0;
+      const int pm = lotd_slot_mask(c);      // slots by vertex parity (lotd_dev.h)
       if (l < a.lotd.n_active)
 #pragma unroll
       for (int slot = 0; slot < 8; ++slot) {
@@ -1764,9 +1763,11 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES, NSIM_SDF_MIN_WAVES) k_field_
           const LotdRes R = a.lotd.res[l];
           const LotdCell c = lotd_cell(p.xx, R, a.lotd);
           float f0 = 0.f, f1 = 0.f;
+          const int pm = lotd_slot_mask(c);
           if (l < a.lotd.n_active)
 #pragma unroll
-          for (int corner = 0; corner < 8; ++corner) {
+          for (int slot = 0; slot < 8; ++slot) {
+            const int corner = slot ^ pm;
             float w, dw[3];
             lotd_corner_w(c, corner, w, dw);
             const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),

@@ -22,9 +22,11 @@ __global__ void __launch_bounds__(256) k_lotd_fwd(const float* __restrict__ x, c
   const LotdCell c = lotd_cell(xx, R, m);
   float f0 = 0.f, f1 = 0.f;
   float j0[3] = {0.f, 0.f, 0.f}, j1[3] = {0.f, 0.f, 0.f};
+  const int pm = lotd_slot_mask(c);      // the library's one vertex order (lotd_dev.h)
   if (l < m.n_active)
 #pragma unroll
-  for (int corner = 0; corner < 8; ++corner) {
+  for (int slot = 0; slot < 8; ++slot) {
+    const int corner = slot ^ pm;
     float w, dw[3];
     lotd_corner_w(c, corner, w, dw);
     const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),

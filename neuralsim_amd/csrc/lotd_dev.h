@@ -89,6 +89,18 @@ __device__ __forceinline__ uint32_t lotd_index(int cx, int cy, int cz, const Lot
   return h & (T - 1u);  // T is a power of two (checked on the host)
 }
 
+// Vertex enumeration of a gather (round 6): slot k = 0..7 reads the vertex whose COORDINATES have the parities of k's bits, i.e.
+// corner k ^ (c0 & 1 per axis).  The eight vertices of a cell have the eight parity combinations once each, so a vertex two
+// neighbouring cells share is the same slot in both: the 64 consecutive samples of one load instruction name fewer distinct
+// vertices, and the level-major gathers run 9-10 % faster (MI355X: 0.0673 -> 0.0610 ms per sampling launch, the street
+// forward 1.009 -> 0.962 ms; profiles/round6_gather_parity_ab.txt).  Only the ORDER of the eight-term sums changes; every
+// gather of the library uses the same order (the fused and the level-major forms stay bit-identical).
+// -DNSIM_GATHER_PARITY=0: slots by corner offset, as rounds 1-5.
+// (the switch itself lives in nsim_common.h: the 4-D pyramid of nerf_field.hip follows it too)
+__device__ __forceinline__ int lotd_slot_mask(const LotdCell& c) {
+  return NSIM_GATHER_PARITY ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2)) : 0;
+}
+
 // trilinear weight of corner (dx,dy,dz) and its derivative w.r.t. the three cell coordinates
 __device__ __forceinline__ void lotd_corner_w(const LotdCell& c, int corner, float& w, float dw[3]) {
   const int dx = corner & 1, dy = (corner >> 1) & 1, dz = (corner >> 2) & 1;

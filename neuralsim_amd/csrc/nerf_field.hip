@@ -86,6 +86,11 @@ __device__ __forceinline__ uint32_t lotd4_index(int cx, int cy, int cz, int cw, 
   return h & (T - 1u);
 }
 
+// vertex order of the 4-D gathers: slot k reads the vertex with the coordinate parities of k's bits (lotd_dev.h, NSIM_GATHER_PARITY)
+__device__ __forceinline__ int lotd4_slot_mask(const Cell4& c) {
+  return NSIM_GATHER_PARITY ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2) | ((c.c0[3] & 1) << 3)) : 0;
+}
+
 __device__ __forceinline__ float lotd4_weight(const Cell4& c, int corner) {
   float w = 1.0f;
 #pragma unroll
@@ -458,8 +463,10 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
           if (l < a.lotd.num_levels) {
             const int Rx = a.lotd.res_xyz[l], Ry = a.lotd.res_y[l], Rz = a.lotd.res_z[l], Rw = a.lotd.res_w[l];
             const Cell4 c = lotd4_cell(u, Rx, Ry, Rz, Rw);
+            const int pm4 = lotd4_slot_mask(c);
 #pragma unroll
-            for (int corner = 0; corner < 16; ++corner) {
+            for (int slot = 0; slot < 16; ++slot) {
+              const int corner = slot ^ pm4;
               const float w = lotd4_weight(c, corner);
               const uint32_t idx = lotd4_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                                c.c0[2] + ((corner >> 2) & 1), c.c0[3] + ((corner >> 3) & 1), Rx, Ry, Rz,
@@ -687,8 +694,10 @@ __global__ void __launch_bounds__(64) k_lotd4_gather_lm(Gather4Args a) {
     for (int q = 0; q < G4_PTS; ++q) {
       const Cell4 c = lotd4_cell(u[q], Rx, Ry, Rz, Rw);
       f0[q] = f1[q] = 0.f;
+      const int pm4 = lotd4_slot_mask(c);
 #pragma unroll
-      for (int corner = 0; corner < 16; ++corner) {
+      for (int slot = 0; slot < 16; ++slot) {
+        const int corner = slot ^ pm4;
         const float w = lotd4_weight(c, corner);
         const uint32_t idx = lotd4_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1), c.c0[2] + ((corner >> 2) & 1),
                                          c.c0[3] + ((corner >> 3) & 1), Rx, Ry, Rz, type, T);

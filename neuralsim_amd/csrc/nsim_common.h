@@ -3,6 +3,10 @@
 // All kernels are written for 64-lane wavefronts.  Everything that names a gfx950 instruction or builtin lives in
 // nsim_prims.h; this file holds the helpers written on top of those primitives.
 #pragma once
+// vertex order of every table gather: 1 = slots by vertex-coordinate parity (round 6, lotd_dev.h), 0 = by corner offset
+#ifndef NSIM_GATHER_PARITY
+#define NSIM_GATHER_PARITY 1
+#endif
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
