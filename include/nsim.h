@@ -329,6 +329,11 @@ typedef struct NsimFieldMeta {
   int32_t sdf_D;         /* hidden layers of the SDF decoder: 1 or 2 (width 64, softplus beta) */
   int32_t precision;     /* 0: fp16 MFMA (v_mfma_f32_32x32x16_f16), 1: exact f32 MFMA (32x32x2 f32) */
   float softplus_beta;   /* 100; a negative value selects relu (decoder_cfg.activation: relu) */
+  int32_t embed_E;       /* width of the embedded-position block appended to the SDF decoder's input: 0 = none, else
+                          * 3 + 6 n_frequencies <= 63 (``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy}`` of the
+                          * StyleLoTD Vehicle block, code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml:319-321).
+                          * W1 is then [64 x (2 num_levels + embed_E)] and the packed first-layer matrices carry two more
+                          * 32-input MFMA chunks; nsim_field_fwd (level-major path) and nsim_wide_bwd_sdf read it */
 } NsimFieldMeta;
 
 /* size in bytes of the packed-fragment weight buffer for a given meta */
@@ -421,27 +426,26 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
 int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const void* J_planes,
                        int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
                        float* dsdf_w, float* dsdf_b, float* dx, int64_t plane_pitch, void* stream);
-/* The SDF decoder with an embedded-position block appended to its input (csrc/wide_field.hip):
+/* The SDF decoder with an embedded-position block appended to its input (meta->embed_E > 0):
  * ``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: N}`` of the StyleLoTD Vehicle block
  * (code_multi/configs/exps/fg_neus=hyper_lotd/no_fg_occ.221218.yaml:319-321).  Input = [2 num_levels features | x_n (3),
  * sin(2^k x_n) (3), cos(2^k x_n) (3), k = 0..N-1], x_n = the AABB-normalised position in [-1, 1] (meta->lotd.x_scale /
- * x_shift); at most 128 values.  Weights are the f32 MASTER tensors (no packed fragments): sdf_w = [W1 (64 x FIN),
- * (W2 (64 x 64)), w_head (64)], sdf_b = [64, (64), 1], FIN = 2 num_levels + 3 + 6 N; rad_w / rad_b as for
- * nsim_field_pack_weights.  meta->precision is not read: f32 arithmetic.  The features and their x-derivative come from
- * level-major planes (features f32, dh/dx in the meta's plane type): nsim_lotd_gather_lm with an f32 meta for the no-grad query, nsim_field_fwd with wpack = NULL
- * ("gather only") for the with-grad one; the hand-off planes of the backward feed nsim_lotd_scatter, the radiance
- * backward is nsim_field_bwd_rad.  Points, n_dev / n_add, plane pitches: as for nsim_field_sdf / _fwd / _bwd_sdf. */
+ * x_shift); sdf_w = [W1 (64 x FIN), (W2 (64 x 64)), w_head (64)], FIN = 2 num_levels + 3 + 6 N.
+ *   with-grad forward: nsim_field_fwd on the level-major planes (h_planes / J_planes given) with the meta's wpack -- the first
+ *     layer contracts over the feature chunks + two embedding chunks on the matrix cores (k_field<.., NE = 2>, csrc/field.hip);
+ *   backward of the SDF branch: nsim_wide_bwd_sdf = nsim_field_bwd_sdf + the sample positions (the embedding and its
+ *     x-derivative are regenerated in the kernel): k_field_bwd_j<.., NE = 2>; no dL/dx output;
+ *   no-grad query (sampling, occupancy): nsim_wide_sdf on the f32 MASTER weights, f32 arithmetic on the VALU
+ *     (csrc/wide_field.hip; meta->precision is not read) over f32 feature planes of nsim_lotd_gather_lm.
+ * The hand-off planes of the backward feed nsim_lotd_scatter, the radiance backward is nsim_field_bwd_rad.  Points, n_dev /
+ * n_add, plane pitches: as for nsim_field_sdf / _fwd / _bwd_sdf. */
 int nsim_wide_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
                   const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
                   const int64_t* n_dev, int64_t n_add, const float* feat_planes, float* sdf, void* stream);
-int nsim_wide_fwd(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* rad_w,
-                  const float* rad_b, const float* x, const float* rays_o, const float* rays_d, const float* t,
-                  const int64_t* ridx, const float* h_appear, int64_t S, const float* h_planes, const void* J_planes,
-                  float* sdf, float* nablas, float* rgb, const int64_t* n_dev, int64_t n_add, void* stream);
-int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, int32_t n_freq, const float* sdf_w, const float* sdf_b, const float* x,
-                      const float* rays_o, const float* rays_d, const float* t, const int64_t* ridx, int64_t S,
-                      const float* h_planes, const void* J_planes, int64_t plane_pitch, const float* dsdf,
-                      const float* gn, float* dh_planes, float* g_planes, float* dsdf_w, float* dsdf_b, void* stream);
+int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* x, const float* rays_o,
+                      const float* rays_d, const float* t, const int64_t* ridx, int64_t S, const float* h_planes,
+                      const void* J_planes, int64_t plane_pitch, const float* dsdf, const float* gn, float* dh_planes,
+                      float* g_planes, float* dsdf_w, float* dsdf_b, void* stream);
 /* (3) LoTD scatter (LoTD backward incl. the dy/dx path): dgrid[level][vertex][f] (f32, atomics) +=
  *     w_c * dh[f] + g[f] * (d w_c/d x . gn).  gn may be NULL (no second-order term).
  *     Levels [level_begin, level_begin + level_count) only (level_count <= 0: all) -- a data-parallel caller scatters

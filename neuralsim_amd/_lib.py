@@ -67,7 +67,8 @@ def jplane_dtype(fm):
 
 
 class FieldMeta(C.Structure):
-    _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float)]
+    _fields_ = [("lotd", LotdMeta), ("sdf_D", C.c_int32), ("precision", C.c_int32), ("softplus_beta", C.c_float),
+                ("embed_E", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -121,8 +122,7 @@ SIGNATURES = {
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
     "nsim_wide_sdf": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P],
-    "nsim_wide_fwd": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
-    "nsim_wide_bwd_sdf": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "nsim_wide_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_set_grad_scratch": [_P, _I64],
     "nsim_permuto_fwd": [C.POINTER(PermutoMeta), _P, _P, _I64, _P, _P],
     "nsim_permuto_bwd": [C.POINTER(PermutoMeta), _P, _I64, _P, _P],

@@ -48,11 +48,14 @@ struct FieldLayout {
 static const int kMatUo[M_COUNT] = {64, 64, 64, 32, 64, 64, 32, 64, 64, 32};
 static const int kMatUi[M_COUNT] = {32, 64, 64, 64, 32, 64, 64, 32, 64, 64};
 
-// nc = number of 16-level feature chunks of the decoder input (1: <= 16 levels, 2: 17..32 levels).  Only the first
-// layer's matrices grow: W1 is [64 x 32 nc], W1T [32 nc x 64].
+// nc = number of 32-input chunks of the decoder's first layer: 16-level feature chunks (1: <= 16 levels, 2: 17..32 levels)
+// + ne embedded-position chunks (0, or 2 with NsimFieldMeta.embed_E > 0).  Only the first layer's matrices grow: W1 is
+// [64 x 32 nc], W1T [32 nc x 64].
 static inline int mat_uo(int m, int nc) { return m == M_W1T ? 32 * nc : kMatUo[m]; }
 static inline int mat_ui(int m, int nc) { return m == M_W1 ? 32 * nc : kMatUi[m]; }
 static inline int field_nc(int num_levels) { return num_levels > 16 ? 2 : 1; }
+static inline int field_ne(const NsimFieldMeta* meta) { return meta->embed_E > 0 ? 2 : 0; }
+static inline int field_ni(const NsimFieldMeta* meta) { return field_nc(meta->lotd.num_levels) + field_ne(meta); }
 
 static inline FieldLayout field_layout(int precision, int nc = 1) {
   FieldLayout L;
@@ -115,14 +118,23 @@ __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
   lo = (f16)((v - (float)hi) * SPLIT_LO_SCALE);
 }
 
-__device__ __forceinline__ float pack_src(int mat, int row, int col, int D, int F1, const float* sdf_w,
+// first-layer input i of the packed matrices -> column of W1 (row length FIN = F1 + E), -1 = zero padding: the feature
+// chunks hold columns [0, F1), the embedded-position chunks (from input EB = 32 x feature chunks on) columns [F1, F1 + E)
+__host__ __device__ inline int w1_col(int i, int F1, int EB, int E) {
+  if (i < EB || E == 0) return i < F1 ? i : -1;
+  return (i - EB) < E ? F1 + (i - EB) : -1;
+}
+
+// F1 = 2 num_levels feature inputs, E embedded-position inputs behind them (0: none), EB = 32 x feature chunks
+__device__ __forceinline__ float pack_src(int mat, int row, int col, int D, int F1, int E, int EB, const float* sdf_w,
                                           const float* rad_w) {
-  const SrcOff o = src_off(D, F1);
+  const int FIN = F1 + E;
+  const SrcOff o = src_off(D, FIN);
   switch (mat) {
-    case M_W1: return col < F1 ? sdf_w[o.w1 + row * F1 + col] : 0.f;
+    case M_W1: { const int c = w1_col(col, F1, EB, E); return c >= 0 ? sdf_w[o.w1 + row * FIN + c] : 0.f; }
     case M_W2: return D == 2 ? sdf_w[o.w2 + row * 64 + col] : 0.f;
     case M_W2T: return D == 2 ? sdf_w[o.w2 + col * 64 + row] : 0.f;
-    case M_W1T: return row < F1 ? sdf_w[o.w1 + col * F1 + row] : 0.f;
+    case M_W1T: { const int c = w1_col(row, F1, EB, E); return c >= 0 ? sdf_w[o.w1 + col * FIN + c] : 0.f; }
     case M_R1: return col < 26 ? rad_w[o.r1 + row * 26 + col] : 0.f;
     case M_R2: return rad_w[o.r2 + row * 64 + col];
     case M_R3: return row < 3 ? rad_w[o.r3 + row * 64 + col] : 0.f;
@@ -135,6 +147,7 @@ __device__ __forceinline__ float pack_src(int mat, int row, int col, int D, int 
 
 struct PackDims {
   int uo[M_COUNT], ui[M_COUNT];
+  int E, EB;      // embedded-position inputs of the first layer (0: none) and the input index they start at
 };
 
 __device__ __forceinline__ void field_pack_elem(const FieldLayout& L, const PackDims& dims, int D, int F1,
@@ -156,7 +169,7 @@ __device__ __forceinline__ void field_pack_elem(const FieldLayout& L, const Pack
         const int mo = fs / nS, s = fs % nS;
         row = 32 * mo + (lane & 31);
         col = 16 * s + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const float w = pack_src(m, row, col, D, F1, sdf_w, rad_w);
+        const float w = pack_src(m, row, col, D, F1, dims.E, dims.EB, sdf_w, rad_w);
         const f16 whi = (f16)w;
         ((f16*)(wpack + L.mat[m]))[k] = whi;
         if (L.split) ((f16*)(wpack + L.mat[m]))[cnt + k] = (f16)((w - (float)whi) * SPLIT_LO_SCALE);
@@ -168,7 +181,7 @@ __device__ __forceinline__ void field_pack_elem(const FieldLayout& L, const Pack
         const int mo = fm / nMi, mi = fm % nMi;
         row = 32 * mo + (lane & 31);
         col = unit_of(mi, r, lane >> 5);
-        ((float*)(wpack + L.mat[m]))[k] = pack_src(m, row, col, D, F1, sdf_w, rad_w);
+        ((float*)(wpack + L.mat[m]))[k] = pack_src(m, row, col, D, F1, dims.E, dims.EB, sdf_w, rad_w);
       }
       return;
     }
@@ -180,7 +193,7 @@ __device__ __forceinline__ void field_pack_elem(const FieldLayout& L, const Pack
     const int v = (int)(vtid >> 6), k = (int)(vtid & 63);
     const int hi = k >> 5, m = (k >> 4) & 1, r = k & 15;
     const int u = unit_of(m, r, hi);
-    const SrcOff o = src_off(D, F1);
+    const SrcOff o = src_off(D, F1 + dims.E);
     float val = 0.f;
     switch (v) {
       case V_B1: val = sdf_b[o.b1 + u]; break;
@@ -323,6 +336,7 @@ struct FieldArgs {
   int64_t rep_stride;                              // copy (b & rep_mask) at + rep_stride floats; 0 / 0 = the caller's buffers
   float *dgrid, *dsdf_w, *dsdf_b, *drad_w, *drad_b, *dh_appear;
   int has_rgb;
+  int embed_E;                                     // embedded-position inputs of the SDF decoder's first layer (k_field / k_field_bwd_j NE = 2)
 };
 
 // LDS accumulator layouts (floats)
@@ -525,6 +539,78 @@ __device__ __forceinline__ void make_rin(float (&rin)[16], const TilePoint& p, c
   }
 }
 
+// ---------------------------------------------------------------------------------- embedded-position input block
+// ``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: N}`` (no_fg_occ.221218.yaml:319-321): the SDF
+// decoder's first layer also reads [x_n (3) | sin(2^k x_n) (3), cos(2^k x_n) (3), k = 0..N-1] (E = 3 + 6 N <= 63 values), x_n =
+// the AABB-normalised position in [-1, 1].  On the matrix cores the block is two more 32-input chunks (NE = 2) behind the NC
+// feature chunks, in activation-register order: register r of a lane holds input I(r, hi) = unit_of(r >> 4, r & 15, hi) of the
+// block -- both candidates (hi = 0 / 1: I and I + 4) are compile-time, one select each.  Conventions fixed here (nr3d_lib is
+// absent): no factor pi, x_n = 2 u - 1 with u the pyramid's unit coordinate; the arithmetic is the one of csrc/wide_field.hip's
+// f32 decoder (the no-grad query of the same model), term for term.
+struct EmbedSlot {
+  int c, k;            // axis, octave
+  bool lin, is_cos;    // the x_n entries | a cosine entry
+};
+__device__ __forceinline__ EmbedSlot embed_slot(int idx) {
+  EmbedSlot e;
+  e.lin = idx < 3;
+  const int m = e.lin ? 0 : idx - 3;
+  e.c = e.lin ? idx : m % 3;
+  e.k = m / 6;
+  e.is_cos = !e.lin && (m % 6) >= 3;
+  return e;
+}
+// v[r]: this lane's 32 inputs of the block (zero past E and for an invalid point); d[r]: d v[r] / d x along the slot's OWN
+// axis (the other two components are zero)
+__device__ __forceinline__ void embed_eval(const FieldArgs& a, const float (&xx)[3], bool valid, int hi, float (&v)[32],
+                                           float (&d)[32]) {
+  float xn[3], dxn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    xn[c] = 2.0f * (xx[c] * a.lotd.xs[c] + a.lotd.xb[c]) - 1.0f;
+    dxn[c] = 2.0f * a.lotd.xs[c];
+  }
+  const float m = valid ? 1.f : 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int i0 = unit_of(r >> 4, r & 15, 0), i1 = i0 + 4;
+    const EmbedSlot e0 = embed_slot(i0), e1 = embed_slot(i1);
+    const float xc = hi ? xn[e1.c] : xn[e0.c], dx = hi ? dxn[e1.c] : dxn[e0.c];
+    const float fr = hi ? (float)(1 << e1.k) : (float)(1 << e0.k);
+    const bool lin = hi ? e1.lin : e0.lin, is_cos = hi ? e1.is_cos : e0.is_cos;
+    const float ang = fr * xc;
+    const float sn = nsim_sin(ang), cs = nsim_cos(ang);
+    float val = is_cos ? cs : sn, dd = (is_cos ? -sn : cs) * fr * dx;
+    if (lin) {
+      val = xc;
+      dd = dx;
+    }
+    const bool on = (hi ? i1 : i0) < a.embed_E;
+    v[r] = on ? val * m : 0.f;
+    d[r] = on ? dd * m : 0.f;
+  }
+}
+// acc[c] += sum over the lane's slots on axis c of g[r] d[r]   (the block's share of the normals: nablas = J^T g)
+__device__ __forceinline__ void embed_nablas(const float* g, const float (&d)[32], int hi, float (&acc)[3]) {
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int i0 = unit_of(r >> 4, r & 15, 0);
+    const int c0 = embed_slot(i0).c, c1 = embed_slot(i0 + 4).c;
+    const float pr = g[r] * d[r];
+    acc[c0] = acc[c0] + ((hi && c0 != c1) ? 0.f : pr);
+    if (c0 != c1) acc[c1] = acc[c1] + (hi ? pr : 0.f);
+  }
+}
+// gh[r] = d[r] gn[axis of slot r]   (the block's share of the input tangent along dL/dnablas)
+__device__ __forceinline__ void embed_tangent(float* gh, const float (&d)[32], const float (&gn)[3], int hi) {
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int i0 = unit_of(r >> 4, r & 15, 0);
+    const int c0 = embed_slot(i0).c, c1 = embed_slot(i0 + 4).c;
+    gh[r] = d[r] * (hi ? gn[c1] : gn[c0]);
+  }
+}
+
 template <int PREC>
 __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32], const float (&rin)[16], const char* W,
                                                 const FieldLayout& L, int hi, const char* WM = nullptr,
@@ -547,7 +633,9 @@ __device__ __forceinline__ void radiance_hidden(float (&r1)[32], float (&r2)[32]
 // 64 features; only on the level-major planes, MODE 2 / 3).
 // GL2 (MODE 3, NC == 2): the plane image of a tile (1 KB per level of the pyramid) is prefetched into LDS as in the
 // 16-level kernel -- possible while weights + 4 images fit the 160 KB (pyramids of up to 23 levels: the street's 19).
-template <int PREC, int SDF_D, int MODE, int NC = 1, bool GL2 = false>
+// NE (MODE 3): 32-input chunks of the embedded-position block behind the feature chunks (0 | 2: NsimFieldMeta.embed_E > 0);
+// such a forward reads the planes directly (no LDS image) and stages the forward matrices only.
+template <int PREC, int SDF_D, int MODE, int NC = 1, bool GL2 = false, int NE = 0>
 __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes
   NSIM_DYN_SMEM(smem);
@@ -563,11 +651,13 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   constexpr bool FWD = (MODE == 1 || MODE == 3);          // forward with normals (+ radiance)
   constexpr bool FROM_PLANES = (MODE == 2 || MODE == 3);  // h / dh-dx come from the level-major planes
   static_assert(NC == 1 || FROM_PLANES, "more than 16 levels: level-major planes only");
+  static_assert(NE == 0 || (MODE == 3 && !GL2), "the embedded-position block: forward on the planes (backward: k_field_bwd_j)");
+  constexpr int NI = NC + NE;      // 32-input chunks of the first layer
   // NC == 2: a private accumulator copy is 34 KB -> three waves per workgroup fit the 160 KB of LDS
   constexpr int NW = (PRIV && NC == 2) ? 3 : FIELD_WAVES;
   // W / L: per-lane vectors (always LDS in fp16 mode); WM / LM: matrix fragments (LDS, or L2 when PRIV)
   // MODE 0 / 2 touch only the SDF decoder (W1, W2, W2T, W1T); MODE 1 also the radiance matrices
-  const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (FWD ? M_COUNT : 4), L, wbytes);
+  const char* W = stage_weights<PREC>(smem, a, 0, PRIV ? 0 : (FWD ? (NE ? M_R3 + 1 : M_COUNT) : 4), L, wbytes);
   const char* WM = PRIV ? a.wpack : W;
   const FieldLayout LM = PRIV ? a.lay : L;
 
@@ -602,7 +692,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
   // piece thanks to the 32-point pitch) are copied global -> LDS by 16 global_load_lds_dwordx4 while this tile computes;
   // half of a tile used to be the wait for these reads (all workgroups burst together at one wave per SIMD).
   static_assert(!GL2 || (MODE == 3 && NC == 2), "GL2 is the 17..32-level forward");
-  constexpr bool GLDS = (MODE == 3 && (NC == 1 || GL2));
+  constexpr bool GLDS = (MODE == 3 && (NC == 1 || GL2) && NE == 0);
   const int nlv = a.lotd.num_levels;      // plane levels past it are neither written by the gather nor read here
   // JDIR (<= 16 levels, NSIM_FWD_JDIRECT): the LDS image holds the FEATURES only (4 KB per wave, 4 copies of 4 levels each);
   // dh/dx -- consumed once, at the very end of the tile -- is loaded straight into registers after the image has been
@@ -644,8 +734,9 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     // The backward does NOT gather again: the forward saved h and dh/dx as level-major planes
     // ([level][sample][..], coalesced across the 32 samples of a tile) -- 512 B per sample of sequential HBM
     // traffic instead of a second latency-bound random gather.
-    float h[16 * NC];
-    float J[(NC == 1 || GL2) ? 16 * NC : 1][3];     // NC == 2 without the LDS image re-reads dh/dx where it is consumed
+    float h[16 * NI];                               // [features (16 NC) | embedded position (16 NE)]
+    float J[((NC == 1 && NE == 0) || GL2) ? 16 * NC : 1][3];     // NC == 2 without the LDS image (and NE: registers) re-reads dh/dx where it is consumed
+    float ed[NE ? 32 : 1];                          // NE: x-derivative of the embedded-position inputs (own axis)
     constexpr bool JPK = JDIR && NSIM_FWD_JPACKED;
     JPair<JT> Jq[JPK ? 8 : 1][3];                   // JPK: this lane's (level, point) entries as stored
     if constexpr (JDIR) {
@@ -719,7 +810,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
               h[r0 + 1] = hp[1];
             }
           }
-      if constexpr (NC == 1) {
+      if constexpr (NC == 1 && NE == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -783,11 +874,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
       }
     }
+    if constexpr (NE > 0) embed_eval(a, p.xx, valid, hi, reinterpret_cast<float(&)[32]>(h[16 * NC]), ed);
     if constexpr (MODE == 2) { KT(1, 1); }
     if constexpr (MODE == 3) { KT(2, 1); }
     // ---------------------------------------------------------------- SDF decoder forward
     float a1[32];
-    dense<PREC, 2, NC>(a1, WM + LM.mat[M_W1], h, true);
+    dense<PREC, 2, NI>(a1, WM + LM.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(W, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];  // last hidden activation (== a1 when SDF_D == 1)
@@ -826,8 +918,8 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         d1[k] = sig_from_softplus(a1[k], beta) * e1[k];
       }
     }
-    float g[16 * NC];
-    dense<PREC, NC, 2>(g, WM + LM.mat[M_W1T], d1, false);
+    float g[16 * NI];
+    dense<PREC, NI, 2>(g, WM + LM.mat[M_W1T], d1, false);
     if constexpr (FWD) {
       if constexpr (MODE == 3) { KT(2, 3); }
       float nab[3];
@@ -842,7 +934,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) nab[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
-      } else if constexpr (NC == 1 || GL2) {
+      } else if constexpr ((NC == 1 && NE == 0) || GL2) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
           float acc = 0.f;
@@ -870,6 +962,12 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
         }
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) nab[c3] = acc[c3] + wave_shfl_xor(acc[c3], 32);
+      }
+      if constexpr (NE > 0) {      // the normals' share through the embedded position's own x-derivative
+        float ea[3] = {0.f, 0.f, 0.f};
+        embed_nablas(&g[16 * NC], ed, hi, ea);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) nab[c3] = nab[c3] + (ea[c3] + wave_shfl_xor(ea[c3], 32));
       }
       if constexpr (MODE == 3) { KT(2, 4); }
       float rgbv[3] = {0.f, 0.f, 0.f};
@@ -1091,8 +1189,14 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 // owns its tile (w >> 1, w & 1) over all 128 points like dW2; h / dL/dg / g / dL/dh are 32 wide; dh/dx is consumed
 // straight from its loads (never held: 96 registers), the next group's features are prefetched into registers (the LDS
 // image of a 32-level tile would be 32 KB per wave).  Round 3: k_field<0,1,2,2> 1.76 ms -> this kernel on the street step.
-template <int PREC, int SDF_D, int NC = 1>
+// NE = 2 (NsimFieldMeta.embed_E > 0): the embedded-position block as two more 32-input chunks of the first layer -- its values
+// and x-derivative are regenerated from the sample positions, its columns of dW1 are more accumulator tiles (column tiles are
+// dealt in PAIRS: wave w owns tile (w >> 1, 2 p + (w & 1)) of pair p over all 128 points; an odd last column tile is split by point
+// halves as for NC = 1), no hand-off planes and no dL/dx for it.
+template <int PREC, int SDF_D, int NC = 1, int NE = 0>
 __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
+  constexpr int NI = NC + NE;                  // 32-input chunks of the first layer
+  constexpr int NPAIR = NI / 2, NODD = NI & 1; // dW1 column tiles: pairs + an odd last one
   using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes
   NSIM_DYN_SMEM(smem);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
@@ -1104,8 +1208,19 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   const char* W = stage_weights<PREC>(smem, a, 0, 4, L, wbytes);
   char* stA = smem + wbytes;
   char* stB = stA + 64 * jstage_row_bytes<PREC>();
-  char* stC = stB + 64 * jstage_row_bytes<PREC>();
-  f32x16 accW1 = zero16(), accW2 = zero16();
+  char* stC = stB + (NI > 2 ? 32 * NI : 64) * jstage_row_bytes<PREC>();
+  f32x16 accW1[NPAIR + NODD], accW2 = zero16();
+#pragma unroll
+  for (int q = 0; q < NPAIR + NODD; ++q) accW1[q] = zero16();
+  // dW1 += A (x) B over the staged group, this wave's tiles
+  auto dw1_tiles = [&](const void* sa, const void* sb) {
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) accW1[q] = jdw_tile<PREC>(sa, wave >> 1, sb, 2 * q + (wave & 1), accW1[q]);
+    if constexpr (NODD) {
+      if (wave < 2) accW1[NPAIR] = jdw_tile<PREC, 0, JOINT_PTS / 32>(sa, wave & 1, sb, NI - 1, accW1[NPAIR]);
+      else accW1[NPAIR] = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(sa, wave & 1, sb, NI - 1, accW1[NPAIR]);
+    }
+  };
   float bs1 = 0.f, bs2 = 0.f, bsh = 0.f, bh = 0.f;      // this wave's share of d b1[lane], d b2[lane], d wh[lane], d b_head
   const bool do_dw = !(a.ablate & 4);
 
@@ -1135,7 +1250,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   };
   // fp16 mode: the whole 16 KB plane image of a wave's NEXT tile (h and dh/dx) is copied global -> LDS while the group
   // computes (as in k_field MODE 3); f32 validation mode (its f32 staging leaves no LDS for it) prefetches h into registers
-  constexpr bool GLDS = (PREC == 0 && NC == 1);
+  constexpr bool GLDS = (PREC == 0 && NC == 1 && NE == 0);
   char* pf = GLDS ? stC + 64 * jstage_row_bytes<PREC>() + wave * 16384 : nullptr;
   // BJD: the image holds the FEATURES only (4 copies of 4 levels each, 256 B per level); dh/dx -- consumed once, for dL/dg = J . gn,
   // AFTER the recomputed forward -- is loaded as packed pairs straight from the planes at the top of a group: 24 registers
@@ -1182,10 +1297,16 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
     }
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
-    float h[16 * NC];
+    float h[16 * NI];                   // [features | embedded position]
     float Jr[(NC == 1 && !BJD) ? 16 : 1][3];      // dh/dx of this group (NC == 2 / BJD: consumed straight from its loads, below)
     JPair<JT> Jq[BJD ? 8 : 1][3];                 // BJD: the (level, point) entries of this lane as stored (three pairs each)
-    float gh[16 * NC];                  // dL / dg = J . gn
+    float gh[16 * NI];                  // dL / dg = J . gn
+    if constexpr (NE > 0) {             // the block's values and its tangent along dL/dnablas, from the sample position
+      const TilePoint tp = load_point(a, grp * JOINT_WAVES + wave, j, false);
+      float ed[32];
+      embed_eval(a, tp.xx, valid, hi, reinterpret_cast<float(&)[32]>(h[16 * NC]), ed);
+      embed_tangent(&gh[16 * NC], ed, gn, hi);
+    }
     if constexpr (BJD) {
       nsim_wait_vm0();                          // this tile's feature image has landed
       const int64_t sc = valid ? s : a.S - 1;   // (a point past the end reads the last point's finite values; nothing of it is stored)
@@ -1272,7 +1393,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     KT(1, 1);
     // ---- decoder forward (recomputed) and d sdf / d h
     float a1[32];
-    dense<PREC, 2, NC>(a1, W + L.mat[M_W1], h, true);
+    dense<PREC, 2, NI>(a1, W + L.mat[M_W1], h, true);
 #pragma unroll
     for (int k = 0; k < 32; ++k) a1[k] = softplus_b(a1[k] + vecf(Wv, L, V_B1, hi, k), beta, inv_beta);
     float a2[32];
@@ -1330,16 +1451,12 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     __syncthreads();
     KT(1, 3);                              // the previous group's readers of the staging areas are done
     jstage<PREC, 2>(stA, d1, wave);
-    jstage<PREC, NC>(stB, gh, wave);
+    jstage<PREC, NI>(stB, gh, wave);
     __syncthreads();
-    if (do_dw) {
-      if constexpr (NC == 2) accW1 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW1);
-      else if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
-      else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
-    }
+    if (do_dw) dw1_tiles(stA, stB);
     KT(1, 4);
     float dh1[32];  // dL / d d1 = W1 . gh
-    dense<PREC, 2, NC>(dh1, W + L.mat[M_W1], gh, true);
+    dense<PREC, 2, NI>(dh1, W + L.mat[M_W1], gh, true);
     KT(1, 5);
     float dz1[32], whv[32];
     if constexpr (SDF_D == 2) {
@@ -1408,13 +1525,11 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     __syncthreads();
     KT(1, 13);
     jstage<PREC, 2>(stA, dz1, wave);
-    jstage<PREC, NC>(stB, h, wave);
+    jstage<PREC, NI>(stB, h, wave);
     if constexpr (SDF_D == 1) jstage<PREC, 2>(stC, whv, wave);
     __syncthreads();
     if (do_dw) {
-      if constexpr (NC == 2) accW1 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW1);
-      else if (wave < 2) accW1 = jdw_tile<PREC, 0, JOINT_PTS / 32>(stA, wave & 1, stB, 0, accW1);
-      else accW1 = jdw_tile<PREC, JOINT_PTS / 32, JOINT_PTS / 16>(stA, wave & 1, stB, 0, accW1);
+      dw1_tiles(stA, stB);
       bs1 += jrow_sum<PREC>(stA, 64, wave);
       if constexpr (SDF_D == 1) bsh += jrow_sum<PREC>(stC, 64, wave);
     }
@@ -1465,11 +1580,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   }
   { const int64_t grp = -1; KT(1, 21); }
   // ---- one flush per wave
-  const int F1 = 2 * a.lotd.num_levels;
-  const SrcOff so = src_off(SDF_D, F1);
+  const int F1 = 2 * a.lotd.num_levels, FIN = F1 + (NE ? a.embed_E : 0);      // W1 rows: [features (F1) | embedded position]
+  const SrcOff so = src_off(SDF_D, FIN);
   const int64_t ro = (int64_t)(blockIdx.x & (unsigned)a.rep_mask) * a.rep_stride;      // this workgroup's replica
-  if constexpr (NC == 2) jflush_tile(a.dsdf_w + ro + so.w1, F1, 64, F1, wave >> 1, wave & 1, accW1);
-  else jflush_tile(a.dsdf_w + ro + so.w1, F1, 64, F1, wave & 1, 0, accW1);
+  // column tile ``no`` of the accumulators -> columns of W1: feature tiles [0, NC) hold columns 32 no + i < F1, the block's
+  // tiles columns F1 + 32 (no - NC) + i < FIN
+  auto flush_w1 = [&](int mo, int no, const f32x16& acc) {
+    if (no < NC) jflush_tile(a.dsdf_w + ro + so.w1, FIN, 64, F1, mo, no, acc);
+    else jflush_tile(a.dsdf_w + ro + so.w1 + (F1 - 32 * NC), FIN, 64, 32 * NC + a.embed_E, mo, no, acc);
+  };
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) flush_w1(wave >> 1, 2 * q + (wave & 1), accW1[q]);
+  if constexpr (NODD) flush_w1(wave & 1, NI - 1, accW1[NPAIR]);
   if constexpr (SDF_D == 2) {
     jflush_tile(a.dsdf_w + ro + so.w2, 64, 64, 64, wave >> 1, wave & 1, accW2);
     if (bs2 != 0.f) atomicAdd(&a.dsdf_b[ro + so.b2 + lane], bs2);
@@ -2358,6 +2480,7 @@ static int field_meta_check(const NsimFieldMeta* m) {
   if (m->lotd.num_levels < 1 || m->lotd.num_levels > 32) return 21;
   if (m->sdf_D != 1 && m->sdf_D != 2) return 22;
   if (m->precision != 0 && m->precision != 1 && m->precision != 2) return 23;
+  if (m->embed_E < 0 || m->embed_E > 63 || (m->embed_E > 0 && (m->embed_E - 3) % 6 != 0)) return 36;
   return 0;
 }
 // precision 2 (split f16: f32-equivalent arithmetic on the f16 matrix cores) exists for the no-grad SDF query only
@@ -2438,7 +2561,8 @@ static void grad_scratch_fold(float* sc, int R, int64_t n_w, int64_t n_b, float*
 static FieldArgs field_args(const NsimFieldMeta* meta) {
   FieldArgs a = FieldArgs();
   a.lotd = lotd_dev(&meta->lotd);
-  a.lay = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
+  a.lay = field_layout(meta->precision, field_ni(meta));
+  a.embed_E = meta->embed_E;
   a.beta = meta->softplus_beta > 0.f ? meta->softplus_beta : 1e30f;      // (<= 0: relu, see softplus_exact)
   static const int code_pf = getenv("NSIM_CODE_PREFETCH") ? atoi(getenv("NSIM_CODE_PREFETCH")) : 0;
   a.code_pf = code_pf;
@@ -2455,7 +2579,7 @@ static unsigned field_grid(int64_t S, int64_t max_blocks, int waves = FIELD_WAVE
 
 static size_t weights_lds_bytes(const NsimFieldMeta* meta, int first = 0, int count = M_COUNT) {
   if (meta->precision == 1) return 0;
-  const FieldLayout L = field_layout(meta->precision, field_nc(meta->lotd.num_levels));
+  const FieldLayout L = field_layout(meta->precision, field_ni(meta));
   const int64_t m1 = (first + count < M_COUNT) ? L.mat[first + count] : L.vec[0];
   return (size_t)(((m1 - L.mat[first]) + (L.total - L.vec[0]) + 15) & ~15);
 }
@@ -2474,6 +2598,24 @@ static int field_launch(const NsimFieldMeta* meta, const FieldArgs& a, size_t sh
   const int nw = field_waves(meta, MODE);
   const dim3 grid(field_grid(a.S, max_blocks, nw)), block(64 * nw);
   const int key = meta->precision * 2 + (meta->sdf_D - 1);
+  if (field_ne(meta)) {      // embedded-position block behind the features: the forward on the planes only
+    if constexpr (MODE == 3) {
+      switch ((field_nc(meta->lotd.num_levels) - 1) * 4 + key) {
+        case 0: hipLaunchKernelGGL((k_field<0, 1, 3, 1, false, 2>), grid, block, shmem, stream, a); break;
+        case 1: hipLaunchKernelGGL((k_field<0, 2, 3, 1, false, 2>), grid, block, shmem, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_field<1, 1, 3, 1, false, 2>), grid, block, shmem, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_field<1, 2, 3, 1, false, 2>), grid, block, shmem, stream, a); break;
+        case 4: hipLaunchKernelGGL((k_field<0, 1, 3, 2, false, 2>), grid, block, shmem, stream, a); break;
+        case 5: hipLaunchKernelGGL((k_field<0, 2, 3, 2, false, 2>), grid, block, shmem, stream, a); break;
+        case 6: hipLaunchKernelGGL((k_field<1, 1, 3, 2, false, 2>), grid, block, shmem, stream, a); break;
+        case 7: hipLaunchKernelGGL((k_field<1, 2, 3, 2, false, 2>), grid, block, shmem, stream, a); break;
+      }
+      NSIM_CHECK_LAUNCH();
+      return 0;
+    } else {
+      return 36;
+    }
+  }
   if (field_nc(meta->lotd.num_levels) == 2) {
     if constexpr (MODE == 3) {
       if (gl2 && meta->precision == 0) {      // plane image in LDS (fp16 mode, <= 23 levels)
@@ -2519,16 +2661,18 @@ extern "C" {
 
 int64_t nsim_field_wpack_bytes(const NsimFieldMeta* meta) {
   if (field_meta_check(meta)) return -1;
-  return field_layout(meta->precision, field_nc(meta->lotd.num_levels)).total;
+  return field_layout(meta->precision, field_ni(meta)).total;
 }
 
 int nsim_field_pack_weights(const NsimFieldMeta* meta, const float* sdf_w, const float* sdf_b, const float* rad_w,
                             const float* rad_b, void* wpack, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
-  const int nc = field_nc(meta->lotd.num_levels);
+  const int nc = field_ni(meta);
   const FieldLayout L = field_layout(meta->precision, nc);
   PackDims dims;
+  dims.E = meta->embed_E;
+  dims.EB = 32 * field_nc(meta->lotd.num_levels);
   int64_t total = 0;
   for (int m = 0; m < M_COUNT; ++m) {
     dims.uo[m] = mat_uo(m, nc);
@@ -2550,15 +2694,17 @@ int nsim_field_pack_weights2(const NsimFieldMeta* meta_a, void* wpack_a, const N
   if (rc) return rc;
   rc = field_meta_check(meta_b);
   if (rc) return rc;
-  if (meta_a->sdf_D != meta_b->sdf_D || meta_a->lotd.num_levels != meta_b->lotd.num_levels) return 2;
+  if (meta_a->sdf_D != meta_b->sdf_D || meta_a->lotd.num_levels != meta_b->lotd.num_levels || meta_a->embed_E != meta_b->embed_E) return 2;
   if (!wpack_a || !wpack_b) return 4;
-  const int nc = field_nc(meta_a->lotd.num_levels);
+  const int nc = field_ni(meta_a);
   PackTwo p;
   const NsimFieldMeta* ms[2] = {meta_a, meta_b};
   int64_t most = 0;
   for (int q = 0; q < 2; ++q) {
     p.L[q] = field_layout(ms[q]->precision, nc);
     int64_t total = (int64_t)V_COUNT * 64;
+    p.dims[q].E = meta_a->embed_E;
+    p.dims[q].EB = 32 * field_nc(meta_a->lotd.num_levels);
     for (int m = 0; m < M_COUNT; ++m) {
       p.dims[q].uo[m] = mat_uo(m, nc);
       p.dims[q].ui[m] = mat_ui(m, nc);
@@ -2648,6 +2794,7 @@ int nsim_field_sdf(const NsimFieldMeta* meta, const void* grid_f16, const void* 
                    const void* feat_planes, float* occ_val, const NsimOccMeta* occ_meta, float occ_inv_s, void* stream) {
   const int rc = field_meta_check(meta);
   if (rc) return rc;
+  if (field_ne(meta)) return 36;      // a model with an embedded-position block queries through nsim_wide_sdf
   if (S <= 0) return 0;
   if (occ_val && !(x && occ_meta)) return 24;
   if (!feat_planes && !x && !(rays_o && rays_d && t && ridx)) return 24;
@@ -2772,6 +2919,8 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     // where that still fits the 160 KB of a CU (NSIM_FWD_GL2=0: the direct-load kernel)
     size_t wl = weights_lds_bytes(meta);
     if (meta->precision != 0) wl = 0;
+    if (field_ne(meta))      // the forward matrices only, no plane image: 66 KB (<= 16 levels) -> two workgroups per CU
+      return field_launch<3>(meta, a, weights_lds_bytes(meta, 0, M_R3 + 1), 512, (hipStream_t)stream, false);
     size_t pf_bytes = field_nc(meta->lotd.num_levels) == 1 ? (size_t)FIELD_WAVES * (NSIM_FWD_JDIRECT ? 4096 : 16384) : 0;
     bool gl2 = false;
     if (field_nc(meta->lotd.num_levels) == 2 && meta->precision == 0) {
@@ -2789,6 +2938,7 @@ int nsim_field_fwd(const NsimFieldMeta* meta, const void* grid_f16, const void* 
     const int fwd_grid = fwd_grid_env > 0 ? fwd_grid_env : ((pf_bytes && !(NSIM_FWD_JDIRECT && !gl2)) ? 256 : 512);
     return field_launch<3>(meta, a, wl + pf_bytes, fwd_grid, (hipStream_t)stream, gl2);
   }
+  if (field_ne(meta)) return 36;      // the embedded-position block exists on the level-major path (h_planes / J_planes) only
   return field_launch<1>(meta, a, weights_lds_bytes(meta), FIELD_GRID_FWD, (hipStream_t)stream);
 }
 
@@ -2852,17 +3002,31 @@ int nsim_field_bwd_rad(const NsimFieldMeta* meta, const void* wpack, const float
   return 0;
 }
 
-int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const void* J_planes,
-                       int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
-                       float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
+}  // extern "C"
+
+// nsim_field_bwd_sdf (pos == NULL, no embedded-position block) | nsim_wide_bwd_sdf (pos = the sample positions of a model with one)
+struct BwdPos {
+  const float *x, *rays_o, *rays_d, *t;
+  const int64_t* ridx;
+};
+static int field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const BwdPos* pos, const float* h_planes,
+                         const void* J_planes, int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes,
+                         float* dsdf_w, float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
   const int rc = field_meta_check_full(meta);
   if (rc) return rc;
   if (S <= 0) return 0;
   if (!dsdf_w || !dsdf_b) return 26;
   if (!h_planes || !J_planes) return 28;
   if ((dh_planes != nullptr) != (g_planes != nullptr)) return 28;
+  const int ne = field_ne(meta);
+  if ((ne != 0) != (pos != nullptr)) return 36;      // the block is regenerated from the positions: nsim_wide_bwd_sdf
+  if (ne && dx) return 36;
   FieldArgs a = field_args(meta);
   a.wpack = (const char*)wpack;
+  if (pos) {
+    if (!pos->x && !(pos->rays_o && pos->rays_d && pos->t && pos->ridx)) return 24;
+    a.x = pos->x; a.rays_o = pos->rays_o; a.rays_d = pos->rays_d; a.t = pos->t; a.ridx = pos->ridx;
+  }
   a.S = S;
   if (plane_pitch != 0 && (plane_pitch < S || (plane_pitch & 31))) return 28;
   a.PS = plane_pitch ? plane_pitch : NSIM_PLANE_PITCH(S);
@@ -2878,25 +3042,35 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   // and no accumulator read-modify-write); forced into 256 registers (two waves per SIMD) it spills 177 and takes 0.275 ms,
   // so the two-hidden-layer instantiation runs one wave per SIMD.  NSIM_SDF_BWD_OLD=1: the round-1 kernel (A/B aid).
   const char* oldp = getenv("NSIM_SDF_BWD_OLD");
-  if (!(oldp && atoi(oldp) == 1)) {
+  if (ne || !(oldp && atoi(oldp) == 1)) {
     // workgroup-joint weight gradients: weights + three staging areas in LDS, two workgroups per CU
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     // + one 16 KB plane-prefetch buffer per wave in fp16 mode (k_field_bwd_j GLDS)
-    const size_t shmem = weights_lds_bytes(meta, 0, 4) + 192 * row + (meta->precision == 0 && nc == 1 ? (size_t)JOINT_WAVES * 16384 : 0);
+    const int ni = nc + ne;      // staging: A 64 rows, B 32 ni (>= 64) rows, C 64 rows
+    const size_t shmem = weights_lds_bytes(meta, 0, 4) + (128 + (ni > 2 ? 32 * ni : 64)) * row +
+                         (meta->precision == 0 && nc == 1 && !ne ? (size_t)JOINT_WAVES * 16384 : 0);
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");
     const int64_t cap = gcap ? atoi(gcap) : 256;          // one resident workgroup per CU (register-limited)
     nb = nb > cap ? cap : (nb < 1 ? 1 : nb);
     const dim3 grid((unsigned)nb), block(64 * JOINT_WAVES);
-    const SrcOff so = src_off(meta->sdf_D, 2 * meta->lotd.num_levels);
+    const SrcOff so = src_off(meta->sdf_D, 2 * meta->lotd.num_levels + meta->embed_E);
     int R = 1;
     float* sc = nb >= grad_replicas_min_wg() ? grad_scratch(stream, so.n_sdf_w + so.n_sdf_b, R) : nullptr;
     if (sc) {
       a.dsdf_w = sc; a.dsdf_b = sc + so.n_sdf_w;
       a.rep_mask = R - 1; a.rep_stride = so.n_sdf_w + so.n_sdf_b;
     }
-    switch ((nc - 1) * 4 + meta->precision * 2 + (meta->sdf_D - 1)) {
+    switch ((ne ? 8 : 0) + (nc - 1) * 4 + meta->precision * 2 + (meta->sdf_D - 1)) {
+      case 8: hipLaunchKernelGGL((k_field_bwd_j<0, 1, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 9: hipLaunchKernelGGL((k_field_bwd_j<0, 2, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 10: hipLaunchKernelGGL((k_field_bwd_j<1, 1, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 11: hipLaunchKernelGGL((k_field_bwd_j<1, 2, 1, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 12: hipLaunchKernelGGL((k_field_bwd_j<0, 1, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 13: hipLaunchKernelGGL((k_field_bwd_j<0, 2, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 14: hipLaunchKernelGGL((k_field_bwd_j<1, 1, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
+      case 15: hipLaunchKernelGGL((k_field_bwd_j<1, 2, 2, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 0: hipLaunchKernelGGL((k_field_bwd_j<0, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 1: hipLaunchKernelGGL((k_field_bwd_j<0, 2>), grid, block, shmem, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((k_field_bwd_j<1, 1>), grid, block, shmem, (hipStream_t)stream, a); break;
@@ -2916,6 +3090,24 @@ int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float
   const size_t shmem = meta->precision == 0 ? weights_lds_bytes(meta, 0, 0) + nw * acc_bytes + nw * stage_bytes(meta)
                                             : weights_lds_bytes(meta, 0, 4) + acc_bytes + FIELD_WAVES * stage_bytes(meta);
   return field_launch<2>(meta, a, shmem, FIELD_GRID_BWD, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int nsim_field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* h_planes, const void* J_planes,
+                       int64_t S, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
+                       float* dsdf_b, float* dx, int64_t plane_pitch, void* stream) {
+  return field_bwd_sdf(meta, wpack, nullptr, h_planes, J_planes, S, dsdf, gn, dh_planes, g_planes, dsdf_w, dsdf_b, dx, plane_pitch,
+                       stream);
+}
+
+int nsim_wide_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const float* x, const float* rays_o, const float* rays_d,
+                      const float* t, const int64_t* ridx, int64_t S, const float* h_planes, const void* J_planes,
+                      int64_t plane_pitch, const float* dsdf, const float* gn, float* dh_planes, float* g_planes, float* dsdf_w,
+                      float* dsdf_b, void* stream) {
+  const BwdPos pos = {x, rays_o, rays_d, t, ridx};
+  return field_bwd_sdf(meta, wpack, &pos, h_planes, J_planes, S, dsdf, gn, dh_planes, g_planes, dsdf_w, dsdf_b, nullptr, plane_pitch,
+                       stream);
 }
 
 int nsim_lotd_scatter(const NsimLotdMeta* meta, const float* x, const float* rays_o, const float* rays_d, const float* t,

@@ -244,13 +244,11 @@ class _FieldFn(torch.autograd.Function):
         # (2) SDF-decoder branch on the saved planes
         if model.pos_embed_E:
             if need_dx:
-                raise NotImplementedError("pose refinement through a model with extra_pos_embed_cfg (csrc/wide_field.hip has no "
+                raise NotImplementedError("pose refinement through a model with extra_pos_embed_cfg (nsim_wide_bwd_sdf has no "
                                           "dL/dx output)")
-            sw_, sb_ = model._wide_weights()
-            _lib.call("nsim_wide_bwd_sdf", fm, int(model.pos_embed_n), _lib.ptr(sw_), _lib.ptr(sb_), _lib.ptr(x),
-                      _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), S, _lib.ptr(h_pl), _lib.ptr(J_pl),
-                      int(ctx.PS), _lib.ptr(gs), _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w),
-                      _lib.ptr(dsdf_b))
+            _lib.call("nsim_wide_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t),
+                      _lib.ptr(ridx), S, _lib.ptr(h_pl), _lib.ptr(J_pl), int(ctx.PS), _lib.ptr(gs), _lib.ptr(gn_total),
+                      _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b))
         else:
             _lib.call("nsim_field_bwd_sdf", fm, _lib.ptr(wpack), _lib.ptr(h_pl), _lib.ptr(J_pl), S, _lib.ptr(gs),
                       _lib.ptr(gn_total), _lib.ptr(dh_pl), _lib.ptr(g_pl), _lib.ptr(dsdf_w), _lib.ptr(dsdf_b), _lib.ptr(dx),
@@ -525,8 +523,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
 
         ``pos_embed_frequencies`` N (``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: N}``,
         no_fg_occ.221218.yaml:319-321): the SDF decoder reads [features | x_n, sin(2^k x_n), cos(2^k x_n), k < N] (x_n = the
-        AABB-normalised position); such a model runs its decoder on csrc/wide_field.hip (f32, first layers up to 128 wide)
-        instead of the 64-input MFMA kernels -- gather, radiance backward, scatter and sampling stay the common path.
+        AABB-normalised position); the first layer of the MFMA decoders then contracts over two more 32-input chunks holding
+        the block (csrc/field.hip NE = 2: ``nsim_field_fwd`` on the planes, ``nsim_wide_bwd_sdf``); the no-grad query of the
+        sampling pass runs in f32 on csrc/wide_field.hip -- gather, radiance backward and scatter stay the common path.
 
         ``reference_params``: the reference's ``model_params`` block passed verbatim, as
         ``import_str(model_class)(**model_params, device=device)`` does (app/resources/asset_bank.py:129-138) --
@@ -560,9 +559,9 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         self.sdf_D, self.ln_inv_s_factor = sdf_D, float(ln_inv_s_factor)
         self.pos_embed_n = None if pos_embed_frequencies is None else int(pos_embed_frequencies)
         self.pos_embed_E = 0 if self.pos_embed_n is None else 3 + 6 * self.pos_embed_n
-        assert 2 * len(lod_res) + self.pos_embed_E <= 128, "csrc/wide_field.hip: first layers up to 128 inputs"
+        assert self.pos_embed_E <= 63 and 2 * len(lod_res) + self.pos_embed_E <= 128, "first layers up to 64 features + 63 embedded values"
         if self.pos_embed_E:
-            self.planes_always = True       # the wide decoder reads the level-major planes in every mode
+            self.planes_always = True       # the decoder with the embedded-position block reads the level-major planes in every mode
         self.encoding = LoTDEncoding(LoTDConfig(lod_res, 2, log2_hashmap_size), bound=param_bound, seed=seed)
         n_sdf_w, n_sdf_b, n_rad_w, n_rad_b = _flat_sizes(sdf_D, len(lod_res), self.pos_embed_E)
         g = torch.Generator().manual_seed(seed + 1)
@@ -614,6 +613,7 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
         fm = _lib.FieldMeta()
         fm.lotd = self.encoding.cfg.meta
         fm.sdf_D = sdf_D
+        fm.embed_E = self.pos_embed_E       # the first layer's embedded-position block (two more MFMA input chunks): csrc/field.hip NE
         fm.precision = {"fp16": 0, "f32": 1}[precision]
         # ``decoder_cfg.activation``: softplus(beta) (the single-object / street configs) or relu (the Vehicle decoder of
         # no_fg_occ.221218.yaml:354-357) -- a non-positive beta selects relu in the kernels
@@ -811,9 +811,6 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
             if buf is None or buf.numel() != nbytes or buf.device != self.sdf_w.device:
                 buf = torch.zeros([nbytes], dtype=torch.uint8, device=self.sdf_w.device)
             sw, sb = self.sdf_w.detach(), self.sdf_b.detach()
-            if self.pos_embed_E:            # the packed fragments serve the radiance kernels only: feature columns of W1
-                F1, FIN = 2 * self.encoding.cfg.num_levels, 2 * self.encoding.cfg.num_levels + self.pos_embed_E
-                sw = torch.cat([sw[:64 * FIN].view(64, FIN)[:, :F1].reshape(-1), sw[64 * FIN:]])
             if self.sdf_scale != 1.0:       # sdf = head / sdf_scale: fold the divisor into the packed head weights
                 sw, sb = sw.clone(), sb.clone()
                 sw[-64:] /= self.sdf_scale
@@ -1053,16 +1050,8 @@ class LoTDNeuSModel(ModelMixin, nn.Module):
 
     def _enc_field_fwd(self, grid16, wpack, x, rays_o, rays_d, t, ridx, goff, ha, S, sdf, nablas, rgb, h_pl, J_pl, n_dev,
                        n_add):
-        if self.pos_embed_E:        # gather only (wpack NULL), then the wide decoder + radiance forward on the planes
-            _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), None, _lib.ptr(x), _lib.ptr(rays_o),
-                      _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), None, S, None, None, None,
-                      _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))
-            sw, sb = self._wide_weights()
-            _lib.call("nsim_wide_fwd", self.field_meta, int(self.pos_embed_n), _lib.ptr(sw), _lib.ptr(sb),
-                      _lib.ptr(self.rad_w.detach()), _lib.ptr(self.rad_b.detach()), _lib.ptr(x), _lib.ptr(rays_o),
-                      _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(ha), S, _lib.ptr(h_pl), _lib.ptr(J_pl),
-                      _lib.ptr(sdf), _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(n_dev), int(n_add))
-            return None
+        # (a model with an embedded-position block, field_meta.embed_E > 0: same entry point -- the level-major gather, then the
+        # decoder whose first layer also contracts over the block's two MFMA chunks)
         _lib.call("nsim_field_fwd", self.field_meta, _lib.ptr(grid16), _lib.ptr(wpack), _lib.ptr(x), _lib.ptr(rays_o),
                   _lib.ptr(rays_d), _lib.ptr(t), _lib.ptr(ridx), _lib.ptr(goff), _lib.ptr(ha), S, _lib.ptr(sdf),
                   _lib.ptr(nablas), _lib.ptr(rgb), _lib.ptr(h_pl), _lib.ptr(J_pl), _lib.ptr(n_dev), int(n_add))

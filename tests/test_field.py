@@ -555,8 +555,10 @@ def _with_pos_embed(p, n_freq, seed):
 def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
     """``surface_cfg.extra_pos_embed_cfg{type: sinusoidal_legacy, n_frequencies: 6}`` (the StyleLoTD Vehicle block,
     no_fg_occ.221218.yaml:319-321, with its relu 2x64 decoder :354-357): the decoder reads [features | embedded position]
-    (71 inputs) on csrc/wide_field.hip -- values, normals, colours, the no-grad query and every gradient against the oracle,
-    including the second-order path of the normals through the embedded position's own x-derivative."""
+    (71 inputs): with-grad forward and backward on the matrix cores with the block as two more 32-input chunks of the first
+    layer (csrc/field.hip NE = 2; f32-MFMA validation mode in four cases, the fp16 product mode in ``vehicle_relu``), the no-grad
+    query in f32 on csrc/wide_field.hip -- values, normals, colours and every gradient against the oracle, including the
+    second-order path of the normals through the embedded position's own x-derivative."""
     sdf_D = 1 if case == "softplus_D1_aabb" else 2
     if case == "24_levels":     # a 24-level pyramid (the 32-level planes of the gather) + ten frequencies: 48 + 63 = 111 inputs
         lod_res = [4 + int(round(2.9 * i + 0.11 * i * i)) for i in range(24)]
@@ -565,8 +567,8 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
         p.grid = p.grid.float()
     else:
         p = make_params(sdf_D=sdf_D, small=True, sphere=False, grid_bound=0.3, seed=11, noise_scale=1.0)
-    # (first-layer widths 71 / 53 / 71 / 95 / 111: the 72-, 56-, 104- and 128-wide instantiations of k_wide; above 72 the
-    # weight-gradient row of a lane goes through LDS instead of registers)
+    # (first-layer widths 71 / 53 / 71 / 95 / 111: three MFMA input chunks up to 16 levels, four for the 24-level pyramid; the
+    # 72-, 56-, 104- and 128-wide instantiations of the no-grad k_wide_sdf)
     n_freq = {"softplus_D1_aabb": 3, "ten_frequencies": 10, "24_levels": 10}.get(case, 6)
     F1 = 2 * len(p.spec.lod_res)
     _with_pos_embed(p, n_freq, seed=3)
@@ -594,16 +596,26 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
     dv = lambda a: a.to(backend).contiguous()
     sdf, nab, rgb = _FieldFn.apply(model, model.encoding.flattened_params, model.sdf_w, model.sdf_b, model.rad_w,
                                    model.rad_b, ha_d, None, dv(rays_o), dv(rays_d), dv(t), dv(ridx), True)
-    # (fp16 field precision: the TABLE is read as fp16 -- the oracle's grid holds fp16-representable values -- the decoder is f32)
-    assert (sdf.cpu() - sdf_r).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
-    assert (nab.cpu() - nab_r).abs().max() < 2e-4 * (1 + nab_r.abs().max())
-    assert (rgb.cpu() - rgb_r).abs().max() < 2e-5
+    # (the tolerances of the other decoder tests of this file: f32-MFMA validation mode | fp16 MFMA product mode)
+    ts, tn, tr = (4e-3, 5e-2, 4e-3) if case == "vehicle_relu" else (2e-5, 2e-4, 2e-5)
+    assert (sdf.cpu() - sdf_r).abs().max() < ts * (1 + sdf_r.abs().max())
+    en = (nab.cpu() - nab_r).abs().amax(dim=-1)
+    if case == "vehicle_relu":
+        # relu has a kink: a hidden unit whose pre-activation lies within the fp16 rounding of zero takes the other branch, and
+        # the normal of that point moves by the unit's whole contribution (0.19 for one point of these 203).  Such points are rare
+        # and the values stay continuous: all but 2 % of the points within the fp16 tolerance, the median at fp16 rounding level
+        assert float((en > tn * (1 + nab_r.abs().max())).float().mean()) < 0.02 and float(en.median()) < 2e-3
+        flipped = en > tn * (1 + nab_r.abs().max())
+    else:
+        assert en.max() < tn * (1 + nab_r.abs().max())
+        flipped = torch.zeros_like(en, dtype=torch.bool)
+    assert (rgb.cpu() - rgb_r).abs()[~flipped].max() < tr
     q = model._query_sdf_rays(dv(rays_o), dv(rays_d), dv(t), dv(ridx)).cpu()
     assert (q - sdf_r.detach()).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
     assert (model.query_sdf(dv(x)).cpu() - sdf_r.detach()).abs().max() < 2e-5 * (1 + sdf_r.abs().max())
     # points mode, no colour (the eikonal query of uniform points)
     out = model.forward_sdf_nablas(dv(x[:50]))
-    assert (out["nablas"].detach().cpu() - nab_r[:50].detach()).abs().max() < 2e-4 * (1 + nab_r.abs().max())
+    assert (out["nablas"].detach().cpu() - nab_r[:50].detach()).abs().amax(dim=-1)[~flipped[:50]].max() < tn * (1 + nab_r.abs().max())
     ws, wn, wr = torch.randn(S, generator=g), torch.randn(S, 3, generator=g) * 0.1, torch.randn(S, 3, generator=g)
     (sdf_r * ws).sum().add((nab_r * wn).sum()).add((rgb_r * wr).sum()).backward()
     (sdf * dv(ws)).sum().add((nab * dv(wn)).sum()).add((rgb * dv(wr)).sum()).backward()
@@ -612,8 +624,7 @@ def test_field_with_extra_pos_embed(backend, case, poisoned_empty):
                rad_w=model.rad_w.grad, rad_b=model.rad_b.grad)
     for k, v in got.items():
         e = rel_l2(v.cpu(), ref[k])
-        # (fp16 field precision: the radiance backward runs on the f16 matrix cores and its dL/dnablas feeds the second-order
-        # terms of every SDF-side gradient -- the tolerance of test_field_with_relu_sdf_decoder; the wide decoder is f32 either way)
+        # (fp16 mode: the tolerance of test_field_with_relu_sdf_decoder)
         assert e < (3e-2 if case == "vehicle_relu" else 3e-4), (k, e)
     assert rel_l2(ha_d.grad.cpu(), ha_o.grad) < (3e-2 if case == "vehicle_relu" else 3e-4)
     # the embedded-position columns of W1 carry gradient (first- and second-order terms)
