@@ -756,7 +756,9 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
         try:
             rec_l = json.loads(lf.read_text())
             kk = rec_l["kernels"]
-            ga, sc_ = kk["void k_lotd_gather_lm<1, false>(FieldArgs)"], kk["k_lotd_scatter(ScatterArgs)"]
+            # (kernel names as rocprofv3 prints them: the scatter became a template in round 6)
+            ga = next(v for k, v in kk.items() if "k_lotd_gather_lm<1, false>" in k)
+            sc_ = next(v for k, v in kk.items() if "k_lotd_scatter" in k)
             roofline["cache_ceilings"] = dict(
                 gather=dict(kernel="k_lotd_gather_lm<1,false>", read_req_per_launch=ga["tcp_tcc_read_req"],
                             achieved_Greq_s=ga["read_req_per_s"], ceiling_Greq_s=rec_l["calibration"]["l2_read_req_ceiling_per_s"] / 1e9,

@@ -727,9 +727,13 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
     (void)grp;
     if constexpr (MODE == 2) { KT(1, 0); }
     if constexpr (MODE == 3) { KT(2, 0); }
-    const TilePoint p = load_point(a, tile, j, FWD);
-    const bool valid = p.valid;
-    const int64_t s = p.s;
+    // JDIR: the point's position / ray / direction (needed by the radiance head only) are requested AFTER the wait for the plane
+    // image below -- in front of it that s_waitcnt vmcnt(0) exposed their (dependent: ridx -> rays) latency at the top of every tile
+    constexpr bool JDIR_ = (MODE == 3 && NC == 1 && NE == 0 && NSIM_FWD_JDIRECT);
+    TilePoint p;
+    if constexpr (!JDIR_) p = load_point(a, tile, j, FWD);
+    const int64_t s = tile * 32 + j;
+    const bool valid = s < a.S;
     // ---------------------------------------------------------------- gather (8 of 16 levels per lane)
     // The backward does NOT gather again: the forward saved h and dh/dx as level-major planes
     // ([level][sample][..], coalesced across the 32 samples of a tile) -- 512 B per sample of sequential HBM
@@ -751,6 +755,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
           h[r0 + 1] = valid ? hp[1] : 0.f;
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+      p = load_point(a, tile, j, FWD);
       // dh/dx of a point past the end: the last point's (finite values; nothing of such a lane is stored)
       const int64_t sc = valid ? s : a.S - 1;
 #pragma unroll
@@ -1289,13 +1294,18 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     const int vo = nsim_opaque_zero();
     const char* Wv = W + vo;
     float gs = 0.f, gn[3] = {0.f, 0.f, 0.f};
-    if (valid) {
-      if (a.dsdf) gs = a.dsdf[s];
-      if (a.dnablas) {
+    auto load_upstream = [&]() {
+      if (valid) {
+        if (a.dsdf) gs = a.dsdf[s];
+        if (a.dnablas) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gn[c] = a.dnablas[3 * s + c];
+          for (int c = 0; c < 3; ++c) gn[c] = a.dnablas[3 * s + c];
+        }
       }
-    }
+    };
+    // BJD: the upstream gradients are requested AFTER the wait for the plane image below -- issued in front of it, that
+    // s_waitcnt vmcnt(0) exposed their full memory latency at the top of every group (s_memtime: 4.4 k of 27 k ticks per group)
+    if constexpr (!(PREC == 0 && NC == 1 && NE == 0 && NSIM_BWD_JDIRECT)) load_upstream();
     // ---- dL/dg = J . gn (second-order path through the normals) and the features, from the level-major planes
     float h[16 * NI];                   // [features | embedded position]
     float Jr[(NC == 1 && !BJD) ? 16 : 1][3];      // dh/dx of this group (NC == 2 / BJD: consumed straight from its loads, below)
@@ -1320,6 +1330,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
           h[r0 + 1] = valid ? hp[1] : 0.f;
         }
       nsim_wait_lgkm0();                        // every lane has read the image: the next copy may overwrite it
+      load_upstream();
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll

@@ -52,6 +52,41 @@ __device__ __forceinline__ float wave_incl_sum(float v) {
   return v;
 }
 
+// the same six DPP steps for a 32-bit integer (ray / sample counts below 2^31; 64-bit sums take the shuffle form)
+#define NSIM_DPP_OLD_I32(oldv, x, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(oldv), (int)(x), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ int wave_incl_sum(int v) {
+  v += NSIM_DPP_OLD_I32(0, v, 0x111, 0xf);
+  v += NSIM_DPP_OLD_I32(0, v, 0x112, 0xf);
+  v += NSIM_DPP_OLD_I32(0, v, 0x114, 0xf);
+  v += NSIM_DPP_OLD_I32(0, v, 0x118, 0xf);
+  v += NSIM_DPP_OLD_I32(0, v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3
+  v += NSIM_DPP_OLD_I32(0, v, 0x143, 0xc);   // row_bcast31 into rows 2 and 3
+  return v;
+}
+
+// ... and for a 64-bit integer: the two words travel separately, the carry of the low word is added locally (the shuffle
+// form costs two ds_bpermute per step on the LDS crossbar; the single-workgroup scans of pack_ops.hip sit on the critical path of
+// the sampling pass)
+__device__ __forceinline__ int64_t wave_incl_sum(int64_t v) {
+  uint32_t lo = (uint32_t)(uint64_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+#define NSIM_SCAN64_STEP(ctrl, rmask)                                  \
+  {                                                                    \
+    const uint32_t sl = (uint32_t)NSIM_DPP_OLD_I32(0, lo, ctrl, rmask); \
+    const uint32_t sh = (uint32_t)NSIM_DPP_OLD_I32(0, hi, ctrl, rmask); \
+    const uint32_t nl = lo + sl;                                       \
+    hi = hi + sh + (nl < lo ? 1u : 0u);                                \
+    lo = nl;                                                           \
+  }
+  NSIM_SCAN64_STEP(0x111, 0xf)
+  NSIM_SCAN64_STEP(0x112, 0xf)
+  NSIM_SCAN64_STEP(0x114, 0xf)
+  NSIM_SCAN64_STEP(0x118, 0xf)
+  NSIM_SCAN64_STEP(0x142, 0xa)
+  NSIM_SCAN64_STEP(0x143, 0xc)
+#undef NSIM_SCAN64_STEP
+  return (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
 __device__ __forceinline__ float wave_incl_prod(float v) {
   v *= NSIM_DPP_OLD_F32(1.f, v, 0x111, 0xf);
   v *= NSIM_DPP_OLD_F32(1.f, v, 0x112, 0xf);

@@ -93,29 +93,33 @@ __global__ void __launch_bounds__(PI_THREADS) k_live_rank(const int64_t* __restr
   // two sums ride one pass: the sample counts (int64) and the live-ray count.  (Rounds 4-5 packed both into one int64 scan with
   // the live count in bits 44..63: 2^19 live rays reached the sign bit -- an 800x800 image queried in one chunk has 640 k rays.)
   __shared__ int64_t wtot[PI_THREADS / 64];
-  __shared__ int64_t wlive[PI_THREADS / 64];
+  __shared__ int wlive[PI_THREADS / 64];
   const int tid = threadIdx.x, lane = nsim_lane(), wave = tid >> 6;
   int64_t carry = 0, carry_live = 0;
   for (int64_t base = 0; base < R; base += (int64_t)PI_THREADS * PI_PER) {
     const int64_t i0 = base + (int64_t)tid * PI_PER;
     int64_t v[PI_PER];
-    int64_t mine = 0, mine_live = 0;
+    int64_t mine = 0;
+    int mine_live = 0;      // (at most PI_THREADS * PI_PER per super-chunk: the 32-bit DPP scan; the running total is 64-bit)
 #pragma unroll
     for (int k = 0; k < PI_PER; ++k) {
       v[k] = (i0 + k) < R ? n[i0 + k] : 0;
       mine += v[k];
       mine_live += v[k] > 0 ? 1 : 0;
     }
-    const int64_t incl = wave_incl_sum(mine), incl_live = wave_incl_sum(mine_live);
+    const int64_t incl = wave_incl_sum(mine);
+    const int incl_live = wave_incl_sum(mine_live);
     if (lane == 63) {
       wtot[wave] = incl;
       wlive[wave] = incl_live;
     }
     __syncthreads();
-    int64_t before = 0, chunk = 0, before_live = 0, chunk_live = 0;
+    int64_t before = 0, chunk = 0;
+    int before_live = 0, chunk_live = 0;
 #pragma unroll
     for (int w = 0; w < PI_THREADS / 64; ++w) {
-      const int64_t x = wtot[w], y = wlive[w];
+      const int64_t x = wtot[w];
+      const int y = wlive[w];
       before += (w < wave) ? x : 0;
       chunk += x;
       before_live += (w < wave) ? y : 0;
