@@ -373,6 +373,11 @@ __host__ __device__ inline RadAccOff rad_acc_off() {
 
 
 #define FIELD_WAVES 4
+#ifndef NSIM_BWD_DBUF
+#define NSIM_BWD_DBUF 0         // k_field_bwd_j, fp16: 1 = two alternating staging sets for the weight-gradient products (4 instead of 8 barriers
+                                // per group).  Measured null on MI355X (nsim_field_bwd_sdf 0.1208 vs 0.1210 ms, street 0.6419 vs 0.6418;
+                                // gpurun_out/r6_s2_call5) at +36 registers: the barriers are not where the kernel's time goes
+#endif
 #ifndef NSIM_BWD_JDIRECT
 #define NSIM_BWD_JDIRECT 1      // k_field_bwd_j, <= 16 levels, fp16 mode: features through the LDS image, dh/dx as packed pairs straight into registers
 #endif
@@ -1211,9 +1216,22 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   int wbytes = 0;
   { const int64_t grp = -1; KT(1, 23); }
   const char* W = stage_weights<PREC>(smem, a, 0, 4, L, wbytes);
-  char* stA = smem + wbytes;
+  // Staging set = A (64 rows) + B (32 NI, at least 64) + C (64).  DB (fp16 mode without the embedded block: LDS allows it): TWO sets
+  // used alternately by the group's weight-gradient products, so only the barrier between a product's writers and its readers
+  // remains -- the set a product writes was last read two products ago, and every wave passed the barrier in between after
+  // its reads (8 -> 4 barriers per group of 128 points; at one wave per SIMD a barrier costs the waves' drift).
+  constexpr bool DB = NSIM_BWD_DBUF && PREC == 0 && NE == 0 && (NC == 2 || NSIM_BWD_JDIRECT);
+  constexpr int SET_ROWS = 128 + (NI > 2 ? 32 * NI : 64);
+  char* const st0 = smem + wbytes;
+  auto set_base = [&](int k) -> char* { return st0 + (DB ? (k & 1) * SET_ROWS * jstage_row_bytes<PREC>() : 0); };
+  char* stA = st0;
   char* stB = stA + 64 * jstage_row_bytes<PREC>();
   char* stC = stB + (NI > 2 ? 32 * NI : 64) * jstage_row_bytes<PREC>();
+  auto use_set = [&](int k) {
+    stA = set_base(k);
+    stB = stA + 64 * jstage_row_bytes<PREC>();
+    stC = stB + (NI > 2 ? 32 * NI : 64) * jstage_row_bytes<PREC>();
+  };
   f32x16 accW1[NPAIR + NODD], accW2 = zero16();
 #pragma unroll
   for (int q = 0; q < NPAIR + NODD; ++q) accW1[q] = zero16();
@@ -1256,7 +1274,7 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   // fp16 mode: the whole 16 KB plane image of a wave's NEXT tile (h and dh/dx) is copied global -> LDS while the group
   // computes (as in k_field MODE 3); f32 validation mode (its f32 staging leaves no LDS for it) prefetches h into registers
   constexpr bool GLDS = (PREC == 0 && NC == 1 && NE == 0);
-  char* pf = GLDS ? stC + 64 * jstage_row_bytes<PREC>() + wave * 16384 : nullptr;
+  char* pf = GLDS ? st0 + (DB ? 2 : 1) * SET_ROWS * jstage_row_bytes<PREC>() + wave * (NSIM_BWD_JDIRECT ? 4096 : 16384) : nullptr;
   // BJD: the image holds the FEATURES only (4 copies of 4 levels each, 256 B per level); dh/dx -- consumed once, for dL/dg = J . gn,
   // AFTER the recomputed forward -- is loaded as packed pairs straight from the planes at the top of a group: 24 registers
   // (f16) instead of 48 converted floats live across the forward, no LDS round trip, the loads fly under the forward
@@ -1459,7 +1477,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     }
     // ---- dW1 += d1 (x) gh
     KT(1, 2);
-    __syncthreads();
+    use_set(0);
+    if constexpr (!DB) __syncthreads();
     KT(1, 3);                              // the previous group's readers of the staging areas are done
     jstage<PREC, 2>(stA, d1, wave);
     jstage<PREC, NI>(stB, gh, wave);
@@ -1483,7 +1502,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       for (int k = 0; k < 32; ++k) d2[k] = sig_from_softplus(a2[k], beta) * vecf(Wv, L, V_WH, hi, k);
       // ---- dW2 += d2 (x) eh1
       KT(1, 6);
-      __syncthreads();
+      use_set(1);
+      if constexpr (!DB) __syncthreads();
       KT(1, 7);
       jstage<PREC, 2>(stA, d2, wave);
       jstage<PREC, 2>(stB, eh1, wave);
@@ -1502,7 +1522,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       }
       // ---- dW2 += dz2 (x) a1, d b2 += rowsum(dz2), d wh += rowsum(whv)
       KT(1, 9);
-      __syncthreads();
+      use_set(0);
+      if constexpr (!DB) __syncthreads();
       KT(1, 10);
       jstage<PREC, 2>(stA, dz2, wave);
       jstage<PREC, 2>(stB, a1, wave);
@@ -1533,7 +1554,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     }
     // ---- dW1 += dz1 (x) h, d b1 += rowsum(dz1)  (+ d wh when there is one hidden layer)
     KT(1, 12);
-    __syncthreads();
+    use_set(1);
+    if constexpr (!DB) __syncthreads();
     KT(1, 13);
     jstage<PREC, 2>(stA, dz1, wave);
     jstage<PREC, NI>(stB, h, wave);
@@ -2260,8 +2282,12 @@ struct ScatterArgs {
 //     slots by corner offset, strided issue (rounds 1-5)   0.376 ms   3.32 ms    25.1 / 43.5 requests per point (model)
 //     parity slots, strided issue                           0.309      2.84       20.4 / 37.5
 //     parity slots, consecutive issue (default)             0.286      2.47       17.8 / 32.4
+#ifndef NSIM_SCATTER_MIN_WAVES
+#define NSIM_SCATTER_MIN_WAVES 5      // waves per SIMD the register allocation leaves room for: 98 -> 96 registers, five waves instead of
+                                      // four (MI355X, bench step: 0.2865 -> 0.2811 ms; 6 -- 80 registers + 64 B scratch -- 0.328 ms)
+#endif
 template <bool CONSEC>
-__global__ void __launch_bounds__(256) k_lotd_scatter(ScatterArgs a) {
+__global__ void __launch_bounds__(256, NSIM_SCATTER_MIN_WAVES) k_lotd_scatter(ScatterArgs a) {
   const int lane = nsim_lane();
   const int l = a.level_begin + (int)blockIdx.y;
   const LotdRes R = a.lotd.res[l];
@@ -3058,8 +3084,9 @@ static int field_bwd_sdf(const NsimFieldMeta* meta, const void* wpack, const Bwd
     const size_t row = meta->precision == 0 ? jstage_row_bytes<0>() : jstage_row_bytes<1>();
     // + one 16 KB plane-prefetch buffer per wave in fp16 mode (k_field_bwd_j GLDS)
     const int ni = nc + ne;      // staging: A 64 rows, B 32 ni (>= 64) rows, C 64 rows
-    const size_t shmem = weights_lds_bytes(meta, 0, 4) + (128 + (ni > 2 ? 32 * ni : 64)) * row +
-                         (meta->precision == 0 && nc == 1 && !ne ? (size_t)JOINT_WAVES * 16384 : 0);
+    const bool dbuf = NSIM_BWD_DBUF && meta->precision == 0 && !ne && (nc == 2 || NSIM_BWD_JDIRECT);      // (DB in the kernel)
+    const size_t shmem = weights_lds_bytes(meta, 0, 4) + (dbuf ? 2 : 1) * (128 + (ni > 2 ? 32 * ni : 64)) * row +
+                         (meta->precision == 0 && nc == 1 && !ne ? (size_t)JOINT_WAVES * (NSIM_BWD_JDIRECT ? 4096 : 16384) : 0);
     const int64_t tiles = (S + 31) / 32;
     int64_t nb = (tiles + JOINT_WAVES - 1) / JOINT_WAVES;
     const char* gcap = getenv("NSIM_SDF_BWD_GRID");

@@ -8,6 +8,8 @@ echo "tests rc=$?"; tail -2 $OUT/tests.log
 B="--steps 64 --warmup 16 --no-cpu-baseline --no-variants --no-parity"
 for rep in 1 2 3; do
   python bench.py $B > $OUT/bench_$rep.json 2> $OUT/bench_$rep.err
+  python tools/variant.py run sc5 $B > $OUT/bench_sc5_$rep.json 2> $OUT/bench_sc5_$rep.err
+  python tools/variant.py run sc6 $B > $OUT/bench_sc6_$rep.json 2> $OUT/bench_sc6_$rep.err
 done
 for f in $OUT/bench_*.json; do python -c "
 import json
