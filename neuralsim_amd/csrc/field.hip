@@ -1661,8 +1661,17 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #ifndef GLM_PTS
 #define GLM_PTS 4
 #endif
+#ifndef NSIM_GATHER_WJ_WAVES
+#define NSIM_GATHER_WJ_WAVES 1   // WJ (with-grad planes): waves per SIMD the register allocation must leave room for (A/B knob of the slot tables)
+#endif
+#ifndef NSIM_GATHER_SLOTS
+#define NSIM_GATHER_SLOTS 0      // 1: the parity enumeration through per-axis operand tables (lotd_slots, ~30 % fewer VALU operations per level) instead
+                                 // of runtime corner indices.  Measured null on MI355X (gpurun_out/r6_s2_call7: nsim_lotd_gather_lm 0.0603 -> 0.0599 ms,
+                                 // the with-grad gather inside nsim_field_fwd +1.5 % at 99 registers / four waves or 96 + 20 B scratch): the
+                                 // gathers wait on L2 requests, not on the VALU
+#endif
 template <int PREC, bool WJ>
-__global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
+__global__ void __launch_bounds__(64, WJ ? NSIM_GATHER_WJ_WAVES : 1) k_lotd_gather_lm(FieldArgs a) {
   using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes (WJ)
   // points per lane.  (Round 5: 1 / 2 points per lane for launches of <= 98 k / 196 k points -- four times the waves for the
   // small up-sampling draws -- measured nothing: 0.0643-0.0658 against 0.0651-0.0666 ms per launch, profiles/round5_gather_ab.txt)
@@ -1722,15 +1731,24 @@ __global__ void __launch_bounds__(64) k_lotd_gather_lm(FieldArgs a) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) j0[q][c3] = j1[q][c3] = 0.f;
       }
+#if NSIM_GATHER_SLOTS
+      const LotdSlots SL = lotd_slots(c);    // slots by vertex parity, the parity folded into the operands (lotd_dev.h)
+#else
       const int pm = lotd_slot_mask(c);      // slots by vertex parity (lotd_dev.h)
+#endif
       if (l < a.lotd.n_active)
 #pragma unroll
       for (int slot = 0; slot < 8; ++slot) {
-        const int corner = slot ^ pm;
         float w, dw[3];
+#if NSIM_GATHER_SLOTS
+        lotd_slot_w(SL, slot, w, dw);
+        const uint32_t idx = lotd_slot_index(SL, slot, R, type, T);
+#else
+        const int corner = slot ^ pm;
         lotd_corner_w(c, corner, w, dw);
         const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
                                         c.c0[2] + ((corner >> 2) & 1), R, type, T);
+#endif
         float g0, g1;
         lotd_load2(gref, off + goff[q] + 2u * idx, g0, g1);
         f0[q] = f0[q] + w * g0;

@@ -101,6 +101,43 @@ __device__ __forceinline__ int lotd_slot_mask(const LotdCell& c) {
   return NSIM_GATHER_PARITY ? ((c.c0[0] & 1) | ((c.c0[1] & 1) << 1) | ((c.c0[2] & 1) << 2)) : 0;
 }
 
+// The same enumeration with the parity folded into the OPERANDS instead of the corner index: per axis the coordinate, the weight
+// and the derivative sign of the vertex with parity bit 0 / 1 (two selects per axis), so the eight slots index them with
+// compile-time bits -- the eight runtime corner indices of ``corner = slot ^ mask`` cost six selects each, and kept the compiler from
+// sharing the per-axis products and hash terms between slots.  lotd_slot_w(S, k, ..) returns the values of
+// lotd_corner_w(c, k ^ lotd_slot_mask(c), ..) bit for bit: (+-1 a) b == +-(a b) exactly.
+struct LotdSlots {
+  int v[3][2];      // coordinate of the vertex with parity bit k on axis a
+  float w[3][2];    // its interpolation weight along the axis
+  float s[3];       // d w[a][0] / d pos_a (= -d w[a][1] / d pos_a): +-1
+};
+__device__ __forceinline__ LotdSlots lotd_slots(const LotdCell& c) {
+  LotdSlots S;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int p = NSIM_GATHER_PARITY ? (c.c0[a] & 1) : 0;
+    S.v[a][0] = c.c0[a] + p;
+    S.v[a][1] = c.c0[a] + (p ^ 1);
+    const float w1 = c.w[a], w0 = 1.0f - c.w[a];
+    S.w[a][0] = p ? w1 : w0;
+    S.w[a][1] = p ? w0 : w1;
+    S.s[a] = p ? 1.0f : -1.0f;
+  }
+  return S;
+}
+__device__ __forceinline__ void lotd_slot_w(const LotdSlots& S, int k, float& w, float dw[3]) {
+  const int kx = k & 1, ky = (k >> 1) & 1, kz = (k >> 2) & 1;
+  const float wx = S.w[0][kx], wy = S.w[1][ky], wz = S.w[2][kz];
+  const float wxy = wx * wy;
+  w = wxy * wz;
+  dw[0] = (kx ? -S.s[0] : S.s[0]) * (wy * wz);
+  dw[1] = (ky ? -S.s[1] : S.s[1]) * (wx * wz);
+  dw[2] = (kz ? -S.s[2] : S.s[2]) * wxy;
+}
+__device__ __forceinline__ uint32_t lotd_slot_index(const LotdSlots& S, int k, const LotdRes& R, int type, uint32_t T) {
+  return lotd_index(S.v[0][k & 1], S.v[1][(k >> 1) & 1], S.v[2][(k >> 2) & 1], R, type, T);
+}
+
 // trilinear weight of corner (dx,dy,dz) and its derivative w.r.t. the three cell coordinates
 __device__ __forceinline__ void lotd_corner_w(const LotdCell& c, int corner, float& w, float dw[3]) {
   const int dx = corner & 1, dy = (corner >> 1) & 1, dz = (corner >> 2) & 1;
