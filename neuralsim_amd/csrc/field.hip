@@ -1206,6 +1206,7 @@ __global__ void __launch_bounds__(64 * FIELD_WAVES) k_field(FieldArgs a) {
 template <int PREC, int SDF_D, int NC = 1, int NE = 0>
 __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
   constexpr int NI = NC + NE;                  // 32-input chunks of the first layer
+  constexpr bool SP = !(NC == 2 && SDF_D == 1 && NE == 0);      // paired bf16 staging (mfma_mlp.h jstage): measured per instantiation
   constexpr int NPAIR = NI / 2, NODD = NI & 1; // dW1 column tiles: pairs + an odd last one
   using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes
   NSIM_DYN_SMEM(smem);
@@ -1480,8 +1481,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     use_set(0);
     if constexpr (!DB) __syncthreads();
     KT(1, 3);                              // the previous group's readers of the staging areas are done
-    jstage<PREC, 2>(stA, d1, wave);
-    jstage<PREC, NI>(stB, gh, wave);
+    jstage<PREC, 2, SP>(stA, d1, wave);
+    jstage<PREC, NI, SP>(stB, gh, wave);
     __syncthreads();
     if (do_dw) dw1_tiles(stA, stB);
     KT(1, 4);
@@ -1505,8 +1506,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       use_set(1);
       if constexpr (!DB) __syncthreads();
       KT(1, 7);
-      jstage<PREC, 2>(stA, d2, wave);
-      jstage<PREC, 2>(stB, eh1, wave);
+      jstage<PREC, 2, SP>(stA, d2, wave);
+      jstage<PREC, 2, SP>(stB, eh1, wave);
       __syncthreads();
       if (do_dw) accW2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW2);
       KT(1, 8);
@@ -1525,9 +1526,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
       use_set(0);
       if constexpr (!DB) __syncthreads();
       KT(1, 10);
-      jstage<PREC, 2>(stA, dz2, wave);
-      jstage<PREC, 2>(stB, a1, wave);
-      jstage<PREC, 2>(stC, whv, wave);
+      jstage<PREC, 2, SP>(stA, dz2, wave);
+      jstage<PREC, 2, SP>(stB, a1, wave);
+      jstage<PREC, 2, SP>(stC, whv, wave);
       __syncthreads();
       if (do_dw) {
         accW2 = jdw_tile<PREC>(stA, wave >> 1, stB, wave & 1, accW2);
@@ -1557,9 +1558,9 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
     use_set(1);
     if constexpr (!DB) __syncthreads();
     KT(1, 13);
-    jstage<PREC, 2>(stA, dz1, wave);
-    jstage<PREC, NI>(stB, h, wave);
-    if constexpr (SDF_D == 1) jstage<PREC, 2>(stC, whv, wave);
+    jstage<PREC, 2, SP>(stA, dz1, wave);
+    jstage<PREC, NI, SP>(stB, h, wave);
+    if constexpr (SDF_D == 1) jstage<PREC, 2, SP>(stC, whv, wave);
     __syncthreads();
     if (do_dw) {
       dw1_tiles(stA, stB);

@@ -234,6 +234,9 @@ __device__ __forceinline__ void rowsum_acc(void* stA, const float (&A)[NM * 16],
 // fp16 mode stages bf16 (v_mfma_f32_32x32x16_bf16, same rate as f16 on gfx950): the f32 exponent range makes the
 // per-tile power-of-two re-scaling of the f16 operands unnecessary, which is what allows the accumulation to run
 // ACROSS tiles; the operands keep 8 significant bits, the sum is f32.  f32 mode stages f32 (exact, validation).
+#ifndef NSIM_STAGE_PAIRS
+#define NSIM_STAGE_PAIRS 1      // jstage, bf16: v_cvt_pk_bf16_f32 converts two staged values per instruction
+#endif
 #define JOINT_WAVES 4
 #define JOINT_PTS (32 * JOINT_WAVES)
 
@@ -254,11 +257,26 @@ __host__ __device__ constexpr int jstage_row_bytes() {
 }
 
 // write this wave's 32 points of an activation (NM m-tiles in activation-register order) into rows [0, 32 NM) of ``st``
-template <int PREC, int NM>
+// PAIRS (bf16): two values per conversion instruction (nsim_cvt2_bf16; MI355X: nsim_field_bwd_sdf 0.1216 -> 0.1135 ms on the bench
+// step -- but the 17..32-level one-hidden-layer backward of the street step got 5 % slower, its register allocation moved 78 more
+// values through AGPRs: that instantiation passes PAIRS = false)
+template <int PREC, int NM, bool PAIRS = true>
 __device__ __forceinline__ void jstage(void* st, const float (&v)[NM * 16], int wave) {
   typedef typename JStageT<PREC>::T T;
   T* p = reinterpret_cast<T*>(st);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  if constexpr (PREC == 0 && NSIM_STAGE_PAIRS && PAIRS) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        bf16 lo, hi16;
+        nsim_cvt2_bf16(v[m * 16 + r], v[m * 16 + r + 1], lo, hi16);
+        p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = lo;
+        p[unit_of(m, r + 1, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = hi16;
+      }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -271,6 +289,18 @@ __device__ __forceinline__ void jstage_scaled(void* st, const float (&v)[NM * 16
   typedef typename JStageT<PREC>::T T;
   T* p = reinterpret_cast<T*>(st);
   const int lane = nsim_lane(), j = lane & 31, hi = lane >> 5;
+  if constexpr (PREC == 0 && NSIM_STAGE_PAIRS) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        bf16 lo, hi16;
+        nsim_cvt2_bf16(v[m * 16 + r] * scale, v[m * 16 + r + 1] * scale, lo, hi16);
+        p[unit_of(m, r, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = lo;
+        p[unit_of(m, r + 1, hi) * JStageT<PREC>::PITCH + 32 * wave + j] = hi16;
+      }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < NM; ++m)
 #pragma unroll

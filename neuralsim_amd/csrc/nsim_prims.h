@@ -168,6 +168,17 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 
 __device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// two f32 -> two bf16 in ONE v_cvt_pk_bf16_f32 (the halves then leave through ds_write_b16 / ds_write_b16_d16_hi): the LDS staging of
+// the weight-gradient operands converts 16 values per m-tile, one conversion instruction each when written as scalar casts
+__device__ __forceinline__ void nsim_cvt2_bf16(float a, float b, bf16& lo, bf16& hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const bf16x2 r = __builtin_convertvector(v, bf16x2);
+  lo = r[0];
+  hi = r[1];
+}
+
 // sum of the eight bf16 of a fragment into s: v_dot2c_f32_bf16 against (1, 1) adds two per issue
 __device__ __forceinline__ float nsim_bf16x8_sum(bf16x8 v, float s) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

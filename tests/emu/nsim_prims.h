@@ -65,6 +65,10 @@ inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
   for (int r = 0; r < 16; ++r) d[r] = dd[r];
   return d;
 }
+inline void nsim_cvt2_bf16(float a, float b, bf16& lo, bf16& hi) {
+  lo = (bf16)a;
+  hi = (bf16)b;
+}
 inline float nsim_bf16x8_sum(bf16x8 v, float s) {
   for (int e = 0; e < 8; ++e) s += (float)v[e];
   return s;
