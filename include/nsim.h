@@ -98,6 +98,23 @@ int nsim_packed_matmul3(const float* x, const float* rot, const int64_t* pack_in
 /* packed_sort(x, pack_infos) -> (sorted, GLOBAL indices)  (buffer_compose_renderer.py:1043-1047) */
 int nsim_packed_sort(const float* x, const int64_t* pack_infos, int64_t P, float* sorted,
                      int64_t* indices, void* stream);
+/* The collect + sort steps of BufferComposeRenderer.ray_query (code_multi/app/renderers/buffer_compose_renderer.py:648-695) in
+ * one launch.  K <= 64 sources (the per-object volume buffers, in the reference's collect order); source k: depths t [S_k] in
+ * packs ``pack_infos`` [P_k, 2] that live on the rays ``rays_inds`` [P_k] (ascending, one pack per ray: the reference's
+ * ``rays_inds_collect`` / ``pack_infos_collect``).  total_pack_infos [N, 2]: (start, count) of every one of the N rays in the merged
+ * buffer (count = the ray's samples over all sources; 0: no samples).  Outputs: t_sorted [S] -- every ray's samples ordered
+ * by depth, ties in collect order (the reference's stable packed_sort of the concatenation) -- and, per source, dst [S_k]: the
+ * position of each of its samples in that order (= ranks[pidx_in_total] of the reference's bookkeeping), so an attribute is
+ * placed with ONE indexed store per source and an object's weights in the scene are vw[dst]. */
+typedef struct NsimComposeSrc {
+  const float* t;
+  const int64_t* rays_inds;
+  const int64_t* pack_infos;
+  int64_t P;
+  int64_t* dst;
+} NsimComposeSrc;
+int nsim_compose_collect_sort(const NsimComposeSrc* src, int32_t K, const int64_t* total_pack_infos, int64_t N,
+                              float* t_sorted, void* stream);
 /* interleave_linstep(start [P], n [P], step): pack_infos = get_pack_infos_from_n(n)  (buffer_compose_renderer.py:1036) */
 int nsim_interleave_linstep(const int64_t* start, const int64_t* pack_infos, int64_t P, int64_t step,
                             int64_t* out, void* stream);

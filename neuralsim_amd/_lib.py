@@ -71,6 +71,10 @@ class FieldMeta(C.Structure):
                 ("embed_E", C.c_int32)]
 
 
+class ComposeSrc(C.Structure):      # include/nsim.h NsimComposeSrc
+    _fields_ = [("t", C.c_void_p), ("rays_inds", C.c_void_p), ("pack_infos", C.c_void_p), ("P", C.c_int64), ("dst", C.c_void_p)]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I = C.c_int
@@ -121,6 +125,7 @@ SIGNATURES = {
     "nsim_field_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, C.POINTER(OccMeta), _F],
     "nsim_lotd_gather_lm": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P],
     "nsim_field_fwd": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64],
+    "nsim_compose_collect_sort": [_P, _I, _P, _I64, _P],
     "nsim_wide_sdf": [C.POINTER(FieldMeta), _I, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P],
     "nsim_wide_bwd_sdf": [C.POINTER(FieldMeta), _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "nsim_set_grad_scratch": [_P, _I64],

@@ -40,6 +40,7 @@ const char* nsim_strerror(int code) {
     case 24: return "need either x or (rays_o, rays_d, t, ridx)";
     case 25: return "radiance needs rays_d and ridx";
     case 26: return "gradient output pointer is NULL";
+    case 37: return "compose collect: at most 64 sources";
     case 36: return "wide decoder: 0..10 embedding frequencies and at most 128 first-layer inputs (2 num_levels + 3 + 6 n_freq)";
     default: return code >= 1000 ? "HIP launch error (code - 1000 = hipError_t)" : "unknown error";
   }

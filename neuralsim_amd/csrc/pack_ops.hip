@@ -291,6 +291,60 @@ __device__ __forceinline__ int lds_lower_bound(const float* a, int n, float v) {
   }
   return lo;
 }
+// The staged sort: stable ranks of the nn values sx[0 .. nn) (nn <= PSORT_CAP, one wave), emit(i, rank, x_i) once per element.
+template <class Emit>
+__device__ __forceinline__ void psort_staged(const float* sx, int* srun, int nn, int lane, Emit emit) {
+  int nrun = 0;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool head = i < nn && (i == 0 || sx[i] < sx[i - 1]);
+    const unsigned long long m = wave_ballot(head);
+    if (head) {
+      const int pos = nrun + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < PSORT_RUNS) srun[pos] = i;
+    }
+    nrun += __popcll(m);
+  }
+  if (nrun <= 1) {
+    for (int i = lane; i < nn; i += 64) emit(i, i, sx[i]);
+    return;
+  }
+  if (nrun <= PSORT_RUNS) {
+    if (lane == 0) srun[nrun] = nn;
+    wave_sync_lds();
+    for (int i = lane; i < nn; i += 64) {
+      const float xi = sx[i];
+      int rank = 0;
+      for (int r = 0; r < nrun; ++r) {
+        const int b = srun[r], e = srun[r + 1];
+        if (e <= i) rank += lds_upper_bound(&sx[b], e - b, xi);
+        else if (b > i) rank += lds_lower_bound(&sx[b], e - b, xi);
+        else rank += i - b;
+      }
+      emit(i, rank, xi);
+    }
+    return;
+  }
+  for (int i0 = 0; i0 < nn; i0 += 256) {      // four elements per lane and sweep
+    float xi[4];
+    int ii[4], rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ii[k] = i0 + lane + 64 * k;
+      xi[k] = ii[k] < nn ? sx[ii[k]] : 0.f;
+      rank[k] = 0;
+    }
+    for (int j = 0; j < nn; ++j) {
+      const float xj = sx[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rank[k] += (xj < xi[k] || (xj == xi[k] && j < ii[k])) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ii[k] < nn) emit(ii[k], rank[k], xi[k]);
+  }
+}
+
 __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restrict__ x,
                                                               const int64_t* __restrict__ pi, int64_t P,
                                                               float* __restrict__ sorted,
@@ -305,63 +359,10 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restr
   if (n <= PSORT_CAP) {
     for (int64_t i = lane; i < n; i += 64) sx[w][i] = x[st + i];
     wave_sync_lds();
-    const int nn = (int)n;
-    int nrun = 0;
-    for (int i0 = 0; i0 < nn; i0 += 64) {
-      const int i = i0 + lane;
-      const bool head = i < nn && (i == 0 || sx[w][i] < sx[w][i - 1]);
-      const unsigned long long m = wave_ballot(head);
-      if (head) {
-        const int pos = nrun + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < PSORT_RUNS) srun[w][pos] = i;
-      }
-      nrun += __popcll(m);
-    }
-    if (nrun <= 1) {
-      for (int i = lane; i < nn; i += 64) {
-        sorted[st + i] = sx[w][i];
-        indices[st + i] = st + i;
-      }
-      return;
-    }
-    if (nrun <= PSORT_RUNS) {
-      if (lane == 0) srun[w][nrun] = nn;
-      wave_sync_lds();
-      for (int i = lane; i < nn; i += 64) {
-        const float xi = sx[w][i];
-        int rank = 0;
-        for (int r = 0; r < nrun; ++r) {
-          const int b = srun[w][r], e = srun[w][r + 1];
-          if (e <= i) rank += lds_upper_bound(&sx[w][b], e - b, xi);
-          else if (b > i) rank += lds_lower_bound(&sx[w][b], e - b, xi);
-          else rank += i - b;
-        }
-        sorted[st + rank] = xi;
-        indices[st + rank] = st + i;
-      }
-      return;
-    }
-    for (int64_t i0 = 0; i0 < n; i0 += 256) {      // four elements per lane and sweep
-      float xi[4];
-      int64_t ii[4], rank[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ii[k] = i0 + lane + 64 * k;
-        xi[k] = ii[k] < n ? sx[w][ii[k]] : 0.f;
-        rank[k] = 0;
-      }
-      for (int64_t j = 0; j < n; ++j) {
-        const float xj = sx[w][j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rank[k] += (xj < xi[k] || (xj == xi[k] && j < ii[k])) ? 1 : 0;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (ii[k] < n) {
-          sorted[st + rank[k]] = xi[k];
-          indices[st + rank[k]] = st + ii[k];
-        }
-    }
+    psort_staged(sx[w], srun[w], (int)n, lane, [&](int i, int rank, float xi) {
+      sorted[st + rank] = xi;
+      indices[st + rank] = st + i;
+    });
     return;
   }
   for (int64_t i = lane; i < n; i += 64) {
@@ -373,6 +374,105 @@ __global__ void __launch_bounds__(PACK_BLOCK) k_packed_sort(const float* __restr
     }
     sorted[st + rank] = xi;
     indices[st + rank] = st + i;
+  }
+}
+
+// ------------------------------------------------------------------------------------ compose: collect + sort in one launch
+// BufferComposeRenderer's collect and sort steps (code_multi/app/renderers/buffer_compose_renderer.py:648-695) as ONE kernel:
+// the reference copies every object's per-ray packs behind a running per-ray cursor into one buffer (interleave_linstep +
+// index_put per object and attribute), sorts every ray's pack by depth (packed_sort) and permutes every attribute.  Here a
+// wave owns a ray: it finds the ray's pack in every source (the sources' ray lists are ascending: binary search, one lane per
+// source), stages the depths source after source -- the reference's cursor order -- and ranks them with the staged sort above,
+// so the order (ties included) is the reference's; it writes the sorted depths and, per source sample, its FINAL position
+// ``dst`` -- every attribute then needs one index_put per source straight into sorted order, and an object's weights in the
+// context of the whole scene are vw[dst] (no unsorted buffer, no permutation, no inverse permutation, no per-source host
+// read of a sample count).
+#define COMPOSE_MAX_SRC 64      // one lane per source
+struct ComposeSrcDev {
+  const float* t;
+  const int64_t *ric, *pi;
+  int64_t P;
+  int64_t* dst;
+};
+struct ComposeArgs {
+  int K;
+  ComposeSrcDev src[COMPOSE_MAX_SRC];
+  const int64_t* total_pi;      // [N, 2] (start, count) of every ray in the merged buffer
+  int64_t N;
+  float* t_sorted;
+};
+
+__global__ void __launch_bounds__(PACK_BLOCK) k_compose_collect_sort(ComposeArgs a) {
+  __shared__ float sx[PACK_WAVES_PER_BLOCK][PSORT_CAP];
+  __shared__ int srun[PACK_WAVES_PER_BLOCK][PSORT_RUNS + 1];
+  __shared__ int s_off[PACK_WAVES_PER_BLOCK][COMPOSE_MAX_SRC + 1];      // offsets of the sources in the ray's unsorted list
+  __shared__ int64_t s_stg[PACK_WAVES_PER_BLOCK][COMPOSE_MAX_SRC];      // start of the ray's pack in each source
+  const int64_t r = pack_wave_id();
+  if (r >= a.N) return;
+  const int lane = nsim_lane();
+  const int w = (int)(threadIdx.x >> 6);
+  const int64_t st = a.total_pi[2 * r], n = a.total_pi[2 * r + 1];
+  if (n <= 0) return;
+  // lane k < K: the pack of ray r in source k (start, count), or count 0
+  int64_t my_st = 0;
+  int my_n = 0;
+  if (lane < a.K) {
+    const ComposeSrcDev& sk = a.src[lane];
+    int64_t lo = 0, hi = sk.P;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sk.ric[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    if (lo < sk.P && sk.ric[lo] == r) {
+      my_st = sk.pi[2 * lo];
+      my_n = (int)sk.pi[2 * lo + 1];
+    }
+  }
+  const int incl = wave_incl_sum(my_n);
+  s_off[w][lane] = incl - my_n;
+  if (lane == 63) s_off[w][64] = incl;
+  s_stg[w][lane] = my_st;
+  wave_sync_lds();
+  const int K = a.K;
+  // unsorted element j -> its source's dst entry / its depth (sources without a pack on this ray have empty ranges)
+  auto source_of = [&](int j) -> int {
+    int lo = 0, hi = K - 1;      // the last k with s_off[k] <= j
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_off[w][mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  if (n <= PSORT_CAP) {
+    for (int k = 0; k < K; ++k) {
+      const int ok = s_off[w][k], nk = s_off[w][k + 1] - ok;
+      const float* tk = a.src[k].t + s_stg[w][k];
+      for (int i = lane; i < nk; i += 64) sx[w][ok + i] = tk[i];
+    }
+    wave_sync_lds();
+    psort_staged(sx[w], srun[w], (int)n, lane, [&](int i, int rank, float xi) {
+      a.t_sorted[st + rank] = xi;
+      const int k = source_of(i);
+      a.src[k].dst[s_stg[w][k] + (i - s_off[w][k])] = st + rank;
+    });
+    return;
+  }
+  // a ray with more samples than the staging area holds: ranks straight from the sources (O(n^2) reads through the caches)
+  for (int64_t i = lane; i < n; i += 64) {
+    const int ki = source_of((int)i);
+    const float xi = a.src[ki].t[s_stg[w][ki] + (i - s_off[w][ki])];
+    int64_t rank = 0;
+    for (int k = 0; k < K; ++k) {
+      const int ok = s_off[w][k], nk = s_off[w][k + 1] - ok;
+      const float* tk = a.src[k].t + s_stg[w][k];
+      for (int jj = 0; jj < nk; ++jj) {
+        const float xj = tk[jj];
+        const int64_t j = ok + jj;
+        rank += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+      }
+    }
+    a.t_sorted[st + rank] = xi;
+    a.src[ki].dst[s_stg[w][ki] + (i - s_off[w][ki])] = st + rank;
   }
 }
 
@@ -984,6 +1084,30 @@ int nsim_packed_sort(const float* x, const int64_t* pack_infos, int64_t P, float
                      void* stream) {
   if (P <= 0) return 0;
   hipLaunchKernelGGL(k_packed_sort, pack_grid(P), dim3(PACK_BLOCK), 0, (hipStream_t)stream, x, pack_infos, P, sorted, indices);
+  NSIM_CHECK_LAUNCH();
+  return 0;
+}
+
+int nsim_compose_collect_sort(const NsimComposeSrc* src, int32_t K, const int64_t* total_pack_infos, int64_t N,
+                              float* t_sorted, void* stream) {
+  if (K < 0 || K > COMPOSE_MAX_SRC) return 37;
+  if (N <= 0 || K == 0) return 0;
+  if (!src || !total_pack_infos || !t_sorted) return 2;
+  ComposeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.K = K;
+  for (int k = 0; k < K; ++k) {
+    if (src[k].P < 0 || (src[k].P > 0 && !(src[k].t && src[k].rays_inds && src[k].pack_infos && src[k].dst))) return 2;
+    a.src[k].t = src[k].t;
+    a.src[k].ric = src[k].rays_inds;
+    a.src[k].pi = src[k].pack_infos;
+    a.src[k].P = src[k].P;
+    a.src[k].dst = src[k].dst;
+  }
+  a.total_pi = total_pack_infos;
+  a.N = N;
+  a.t_sorted = t_sorted;
+  hipLaunchKernelGGL(k_compose_collect_sort, pack_grid(N), dim3(PACK_BLOCK), 0, (hipStream_t)stream, a);
   NSIM_CHECK_LAUNCH();
   return 0;
 }

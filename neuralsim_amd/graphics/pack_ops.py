@@ -268,6 +268,29 @@ def packed_sort(x: torch.Tensor, pack_infos: torch.Tensor):
     return sorted_, idx
 
 
+def compose_collect_sort(sources, total_pack_infos: torch.Tensor, S: int):
+    """The collect + sort steps of ``BufferComposeRenderer.ray_query`` (buffer_compose_renderer.py:648-695) in one launch
+    (``nsim_compose_collect_sort``).  ``sources``: list of (t [S_k], rays_inds [P_k] ascending, pack_infos [P_k, 2]) in
+    collect order; ``total_pack_infos`` [N, 2]: every ray's (start, count) in the merged buffer of S samples.
+    -> (t_sorted [S], [dst_k [S_k]]): the depths of every ray in order (ties in collect order: the reference's stable sort of
+    the concatenation) and, per source, each sample's position in that order."""
+    dev = total_pack_infos.device
+    t_sorted = torch.empty([S], dtype=torch.float32, device=dev)
+    K = len(sources)
+    arr = (_lib.ComposeSrc * max(K, 1))()
+    keep, dsts = [], []
+    for k, (t, ric, pi) in enumerate(sources):
+        td, ric, pi = _f32c(t.detach()).reshape(-1), ric.long().contiguous(), pi.long().contiguous()
+        dst = torch.empty([td.shape[0]], dtype=torch.long, device=dev)
+        p_t, p_r, p_p, p_d = _lib._marshal((td, ric, pi, dst))
+        arr[k].t, arr[k].rays_inds, arr[k].pack_infos, arr[k].P, arr[k].dst = p_t, p_r, p_p, int(ric.shape[0]), p_d
+        keep.append((td, ric, pi))
+        dsts.append(dst)
+    tpi = total_pack_infos.long().contiguous()
+    _lib.call("nsim_compose_collect_sort", C.cast(arr, C.c_void_p), K, _lib.ptr(tpi), int(tpi.shape[0]), _lib.ptr(t_sorted))
+    return t_sorted, dsts
+
+
 def interleave_linstep(start: torch.Tensor, n: torch.Tensor, step=1, return_idx: bool = False):
     """concat_p(start[p] + step*arange(n[p]))  (buffer_compose_renderer.py:668,1036)."""
     assert not torch.is_floating_point(start), "interleave_linstep: integer start expected"

@@ -5,9 +5,10 @@ path:
   app/resources/scenes.py:631-683) -> ``model.ray_test`` / ``model.ray_query`` for single models or
   ``model.batched_ray_test(compact_batch=True)`` / ``set_condition`` / ``model.batched_ray_query`` for a shared batched
   model; normals rotated to world with ``packed_matmul`` (:333-345);
-* collect (:644-681): every ray's samples of every object are written to one packed buffer through
-  ``interleave_linstep`` on a running per-ray cursor; sort (:683-695): ``packed_sort`` by depth; integrate (:697-718):
-  here ONE fused compositing launch instead of the reference's chain of packed_sum / packed_div;
+* collect (:644-681: every ray's samples of every object written to one packed buffer through ``interleave_linstep`` on a
+  running per-ray cursor) and sort (:683-695: ``packed_sort`` by depth + a permutation of every attribute): here ONE launch
+  (``nsim_compose_collect_sort``, csrc/pack_ops.hip) that returns the sorted depths and every object sample's final position;
+  integrate (:697-718): ONE fused compositing launch instead of the reference's chain of packed_sum / packed_div;
 * ``vw_in_total`` of every object buffer (:720-727) and the sky blend (:820-833, as in the single renderer).
 
 There is no Scene graph in this repository (harness, out of scope): drawables are passed explicitly as
@@ -26,6 +27,8 @@ import torch.nn.functional as F
 from ..fields.neus import LoTDNeuSModel, volume_integration
 from ..graphics import pack_ops as po
 from .single_volume_renderer import prepare_empty_rendered
+
+_COMPOSE_FUSED = os.environ.get("NSIM_COMPOSE_FUSED", "1") != "0"
 
 
 @dataclass
@@ -196,31 +199,49 @@ class BufferComposeRenderer(nn.Module):
             total_pack_infos = pi_sparse[total_rays_inds_hit]
             S = int(tot.item())
             f32 = dict(dtype=torch.float32, device=dev)
-            depths, alphas = torch.zeros([S], **f32), torch.zeros([S], **f32)
+            # collect + sort in ONE launch (nsim_compose_collect_sort): every ray's depths in order and, per object buffer, the
+            # final position of each of its samples -- the reference's cursor / interleave_linstep / packed_sort / permutation
+            # bookkeeping (:660-695) without the unsorted intermediate; an attribute is one indexed store per object
+            live = [raw["volume_buffer"] for raw in raw_per_obj_model.values() if raw["volume_buffer"]["type"] != "empty"]
+            if len(live) <= 64 and _COMPOSE_FUSED:
+                t_sorted, dsts = po.compose_collect_sort(
+                    [(vb["t"], vb["rays_inds_collect"], vb["pack_infos_collect"]) for vb in live], pi_sparse, S)
+            else:       # more object buffers than the kernel has lanes for (or NSIM_COMPOSE_FUSED=0, the A/B aid): the reference's steps
+                depths = torch.zeros([S], **f32)
+                cursor, pidx = pi_sparse[:, 0].clone(), []
+                for vb in live:
+                    ric, n = vb["rays_inds_collect"], vb["pack_infos_collect"][:, 1]
+                    pidx.append(po.interleave_linstep(cursor[ric], n, 1))
+                    depths[pidx[-1]] = vb["t"].detach().flatten().float()
+                    cursor.index_add_(0, ric, n)
+                t_sorted, sort_idx = po.packed_sort(depths, total_pack_infos)
+                ranks = po.inverse_permutation(sort_idx)
+                dsts = [ranks[p_] for p_ in pidx]
+            alphas = torch.zeros([S], **f32)
             rgbs = torch.zeros([S, 3], **f32) if with_rgb else None
             nabs = torch.zeros([S, 3], **f32) if with_normal else None
-            cursor = pi_sparse[:, 0].clone()
-            for raw in raw_per_obj_model.values():
-                vb = raw["volume_buffer"]
-                if vb["type"] == "empty":
-                    continue
-                ric, n = vb["rays_inds_collect"], vb["pack_infos_collect"][:, 1]
-                vb["pidx_in_total"] = pidx = po.interleave_linstep(cursor[ric], n, 1)
-                depths = depths.index_put((pidx,), vb["t"].flatten())
-                alphas = alphas.index_put((pidx,), vb["opacity_alpha"].flatten())
+            t_grad = None
+            for vb, dst in zip(live, dsts):
+                vb["pidx_in_total"] = dst         # (position in the SORTED total buffer)
+                alphas = alphas.index_put((dst,), vb["opacity_alpha"].flatten())
                 if with_rgb:
-                    rgbs = rgbs.index_put((pidx,), vb["rgb"].flatten(0, -2))
+                    rgbs = rgbs.index_put((dst,), vb["rgb"].flatten(0, -2))
                 if with_normal and "nablas_in_world" in vb:
-                    nabs = nabs.index_put((pidx,), vb["nablas_in_world"].flatten(0, -2))
-                cursor.index_add_(0, ric, n)
-            # ---- sort by depth inside every ray (reference :683-695)
-            t_sorted, sort_idx = po.packed_sort(depths, total_pack_infos)
+                    nabs = nabs.index_put((dst,), vb["nablas_in_world"].flatten(0, -2))
+                if vb["t"].requires_grad:         # depths that carry a gradient (pose refinement) keep it
+                    t_grad = (torch.zeros([S], **f32) if t_grad is None else t_grad).index_put((dst,), vb["t"].flatten())
+            if t_grad is not None:                # (values of the other sources from the kernel's output)
+                got = torch.zeros([S], dtype=torch.bool, device=dev)
+                for vb, dst in zip(live, dsts):
+                    if vb["t"].requires_grad:
+                        got[dst] = True
+                t_sorted = torch.where(got, t_grad, t_sorted)
             total_volume_buffer = dict(type="packed", rays_inds_hit=total_rays_inds_hit, pack_infos_hit=total_pack_infos,
-                                       t=t_sorted, opacity_alpha=po.permute_rows(alphas, sort_idx))
+                                       t=t_sorted, opacity_alpha=alphas)
             if with_rgb:
-                total_volume_buffer["rgb"] = po.permute_rows(rgbs, sort_idx)
+                total_volume_buffer["rgb"] = rgbs
             if with_normal:
-                total_volume_buffer["nablas"] = po.permute_rows(nabs, sort_idx)
+                total_volume_buffer["nablas"] = nabs
             # ---- integrate (reference :697-718), one fused launch
             tvb = total_volume_buffer
             nab = tvb.get("nablas") if with_normal else None
@@ -233,14 +254,13 @@ class BufferComposeRenderer(nn.Module):
                 if k in out and k in total_rendered:
                     total_rendered[k] = total_rendered[k].index_put((total_rays_inds_hit,), out[k])
             # ---- every object's weights in the context of the whole scene (reference :720-727)
-            ranks = po.inverse_permutation(sort_idx)
             for raw in raw_per_obj_model.values():
                 vb = raw["volume_buffer"]
                 if vb["type"] != "empty":
-                    vb["vw_in_total"] = out["vw"][ranks[vb["pidx_in_total"]]]
+                    vb["vw_in_total"] = out["vw"][vb["pidx_in_total"]]
                     thre = float(cfgd.get("distant_bwd_trans_thre", os.environ.get("NSIM_DISTANT_BWD_THRE", 1e-3)))
                     if thre > 0 and self.training and "_bwd_holder" in raw:
-                        raw["_bwd_holder"]["keep"] = (out["trans"][ranks[vb["pidx_in_total"]]] >= thre).to(torch.uint8)
+                        raw["_bwd_holder"]["keep"] = (out["trans"][vb["pidx_in_total"]] >= thre).to(torch.uint8)
         norm_depth = cfgd.get("depth_use_normalized_vw", True)
 
         def share(vb, pack_infos):

@@ -256,6 +256,65 @@ def test_reference_fixture_collect_and_merge(backend):
     srt, indices = po.packed_sort(depths, total_pack_infos)
     assert torch.equal(srt, depths[indices])
     assert torch.allclose(srt.cpu(), torch.tensor(gold["sorted_depths"]), atol=0, rtol=0)
+    # the same collect + sort as ONE launch (nsim_compose_collect_sort): the reference's sorted depths, and every buffer
+    # sample's final position = ranks[pidx_in_total] of the three-step bookkeeping above
+    t_sorted, dsts = po.compose_collect_sort([(vb["t"].flatten(), vb["rays_inds_collect"], vb["pack_infos_collect"]) for vb in bufs],
+                                             sparse, total)
+    assert torch.allclose(t_sorted.cpu(), torch.tensor(gold["sorted_depths"]), atol=0, rtol=0)
+    ranks = po.inverse_permutation(indices)
+    cur = sparse[:, 0].clone()
+    for vb, dst in zip(bufs, dsts):
+        ric, pic = vb["rays_inds_collect"], vb["pack_infos_collect"]
+        pidx = po.interleave_linstep(cur[ric], pic[:, 1], 1, False)
+        assert torch.equal(dst, ranks[pidx])
+        cur.index_add_(0, ric, pic[:, 1])
+
+
+@pytest.mark.parametrize("K", [1, 3, 9])
+def test_compose_collect_sort_equals_the_three_step_bookkeeping(backend, K, poisoned_empty):
+    """``nsim_compose_collect_sort`` against interleave_linstep + packed_sort + inverse permutation (the reference's collect and sort,
+    buffer_compose_renderer.py:648-695) on random object buffers: sources missing on some rays, rays without samples, ties inside
+    and across sources, sources that are concatenations of sorted runs (a batched model's regrouped packs), a ray beyond the
+    staging capacity of the sort, more sources than fit one hand."""
+    g = torch.Generator().manual_seed(100 + K)
+    N = 41
+    srcs, counts = [], torch.zeros([N], dtype=torch.long)
+    for k in range(K):
+        on = torch.rand(N, generator=g) < (0.7 if k else 0.9)
+        on[5] = False                                   # a ray no source hits
+        on[7] = True
+        ric = on.nonzero()[:, 0]
+        n = torch.randint(1, 40, (ric.shape[0],), generator=g)
+        if k == 0:
+            n[(ric == 7).nonzero()[0, 0]] = 1100          # ray 7: beyond PSORT_CAP
+        pi = opo.get_pack_infos_from_n(n)
+        t = torch.rand(int(n.sum()), generator=g)
+        t = (t * 50).round() / 50 if k % 2 == 0 else t  # a coarse lattice: ties inside and across sources
+        if k == 1:                                      # packs that are two sorted runs each
+            half = opo.get_pack_infos_from_n(torch.stack([n // 2, n - n // 2], 1).flatten())
+            t = opo.packed_sort(t, half)[0]
+        else:
+            t = opo.packed_sort(t, pi)[0]
+        srcs.append((t, ric, pi))
+        counts.index_add_(0, ric, n)
+    dev = backend
+    sparse, tot = po.get_pack_infos_from_n(counts.to(dev), return_total=True)
+    S = int(tot.item())
+    hit = counts.to(dev).nonzero()[:, 0]
+    depths = torch.zeros([S], dtype=torch.float32, device=dev)
+    cur = sparse[:, 0].clone()
+    pidx = []
+    for t, ric, pi in srcs:
+        p_ = po.interleave_linstep(cur[ric.to(dev)], pi[:, 1].to(dev), 1)
+        depths[p_] = t.to(dev)
+        cur.index_add_(0, ric.to(dev), pi[:, 1].to(dev))
+        pidx.append(p_)
+    srt, indices = po.packed_sort(depths, sparse[hit])
+    ranks = po.inverse_permutation(indices)
+    t_sorted, dsts = po.compose_collect_sort([(t.to(dev), ric.to(dev), pi.to(dev)) for t, ric, pi in srcs], sparse, S)
+    assert torch.equal(t_sorted, srt)
+    for p_, dst in zip(pidx, dsts):
+        assert torch.equal(dst, ranks[p_])
 
 
 def test_pack_infos_large_and_capped(backend):
