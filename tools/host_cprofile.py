@@ -14,13 +14,15 @@ import bench  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    tr = bench.build_trainer(dev, 0, 1)
-    for it in range(241, 300):
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "object"      # object | street | indoor | multi
+    tr = bench.build_trainer(dev, 0, 1) if cfg == "object" else bench.build_config_trainer(cfg, dev, 0, 1, 16384)
+    n0, n1 = (59, 48) if cfg == "object" else (10, 12)
+    for it in range(241, 241 + n0):
         tr.train_step(it)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
-    for it in range(305, 305 + 48):
+    for it in range(305, 305 + n1):
         tr.train_step(it)
     torch.cuda.synchronize()
     pr.disable()
