@@ -1662,8 +1662,17 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 #ifndef GLM_PTS
 #define GLM_PTS 4
 #endif
+#ifndef GLM_PTS_WJ
+#define GLM_PTS_WJ 1      // points per lane of the with-grad form (eight accumulators per point: f, dh/dx): one -- 57 registers, eight
+                          // waves per SIMD -- with the slot tables below: nsim_field_fwd 0.1200 -> 0.1131 ms on the bench step (4 points:
+                          // 96 registers, five waves; 2 points 0.1161, 2 + tables 0.1154, 3 + tables 0.1192; gpurun_out/r6_s2_call13)
+#endif
 #ifndef NSIM_GATHER_WJ_WAVES
 #define NSIM_GATHER_WJ_WAVES 1   // WJ (with-grad planes): waves per SIMD the register allocation must leave room for (A/B knob of the slot tables)
+#endif
+#ifndef NSIM_GATHER_SLOTS_WJ
+#define NSIM_GATHER_SLOTS_WJ 1   // ... for the with-grad form only: that form is VALU-heavy enough (dh/dx) for the tables to pay once its
+                                 // register count no longer costs waves
 #endif
 #ifndef NSIM_GATHER_SLOTS
 #define NSIM_GATHER_SLOTS 0      // 1: the parity enumeration through per-axis operand tables (lotd_slots, ~30 % fewer VALU operations per level) instead
@@ -1676,7 +1685,7 @@ __global__ void __launch_bounds__(64, WJ ? NSIM_GATHER_WJ_WAVES : 1) k_lotd_gath
   using JT = typename JPlane<PREC>::T;      // element type of the dh/dx planes (WJ)
   // points per lane.  (Round 5: 1 / 2 points per lane for launches of <= 98 k / 196 k points -- four times the waves for the
   // small up-sampling draws -- measured nothing: 0.0643-0.0658 against 0.0651-0.0666 ms per launch, profiles/round5_gather_ab.txt)
-  constexpr int NP = GLM_PTS;
+  constexpr int NP = WJ ? GLM_PTS_WJ : GLM_PTS;
   const int lane = nsim_lane();
   const int xcd = (int)(blockIdx.x & 7u);
   const int64_t s0 = (int64_t)(blockIdx.x >> 3) * (64 * NP) + lane;
@@ -1732,24 +1741,23 @@ __global__ void __launch_bounds__(64, WJ ? NSIM_GATHER_WJ_WAVES : 1) k_lotd_gath
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) j0[q][c3] = j1[q][c3] = 0.f;
       }
-#if NSIM_GATHER_SLOTS
-      const LotdSlots SL = lotd_slots(c);    // slots by vertex parity, the parity folded into the operands (lotd_dev.h)
-#else
-      const int pm = lotd_slot_mask(c);      // slots by vertex parity (lotd_dev.h)
-#endif
+      // slots by vertex parity (lotd_dev.h): through per-axis operand tables (SLOTS) or runtime corner indices
+      constexpr bool SLOTS = NSIM_GATHER_SLOTS || (WJ && NSIM_GATHER_SLOTS_WJ);
+      const LotdSlots SL = lotd_slots(c);
+      const int pm = lotd_slot_mask(c);
       if (l < a.lotd.n_active)
 #pragma unroll
       for (int slot = 0; slot < 8; ++slot) {
         float w, dw[3];
-#if NSIM_GATHER_SLOTS
-        lotd_slot_w(SL, slot, w, dw);
-        const uint32_t idx = lotd_slot_index(SL, slot, R, type, T);
-#else
-        const int corner = slot ^ pm;
-        lotd_corner_w(c, corner, w, dw);
-        const uint32_t idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1),
-                                        c.c0[2] + ((corner >> 2) & 1), R, type, T);
-#endif
+        uint32_t idx;
+        if constexpr (SLOTS) {
+          lotd_slot_w(SL, slot, w, dw);
+          idx = lotd_slot_index(SL, slot, R, type, T);
+        } else {
+          const int corner = slot ^ pm;
+          lotd_corner_w(c, corner, w, dw);
+          idx = lotd_index(c.c0[0] + (corner & 1), c.c0[1] + ((corner >> 1) & 1), c.c0[2] + ((corner >> 2) & 1), R, type, T);
+        }
         float g0, g1;
         lotd_load2(gref, off + goff[q] + 2u * idx, g0, g1);
         f0[q] = f0[q] + w * g0;
@@ -1804,7 +1812,7 @@ __global__ void __launch_bounds__(64, WJ ? NSIM_GATHER_WJ_WAVES : 1) k_lotd_gath
 
 template <int PREC, bool WJ>
 static void launch_gather_lm(const FieldArgs& a, int64_t S, hipStream_t stream) {
-  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * GLM_PTS)));
+  const dim3 gg((unsigned)(8 * nsim_blocks(S, 64 * (WJ ? GLM_PTS_WJ : GLM_PTS))));
   hipLaunchKernelGGL((k_lotd_gather_lm<PREC, WJ>), gg, dim3(64), 0, stream, a);
 }
 
