@@ -657,7 +657,9 @@ __global__ void __launch_bounds__(64 * ((PREC == 0 && BWD) ? NERF_WAVES_PRIV : N
 // of the pyramid at once, with G4_PTS x 16 independent 4-byte loads in flight per lane.  The 64 lanes are consecutive
 // shells of one ray: on the coarse levels they share cells (same lines: coalesced by the texture unit), the fine hashed
 // levels cost one line per x-pair.  Output: the f32 planes h [16][S][2] the decoders (forward AND backward) read.
+#ifndef G4_PTS
 #define G4_PTS 2
+#endif
 struct Gather4Args {
   Lotd4Dev lotd;
   const f16* grid;
