@@ -1660,8 +1660,8 @@ __global__ void __launch_bounds__(64 * JOINT_WAVES) k_field_bwd_j(FieldArgs a) {
 // the decoder kernels (k_field MODE 3 forward, MODE 2 backward) read -- the same split, so the 6.7 k-instruction
 // forward no longer carries the gather's address registers (it spilled 440 B per lane).
 #ifndef GLM_PTS
-#define GLM_PTS 4
-#endif
+#define GLM_PTS 2      // points per lane of the no-grad forms (round 6: 4 -> 2, nsim_lotd_gather_lm 0.0608 -> 0.0593 ms per launch over two
+#endif                 // alternated runs each, gpurun_out/r6_s2_call15; 1 point and / or the operand tables: the same within noise)
 #ifndef GLM_PTS_WJ
 #define GLM_PTS_WJ 1      // points per lane of the with-grad form (eight accumulators per point: f, dh/dx): one -- 57 registers, eight
                           // waves per SIMD -- with the slot tables below: nsim_field_fwd 0.1200 -> 0.1131 ms on the bench step (4 points:
