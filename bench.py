@@ -284,16 +284,17 @@ def parity_check(tr):
 def time_steps(tr, steps, warmup, it):
     """ms per step of ``steps`` iterations after ``warmup`` untimed ones (device-synchronised on both sides)."""
     sync = torch.cuda.synchronize if tr.model.device.type == "cuda" else (lambda: None)
-    for _ in range(warmup):
-        tr.train_step(it)
-        it += 1
     # the cyclic collector is parked over the timed steps, as in ``timed_run`` (a generation-2 pass over torch's module
-    # graphs costs tens of ms: one of them inside a 12-step variant reads as +5 ms per step); NSIM_BENCH_GC=1 leaves it on
+    # graphs costs tens of ms: one of them inside a 12-step variant reads as +5 ms per step); NSIM_BENCH_GC=1 leaves it on.
+    # The collection runs BEFORE the warm-up steps (in front of the timed ones it left the GPU idle and clocking down).
     import gc
     park = os.environ.get("NSIM_BENCH_GC") != "1" and gc.isenabled()
     if park:
         gc.collect()
         gc.disable()
+    for _ in range(warmup):
+        tr.train_step(it)
+        it += 1
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -654,9 +655,26 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     on_gpu = dev.type == "cuda"
     it0 = 257                      # timed region starts right after an occupancy refresh (every 16 iterations)
     it = it0 - max(warmup, 1)
-    for _ in range(warmup):
+    # the warm-up steps run with the same instrumentation as the timed ones (HIP-event pairs around the modelled entry points:
+    # their first creations are slow), so the first timed step does not pay for the bench's own timer
+    dm_w = getattr(tr, "distant_model", None) or getattr(tr, "distant", None)
+    if on_gpu and os.environ.get("NSIM_BENCH_WARM_TIMER", "1") == "1":
+        _lib.TIMER = _lib.KernelTimer(only=kernel_model(tr.model.encoding.cfg.num_levels,
+                                                        dm_w.cfg.num_levels if dm_w is not None else 12).keys())
+    import gc
+    for w_ in range(warmup):
+        if w_ == max(0, warmup - 4):
+            # the cyclic collector is parked over the timed steps (a generation-2 pass over torch's module graph costs tens
+            # of ms, i.e. ~10 steps); NSIM_BENCH_GC=1 leaves it on.  The collection itself runs HERE, with warm-up steps
+            # still to come: done right in front of the timed region it left the GPU idle for tens of ms and the first
+            # timed steps ran on a chip that was clocking back up (first step 2.5-3.0 ms instead of 1.2)
+            gc.collect()
+            if os.environ.get("NSIM_BENCH_GC") != "1":
+                gc.freeze()
+                gc.disable()
         tr.train_step(it)
         it += 1
+    timer_w, _lib.TIMER = _lib.TIMER, None
     it = it0
 
     def fence():
@@ -665,18 +683,29 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    # the cyclic collector is parked over the timed steps (a generation-2 pass over torch's module graph costs tens
-    # of ms, i.e. ~10 steps); NSIM_BENCH_GC=1 leaves it on
-    import gc
-    gc.collect()
-    if os.environ.get("NSIM_BENCH_GC") != "1":
-        gc.freeze()
-        gc.disable()
+    if warmup == 0:
+        gc.collect()
+        if os.environ.get("NSIM_BENCH_GC") != "1":
+            gc.freeze()
+            gc.disable()
     fence()
     # HIP events around the modelled kernels only (on the launch stream)
     dm_ = getattr(tr, "distant_model", None) or getattr(tr, "distant", None)
     KM = kernel_model(tr.model.encoding.cfg.num_levels, dm_.cfg.num_levels if dm_ is not None else 12)
-    _lib.TIMER = _lib.KernelTimer(only=KM.keys()) if on_gpu else None
+    # Inside the timed region ONLY the dominant kernel carries HIP events (the roofline's live measurement): an event pair is a
+    # marker packet on either side of a launch, and the 14 pairs per step of the full per-kernel table cost the step 0.085 ms
+    # (1.20 -> 1.12 ms median, measured: gpurun_out/r6_s2_trace) -- the bench was slowing down what it measures.  Which kernel
+    # dominates is read from the instrumented warm-up steps; the table of all modelled kernels comes from a short instrumented
+    # pass AFTER the timed region (``kernels_source`` says so).  NSIM_BENCH_KTIMER=full: every modelled kernel inside, as before.
+    kt_mode = os.environ.get("NSIM_BENCH_KTIMER", "1")
+    dom_w = "nsim_lotd_scatter"
+    if timer_w is not None and timer_w.events:
+        sw = timer_w.summary()
+        cand = [k for k in sw if k in KM]
+        if cand:
+            dom_w = max(cand, key=lambda k: sw[k]["total_ms"])
+    only_ = KM.keys() if kt_mode == "full" else [dom_w]
+    _lib.TIMER = _lib.KernelTimer(only=only_) if (on_gpu and kt_mode != "0") else None
     _lib.CALL_COUNT = 0
     _lib.HOST_WAIT = 0.0
     S_f = S_hit = S_q = S_live = 0
@@ -711,9 +740,23 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
         if os.environ.get("NSIM_BENCH_TRACE") == "2":       # every step (host-side marks: each step blocks once)
             d = [marks[0]] + [b - a for a, b in zip(marks, marks[1:])]
             print("[trace] per step ms: " + " ".join(f"{x * 1e3:.2f}" for x in d), file=sys.stderr)
+    # the per-kernel table: a short pass with every modelled entry point instrumented, outside the timed region (all ranks)
+    n_post = 0
+    ksum_post = {}
+    if timer is not None and kt_mode != "full":
+        n_post = max(1, min(16, steps))
+        _lib.TIMER = _lib.KernelTimer(only=KM.keys())
+        for _ in range(n_post):
+            tr.train_step(it)
+            it += 1
+        fence()
+        tp, _lib.TIMER = _lib.TIMER, None
+        ksum_post = tp.summary()
     if rank != 0:
         return None, it
     ksum = timer.summary() if timer is not None else {}
+    for k_, v_ in ksum_post.items():      # (the dominant kernel keeps its timed-region measurement)
+        ksum.setdefault(k_, v_)
     total_rays = rays_per_gpu * world * steps
     ms = elapsed / steps * 1e3
     if not ksum:
@@ -840,6 +883,10 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
                ms_per_step_p50=q(0.5), value_p50=round(rays_per_gpu * world / max(q(0.5), 1e-9) * 1e3, 1),
                step_ms=dict(p10=q(0.1), p50=q(0.5), p90=q(0.9), max=round(d[-1] * 1e3, 3)),
                roofline=roofline, kernels=per_kernel,
+               kernels_source=(f"HIP events inside the timed region for the dominant kernel ({dom}: the roofline's live measurement); the "
+                               f"other entry points from {n_post} instrumented steps run right after it -- 14 event pairs per step inside "
+                               "the timed region cost the step 0.085 ms (NSIM_BENCH_KTIMER=full restores them)") if n_post else
+                              "HIP events inside the timed region for every modelled entry point (NSIM_BENCH_KTIMER=full)",
                # C-ABI entry-point calls of this package per step (each is one kernel launch, three of them two); the ATen /
                # rocprim launches of the host glue (rand, fill, cat, compaction) are on top: profiles/round4_rocprofv3_kernel_stats
                abi_calls_per_step=round(abi_calls / max(1, steps), 1) if abi_calls is not None else None,
