@@ -19,6 +19,7 @@ import os
 from .fields.neus import LoTDNeuSModel, volume_integration, append_extra_points, _flat_sizes
 from .graphics.cameras import selected_rays
 from .optim import FusedAdam
+_PREFETCH_HANDOFF = os.environ.get("NSIM_PREFETCH_HANDOFF", "1") == "1"
 from .losses import eikonal_loss, mse_loss, embedding_lookup, mono_depth_loss, mono_normal_loss
 
 
@@ -81,6 +82,7 @@ class RenderTrainer:
         # produced while the host waits for the current batch's sample count -- one blocking wait per step
         self.pipeline = pipeline
         self._prefetched = None
+        self._retired = None           # the last consumed batch of an event hand-over (see _prefetch)
         # the prefetch runs on its own HIP stream (NSIM_PREFETCH_STREAM=0: on the caller's): its dozen small launches and
         # its hit-ray compaction sync then neither queue behind the sampling kernels of the current step nor drain them
         self._side = None
@@ -516,14 +518,35 @@ class RenderTrainer:
             self._prefetched = self._make_batch()
             return
         main = torch.cuda.current_stream()
+        # How the batch's tensors -- allocated on the side stream, consumed on the caller's -- are kept from being re-used too
+        # early.  ``record_stream`` per tensor (the general form) makes the caching allocator record one event per block when the
+        # batch dies: ~20 event records per step, and every 512 records the runtime's signal pool turns over with the host blocked
+        # until the queue drains; every record is a marker packet on the stream, too (together 0.07 ms per step: 1.12 -> 1.05 ms,
+        # profiles/round6_bench_instrumentation.txt).  A training step queues every consumer of its batch before it returns -- the
+        # launch chain, or the autograd graph and its backward -- so the batch is handed over with ONE event instead: a consumed batch stays referenced
+        # (``_retired``, with an event recorded on the caller's stream at the end of its step) until the side stream has been made
+        # to wait for that event, and only then returns its blocks to the side stream's pool (NSIM_PREFETCH_HANDOFF=0:
+        # record_stream everywhere).
+        handoff = _PREFETCH_HANDOFF
+        self._release_retired()
         with torch.cuda.stream(self._side):
             b = self._make_batch()
             b["_ready"] = self._side.record_event()
-        # the tensors were allocated on the side stream and are consumed on the caller's
-        for v in list(b.values()) + list(b["tested"].values()):
-            if isinstance(v, torch.Tensor):
-                v.record_stream(main)
+        if handoff:
+            b["_handoff"] = True
+        else:       # the tensors were allocated on the side stream and are consumed on the caller's
+            for v in list(b.values()) + list(b["tested"].values()):
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(main)
         self._prefetched = b
+
+    def _release_retired(self):
+        """Let go of a batch that was handed over by event (see ``_prefetch``): the side stream first waits for the event recorded on
+        the caller's stream at the END of the step that consumed it -- behind every consumer of that batch, and long reached by the
+        time the next batch is produced -- then the references go."""
+        if getattr(self, "_retired", None) is not None and self._side is not None:
+            self._side.wait_event(self._retired[1])
+        self._retired = None
 
     def sample_uniform_x(self) -> torch.Tensor:
         lo, hi = self.model.accel.aabb[0], self.model.accel.aabb[1]
@@ -651,12 +674,13 @@ class RenderTrainer:
         model.training_before_per_step(it)          # inv_s control (var_ctrl_cfg); a no-op unless set_var_ctrl() was called
         if not self_driven and it >= acc.n_steps_warmup and it % acc.n_steps_between_update == 0:
             acc.update_from_net(model.query_sdf, generator=self.gen_shared)
-        batch = None
+        batch, handed = None, False
         if self.pipeline:
             batch, self._prefetched = (self._prefetched or self._make_batch()), None
             ev = batch.pop("_ready", None)
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
+            handed = batch.pop("_handoff", False)       # handed over by event instead of record_stream (see _prefetch)
             xy, fidx, gt = batch["xy"], batch["fidx"], batch["gt"]
         else:
             xy, fidx, gt = self.sample_batch()
@@ -712,4 +736,7 @@ class RenderTrainer:
             if self.world_size > 1 and not self.skip_allreduce:
                 ndist.allreduce_grads([self.pose_delta], average=True, wire_dtype=torch.float32)
             self.pose_optim.step()
+        if handed:      # every consumer of this batch is queued: it stays referenced until the side stream has been made to wait for them
+            self._release_retired()
+            self._retired = (batch, torch.cuda.current_stream().record_event())
         return loss.detach()
