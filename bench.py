@@ -113,7 +113,13 @@ def oracle_of(tr, table="master"):
     grid = m.encoding.flattened_params if table == "master" else m._shadow()[0].detach().float()
     p = ofield.params_from_flat(cfg.lod_res, int(math.log2(cfg.hashmap_size)), grid, m.sdf_w, m.sdf_b,
                                 m.rad_w, m.rad_b, m.ln_inv_s, sdf_D=m.sdf_D, ln_inv_s_factor=m.ln_inv_s_factor)
-    occ = (m.accel.occ_val.detach().cpu() > m.accel.occ_thre)
+    # the occupancy the kernels march against: the packed BITFIELD of the last refresh -- not the value grid thresholded now:
+    # between refreshes the sampling passes fold their SDFs into the values (``update_from_samples``, bits untouched), and an
+    # oracle marching the values saw voxels the kernels do not yet (one grazing ray of 2048 at 0.06, the "worst ray" of
+    # profiles/round6_bench_instrumentation.txt)
+    bits = m.accel.occ_bits.detach().cpu().to(torch.int64) & 0xFFFFFFFF
+    nvox = int(m.accel.occ_val.shape[0])
+    occ = ((bits[:, None] >> torch.arange(32)[None, :]) & 1).reshape(-1)[:nvox].to(torch.bool)
     return p, occ
 
 
@@ -274,9 +280,8 @@ def parity_check(tr):
         mse = float(((rgb_h - rgb_o) ** 2).mean())
         err = (rgb_h - rgb_o).abs().max(dim=-1).values
         # the gate is on robust statistics -- PSNR over all but the worst 0.1 % of the rays, the 99th and 99.9th percentiles --; the
-        # maximum is REPORTED with the number of rays beyond it: at some training states ONE ray of the 2048 sits at 0.06 (a sample
-        # set that differs between the fp16 and the f32 run on a grazing ray) while the rest stays below 2e-3, at others none does
-        # (profiles/round6_bench_instrumentation.txt), and a gate on a single ray made the whole bench exit non-zero on such a state
+        # maximum is REPORTED with the number of rays beyond it (a gate on the maximum over 2048 rays made the whole bench exit
+        # non-zero when ONE ray differed -- then because the oracle marched another occupancy than the kernels, oracle_of)
         k_trim = max(1, int(0.001 * n_par))
         keep = err.argsort()[:n_par - k_trim]
         mse_trim = float(((rgb_h - rgb_o)[keep] ** 2).mean())
@@ -418,9 +423,8 @@ def main():
         out["config"]["launch_chain"] = "fused (no autograd engine)" if tr._fused_ok() else "autograd"
         plain = world == 1 and not args.distant and not args.sky
         if plain and not args.no_parity:
-            # the rendering check runs on the state the headline was just measured on, BEFORE the side measurements train the
-            # model further through other paths (after them the same check sits at 61-76 dB with single rays at 1e-2..6e-2:
-            # profiles/round6_bench_instrumentation.txt)
+            # the rendering check runs on the state the headline was just measured on, before the side measurements train the
+            # model further through other paths
             out["parity"] = parity_check(tr)
         if plain and not args.no_variants:
             # side measurements of the same workload, a few steps each (not `value`): the drop-in API path (renderer +
