@@ -718,12 +718,18 @@ def timed_run(tr, steps, warmup, rank, world, dev, rays_per_gpu, workload=None):
     # pass AFTER the timed region (``kernels_source`` says so).  NSIM_BENCH_KTIMER=full: every modelled kernel inside, as before.
     kt_mode = os.environ.get("NSIM_BENCH_KTIMER", "1")
     dom_w = "nsim_lotd_scatter"
-    if timer_w is not None and timer_w.events:
-        sw = timer_w.summary()
-        cand = [k for k in sw if k in KM]
-        if cand:      # (the table scatter unless another entry point clearly outweighs it: a short, cold warm-up must not flip a close call)
-            best = max(cand, key=lambda k: sw[k]["total_ms"])
-            if dom_w not in sw or sw[best]["total_ms"] > 1.15 * sw[dom_w]["total_ms"]:
+    if timer_w is not None and timer_w.events and warmup >= 3:
+        # per entry point: launches x MEDIAN launch time over the warm-up (the first, cold launches of a short warm-up skew a mean:
+        # a 5-step warm-up once put the gathers in front of the scatter); the table scatter stays unless another one clearly outweighs it
+        torch.cuda.synchronize()
+        tot_w = {}
+        for k_, evs in timer_w.events.items():
+            if k_ in KM and evs:
+                ms_ = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+                tot_w[k_] = len(ms_) * ms_[len(ms_) // 2]
+        if tot_w:
+            best = max(tot_w, key=tot_w.get)
+            if dom_w not in tot_w or tot_w[best] > 1.15 * tot_w[dom_w]:
                 dom_w = best
     only_ = KM.keys() if kt_mode == "full" else [dom_w]
     _lib.TIMER = _lib.KernelTimer(only=only_) if (on_gpu and kt_mode != "0") else None
