@@ -234,6 +234,32 @@ def test_occ_update_and_bits(backend):
         assert bool((bits[v >> 5] >> (v & 31)) & 1) == bool(occ[v])
 
 
+def test_bench_oracle_marches_the_packed_bitfield(backend):
+    """bench.oracle_of hands the oracle the occupancy the KERNELS march against -- the bitfield packed at the last refresh -- not
+    the value grid thresholded now: between refreshes the sampling passes fold SDFs into the values (``collect``: max, bits
+    untouched), and an oracle on the values marched voxels the kernels did not (round 6: one ray of the bench's 2048 at 0.06)."""
+    import sys
+    from pathlib import Path
+    from types import SimpleNamespace
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    from util import make_params, model_from_params
+    p = make_params(sdf_D=2, small=True, sphere=True, seed=3)
+    model = model_from_params(p, backend, precision="f32")
+    acc = OccGridAccel(AABB, resolution=(16, 8, 4), inv_s=64.0, device=backend)
+    g = torch.Generator().manual_seed(5)
+    acc.occ_val.copy_((torch.rand(16 * 8 * 4, generator=g) * 0.6).to(backend))
+    acc.pack_bits()
+    at_pack = (acc.occ_val.cpu() > acc.occ_thre)
+    # what a sampling pass does between refreshes: values go up, the bits stay
+    pts = (torch.rand(400, 3, generator=g) * 2 - 1).to(backend)
+    acc.collect(pts, torch.zeros(400, device=backend))
+    assert int(((acc.occ_val.cpu() > acc.occ_thre) != at_pack).sum()) > 0
+    model.accel = acc
+    _, occ = bench.oracle_of(SimpleNamespace(model=model), table="master")
+    assert torch.equal(occ, at_pack)
+
+
 def test_coarse_upsample_merge(backend):
     g = torch.Generator().manual_seed(7)
     R, C = 23, 64
